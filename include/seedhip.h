@@ -1,0 +1,147 @@
+/* seedhip.h -- C ABI of libseedhip.so: the MI355X (gfx950) SEED-RL learner hot path.
+ *
+ * The reference hot path is pure Python/TensorFlow graph code with no FFI of its
+ * own; each entry point below replaces one Python-level function
+ * (or the TF op sequence it expands to) of /root/reference and is what a binding
+ * for that function would call (see INTEGRATION.md for the ctypes stubs).
+ *
+ * Conventions:
+ *   - all pointers are DEVICE pointers to caller-allocated HBM, never retained past
+ *     the call; no hidden allocations (workspaces are passed in, sized by the
+ *     matching *_workspace_bytes query);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it;
+ *   - returns 0 on success, <0 on error (never throws / aborts);
+ *     seedhip_last_error() gives the thread-local message;
+ *   - re-entrant, no global mutable state; reductions are deterministic
+ *     (no floating-point atomics);
+ *   - tensors are contiguous row-major, time-major [T, B, ...], NHWC, fp32 unless
+ *     stated; Keras kernel layouts ([kh,kw,cin,cout], Dense [in,out]).
+ */
+#ifndef SEEDHIP_H_
+#define SEEDHIP_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEEDHIP_ABI_VERSION 1
+
+const char* seedhip_last_error(void);
+int seedhip_abi_version(void);
+
+/* ---- V-trace ------------------------------------------------------------------
+ * Replaces common/vtrace.py:34-148 `from_importance_weights` (arithmetic :84-148).
+ * Inputs [T,B] (+[B] bootstrap), outputs vs / pg_advantages [T,B].  Trailing dims of
+ * the reference ([T,B,C], vtrace.py:49-51) are folded into B by the caller.
+ * clip_*_threshold < 0 means None (no clipping, vtrace.py:111-114,138-142). */
+int seedhip_vtrace_from_importance_weights(
+    const float* target_action_log_probs, const float* behaviour_action_log_probs,
+    const float* discounts, const float* rewards, const float* values,
+    const float* bootstrap_value, float clip_rho_threshold, float clip_pg_rho_threshold,
+    float lambda_, int T, long long B, float* vs, float* pg_advantages, void* stream);
+
+/* ---- categorical distribution ---------------------------------------------------
+ * Replaces common/parametric_distribution.py:69-74 log_prob / entropy for
+ * categorical_distribution (:83-97; tfd.Categorical).  logits [rows, A]; actions
+ * int32 (elem_size 4) or int64 (8); either output may be NULL. */
+int seedhip_categorical_log_prob_entropy(const float* logits, const void* actions, int action_elem_size,
+                                         long long rows, int A, float* log_prob, float* entropy,
+                                         void* stream);
+
+/* ---- IMPALA loss head, forward + backward -------------------------------------------
+ * Replaces agents/vtrace/learner.py:82-157 (compute_loss after the agent unroll)
+ * and its autodiff wrt the learner outputs.  All inputs have T+1 time steps.
+ * logits rows may be strided (row stride in floats) so the head GEMM output
+ * [rows, ld] can be consumed / its gradient produced in place:
+ *   learner_policy_logits[(t*B+b)*logits_ld + a], learner_baseline[(t*B+b)*baseline_ld],
+ *   d_policy_logits / d_baseline use the same strides.
+ * mean_denominator = N of the reduce_means (T*B; global T*B for data-parallel mean).
+ * vs / pg_advantages ([T,B], optional) are the V-trace outputs for parity checks.
+ * scalars[SEEDHIP_LOSS_NUM] receives the losses and the logged values. */
+enum {
+  SEEDHIP_LOSS_TOTAL = 0,       /* learner.py:134-135 */
+  SEEDHIP_LOSS_POLICY = 1,      /* :111-112 */
+  SEEDHIP_LOSS_V = 2,           /* :115-116 */
+  SEEDHIP_LOSS_ENTROPY = 3,     /* :121 */
+  SEEDHIP_LOSS_KL = 4,          /* :124-125 */
+  SEEDHIP_LOSS_ENTROPY_MEAN = 5,/* :119-120, logged :154 */
+  SEEDHIP_LOSS_KL_MEAN = 6,     /* logged :156 */
+  SEEDHIP_LOSS_VALUE_MEAN = 7,  /* logged :139-140 */
+  SEEDHIP_LOSS_V_L2_ERROR = 8,  /* logged :141 */
+  SEEDHIP_LOSS_MAX_ACTION_ABS = 9, /* logged :152-153 */
+  SEEDHIP_LOSS_NUM = 16
+};
+size_t seedhip_impala_loss_workspace_bytes(int T, int B);
+int seedhip_impala_loss_fwd_bwd(
+    const float* learner_policy_logits, int logits_ld, const float* learner_baseline, int baseline_ld,
+    const float* behaviour_policy_logits, const void* actions, int action_elem_size,
+    const float* rewards, const uint8_t* done, int T, int B, int A,
+    float entropy_cost, float baseline_cost, float kl_cost, float discounting, float lambda_,
+    float max_abs_reward, float clip_rho_threshold, float clip_pg_rho_threshold,
+    float mean_denominator, float* d_policy_logits, float* d_baseline, float* vs, float* pg_advantages,
+    float* scalars, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- optimizer --------------------------------------------------------------------
+ * Replaces the Keras Adam apply_gradients of agents/vtrace/learner.py:272-275
+ * (dmlab/vtrace_main.py:46-51) over ONE flat parameter buffer.  lr_t already
+ * includes the bias correction (host, fp64).  grad_scale multiplies the gradient
+ * first (1/world for data-parallel mean; 1 for the reference cross-replica SUM). */
+int seedhip_adam_flat(float* params, const float* grads, float* m, float* v, long long n,
+                      float lr_t, float beta_1, float beta_2, float epsilon, float grad_scale, void* stream);
+/* tf.clip_by_global_norm(grads, clip_norm) of agents/r2d2/learner.py:606-609; sumsq_out[0] = |g|^2.
+ * clip_norm <= 0: only compute the norm. */
+size_t seedhip_global_norm_workspace_bytes(void);
+int seedhip_clip_by_global_norm(float* grads, long long n, float clip_norm, float* sumsq_out,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- frame stacking -------------------------------------------------------------------
+ * Replaces atari/networks.py:57-173 `stack_frames` (bit-packed int32 state, :32-54).
+ * frames_ext is uint8 [3+T, B, HW]: rows 3.. hold the unroll's frames (written by the
+ * caller / the unroll store), rows 0..2 are filled by seedhip_stack_prepare from
+ * the packed state; nvalid is uint8 [T,B] (number of valid stack channels). */
+int seedhip_stack_prepare(const int* frame_stacking_state, const uint8_t* done, int T, int B, long long HW,
+                          uint8_t* frames_ext, uint8_t* nvalid, void* stream);
+int seedhip_stack_frames_f32(const uint8_t* frames_ext, const uint8_t* nvalid, int T, int B, long long HW,
+                             float* stacked /* [T,B,HW,4] newest->oldest, range 0..255 */, void* stream);
+int seedhip_stack_pack_state(const uint8_t* frames_ext, const uint8_t* nvalid, int T, int B, long long HW,
+                             int* new_state /* [B,HW] */, void* stream);
+
+/* ---- Conv2D / Dense on fp32 MFMA -------------------------------------------------------
+ * Replace the Keras Conv2D / Dense forward of dmlab/networks.py:31-60,84-89,116-118 and
+ * atari/networks.py:233-251 and their TF autodiff.  NHWC fp32; kernel [kh,kw,cin,cout];
+ * Dense == 1x1 conv on a 1x1 image (n_img = rows).  ld_in / ld_out = pixel strides. */
+typedef struct {
+  int n_img, ih, iw, cin, oh, ow, kh, kw, stride, pad_t, pad_l, cout;
+  int ld_in, ld_out;
+} seedhip_conv_geom;
+/* in_dtype: 0 = fp32, 1 = uint8 scaled by 1/255 (dmlab/networks.py:98-100).
+ * out = act(conv(relu?(in)) + bias (+ residual)); bias / residual may be NULL. */
+int seedhip_conv2d_fwd(const seedhip_conv_geom* geom, const void* in, int in_dtype, int in_relu,
+                       const float* w, const float* bias, float* out, int out_relu,
+                       const float* residual, void* stream);
+/* dx = conv_transpose(dy, w); then dx *= (relu_mask > 0) if relu_mask; dx += add if add. */
+int seedhip_conv2d_bwd_data(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
+                            const float* relu_mask, const float* add, void* stream);
+size_t seedhip_conv2d_bwd_weight_workspace_bytes(const seedhip_conv_geom* geom);
+/* dw[kh,kw,cin,cout] and dbias[cout] (dbias may be NULL) are OVERWRITTEN. */
+int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const void* in, int in_dtype, int in_relu,
+                              const float* dy, float* dw, float* dbias, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
+/* First Atari conv fused with frame stacking + /255 (atari/networks.py:57-173,234,330):
+ * consumes frames_ext / nvalid directly, VALID padding, 4 stacked channels. */
+typedef struct { int T, B, ih, iw, oh, ow, kh, kw, stride, cout, ld_out; } seedhip_stack_conv_geom;
+int seedhip_conv2d_stack_fwd(const seedhip_stack_conv_geom* geom, const uint8_t* frames_ext,
+                             const uint8_t* nvalid, const float* w, const float* bias, float* out,
+                             int out_relu, void* stream);
+size_t seedhip_conv2d_stack_bwd_weight_workspace_bytes(const seedhip_stack_conv_geom* geom);
+int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* geom, const uint8_t* frames_ext,
+                                    const uint8_t* nvalid, const float* dy, float* dw, float* dbias,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEEDHIP_H_ */

@@ -1,0 +1,120 @@
+// V-trace reverse-time scan.
+//
+// Replaces /root/reference/common/vtrace.py:84-148 (from_importance_weights):
+// ~100 tiny TF ops (4 [B]-vector ops x T + concat/stack/reverse) become ONE
+// launch.  One lane owns one (or 4 adjacent) batch column(s); time-major [T,B]
+// rows make every load/store a fully coalesced 256 B (1 KiB for the float4
+// form) wave access.  Loads are independent of the recurrence, so they are
+// issued U timesteps ahead of the serial `acc` chain.
+//
+// HBM-bound: 28 B per (t,b) element (5 fp32 reads + 2 fp32 writes) + 4 B per
+// column (bootstrap).  Arithmetic order and rounding mirror the reference
+// exactly (file compiled with -ffp-contract=off; IEEE expf, no fast-math):
+//   acc = delta + (discount * c) * acc            (vtrace.py:128)
+#include "common.h"
+#include "../../include/seedhip.h"
+
+namespace {
+
+template <int V> struct Vec;
+template <> struct Vec<1> { using type = float; };
+template <> struct Vec<4> { using type = float4; };
+
+template <int V> __device__ __forceinline__ void ld(const float* p, float (&o)[V]) {
+  if constexpr (V == 4) { float4 v = *reinterpret_cast<const float4*>(p); o[0]=v.x; o[1]=v.y; o[2]=v.z; o[3]=v.w; }
+  else o[0] = *p;
+}
+template <int V> __device__ __forceinline__ void st(float* p, const float (&o)[V]) {
+  if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  else *p = o[0];
+}
+
+// U = timesteps whose loads are in flight together.
+template <int V, int U>
+__global__ void __launch_bounds__(256)
+vtrace_scan_kernel(const float* __restrict__ tgt, const float* __restrict__ beh,
+                   const float* __restrict__ disc, const float* __restrict__ rew,
+                   const float* __restrict__ val, const float* __restrict__ boot,
+                   float clip_rho, float clip_pg, float lambda, int T, long long B,
+                   float* __restrict__ vs_out, float* __restrict__ pg_out) {
+  const long long col = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
+  if (col >= B) return;
+  float acc[V], vs_next[V], v_next[V];
+  {
+    float b[V]; ld<V>(boot + col, b);
+#pragma unroll
+    for (int i = 0; i < V; ++i) { acc[i] = 0.f; vs_next[i] = b[i]; v_next[i] = b[i]; }
+  }
+  const bool has_rho = clip_rho >= 0.f, has_pg = clip_pg >= 0.f;
+  int t = T - 1;
+  while (t >= 0) {
+    const int n = (t + 1 < U) ? t + 1 : U;      // steps in this chunk
+    float a_t[U][V], a_b[U][V], a_d[U][V], a_r[U][V], a_v[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (u < n) {
+        const long long off = (long long)(t - u) * B + col;
+        ld<V>(tgt + off, a_t[u]); ld<V>(beh + off, a_b[u]); ld<V>(disc + off, a_d[u]);
+        ld<V>(rew + off, a_r[u]); ld<V>(val + off, a_v[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (u < n) {
+        float o_vs[V], o_pg[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float log_rho = a_t[u][i] - a_b[u][i];                 // :84
+          const float rho = expf(log_rho);                              // :110
+          const float crho = has_rho ? fminf(clip_rho, rho) : rho;     // :111-114
+          const float c = fminf(1.0f, rho) * lambda;                   // :116-117
+          const float d = a_d[u][i], r = a_r[u][i], v = a_v[u][i];
+          const float delta = crho * ((r + d * v_next[i]) - v);        // :122
+          acc[i] = delta + (d * c) * acc[i];                           // :128
+          const float vs = acc[i] + v;                                 // :133
+          const float cpg = has_pg ? fminf(clip_pg, rho) : rho;        // :138-142
+          o_pg[i] = cpg * ((r + d * vs_next[i]) - v);                  // :143-144
+          o_vs[i] = vs; vs_next[i] = vs; v_next[i] = v;
+        }
+        const long long off = (long long)(t - u) * B + col;
+        st<V>(vs_out + off, o_vs); st<V>(pg_out + off, o_pg);
+      }
+    }
+    t -= n;
+  }
+}
+
+}  // namespace
+
+extern "C" int seedhip_vtrace_from_importance_weights(
+    const float* target_action_log_probs, const float* behaviour_action_log_probs,
+    const float* discounts, const float* rewards, const float* values,
+    const float* bootstrap_value, float clip_rho_threshold, float clip_pg_rho_threshold,
+    float lambda_, int T, long long B, float* vs, float* pg_advantages, void* stream) {
+  SEEDHIP_REQUIRE(T >= 0 && B >= 0, "vtrace: negative T=%d or B=%lld", T, B);
+  if (T == 0 || B == 0) return SEEDHIP_OK;
+  SEEDHIP_REQUIRE(target_action_log_probs && behaviour_action_log_probs && discounts && rewards &&
+                  values && bootstrap_value && vs && pg_advantages, "vtrace: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  auto aligned16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  const bool vec4 = (B % 4 == 0) && B >= (1 << 16) && aligned16(target_action_log_probs) &&
+                    aligned16(behaviour_action_log_probs) && aligned16(discounts) &&
+                    aligned16(rewards) && aligned16(values) && aligned16(bootstrap_value) &&
+                    aligned16(vs) && aligned16(pg_advantages);
+  if (vec4) {
+    const long long nthr = B / 4;
+    const int block = 256;
+    hipLaunchKernelGGL((vtrace_scan_kernel<4, 2>), dim3(seedhip::cdiv(nthr, block)), dim3(block), 0, s,
+                       target_action_log_probs, behaviour_action_log_probs, discounts, rewards, values,
+                       bootstrap_value, clip_rho_threshold, clip_pg_rho_threshold, lambda_, T, B, vs,
+                       pg_advantages);
+  } else {
+    // Small B: spread the columns over as many CUs as possible (64-lane blocks).
+    const int block = (B >= (1 << 15)) ? 256 : 64;
+    hipLaunchKernelGGL((vtrace_scan_kernel<1, 4>), dim3(seedhip::cdiv(B, block)), dim3(block), 0, s,
+                       target_action_log_probs, behaviour_action_log_probs, discounts, rewards, values,
+                       bootstrap_value, clip_rho_threshold, clip_pg_rho_threshold, lambda_, T, B, vs,
+                       pg_advantages);
+  }
+  return seedhip::check_launch("vtrace_scan_kernel");
+}

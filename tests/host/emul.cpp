@@ -1,0 +1,102 @@
+// Host-side element-level executor for the implicit-GEMM problem accessors
+// (seed_rl_amd/csrc/conv_problems.h).  TEST INFRASTRUCTURE: compiled with g++ and
+// driven from tests/test_host_emul.py; it runs the SAME accessor code the GPU
+// kernel runs (index decode, padding, parity classes, split-K, permutations) with
+// plain loops instead of MFMA tiles, so layout bugs are caught without a GPU.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../seed_rl_amd/csrc/conv_problems.h"
+
+using namespace seedhip;
+
+template <class P>
+static void run_problem(const P& p, int slices) {
+  for (int z = 0; z < slices; ++z) {
+    int k0, k1;
+    p.k_range(z, k0, k1);
+    std::vector<double> colsum(p.N, 0.0);
+    for (int m = 0; m < p.M; ++m) {
+      for (int n = 0; n < p.N; ++n) {
+        double acc = 0.0;
+        for (int k = k0; k < k1; ++k) {
+          float a, b;
+          if (P::kAVecK) a = f4_get(p.load_a(p.a_row(m, z), k0 + ((k - k0) & ~3), z), (k - k0) & 3);
+          else a = f4_get(p.load_a(p.a_row(m & ~3, z), k, z), m & 3);
+          if (P::kBVecN) b = f4_get(p.load_b(p.b_col(n & ~3, z), k, z), n & 3);
+          else b = f4_get(p.load_b(p.b_col(n, z), k0 + ((k - k0) & ~3), z), (k - k0) & 3);
+          acc += (double)a * (double)b;
+          if (P::kColSumB && m == 0) colsum[n] += b;
+        }
+        p.store(m, n, (float)acc, z);
+      }
+    }
+    if (P::kColSumB) for (int n = 0; n < p.N; ++n) p.store_colsum(n, (float)colsum[n], z);
+  }
+}
+
+static void reduce_slices(const float* partial, int slices, long long n, float* out) {
+  for (long long i = 0; i < n; ++i) {
+    double a = 0; for (int z = 0; z < slices; ++z) a += partial[(long long)z * n + i];
+    out[i] = (float)a;
+  }
+}
+
+extern "C" {
+
+struct geom_c { int n_img, ih, iw, cin, oh, ow, kh, kw, stride, pad_t, pad_l, cout, ld_in, ld_out; };
+struct sgeom_c { int T, B, ih, iw, oh, ow, kh, kw, stride, cout, ld_out; };
+
+static ConvGeom cg(const geom_c* g) {
+  ConvGeom c; memcpy(&c, g, sizeof(c)); return c;
+}
+static StackGeom sg(const sgeom_c* g) { StackGeom s; memcpy(&s, g, sizeof(s)); return s; }
+
+int emul_fastdiv_check(uint32_t d, uint32_t xmax, uint32_t step) {
+  FastDiv f; f.init(d);
+  for (uint64_t x = 0; x <= xmax; x += step) {
+    uint32_t q, r; f.divmod((uint32_t)x, q, r);
+    if (q != (uint32_t)x / d || r != (uint32_t)x % d) return 0;
+  }
+  return 1;
+}
+
+void emul_conv_fwd(const geom_c* g, const void* in, int in_dtype, int in_relu, const float* w, const float* bias,
+                   float* out, int out_relu, const float* residual) {
+  ConvFwd p; p.in = in; p.in_dtype = in_dtype; p.in_relu = in_relu; p.w = w; p.bias = bias; p.out = out;
+  p.out_relu = out_relu; p.residual = residual; p.init(cg(g));
+  run_problem(p, 1);
+}
+void emul_conv_dgrad(const geom_c* g, const float* dy, const float* w, float* dx, const float* mask, const float* add) {
+  ConvDgrad p; p.dy = dy; p.w = w; p.dx = dx; p.mask = mask; p.add = add; p.init(cg(g));
+  run_problem(p, p.slices());
+}
+void emul_conv_wgrad(const geom_c* g, const void* in, int in_dtype, int in_relu, const float* dy, float* dw,
+                     float* dbias, int k_per_slice) {
+  ConvWgrad p; p.in = in; p.in_dtype = in_dtype; p.in_relu = in_relu; p.dy = dy; p.init(cg(g), k_per_slice);
+  const int s = p.slices();
+  std::vector<float> pw((size_t)s * p.M * p.N), pb((size_t)s * p.N);
+  p.partial_w = pw.data(); p.partial_b = pb.data();
+  run_problem(p, s);
+  reduce_slices(pw.data(), s, (long long)p.M * p.N, dw);
+  reduce_slices(pb.data(), s, p.N, dbias);
+}
+void emul_stack_fwd(const sgeom_c* g, const uint8_t* frames_ext, const uint8_t* nvalid, const float* w,
+                    const float* bias, float* out, int out_relu) {
+  ConvStackFwd p; p.frames_ext = frames_ext; p.nvalid = nvalid; p.w = w; p.bias = bias; p.out = out;
+  p.out_relu = out_relu; p.init(sg(g));
+  run_problem(p, 1);
+}
+void emul_stack_wgrad(const sgeom_c* g, const uint8_t* frames_ext, const uint8_t* nvalid, const float* dy, float* dw,
+                      float* dbias, int k_per_slice) {
+  ConvStackWgrad p; p.frames_ext = frames_ext; p.nvalid = nvalid; p.dy = dy; p.init(sg(g), k_per_slice);
+  const int s = p.slices();
+  std::vector<float> pw((size_t)s * p.M * p.N), pb((size_t)s * p.N);
+  p.partial_w = pw.data(); p.partial_b = pb.data();
+  run_problem(p, s);
+  reduce_slices(pw.data(), s, (long long)p.M * p.N, dw);
+  reduce_slices(pb.data(), s, p.N, dbias);
+}
+
+}  // extern "C"
