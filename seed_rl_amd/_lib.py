@@ -1,0 +1,106 @@
+"""ctypes binding of libseedhip.so (the C ABI declared in include/seedhip.h).
+
+The library is built in-tree by `python -m seed_rl_amd.build` (or
+`__graft_entry__.build()`); there is no fallback -- if it is missing or a
+symbol is absent this module raises at import/use.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libseedhip.so')
+
+c_int, c_ll, c_float, c_size_t, c_void_p = (
+    ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p)
+P = c_void_p
+
+
+class ConvGeom(ctypes.Structure):
+  """seedhip_conv_geom."""
+  _fields_ = [(n, c_int) for n in
+              'n_img ih iw cin oh ow kh kw stride pad_t pad_l cout ld_in ld_out'.split()]
+
+
+class StackConvGeom(ctypes.Structure):
+  """seedhip_stack_conv_geom."""
+  _fields_ = [(n, c_int) for n in 'T B ih iw oh ow kh kw stride cout ld_out'.split()]
+
+
+# name -> (restype, argtypes); every symbol include/seedhip.h declares.
+SIGNATURES = {
+    'seedhip_last_error': (ctypes.c_char_p, []),
+    'seedhip_abi_version': (c_int, []),
+    'seedhip_vtrace_from_importance_weights':
+        (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, c_int, c_ll, P, P, P]),
+    'seedhip_categorical_log_prob_entropy': (c_int, [P, P, c_int, c_ll, c_int, P, P, P]),
+    'seedhip_impala_loss_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'seedhip_impala_loss_fwd_bwd':
+        (c_int, [P, c_int, P, c_int, P, P, c_int, P, P, c_int, c_int, c_int,
+                 c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float,
+                 P, P, P, P, P, P, c_size_t, P]),
+    'seedhip_adam_flat': (c_int, [P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, P]),
+    'seedhip_global_norm_workspace_bytes': (c_size_t, []),
+    'seedhip_clip_by_global_norm': (c_int, [P, c_ll, c_float, P, P, c_size_t, P]),
+    'seedhip_stack_prepare': (c_int, [P, P, c_int, c_int, c_ll, P, P, P]),
+    'seedhip_stack_frames_f32': (c_int, [P, P, c_int, c_int, c_ll, P, P]),
+    'seedhip_stack_pack_state': (c_int, [P, P, c_int, c_int, c_ll, P, P]),
+    'seedhip_conv2d_fwd': (c_int, [ctypes.POINTER(ConvGeom), P, c_int, c_int, P, P, P, c_int, P, P]),
+    'seedhip_conv2d_bwd_data': (c_int, [ctypes.POINTER(ConvGeom), P, P, P, P, P, P]),
+    'seedhip_conv2d_bwd_weight_workspace_bytes': (c_size_t, [ctypes.POINTER(ConvGeom)]),
+    'seedhip_conv2d_bwd_weight':
+        (c_int, [ctypes.POINTER(ConvGeom), P, c_int, c_int, P, P, P, P, c_size_t, P]),
+    'seedhip_conv2d_stack_fwd': (c_int, [ctypes.POINTER(StackConvGeom), P, P, P, P, P, c_int, P]),
+    'seedhip_conv2d_stack_bwd_weight_workspace_bytes': (c_size_t, [ctypes.POINTER(StackConvGeom)]),
+    'seedhip_conv2d_stack_bwd_weight':
+        (c_int, [ctypes.POINTER(StackConvGeom), P, P, P, P, P, P, c_size_t, P]),
+}
+
+
+class SeedHipError(RuntimeError):
+  pass
+
+
+_lib = None
+
+
+def lib():
+  """Loads libseedhip.so once; raises if it has not been built."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise SeedHipError(
+          'libseedhip.so not built (%s). Run `python -m seed_rl_amd.build`. '
+          'There is no CPU fallback for the HIP hot path.' % LIB_PATH)
+    l = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+      fn = getattr(l, name)            # AttributeError if the symbol is missing
+      fn.restype = res
+      fn.argtypes = args
+    _lib = l
+  return _lib
+
+
+def check(rc, what=''):
+  if rc != 0:
+    msg = lib().seedhip_last_error()
+    raise SeedHipError('%s failed (rc=%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def ptr(t):
+  """Device pointer of a torch tensor (None -> NULL)."""
+  return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream():
+  """The current torch HIP stream as a hipStream_t (void*)."""
+  import torch
+  return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+  for t in tensors:
+    if t is not None and not t.is_cuda:
+      raise SeedHipError('seed_rl_amd kernels need device tensors (got a %s tensor); '
+                         'there is no CPU fallback.' % t.device)
+    if t is not None and not t.is_contiguous():
+      raise SeedHipError('seed_rl_amd kernels need contiguous tensors')

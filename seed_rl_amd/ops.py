@@ -1,0 +1,137 @@
+"""Thin torch-tensor wrappers over the C ABI (pointers + sizes only cross it)."""
+import ctypes
+
+import torch
+
+from seed_rl_amd import _lib
+from seed_rl_amd._lib import ConvGeom, StackConvGeom
+
+IN_F32, IN_U8_DIV255 = 0, 1
+
+
+def conv_geom(n_img, ih, iw, cin, kh, kw, stride, padding, cout, ld_in=None, ld_out=None):
+  """Keras Conv2D geometry; padding in {'same','valid'}."""
+  if padding == 'same':
+    oh, ow = -(-ih // stride), -(-iw // stride)
+    pt = max((oh - 1) * stride + kh - ih, 0) // 2
+    pl = max((ow - 1) * stride + kw - iw, 0) // 2
+  elif padding == 'valid':
+    oh, ow, pt, pl = (ih - kh) // stride + 1, (iw - kw) // stride + 1, 0, 0
+  else:
+    raise ValueError(padding)
+  return ConvGeom(n_img, ih, iw, cin, oh, ow, kh, kw, stride, pt, pl, cout,
+                  ld_in or cin, ld_out or cout)
+
+
+def dense_geom(rows, cin, cout, ld_in=None, ld_out=None):
+  return conv_geom(rows, 1, 1, cin, 1, 1, 1, 'valid', cout, ld_in, ld_out)
+
+
+def _dev(t):
+  return torch.cuda.device(t.device)
+
+
+def conv2d_fwd(g, x, w, bias, out, in_dtype=IN_F32, in_relu=False, out_relu=False, residual=None):
+  with _dev(out):
+    _lib.check(_lib.lib().seedhip_conv2d_fwd(
+        ctypes.byref(g), _lib.ptr(x), in_dtype, int(in_relu), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out),
+        int(out_relu), _lib.ptr(residual), _lib.stream()), 'seedhip_conv2d_fwd')
+  return out
+
+
+def conv2d_bwd_data(g, dy, w, dx, relu_mask=None, add=None):
+  with _dev(dx):
+    _lib.check(_lib.lib().seedhip_conv2d_bwd_data(
+        ctypes.byref(g), _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(relu_mask), _lib.ptr(add),
+        _lib.stream()), 'seedhip_conv2d_bwd_data')
+  return dx
+
+
+def conv2d_bwd_weight_workspace_bytes(g):
+  return int(_lib.lib().seedhip_conv2d_bwd_weight_workspace_bytes(ctypes.byref(g)))
+
+
+def conv2d_bwd_weight(g, x, dy, dw, dbias, workspace, in_dtype=IN_F32, in_relu=False):
+  with _dev(dw):
+    _lib.check(_lib.lib().seedhip_conv2d_bwd_weight(
+        ctypes.byref(g), _lib.ptr(x), in_dtype, int(in_relu), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(dbias),
+        _lib.ptr(workspace), workspace.numel() * workspace.element_size(), _lib.stream()),
+        'seedhip_conv2d_bwd_weight')
+
+
+def stack_prepare(state, done_u8, T, B, HW, frames_ext, nvalid):
+  with _dev(frames_ext):
+    _lib.check(_lib.lib().seedhip_stack_prepare(
+        _lib.ptr(state), _lib.ptr(done_u8), T, B, HW, _lib.ptr(frames_ext), _lib.ptr(nvalid), _lib.stream()),
+        'seedhip_stack_prepare')
+
+
+def stack_frames_f32(frames_ext, nvalid, T, B, HW, out):
+  with _dev(out):
+    _lib.check(_lib.lib().seedhip_stack_frames_f32(
+        _lib.ptr(frames_ext), _lib.ptr(nvalid), T, B, HW, _lib.ptr(out), _lib.stream()),
+        'seedhip_stack_frames_f32')
+
+
+def stack_pack_state(frames_ext, nvalid, T, B, HW, new_state):
+  with _dev(new_state):
+    _lib.check(_lib.lib().seedhip_stack_pack_state(
+        _lib.ptr(frames_ext), _lib.ptr(nvalid), T, B, HW, _lib.ptr(new_state), _lib.stream()),
+        'seedhip_stack_pack_state')
+
+
+def conv2d_stack_fwd(g, frames_ext, nvalid, w, bias, out, out_relu=True):
+  with _dev(out):
+    _lib.check(_lib.lib().seedhip_conv2d_stack_fwd(
+        ctypes.byref(g), _lib.ptr(frames_ext), _lib.ptr(nvalid), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out),
+        int(out_relu), _lib.stream()), 'seedhip_conv2d_stack_fwd')
+
+
+def conv2d_stack_bwd_weight_workspace_bytes(g):
+  return int(_lib.lib().seedhip_conv2d_stack_bwd_weight_workspace_bytes(ctypes.byref(g)))
+
+
+def conv2d_stack_bwd_weight(g, frames_ext, nvalid, dy, dw, dbias, workspace):
+  with _dev(dw):
+    _lib.check(_lib.lib().seedhip_conv2d_stack_bwd_weight(
+        ctypes.byref(g), _lib.ptr(frames_ext), _lib.ptr(nvalid), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(dbias),
+        _lib.ptr(workspace), workspace.numel() * workspace.element_size(), _lib.stream()),
+        'seedhip_conv2d_stack_bwd_weight')
+
+
+def impala_loss_workspace_bytes(T, B):
+  return int(_lib.lib().seedhip_impala_loss_workspace_bytes(T, B))
+
+
+def impala_loss_fwd_bwd(logits, logits_ld, baseline, baseline_ld, beh_logits, actions, rewards, done_u8,
+                        T, B, A, d_logits, d_baseline, scalars, workspace, vs=None, pg=None,
+                        entropy_cost=0.00025, baseline_cost=0.5, kl_cost=0.0, discounting=0.99,
+                        lambda_=1.0, max_abs_reward=0.0, clip_rho=1.0, clip_pg_rho=1.0,
+                        mean_denominator=None):
+  n = float(T * B if mean_denominator is None else mean_denominator)
+  with _dev(scalars):
+    _lib.check(_lib.lib().seedhip_impala_loss_fwd_bwd(
+        _lib.ptr(logits), logits_ld, _lib.ptr(baseline), baseline_ld, _lib.ptr(beh_logits), _lib.ptr(actions),
+        actions.element_size(), _lib.ptr(rewards), _lib.ptr(done_u8), T, B, A,
+        entropy_cost, baseline_cost, kl_cost, discounting, lambda_, max_abs_reward, clip_rho, clip_pg_rho,
+        n, _lib.ptr(d_logits), _lib.ptr(d_baseline), _lib.ptr(vs), _lib.ptr(pg), _lib.ptr(scalars),
+        _lib.ptr(workspace), workspace.numel() * workspace.element_size(), _lib.stream()),
+        'seedhip_impala_loss_fwd_bwd')
+
+
+def adam_flat(params, grads, m, v, lr_t, beta_1, beta_2, epsilon, grad_scale=1.0):
+  with _dev(params):
+    _lib.check(_lib.lib().seedhip_adam_flat(
+        _lib.ptr(params), _lib.ptr(grads), _lib.ptr(m), _lib.ptr(v), params.numel(), lr_t, beta_1, beta_2,
+        epsilon, grad_scale, _lib.stream()), 'seedhip_adam_flat')
+
+
+def global_norm_workspace_bytes():
+  return int(_lib.lib().seedhip_global_norm_workspace_bytes())
+
+
+def clip_by_global_norm(grads, clip_norm, sumsq_out, workspace):
+  with _dev(grads):
+    _lib.check(_lib.lib().seedhip_clip_by_global_norm(
+        _lib.ptr(grads), grads.numel(), float(clip_norm), _lib.ptr(sumsq_out), _lib.ptr(workspace),
+        workspace.numel() * workspace.element_size(), _lib.stream()), 'seedhip_clip_by_global_norm')

@@ -1,0 +1,397 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI, vs the CPU oracle
+on identical seeded inputs.  Tolerances are stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import categorical_np, frames_np, loss_np, nets_torch, vtrace_np
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, device):
+  return torch.as_tensor(np.ascontiguousarray(a)).to(device)
+
+
+# ------------------------------- V-trace ------------------------------------- #
+def _run_vtrace(device, inp, **kw):
+  from seed_rl_amd import vtrace
+  t = {k: dev(v, device) for k, v in inp.items()}
+  out = vtrace.from_importance_weights(**t, **kw)
+  return out.vs.cpu().numpy(), out.pg_advantages.cpu().numpy()
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+@pytest.mark.parametrize('kw', [dict(), dict(lambda_=0.95),
+                                dict(clip_rho_threshold=3.7, clip_pg_rho_threshold=2.2),
+                                dict(clip_rho_threshold=None, clip_pg_rho_threshold=None)])
+def test_vtrace_cfg1_parity(device, seed, kw):
+  """BASELINE.json configs[0]: [T=20,B=32,A=6]; bar = 1e-5 max-abs vs the fp32 oracle."""
+  for stress in (False, True):
+    inp = synth.vtrace_inputs(seed, 20, 32, 6, stress=stress)
+    vs, pg = _run_vtrace(device, inp, **kw)
+    ref = vtrace_np.from_importance_weights(**inp, **kw)
+    assert np.max(np.abs(vs - ref.vs)) <= 1e-5
+    assert np.max(np.abs(pg - ref.pg_advantages)) <= 1e-5
+    ref64 = vtrace_np.from_importance_weights(**inp, **kw, dtype=np.float64)
+    assert np.max(np.abs(vs - ref64.vs)) <= 1e-4       # fp32 rounding distance to fp64 truth
+
+
+def test_vtrace_reference_golden(device):
+  """tests/vtrace_test.py:120-145 inputs through the HIP kernel."""
+  from tests.test_oracle_golden import _ref_vtrace_inputs
+  v = _ref_vtrace_inputs()
+  kw = dict(clip_rho_threshold=v.pop('clip_rho_threshold'), clip_pg_rho_threshold=v.pop('clip_pg_rho_threshold'))
+  vs, pg = _run_vtrace(device, v, **kw)
+  gt = vtrace_np.ground_truth_calculation(**v, **kw)
+  np.testing.assert_allclose(vs, gt.vs, rtol=1e-6, atol=1e-6)         # reference's own tolerance
+  np.testing.assert_allclose(pg, gt.pg_advantages, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('T,B', [(1, 1), (3, 7), (20, 512), (20, 4096), (5, 65536), (20, 262144), (100, 33)])
+def test_vtrace_shapes(device, T, B):
+  inp = synth.vtrace_inputs(3, T, B, 4) if B <= 4096 else None
+  if inp is None:
+    rng = np.random.default_rng(T + B)
+    inp = dict(target_action_log_probs=rng.uniform(-2, 0, (T, B)).astype(np.float32),
+               behaviour_action_log_probs=rng.uniform(-2, 0, (T, B)).astype(np.float32),
+               discounts=(0.99 * (rng.uniform(size=(T, B)) > 0.05)).astype(np.float32),
+               rewards=rng.uniform(0, 3, (T, B)).astype(np.float32),
+               values=rng.uniform(0, 3, (T, B)).astype(np.float32),
+               bootstrap_value=rng.uniform(0, 3, (B,)).astype(np.float32))
+  vs, pg = _run_vtrace(device, inp, lambda_=0.95)
+  ref = vtrace_np.from_importance_weights(**inp, lambda_=0.95)
+  assert np.max(np.abs(vs - ref.vs)) <= 1e-5 and np.max(np.abs(pg - ref.pg_advantages)) <= 1e-5
+
+
+def test_vtrace_extra_dims_and_errors(device):
+  """vtrace.py:49-51 trailing dims; :99-107 rank errors; empty T."""
+  from seed_rl_amd import vtrace
+  rng = np.random.default_rng(0)
+  T, B, C = 6, 5, 3
+  mk = lambda *s: rng.uniform(-1, 1, s).astype(np.float32)
+  inp = dict(target_action_log_probs=mk(T, B, C), behaviour_action_log_probs=mk(T, B, C),
+             discounts=np.full((T, B, C), 0.9, np.float32), rewards=mk(T, B, C), values=mk(T, B, C),
+             bootstrap_value=mk(B, C))
+  vs, pg = _run_vtrace(device, inp)
+  ref = vtrace_np.from_importance_weights(**inp)
+  assert vs.shape == (T, B, C) and np.max(np.abs(vs - ref.vs)) <= 1e-5
+  bad = {k: dev(v, device) for k, v in inp.items()}
+  bad['bootstrap_value'] = bad['values']
+  with pytest.raises(ValueError):
+    vtrace.from_importance_weights(**bad)
+  with pytest.raises(Exception):
+    vtrace.from_importance_weights(**{k: torch.as_tensor(v) for k, v in inp.items()})   # CPU tensors: no fallback
+  e = {k: dev(v[:0] if k != 'bootstrap_value' else v, device) for k, v in inp.items()}
+  out = vtrace.from_importance_weights(**e)
+  assert out.vs.shape == (0, B, C)
+
+
+def test_vtrace_linearity_full_size(device):
+  """Size-independent property at cfg4 global size (T=20,B=4096): with rho clipped to
+  constants (log-rho = 0) V-trace is linear in (rewards, values, bootstrap)."""
+  rng = np.random.default_rng(5)
+  T, B = 20, 4096
+  z = np.zeros((T, B), np.float32)
+  disc = (0.99 * (rng.uniform(size=(T, B)) > 0.05)).astype(np.float32)
+  def run(r, v, b):
+    return _run_vtrace(device, dict(target_action_log_probs=z, behaviour_action_log_probs=z, discounts=disc,
+                                    rewards=r, values=v, bootstrap_value=b))
+  r1, v1, b1 = rng.normal(size=(T, B)).astype(np.float32), rng.normal(size=(T, B)).astype(np.float32), rng.normal(size=B).astype(np.float32)
+  r2, v2, b2 = rng.normal(size=(T, B)).astype(np.float32), rng.normal(size=(T, B)).astype(np.float32), rng.normal(size=B).astype(np.float32)
+  a1, _ = run(r1, v1, b1); a2, _ = run(r2, v2, b2); a3, _ = run(r1 + r2, v1 + v2, b1 + b2)
+  assert np.max(np.abs(a3 - (a1 + a2))) < 2e-4
+
+
+# ------------------------------ categorical ---------------------------------- #
+@pytest.mark.parametrize('A', [1, 3, 6, 9, 18, 37, 100])
+def test_categorical(device, A):
+  from seed_rl_amd import parametric_distribution as pd
+  rng = np.random.default_rng(A)
+  logits = (rng.normal(size=(7, 5, A)) * 3).astype(np.float32)
+  for dt in (np.int32, np.int64):
+    act = rng.integers(0, A, (7, 5)).astype(dt)
+    d = pd.categorical_distribution(A)
+    lp = d.log_prob(dev(logits, device), dev(act, device)).cpu().numpy()
+    ent = d.entropy(dev(logits, device)).cpu().numpy()
+    np.testing.assert_allclose(lp, categorical_np.log_prob(logits, act), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(ent, categorical_np.entropy(logits), rtol=1e-5, atol=2e-6)
+
+
+def test_categorical_reference_golden(device):
+  """tests/vtrace_test.py:88-115."""
+  from seed_rl_amd import parametric_distribution as pd
+  logits = (np.arange(7 * 2 * 3, dtype=np.float32).reshape(7, 2, 3) + 10)
+  act = np.random.default_rng(0).integers(0, 2, (7, 2)).astype(np.int32)
+  lp = pd.categorical_distribution(3, torch.int32).log_prob(dev(logits, device), dev(act, device)).cpu().numpy()
+  sm = np.exp(logits) / np.exp(logits).sum(-1, keepdims=True)
+  gt = np.take_along_axis(np.log(sm), act[..., None].astype(np.int64), -1)[..., 0]
+  np.testing.assert_allclose(lp, gt, rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------ loss head ------------------------------------ #
+def _run_loss(device, tgt, base, beh, act, rew, done, ld=None, **kw):
+  from seed_rl_amd import ops
+  T1, B, A = tgt.shape
+  T = T1 - 1
+  ld = ld or A
+  if ld == A:
+    logits_d = dev(tgt, device); base_d = dev(base, device); bld = 1
+    d_logits = torch.full((T1, B, A), 7.0, device=device); d_base = torch.full((T1, B), 7.0, device=device)
+  else:   # head-GEMM layout: [rows, ld] with baseline in column A
+    head = np.zeros((T1, B, ld), np.float32); head[..., :A] = tgt; head[..., A] = base
+    head_d = dev(head, device)
+    logits_d = head_d; base_d = head_d.reshape(-1)[A:]; bld = ld
+    d_head = torch.zeros((T1, B, ld), device=device)
+    d_logits = d_head; d_base = d_head.reshape(-1)[A:]
+  vs = torch.empty((T, B), device=device); pg = torch.empty((T, B), device=device)
+  scalars = torch.zeros(16, device=device)
+  ws = torch.empty(ops.impala_loss_workspace_bytes(T, B) // 4 + 1, device=device)
+  ops.impala_loss_fwd_bwd(logits_d, ld, base_d, bld, dev(beh, device), dev(act, device), dev(rew, device),
+                          dev(done.astype(np.uint8), device), T, B, A, d_logits, d_base, scalars, ws, vs, pg, **kw)
+  torch.cuda.synchronize()
+  if ld == A:
+    dl, db = d_logits.cpu().numpy(), d_base.cpu().numpy()
+  else:
+    dh = d_head.cpu().numpy(); dl, db = dh[..., :A], dh[..., A]
+    assert np.all(dh[..., A + 1:] == 0)
+  return scalars.cpu().numpy(), dl, db, vs.cpu().numpy(), pg.cpu().numpy()
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+@pytest.mark.parametrize('cfg', [
+    dict(T=20, B=32, A=6, kw=dict()),
+    dict(T=20, B=32, A=6, kw=dict(lambda_=0.95, kl_cost=0.1, max_abs_reward=1.0, entropy_cost=0.01)),
+    dict(T=20, B=37, A=18, kw=dict(), adt=np.int32),
+    dict(T=5, B=3, A=9, kw=dict(lambda_=0.95)),
+    dict(T=100, B=16, A=18, kw=dict()),
+])
+def test_loss_head_parity(device, seed, cfg):
+  """V-trace outputs <= 1e-5 (north_star bar); loss scalars / gradients fp32-rounding close."""
+  tgt, base, beh, act, rew, done = synth.loss_inputs(seed, cfg['T'], cfg['B'], cfg['A'], cfg.get('adt', np.int64))
+  ref = loss_np.compute_loss_from_outputs(tgt, base, beh, act, rew, done, **cfg['kw'])
+  for ld in (None, ((cfg['A'] + 1 + 3) // 4) * 4):
+    sc, dl, db, vs, pg = _run_loss(device, tgt, base, beh, act, rew, done, ld=ld, **cfg['kw'])
+    assert np.max(np.abs(vs - ref.vs)) <= 1e-5
+    assert np.max(np.abs(pg - ref.pg_advantages)) <= 1e-5
+    for i, name in enumerate(['total_loss', 'policy_loss', 'v_loss', 'entropy_loss', 'kl_loss', 'entropy',
+                              'kl_mean', 'value_mean', 'v_l2_error']):
+      r = float(getattr(ref, name))
+      assert abs(sc[i] - r) <= 2e-5 * max(1.0, abs(r)), (name, sc[i], r)
+    assert sc[9] == ref.max_action_abs
+    np.testing.assert_allclose(dl, ref.d_policy_logits, rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(db, ref.d_baseline, rtol=1e-4, atol=1e-7)
+
+
+def test_loss_head_mean_denominator_shards(device):
+  """Data-parallel mean semantics: two column shards with the GLOBAL N sum to the
+  single-batch result."""
+  tgt, base, beh, act, rew, done = synth.loss_inputs(7, 20, 64, 6)
+  full = _run_loss(device, tgt, base, beh, act, rew, done)
+  n = 20 * 64
+  parts = [_run_loss(device, tgt[:, s], base[:, s], beh[:, s], act[:, s], rew[:, s], done[:, s],
+                     mean_denominator=n) for s in (slice(0, 32), slice(32, 64))]
+  assert abs(parts[0][0][0] + parts[1][0][0] - full[0][0]) < 1e-5
+  np.testing.assert_allclose(np.concatenate([parts[0][1], parts[1][1]], 1), full[1], rtol=1e-5, atol=1e-8)
+
+
+# ------------------------------ Adam ------------------------------------------ #
+def test_adam_flat_matches_keras_restatement(device):
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(0)
+  n = 100003
+  p0 = rng.normal(size=n).astype(np.float32)
+  for b1, eps in ((0.9, 1e-7), (0.0, 3.125e-7)):
+    p = torch.tensor(p0.copy())
+    opt = nets_torch.KerasAdam([p], nets_torch.polynomial_decay(4.8e-4, 1000), beta_1=b1, epsilon=eps)
+    pd_ = dev(p0, device).clone(); m = torch.zeros(n, device=device); v = torch.zeros(n, device=device)
+    for it in range(3):
+      g = rng.normal(size=n).astype(np.float32)
+      lr = nets_torch.polynomial_decay(4.8e-4, 1000)(it)
+      t = it + 1
+      lr_t = lr * np.sqrt(1 - 0.999 ** t) / (1 - b1 ** t)
+      ops.adam_flat(pd_, dev(g, device), m, v, float(lr_t), b1, 0.999, eps, 1.0)
+      opt.apply_gradients([torch.tensor(g)])
+    np.testing.assert_allclose(pd_.cpu().numpy(), p.numpy(), rtol=2e-6, atol=2e-7)
+
+
+def test_clip_by_global_norm(device):
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(1)
+  g0 = rng.normal(size=300001).astype(np.float32)
+  for clip in (40.0, 1000.0):
+    g = dev(g0, device).clone()
+    ss = torch.zeros(1, device=device)
+    ws = torch.empty(ops.global_norm_workspace_bytes() // 4, device=device)
+    ops.clip_by_global_norm(g, clip, ss, ws)
+    norm = np.sqrt((g0.astype(np.float64) ** 2).sum())
+    assert abs(np.sqrt(float(ss[0])) - norm) < 1e-3 * norm
+    np.testing.assert_allclose(g.cpu().numpy(), g0 * (clip / max(norm, clip)), rtol=1e-5)
+
+
+# ------------------------------ frame stacking -------------------------------- #
+@pytest.mark.parametrize('T,B,H,W', [(6, 3, 5, 4), (21, 4, 84, 84), (1, 2, 7, 3)])
+def test_stack_frames_parity(device, T, B, H, W):
+  """Bit-exact vs oracle stack_frames (atari/networks.py:57-173), incl. the new state."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(T * B)
+  frames = rng.integers(0, 256, (T, B, H, W, 1)).astype(np.uint8)
+  done = rng.uniform(size=(T, B)) < 0.3
+  state = rng.integers(0, 2 ** 24, (B, H * W)).astype(np.int32)
+  ref, ref_state = frames_np.stack_frames(frames, state, done, 4)
+  HW = H * W
+  ext = torch.zeros((T + 3, B, HW), dtype=torch.uint8, device=device)
+  ext[3:] = dev(frames.reshape(T, B, HW), device)
+  nv = torch.zeros((T, B), dtype=torch.uint8, device=device)
+  ops.stack_prepare(dev(state, device), dev(done.astype(np.uint8), device), T, B, HW, ext, nv)
+  out = torch.empty((T, B, HW, 4), device=device)
+  ops.stack_frames_f32(ext, nv, T, B, HW, out)
+  new_state = torch.empty((B, HW), dtype=torch.int32, device=device)
+  ops.stack_pack_state(ext, nv, T, B, HW, new_state)
+  np.testing.assert_array_equal(out.cpu().numpy().reshape(ref.shape), ref)
+  np.testing.assert_array_equal(new_state.cpu().numpy(), ref_state)
+
+
+def test_stack_frames_reference_golden(device):
+  """atari/networks_test.py:186-247 sequences (incl. done in the middle)."""
+  from seed_rl_amd import ops
+  def run(frames, done, state):
+    T = len(frames)
+    ext = torch.zeros((T + 3, 1, 1), dtype=torch.uint8, device=device)
+    ext[3:, 0, 0] = torch.tensor(frames, dtype=torch.uint8)
+    nv = torch.zeros((T, 1), dtype=torch.uint8, device=device)
+    ops.stack_prepare(state, torch.tensor(done, dtype=torch.uint8, device=device).reshape(T, 1), T, 1, 1, ext, nv)
+    out = torch.empty((T, 1, 1, 4), device=device)
+    ops.stack_frames_f32(ext, nv, T, 1, 1, out)
+    ns = torch.empty((1, 1), dtype=torch.int32, device=device)
+    ops.stack_pack_state(ext, nv, T, 1, 1, ns)
+    return out.cpu().numpy().reshape(T, 4), ns
+  st = torch.zeros((1, 1), dtype=torch.int32, device=device)
+  o, st = run([1], [0], st); assert o.tolist() == [[1, 0, 0, 0]]
+  o, st2 = run([2], [0], st); assert o.tolist() == [[2, 1, 0, 0]]
+  o, _ = run([3, 4, 5, 6, 7, 8], [0] * 6, st2)
+  assert o[0].tolist() == [3, 2, 1, 0] and o[5].tolist() == [8, 7, 6, 5]
+  o, st3 = run([2], [1], st); assert o.tolist() == [[2, 0, 0, 0]]
+  o, _ = run([3, 4, 5, 6, 7, 8], [0, 0, 0, 0, 1, 0], st3)
+  assert o[0].tolist() == [3, 2, 0, 0] and o[5].tolist() == [8, 7, 0, 0]
+
+
+# ------------------------------ conv / dense ---------------------------------- #
+CONV_CASES = [
+    # n, ih, iw, cin, kh, kw, stride, padding, cout      (the layer shapes of the three agents)
+    (3, 72, 96, 3, 3, 3, 1, 'same', 16),      # ImpalaDeep stack0 conv (u8 input)
+    (3, 36, 48, 16, 3, 3, 1, 'same', 16),     # stack0 res conv
+    (3, 36, 48, 16, 3, 3, 1, 'same', 32),     # stack1 conv
+    (5, 18, 24, 32, 3, 3, 1, 'same', 32),     # stack1/2 res conv
+    (7, 20, 20, 16, 4, 4, 2, 'valid', 32),    # shallow conv2
+    (4, 20, 20, 32, 4, 4, 2, 'valid', 64),    # DQN conv2
+    (4, 9, 9, 64, 3, 3, 1, 'valid', 64),      # DQN conv3
+    (300, 1, 1, 2592, 1, 1, 1, 'valid', 256), # shallow FC
+    (300, 1, 1, 256, 1, 1, 1, 'valid', 20),   # heads (A=18 -> ld 20)
+    (70, 1, 1, 268, 1, 1, 1, 'valid', 1024),  # LSTM input projection
+    (3, 11, 9, 8, 5, 3, 2, 'valid', 12),      # odd shape
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_bwd_parity(device, case):
+  """fp32 MFMA conv/dense fwd, dgrad, wgrad vs torch-CPU fp32 (oracle conv2d).
+  Tolerance: 2e-4 relative to the output scale (fp32 accumulation-order noise, K<=2592)."""
+  from seed_rl_amd import ops
+  n, ih, iw, cin, kh, kw, stride, padding, cout = case
+  rng = np.random.default_rng(abs(hash(case)) % 1000)
+  u8 = cin == 3
+  if u8:
+    x_raw = rng.integers(0, 256, (n, ih, iw, cin)).astype(np.uint8)
+    x = torch.tensor(x_raw).float() / 255
+  else:
+    x_raw = rng.normal(size=(n, ih, iw, cin)).astype(np.float32)
+    x = torch.tensor(x_raw)
+  w = (rng.normal(size=(kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)).astype(np.float32)
+  b = rng.normal(size=(cout,)).astype(np.float32)
+  in_relu = not u8
+  x.requires_grad_(True)
+  wt = torch.tensor(w, requires_grad=True); bt = torch.tensor(b, requires_grad=True)
+  y = F.relu(nets_torch.conv2d(F.relu(x) if in_relu else x, wt, bt, stride, padding))
+  dy = rng.normal(size=y.shape).astype(np.float32)
+  y.backward(torch.tensor(dy))
+  yr = y.detach().numpy()
+
+  g = ops.conv_geom(n, ih, iw, cin, kh, kw, stride, padding, cout)
+  xd = dev(x_raw, device); wd = dev(w, device); bd = dev(b, device)
+  out = torch.full((n, g.oh, g.ow, cout), 7.0, device=device)
+  ops.conv2d_fwd(g, xd, wd, bd, out, in_dtype=ops.IN_U8_DIV255 if u8 else ops.IN_F32, in_relu=in_relu, out_relu=True)
+  tol = 2e-4 * max(1.0, np.abs(yr).max())
+  assert np.max(np.abs(out.cpu().numpy() - yr)) <= tol
+
+  dz = dev(np.ascontiguousarray(dy * (yr > 0), np.float32), device)
+  dw = torch.full(w.shape, 7.0, device=device); db = torch.full(b.shape, 7.0, device=device)
+  ws = torch.empty(ops.conv2d_bwd_weight_workspace_bytes(g) // 4 + 1, device=device)
+  ops.conv2d_bwd_weight(g, xd, dz, dw, db, ws, in_dtype=ops.IN_U8_DIV255 if u8 else ops.IN_F32, in_relu=in_relu)
+  gw = wt.grad.numpy(); gb = bt.grad.numpy()
+  assert np.max(np.abs(dw.cpu().numpy() - gw)) <= 3e-4 * max(1.0, np.abs(gw).max())
+  assert np.max(np.abs(db.cpu().numpy() - gb)) <= 3e-4 * max(1.0, np.abs(gb).max())
+  if not u8:
+    dx = torch.full(x_raw.shape, 7.0, device=device)
+    ops.conv2d_bwd_data(g, dz, wd, dx, relu_mask=xd)
+    gx = x.grad.numpy()
+    assert np.max(np.abs(dx.cpu().numpy() - gx)) <= 2e-4 * max(1.0, np.abs(gx).max())
+
+
+def test_conv_residual_and_accumulate(device):
+  """Residual epilogue (dmlab/networks.py:58) and dgrad accumulate-into (skip path)."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(0)
+  n, h, w_, c = 2, 9, 12, 32
+  x = rng.normal(size=(n, h, w_, c)).astype(np.float32)
+  k = (rng.normal(size=(3, 3, c, c)) * 0.05).astype(np.float32)
+  b = rng.normal(size=c).astype(np.float32)
+  res = rng.normal(size=(n, h, w_, c)).astype(np.float32)
+  ref = nets_torch.conv2d(torch.tensor(x), torch.tensor(k), torch.tensor(b), 1, 'same') + torch.tensor(res)
+  g = ops.conv_geom(n, h, w_, c, 3, 3, 1, 'same', c)
+  out = torch.empty((n, h, w_, c), device=device)
+  ops.conv2d_fwd(g, dev(x, device), dev(k, device), dev(b, device), out, residual=dev(res, device))
+  assert np.max(np.abs(out.cpu().numpy() - ref.numpy())) < 2e-4
+  dy = rng.normal(size=(n, h, w_, c)).astype(np.float32)
+  add = rng.normal(size=(n, h, w_, c)).astype(np.float32)
+  xt = torch.tensor(x, requires_grad=True)
+  nets_torch.conv2d(xt, torch.tensor(k), None, 1, 'same').backward(torch.tensor(dy))
+  dx = torch.empty((n, h, w_, c), device=device)
+  ops.conv2d_bwd_data(g, dev(dy, device), dev(k, device), dx, add=dev(add, device))
+  assert np.max(np.abs(dx.cpu().numpy() - (xt.grad.numpy() + add))) < 2e-4
+
+
+@pytest.mark.parametrize('T1,B', [(5, 3), (21, 8)])
+def test_stack_conv_parity(device, T1, B):
+  """Fused stack_frames + /255 + conv1 (u8 frames in, never materialising the fp32
+  stacked tensor) vs oracle stack_frames -> conv2d, forward and weight gradient."""
+  from seed_rl_amd import ops
+  u = synth.atari_unroll(11, T1, B, done_p=0.15, zero_state=False)
+  stacked, _ = frames_np.stack_frames(u['frames'], u['frame_state'], u['done'], 4)
+  rng = np.random.default_rng(0)
+  cout = 16
+  w = (rng.normal(size=(8, 8, 4, cout)) / 16).astype(np.float32)
+  b = rng.normal(size=cout).astype(np.float32)
+  wt = torch.tensor(w, requires_grad=True); bt = torch.tensor(b, requires_grad=True)
+  y = F.relu(nets_torch.conv2d(torch.tensor(stacked / np.float32(255)).reshape(T1 * B, 84, 84, 4), wt, bt, 4, 'valid'))
+  dy = rng.normal(size=y.shape).astype(np.float32)
+  y.backward(torch.tensor(dy))
+  HW = 84 * 84
+  ext = torch.zeros((T1 + 3, B, HW), dtype=torch.uint8, device=device)
+  ext[3:] = dev(u['frames'].reshape(T1, B, HW), device)
+  nv = torch.zeros((T1, B), dtype=torch.uint8, device=device)
+  ops.stack_prepare(dev(u['frame_state'], device), dev(u['done'].astype(np.uint8), device), T1, B, HW, ext, nv)
+  g = ops.StackConvGeom(T1, B, 84, 84, 20, 20, 8, 8, 4, cout, cout)
+  out = torch.empty((T1 * B, 20, 20, cout), device=device)
+  ops.conv2d_stack_fwd(g, ext, nv, dev(w, device), dev(b, device), out, out_relu=True)
+  yr = y.detach().numpy()
+  assert np.max(np.abs(out.cpu().numpy() - yr)) <= 2e-4 * max(1.0, np.abs(yr).max())
+  dz = dev(np.ascontiguousarray(dy * (yr > 0), np.float32), device)
+  dw = torch.empty(w.shape, device=device); db = torch.empty(b.shape, device=device)
+  ws = torch.empty(ops.conv2d_stack_bwd_weight_workspace_bytes(g) // 4 + 1, device=device)
+  ops.conv2d_stack_bwd_weight(g, ext, nv, dz, dw, db, ws)
+  gw = wt.grad.numpy()
+  assert np.max(np.abs(dw.cpu().numpy() - gw)) <= 3e-4 * max(1.0, np.abs(gw).max())
+  assert np.max(np.abs(db.cpu().numpy() - bt.grad.numpy())) <= 3e-4 * max(1.0, np.abs(bt.grad.numpy()).max())
