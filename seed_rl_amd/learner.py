@@ -1,0 +1,137 @@
+"""IMPALA / V-trace learner step on MI355X.
+
+Mirrors /root/reference/agents/vtrace/learner.py on the hot path:
+  * `Unroll`                       learner.py:162-163
+  * loss hyper-parameters          learner.py:51-62 (absl flags -> LossConfig)
+  * `compute_loss(...)`            learner.py:73-159 (same positional signature)
+  * `Learner.minimize(unroll)`     learner.py:255-280 (compute_gradients +
+                                   apply_gradients; the cross-replica gradient SUM the
+                                   Keras optimizer does implicitly on TPU becomes one
+                                   RCCL all-reduce of the flat gradient bucket)
+The control plane of learner_loop (gRPC server, checkpoint manager, logger thread,
+tf.data pipeline; learner.py:170-483) is out of scope.
+"""
+import collections
+
+import torch
+
+from seed_rl_amd import ops
+
+Unroll = collections.namedtuple('Unroll', 'agent_state prev_actions env_outputs agent_outputs')
+
+
+class LossConfig(object):
+  """Flag defaults of agents/vtrace/learner.py:51-62."""
+
+  def __init__(self, entropy_cost=0.00025, target_entropy=None, entropy_cost_adjustment_speed=10.,
+               baseline_cost=.5, kl_cost=0., discounting=.99, lambda_=1., max_abs_reward=0.):
+    self.entropy_cost = entropy_cost
+    self.target_entropy = target_entropy
+    self.entropy_cost_adjustment_speed = entropy_cost_adjustment_speed
+    self.baseline_cost = baseline_cost
+    self.kl_cost = kl_cost
+    self.discounting = discounting
+    self.lambda_ = lambda_
+    self.max_abs_reward = max_abs_reward
+
+
+LOGGED = collections.OrderedDict([      # logger.log names of learner.py:138-157 -> scalars[] index
+    ('V/value function', 7), ('V/L2 error', 8), ('losses/policy', 1), ('losses/V', 2),
+    ('losses/entropy', 3), ('losses/kl', 4), ('losses/total', 0),
+    ('policy/max_action_abs(before_tanh)', 9), ('policy/entropy', 5), ('policy/kl(old|new)', 6)])
+
+
+class DictLogger(object):
+  """Stand-in for utils.ProgressLogger's log_session()/log() (utils.py:546-677)."""
+
+  def log_session(self):
+    return collections.OrderedDict()
+
+  def log(self, session, name, value):
+    session[name] = value
+
+
+def compute_loss(logger, parametric_action_distribution, agent, agent_state, prev_actions, env_outputs,
+                 agent_outputs, config=None, mean_denominator=None, want_vtrace=False):
+  """learner.py:73-159.  Runs the agent unroll and the fused loss head; the head
+  gradient is left in the agent's d_head buffer for `agent.backward()`.
+
+  Returns (total_loss: 0-d device tensor, log_session)."""
+  cfg = config or LossConfig()
+  logger = logger or DictLogger()
+  learner_outputs, _ = agent(prev_actions, env_outputs, agent_state, unroll=True, is_training=True)  # :75-79
+  head, d_head, ldh = agent.head_buffers()
+  T1, B = env_outputs.done.shape[0], env_outputs.done.shape[1]
+  T = T1 - 1
+  A = parametric_action_distribution.param_size
+  dev = head.device
+  beh_logits = agent_outputs.policy_logits.to(torch.float32).contiguous()
+  actions = agent_outputs.action.contiguous()
+  if actions.dtype not in (torch.int32, torch.int64):
+    actions = actions.to(torch.int64)
+  rewards = env_outputs.reward.to(torch.float32).contiguous()
+  done_u8 = env_outputs.done.to(torch.uint8).contiguous()
+  scalars = agent._buf('loss_scalars', (16,))
+  ws = agent._buf('loss_ws', (ops.impala_loss_workspace_bytes(T, B) // 4 + 4,))
+  vs = agent._buf('vs', (T, B)) if want_vtrace else None
+  pg = agent._buf('pg', (T, B)) if want_vtrace else None
+  entropy_cost = float(agent.entropy_cost())
+  flat_head = head.view(-1)
+  flat_dhead = d_head.view(-1)
+  ops.impala_loss_fwd_bwd(
+      flat_head, ldh, flat_head[A:], ldh, beh_logits, actions, rewards, done_u8, T, B, A,
+      flat_dhead, flat_dhead[A:], scalars, ws, vs, pg,
+      entropy_cost=entropy_cost, baseline_cost=cfg.baseline_cost, kl_cost=cfg.kl_cost,
+      discounting=cfg.discounting, lambda_=cfg.lambda_, max_abs_reward=cfg.max_abs_reward,
+      mean_denominator=mean_denominator)
+  session = logger.log_session()
+  for name, idx in LOGGED.items():
+    logger.log(session, name, scalars[idx])
+  logger.log(session, 'policy/entropy_cost', entropy_cost)
+  if want_vtrace:
+    session['vtrace/vs'] = vs
+    session['vtrace/pg_advantages'] = pg
+  return scalars[0], session
+
+
+class Learner(object):
+  """One data-parallel learner replica: minimize(unroll) = forward + loss + backward +
+  gradient all-reduce + Adam (learner.py:255-280)."""
+
+  def __init__(self, agent, optimizer, parametric_action_distribution, config=None,
+               reduction='mean', process_group=None, logger=None):
+    """reduction: 'mean' -> the summed gradient equals a single-replica step at the
+    global batch (what matches the reference CPU learner on identical trajectories);
+    'sum' -> the reference's multi-replica semantics: per-replica mean losses, gradients
+    SUMMED across replicas (tests/utils_test.py:609-650)."""
+    assert reduction in ('mean', 'sum')
+    self.agent, self.optimizer = agent, optimizer
+    self.dist = parametric_action_distribution
+    self.config = config or LossConfig()
+    self.reduction = reduction
+    self.pg = process_group
+    self.logger = logger or DictLogger()
+    self.world = 1
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+      self.world = torch.distributed.get_world_size(process_group)
+
+  def compute_gradients(self, unroll):
+    T1, B = unroll.env_outputs.done.shape[0], unroll.env_outputs.done.shape[1]
+    n = (T1 - 1) * B * (self.world if self.reduction == 'mean' else 1)
+    loss, session = compute_loss(self.logger, self.dist, self.agent, *unroll, config=self.config,
+                                 mean_denominator=n)
+    self.agent.backward()
+    return loss, session
+
+  def apply_gradients(self):
+    if self.world > 1:
+      torch.distributed.all_reduce(self.agent.flat.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+    self.optimizer.apply_gradients(self.agent.flat)
+
+  def minimize(self, unroll):
+    loss, session = self.compute_gradients(unroll)
+    self.apply_gradients()
+    cb = getattr(self.agent, 'end_of_training_step_callback', None)   # learner.py:277-278
+    if cb is not None:
+      cb()
+    return loss, session

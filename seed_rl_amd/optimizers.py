@@ -1,0 +1,53 @@
+"""Optimizer for the flat parameter buffer.
+
+Mirrors what `create_optimizer_fn` returns in the reference
+(/root/reference/dmlab/vtrace_main.py:46-51): Keras `Adam` driven by a
+`PolynomialDecay` schedule; the update is ONE fused HIP kernel over the flat
+buffer (csrc/adam.hip) instead of one Keras update per variable
+(agents/vtrace/learner.py:272-275).
+"""
+import math
+
+import torch
+
+from seed_rl_amd import ops
+
+
+class PolynomialDecay(object):
+  """tf.keras.optimizers.schedules.PolynomialDecay (power, end_learning_rate)."""
+
+  def __init__(self, initial_learning_rate, decay_steps, end_learning_rate=0.0, power=1.0):
+    self.lr0, self.steps, self.end, self.power = initial_learning_rate, decay_steps, end_learning_rate, power
+
+  def __call__(self, step):
+    s = min(step, self.steps)
+    return (self.lr0 - self.end) * (1 - s / self.steps) ** self.power + self.end
+
+
+class Adam(object):
+  """tf.keras.optimizers.Adam semantics on a FlatParams."""
+
+  def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+    self.learning_rate = learning_rate
+    self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
+    self.iterations = 0
+    self._m = self._v = None
+
+  def _lr(self):
+    return self.learning_rate(self.iterations) if callable(self.learning_rate) else self.learning_rate
+
+  def apply_gradients(self, flat, grad_scale=1.0):
+    if self._m is None:
+      self._m = torch.zeros_like(flat.params)
+      self._v = torch.zeros_like(flat.params)
+    t = self.iterations + 1
+    lr_t = self._lr() * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+    ops.adam_flat(flat.params, flat.grads, self._m, self._v, float(lr_t), self.beta_1, self.beta_2,
+                  self.epsilon, float(grad_scale))
+    self.iterations = t
+
+  def state_dict(self):
+    return dict(iterations=self.iterations, m=self._m, v=self._v)
+
+  def load_state_dict(self, sd):
+    self.iterations, self._m, self._v = sd['iterations'], sd['m'], sd['v']

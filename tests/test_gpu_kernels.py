@@ -33,10 +33,16 @@ def test_vtrace_cfg1_parity(device, seed, kw):
     inp = synth.vtrace_inputs(seed, 20, 32, 6, stress=stress)
     vs, pg = _run_vtrace(device, inp, **kw)
     ref = vtrace_np.from_importance_weights(**inp, **kw)
-    assert np.max(np.abs(vs - ref.vs)) <= 1e-5
-    assert np.max(np.abs(pg - ref.pg_advantages)) <= 1e-5
+    # 1e-5 absolute is the north_star bar for the learner's setting (rho clipped).  With
+    # clipping disabled and |log rho| up to 2.5 the outputs reach ~1e3, where one fp32 ulp
+    # already exceeds 1e-5: that case is held to 4 ulp of the output scale instead.
+    unclipped = kw.get('clip_rho_threshold', 1.0) is None
+    tol_vs = 4 * np.spacing(np.float32(np.abs(ref.vs).max())) if unclipped else 1e-5
+    tol_pg = 4 * np.spacing(np.float32(np.abs(ref.pg_advantages).max())) if unclipped else 1e-5
+    assert np.max(np.abs(vs - ref.vs)) <= max(tol_vs, 1e-5)
+    assert np.max(np.abs(pg - ref.pg_advantages)) <= max(tol_pg, 1e-5)
     ref64 = vtrace_np.from_importance_weights(**inp, **kw, dtype=np.float64)
-    assert np.max(np.abs(vs - ref64.vs)) <= 1e-4       # fp32 rounding distance to fp64 truth
+    assert np.max(np.abs(vs - ref64.vs)) <= 1e-4 * max(1.0, np.abs(ref64.vs).max() / 50)  # fp32 distance to fp64
 
 
 def test_vtrace_reference_golden(device):
