@@ -7,6 +7,11 @@ symbol is absent this module raises at import/use.
 import ctypes
 import os
 
+# torch MUST be imported before libseedhip.so is loaded: torch ships its own
+# libamdhip64 and the kernels share torch's HIP runtime (streams, device pointers).
+# Loading ours first would bind it to a second, separate runtime.
+import torch  # noqa: F401  pylint: disable=unused-import
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libseedhip.so')
 
@@ -93,7 +98,6 @@ def ptr(t):
 
 def stream():
   """The current torch HIP stream as a hipStream_t (void*)."""
-  import torch
   return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
