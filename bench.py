@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py -- learner env-frames/s (T=20) of the MI355X-native SEED-RL learner step.
+
+Workload (BASELINE.json configs[1]): Atari 84x84x4 IMPALA shallow ConvNet, T=20, B=512
+per GPU, synthetic uint8 frames resident in HBM, fp32 everywhere (the reference never
+uses mixed precision).  One "step" = Learner.minimize(unroll): frame stacking -> conv
+torso -> heads -> fused V-trace/loss head -> full backward -> (N>1: RCCL all-reduce of
+the flat gradient bucket) -> fused Adam.  env-frames/s = N*B*T*num_action_repeats/step
+with num_action_repeats=1 (common/common_flags.py:43; learner.py:236-237).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA dense peak (v_mfma_f32_16x16x4_f32)
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--batch', type=int, default=512, help='per-GPU batch columns B')
+  ap.add_argument('--unroll', type=int, default=20, help='T')
+  ap.add_argument('--actions', type=int, default=18)
+  ap.add_argument('--torso', default='shallow', choices=['shallow', 'dqn'])
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cpu-batch', type=int, default=64)
+  ap.add_argument('--reduction', default='mean', choices=['mean', 'sum'])
+  return ap.parse_args()
+
+
+def vtrace_checks(dev):
+  """V-trace fp32 max-abs-err vs the oracle on configs[0] + HBM roofline of the scan."""
+  from oracle import vtrace_np
+  from seed_rl_amd import vtrace
+  from tests import synth
+  err = 0.0
+  for seed in (0, 1, 2):
+    inp = synth.vtrace_inputs(seed, 20, 32, 6)
+    out = vtrace.from_importance_weights(**{k: torch.as_tensor(v).to(dev) for k, v in inp.items()})
+    ref = vtrace_np.from_importance_weights(**inp)
+    err = max(err, float(np.max(np.abs(out.vs.cpu().numpy() - ref.vs))),
+              float(np.max(np.abs(out.pg_advantages.cpu().numpy() - ref.pg_advantages))))
+  sweep = []
+  for B in (512, 1 << 14, 1 << 17, 1 << 20, 1 << 22):
+    T = 20
+    t = [torch.rand((T, B), device=dev) for _ in range(5)]
+    boot = torch.rand(B, device=dev)
+    for _ in range(3):
+      vtrace.from_importance_weights(t[0], t[1], t[2], t[3], t[4], boot)
+    reps = 20
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    from seed_rl_amd import _lib
+    vs, pg = torch.empty_like(t[0]), torch.empty_like(t[0])
+    s.record()
+    for _ in range(reps):
+      _lib.lib().seedhip_vtrace_from_importance_weights(
+          _lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(t[2]), _lib.ptr(t[3]), _lib.ptr(t[4]), _lib.ptr(boot),
+          1.0, 1.0, 1.0, T, B, _lib.ptr(vs), _lib.ptr(pg), _lib.stream())
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / reps
+    nbytes = T * B * 28 + B * 4
+    sweep.append(dict(B=B, us=round(us, 2), GBs=round(nbytes / us / 1e3, 1),
+                      frac_hbm=round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)))
+  return err, sweep
+
+
+def main():
+  args = parse()
+  rank = int(os.environ.get('RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the HIP path)'
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    torch.distributed.init_process_group('nccl', device_id=dev)
+  assert world == args.gpus or world == 1, 'launch with torchrun for --gpus > 1'
+
+  from seed_rl_amd import learner, networks, ops, optimizers, parametric_distribution as pd, smoke_step
+  T, B, A = args.unroll, args.batch, args.actions
+  T1 = T + 1
+  agent = networks.AtariShallow(A, torso=args.torso, device=dev, seed=0)      # identical params on all ranks
+  final_iteration = 10 ** 9 // (T * B * max(world, 1))
+  opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, final_iteration), beta_1=0.0, epsilon=3.125e-7)
+  lrn = learner.Learner(agent, opt, pd.categorical_distribution(A), reduction=args.reduction)
+  unroll = smoke_step.make_unroll(agent, T1, B, A, dev, seed=1000 + rank)
+  # place the frames directly in the agent's extended trajectory buffer (no per-step copy)
+  ext = agent.frames_buffer(T1, B)
+  ext[3:].copy_(unroll.env_outputs.observation.reshape(T1, B, -1))
+  unroll = unroll._replace(env_outputs=unroll.env_outputs._replace(
+      observation=ext[3:].view(T1, B, agent._obs[0], agent._obs[1], 1)))
+
+  def barrier():
+    if world > 1:
+      torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+  # ---- warmup (+ per-kernel profile pass to find the dominant kernel) ----
+  for _ in range(max(args.warmup - 1, 0)):
+    lrn.minimize(unroll)
+  prof_all = ops.Profiler()
+  ops.set_profiler(prof_all)
+  lrn.minimize(unroll)
+  ops.set_profiler(None)
+  kern = prof_all.summary()
+  dominant = max(kern, key=lambda k: kern[k]['total_ms'])
+  if args.warmup == 0:
+    dominant = 'stack_conv_fwd'
+
+  # ---- timed region: exactly K steps, barrier + sync on both sides ----
+  prof = ops.Profiler(only=[dominant])
+  ops.set_profiler(prof)
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    loss, _ = lrn.minimize(unroll)
+  barrier()
+  dt = time.perf_counter() - t0
+  ops.set_profiler(None)
+  if world > 1:
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tt[0])
+  loss_val = float(loss)
+  assert np.isfinite(loss_val)
+
+  ms_per_step = dt / args.steps * 1e3
+  frames_per_s = world * B * T / (dt / args.steps)
+  d = prof.summary()[dominant]
+  flops, nbytes = d['flops'], d['bytes']
+  if flops > 0:
+    ach = flops / (d['avg_ms'] * 1e-3) / 1e12
+    roofline = dict(bound='mfma', kernel=dominant, achieved=round(ach, 2), peak=MFMA_F32_PEAK_TF,
+                    unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TF, 4), traffic=None,
+                    avg_kernel_ms=round(d['avg_ms'], 4), algorithmic_flops=flops, algorithmic_bytes=nbytes)
+  else:
+    ach = nbytes / (d['avg_ms'] * 1e-3) / 1e9
+    roofline = dict(bound='hbm', kernel=dominant, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, avg_kernel_ms=round(d['avg_ms'], 4),
+                    algorithmic_bytes=nbytes)
+
+  if rank != 0:
+    return
+  result = {
+      'metric': 'learner env-frames/s (T=20)', 'value': round(frames_per_s, 1), 'unit': 'env-frames/s',
+      'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'config': {'workload': 'Atari 84x84x4 IMPALA %s ConvNet learner step, T=%d B=%d/GPU A=%d, '
+                             'synthetic uint8 frames in HBM, num_action_repeats=1' % (args.torso, T, B, A),
+                 'global_batch': B * world, 'unroll_length': T, 'parallelism': 'dp%d' % world,
+                 'grad_reduction': args.reduction, 'params': agent.flat.num_params()},
+      'roofline': roofline,
+      'loss': round(loss_val, 6),
+      'kernels_ms_per_step': {k: round(v['total_ms'], 4) for k, v in kern.items()},
+  }
+  if world == 1:
+    err, sweep = vtrace_checks(dev)
+    result['vtrace_max_abs_err'] = err
+    result['vtrace_scan_hbm'] = sweep
+    if not args.no_cpu_baseline:
+      from oracle import cpu_learner
+      kind = 'atari_shallow' if args.torso == 'shallow' else 'atari_dqn_body'
+      fps, sec, thr = cpu_learner.time_cpu_learner(kind, A, T1, args.cpu_batch, steps=3, warmup=1)
+      result['cpu_baseline'] = {
+          'value': round(fps, 1), 'unit': 'env-frames/s', 'cores': thr, 'kind': 'port',
+          'sample': 'same learner step as eager PyTorch-CPU fp32 restatement of the reference graph '
+                    '(oracle/cpu_learner.py), T=%d B=%d (per-frame cost is B-independent), median of 3 '
+                    'steps, %.2f s/step; host cpu_count=%d' % (T, args.cpu_batch, sec, os.cpu_count())}
+      result['speedup_vs_cpu_baseline'] = round(frames_per_s / fps, 1)
+  print(json.dumps(result))
+  if world > 1:
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,55 @@
+"""Eager PyTorch-CPU fp32 learner step: restatement of the reference learner's
+compute_gradients + apply_gradients (/root/reference/agents/vtrace/learner.py:255-280)
+for the Atari configs (oracle; also the `cpu_baseline` "port" leg of bench.py).
+
+Same graph as the reference would run (frame stacking -> /255 -> conv torso ->
+heads -> unfused loss ops -> per-variable Keras Adam), torch autograd standing in for
+tf.GradientTape.  NOT TensorFlow (not installable here): labelled "port".
+"""
+import time
+
+import numpy as np
+import torch
+
+from oracle import nets_torch
+
+
+class CpuAtariLearner(object):
+
+  def __init__(self, kind, num_actions, seed=0, lr=4.8e-4, decay_steps=10000):
+    self.kind, self.A = kind, num_actions
+    self.params = nets_torch.to_torch(
+        nets_torch.init_params(nets_torch.param_spec(kind, num_actions), seed), requires_grad=True)
+    self.opt = nets_torch.KerasAdam(list(self.params.values()), nets_torch.polynomial_decay(lr, decay_steps),
+                                    beta_1=0.0, epsilon=3.125e-7)
+
+  def step(self, u, **loss_kw):
+    for p in self.params.values():
+      p.grad = None
+    logits, baseline, new_fs, _ = nets_torch.atari_shallow_unroll(
+        self.params, self.kind, self.A, u['prev_actions'], u['reward'], u['done'], u['frames'],
+        u['frame_state'])
+    total, aux = nets_torch.impala_loss_torch(logits, baseline, u['behaviour_logits'], u['actions'],
+                                              u['reward'], u['done'], **loss_kw)
+    total.backward()
+    self.opt.apply_gradients([p.grad for p in self.params.values()])
+    return float(total.detach())
+
+
+def time_cpu_learner(kind, num_actions, T1, B, steps=3, warmup=1, threads=None, seed=0):
+  """Returns (env_frames_per_s, seconds_per_step, threads)."""
+  from tests import synth
+  if threads:
+    torch.set_num_threads(threads)
+  u = synth.atari_unroll(seed, T1, B, num_actions)
+  u = {k: torch.as_tensor(v) for k, v in u.items()}
+  lrn = CpuAtariLearner(kind, num_actions, seed)
+  for _ in range(warmup):
+    lrn.step(u)
+  ts = []
+  for _ in range(steps):
+    t0 = time.perf_counter()
+    lrn.step(u)
+    ts.append(time.perf_counter() - t0)
+  sec = float(np.median(ts))
+  return (T1 - 1) * B / sec, sec, torch.get_num_threads()

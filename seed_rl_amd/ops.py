@@ -1,4 +1,6 @@
 """Thin torch-tensor wrappers over the C ABI (pointers + sizes only cross it)."""
+import collections
+import contextlib
 import ctypes
 
 import torch
@@ -7,6 +9,62 @@ from seed_rl_amd import _lib
 from seed_rl_amd._lib import ConvGeom, StackConvGeom
 
 IN_F32, IN_U8_DIV255 = 0, 1
+
+
+# --------------------------------------------------------------------------- #
+# Optional per-kernel timing with HIP events on the launch stream (bench.py).
+# --------------------------------------------------------------------------- #
+class Profiler(object):
+  """Records (start, end) HIP events around C-ABI calls on torch's current stream.
+  `only`: restrict to a set of region names (cheap enough for the timed region)."""
+
+  def __init__(self, only=None):
+    self.only = set(only) if only is not None else None
+    self.events = collections.OrderedDict()
+    self.meta = {}
+
+  def summary(self):
+    torch.cuda.synchronize()
+    out = collections.OrderedDict()
+    for name, evs in self.events.items():
+      ms = [s.elapsed_time(e) for s, e in evs]
+      flops, nbytes = self.meta[name]
+      out[name] = dict(calls=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms), flops=flops, bytes=nbytes)
+    return out
+
+
+_PROFILER = None
+
+
+def set_profiler(p):
+  global _PROFILER
+  _PROFILER = p
+
+
+@contextlib.contextmanager
+def _region(name, flops=0, nbytes=0):
+  p = _PROFILER
+  if p is None or (p.only is not None and name not in p.only):
+    yield
+    return
+  s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  s.record()
+  yield
+  e.record()
+  p.events.setdefault(name, []).append((s, e))
+  p.meta[name] = (flops, nbytes)
+
+
+def _conv_name(kind, g):
+  return '%s[%dx%d/%d %d->%d @%dx%d]' % (kind, g.kh, g.kw, g.stride, g.cin, g.cout, g.ih, g.iw)
+
+
+def _conv_cost(g, in_bytes_per_el=4):
+  """Algorithmic flops and bytes of one conv/dense op."""
+  flops = 2.0 * g.n_img * g.oh * g.ow * g.cout * g.kh * g.kw * g.cin
+  nbytes = (g.n_img * g.ih * g.iw * g.cin * in_bytes_per_el + g.kh * g.kw * g.cin * g.cout * 4 +
+            g.n_img * g.oh * g.ow * g.cout * 4)
+  return flops, nbytes
 
 
 def conv_geom(n_img, ih, iw, cin, kh, kw, stride, padding, cout, ld_in=None, ld_out=None):
@@ -32,19 +90,21 @@ def _dev(t):
 
 
 def conv2d_fwd(g, x, w, bias, out, in_dtype=IN_F32, in_relu=False, out_relu=False, residual=None):
-  with _dev(out):
-    _lib.check(_lib.lib().seedhip_conv2d_fwd(
-        ctypes.byref(g), _lib.ptr(x), in_dtype, int(in_relu), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out),
-        int(out_relu), _lib.ptr(residual), _lib.stream()), 'seedhip_conv2d_fwd')
-  return out
+  with _region(_conv_name('conv_fwd', g), *_conv_cost(g, 1 if in_dtype else 4)):
+    with _dev(out):
+      _lib.check(_lib.lib().seedhip_conv2d_fwd(
+          ctypes.byref(g), _lib.ptr(x), in_dtype, int(in_relu), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out),
+          int(out_relu), _lib.ptr(residual), _lib.stream()), 'seedhip_conv2d_fwd')
+    return out
 
 
 def conv2d_bwd_data(g, dy, w, dx, relu_mask=None, add=None):
-  with _dev(dx):
-    _lib.check(_lib.lib().seedhip_conv2d_bwd_data(
-        ctypes.byref(g), _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(relu_mask), _lib.ptr(add),
-        _lib.stream()), 'seedhip_conv2d_bwd_data')
-  return dx
+  with _region(_conv_name('conv_dgrad', g), *_conv_cost(g)):
+    with _dev(dx):
+      _lib.check(_lib.lib().seedhip_conv2d_bwd_data(
+          ctypes.byref(g), _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(relu_mask), _lib.ptr(add),
+          _lib.stream()), 'seedhip_conv2d_bwd_data')
+    return dx
 
 
 def conv2d_bwd_weight_workspace_bytes(g):
@@ -52,18 +112,20 @@ def conv2d_bwd_weight_workspace_bytes(g):
 
 
 def conv2d_bwd_weight(g, x, dy, dw, dbias, workspace, in_dtype=IN_F32, in_relu=False):
-  with _dev(dw):
-    _lib.check(_lib.lib().seedhip_conv2d_bwd_weight(
-        ctypes.byref(g), _lib.ptr(x), in_dtype, int(in_relu), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(dbias),
-        _lib.ptr(workspace), workspace.numel() * workspace.element_size(), _lib.stream()),
-        'seedhip_conv2d_bwd_weight')
+  with _region(_conv_name('conv_wgrad', g), *_conv_cost(g, 1 if in_dtype else 4)):
+    with _dev(dw):
+      _lib.check(_lib.lib().seedhip_conv2d_bwd_weight(
+          ctypes.byref(g), _lib.ptr(x), in_dtype, int(in_relu), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(dbias),
+          _lib.ptr(workspace), workspace.numel() * workspace.element_size(), _lib.stream()),
+          'seedhip_conv2d_bwd_weight')
 
 
 def stack_prepare(state, done_u8, T, B, HW, frames_ext, nvalid):
-  with _dev(frames_ext):
-    _lib.check(_lib.lib().seedhip_stack_prepare(
-        _lib.ptr(state), _lib.ptr(done_u8), T, B, HW, _lib.ptr(frames_ext), _lib.ptr(nvalid), _lib.stream()),
-        'seedhip_stack_prepare')
+  with _region('stack_prepare', 0, B * HW * 7):
+    with _dev(frames_ext):
+      _lib.check(_lib.lib().seedhip_stack_prepare(
+          _lib.ptr(state), _lib.ptr(done_u8), T, B, HW, _lib.ptr(frames_ext), _lib.ptr(nvalid), _lib.stream()),
+          'seedhip_stack_prepare')
 
 
 def stack_frames_f32(frames_ext, nvalid, T, B, HW, out):
@@ -74,17 +136,19 @@ def stack_frames_f32(frames_ext, nvalid, T, B, HW, out):
 
 
 def stack_pack_state(frames_ext, nvalid, T, B, HW, new_state):
-  with _dev(new_state):
-    _lib.check(_lib.lib().seedhip_stack_pack_state(
-        _lib.ptr(frames_ext), _lib.ptr(nvalid), T, B, HW, _lib.ptr(new_state), _lib.stream()),
-        'seedhip_stack_pack_state')
+  with _region('stack_pack_state', 0, B * HW * 7):
+    with _dev(new_state):
+      _lib.check(_lib.lib().seedhip_stack_pack_state(
+          _lib.ptr(frames_ext), _lib.ptr(nvalid), T, B, HW, _lib.ptr(new_state), _lib.stream()),
+          'seedhip_stack_pack_state')
 
 
 def conv2d_stack_fwd(g, frames_ext, nvalid, w, bias, out, out_relu=True):
-  with _dev(out):
-    _lib.check(_lib.lib().seedhip_conv2d_stack_fwd(
-        ctypes.byref(g), _lib.ptr(frames_ext), _lib.ptr(nvalid), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out),
-        int(out_relu), _lib.stream()), 'seedhip_conv2d_stack_fwd')
+  with _region('stack_conv_fwd', 2.0 * g.T * g.B * g.oh * g.ow * g.cout * g.kh * g.kw * 4, g.T * g.B * g.ih * g.iw + g.T * g.B * g.oh * g.ow * g.cout * 4):
+    with _dev(out):
+      _lib.check(_lib.lib().seedhip_conv2d_stack_fwd(
+          ctypes.byref(g), _lib.ptr(frames_ext), _lib.ptr(nvalid), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out),
+          int(out_relu), _lib.stream()), 'seedhip_conv2d_stack_fwd')
 
 
 def conv2d_stack_bwd_weight_workspace_bytes(g):
@@ -92,11 +156,12 @@ def conv2d_stack_bwd_weight_workspace_bytes(g):
 
 
 def conv2d_stack_bwd_weight(g, frames_ext, nvalid, dy, dw, dbias, workspace):
-  with _dev(dw):
-    _lib.check(_lib.lib().seedhip_conv2d_stack_bwd_weight(
-        ctypes.byref(g), _lib.ptr(frames_ext), _lib.ptr(nvalid), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(dbias),
-        _lib.ptr(workspace), workspace.numel() * workspace.element_size(), _lib.stream()),
-        'seedhip_conv2d_stack_bwd_weight')
+  with _region('stack_conv_wgrad', 2.0 * g.T * g.B * g.oh * g.ow * g.cout * g.kh * g.kw * 4, g.T * g.B * g.ih * g.iw + g.T * g.B * g.oh * g.ow * g.cout * 4):
+    with _dev(dw):
+      _lib.check(_lib.lib().seedhip_conv2d_stack_bwd_weight(
+          ctypes.byref(g), _lib.ptr(frames_ext), _lib.ptr(nvalid), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(dbias),
+          _lib.ptr(workspace), workspace.numel() * workspace.element_size(), _lib.stream()),
+          'seedhip_conv2d_stack_bwd_weight')
 
 
 def impala_loss_workspace_bytes(T, B):
@@ -109,21 +174,23 @@ def impala_loss_fwd_bwd(logits, logits_ld, baseline, baseline_ld, beh_logits, ac
                         lambda_=1.0, max_abs_reward=0.0, clip_rho=1.0, clip_pg_rho=1.0,
                         mean_denominator=None):
   n = float(T * B if mean_denominator is None else mean_denominator)
-  with _dev(scalars):
-    _lib.check(_lib.lib().seedhip_impala_loss_fwd_bwd(
-        _lib.ptr(logits), logits_ld, _lib.ptr(baseline), baseline_ld, _lib.ptr(beh_logits), _lib.ptr(actions),
-        actions.element_size(), _lib.ptr(rewards), _lib.ptr(done_u8), T, B, A,
-        entropy_cost, baseline_cost, kl_cost, discounting, lambda_, max_abs_reward, clip_rho, clip_pg_rho,
-        n, _lib.ptr(d_logits), _lib.ptr(d_baseline), _lib.ptr(vs), _lib.ptr(pg), _lib.ptr(scalars),
-        _lib.ptr(workspace), workspace.numel() * workspace.element_size(), _lib.stream()),
-        'seedhip_impala_loss_fwd_bwd')
+  with _region('impala_loss', 0, T * B * (12 * A + 29)):
+    with _dev(scalars):
+      _lib.check(_lib.lib().seedhip_impala_loss_fwd_bwd(
+          _lib.ptr(logits), logits_ld, _lib.ptr(baseline), baseline_ld, _lib.ptr(beh_logits), _lib.ptr(actions),
+          actions.element_size(), _lib.ptr(rewards), _lib.ptr(done_u8), T, B, A,
+          entropy_cost, baseline_cost, kl_cost, discounting, lambda_, max_abs_reward, clip_rho, clip_pg_rho,
+          n, _lib.ptr(d_logits), _lib.ptr(d_baseline), _lib.ptr(vs), _lib.ptr(pg), _lib.ptr(scalars),
+          _lib.ptr(workspace), workspace.numel() * workspace.element_size(), _lib.stream()),
+          'seedhip_impala_loss_fwd_bwd')
 
 
 def adam_flat(params, grads, m, v, lr_t, beta_1, beta_2, epsilon, grad_scale=1.0):
-  with _dev(params):
-    _lib.check(_lib.lib().seedhip_adam_flat(
-        _lib.ptr(params), _lib.ptr(grads), _lib.ptr(m), _lib.ptr(v), params.numel(), lr_t, beta_1, beta_2,
-        epsilon, grad_scale, _lib.stream()), 'seedhip_adam_flat')
+  with _region('adam_flat', 0, params.numel() * 28):
+    with _dev(params):
+      _lib.check(_lib.lib().seedhip_adam_flat(
+          _lib.ptr(params), _lib.ptr(grads), _lib.ptr(m), _lib.ptr(v), params.numel(), lr_t, beta_1, beta_2,
+          epsilon, grad_scale, _lib.stream()), 'seedhip_adam_flat')
 
 
 def global_norm_workspace_bytes():
