@@ -2,36 +2,12 @@
 // on the fp32-MFMA implicit-GEMM core (igemm.h + conv_problems.h).
 #include "common.h"
 #include "conv_problems.h"
+#include "conv_launch.h"
 #include "../../include/seedhip.h"
 
 using namespace seedhip;
 
 namespace {
-
-// out[i] = sum_z partial[z][i]  (fixed order => deterministic), float4 vectorised.
-__global__ void __launch_bounds__(256)
-reduce_slices_kernel(const float* __restrict__ partial, int slices, long long n, float* __restrict__ out) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  const long long n4 = n >> 2;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float4 a = reinterpret_cast<const float4*>(partial)[i];
-    for (int z = 1; z < slices; ++z) {
-      const float4 b = reinterpret_cast<const float4*>(partial + (long long)z * n)[i];
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
-    reinterpret_cast<float4*>(out)[i] = a;
-  }
-  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    float a = partial[i];
-    for (int z = 1; z < slices; ++z) a += partial[(long long)z * n + i];
-    out[i] = a;
-  }
-}
-
-void reduce_slices(const float* partial, int slices, long long n, float* out, hipStream_t s) {
-  int blocks = cdiv(n / 4 + 1, 256); if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(reduce_slices_kernel, dim3(blocks), dim3(256), 0, s, partial, slices, n, out);
-}
 
 ConvGeom to_geom(const seedhip_conv_geom* g) {
   ConvGeom c;
@@ -52,23 +28,6 @@ int check_geom(const seedhip_conv_geom* g, const char* what) {
   SEEDHIP_REQUIRE((g->oh - 1) * g->stride - g->pad_t < g->ih && (g->ow - 1) * g->stride - g->pad_l < g->iw,
                   "%s: output extent does not fit the padded input", what);
   return SEEDHIP_OK;
-}
-
-// pixels per split-K slice for weight gradients: enough slices to fill the chip,
-// few enough that the partial-sum traffic stays small.
-int pick_k_per_slice(long long pixels, long long tiles_mn) {
-  long long want_slices = (1024 + tiles_mn - 1) / tiles_mn;     // ~4 workgroups per CU
-  if (want_slices < 1) want_slices = 1;
-  if (want_slices > 256) want_slices = 256;
-  long long per = (pixels + want_slices - 1) / want_slices;
-  per = ((per + 63) / 64) * 64;
-  if (per < 256) per = 256;
-  return (int)per;
-}
-long long tiles_for(int M, int N) {
-  int bm, bn;
-  if (N <= 16) { bm = 256; bn = 16; } else if (N <= 32) { bm = 128; bn = 32; } else if (N <= 48) { bm = 128; bn = 48; } else { bm = 128; bn = 64; }
-  return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
 }
 
 }  // namespace
@@ -130,64 +89,3 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
   return check_launch("conv2d_bwd_weight");
 }
 
-// ---- frame-stacked first conv (Atari) ------------------------------------- //
-namespace {
-int check_stack(const seedhip_stack_conv_geom* g, const char* what) {
-  SEEDHIP_REQUIRE(g, "%s: null geometry", what);
-  SEEDHIP_REQUIRE(g->T >= 1 && g->B >= 1 && g->ih >= 1 && g->iw >= 1 && g->kh >= 1 && g->kw >= 1 && g->stride >= 1 &&
-                  g->cout >= 1, "%s: non-positive geometry field", what);
-  SEEDHIP_REQUIRE(g->oh == (g->ih - g->kh) / g->stride + 1 && g->ow == (g->iw - g->kw) / g->stride + 1,
-                  "%s: oh/ow must be the VALID-padding output size", what);
-  SEEDHIP_REQUIRE(g->ld_out >= g->cout, "%s: ld_out < cout", what);
-  SEEDHIP_REQUIRE((long long)g->T * g->B * g->oh * g->ow < (1LL << 31), "%s: more than 2^31 pixels", what);
-  return SEEDHIP_OK;
-}
-StackGeom to_stack(const seedhip_stack_conv_geom* g) {
-  StackGeom s; s.T = g->T; s.B = g->B; s.ih = g->ih; s.iw = g->iw; s.oh = g->oh; s.ow = g->ow; s.kh = g->kh;
-  s.kw = g->kw; s.stride = g->stride; s.cout = g->cout; s.ld_out = g->ld_out;
-  return s;
-}
-}  // namespace
-
-extern "C" int seedhip_conv2d_stack_fwd(const seedhip_stack_conv_geom* geom, const uint8_t* frames_ext,
-                                        const uint8_t* nvalid, const float* w, const float* bias, float* out,
-                                        int out_relu, void* stream) {
-  int rc = check_stack(geom, "conv2d_stack_fwd"); if (rc) return rc;
-  SEEDHIP_REQUIRE(frames_ext && nvalid && w && out, "conv2d_stack_fwd: null pointer");
-  ConvStackFwd p;
-  p.frames_ext = frames_ext; p.nvalid = nvalid; p.w = w; p.bias = bias; p.out = out; p.out_relu = out_relu;
-  p.init(to_stack(geom));
-  launch_igemm_auto(p, 1, (hipStream_t)stream);
-  return check_launch("conv2d_stack_fwd");
-}
-
-extern "C" size_t seedhip_conv2d_stack_bwd_weight_workspace_bytes(const seedhip_stack_conv_geom* g) {
-  if (!g) return 0;
-  const int M = 4 * g->kh * g->kw, N = g->cout;
-  const long long pixels = (long long)g->T * g->B * g->oh * g->ow;
-  const int per = pick_k_per_slice(pixels, tiles_for(M, N));
-  const long long slices = (pixels + per - 1) / per;
-  return (size_t)slices * ((size_t)M * N + N) * sizeof(float);
-}
-
-extern "C" int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* geom, const uint8_t* frames_ext,
-                                               const uint8_t* nvalid, const float* dy, float* dw, float* dbias,
-                                               void* workspace, size_t workspace_bytes, void* stream) {
-  int rc = check_stack(geom, "conv2d_stack_bwd_weight"); if (rc) return rc;
-  SEEDHIP_REQUIRE(frames_ext && nvalid && dy && dw && workspace, "conv2d_stack_bwd_weight: null pointer");
-  SEEDHIP_REQUIRE(workspace_bytes >= seedhip_conv2d_stack_bwd_weight_workspace_bytes(geom),
-                  "conv2d_stack_bwd_weight: workspace too small");
-  ConvStackWgrad p;
-  p.frames_ext = frames_ext; p.nvalid = nvalid; p.dy = dy;
-  const int M = 4 * geom->kh * geom->kw, N = geom->cout;
-  const long long pixels = (long long)geom->T * geom->B * geom->oh * geom->ow;
-  p.init(to_stack(geom), pick_k_per_slice(pixels, tiles_for(M, N)));
-  const int slices = p.slices();
-  p.partial_w = (float*)workspace;
-  p.partial_b = dbias ? (float*)workspace + (size_t)slices * M * N : nullptr;
-  hipStream_t s = (hipStream_t)stream;
-  launch_igemm_auto(p, slices, s);
-  reduce_slices(p.partial_w, slices, (long long)M * N, dw, s);
-  if (dbias) reduce_slices(p.partial_b, slices, N, dbias, s);
-  return check_launch("conv2d_stack_bwd_weight");
-}

@@ -1,0 +1,468 @@
+// First Atari conv (8x8 stride 4, VALID) fused with learner-side frame stacking
+// and the /255 normalisation: forward and weight gradient, specialised for CDNA4.
+//
+// Replaces /root/reference/atari/networks.py:57-173 (stack_frames) + :330 (/255) +
+// the first Conv2D of the torso (:234; IMPALA-paper shallow torso: Conv 8x8/4 x16) and
+// the TF autodiff of that conv wrt its kernel/bias.
+//
+// Why a dedicated kernel: this layer is 45% of the learner step's flops, its GEMM is
+// skinny (N = 16 output channels) and its A operand is an im2col gather over uint8
+// frames.  The generic implicit-GEMM core spends its time on gather index math; here
+//   * a workgroup owns ONE batch column b and walks the unroll in time, keeping a ring
+//     of 5 raw uint8 frames in LDS (35 KB): every frame byte is read from HBM ONCE
+//     (1 B per pixel per frame -- the algorithmic minimum) and serves the 4 stack
+//     positions it appears in; the next frame is prefetched into registers while the
+//     current step computes;
+//   * MFMA operands are built straight from the LDS bytes: one ds_read_b32 yields 4
+//     horizontally adjacent pixels = 4 consecutive k of the reduction, converted with
+//     v_cvt_f32_ubyte{0..3}; K is ordered so that a lane's (pixel, k-quad) address
+//     is a fixed per-lane offset plus compile-time row offsets -- no div/mod in the loop;
+//   * 1/255 is folded into the LDS copy of the weights (forward) / applied once to the
+//     reduced dW (backward) instead of once per input element;
+//   * cumulative-OR done masking (networks.py:131-157) = "channels c >= nvalid[t,b]
+//     are zero" => those k-steps are skipped (fwd) or fed zero words (wgrad);
+//   * forward computes out^T tiles (rows = channels, cols = pixels) so that each lane
+//     ends up with 4 consecutive channels of one pixel: 16-byte fully coalesced stores.
+// 5 waves per workgroup: 400 output pixels = 5 waves x 5 MFMA tiles (fwd) /
+// 5 waves x 20 four-pixel groups (wgrad) -- perfectly balanced for 84x84 frames.
+//
+// MFMA-bound (fp32 v_mfma_f32_16x16x4_f32): 2*400*256*Cout flops per frame.
+#include "common.h"
+#include "conv_problems.h"
+#include "conv_launch.h"
+#include "../../include/seedhip.h"
+
+namespace seedhip {
+namespace stackconv {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kWaves = 5;
+constexpr int kThreads = kWaves * 64;
+constexpr int kRing = 5;       // frame slots in LDS
+constexpr int kMT = 5;         // MFMA tiles in flight per wave (forward)
+constexpr int kWFloats = 64 * 64;   // one 16-channel slice of the kernel: [64 k-steps][64 lanes]
+
+struct Params {
+  const uint8_t* frames_ext;   // u8 [3+T1, B, fsz]
+  const uint8_t* nvalid;       // u8 [T1, B]
+  const float* w;              // [8,8,4,cout]
+  const float* bias;           // [cout] or null
+  float* out;                  // fwd: [T1*B, oh*ow, ld_out]
+  const float* dy;             // wgrad: same layout as out
+  float* partial_w;            // wgrad: [gridDim.x][256*cout]
+  float* partial_b;            // wgrad: [gridDim.x][cout] or null
+  int T1, B, ih, iw, oh, ow, cout, ld_out, out_relu;
+  int fsz;                     // ih*iw bytes, multiple of 16, <= 2*kThreads*16
+  int spc, items;              // steps per chunk; items = B * nchunks
+};
+
+__device__ __forceinline__ float ubyte(uint32_t w, int q) { return (float)((w >> (8 * q)) & 0xFFu); }
+
+// Copies the frames the first step of a chunk needs (ext rows t0 .. t0+3) into the ring.
+__device__ __forceinline__ void ring_prologue(const Params& p, unsigned char* ring, int b, int t0, int tid) {
+  const int nvec = p.fsz >> 4;
+  for (int e = t0; e < t0 + 4; ++e) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)e * p.B + b) * p.fsz);
+    uint4* dst = reinterpret_cast<uint4*>(ring + (e % kRing) * p.fsz);
+    for (int v = tid; v < nvec; v += kThreads) dst[v] = src[v];
+  }
+}
+
+// ------------------------------------------------------------------------------------ //
+// Forward.  k-step ks = (c*4 + r)*4 + q ; lane (kq = lane>>4, j = lane&15) supplies
+//   weights  W[ky = 2r + (kq>>1)][kx = 4(kq&1) + q][c][co0 + j] / 255      (MFMA A: rows = channels)
+//   pixels   frame_{t-c}[(oy*4 + ky)*iw + ox*4 + kx],  pixel = tile*16 + j  (MFMA B: cols = pixels)
+// D: lane holds channels co0 + 4*(lane>>4) + {0..3} of pixel tile*16 + (lane&15).
+// ------------------------------------------------------------------------------------ //
+__global__ void __launch_bounds__(kThreads)
+stackconv_fwd_kernel(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* w_lds = reinterpret_cast<float*>(smem);
+  unsigned char* ring = smem + kWFloats * sizeof(float);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4, j = lane & 15;
+  const int co0 = blockIdx.z * 16;
+
+  for (int idx = tid; idx < kWFloats; idx += kThreads) {
+    const int l = idx & 63, ks = idx >> 6;
+    const int q = ks & 3, r = (ks >> 2) & 3, c = ks >> 4;
+    const int ky = 2 * r + ((l >> 4) >> 1), kx = 4 * ((l >> 4) & 1) + q;
+    w_lds[idx] = p.w[((ky * 8 + kx) * 4 + c) * p.cout + co0 + (l & 15)] / 255.0f;
+  }
+  const int P = p.oh * p.ow;
+  const int ntiles = (P + 15) >> 4;
+  const int tpw = (ntiles + kWaves - 1) / kWaves;
+  const int nvec = p.fsz >> 4;
+  f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+    const float4 bv = *reinterpret_cast<const float4*>(p.bias + co0 + 4 * kq);
+    bias4 = f32x4_t{bv.x, bv.y, bv.z, bv.w};
+  }
+
+  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+    const int b = item % p.B, chunk = item / p.B;
+    const int t0 = chunk * p.spc;
+    const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
+    __syncthreads();
+    ring_prologue(p, ring, b, t0, tid);
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+      // Prefetch the frame step t+1 adds (ext row t+4) while this step computes.
+      const bool more = t + 1 < t1;
+      uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
+      if (more) {
+        const uint4* src = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t + 4) * p.B + b) * p.fsz);
+        if (tid < nvec) pf0 = src[tid];
+        if (tid + kThreads < nvec) pf1 = src[tid + kThreads];
+      }
+      const int nv = p.nvalid[(long long)t * p.B + b];
+      for (int tc = 0; tc < tpw; tc += kMT) {
+        int aoff[kMT];
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) {
+          int pix = (wave * tpw + tc + m) * 16 + j;
+          if (pix > P - 1) pix = P - 1;
+          const int oy = pix / p.ow, ox = pix - oy * p.ow;
+          aoff[m] = (oy * 4 + (kq >> 1)) * p.iw + ox * 4 + 4 * (kq & 1);
+        }
+        f32x4_t acc[kMT];
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < nv; ++c) {
+          const unsigned char* base = ring + ((t + 3 - c) % kRing) * p.fsz;
+          const float* wl = w_lds + c * 16 * 64 + lane;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            uint32_t a[kMT];
+#pragma unroll
+            for (int m = 0; m < kMT; ++m)
+              a[m] = *reinterpret_cast<const uint32_t*>(base + aoff[m] + r * 2 * p.iw);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float bw = wl[(r * 4 + q) * 64];
+#pragma unroll
+              for (int m = 0; m < kMT; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw, ubyte(a[m], q), acc[m], 0, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) {
+          const int tile = wave * tpw + tc + m;
+          const int pix = tile * 16 + j;
+          if (tc + m < tpw && pix < P) {
+            f32x4_t v = acc[m] + bias4;
+            if (p.out_relu) {
+              v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            }
+            float* o = p.out + (((long long)t * p.B + b) * P + pix) * p.ld_out + co0 + 4 * kq;
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+      if (more) {
+        uint4* dst = reinterpret_cast<uint4*>(ring + ((t + 4) % kRing) * p.fsz);
+        if (tid < nvec) dst[tid] = pf0;
+        if (tid + kThreads < nvec) dst[tid + kThreads] = pf1;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ //
+// Weight gradient.  dW[k][co] = sum_pixels X[pixel][k] * dY[pixel][co]; one MFMA reduces
+// over 4 pixels (a "group").  Lane (kq = lane>>4, i = lane&15):
+//   MFMA A (rows = 16 k-rows of an m-tile): X[pixel 4g+kq][c][ky = i>>1][kx = 4(i&1) + q]
+//          -> ONE ds_read_b32 per channel c yields the bytes of the 4 m-tiles (c, q=0..3)
+//   MFMA B (cols = channels):               dY[pixel 4g+kq][co0 + i]   (256-B coalesced global load)
+// 16 accumulators (m-tile = c*4 + q); D: lane holds k-rows 4*(lane>>4)+{0..3}, channel co0 + (lane&15).
+// Each workgroup accumulates over all the (column, time-chunk) items it is given, then
+// reduces its 5 waves through LDS in a fixed order and writes ONE partial slice.
+// ------------------------------------------------------------------------------------ //
+__global__ void __launch_bounds__(kThreads, 4)
+stackconv_wgrad_kernel(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);                       // [256 k_mem][16]
+  float* redb = red + kWFloats;                                      // [kWaves][16]
+  unsigned char* ring = smem + (kWFloats + kWaves * 16) * sizeof(float);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = lane >> 4, i = lane & 15;
+  const int co0 = blockIdx.z * 16;
+  const int P = p.oh * p.ow;
+  const int G = (P + 3) >> 2;
+  const int gpw = (((G + kWaves - 1) / kWaves) + 3) & ~3;            // groups per wave, multiple of 4
+  const int nvec = p.fsz >> 4;
+
+  f32x4_t acc[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+    const int b = item % p.B, chunk = item / p.B;
+    const int t0 = chunk * p.spc;
+    const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
+    __syncthreads();
+    ring_prologue(p, ring, b, t0, tid);
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+      const bool more = t + 1 < t1;
+      uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
+      if (more) {
+        const uint4* src = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t + 4) * p.B + b) * p.fsz);
+        if (tid < nvec) pf0 = src[tid];
+        if (tid + kThreads < nvec) pf1 = src[tid + kThreads];
+      }
+      const int nv = p.nvalid[(long long)t * p.B + b];
+      const float* dy_img = p.dy + ((long long)t * p.B + b) * P * p.ld_out + co0 + i;
+      const unsigned char* slot[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) slot[c] = ring + ((t + 3 - c) % kRing) * p.fsz;
+
+      const int g_begin = wave * gpw, g_end = g_begin + gpw;
+      float dyn[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pk = 4 * (g_begin + u) + kq;
+        dyn[u] = pk < P ? dy_img[(long long)pk * p.ld_out] : 0.f;
+      }
+      for (int g0 = g_begin; g0 < g_end; g0 += 4) {
+        float dyv[4];
+        uint32_t word[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          dyv[u] = dyn[u];
+          int pk = 4 * (g0 + u) + kq;
+          if (pk > P - 1) pk = P - 1;
+          const int oy = pk / p.ow, ox = pk - oy * p.ow;
+          const int aoff = (oy * 4 + (i >> 1)) * p.iw + ox * 4 + 4 * (i & 1);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            word[u][c] = c < nv ? *reinterpret_cast<const uint32_t*>(slot[c] + aoff) : 0u;
+        }
+        if (g0 + 4 < g_end) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int pk = 4 * (g0 + 4 + u) + kq;
+            dyn[u] = pk < P ? dy_img[(long long)pk * p.ld_out] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          bsum += dyv[u];
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc[c * 4 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ubyte(word[u][c], q), dyv[u], acc[c * 4 + q], 0, 0, 0);
+        }
+      }
+      if (more) {
+        uint4* dst = reinterpret_cast<uint4*>(ring + ((t + 4) % kRing) * p.fsz);
+        if (tid < nvec) dst[tid] = pf0;
+        if (tid + kThreads < nvec) dst[tid + kThreads] = pf1;
+      }
+      __syncthreads();
+    }
+  }
+
+  // Cross-wave reduction in wave order (deterministic), then one partial slice per workgroup.
+  bsum += __shfl_xor(bsum, 16, 64);
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (lane < 16) redb[wave * 16 + lane] = bsum;
+  for (int w = 0; w < kWaves; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int c = m >> 2, q = m & 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * kq + r;                       // k-row within the m-tile
+          const int ky = row >> 1, kx = 4 * (row & 1) + q;
+          const int idx = ((ky * 8 + kx) * 4 + c) * 16 + i;
+          red[idx] = (w == 0) ? acc[m][r] : red[idx] + acc[m][r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* pw = p.partial_w + (long long)blockIdx.x * 256 * p.cout;
+  for (int idx = tid; idx < kWFloats; idx += kThreads)
+    pw[(idx >> 4) * p.cout + co0 + (idx & 15)] = red[idx] / 255.0f;
+  if (p.partial_b && tid < 16) {
+    float s = 0.f;
+    for (int w = 0; w < kWaves; ++w) s += redb[w * 16 + tid];
+    p.partial_b[(long long)blockIdx.x * p.cout + co0 + tid] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------ //
+// Host side: eligibility, work decomposition, launch.
+// ------------------------------------------------------------------------------------ //
+bool eligible(const seedhip_stack_conv_geom* g, const void* frames_ext, const void* io) {
+  const long long fsz = (long long)g->ih * g->iw;
+  return g->kh == 8 && g->kw == 8 && g->stride == 4 && g->iw % 4 == 0 && fsz % 16 == 0 &&
+         fsz <= 2 * kThreads * 16 && g->cout % 16 == 0 && g->ld_out % 4 == 0 &&
+         (((uintptr_t)frames_ext) & 15) == 0 && (((uintptr_t)io) & 15) == 0 &&
+         (long long)kRing * fsz + (kWFloats + kWaves * 16) * 4 <= 150 * 1024;
+}
+
+// Chooses the time chunking so that the persistent grid is evenly loaded.
+void decompose(int T1, int B, int max_grid, int* spc, int* items, int* grid) {
+  double best = -1.0;
+  int best_n = 1;
+  for (int n = 1; n <= T1; ++n) {
+    const int s = (T1 + n - 1) / n;
+    if ((T1 + s - 1) / s != n) continue;                   // n must be the real chunk count for this s
+    const long long it = (long long)B * n;
+    const long long gr = it < max_grid ? it : max_grid;
+    const double rounds = (double)((it + gr - 1) / gr);
+    const double balance = (double)it / (rounds * gr);
+    const double fill = (double)gr / max_grid;             // prefer using the whole chip
+    const double overhead = (double)s / (s + 0.75);        // 3 extra frame loads per chunk
+    const double score = balance * (fill < 1.0 ? fill : 1.0) * overhead;
+    if (score > best + 1e-9) { best = score; best_n = n; }
+  }
+  *spc = (T1 + best_n - 1) / best_n;
+  const long long it = (long long)B * best_n;
+  *items = (int)it;
+  *grid = (int)(it < max_grid ? it : max_grid);
+}
+
+// MI355X: 256 CUs (this library targets gfx950 only); a fixed number keeps the workspace
+// query a pure function of the geometry.
+int max_grid_for(int wgs_per_cu) { return 256 * wgs_per_cu; }
+
+Params make_params(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, const uint8_t* nvalid) {
+  Params p;
+  memset(&p, 0, sizeof(p));
+  p.frames_ext = frames_ext; p.nvalid = nvalid;
+  p.T1 = g->T; p.B = g->B; p.ih = g->ih; p.iw = g->iw; p.oh = g->oh; p.ow = g->ow; p.cout = g->cout;
+  p.ld_out = g->ld_out; p.fsz = g->ih * g->iw;
+  return p;
+}
+
+int launch_fwd(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, const uint8_t* nvalid, const float* w,
+               const float* bias, float* out, int out_relu, hipStream_t s) {
+  Params p = make_params(g, frames_ext, nvalid);
+  p.w = w; p.bias = bias; p.out = out; p.out_relu = out_relu;
+  const size_t lds = kWFloats * sizeof(float) + (size_t)kRing * p.fsz;
+  const int per_cu = (int)((160 * 1024) / lds) < 3 ? (int)((160 * 1024) / lds) : 3;
+  int grid;
+  decompose(p.T1, p.B, max_grid_for(per_cu < 1 ? 1 : per_cu), &p.spc, &p.items, &grid);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)stackconv_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(stackconv_fwd_kernel, dim3(grid, 1, g->cout / 16), dim3(kThreads), lds, s, p);
+  return check_launch("stackconv_fwd_kernel");
+}
+
+size_t wgrad_lds(int fsz) { return (kWFloats + kWaves * 16) * sizeof(float) + (size_t)kRing * fsz; }
+
+int wgrad_grid(const seedhip_stack_conv_geom* g, int* spc, int* items) {
+  const size_t lds = wgrad_lds(g->ih * g->iw);
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 3) per_cu = 3;
+  if (per_cu < 1) per_cu = 1;
+  int grid;
+  decompose(g->T, g->B, max_grid_for(per_cu), spc, items, &grid);
+  return grid;
+}
+
+}  // namespace stackconv
+}  // namespace seedhip
+
+using namespace seedhip;
+
+namespace {
+int check_stack(const seedhip_stack_conv_geom* g, const char* what) {
+  SEEDHIP_REQUIRE(g, "%s: null geometry", what);
+  SEEDHIP_REQUIRE(g->T >= 1 && g->B >= 1 && g->ih >= 1 && g->iw >= 1 && g->kh >= 1 && g->kw >= 1 && g->stride >= 1 &&
+                  g->cout >= 1, "%s: non-positive geometry field", what);
+  SEEDHIP_REQUIRE(g->oh == (g->ih - g->kh) / g->stride + 1 && g->ow == (g->iw - g->kw) / g->stride + 1,
+                  "%s: oh/ow must be the VALID-padding output size", what);
+  SEEDHIP_REQUIRE(g->ld_out >= g->cout, "%s: ld_out < cout", what);
+  SEEDHIP_REQUIRE((long long)g->T * g->B * g->oh * g->ow < (1LL << 31), "%s: more than 2^31 pixels", what);
+  return SEEDHIP_OK;
+}
+StackGeom to_stack(const seedhip_stack_conv_geom* g) {
+  StackGeom s; s.T = g->T; s.B = g->B; s.ih = g->ih; s.iw = g->iw; s.oh = g->oh; s.ow = g->ow; s.kh = g->kh;
+  s.kw = g->kw; s.stride = g->stride; s.cout = g->cout; s.ld_out = g->ld_out;
+  return s;
+}
+size_t generic_wgrad_ws(const seedhip_stack_conv_geom* g) {
+  const int M = 4 * g->kh * g->kw, N = g->cout;
+  const long long pixels = (long long)g->T * g->B * g->oh * g->ow;
+  const int per = pick_k_per_slice(pixels, tiles_for(M, N));
+  const long long slices = (pixels + per - 1) / per;
+  return (size_t)slices * ((size_t)M * N + N) * sizeof(float);
+}
+size_t fast_wgrad_ws(const seedhip_stack_conv_geom* g) {
+  // geometry-only eligibility (pointer alignment is checked at launch)
+  const long long fsz = (long long)g->ih * g->iw;
+  if (!(g->kh == 8 && g->kw == 8 && g->stride == 4 && g->iw % 4 == 0 && fsz % 16 == 0 &&
+        fsz <= 2 * stackconv::kThreads * 16 && g->cout % 16 == 0)) return 0;
+  int spc, items;
+  const int grid = stackconv::wgrad_grid(g, &spc, &items);
+  return (size_t)grid * ((size_t)256 * g->cout + g->cout) * sizeof(float);
+}
+}  // namespace
+
+extern "C" int seedhip_conv2d_stack_fwd(const seedhip_stack_conv_geom* geom, const uint8_t* frames_ext,
+                                        const uint8_t* nvalid, const float* w, const float* bias, float* out,
+                                        int out_relu, void* stream) {
+  int rc = check_stack(geom, "conv2d_stack_fwd"); if (rc) return rc;
+  SEEDHIP_REQUIRE(frames_ext && nvalid && w && out, "conv2d_stack_fwd: null pointer");
+  if (stackconv::eligible(geom, frames_ext, out) && (!bias || (((uintptr_t)bias) & 15) == 0))
+    return stackconv::launch_fwd(geom, frames_ext, nvalid, w, bias, out, out_relu, (hipStream_t)stream);
+  ConvStackFwd p;                                   // generic geometry: implicit-GEMM core
+  p.frames_ext = frames_ext; p.nvalid = nvalid; p.w = w; p.bias = bias; p.out = out; p.out_relu = out_relu;
+  p.init(to_stack(geom));
+  launch_igemm_auto(p, 1, (hipStream_t)stream);
+  return check_launch("conv2d_stack_fwd");
+}
+
+extern "C" size_t seedhip_conv2d_stack_bwd_weight_workspace_bytes(const seedhip_stack_conv_geom* g) {
+  if (!g) return 0;
+  const size_t a = generic_wgrad_ws(g), b = fast_wgrad_ws(g);
+  return a > b ? a : b;
+}
+
+extern "C" int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* geom, const uint8_t* frames_ext,
+                                               const uint8_t* nvalid, const float* dy, float* dw, float* dbias,
+                                               void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_stack(geom, "conv2d_stack_bwd_weight"); if (rc) return rc;
+  SEEDHIP_REQUIRE(frames_ext && nvalid && dy && dw && workspace, "conv2d_stack_bwd_weight: null pointer");
+  SEEDHIP_REQUIRE(workspace_bytes >= seedhip_conv2d_stack_bwd_weight_workspace_bytes(geom),
+                  "conv2d_stack_bwd_weight: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int M = 4 * geom->kh * geom->kw, N = geom->cout;
+  if (stackconv::eligible(geom, frames_ext, dy)) {
+    stackconv::Params p = stackconv::make_params(geom, frames_ext, nvalid);
+    const int grid = stackconv::wgrad_grid(geom, &p.spc, &p.items);
+    p.dy = dy;
+    p.partial_w = (float*)workspace;
+    p.partial_b = dbias ? (float*)workspace + (size_t)grid * M * N : nullptr;
+    const size_t lds = stackconv::wgrad_lds(p.fsz);
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(stackconv::stackconv_wgrad_kernel, dim3(grid, 1, N / 16), dim3(stackconv::kThreads), lds, s, p);
+    rc = check_launch("stackconv_wgrad_kernel"); if (rc) return rc;
+    reduce_slices(p.partial_w, grid, (long long)M * N, dw, s);
+    if (dbias) reduce_slices(p.partial_b, grid, N, dbias, s);
+    return check_launch("conv2d_stack_bwd_weight");
+  }
+  ConvStackWgrad p;
+  p.frames_ext = frames_ext; p.nvalid = nvalid; p.dy = dy;
+  const long long pixels = (long long)geom->T * geom->B * geom->oh * geom->ow;
+  p.init(to_stack(geom), pick_k_per_slice(pixels, tiles_for(M, N)));
+  const int slices = p.slices();
+  p.partial_w = (float*)workspace;
+  p.partial_b = dbias ? (float*)workspace + (size_t)slices * M * N : nullptr;
+  launch_igemm_auto(p, slices, s);
+  reduce_slices(p.partial_w, slices, (long long)M * N, dw, s);
+  if (dbias) reduce_slices(p.partial_b, slices, N, dbias, s);
+  return check_launch("conv2d_stack_bwd_weight");
+}

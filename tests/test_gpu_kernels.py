@@ -369,15 +369,15 @@ def test_conv_residual_and_accumulate(device):
   assert np.max(np.abs(dx.cpu().numpy() - (xt.grad.numpy() + add))) < 2e-4
 
 
-@pytest.mark.parametrize('T1,B', [(5, 3), (21, 8)])
-def test_stack_conv_parity(device, T1, B):
+@pytest.mark.parametrize('T1,B,cout', [(5, 3, 16), (21, 8, 16), (21, 37, 32), (4, 2, 8), (1, 64, 16)])
+def test_stack_conv_parity(device, T1, B, cout):
   """Fused stack_frames + /255 + conv1 (u8 frames in, never materialising the fp32
   stacked tensor) vs oracle stack_frames -> conv2d, forward and weight gradient."""
   from seed_rl_amd import ops
   u = synth.atari_unroll(11, T1, B, done_p=0.15, zero_state=False)
   stacked, _ = frames_np.stack_frames(u['frames'], u['frame_state'], u['done'], 4)
   rng = np.random.default_rng(0)
-  cout = 16
+  # cout % 16 == 0 -> dedicated LDS-ring kernel (csrc/stackconv.hip); cout = 8 -> generic implicit-GEMM path
   w = (rng.normal(size=(8, 8, 4, cout)) / 16).astype(np.float32)
   b = rng.normal(size=cout).astype(np.float32)
   wt = torch.tensor(w, requires_grad=True); bt = torch.tensor(b, requires_grad=True)
