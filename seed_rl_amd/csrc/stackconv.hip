@@ -59,13 +59,22 @@ struct Params {
 
 __device__ __forceinline__ float ubyte(uint32_t w, int q) { return (float)((w >> (8 * q)) & 0xFFu); }
 
-// Copies the frames the first step of a chunk needs (ext rows t0 .. t0+3) into the ring.
+// Copies the frames the first step of a chunk needs (ext rows t0 .. t0+3) into the ring.  All
+// global loads are issued before the first LDS store (one memory latency, not eight).
 __device__ __forceinline__ void ring_prologue(const Params& p, unsigned char* ring, int b, int t0, int tid) {
   const int nvec = p.fsz >> 4;
-  for (int e = t0; e < t0 + 4; ++e) {
-    const uint4* src = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)e * p.B + b) * p.fsz);
-    uint4* dst = reinterpret_cast<uint4*>(ring + (e % kRing) * p.fsz);
-    for (int v = tid; v < nvec; v += kThreads) dst[v] = src[v];
+  uint4 v[4][2];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t0 + e) * p.B + b) * p.fsz);
+    v[e][0] = tid < nvec ? src[tid] : make_uint4(0, 0, 0, 0);
+    v[e][1] = tid + kThreads < nvec ? src[tid + kThreads] : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    uint4* dst = reinterpret_cast<uint4*>(ring + ((t0 + e) % kRing) * p.fsz);
+    if (tid < nvec) dst[tid] = v[e][0];
+    if (tid + kThreads < nvec) dst[tid + kThreads] = v[e][1];
   }
 }
 
@@ -84,11 +93,22 @@ stackconv_fwd_kernel(const Params p) {
   const int kq = lane >> 4, j = lane & 15;
   const int co0 = blockIdx.z * 16;
 
-  for (int idx = tid; idx < kWFloats; idx += kThreads) {
-    const int l = idx & 63, ks = idx >> 6;
-    const int q = ks & 3, r = (ks >> 2) & 3, c = ks >> 4;
-    const int ky = 2 * r + ((l >> 4) >> 1), kx = 4 * ((l >> 4) & 1) + q;
-    w_lds[idx] = p.w[((ky * 8 + kx) * 4 + c) * p.cout + co0 + (l & 15)] / 255.0f;
+  {
+    constexpr int kPer = (kWFloats + kThreads - 1) / kThreads;
+    float wv[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int idx = tid + u * kThreads;
+      const int l = idx & 63, ks = (idx >> 6) & 63;
+      const int q = ks & 3, r = (ks >> 2) & 3, c = ks >> 4;
+      const int ky = 2 * r + ((l >> 4) >> 1), kx = 4 * ((l >> 4) & 1) + q;
+      wv[u] = p.w[((ky * 8 + kx) * 4 + c) * p.cout + co0 + (l & 15)];
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int idx = tid + u * kThreads;
+      if (idx < kWFloats) w_lds[idx] = wv[u] / 255.0f;
+    }
   }
   const int P = p.oh * p.ow;
   const int ntiles = (P + 15) >> 4;
@@ -363,7 +383,7 @@ size_t wgrad_lds(int fsz) { return (kWFloats + kWaves * 16) * sizeof(float) + (s
 int wgrad_grid(const seedhip_stack_conv_geom* g, int* spc, int* items) {
   const size_t lds = wgrad_lds(g->ih * g->iw);
   int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu > 3) per_cu = 3;
+  if (per_cu > 2) per_cu = 2;                     // measured: 2 workgroups per CU beat 3 (0.70 vs 0.81 ms at cfg2)
   if (per_cu < 1) per_cu = 1;
   int grid;
   decompose(g->T, g->B, max_grid_for(per_cu), spc, items, &grid);

@@ -1,0 +1,94 @@
+#!/usr/bin/env python
+"""Per-kernel micro-benchmarks at the cfg2 / cfg3 layer shapes (HIP events on the launch stream).
+
+  python tools/bench_kernels.py [stack|conv|fc|all] [--B 512]
+Prints one line per kernel: avg ms, TFLOP/s (fp32 MFMA peak 157.3) or GB/s.
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from seed_rl_amd import ops
+
+
+def timeit(fn, reps=20, warm=3):
+  for _ in range(warm):
+    fn()
+  s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  s.record()
+  for _ in range(reps):
+    fn()
+  e.record()
+  torch.cuda.synchronize()
+  return s.elapsed_time(e) / reps
+
+
+def report(name, ms, flops=0, nbytes=0):
+  print('%-44s %8.4f ms  %7.1f TF/s (%.1f%% fp32-MFMA)  %7.1f GB/s' %
+        (name, ms, flops / ms / 1e9, flops / ms / 1e9 / 157.3 * 100, nbytes / ms / 1e6))
+
+
+def bench_stack(B, T1=21, cout=16):
+  dev = torch.device('cuda')
+  HW = 84 * 84
+  ext = torch.randint(0, 256, (T1 + 3, B, HW), dtype=torch.uint8, device=dev)
+  nv = torch.full((T1, B), 4, dtype=torch.uint8, device=dev)
+  w = torch.randn(8, 8, 4, cout, device=dev) / 16
+  b = torch.randn(cout, device=dev)
+  g = ops.StackConvGeom(T1, B, 84, 84, 20, 20, 8, 8, 4, cout, cout)
+  out = torch.empty((T1 * B, 20, 20, cout), device=dev)
+  dy = torch.randn((T1 * B, 20, 20, cout), device=dev)
+  dw, db = torch.empty_like(w), torch.empty_like(b)
+  ws = torch.empty(ops.conv2d_stack_bwd_weight_workspace_bytes(g) // 4 + 4, device=dev)
+  fl = 2.0 * T1 * B * 400 * cout * 256
+  report('stack_conv_fwd cout=%d' % cout, timeit(lambda: ops.conv2d_stack_fwd(g, ext, nv, w, b, out)), fl,
+         T1 * B * HW + out.numel() * 4)
+  report('stack_conv_wgrad cout=%d' % cout, timeit(lambda: ops.conv2d_stack_bwd_weight(g, ext, nv, dy, dw, db, ws)), fl,
+         T1 * B * HW + out.numel() * 4)
+
+
+def bench_conv(name, n, ih, iw, cin, k, s, padding, cout):
+  dev = torch.device('cuda')
+  g = ops.conv_geom(n, ih, iw, cin, k, k, s, padding, cout)
+  x = torch.randn((n, ih, iw, cin), device=dev)
+  w = torch.randn((k, k, cin, cout), device=dev) / (k * k * cin) ** 0.5
+  b = torch.randn(cout, device=dev)
+  out = torch.empty((n, g.oh, g.ow, cout), device=dev)
+  dy = torch.randn_like(out)
+  dx = torch.empty_like(x)
+  dw, db = torch.empty_like(w), torch.empty_like(b)
+  ws = torch.empty(ops.conv2d_bwd_weight_workspace_bytes(g) // 4 + 4, device=dev)
+  fl = 2.0 * n * g.oh * g.ow * cout * k * k * cin
+  by = (x.numel() + out.numel() + w.numel()) * 4
+  report(name + ' fwd', timeit(lambda: ops.conv2d_fwd(g, x, w, b, out, out_relu=True)), fl, by)
+  report(name + ' dgrad', timeit(lambda: ops.conv2d_bwd_data(g, dy, w, dx, relu_mask=x)), fl, by)
+  report(name + ' wgrad', timeit(lambda: ops.conv2d_bwd_weight(g, x, dy, dw, db, ws)), fl, by)
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('what', nargs='?', default='all')
+  ap.add_argument('--B', type=int, default=512)
+  a = ap.parse_args()
+  N = 21 * a.B
+  if a.what in ('stack', 'all'):
+    bench_stack(a.B)
+  if a.what in ('conv', 'all'):
+    bench_conv('conv 4x4/2 16->32 @20x20', N, 20, 20, 16, 4, 2, 'valid', 32)
+  if a.what in ('fc', 'all'):
+    bench_conv('fc 2592->256', N, 1, 1, 2592, 1, 1, 'valid', 256)
+    bench_conv('heads 256->20', N, 1, 1, 256, 1, 1, 'valid', 20)
+  if a.what in ('deep',):
+    n = 21 * 256
+    bench_conv('deep s0 3x3 16->16 @36x48', n, 36, 48, 16, 3, 1, 'same', 16)
+    bench_conv('deep s1 3x3 16->32 @36x48', n, 36, 48, 16, 3, 1, 'same', 32)
+    bench_conv('deep s1 3x3 32->32 @18x24', n, 18, 24, 32, 3, 1, 'same', 32)
+    bench_conv('deep s2 3x3 32->32 @9x12', n, 9, 12, 32, 3, 1, 'same', 32)
+
+
+if __name__ == '__main__':
+  main()
