@@ -141,6 +141,39 @@ int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* geom, const u
                                     const uint8_t* nvalid, const float* dy, float* dw, float* dbias,
                                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- MaxPool2D(3, strides 2, 'same') -------------------------------------------------------
+ * Replaces the Keras MaxPool2D of dmlab/networks.py:36-37 and its autodiff (TF 'SAME' padding:
+ * 0 before / 1 after for even sizes).  NHWC fp32, c % 4 == 0.  y [n, ceil(ih/2), ceil(iw/2), c];
+ * argmax (uint8, same shape as y) is written by fwd and consumed by bwd. */
+int seedhip_maxpool3x3s2_same_fwd(int n, int ih, int iw, int c, const float* x, float* y, uint8_t* argmax,
+                                  void* stream);
+int seedhip_maxpool3x3s2_same_bwd(int n, int ih, int iw, int c, const float* dy, const uint8_t* argmax, float* dx,
+                                  void* stream);
+
+/* ---- LSTM core with done-reset ---------------------------------------------------------------
+ * Replace the time loop of dmlab/networks.py:152-171 / atari/networks.py:176-218 (_unroll_cell)
+ * around tf.keras.layers.LSTMCell (gate order i,f,g,o; one bias) and its autodiff; the dense
+ * contractions (x W + b for all steps, h U per step, dz U^T per step, dW/dU/db at the end) are
+ * seedhip_conv2d_* calls on 1x1 geometries -- see seed_rl_amd/networks.py:_LstmCore.
+ *   assemble_inputs: x[n, feat] = reward (clipped to [-1,1] if clip_reward: dmlab/networks.py:112;
+ *                    raw for R2D2: atari/networks.py:263-271), x[n, feat+1+a] = one_hot(prev_action),
+ *                    remaining pad columns up to ldx = 0.
+ *   mask_state:      hin/cin = where(done0, 0, h0/c0)
+ *   gates_fwd:       z [B,4H] pre-activations, cin [B,H] (already reset) -> h_out [B,H] (stride ld_h),
+ *                    hin_next/cin_next = where(done_next, 0, (h', c')); done_next NULL = no reset.
+ *   gates_bwd:       dh_out (stride ld_dh) + keep_next * dh_rec -> dz [B,4H], dc_prev [B,H];
+ *                    dh_rec / dc_rec may be NULL (last step). */
+int seedhip_lstm_assemble_inputs(float* x, int ldx, int feat, int num_actions, const float* reward,
+                                 const void* prev_actions, int action_elem_size, int clip_reward, long long rows,
+                                 void* stream);
+int seedhip_lstm_mask_state(const float* h0, const float* c0, const uint8_t* done0, int B, int H, float* hin,
+                            float* cin, void* stream);
+int seedhip_lstm_gates_fwd(const float* z, const float* cin, const uint8_t* done_next, int B, int H, float* h_out,
+                           int ld_h, float* hin_next, float* cin_next, void* stream);
+int seedhip_lstm_gates_bwd(const float* z, const float* cin, const float* dh_out, int ld_dh, const float* dh_rec,
+                           const float* dc_rec, const uint8_t* done_next, int B, int H, float* dz, float* dc_prev,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

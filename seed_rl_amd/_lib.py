@@ -58,6 +58,12 @@ SIGNATURES = {
     'seedhip_conv2d_stack_bwd_weight_workspace_bytes': (c_size_t, [ctypes.POINTER(StackConvGeom)]),
     'seedhip_conv2d_stack_bwd_weight':
         (c_int, [ctypes.POINTER(StackConvGeom), P, P, P, P, P, P, c_size_t, P]),
+    'seedhip_maxpool3x3s2_same_fwd': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
+    'seedhip_maxpool3x3s2_same_bwd': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
+    'seedhip_lstm_assemble_inputs': (c_int, [P, c_int, c_int, c_int, P, P, c_int, c_int, c_ll, P]),
+    'seedhip_lstm_mask_state': (c_int, [P, P, P, c_int, c_int, P, P, P]),
+    'seedhip_lstm_gates_fwd': (c_int, [P, P, P, c_int, c_int, P, c_int, P, P, P]),
+    'seedhip_lstm_gates_bwd': (c_int, [P, P, P, c_int, P, P, P, c_int, c_int, P, P, P]),
 }
 
 

@@ -160,6 +160,73 @@ class _Agent(object):
     return AgentOutput(action, logits, baseline)
 
 
+  # head-gradient buffer the fused loss kernel writes into (same layout as `head`)
+  def head_buffers(self):
+    L = self._last
+    d_head = self._buf('d_head', (L['N'], self._ldh), zero=True)
+    return L['head'], d_head, self._ldh
+
+  # -- LSTM core with done-reset (dmlab/networks.py:152-171; atari/networks.py:176-218) ---- #
+  def _lstm_fwd(self, X, ldx, in_dim, H, T1, B, done_u8, state, prefix='core'):
+    """X [T1*B, ldx] (features | reward | one-hot action); returns core outputs [T1*B, H] and
+    the new (h, c).  Keeps what the backward needs in self._last['lstm']."""
+    N = T1 * B
+    fl = self.flat
+    gx = ops.dense_geom(N, in_dim, 4 * H, ld_in=ldx)
+    Zx = self._buf('lstm_zx', (N, 4 * H))
+    ops.conv2d_fwd(gx, X, fl.p(prefix + '/kernel'), fl.p(prefix + '/bias'), Zx)
+    Hin = self._buf('lstm_hin', (T1 + 1, B, H))
+    Cin = self._buf('lstm_cin', (T1 + 1, B, H))
+    h0, c0 = state
+    ops.lstm_mask_state(h0.contiguous(), c0.contiguous(), done_u8[0], B, H, Hin[0], Cin[0])
+    Z = self._buf('lstm_z', (T1, B, 4 * H))
+    Hout = self._buf('lstm_hout', (N, H))
+    gu = ops.dense_geom(B, H, 4 * H)
+    U = fl.p(prefix + '/recurrent_kernel')
+    Zx3, Hout3 = Zx.view(T1, B, 4 * H), Hout.view(T1, B, H)
+    for t in range(T1):
+      ops.conv2d_fwd(gu, Hin[t], U, None, Z[t], residual=Zx3[t])
+      ops.lstm_gates_fwd(Z[t], Cin[t], done_u8[t + 1] if t + 1 < T1 else None, B, H, Hout3[t], H, Hin[t + 1],
+                         Cin[t + 1])
+    self._last_lstm = dict(X=X, ldx=ldx, in_dim=in_dim, H=H, T1=T1, B=B, done=done_u8, gx=gx, gu=gu, Z=Z, Hin=Hin,
+                           Cin=Cin, Hout=Hout, prefix=prefix)
+    return Hout, (Hin[T1].clone(), Cin[T1].clone())
+
+  def _lstm_bwd(self, dHout, wsb):
+    """dHout [T1*B, H]: gradient wrt the core outputs.  Fills the core's weight gradients and returns
+    dX [T1*B, ldx] (columns >= in_dim undefined), already masked by X > 0 (ReLU of the feature layer;
+    reward / one-hot columns carry no gradient we use)."""
+    L = self._last_lstm
+    T1, B, H, N = L['T1'], L['B'], L['H'], L['T1'] * L['B']
+    fl, prefix = self.flat, L['prefix']
+    U = fl.p(prefix + '/recurrent_kernel')
+    dZ = self._buf('lstm_dz', (T1, B, 4 * H))
+    dcb = [self._buf('lstm_dc0', (B, H)), self._buf('lstm_dc1', (B, H))]
+    dhb = self._buf('lstm_dh', (B, H))
+    dH3 = dHout.view(T1, B, H)
+    dh_rec = dc_rec = None
+    for t in range(T1 - 1, -1, -1):
+      ops.lstm_gates_bwd(L['Z'][t], L['Cin'][t], dH3[t], H, dh_rec, dc_rec,
+                         L['done'][t + 1] if t + 1 < T1 else None, B, H, dZ[t], dcb[t & 1])
+      dc_rec = dcb[t & 1]
+      if t > 0:
+        ops.conv2d_bwd_data(L['gu'], dZ[t], U, dhb)
+        dh_rec = dhb
+    dZf = dZ.view(N, 4 * H)
+    gall = ops.dense_geom(N, H, 4 * H)
+    ops.conv2d_bwd_weight(gall, L['Hin'][:T1].view(N, H), dZf, fl.g(prefix + '/recurrent_kernel'), None, wsb)
+    ops.conv2d_bwd_weight(L['gx'], L['X'], dZf, fl.g(prefix + '/kernel'), fl.g(prefix + '/bias'), wsb)
+    dX = self._buf('lstm_dx', (N, L['ldx']))
+    ops.conv2d_bwd_data(L['gx'], dZf, fl.p(prefix + '/kernel'), dX, relu_mask=L['X'])
+    return dX
+
+  def _lstm_ws_bytes(self):
+    L = self._last_lstm
+    N = L['T1'] * L['B']
+    return max(ops.conv2d_bwd_weight_workspace_bytes(ops.dense_geom(N, L['H'], 4 * L['H'])),
+               ops.conv2d_bwd_weight_workspace_bytes(L['gx']))
+
+
 class AtariShallow(_Agent):
   """Frame-stacked Atari policy/value agent (see module docstring, D1)."""
 
@@ -246,12 +313,6 @@ class AtariShallow(_Agent):
       out = AgentOutput(*[None if t is None else t[0] for t in out])
     return out, AgentState(core_state=(), frame_stacking_state=new_fs)
 
-  # head-gradient buffer the fused loss kernel writes into (same layout as `head`)
-  def head_buffers(self):
-    L = self._last
-    d_head = self._buf('d_head', (L['N'], self._ldh), zero=True)
-    return L['head'], d_head, self._ldh
-
   def backward(self):
     """Gradients of the loss wrt all parameters, given d_head (written by the loss kernel)."""
     L = self._last
@@ -291,3 +352,146 @@ class AtariShallow(_Agent):
 
   def _stack_ws(self, g0):
     return self._buf('stack_ws', (ops.conv2d_stack_bwd_weight_workspace_bytes(g0) // 4 + 4,))
+
+
+class ImpalaDeep(_Agent):
+  """IMPALA deep ResNet + LSTM(256) agent: mirror of /root/reference/dmlab/networks.py:63-171
+  (3 stacks of Conv3x3 -> MaxPool 3/2 -> 2 residual blocks, channels 16/32/32; Dense 256; LSTM 256 on
+  [features, clip(reward), one_hot(prev_action)]; policy / baseline heads).  39 trainable tensors in the
+  reference's creation order (tests/agents_test.py:45)."""
+
+  def __init__(self, num_actions, observation_shape=(72, 96, 3), device='cuda', seed=0, entropy_cost=0.00025,
+               channels=(16, 32, 32), fc=256, lstm=256):
+    super(ImpalaDeep, self).__init__(num_actions, device)
+    h, w, c = observation_shape
+    self._obs = (h, w, c)
+    self._channels, self._fc, self._H = tuple(channels), fc, lstm
+    self._entropy_cost = entropy_cost
+    spec, cin = [], c
+    self._stack_shapes = []                    # (ih, iw, cin, ch, oh, ow)
+    for i, ch in enumerate(self._channels):
+      spec += [('stack%d/conv/kernel' % i, (3, 3, cin, ch), 'glorot'), ('stack%d/conv/bias' % i, (ch,), 'zeros')]
+      for b in range(2):
+        for j in range(2):
+          spec += [('stack%d/res_%d/conv2d_%d/kernel' % (i, b, j), (3, 3, ch, ch), 'glorot'),
+                   ('stack%d/res_%d/conv2d_%d/bias' % (i, b, j), (ch,), 'zeros')]
+      oh, ow = (h + 1) // 2, (w + 1) // 2
+      self._stack_shapes.append((h, w, cin, ch, oh, ow))
+      h, w, cin = oh, ow, ch
+    self._flat_dim = h * w * cin
+    self._in_dim = fc + 1 + num_actions
+    self._ldx = _round4(self._in_dim)
+    H = lstm
+    spec += [('conv_to_linear/kernel', (self._flat_dim, fc), 'glorot'), ('conv_to_linear/bias', (fc,), 'zeros'),
+             ('core/kernel', (self._in_dim, 4 * H), 'glorot'), ('core/recurrent_kernel', (H, 4 * H), 'orthogonal'),
+             ('core/bias', (4 * H,), 'lstm_bias'),
+             ('policy_logits/kernel', (H, num_actions), 'glorot'), ('policy_logits/bias', (num_actions,), 'zeros'),
+             ('baseline/kernel', (H, 1), 'glorot'), ('baseline/bias', (1,), 'zeros')]
+    self._build_params(spec, seed)
+    self._last = None
+
+  def entropy_cost(self):
+    return self._entropy_cost
+
+  def initial_state(self, batch_size):
+    z = torch.zeros((batch_size, self._H), dtype=torch.float32, device=self.device)
+    return (z, z.clone())
+
+  def __call__(self, prev_actions, env_outputs, core_state, unroll=False, is_training=False):
+    reward, done, obs = env_outputs.reward, env_outputs.done, env_outputs.observation
+    if not unroll:
+      reward, done, obs, prev_actions = reward[None], done[None], obs[None], prev_actions[None]
+    T1, B = done.shape[0], done.shape[1]
+    N = T1 * B
+    if obs.dtype != torch.uint8:
+      raise ValueError('observations must be uint8 frames')
+    fl = self.flat
+    h0, w0, c0 = self._obs
+    x = obs.reshape(N, h0, w0, c0).contiguous()
+    saved = []
+    for i, (ih, iw, cin, ch, oh, ow) in enumerate(self._stack_shapes):
+      g = ops.conv_geom(N, ih, iw, cin, 3, 3, 1, 'same', ch)
+      a = self._buf('s%d_a' % i, (N, ih, iw, ch))
+      ops.conv2d_fwd(g, x, fl.p('stack%d/conv/kernel' % i), fl.p('stack%d/conv/bias' % i), a,
+                     in_dtype=ops.IN_U8_DIV255 if i == 0 else ops.IN_F32)          # dmlab/networks.py:98-100
+      p = self._buf('s%d_p' % i, (N, oh, ow, ch))
+      arg = self._buf('s%d_arg' % i, (N, oh, ow, ch), torch.uint8)
+      ops.maxpool_fwd(a, p, arg)
+      gres = ops.conv_geom(N, oh, ow, ch, 3, 3, 1, 'same', ch)
+      blocks = []
+      for b in range(2):                                                             # dmlab/networks.py:52-59
+        r1 = self._buf('s%d_b%d_r1' % (i, b), (N, oh, ow, ch))
+        ops.conv2d_fwd(gres, p, fl.p('stack%d/res_%d/conv2d_0/kernel' % (i, b)),
+                       fl.p('stack%d/res_%d/conv2d_0/bias' % (i, b)), r1, in_relu=True)
+        r2 = self._buf('s%d_b%d_r2' % (i, b), (N, oh, ow, ch))
+        ops.conv2d_fwd(gres, r1, fl.p('stack%d/res_%d/conv2d_1/kernel' % (i, b)),
+                       fl.p('stack%d/res_%d/conv2d_1/bias' % (i, b)), r2, in_relu=True, residual=p)
+        blocks.append((p, r1))
+        p = r2
+      saved.append(dict(g=g, gres=gres, x=x, arg=arg, a_shape=(N, ih, iw, ch), blocks=blocks))
+      x = p
+    flat = x.view(N, self._flat_dim)
+    ldx = self._ldx
+    X = self._buf('lstm_x', (N, ldx))
+    gfc = ops.dense_geom(N, self._flat_dim, self._fc, ld_out=ldx)
+    ops.conv2d_fwd(gfc, flat, fl.p('conv_to_linear/kernel'), fl.p('conv_to_linear/bias'), X, in_relu=True,
+                   out_relu=True)                                                    # :105-109
+    ops.lstm_assemble_inputs(X, ldx, self._fc, self._num_actions, reward.to(torch.float32).contiguous(),
+                             prev_actions.contiguous(), True, N)                     # :112-114
+    done_u8 = done.to(torch.uint8).contiguous()
+    Hout, new_state = self._lstm_fwd(X, ldx, self._in_dim, self._H, T1, B, done_u8, core_state)
+    head = self._head_fwd(Hout, N, self._H)
+    self._last = dict(T1=T1, B=B, N=N, saved=saved, flat=flat, gfc=gfc, X=X, Hout=Hout, head=head)
+    out = self._agent_output(head, T1, B, sample=not is_training)
+    if not unroll:
+      out = AgentOutput(*[None if t is None else t[0] for t in out])
+    return out, new_state
+
+  def backward(self):
+    L = self._last
+    N = L['N']
+    fl = self.flat
+    d_head = self._buf('d_head', (N, self._ldh), zero=True)
+    wsb = self._wgrad_ws()
+    H = self._H
+    gh = ops.dense_geom(N, H, self._ldh)
+    ops.conv2d_bwd_weight(gh, L['Hout'], d_head, fl.g('heads/kernel'), fl.g('heads/bias'), wsb)
+    dHout = self._buf('d_hout', (N, H))
+    ops.conv2d_bwd_data(gh, d_head, fl.p('heads/kernel'), dHout)
+    dX = self._lstm_bwd(dHout, wsb)
+    # Dense 256 (its ReLU mask was applied to dX by the LSTM input-projection dgrad)
+    ops.conv2d_bwd_weight(L['gfc'], L['flat'], dX, fl.g('conv_to_linear/kernel'), fl.g('conv_to_linear/bias'), wsb,
+                          in_relu=True)
+    d_flat = self._buf('d_flat', tuple(L['flat'].shape))
+    ops.conv2d_bwd_data(L['gfc'], dX, fl.p('conv_to_linear/kernel'), d_flat, relu_mask=L['flat'])
+    dp = d_flat
+    for i in range(len(L['saved']) - 1, -1, -1):
+      S = L['saved'][i]
+      gres = S['gres']
+      for b in (1, 0):
+        p_in, r1 = S['blocks'][b]
+        k0, k1 = 'stack%d/res_%d/conv2d_0' % (i, b), 'stack%d/res_%d/conv2d_1' % (i, b)
+        ops.conv2d_bwd_weight(gres, r1, dp, fl.g(k1 + '/kernel'), fl.g(k1 + '/bias'), wsb, in_relu=True)
+        d_r1 = self._buf('d_s%d_b%d_r1' % (i, b), tuple(r1.shape))
+        ops.conv2d_bwd_data(gres, dp, fl.p(k1 + '/kernel'), d_r1, relu_mask=r1)
+        ops.conv2d_bwd_weight(gres, p_in, d_r1, fl.g(k0 + '/kernel'), fl.g(k0 + '/bias'), wsb, in_relu=True)
+        d_pin = self._buf('d_s%d_b%d_p' % (i, b), tuple(p_in.shape))
+        ops.conv2d_bwd_data(gres, d_r1, fl.p(k0 + '/kernel'), d_pin, relu_mask=p_in, add=dp)   # + skip path
+        dp = d_pin
+      d_a = self._buf('d_s%d_a' % i, S['a_shape'])
+      ops.maxpool_bwd(dp, S['arg'], d_a)
+      kc = 'stack%d/conv' % i
+      ops.conv2d_bwd_weight(S['g'], S['x'], d_a, fl.g(kc + '/kernel'), fl.g(kc + '/bias'), wsb,
+                            in_dtype=ops.IN_U8_DIV255 if i == 0 else ops.IN_F32)
+      if i > 0:
+        dx = self._buf('d_s%d_x' % i, tuple(S['x'].shape))
+        ops.conv2d_bwd_data(S['g'], d_a, fl.p(kc + '/kernel'), dx)
+        dp = dx
+
+  def _wgrad_ws(self):
+    L = self._last
+    need = ops.conv2d_bwd_weight_workspace_bytes(ops.dense_geom(L['N'], self._H, self._ldh))
+    need = max(need, ops.conv2d_bwd_weight_workspace_bytes(L['gfc']), self._lstm_ws_bytes())
+    for S in L['saved']:
+      need = max(need, ops.conv2d_bwd_weight_workspace_bytes(S['g']), ops.conv2d_bwd_weight_workspace_bytes(S['gres']))
+    return self._buf('wgrad_ws', (need // 4 + 4,))

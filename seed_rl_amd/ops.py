@@ -202,3 +202,49 @@ def clip_by_global_norm(grads, clip_norm, sumsq_out, workspace):
     _lib.check(_lib.lib().seedhip_clip_by_global_norm(
         _lib.ptr(grads), grads.numel(), float(clip_norm), _lib.ptr(sumsq_out), _lib.ptr(workspace),
         workspace.numel() * workspace.element_size(), _lib.stream()), 'seedhip_clip_by_global_norm')
+
+
+def maxpool_fwd(x, y, argmax):
+  """MaxPool2D(3, 2, 'same') on NHWC fp32 (dmlab/networks.py:36-37)."""
+  n, ih, iw, c = x.shape
+  with _region('maxpool_fwd[%dx%dx%d]' % (ih, iw, c), 0, x.numel() * 4 + y.numel() * 5):
+    with _dev(y):
+      _lib.check(_lib.lib().seedhip_maxpool3x3s2_same_fwd(n, ih, iw, c, _lib.ptr(x), _lib.ptr(y), _lib.ptr(argmax),
+                                                         _lib.stream()), 'seedhip_maxpool3x3s2_same_fwd')
+
+
+def maxpool_bwd(dy, argmax, dx):
+  n, ih, iw, c = dx.shape
+  with _region('maxpool_bwd[%dx%dx%d]' % (ih, iw, c), 0, dx.numel() * 4 + dy.numel() * 5):
+    with _dev(dx):
+      _lib.check(_lib.lib().seedhip_maxpool3x3s2_same_bwd(n, ih, iw, c, _lib.ptr(dy), _lib.ptr(argmax), _lib.ptr(dx),
+                                                         _lib.stream()), 'seedhip_maxpool3x3s2_same_bwd')
+
+
+def lstm_assemble_inputs(x, ldx, feat, num_actions, reward, prev_actions, clip_reward, rows):
+  with _dev(x):
+    _lib.check(_lib.lib().seedhip_lstm_assemble_inputs(
+        _lib.ptr(x), ldx, feat, num_actions, _lib.ptr(reward), _lib.ptr(prev_actions), prev_actions.element_size(),
+        int(clip_reward), rows, _lib.stream()), 'seedhip_lstm_assemble_inputs')
+
+
+def lstm_mask_state(h0, c0, done0_u8, B, H, hin, cin):
+  with _dev(hin):
+    _lib.check(_lib.lib().seedhip_lstm_mask_state(_lib.ptr(h0), _lib.ptr(c0), _lib.ptr(done0_u8), B, H, _lib.ptr(hin),
+                                                  _lib.ptr(cin), _lib.stream()), 'seedhip_lstm_mask_state')
+
+
+def lstm_gates_fwd(z, cin, done_next_u8, B, H, h_out, ld_h, hin_next, cin_next):
+  with _region('lstm_gates_fwd', 0, B * H * 4 * 8):
+    with _dev(h_out):
+      _lib.check(_lib.lib().seedhip_lstm_gates_fwd(
+          _lib.ptr(z), _lib.ptr(cin), _lib.ptr(done_next_u8), B, H, _lib.ptr(h_out), ld_h, _lib.ptr(hin_next),
+          _lib.ptr(cin_next), _lib.stream()), 'seedhip_lstm_gates_fwd')
+
+
+def lstm_gates_bwd(z, cin, dh_out, ld_dh, dh_rec, dc_rec, done_next_u8, B, H, dz, dc_prev):
+  with _region('lstm_gates_bwd', 0, B * H * 4 * 13):
+    with _dev(dz):
+      _lib.check(_lib.lib().seedhip_lstm_gates_bwd(
+          _lib.ptr(z), _lib.ptr(cin), _lib.ptr(dh_out), ld_dh, _lib.ptr(dh_rec), _lib.ptr(dc_rec),
+          _lib.ptr(done_next_u8), B, H, _lib.ptr(dz), _lib.ptr(dc_prev), _lib.stream()), 'seedhip_lstm_gates_bwd')

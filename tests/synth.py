@@ -57,3 +57,18 @@ def atari_unroll(seed, T1=21, B=4, A=18, H=84, W=84, done_p=0.01, zero_state=Tru
   beh_baseline = rng.normal(size=(T1, B)).astype(np.float32)
   return dict(frames=frames, frame_state=state, done=done, prev_actions=prev_actions, actions=actions,
               reward=reward, behaviour_logits=beh_logits, behaviour_baseline=beh_baseline)
+
+
+def dmlab_unroll(seed, T1=21, B=4, A=9, H=72, W=96, done_p=0.05, H_lstm=256):
+  """cfg3-shaped unroll: uint8 RGB frames, LSTM initial state ~N(0,0.1)."""
+  rng = np.random.default_rng(seed)
+  return dict(
+      frames=rng.integers(0, 256, (T1, B, H, W, 3)).astype(np.uint8),
+      done=rng.uniform(size=(T1, B)) < done_p,
+      prev_actions=rng.integers(0, A, (T1, B)).astype(np.int64),
+      actions=rng.integers(0, A, (T1, B)).astype(np.int64),
+      reward=(2 * rng.normal(size=(T1, B))).astype(np.float32),
+      behaviour_logits=rng.normal(size=(T1, B, A)).astype(np.float32),
+      behaviour_baseline=rng.normal(size=(T1, B)).astype(np.float32),
+      h0=(0.1 * rng.normal(size=(B, H_lstm))).astype(np.float32),
+      c0=(0.1 * rng.normal(size=(B, H_lstm))).astype(np.float32))

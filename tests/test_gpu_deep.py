@@ -1,0 +1,118 @@
+"""GPU parity of the ImpalaDeep path (dmlab/networks.py) -- max-pool, LSTM unroll with done-reset, and the
+whole train step -- vs the torch-CPU fp32 oracle (oracle/nets_torch.py) on identical seeded inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import nets_torch
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _to(device, a):
+  return torch.as_tensor(np.ascontiguousarray(a)).to(device)
+
+
+@pytest.mark.parametrize('n,ih,iw,c', [(2, 72, 96, 16), (3, 36, 48, 32), (2, 9, 12, 32), (2, 7, 5, 4), (1, 1, 1, 8)])
+def test_maxpool_same_parity(device, n, ih, iw, c):
+  """TF 'SAME' 3x3/2 max-pool (asymmetric padding for even sizes) forward: exact; backward: exact
+  (gradient routed to the window argmax)."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(n * 100 + ih)
+  x = rng.normal(size=(n, ih, iw, c)).astype(np.float32)
+  xt = torch.tensor(x, requires_grad=True)
+  y = nets_torch.max_pool_3x3_s2_same(xt)
+  dy = rng.normal(size=tuple(y.shape)).astype(np.float32)
+  y.backward(torch.tensor(dy))
+  oh, ow = (ih + 1) // 2, (iw + 1) // 2
+  yd = torch.empty((n, oh, ow, c), device=device)
+  arg = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=device)
+  ops.maxpool_fwd(_to(device, x), yd, arg)
+  np.testing.assert_array_equal(yd.cpu().numpy(), y.detach().numpy())
+  dx = torch.full((n, ih, iw, c), 7.0, device=device)
+  ops.maxpool_bwd(_to(device, dy), arg, dx)
+  np.testing.assert_allclose(dx.cpu().numpy(), xt.grad.numpy(), rtol=0, atol=1e-6)
+
+
+def _deep_unroll(device, u):
+  from seed_rl_amd import learner, networks, utils
+  T1, B = u['done'].shape
+  env = utils.EnvOutput(reward=_to(device, u['reward']), done=_to(device, u['done']),
+                        observation=_to(device, u['frames']),
+                        abandoned=torch.zeros((T1, B), dtype=torch.bool, device=device),
+                        episode_step=torch.ones((T1, B), dtype=torch.int32, device=device))
+  ao = networks.AgentOutput(_to(device, u['actions']), _to(device, u['behaviour_logits']),
+                            _to(device, u['behaviour_baseline']))
+  return learner.Unroll((_to(device, u['h0']), _to(device, u['c0'])), _to(device, u['prev_actions']), env, ao)
+
+
+@pytest.mark.parametrize('T1,B,A,obs', [(5, 3, 9, (72, 96, 3)), (21, 2, 9, (72, 96, 3)), (4, 5, 6, (24, 32, 3))])
+def test_impala_deep_train_step_parity(device, T1, B, A, obs):
+  """ImpalaDeep unroll -> fused loss -> backward (BPTT through the LSTM with done-reset, residual stacks,
+  max-pool) -> Adam vs the oracle graph.  Tolerances: logits/baseline 3e-4 abs; gradients 1e-3 of each tensor's
+  max (15 conv layers + 21 recurrent steps of fp32 re-association); parameters after one Adam step 5e-5."""
+  from seed_rl_amd import learner, networks, optimizers, parametric_distribution as pd
+  u = synth.dmlab_unroll(7, T1, B, A, H=obs[0], W=obs[1], done_p=0.15)
+  agent = networks.ImpalaDeep(A, observation_shape=obs, device=device, seed=3)
+  assert len(agent.trainable_variables) == 39                       # tests/agents_test.py:45
+  if obs == (72, 96, 3) and A == 9:
+    assert agent.flat.num_params() - (agent._ldh - A - 1) * (agent._H + 1) == 1520714
+  ref_params = nets_torch.init_params(nets_torch.param_spec('impala_deep', A, obs), seed=3)
+  for (n, v) in agent.trainable_variables:
+    np.testing.assert_array_equal(v.cpu().numpy(), ref_params[n])
+  cfg = learner.LossConfig(lambda_=0.95, max_abs_reward=1.0)
+  opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, 100), beta_1=0.0, epsilon=3.125e-7)
+  lrn = learner.Learner(agent, opt, pd.categorical_distribution(A), config=cfg)
+  unroll = _deep_unroll(device, u)
+  loss, session = learner.compute_loss(None, lrn.dist, agent, *unroll, config=cfg, want_vtrace=True)
+  agent.backward()
+  head, _, ldh = agent.head_buffers()
+  head = head.cpu().numpy().reshape(T1, B, ldh)
+
+  p = nets_torch.to_torch(ref_params, requires_grad=True)
+  logits, baseline, state = nets_torch.impala_deep_unroll(
+      p, A, torch.tensor(u['prev_actions']), torch.tensor(u['reward']), torch.tensor(u['done']),
+      torch.tensor(u['frames']), (torch.tensor(u['h0']), torch.tensor(u['c0'])))
+  total, aux = nets_torch.impala_loss_torch(
+      logits, baseline, torch.tensor(u['behaviour_logits']), torch.tensor(u['actions']),
+      torch.tensor(u['reward']), torch.tensor(u['done']), entropy_cost=0.00025, lambda_=0.95, max_abs_reward=1.0)
+  total.backward()
+  assert np.max(np.abs(head[..., :A] - logits.detach().numpy())) < 3e-4
+  assert np.max(np.abs(head[..., A] - baseline.detach().numpy())) < 3e-4
+  assert abs(float(loss) - float(total.detach())) < 2e-4 * max(1.0, abs(float(total.detach())))
+  # final LSTM state handed to the next unroll
+  _, st = agent(unroll.prev_actions, unroll.env_outputs, unroll.agent_state, unroll=True, is_training=True)
+  assert np.max(np.abs(st[0].cpu().numpy() - state[0].detach().numpy())) < 2e-4
+  assert np.max(np.abs(st[1].cpu().numpy() - state[1].detach().numpy())) < 2e-4
+  grads = agent.reference_gradients()
+  for n, t in p.items():
+    g, r = grads[n].cpu().numpy(), t.grad.numpy()
+    assert np.max(np.abs(g - r)) <= 1e-3 * max(np.abs(r).max(), 1e-3), n
+  lrn.apply_gradients()
+  kopt = nets_torch.KerasAdam(list(p.values()), nets_torch.polynomial_decay(4.8e-4, 100), beta_1=0.0,
+                              epsilon=3.125e-7)
+  kopt.apply_gradients([t.grad for t in p.values()])
+  for (n, v), t in zip(agent.trainable_variables, p.values()):
+    assert np.max(np.abs(v.cpu().numpy() - t.detach().numpy())) < 5e-5, n
+
+
+def test_impala_deep_single_step_inference(device):
+  """unroll=False (central inference, learner.py:386-390) == first step of the unroll; state carried."""
+  from seed_rl_amd import networks, utils
+  A = 9
+  u = synth.dmlab_unroll(2, 3, 4, A, H=24, W=32)
+  agent = networks.ImpalaDeep(A, observation_shape=(24, 32, 3), device=device, seed=1)
+  st = (_to(device, u['h0']), _to(device, u['c0']))
+  env1 = utils.EnvOutput(_to(device, u['reward'][0]), _to(device, u['done'][0]), _to(device, u['frames'][0]), None, None)
+  out1, st1 = agent(_to(device, u['prev_actions'][0]), env1, st)
+  l1, b1 = out1.policy_logits.clone(), out1.baseline.clone()
+  assert out1.action.shape == (4,) and int(out1.action.max()) < A
+  envT = utils.EnvOutput(_to(device, u['reward']), _to(device, u['done']), _to(device, u['frames']), None, None)
+  outT, _ = agent(_to(device, u['prev_actions']), envT, st, unroll=True, is_training=True)
+  assert torch.allclose(l1, outT.policy_logits[0], atol=1e-5) and torch.allclose(b1, outT.baseline[0], atol=1e-5)
+  # second single step from the carried state == second unroll step
+  env2 = utils.EnvOutput(_to(device, u['reward'][1]), _to(device, u['done'][1]), _to(device, u['frames'][1]), None, None)
+  out2, _ = agent(_to(device, u['prev_actions'][1]), env2, st1)
+  assert torch.allclose(out2.policy_logits, outT.policy_logits[1], atol=1e-5)
