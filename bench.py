@@ -34,9 +34,11 @@ def parse():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=20)
   ap.add_argument('--warmup', type=int, default=5)
-  ap.add_argument('--batch', type=int, default=512, help='per-GPU batch columns B')
+  ap.add_argument('--batch', type=int, default=0, help='per-GPU batch columns B (default 512 atari / 256 dmlab)')
   ap.add_argument('--unroll', type=int, default=20, help='T')
-  ap.add_argument('--actions', type=int, default=18)
+  ap.add_argument('--actions', type=int, default=0, help='default 18 atari / 9 dmlab')
+  ap.add_argument('--config', default='atari', choices=['atari', 'dmlab'],
+                  help='atari = BASELINE configs[1] (headline); dmlab = configs[2] (ImpalaDeep + LSTM, B=256)')
   ap.add_argument('--torso', default='shallow', choices=['shallow', 'dqn'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-batch', type=int, default=64)
@@ -95,18 +97,27 @@ def main():
   assert world == args.gpus or world == 1, 'launch with torchrun for --gpus > 1'
 
   from seed_rl_amd import learner, networks, ops, optimizers, parametric_distribution as pd, smoke_step
-  T, B, A = args.unroll, args.batch, args.actions
+  deep = args.config == 'dmlab'
+  T = args.unroll
+  B = args.batch or (256 if deep else 512)
+  A = args.actions or (9 if deep else 18)
   T1 = T + 1
-  agent = networks.AtariShallow(A, torso=args.torso, device=dev, seed=0)      # identical params on all ranks
   final_iteration = 10 ** 9 // (T * B * max(world, 1))
   opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, final_iteration), beta_1=0.0, epsilon=3.125e-7)
+  if deep:
+    agent = networks.ImpalaDeep(A, device=dev, seed=0)                          # identical params on all ranks
+    unroll = smoke_step.make_deep_unroll(agent, T1, B, A, dev, seed=1000 + rank)
+    workload = 'DeepMind Lab 72x96x3 IMPALA deep ResNet + LSTM(256) learner step'
+  else:
+    agent = networks.AtariShallow(A, torso=args.torso, device=dev, seed=0)
+    unroll = smoke_step.make_unroll(agent, T1, B, A, dev, seed=1000 + rank)
+    # place the frames directly in the agent's extended trajectory buffer (no per-step copy)
+    ext = agent.frames_buffer(T1, B)
+    ext[3:].copy_(unroll.env_outputs.observation.reshape(T1, B, -1))
+    unroll = unroll._replace(env_outputs=unroll.env_outputs._replace(
+        observation=ext[3:].view(T1, B, agent._obs[0], agent._obs[1], 1)))
+    workload = 'Atari 84x84x4 IMPALA %s ConvNet learner step' % args.torso
   lrn = learner.Learner(agent, opt, pd.categorical_distribution(A), reduction=args.reduction)
-  unroll = smoke_step.make_unroll(agent, T1, B, A, dev, seed=1000 + rank)
-  # place the frames directly in the agent's extended trajectory buffer (no per-step copy)
-  ext = agent.frames_buffer(T1, B)
-  ext[3:].copy_(unroll.env_outputs.observation.reshape(T1, B, -1))
-  unroll = unroll._replace(env_outputs=unroll.env_outputs._replace(
-      observation=ext[3:].view(T1, B, agent._obs[0], agent._obs[1], 1)))
 
   def barrier():
     if world > 1:
@@ -123,7 +134,7 @@ def main():
   kern = prof_all.summary()
   dominant = max(kern, key=lambda k: kern[k]['total_ms'])
   if args.warmup == 0:
-    dominant = 'stack_conv_fwd'
+    dominant = sorted(kern)[0]
 
   # ---- timed region: exactly K steps, barrier + sync on both sides ----
   prof = ops.Profiler(only=[dominant])
@@ -163,8 +174,8 @@ def main():
       'metric': 'learner env-frames/s (T=20)', 'value': round(frames_per_s, 1), 'unit': 'env-frames/s',
       'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-      'config': {'workload': 'Atari 84x84x4 IMPALA %s ConvNet learner step, T=%d B=%d/GPU A=%d, '
-                             'synthetic uint8 frames in HBM, num_action_repeats=1' % (args.torso, T, B, A),
+      'config': {'workload': '%s, T=%d B=%d/GPU A=%d, synthetic uint8 frames in HBM, num_action_repeats=1'
+                             % (workload, T, B, A),
                  'global_batch': B * world, 'unroll_length': T, 'parallelism': 'dp%d' % world,
                  'grad_reduction': args.reduction, 'params': agent.flat.num_params()},
       'roofline': roofline,
@@ -177,13 +188,18 @@ def main():
     result['vtrace_scan_hbm'] = sweep
     if not args.no_cpu_baseline:
       from oracle import cpu_learner
-      kind = 'atari_shallow' if args.torso == 'shallow' else 'atari_dqn_body'
-      fps, sec, thr = cpu_learner.time_cpu_learner(kind, A, T1, args.cpu_batch, steps=3, warmup=1)
+      if deep:
+        cb = args.cpu_batch if args.cpu_batch != 64 else 16
+        fps, sec, thr = cpu_learner.time_cpu_deep_learner(A, T1, cb, steps=2, warmup=1)
+      else:
+        cb = args.cpu_batch
+        kind = 'atari_shallow' if args.torso == 'shallow' else 'atari_dqn_body'
+        fps, sec, thr = cpu_learner.time_cpu_learner(kind, A, T1, cb, steps=3, warmup=1)
       result['cpu_baseline'] = {
           'value': round(fps, 1), 'unit': 'env-frames/s', 'cores': thr, 'kind': 'port',
           'sample': 'same learner step as eager PyTorch-CPU fp32 restatement of the reference graph '
-                    '(oracle/cpu_learner.py), T=%d B=%d (per-frame cost is B-independent), median of 3 '
-                    'steps, %.2f s/step; host cpu_count=%d' % (T, args.cpu_batch, sec, os.cpu_count())}
+                    '(oracle/cpu_learner.py), T=%d B=%d (per-frame cost is B-independent), median of timed '
+                    'steps, %.2f s/step; host cpu_count=%d' % (T, cb, sec, os.cpu_count())}
       result['speedup_vs_cpu_baseline'] = round(frames_per_s / fps, 1)
   print(json.dumps(result))
   if world > 1:

@@ -53,3 +53,40 @@ def time_cpu_learner(kind, num_actions, T1, B, steps=3, warmup=1, threads=None, 
     ts.append(time.perf_counter() - t0)
   sec = float(np.median(ts))
   return (T1 - 1) * B / sec, sec, torch.get_num_threads()
+
+
+class CpuDeepLearner(object):
+  """ImpalaDeep (dmlab/networks.py) learner step, eager PyTorch-CPU fp32."""
+
+  def __init__(self, num_actions, obs=(72, 96, 3), seed=0, lr=4.8e-4, decay_steps=10000):
+    self.A = num_actions
+    self.params = nets_torch.to_torch(
+        nets_torch.init_params(nets_torch.param_spec('impala_deep', num_actions, obs), seed), requires_grad=True)
+    self.opt = nets_torch.KerasAdam(list(self.params.values()), nets_torch.polynomial_decay(lr, decay_steps),
+                                    beta_1=0.0, epsilon=3.125e-7)
+
+  def step(self, u, **loss_kw):
+    for p in self.params.values():
+      p.grad = None
+    logits, baseline, _ = nets_torch.impala_deep_unroll(
+        self.params, self.A, u['prev_actions'], u['reward'], u['done'], u['frames'], (u['h0'], u['c0']))
+    total, _ = nets_torch.impala_loss_torch(logits, baseline, u['behaviour_logits'], u['actions'], u['reward'],
+                                            u['done'], **loss_kw)
+    total.backward()
+    self.opt.apply_gradients([p.grad for p in self.params.values()])
+    return float(total.detach())
+
+
+def time_cpu_deep_learner(num_actions, T1, B, steps=3, warmup=1, seed=0):
+  from tests import synth
+  u = {k: torch.as_tensor(v) for k, v in synth.dmlab_unroll(seed, T1, B, num_actions).items()}
+  lrn = CpuDeepLearner(num_actions, seed=seed)
+  for _ in range(warmup):
+    lrn.step(u)
+  ts = []
+  for _ in range(steps):
+    t0 = time.perf_counter()
+    lrn.step(u)
+    ts.append(time.perf_counter() - t0)
+  sec = float(np.median(ts))
+  return (T1 - 1) * B / sec, sec, torch.get_num_threads()
