@@ -3,6 +3,7 @@
 #include "common.h"
 #include "conv_problems.h"
 #include "conv_launch.h"
+#include "halo_wgrad.h"
 #include "../../include/seedhip.h"
 
 using namespace seedhip;
@@ -63,7 +64,9 @@ extern "C" size_t seedhip_conv2d_bwd_weight_workspace_bytes(const seedhip_conv_g
   const long long pixels = (long long)g->n_img * g->oh * g->ow;
   const int per = pick_k_per_slice(pixels, tiles_for(M, N));
   const long long slices = (pixels + per - 1) / per;
-  return (size_t)slices * ((size_t)M * N + N) * sizeof(float);
+  const size_t generic = (size_t)slices * ((size_t)M * N + N) * sizeof(float);
+  const halo::WgradPlan pl = halo::plan_wgrad(g);
+  return (pl.ok && pl.ws_bytes > generic) ? pl.ws_bytes : generic;
 }
 
 extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const void* in, int in_dtype, int in_relu,
@@ -74,6 +77,12 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
   SEEDHIP_REQUIRE(in_dtype == kInF32 || in_dtype == kInU8Div255, "conv2d_bwd_weight: bad in_dtype %d", in_dtype);
   SEEDHIP_REQUIRE(workspace_bytes >= seedhip_conv2d_bwd_weight_workspace_bytes(geom),
                   "conv2d_bwd_weight: workspace too small");
+  {
+    // 3x3 stride-1 layers: input band + halo staged once per tile in LDS (halo_wgrad.h)
+    const halo::WgradPlan pl = halo::plan_wgrad(geom);
+    if (pl.ok && (((uintptr_t)in) & 15) == 0 && (((uintptr_t)dy) & 15) == 0)
+      return halo::launch_wgrad(geom, pl, in, in_dtype, in_relu, dy, dw, dbias, workspace, (hipStream_t)stream);
+  }
   ConvWgrad p;
   p.in = in; p.in_dtype = in_dtype; p.in_relu = in_relu; p.dy = dy;
   const int M = geom->kh * geom->kw * geom->cin, N = geom->cout;

@@ -298,6 +298,9 @@ CONV_CASES = [
     (300, 1, 1, 256, 1, 1, 1, 'valid', 20),   # heads (A=18 -> ld 20)
     (70, 1, 1, 268, 1, 1, 1, 'valid', 1024),  # LSTM input projection
     (3, 11, 9, 8, 5, 3, 2, 'valid', 12),      # odd shape
+    (2, 10, 14, 64, 3, 3, 1, 'valid', 64),    # halo wgrad, 4-way row split (ow % 4 == 0)
+    (3, 13, 20, 32, 3, 3, 1, 'same', 16),     # halo wgrad, 2-way row split, partial last band
+    (70, 9, 12, 32, 3, 3, 1, 'same', 32),     # ImpalaDeep stack2 res conv, many images per workgroup
 ]
 
 
