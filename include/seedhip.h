@@ -174,6 +174,25 @@ int seedhip_lstm_gates_bwd(const float* z, const float* cin, const float* dh_out
                            const float* dc_rec, const uint8_t* done_next, int B, int H, float* dz, float* dc_prev,
                            void* stream);
 
+/* ---- R2D2: dueling head + n-step double-Q loss ---------------------------------------------------
+ * dueling_fwd/bwd replace atari/networks.py:273-285 (_head): va [rows, ld] holds the advantage head
+ * output in columns 0..A-1 and the value head output in column A; q = value + adv - mean(adv),
+ * action = argmax(q) (int32, may be NULL).  bwd: d_va from dq (same layout, pad columns zeroed).
+ * r2d2_loss_fwd_bwd replaces agents/r2d2/learner.py:258-330 + the `reduce_mean(loss * importance_weights)`
+ * of :604 and its gradient wrt training_q: inputs are the post-burn-in [T,B,...] tensors; actions int32;
+ * n-step double-Q Bellman target with value rescaling (epsilon = --value_function_rescaling_epsilon);
+ * outputs loss_per_sequence [B], priorities [B], d_training_q [T,B,A], total_loss [1]
+ * (= sum_b loss_b * w_b / mean_denominator; importance_weights NULL = 1). */
+int seedhip_dueling_fwd(const float* va, int ld, long long rows, int A, float* q, int* action, void* stream);
+int seedhip_dueling_bwd(const float* dq, long long rows, int A, float* d_va, int ld, void* stream);
+size_t seedhip_r2d2_loss_workspace_bytes(int T, int B, int n_steps);
+int seedhip_r2d2_loss_fwd_bwd(const float* training_q, const float* target_q, const int* actions,
+                              const float* rewards, const uint8_t* done, const float* importance_weights,
+                              int T, int B, int A, float gamma, int n_steps, float eta, float epsilon,
+                              float mean_denominator, float* loss_per_sequence, float* priorities,
+                              float* d_training_q, float* total_loss, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -370,3 +370,29 @@ def polynomial_decay(lr0, decay_steps, end_lr=0.0, power=1.0):
     s = min(step, decay_steps)
     return (lr0 - end_lr) * (1 - s / decay_steps) ** power + end_lr
   return fn
+
+
+def r2d2_loss_torch(training_q, target_q, actions, rewards, done, importance_weights=None, gamma=0.997,
+                    n_steps=5, eta=0.9, eps=1e-3):
+  """agents/r2d2/learner.py:258-330 + :604 in torch (differentiable wrt training_q)."""
+  def h(x):
+    return torch.sign(x) * (torch.sqrt(torch.abs(x) + 1.) - 1.) + eps * x
+  def h_inv(x):
+    return torch.sign(x) * (torch.square((torch.sqrt(1. + 4. * eps * (torch.abs(x) + 1. + eps)) - 1.) / (2. * eps)) - 1.)
+  T, B, A = training_q.shape
+  act = actions.long()
+  replay_q = training_q.gather(-1, act[..., None])[..., 0]
+  best = training_q.argmax(-1)
+  qmax = h_inv(target_q.gather(-1, best[..., None])[..., 0])
+  bt = torch.cat([torch.zeros_like(qmax[0:1]), qmax] + [qmax[-1:] / gamma ** k for k in range(1, n_steps)], 0)
+  d = torch.cat([done] + [torch.zeros_like(done[0:1])] * n_steps, 0)
+  r = torch.cat([rewards] + [torch.zeros_like(rewards[0:1])] * n_steps, 0)
+  for _ in range(n_steps):
+    r, d = r[:-1], d[:-1]
+    bt = r + gamma * (1. - d.float()) * bt[1:]
+  bt = h(bt[1:].detach())
+  abs_td = torch.abs(bt - replay_q[:-1])
+  prio = eta * abs_td.max(0)[0] + (1 - eta) * abs_td.mean(0)
+  loss = 0.5 * torch.sum(abs_td ** 2, 0)
+  w = torch.ones(B) if importance_weights is None else importance_weights
+  return (loss * w).mean(), loss, prio

@@ -64,6 +64,12 @@ SIGNATURES = {
     'seedhip_lstm_mask_state': (c_int, [P, P, P, c_int, c_int, P, P, P]),
     'seedhip_lstm_gates_fwd': (c_int, [P, P, P, c_int, c_int, P, c_int, P, P, P]),
     'seedhip_lstm_gates_bwd': (c_int, [P, P, P, c_int, P, P, P, c_int, c_int, P, P, P]),
+    'seedhip_dueling_fwd': (c_int, [P, c_int, c_ll, c_int, P, P, P]),
+    'seedhip_dueling_bwd': (c_int, [P, c_ll, c_int, P, c_int, P]),
+    'seedhip_r2d2_loss_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'seedhip_r2d2_loss_fwd_bwd':
+        (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, c_float, c_float, c_float,
+                 P, P, P, P, P, c_size_t, P]),
 }
 
 

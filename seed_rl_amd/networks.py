@@ -81,9 +81,11 @@ class _Agent(object):
       if name.startswith('policy_logits/') or name.startswith('baseline/'):
         continue
       internal.append((name, shape))
-    feat = dict((n, s) for n, s, _ in ref_spec)['policy_logits/kernel'][0]
-    internal.append(('heads/kernel', (feat, self._ldh)))
-    internal.append(('heads/bias', (self._ldh,)))
+    shapes = dict((n, s) for n, s, _ in ref_spec)
+    if 'policy_logits/kernel' in shapes:
+      feat = shapes['policy_logits/kernel'][0]
+      internal.append(('heads/kernel', (feat, self._ldh)))
+      internal.append(('heads/bias', (self._ldh,)))
     self.flat = FlatParams(internal, self.device)
     self.load_reference_params(keras_init(ref_spec, seed))
 
@@ -227,30 +229,104 @@ class _Agent(object):
                ops.conv2d_bwd_weight_workspace_bytes(L['gx']))
 
 
-class AtariShallow(_Agent):
+class _AtariTorso(object):
+  """Learner-side frame stacking (atari/networks.py:57-173) + /255 (:330) + VALID conv body + Dense(ReLU):
+  shared by AtariShallow and DuelingLSTMDQNNet.  The first conv reads the uint8 frames directly."""
+
+  def _torso_init(self, observation_shape, convs, fc, prefix=''):
+    h, w, c = observation_shape
+    if c != 1:
+      raise ValueError('frame stacking needs a single-channel observation (atari/networks.py:86-88)')
+    self._obs = (h, w)
+    self._convs, self._fc, self._tp = convs, fc, prefix
+    spec, cin = [], 4
+    self._shapes = []                       # (ih, iw, cin, k, s, cout, oh, ow)
+    for i, (k, s, ch) in enumerate(convs):
+      spec += [('%sconv%d/kernel' % (prefix, i), (k, k, cin, ch), 'glorot'), ('%sconv%d/bias' % (prefix, i), (ch,), 'zeros')]
+      oh, ow = (h - k) // s + 1, (w - k) // s + 1
+      self._shapes.append((h, w, cin, k, s, ch, oh, ow))
+      h, w, cin = oh, ow, ch
+    self._flat_dim = h * w * cin
+    spec += [(prefix + 'fc/kernel', (self._flat_dim, fc), 'glorot'), (prefix + 'fc/bias', (fc,), 'zeros')]
+    return spec
+
+  def frames_buffer(self, T1, B):
+    """uint8 [3+T1, B, H*W] trajectory buffer; rows 3.. are the unroll's frames.  A data
+    pipeline can write observations straight into `frames_buffer(T1,B)[3:]` (time-major)
+    and pass that view as env_outputs.observation: no copy is made then."""
+    return self._buf('frames_ext', (T1 + 3, B, self._obs[0] * self._obs[1]), torch.uint8, zero=True)
+
+  def _torso_fwd(self, obs, done_u8, frame_state, out, ld_out):
+    """obs uint8 [T1,B,H,W,1]; writes relu(fc) into out[:, :fc] (row stride ld_out).  Returns the new
+    frame-stacking state and the context the backward needs."""
+    T1, B = done_u8.shape[0], done_u8.shape[1]
+    H, W = self._obs
+    HW, N = H * W, T1 * B
+    fl, tp = self.flat, self._tp
+    ext = self.frames_buffer(T1, B)
+    fr = obs.reshape(T1, B, HW)
+    if fr.dtype != torch.uint8:
+      raise ValueError('observations must be uint8 frames')
+    if fr.data_ptr() != ext[3:].data_ptr():
+      ext[3:].copy_(fr)
+    nvalid = self._buf('nvalid', (T1, B), torch.uint8)
+    ops.stack_prepare(frame_state.contiguous(), done_u8, T1, B, HW, ext, nvalid)
+    acts, geoms = [], []
+    ih, iw, cin, k, s, ch, oh, ow = self._shapes[0]
+    g0 = ops.StackConvGeom(T1, B, ih, iw, oh, ow, k, k, s, ch, ch)
+    a = self._buf('act0', (N, oh, ow, ch))
+    ops.conv2d_stack_fwd(g0, ext, nvalid, fl.p(tp + 'conv0/kernel'), fl.p(tp + 'conv0/bias'), a, out_relu=True)
+    acts.append(a); geoms.append(g0)
+    for i in range(1, len(self._shapes)):
+      ih, iw, cin, k, s, ch, oh, ow = self._shapes[i]
+      g = ops.conv_geom(N, ih, iw, cin, k, k, s, 'valid', ch)
+      a2 = self._buf('act%d' % i, (N, oh, ow, ch))
+      ops.conv2d_fwd(g, a, fl.p('%sconv%d/kernel' % (tp, i)), fl.p('%sconv%d/bias' % (tp, i)), a2, out_relu=True)
+      acts.append(a2); geoms.append(g); a = a2
+    gfc = ops.dense_geom(N, self._flat_dim, self._fc, ld_out=ld_out)
+    ops.conv2d_fwd(gfc, a, fl.p(tp + 'fc/kernel'), fl.p(tp + 'fc/bias'), out, out_relu=True)
+    new_fs = torch.empty_like(frame_state)
+    ops.stack_pack_state(ext, nvalid, T1, B, HW, new_fs)
+    return new_fs, dict(ext=ext, nvalid=nvalid, acts=acts, geoms=geoms, gfc=gfc)
+
+  def _torso_bwd(self, ctx, dz, wsb):
+    """dz: gradient wrt the Dense pre-activation (already masked by its ReLU), row stride = gfc.ld_out."""
+    fl, tp = self.flat, self._tp
+    acts, geoms, gfc = ctx['acts'], ctx['geoms'], ctx['gfc']
+    a_last = acts[-1]
+    ops.conv2d_bwd_weight(gfc, a_last, dz, fl.g(tp + 'fc/kernel'), fl.g(tp + 'fc/bias'), wsb)
+    da = self._buf('d_act%d' % (len(acts) - 1), tuple(a_last.shape))
+    ops.conv2d_bwd_data(gfc, dz, fl.p(tp + 'fc/kernel'), da, relu_mask=a_last)
+    for i in range(len(acts) - 1, 0, -1):
+      g, a_in = geoms[i], acts[i - 1]
+      ops.conv2d_bwd_weight(g, a_in, da, fl.g('%sconv%d/kernel' % (tp, i)), fl.g('%sconv%d/bias' % (tp, i)), wsb)
+      d_in = self._buf('d_act%d' % (i - 1), tuple(a_in.shape))
+      ops.conv2d_bwd_data(g, da, fl.p('%sconv%d/kernel' % (tp, i)), d_in, relu_mask=a_in)
+      da = d_in
+    # first conv: weight gradient straight from the uint8 frames
+    ws0 = self._buf('stack_ws', (ops.conv2d_stack_bwd_weight_workspace_bytes(geoms[0]) // 4 + 4,))
+    ops.conv2d_stack_bwd_weight(geoms[0], ctx['ext'], ctx['nvalid'], da, fl.g(tp + 'conv0/kernel'),
+                                fl.g(tp + 'conv0/bias'), ws0)
+
+  def _torso_ws_bytes(self, ctx):
+    need = ops.conv2d_bwd_weight_workspace_bytes(ctx['gfc'])
+    for g in ctx['geoms'][1:]:
+      need = max(need, ops.conv2d_bwd_weight_workspace_bytes(g))
+    return need
+
+
+class AtariShallow(_Agent, _AtariTorso):
   """Frame-stacked Atari policy/value agent (see module docstring, D1)."""
 
   def __init__(self, num_actions, observation_shape=(84, 84, 1), torso='shallow', device='cuda', seed=0,
                entropy_cost=0.00025):
     super(AtariShallow, self).__init__(num_actions, device)
-    h, w, c = observation_shape
-    if c != 1:
-      raise ValueError('frame stacking needs a single-channel observation (atari/networks.py:86-88)')
-    self._obs = (h, w)
-    self._convs = [(8, 4, 16), (4, 2, 32)] if torso == 'shallow' else [(8, 4, 32), (4, 2, 64), (3, 1, 64)]
-    self._fc = 256 if torso == 'shallow' else 512
+    convs = [(8, 4, 16), (4, 2, 32)] if torso == 'shallow' else [(8, 4, 32), (4, 2, 64), (3, 1, 64)]
+    fc = 256 if torso == 'shallow' else 512
     self._entropy_cost = entropy_cost
-    spec, cin = [], 4
-    self._shapes = []                       # (ih, iw, cin, k, s, cout, oh, ow)
-    for i, (k, s, ch) in enumerate(self._convs):
-      spec += [('conv%d/kernel' % i, (k, k, cin, ch), 'glorot'), ('conv%d/bias' % i, (ch,), 'zeros')]
-      oh, ow = (h - k) // s + 1, (w - k) // s + 1
-      self._shapes.append((h, w, cin, k, s, ch, oh, ow))
-      h, w, cin = oh, ow, ch
-    self._flat_dim = h * w * cin
-    spec += [('fc/kernel', (self._flat_dim, self._fc), 'glorot'), ('fc/bias', (self._fc,), 'zeros'),
-             ('policy_logits/kernel', (self._fc, num_actions), 'glorot'), ('policy_logits/bias', (num_actions,), 'zeros'),
-             ('baseline/kernel', (self._fc, 1), 'glorot'), ('baseline/bias', (1,), 'zeros')]
+    spec = self._torso_init(observation_shape, convs, fc)
+    spec += [('policy_logits/kernel', (fc, num_actions), 'glorot'), ('policy_logits/bias', (num_actions,), 'zeros'),
+             ('baseline/kernel', (fc, 1), 'glorot'), ('baseline/bias', (1,), 'zeros')]
     self._build_params(spec, seed)
     self._last = None
 
@@ -262,52 +338,18 @@ class AtariShallow(_Agent):
     return AgentState(core_state=(), frame_stacking_state=torch.zeros((batch_size, hw), dtype=torch.int32,
                                                                       device=self.device))
 
-  def frames_buffer(self, T1, B):
-    """uint8 [3+T1, B, H*W] trajectory buffer; rows 3.. are the unroll's frames.  A data
-    pipeline can write observations straight into `frames_buffer(T1,B)[3:]` (time-major)
-    and pass that view as env_outputs.observation: no copy is made then."""
-    return self._buf('frames_ext', (T1 + 3, B, self._obs[0] * self._obs[1]), torch.uint8, zero=True)
-
   def __call__(self, prev_actions, env_outputs, agent_state, unroll=False, is_training=False):
     del prev_actions   # the feed-forward agent does not consume it
     obs, done = env_outputs.observation, env_outputs.done
     if not unroll:
       obs, done = obs[None], done[None]
     T1, B = done.shape[0], done.shape[1]
-    H, W = self._obs
-    HW = H * W
     N = T1 * B
-    ext = self.frames_buffer(T1, B)
-    fr = obs.reshape(T1, B, HW)
-    if fr.dtype != torch.uint8:
-      raise ValueError('observations must be uint8 frames')
-    if fr.data_ptr() != ext[3:].data_ptr():
-      ext[3:].copy_(fr)
-    nvalid = self._buf('nvalid', (T1, B), torch.uint8)
     done_u8 = done.to(torch.uint8).contiguous()
-    ops.stack_prepare(agent_state.frame_stacking_state.contiguous(), done_u8, T1, B, HW, ext, nvalid)
-
-    acts = []
-    ih, iw, cin, k, s, ch, oh, ow = self._shapes[0]
-    g0 = ops.StackConvGeom(T1, B, ih, iw, oh, ow, k, k, s, ch, ch)
-    a = self._buf('act0', (N, oh, ow, ch))
-    ops.conv2d_stack_fwd(g0, ext, nvalid, self.flat.p('conv0/kernel'), self.flat.p('conv0/bias'), a, out_relu=True)
-    acts.append(a)
-    geoms = [g0]
-    for i in range(1, len(self._shapes)):
-      ih, iw, cin, k, s, ch, oh, ow = self._shapes[i]
-      g = ops.conv_geom(N, ih, iw, cin, k, k, s, 'valid', ch)
-      a2 = self._buf('act%d' % i, (N, oh, ow, ch))
-      ops.conv2d_fwd(g, a, self.flat.p('conv%d/kernel' % i), self.flat.p('conv%d/bias' % i), a2, out_relu=True)
-      acts.append(a2); geoms.append(g); a = a2
-    gfc = ops.dense_geom(N, self._flat_dim, self._fc)
     hfc = self._buf('fc_out', (N, self._fc))
-    ops.conv2d_fwd(gfc, a, self.flat.p('fc/kernel'), self.flat.p('fc/bias'), hfc, out_relu=True)
+    new_fs, ctx = self._torso_fwd(obs, done_u8, agent_state.frame_stacking_state, hfc, self._fc)
     head = self._head_fwd(hfc, N, self._fc)
-
-    new_fs = torch.empty_like(agent_state.frame_stacking_state)
-    ops.stack_pack_state(ext, nvalid, T1, B, HW, new_fs)
-    self._last = dict(T1=T1, B=B, N=N, ext=ext, nvalid=nvalid, acts=acts, geoms=geoms, gfc=gfc, hfc=hfc, head=head)
+    self._last = dict(T1=T1, B=B, N=N, ctx=ctx, hfc=hfc, head=head)
     out = self._agent_output(head, T1, B, sample=not is_training)
     if not unroll:
       out = AgentOutput(*[None if t is None else t[0] for t in out])
@@ -319,39 +361,114 @@ class AtariShallow(_Agent):
     N = L['N']
     fl = self.flat
     d_head = self._buf('d_head', (N, self._ldh), zero=True)
-    wsb = self._wgrad_ws()
-    # heads
     gh = ops.dense_geom(N, self._fc, self._ldh)
+    need = max(ops.conv2d_bwd_weight_workspace_bytes(gh), self._torso_ws_bytes(L['ctx']))
+    wsb = self._buf('wgrad_ws', (need // 4 + 4,))
     ops.conv2d_bwd_weight(gh, L['hfc'], d_head, fl.g('heads/kernel'), fl.g('heads/bias'), wsb)
     dz = self._buf('d_fc', (N, self._fc))
     ops.conv2d_bwd_data(gh, d_head, fl.p('heads/kernel'), dz, relu_mask=L['hfc'])
-    # fc
-    a_last = L['acts'][-1]
-    ops.conv2d_bwd_weight(L['gfc'], a_last, dz, fl.g('fc/kernel'), fl.g('fc/bias'), wsb)
-    da = self._buf('d_act%d' % (len(L['acts']) - 1), tuple(a_last.shape))
-    ops.conv2d_bwd_data(L['gfc'], dz, fl.p('fc/kernel'), da, relu_mask=a_last)
-    # convs, last to second
-    for i in range(len(L['acts']) - 1, 0, -1):
-      g = L['geoms'][i]
-      a_in = L['acts'][i - 1]
-      ops.conv2d_bwd_weight(g, a_in, da, fl.g('conv%d/kernel' % i), fl.g('conv%d/bias' % i), wsb)
-      d_in = self._buf('d_act%d' % (i - 1), tuple(a_in.shape))
-      ops.conv2d_bwd_data(g, da, fl.p('conv%d/kernel' % i), d_in, relu_mask=a_in)
-      da = d_in
-    # first conv: weight gradient straight from the uint8 frames
-    ops.conv2d_stack_bwd_weight(L['geoms'][0], L['ext'], L['nvalid'], da, fl.g('conv0/kernel'), fl.g('conv0/bias'),
-                                self._stack_ws(L['geoms'][0]))
+    self._torso_bwd(L['ctx'], dz, wsb)
 
-  def _wgrad_ws(self):
+
+R2D2AgentOutput = collections.namedtuple('R2D2AgentOutput', 'action q_values')
+
+
+class DuelingLSTMDQNNet(_Agent, _AtariTorso):
+  """R2D2 recurrent dueling Q-network: mirror of /root/reference/atari/networks.py:221-340
+  (conv 8x8/4x32 -> 4x4/2x64 -> 3x3/1x64 -> Dense 512; LSTM(512) on [features, reward, one_hot(prev_action)];
+  value 512->512->1 and advantage 512->512->A (no bias) heads; q = v + a - mean(a)).
+  Signature follows the reference: __call__((prev_actions, env_outputs), agent_state, unroll=False)."""
+
+  def __init__(self, num_actions, observation_shape=(84, 84, 1), stack_size=4, device='cuda', seed=0):
+    super(DuelingLSTMDQNNet, self).__init__(num_actions, device)
+    if stack_size != 4:
+      raise ValueError('the fused first conv implements stack_size=4 (atari/r2d2_main.py:36)')
+    H = self._H = 512
+    spec = self._torso_init(observation_shape, [(8, 4, 32), (4, 2, 64), (3, 1, 64)], 512, prefix='body/')
+    self._in_dim = 512 + 1 + num_actions
+    self._ldx = _round4(self._in_dim)
+    self._ldq = _round4(num_actions + 1)
+    spec += [('value/hidden/kernel', (H, 512), 'glorot'), ('value/hidden/bias', (512,), 'zeros'),
+             ('value/head/kernel', (512, 1), 'glorot'), ('value/head/bias', (1,), 'zeros'),
+             ('advantage/hidden/kernel', (H, 512), 'glorot'), ('advantage/hidden/bias', (512,), 'zeros'),
+             ('advantage/head/kernel', (512, num_actions), 'glorot'),
+             ('core/kernel', (self._in_dim, 4 * H), 'glorot'), ('core/recurrent_kernel', (H, 4 * H), 'orthogonal'),
+             ('core/bias', (4 * H,), 'lstm_bias')]
+    self._build_params(spec, seed)
+    self._last = None
+
+  def initial_state(self, batch_size):
+    hw = self._obs[0] * self._obs[1]
+    z = torch.zeros((batch_size, self._H), dtype=torch.float32, device=self.device)
+    return AgentState(core_state=(z, z.clone()),
+                      frame_stacking_state=torch.zeros((batch_size, hw), dtype=torch.int32, device=self.device))
+
+  def __call__(self, input_, agent_state, unroll=False):
+    prev_actions, env_outputs = input_
+    reward, done, obs = env_outputs.reward, env_outputs.done, env_outputs.observation
+    if not unroll:
+      reward, done, obs, prev_actions = reward[None], done[None], obs[None], prev_actions[None]
+    T1, B = done.shape[0], done.shape[1]
+    N, A, H = T1 * B, self._num_actions, self._H
+    fl = self.flat
+    done_u8 = done.to(torch.uint8).contiguous()
+    ldx = self._ldx
+    X = self._buf('lstm_x', (N, ldx))
+    new_fs, ctx = self._torso_fwd(obs, done_u8, agent_state.frame_stacking_state, X, ldx)
+    ops.lstm_assemble_inputs(X, ldx, 512, A, reward.to(torch.float32).contiguous(), prev_actions.contiguous(),
+                             False, N)                                               # networks.py:263-271 (raw reward)
+    Hout, core_state = self._lstm_fwd(X, ldx, self._in_dim, H, T1, B, done_u8, agent_state.core_state)
+    hid = self._buf('hid', (N, 1024))
+    hf = hid.view(-1)
+    ghid = ops.dense_geom(N, H, 512, ld_out=1024)
+    ops.conv2d_fwd(ghid, Hout, fl.p('value/hidden/kernel'), fl.p('value/hidden/bias'), hf, out_relu=True)
+    ops.conv2d_fwd(ghid, Hout, fl.p('advantage/hidden/kernel'), fl.p('advantage/hidden/bias'), hf[512:], out_relu=True)
+    ldq = self._ldq
+    va = self._buf('va', (N, ldq), zero=True)
+    vf = va.view(-1)
+    gadv = ops.dense_geom(N, 512, A, ld_in=1024, ld_out=ldq)
+    gval = ops.dense_geom(N, 512, 1, ld_in=1024, ld_out=ldq)
+    ops.conv2d_fwd(gadv, hf[512:], fl.p('advantage/head/kernel'), None, vf)
+    ops.conv2d_fwd(gval, hf, fl.p('value/head/kernel'), fl.p('value/head/bias'), vf[A:])
+    q = self._buf('q', (N, A))
+    action = self._buf('q_action', (N,), torch.int32)
+    ops.dueling_fwd(va, ldq, N, A, q, action)
+    self._last = dict(T1=T1, B=B, N=N, ctx=ctx, Hout=Hout, hid=hid, ghid=ghid, gadv=gadv, gval=gval)
+    out = R2D2AgentOutput(action.view(T1, B), q.view(T1, B, A))
+    if not unroll:
+      out = R2D2AgentOutput(out.action[0], out.q_values[0])
+    return out, AgentState(core_state=core_state, frame_stacking_state=new_fs)
+
+  def backward(self, dq=None):
+    """dq [T,B,A]: gradient of the loss wrt q_values (default: the one the fused R2D2 loss kernel left in
+    self._last['dq']); fills the flat gradient buffer."""
     L = self._last
-    need = ops.conv2d_bwd_weight_workspace_bytes(ops.dense_geom(L['N'], self._fc, self._ldh))
-    need = max(need, ops.conv2d_bwd_weight_workspace_bytes(L['gfc']))
-    for g in L['geoms'][1:]:
-      need = max(need, ops.conv2d_bwd_weight_workspace_bytes(g))
-    return self._buf('wgrad_ws', (need // 4 + 4,))
-
-  def _stack_ws(self, g0):
-    return self._buf('stack_ws', (ops.conv2d_stack_bwd_weight_workspace_bytes(g0) // 4 + 4,))
+    if dq is None:
+      dq = L['dq']
+    N, A, H = L['N'], self._num_actions, self._H
+    fl = self.flat
+    need = max(ops.conv2d_bwd_weight_workspace_bytes(L['ghid']), self._lstm_ws_bytes(), self._torso_ws_bytes(L['ctx']),
+               ops.conv2d_bwd_weight_workspace_bytes(L['gadv']), ops.conv2d_bwd_weight_workspace_bytes(L['gval']))
+    wsb = self._buf('wgrad_ws', (need // 4 + 4,))
+    ldq = self._ldq
+    d_va = self._buf('d_va', (N, ldq))
+    ops.dueling_bwd(dq.contiguous().view(N, A), N, A, d_va, ldq)
+    dvf = d_va.view(-1)
+    hf = L['hid'].view(-1)
+    d_hid = self._buf('d_hid', (N, 1024))
+    dhf = d_hid.view(-1)
+    ops.conv2d_bwd_weight(L['gadv'], hf[512:], dvf, fl.g('advantage/head/kernel'), None, wsb)
+    ops.conv2d_bwd_data(L['gadv'], dvf, fl.p('advantage/head/kernel'), dhf[512:], relu_mask=hf[512:])
+    ops.conv2d_bwd_weight(L['gval'], hf, dvf[A:], fl.g('value/head/kernel'), fl.g('value/head/bias'), wsb)
+    ops.conv2d_bwd_data(L['gval'], dvf[A:], fl.p('value/head/kernel'), dhf, relu_mask=hf)
+    ghid = L['ghid']
+    ops.conv2d_bwd_weight(ghid, L['Hout'], dhf, fl.g('value/hidden/kernel'), fl.g('value/hidden/bias'), wsb)
+    ops.conv2d_bwd_weight(ghid, L['Hout'], dhf[512:], fl.g('advantage/hidden/kernel'), fl.g('advantage/hidden/bias'), wsb)
+    dHout = self._buf('d_hout', (N, H))
+    ops.conv2d_bwd_data(ghid, dhf, fl.p('value/hidden/kernel'), dHout)
+    ops.conv2d_bwd_data(ghid, dhf[512:], fl.p('advantage/hidden/kernel'), dHout, add=dHout)
+    dX = self._lstm_bwd(dHout, wsb)
+    self._torso_bwd(L['ctx'], dX, wsb)
 
 
 class ImpalaDeep(_Agent):

@@ -248,3 +248,30 @@ def lstm_gates_bwd(z, cin, dh_out, ld_dh, dh_rec, dc_rec, done_next_u8, B, H, dz
       _lib.check(_lib.lib().seedhip_lstm_gates_bwd(
           _lib.ptr(z), _lib.ptr(cin), _lib.ptr(dh_out), ld_dh, _lib.ptr(dh_rec), _lib.ptr(dc_rec),
           _lib.ptr(done_next_u8), B, H, _lib.ptr(dz), _lib.ptr(dc_prev), _lib.stream()), 'seedhip_lstm_gates_bwd')
+
+
+def dueling_fwd(va, ld, rows, A, q, action):
+  with _dev(q):
+    _lib.check(_lib.lib().seedhip_dueling_fwd(_lib.ptr(va), ld, rows, A, _lib.ptr(q), _lib.ptr(action), _lib.stream()),
+               'seedhip_dueling_fwd')
+
+
+def dueling_bwd(dq, rows, A, d_va, ld):
+  with _dev(d_va):
+    _lib.check(_lib.lib().seedhip_dueling_bwd(_lib.ptr(dq), rows, A, _lib.ptr(d_va), ld, _lib.stream()),
+               'seedhip_dueling_bwd')
+
+
+def r2d2_loss_workspace_bytes(T, B, n_steps):
+  return int(_lib.lib().seedhip_r2d2_loss_workspace_bytes(T, B, n_steps))
+
+
+def r2d2_loss_fwd_bwd(training_q, target_q, actions_i32, rewards, done_u8, importance_weights, T, B, A, gamma,
+                      n_steps, eta, epsilon, mean_denominator, loss_b, prio_b, d_training_q, total, workspace):
+  with _region('r2d2_loss', 0, T * B * (12 * A + 20)):
+    with _dev(total):
+      _lib.check(_lib.lib().seedhip_r2d2_loss_fwd_bwd(
+          _lib.ptr(training_q), _lib.ptr(target_q), _lib.ptr(actions_i32), _lib.ptr(rewards), _lib.ptr(done_u8),
+          _lib.ptr(importance_weights), T, B, A, gamma, n_steps, eta, epsilon, float(mean_denominator),
+          _lib.ptr(loss_b), _lib.ptr(prio_b), _lib.ptr(d_training_q), _lib.ptr(total), _lib.ptr(workspace),
+          workspace.numel() * workspace.element_size(), _lib.stream()), 'seedhip_r2d2_loss_fwd_bwd')
