@@ -35,10 +35,11 @@ def parse():
   ap.add_argument('--steps', type=int, default=20)
   ap.add_argument('--warmup', type=int, default=5)
   ap.add_argument('--batch', type=int, default=0, help='per-GPU batch columns B (default 512 atari / 256 dmlab)')
-  ap.add_argument('--unroll', type=int, default=20, help='T')
+  ap.add_argument('--unroll', type=int, default=0, help='T (default 20; 120 for r2d2)')
   ap.add_argument('--actions', type=int, default=0, help='default 18 atari / 9 dmlab')
-  ap.add_argument('--config', default='atari', choices=['atari', 'dmlab'],
-                  help='atari = BASELINE configs[1] (headline); dmlab = configs[2] (ImpalaDeep + LSTM, B=256)')
+  ap.add_argument('--config', default='atari', choices=['atari', 'dmlab', 'r2d2'],
+                  help='atari = BASELINE configs[1] (headline); dmlab = configs[2] (ImpalaDeep + LSTM, B=256); '
+                       'r2d2 = configs[4] (DuelingLSTMDQNNet, replayed T=120 B=256 sequences, burn-in 40)')
   ap.add_argument('--torso', default='shallow', choices=['shallow', 'dqn'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-batch', type=int, default=64)
@@ -97,14 +98,24 @@ def main():
   assert world == args.gpus or world == 1, 'launch with torchrun for --gpus > 1'
 
   from seed_rl_amd import learner, networks, ops, optimizers, parametric_distribution as pd, smoke_step
-  deep = args.config == 'dmlab'
-  T = args.unroll
-  B = args.batch or (256 if deep else 512)
+  deep, r2 = args.config == 'dmlab', args.config == 'r2d2'
+  T = args.unroll or (120 if r2 else 20)
+  B = args.batch or (256 if (deep or r2) else 512)
   A = args.actions or (9 if deep else 18)
   T1 = T + 1
   final_iteration = 10 ** 9 // (T * B * max(world, 1))
   opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, final_iteration), beta_1=0.0, epsilon=3.125e-7)
-  if deep:
+  if r2:
+    from seed_rl_amd import r2d2_learner
+    agent = networks.DuelingLSTMDQNNet(A, device=dev, seed=0)
+    target = networks.DuelingLSTMDQNNet(A, device=dev, seed=0)
+    u0 = smoke_step.make_unroll(agent, T1, B, A, dev, seed=1000 + rank)
+    unroll = r2d2_learner.Unroll(agent.initial_state(B), None, u0.prev_actions, u0.env_outputs,
+                                 networks.R2D2AgentOutput(u0.agent_outputs.action.to(torch.int32), None))
+    iw = torch.rand(B, device=dev) * 0.9 + 0.1
+    workload = 'Atari R2D2 DuelingLSTMDQNNet (conv 32/64/64, FC512, LSTM512, dueling heads) learner step on replayed ' \
+               'sequences, burn-in 40, n-step(5) double-Q target, training + target network'
+  elif deep:
     agent = networks.ImpalaDeep(A, device=dev, seed=0)                          # identical params on all ranks
     unroll = smoke_step.make_deep_unroll(agent, T1, B, A, dev, seed=1000 + rank)
     workload = 'DeepMind Lab 72x96x3 IMPALA deep ResNet + LSTM(256) learner step'
@@ -117,7 +128,17 @@ def main():
     unroll = unroll._replace(env_outputs=unroll.env_outputs._replace(
         observation=ext[3:].view(T1, B, agent._obs[0], agent._obs[1], 1)))
     workload = 'Atari 84x84x4 IMPALA %s ConvNet learner step' % args.torso
-  lrn = learner.Learner(agent, opt, pd.categorical_distribution(A), reduction=args.reduction)
+  if r2:
+    opt = optimizers.Adam(4.8e-4, epsilon=1e-3)                                 # atari/r2d2_main.py:36-39
+    r2l = r2d2_learner.R2D2Learner(agent, target, opt, r2d2_learner.R2D2Config(), reduction=args.reduction)
+
+    class _Step(object):
+      def minimize(self, unroll):
+        total, _, _ = r2l.minimize(unroll, iw)
+        return total, None
+    lrn = _Step()
+  else:
+    lrn = learner.Learner(agent, opt, pd.categorical_distribution(A), reduction=args.reduction)
 
   def barrier():
     if world > 1:
@@ -171,7 +192,7 @@ def main():
   if rank != 0:
     return
   result = {
-      'metric': 'learner env-frames/s (T=20)', 'value': round(frames_per_s, 1), 'unit': 'env-frames/s',
+      'metric': 'learner env-frames/s (T=%d)' % T, 'value': round(frames_per_s, 1), 'unit': 'env-frames/s',
       'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
       'config': {'workload': '%s, T=%d B=%d/GPU A=%d, synthetic uint8 frames in HBM, num_action_repeats=1'
@@ -188,7 +209,10 @@ def main():
     result['vtrace_scan_hbm'] = sweep
     if not args.no_cpu_baseline:
       from oracle import cpu_learner
-      if deep:
+      if r2:
+        cb = args.cpu_batch if args.cpu_batch != 64 else 8
+        fps, sec, thr = cpu_learner.time_cpu_r2d2_learner(A, T1, cb, steps=2, warmup=1)
+      elif deep:
         cb = args.cpu_batch if args.cpu_batch != 64 else 16
         fps, sec, thr = cpu_learner.time_cpu_deep_learner(A, T1, cb, steps=2, warmup=1)
       else:

@@ -90,3 +90,54 @@ def time_cpu_deep_learner(num_actions, T1, B, steps=3, warmup=1, seed=0):
     ts.append(time.perf_counter() - t0)
   sec = float(np.median(ts))
   return (T1 - 1) * B / sec, sec, torch.get_num_threads()
+
+
+class CpuR2D2Learner(object):
+  """R2D2 learner step (agents/r2d2/learner.py:572-636), eager PyTorch-CPU fp32."""
+
+  def __init__(self, num_actions, seed=0, burn_in=40, n_steps=5, gamma=0.997, clip_norm=40.0):
+    self.A, self.burn_in, self.n_steps, self.gamma, self.clip = num_actions, burn_in, n_steps, gamma, clip_norm
+    spec = nets_torch.param_spec('r2d2', num_actions)
+    self.params = nets_torch.to_torch(nets_torch.init_params(spec, seed), requires_grad=True)
+    self.target = nets_torch.to_torch(nets_torch.init_params(spec, seed))
+    self.opt = nets_torch.KerasAdam(list(self.params.values()), lambda step: 4.8e-4, epsilon=1e-3)
+
+  def step(self, u, iw):
+    for p in self.params.values():
+      p.grad = None
+    b = self.burn_in
+    def run(pp, lo, hi, fs, core):
+      return nets_torch.r2d2_unroll(pp, self.A, u['prev_actions'][lo:hi], u['reward'][lo:hi], u['done'][lo:hi],
+                                    u['frames'][lo:hi], fs, core)
+    T1 = u['done'].shape[0]
+    with torch.no_grad():
+      _, fs1, core1 = run(self.params, 0, b, u['frame_state'], (u['h0'], u['c0']))
+      _, fs1t, core1t = run(self.target, 0, b, u['frame_state'], (u['h0'], u['c0']))
+      out_t, _, _ = run(self.target, b, T1, fs1t, core1t)
+    out, _, _ = run(self.params, b, T1, fs1, tuple(x.detach() for x in core1))
+    total, _, _ = nets_torch.r2d2_loss_torch(out.q_values, out_t.q_values, u['actions'][b:], u['reward'][b:],
+                                             u['done'][b:], iw, self.gamma, self.n_steps)
+    total.backward()
+    grads = [p.grad for p in self.params.values()]
+    gn = float(torch.sqrt(sum((g ** 2).sum() for g in grads)))
+    scale = min(1.0, self.clip / max(gn, 1e-30))
+    self.opt.apply_gradients([g * scale for g in grads])
+    return float(total.detach())
+
+
+def time_cpu_r2d2_learner(num_actions, T1, B, burn_in=40, steps=2, warmup=1, seed=0):
+  from tests import synth
+  u = synth.atari_unroll(seed, T1, B, num_actions)
+  u = {k: torch.as_tensor(v) for k, v in u.items()}
+  u['h0'] = torch.zeros((B, 512)); u['c0'] = torch.zeros((B, 512))
+  iw = torch.ones(B)
+  lrn = CpuR2D2Learner(num_actions, seed, burn_in=burn_in)
+  for _ in range(warmup):
+    lrn.step(u, iw)
+  ts = []
+  for _ in range(steps):
+    t0 = time.perf_counter()
+    lrn.step(u, iw)
+    ts.append(time.perf_counter() - t0)
+  sec = float(np.median(ts))
+  return (T1 - 1) * B / sec, sec, torch.get_num_threads()

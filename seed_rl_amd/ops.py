@@ -23,11 +23,25 @@ class Profiler(object):
     self.events = collections.OrderedDict()
     self.meta = {}
 
+  @staticmethod
+  def event_overhead_ms(n=50):
+    """Elapsed time HIP reports for an EMPTY (start, end) event pair: subtracted from every region so that
+    kernels launched hundreds of times per step (LSTM steps) are not ranked by event overhead."""
+    pairs = []
+    for _ in range(n):
+      s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      s.record(); e.record()
+      pairs.append((s, e))
+    torch.cuda.synchronize()
+    v = sorted(s.elapsed_time(e) for s, e in pairs)
+    return v[len(v) // 2]
+
   def summary(self):
     torch.cuda.synchronize()
+    ovh = self.event_overhead_ms()
     out = collections.OrderedDict()
     for name, evs in self.events.items():
-      ms = [s.elapsed_time(e) for s, e in evs]
+      ms = [max(s.elapsed_time(e) - ovh, 0.0) for s, e in evs]
       flops, nbytes = self.meta[name]
       out[name] = dict(calls=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms), flops=flops, bytes=nbytes)
     return out
