@@ -94,6 +94,27 @@ def compute_loss(logger, parametric_action_distribution, agent, agent_state, pre
   return scalars[0], session
 
 
+def shard_columns(num_columns, rank, world):
+  """Contiguous batch-column shard of rank `rank` (every column is an independent
+  trajectory; cfg4: 4096 columns -> 8 x 512)."""
+  if num_columns % world:
+    raise ValueError('batch columns (%d) must divide evenly over %d replicas' % (num_columns, world))
+  per = num_columns // world
+  return slice(rank * per, (rank + 1) * per)
+
+
+def all_reduce_gradients(flat_grads, process_group=None):
+  """The one exchange step of a train step: SUM of the flat fp32 gradient bucket over the replicas
+  (RCCL over xGMI on GPUs; the reference does this implicitly inside Keras apply_gradients on TPU,
+  learner.py:272-275).  With reduction='mean' each replica has already divided its loss by the GLOBAL
+  number of (t,b) elements, so the sum equals the single-replica gradient of the global batch; with
+  'sum' it reproduces the reference's cross-replica gradient SUM (tests/utils_test.py:609-650)."""
+  if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+      torch.distributed.get_world_size(process_group) > 1:
+    torch.distributed.all_reduce(flat_grads, op=torch.distributed.ReduceOp.SUM, group=process_group)
+  return flat_grads
+
+
 class Learner(object):
   """One data-parallel learner replica: minimize(unroll) = forward + loss + backward +
   gradient all-reduce + Adam (learner.py:255-280)."""
@@ -124,8 +145,7 @@ class Learner(object):
     return loss, session
 
   def apply_gradients(self):
-    if self.world > 1:
-      torch.distributed.all_reduce(self.agent.flat.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+    all_reduce_gradients(self.agent.flat.grads, self.pg)
     self.optimizer.apply_gradients(self.agent.flat)
 
   def minimize(self, unroll):

@@ -17,6 +17,7 @@ import collections
 import torch
 
 from seed_rl_amd import ops
+from seed_rl_amd.learner import all_reduce_gradients
 
 Unroll = collections.namedtuple('Unroll', 'agent_state priority prev_actions env_outputs agent_outputs')
 
@@ -98,8 +99,7 @@ class R2D2Learner(object):
         unroll.agent_outputs, cfg.discounting, cfg.burn_in, cfg, importance_weights, mean_denominator=n)
     self.agent.backward()
     flat = self.agent.flat
-    if self.world > 1:
-      torch.distributed.all_reduce(flat.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+    all_reduce_gradients(flat.grads, self.pg)
     sumsq = self.agent._buf('gnorm_sumsq', (1,))
     gws = self.agent._buf('gnorm_ws', (ops.global_norm_workspace_bytes() // 4 + 4,))
     ops.clip_by_global_norm(flat.grads, cfg.clip_norm or 0.0, sumsq, gws)               # learner.py:605-609

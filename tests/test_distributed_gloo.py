@@ -1,0 +1,122 @@
+"""Data-parallel path on CPU: 2 processes, gloo backend (the GPU path uses the same code with RCCL).
+
+Covers SURVEY.md 8(e): contiguous batch-column shards, ONE all-reduce(SUM) of the flat gradient bucket,
+'mean' (global denominator => equals the single-replica gradient of the global batch) and 'sum' (the
+reference's cross-replica semantics, tests/utils_test.py:609-650) reductions.  Per-shard gradients come from
+the torch-CPU oracle of the loss head (the HIP kernels need a GPU); what is exercised here is the sharding,
+the denominators and the exchange."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _shard_grad(tgt, base, beh, act, rew, done, denom):
+  """d(sum-of-losses / denom) / d(logits, baseline) on a shard, via the torch oracle."""
+  from oracle import nets_torch
+  t = torch.tensor(tgt, requires_grad=True)
+  b = torch.tensor(base, requires_grad=True)
+  total, _ = nets_torch.impala_loss_torch(t, b, torch.tensor(beh), torch.tensor(act), torch.tensor(rew),
+                                          torch.tensor(done))
+  n_local = (tgt.shape[0] - 1) * tgt.shape[1]
+  (total * n_local / denom).backward()            # oracle takes a local mean; re-normalise to `denom`
+  return torch.cat([t.grad.reshape(-1), b.grad.reshape(-1)])
+
+
+def _worker(rank, world, port, reduction, out):
+  sys.path.insert(0, ROOT)
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from seed_rl_amd import learner
+    from seed_rl_amd.flat import FlatParams
+    from tests import synth
+    T, B, A = 6, 8, 5
+    tgt, base, beh, act, rew, done = synth.loss_inputs(0, T, B, A)
+    cols = learner.shard_columns(B, rank, world)
+    n_global = T * B
+    denom = n_global if reduction == 'mean' else T * (B // world)
+    g = _shard_grad(tgt[:, cols], base[:, cols], beh[:, cols], act[:, cols], rew[:, cols], done[:, cols], denom)
+    # the exchange runs on a flat bucket exactly like the GPU path (here: CPU tensors, gloo)
+    flat = FlatParams([('x', (g.numel(),))], torch.device('cpu'))
+    flat.grads.copy_(g)
+    learner.all_reduce_gradients(flat.grads)
+    # scatter back into global column order for comparison
+    res = torch.zeros((T + 1) * B * A + (T + 1) * B)
+    if rank == 0:
+      parts = [None] * world
+    # every rank holds the SUM over ranks of its zero-padded shard gradient: rebuild it explicitly
+    full_l = torch.zeros((T + 1, B, A)); full_b = torch.zeros((T + 1, B))
+    per = B // world
+    full_l[:, cols] = g[:(T + 1) * per * A].reshape(T + 1, per, A)
+    full_b[:, cols] = g[(T + 1) * per * A:].reshape(T + 1, per)
+    padded = torch.cat([full_l.reshape(-1), full_b.reshape(-1)])
+    torch.distributed.all_reduce(padded)
+    if rank == 0:
+      torch.save(dict(padded=padded, reduced_shard_sum=flat.grads.clone()), out)
+  finally:
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('reduction', ['mean', 'sum'])
+def test_data_parallel_gradient_exchange_gloo(tmp_path, reduction):
+  world, port = 2, _free_port()
+  out = str(tmp_path / 'r0.pt')
+  mp.spawn(_worker, args=(world, port, reduction, out), nprocs=world, join=True)
+  got = torch.load(out)
+  sys.path.insert(0, ROOT)
+  from tests import synth
+  T, B, A = 6, 8, 5
+  tgt, base, beh, act, rew, done = synth.loss_inputs(0, T, B, A)
+  # single-replica gradient of the GLOBAL batch
+  scale = 1.0 if reduction == 'mean' else float(world)     # 'sum': each replica's mean is over B/world columns
+  ref = _shard_grad(tgt, base, beh, act, rew, done, T * B) * scale
+  np.testing.assert_allclose(got['padded'].numpy(), ref.numpy(), rtol=1e-5, atol=1e-7)
+
+
+def _sgd_worker(rank, world, port, out):
+  """tests/utils_test.py:609-650 (MinimizeTest): loss = 2a per replica, gradients SUMMED across replicas,
+  SGD(0.1): a = 1 - world * 0.2 on every replica."""
+  sys.path.insert(0, ROOT)
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from seed_rl_amd import learner
+    a = torch.tensor([1.0])
+    grad = torch.tensor([2.0])                       # d(2a)/da on this replica
+    learner.all_reduce_gradients(grad)               # reference semantics: SUM
+    a -= 0.1 * grad
+    torch.save(a, out + str(rank))
+  finally:
+    torch.distributed.destroy_process_group()
+
+
+def test_minimize_sum_semantics_like_reference(tmp_path):
+  world, port = 2, _free_port()
+  out = str(tmp_path / 'a')
+  mp.spawn(_sgd_worker, args=(world, port, out), nprocs=world, join=True)
+  for r in range(world):
+    assert abs(float(torch.load(out + str(r))[0]) - (1.0 - world * 0.2)) < 1e-6
+
+
+def test_shard_columns():
+  from seed_rl_amd import learner
+  assert learner.shard_columns(4096, 3, 8) == slice(1536, 2048)
+  with pytest.raises(ValueError):
+    learner.shard_columns(10, 0, 4)
