@@ -193,6 +193,16 @@ int seedhip_r2d2_loss_fwd_bwd(const float* training_q, const float* target_q, co
                               float* d_training_q, float* total_loss, void* workspace, size_t workspace_bytes,
                               void* stream);
 
+/* ---- trajectory store row mover -------------------------------------------------------------------
+ * The one data-movement primitive behind the device-resident UnrollStore / Aggregator
+ * (common/utils.py:155-257, 461-543: scatter_nd_update / sparse_read / gather_nd) and the direct
+ * time-major batch assembly that replaces make_time_major (utils.py:735-761):
+ *   dst[dst_rows[i]] = src[src_rows[i]],  i < n, rows of row_bytes bytes.
+ * dst_rows / src_rows NULL = identity (row i); src NULL = zero fill.  Rows written must be distinct and
+ * must not alias rows read. */
+int seedhip_rows_move(void* dst, const long long* dst_rows, const void* src, const long long* src_rows,
+                      long long n, long long row_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,7 @@ SIGNATURES = {
     'seedhip_lstm_mask_state': (c_int, [P, P, P, c_int, c_int, P, P, P]),
     'seedhip_lstm_gates_fwd': (c_int, [P, P, P, c_int, c_int, P, c_int, P, P, P]),
     'seedhip_lstm_gates_bwd': (c_int, [P, P, P, c_int, P, P, P, c_int, c_int, P, P, P]),
+    'seedhip_rows_move': (c_int, [P, P, P, P, c_ll, c_ll, P]),
     'seedhip_dueling_fwd': (c_int, [P, c_int, c_ll, c_int, P, P, P]),
     'seedhip_dueling_bwd': (c_int, [P, c_ll, c_int, P, c_int, P]),
     'seedhip_r2d2_loss_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

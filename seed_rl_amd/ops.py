@@ -289,3 +289,12 @@ def r2d2_loss_fwd_bwd(training_q, target_q, actions_i32, rewards, done_u8, impor
           _lib.ptr(importance_weights), T, B, A, gamma, n_steps, eta, epsilon, float(mean_denominator),
           _lib.ptr(loss_b), _lib.ptr(prio_b), _lib.ptr(d_training_q), _lib.ptr(total), _lib.ptr(workspace),
           workspace.numel() * workspace.element_size(), _lib.stream()), 'seedhip_r2d2_loss_fwd_bwd')
+
+
+def rows_move(dst, dst_rows, src, src_rows, n, row_bytes):
+  """dst[dst_rows[i]] = src[src_rows[i]] over rows of row_bytes bytes (None rows = identity; src None = zeros)."""
+  if n == 0:
+    return
+  with _dev(dst):
+    _lib.check(_lib.lib().seedhip_rows_move(_lib.ptr(dst), _lib.ptr(dst_rows), _lib.ptr(src), _lib.ptr(src_rows), n,
+                                            row_bytes, _lib.stream()), 'seedhip_rows_move')
