@@ -1,9 +1,9 @@
-// Weight gradient of 3x3 stride-1 convolutions with the input staged ONCE per spatial tile.
+// Weight gradient of small-kernel convolutions (3x3/1, 4x4/2, ...) with the input staged ONCE per spatial tile.
 //
 // Used by seedhip_conv2d_bwd_weight for the ResNet stacks of
 // /root/reference/dmlab/networks.py:31-60 (TF autodiff of Conv2D wrt kernel / bias).
 //
-//   dW[ky,kx,c,co] = sum_{n,oy,ox} X[n, oy+ky-pad, ox+kx-pad, c] * dY[n,oy,ox,co],  db[co] = sum dY
+//   dW[ky,kx,c,co] = sum_{n,oy,ox} X[n, oy*s+ky-pad, ox*s+kx-pad, c] * dY[n,oy,ox,co],  db[co] = sum dY
 //
 // The implicit-GEMM formulation gathers every input element 9 times from global memory with
 // per-element index arithmetic (VALU-bound: 4-16% of the fp32 MFMA peak on these shapes).  Here
@@ -34,13 +34,14 @@ struct WgradParams {
   const float* dy;
   float* partial_w;            // [grid][rows*cout]
   float* partial_b;            // [grid][cout] or null
-  int n_img, ih, iw, cin, oh, ow, cout, ld_in, ld_out, pad;
+  int n_img, ih, iw, cin, oh, ow, cout, ld_in, ld_out, pad_t, pad_l, kh, kw, stride;
   int TH;                      // output rows per tile
   int bands;                   // ceil(oh / TH)
   int ntiles;                  // n_img * bands
-  int rows;                    // 9 * cin
+  int rows;                    // kh * kw * cin
   int xs;                      // LDS pixel stride of the X tile (floats)
-  int twp;                     // tile width incl. halo = ow + 2
+  int twp;                     // tile width incl. halo = (ow - 1) * stride + kw
+  int thp;                     // tile rows incl. halo for a full band = (TH - 1) * stride + kh
   FastDiv d_ow;
 };
 
@@ -49,7 +50,7 @@ __global__ void __launch_bounds__(256)
 halo_wgrad_kernel(const WgradParams p) {
   constexpr int PP = 4 / MSPLIT;                      // pixel partitions
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int x_floats = ((p.TH + 2) * p.twp * p.xs + 3) & ~3;
+  const int x_floats = (p.thp * p.twp * p.xs + 3) & ~3;
   float* xs_lds = smem;
   float* dy_lds = smem + x_floats;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -66,7 +67,7 @@ halo_wgrad_kernel(const WgradParams p) {
     row_ok[mt] = R < p.rows;
     const int Rc = row_ok[mt] ? R : 0;
     const int tap = Rc / p.cin, c = Rc - tap * p.cin;
-    lane_off[mt] = ((tap / 3) * p.twp + (tap % 3)) * p.xs + c;
+    lane_off[mt] = ((tap / p.kw) * p.twp + (tap % p.kw)) * p.xs + c;
   }
   f32x4_t acc[MTW][NT];
 #pragma unroll
@@ -77,67 +78,115 @@ halo_wgrad_kernel(const WgradParams p) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
 
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-    const int n = tile / p.bands, band = tile - n * p.bands;
-    const int y0 = band * p.TH;
-    const int th = (y0 + p.TH <= p.oh) ? p.TH : p.oh - y0;
-    __syncthreads();                                   // previous tile fully consumed
-    // ---- X band + halo -> LDS (zero outside the image), converted once ----
-    {
-      const int rowf = p.twp * p.xs;                   // floats per LDS row
-      const int nrows = th + 2;
-      if (p.in_dtype == 0 && (p.cin & 3) == 0 && (p.ld_in & 3) == 0) {
-        const int c4 = p.cin >> 2;
-        const int per_row = p.twp * c4;
-        for (int v = tid; v < nrows * per_row; v += 256) {
+  // Software pipeline over tiles: the global loads of tile i+1 (float4 per lane, kept in registers)
+  // are in flight while tile i is reduced out of LDS.
+  constexpr int kXV = 7, kDV = 3;                      // float4 registers per thread for the X / dY tile
+  const bool vec = p.in_dtype == 0 && (p.cin & 3) == 0 && (p.ld_in & 3) == 0;
+  float4 xr[kXV], dr[kDV];
+  auto band_of = [&](int tile, int& n, int& y0, int& th) {
+    n = tile / p.bands;
+    const int band = tile - n * p.bands;
+    y0 = band * p.TH;
+    th = (y0 + p.TH <= p.oh) ? p.TH : p.oh - y0;
+  };
+  auto load_tile = [&](int tile) {
+    int n, y0, th; band_of(tile, n, y0, th);
+    if (vec) {
+      const int c4 = p.cin >> 2;
+      const int per_row = p.twp * c4;
+      const int nvec = ((th - 1) * p.stride + p.kh) * per_row;
+#pragma unroll
+      for (int u = 0; u < kXV; ++u) {
+        const int v = tid + u * 256;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v < nvec) {
           const int r = v / per_row, rem = v - r * per_row;
           const int xcol = rem / c4, cq = rem - xcol * c4;
-          const int iy = y0 - p.pad + r, ix = xcol - p.pad;
-          float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (iy >= 0 && iy < p.ih && ix >= 0 && ix < p.iw) {
+          const int iy = y0 * p.stride - p.pad_t + r, ix = xcol - p.pad_l;
+          if (iy >= 0 && iy < p.ih && ix >= 0 && ix < p.iw)
             val = *reinterpret_cast<const float4*>((const float*)p.in + (((long long)n * p.ih + iy) * p.iw + ix) * p.ld_in + 4 * cq);
-            if (p.in_relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
-          }
+        }
+        xr[u] = val;
+      }
+    }
+    const int c4 = coutp >> 2;
+    const int nd = th * p.ow * c4;
+    const float* src = p.dy + ((long long)n * p.oh + y0) * p.ow * p.ld_out;
+#pragma unroll
+    for (int u = 0; u < kDV; ++u) {
+      const int v = tid + u * 256;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v < nd) {
+        const int pix = v / c4, cq = v - pix * c4;
+        val = *reinterpret_cast<const float4*>(src + (long long)pix * p.ld_out + 4 * cq);
+      }
+      dr[u] = val;
+    }
+  };
+  auto store_tile = [&](int tile) {
+    int n, y0, th; band_of(tile, n, y0, th);
+    const int rowf = p.twp * p.xs;                     // floats per LDS row
+    const int nrows = (th - 1) * p.stride + p.kh;
+    if (vec) {
+      const int c4 = p.cin >> 2;
+      const int per_row = p.twp * c4;
+#pragma unroll
+      for (int u = 0; u < kXV; ++u) {
+        const int v = tid + u * 256;
+        if (v < nrows * per_row) {
+          const int r = v / per_row, rem = v - r * per_row;
+          const int xcol = rem / c4, cq = rem - xcol * c4;
+          float4 val = xr[u];
+          if (p.in_relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
           *reinterpret_cast<float4*>(xs_lds + r * rowf + xcol * p.xs + 4 * cq) = val;
         }
-      } else {
-        const int per_row = p.twp * p.cin;
-        for (int v = tid; v < nrows * per_row; v += 256) {
-          const int r = v / per_row, rem = v - r * per_row;
-          const int xcol = rem / p.cin, c = rem - xcol * p.cin;
-          const int iy = y0 - p.pad + r, ix = xcol - p.pad;
-          float val = 0.f;
-          if (iy >= 0 && iy < p.ih && ix >= 0 && ix < p.iw) {
-            const long long off = (((long long)n * p.ih + iy) * p.iw + ix) * p.ld_in + c;
-            val = p.in_dtype == 1 ? (float)((const uint8_t*)p.in)[off] / 255.0f : ((const float*)p.in)[off];
-            if (p.in_relu) val = fmaxf(val, 0.f);
-          }
-          xs_lds[r * rowf + xcol * p.xs + c] = val;
+      }
+    } else {                                           // first layer (u8 / odd channel counts): direct, synchronous
+      const int per_row = p.twp * p.cin;
+      for (int v = tid; v < nrows * per_row; v += 256) {
+        const int r = v / per_row, rem = v - r * per_row;
+        const int xcol = rem / p.cin, c = rem - xcol * p.cin;
+        const int iy = y0 * p.stride - p.pad_t + r, ix = xcol - p.pad_l;
+        float val = 0.f;
+        if (iy >= 0 && iy < p.ih && ix >= 0 && ix < p.iw) {
+          const long long off = (((long long)n * p.ih + iy) * p.iw + ix) * p.ld_in + c;
+          val = p.in_dtype == 1 ? (float)((const uint8_t*)p.in)[off] / 255.0f : ((const float*)p.in)[off];
+          if (p.in_relu) val = fmaxf(val, 0.f);
         }
+        xs_lds[r * rowf + xcol * p.xs + c] = val;
       }
     }
-    // ---- dY band -> LDS ----
-    {
-      const int c4 = coutp >> 2;
-      const int npix = th * p.ow;
-      const float* src = p.dy + ((long long)n * p.oh + y0) * p.ow * p.ld_out;
-      for (int v = tid; v < npix * c4; v += 256) {
-        const int pix = v / c4, cq = v - pix * c4;
-        *reinterpret_cast<float4*>(dy_lds + pix * coutp + 4 * cq) =
-            *reinterpret_cast<const float4*>(src + (long long)pix * p.ld_out + 4 * cq);
-      }
+    const int c4 = coutp >> 2;
+    const int nd = th * p.ow * c4;
+#pragma unroll
+    for (int u = 0; u < kDV; ++u) {
+      const int v = tid + u * 256;
+      if (v < nd) *reinterpret_cast<float4*>(dy_lds + 4 * v) = dr[u];
     }
+  };
+
+  if ((int)blockIdx.x < p.ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    int n, y0, th; band_of(tile, n, y0, th);
+    __syncthreads();                                   // previous tile fully consumed
+    store_tile(tile);
     __syncthreads();
+    if (tile + (int)gridDim.x < p.ntiles) load_tile(tile + gridDim.x);
     // ---- MFMA over this wave's pixel groups ----
-    const int G = (th * p.ow) >> 2;                    // ow % 4 == 0
+    const int npix = th * p.ow;
+    const int G = (npix + 3) >> 2;
     for (int g = pp; g < G; g += PP) {
       const int pix = 4 * g + kq;
+      const bool pv = pix < npix;                      // tail group of a band whose pixel count is not 4k
       uint32_t py, px;
-      p.d_ow.divmod((uint32_t)pix, py, px);
-      const float* xb = xs_lds + ((int)py * p.twp + (int)px) * p.xs;
+      p.d_ow.divmod((uint32_t)(pv ? pix : 0), py, px);
+      const float* xb = xs_lds + ((int)py * p.stride * p.twp + (int)px * p.stride) * p.xs;
       float b[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) { b[nt] = dy_lds[pix * coutp + nt * 16 + i]; if (ms == 0) bsum[nt] += b[nt]; }
+      for (int nt = 0; nt < NT; ++nt) {
+        b[nt] = pv ? dy_lds[pix * coutp + nt * 16 + i] : 0.f;
+        if (ms == 0) bsum[nt] += b[nt];
+      }
       float a[MTW];
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) a[mt] = row_ok[mt] ? xb[lane_off[mt]] : 0.f;
@@ -196,29 +245,32 @@ struct WgradPlan { bool ok; int MTW, NT, MSPLIT, TH, grid; size_t lds; size_t ws
 
 inline WgradPlan plan_wgrad(const seedhip_conv_geom* g) {
   WgradPlan pl; memset(&pl, 0, sizeof(pl));
-  if (!(g->kh == 3 && g->kw == 3 && g->stride == 1 && g->pad_t == g->pad_l && (g->pad_t == 0 || g->pad_t == 1))) return pl;
-  if (g->ow % 4 != 0 || g->cout % 16 != 0 || g->cout > 64 || g->ld_out % 4 != 0) return pl;
-  if (g->oh != g->ih + 2 * g->pad_t - 2 || g->ow != g->iw + 2 * g->pad_l - 2) return pl;
-  const int rows = 9 * g->cin;
+  if (g->kh > 4 || g->kw > 4 || g->stride > 2 || g->kh < g->stride || g->kw < g->stride) return pl;
+  if (g->cout % 16 != 0 || g->cout > 64 || g->ld_out % 4 != 0 || g->oh * g->ow < 16) return pl;
+  const int rows = g->kh * g->kw * g->cin;
   const int MT = (rows + 15) / 16;
-  int msplit = 1;
-  if (MT > 9) msplit = (MT + 8) / 9;                   // <= 9 row-tiles per wave
-  if (msplit == 3) msplit = 4;
-  if (msplit > 4) return pl;
-  pl.MSPLIT = msplit;
-  pl.MTW = (MT + msplit - 1) / msplit;
-  pl.NT = g->cout / 16;
-  if (!((pl.MTW == 2 && pl.NT == 1) || (pl.MTW == 9 && (pl.NT == 1 || pl.NT == 2 || pl.NT == 4)))) return pl;
-  if (pl.MTW == 9 && pl.NT == 4 && pl.MSPLIT != 4) return pl;
-  if (pl.MTW == 9 && pl.NT <= 2 && pl.MSPLIT > 2) return pl;
-  // rows per band: ~192-256 output pixels
+  // row-tiles per wave: 2 (tiny first layer), 8 or 9; split the rows over 1, 2 or 4 waves
+  int msplit = 1, mtw = 0;
+  if (MT <= 2) { mtw = 2; }
+  else {
+    for (msplit = 1; msplit <= 4; msplit *= 2) {
+      const int per = (MT + msplit - 1) / msplit;
+      if (per <= 9) { mtw = per <= 8 ? 8 : 9; break; }
+    }
+    if (!mtw) return pl;
+  }
+  pl.MSPLIT = msplit; pl.MTW = mtw; pl.NT = g->cout / 16;
+  if (pl.MTW == 2 && pl.NT != 1) return pl;
+  if (pl.NT == 3) return pl;
+  if (pl.MTW * pl.NT > 36) return pl;                  // accumulator registers
+  const int twp = (g->ow - 1) * g->stride + g->kw;
   int th = 256 / g->ow; if (th < 1) th = 1; if (th > g->oh) th = g->oh;
-  const int twp = g->ow + 2;
+  size_t red_b = (size_t)msplit * pl.MTW * 16 * g->cout * 4;
   for (;; --th) {
-    const size_t x_b = (size_t)(th + 2) * twp * g->cin * 4, dy_b = (size_t)th * g->ow * g->cout * 4;
-    size_t red_b = (size_t)msplit * pl.MTW * 16 * g->cout * 4;
+    const size_t x_b = (size_t)((th - 1) * g->stride + g->kh) * twp * g->cin * 4, dy_b = (size_t)th * g->ow * g->cout * 4;
     size_t need = x_b + dy_b + 16; if (need < red_b) need = red_b;
-    if (need <= 64 * 1024 || th == 1) { pl.lds = need; break; }
+    const bool fits_regs = (g->cin % 4 != 0 || x_b <= 7 * 256 * 16) && dy_b <= 3 * 256 * 16;   // kXV / kDV
+    if ((need <= 64 * 1024 && fits_regs) || th == 1) { pl.lds = need; if (!fits_regs) return pl; break; }
   }
   if (pl.lds > 150 * 1024) return pl;
   pl.TH = th;
@@ -237,9 +289,11 @@ inline int launch_wgrad(const seedhip_conv_geom* g, const WgradPlan& pl, const v
   WgradParams p;
   p.in = in; p.in_dtype = in_dtype; p.in_relu = in_relu; p.dy = dy;
   p.n_img = g->n_img; p.ih = g->ih; p.iw = g->iw; p.cin = g->cin; p.oh = g->oh; p.ow = g->ow; p.cout = g->cout;
-  p.ld_in = g->ld_in; p.ld_out = g->ld_out; p.pad = g->pad_t;
+  p.ld_in = g->ld_in; p.ld_out = g->ld_out; p.pad_t = g->pad_t; p.pad_l = g->pad_l;
+  p.kh = g->kh; p.kw = g->kw; p.stride = g->stride;
   p.TH = pl.TH; p.bands = (g->oh + pl.TH - 1) / pl.TH; p.ntiles = g->n_img * p.bands;
-  p.rows = 9 * g->cin; p.xs = g->cin; p.twp = g->ow + 2;
+  p.rows = g->kh * g->kw * g->cin; p.xs = g->cin;
+  p.twp = (g->ow - 1) * g->stride + g->kw; p.thp = (pl.TH - 1) * g->stride + g->kh;
   p.d_ow.init(g->ow);
   p.partial_w = (float*)workspace;
   p.partial_b = dbias ? (float*)workspace + (size_t)pl.grid * p.rows * g->cout : nullptr;
@@ -250,12 +304,16 @@ inline int launch_wgrad(const seedhip_conv_geom* g, const WgradPlan& pl, const v
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);                          \
     hipLaunchKernelGGL((halo_wgrad_kernel<MTW_, NT_, MS_>), dim3(pl.grid), dim3(256), pl.lds, s, p);               \
   } while (0)
-  if (pl.MTW == 2) SEEDHIP_HALO_LAUNCH(2, 1, 1);
-  else if (pl.NT == 1 && pl.MSPLIT == 1) SEEDHIP_HALO_LAUNCH(9, 1, 1);
-  else if (pl.NT == 2 && pl.MSPLIT == 1) SEEDHIP_HALO_LAUNCH(9, 2, 1);
-  else if (pl.NT == 1 && pl.MSPLIT == 2) SEEDHIP_HALO_LAUNCH(9, 1, 2);
-  else if (pl.NT == 2 && pl.MSPLIT == 2) SEEDHIP_HALO_LAUNCH(9, 2, 2);
-  else SEEDHIP_HALO_LAUNCH(9, 4, 4);
+#define SEEDHIP_HALO_CASE(MTW_, NT_, MS_) if (pl.MTW == MTW_ && pl.NT == NT_ && pl.MSPLIT == MS_) { SEEDHIP_HALO_LAUNCH(MTW_, NT_, MS_); launched = true; }
+  bool launched = false;
+  SEEDHIP_HALO_CASE(2, 1, 1)
+  SEEDHIP_HALO_CASE(9, 1, 1) SEEDHIP_HALO_CASE(9, 2, 1) SEEDHIP_HALO_CASE(9, 1, 2) SEEDHIP_HALO_CASE(9, 2, 2)
+  SEEDHIP_HALO_CASE(9, 4, 4) SEEDHIP_HALO_CASE(9, 4, 2) SEEDHIP_HALO_CASE(9, 2, 4) SEEDHIP_HALO_CASE(9, 1, 4)
+  SEEDHIP_HALO_CASE(8, 1, 1) SEEDHIP_HALO_CASE(8, 2, 1) SEEDHIP_HALO_CASE(8, 1, 2) SEEDHIP_HALO_CASE(8, 2, 2)
+  SEEDHIP_HALO_CASE(8, 4, 4) SEEDHIP_HALO_CASE(8, 4, 2) SEEDHIP_HALO_CASE(8, 2, 4) SEEDHIP_HALO_CASE(8, 1, 4)
+  SEEDHIP_HALO_CASE(8, 4, 1) SEEDHIP_HALO_CASE(9, 4, 1)
+#undef SEEDHIP_HALO_CASE
+  if (!launched) return fail(SEEDHIP_ERR_UNSUPPORTED, "halo_wgrad: no kernel for MTW=%d NT=%d MSPLIT=%d", pl.MTW, pl.NT, pl.MSPLIT);
 #undef SEEDHIP_HALO_LAUNCH
   int rc = check_launch("halo_wgrad_kernel"); if (rc) return rc;
   reduce_slices(p.partial_w, pl.grid, (long long)p.rows * g->cout, dw, s);
