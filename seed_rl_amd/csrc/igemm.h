@@ -127,12 +127,12 @@ igemm_kernel(const P p) {
     else bcol[i] = p.b_col(n0 + b_slow[i], z);                           // slow = n, fast = k
   }
 
-  float4 ra[VA], rb[VB];
+  float4 ra0[VA], rb0[VB], ra1[VA], rb1[VB];     // two register stages: tiles kt+1 and kt+2 in flight
   float4 colsum[VB];
 #pragma unroll
   for (int i = 0; i < VB; ++i) colsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, float4 (&ra)[VA], float4 (&rb)[VB]) {
     const int kb = k0 + kt * BK;
 #pragma unroll
     for (int i = 0; i < VA; ++i) {
@@ -146,13 +146,10 @@ igemm_kernel(const P p) {
       if (NVB >= 256 || tid + i * 256 < NVB) {
         const int k = kb + (P::kBVecN ? b_slow[i] : b_fast[i]);
         rb[i] = (k < k1) ? p.load_b(bcol[i], k, z) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (P::kColSumB) {
-          colsum[i].x += rb[i].x; colsum[i].y += rb[i].y; colsum[i].z += rb[i].z; colsum[i].w += rb[i].w;
-        }
       }
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, float4 (&ra)[VA], float4 (&rb)[VB]) {
     float* A = As + buf * BM * LDA;
     float* B = Bs + buf * BK * LDB;
 #pragma unroll
@@ -171,6 +168,9 @@ igemm_kernel(const P p) {
 #pragma unroll
     for (int i = 0; i < VB; ++i) {
       if (NVB >= 256 || tid + i * 256 < NVB) {
+        if constexpr (P::kColSumB) {                   // bias gradient: summed when the tile is consumed, not when its
+          colsum[i].x += rb[i].x; colsum[i].y += rb[i].y; colsum[i].z += rb[i].z; colsum[i].w += rb[i].w;   // load is issued
+        }
         if constexpr (P::kBVecN) {
           *reinterpret_cast<float4*>(B + b_slow[i] * LDB + b_fast[i]) = rb[i];   // LDB % 4 == 0
         } else {
@@ -187,17 +187,19 @@ igemm_kernel(const P p) {
 #pragma unroll
     for (int j = 0; j < NR; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  if (nkt > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
+  // Pipeline: LDS double buffer + TWO register stages.  While tile kt is multiplied out of LDS, tile kt+1
+  // sits in one register set (stored to the other LDS buffer after the MFMAs) and the global loads of tile
+  // kt+2 are issued into the other set -- two k-tiles (~2 x 1000 matrix-pipe cycles) of load latency cover,
+  // which matters at the 1-2 workgroups per CU these layer shapes give.
+  if (nkt > 0) { load_tile(0, ra0, rb0); store_tile(0, ra0, rb0); }
+  if (nkt > 1) load_tile(1, ra1, rb1);
   __syncthreads();
 
   const int a_frag_off = (wm * MR * 16 + (lane & 15)) * LDA + (lane >> 4);
   const int b_frag_off = (lane >> 4) * LDB + wn * NR * 16 + (lane & 15);
-  for (int kt = 0; kt < nkt; ++kt) {
+  auto step = [&](int kt, float4 (&la)[VA], float4 (&lb)[VB], float4 (&sa)[VA], float4 (&sb)[VB]) {
     const int buf = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1);            // global loads fly under the MFMAs below
+    if (kt + 2 < nkt) load_tile(kt + 2, la, lb);
     const float* A = As + buf * BM * LDA + a_frag_off;
     const float* B = Bs + buf * BK * LDB + b_frag_off;
 #pragma unroll
@@ -213,8 +215,12 @@ igemm_kernel(const P p) {
         for (int j = 0; j < NR; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    if (kt + 1 < nkt) store_tile(buf ^ 1, sa, sb);
     __syncthreads();
+  };
+  for (int kt = 0; kt < nkt; kt += 2) {
+    step(kt, ra0, rb0, ra1, rb1);                    // even: tile kt+2 -> set 0, tile kt+1 (set 1) -> LDS
+    if (kt + 1 < nkt) step(kt + 1, ra1, rb1, ra0, rb0);
   }
 
   // Epilogue: C[row = 4*(lane>>4) + reg][col = lane & 15] per 16x16 tile.
