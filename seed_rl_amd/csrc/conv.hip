@@ -19,6 +19,11 @@ ConvGeom to_geom(const seedhip_conv_geom* g) {
   return c;
 }
 
+bool is_dense(const seedhip_conv_geom* g) {
+  return g->kh == 1 && g->kw == 1 && g->ih == 1 && g->iw == 1 && g->oh == 1 && g->ow == 1 && g->stride == 1 &&
+         g->pad_t == 0 && g->pad_l == 0;
+}
+
 int check_geom(const seedhip_conv_geom* g, const char* what) {
   SEEDHIP_REQUIRE(g, "%s: null geometry", what);
   SEEDHIP_REQUIRE(g->n_img >= 1 && g->ih >= 1 && g->iw >= 1 && g->cin >= 1 && g->oh >= 1 && g->ow >= 1 &&
@@ -62,6 +67,14 @@ extern "C" int seedhip_conv2d_fwd(const seedhip_conv_geom* geom, const void* in,
       halo::fill_tiling(hp, pl);
       return halo::launch_fwd_kernel(hp, pl, (hipStream_t)stream);
     }
+  }
+  if (is_dense(geom) && in_dtype == kInF32 && geom->cin % 4 == 0 && geom->ld_in % 4 == 0 && (((uintptr_t)in) & 15) == 0) {
+    DenseFwd d;
+    d.in = (const float*)in; d.in_relu = in_relu; d.w = w; d.bias = bias; d.out = out; d.out_relu = out_relu;
+    d.residual = residual;
+    d.init(to_geom(geom));
+    launch_igemm_auto(d, 1, (hipStream_t)stream);
+    return check_launch("conv2d_fwd(dense)");
   }
   ConvFwd p;
   p.in = in; p.in_dtype = in_dtype; p.in_relu = in_relu; p.w = w; p.bias = bias; p.out = out;
@@ -116,6 +129,13 @@ extern "C" int seedhip_conv2d_bwd_data(const seedhip_conv_geom* geom, const floa
       return SEEDHIP_OK;
     }
   }
+  if (is_dense(geom) && geom->cout % 4 == 0 && geom->ld_out % 4 == 0 && (((uintptr_t)dy | (uintptr_t)w) & 15) == 0) {
+    DenseDgrad d;
+    d.dy = dy; d.w = w; d.dx = dx; d.mask = relu_mask; d.add = add;
+    d.init(to_geom(geom));
+    launch_igemm_auto(d, 1, (hipStream_t)stream);
+    return check_launch("conv2d_bwd_data(dense)");
+  }
   ConvDgrad p;
   p.dy = dy; p.w = w; p.dx = dx; p.mask = relu_mask; p.add = add;
   p.init(to_geom(geom));
@@ -147,6 +167,20 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
     const halo::WgradPlan pl = halo::plan_wgrad(geom);
     if (pl.ok && (((uintptr_t)in) & 15) == 0 && (((uintptr_t)dy) & 15) == 0)
       return halo::launch_wgrad(geom, pl, in, in_dtype, in_relu, dy, dw, dbias, workspace, (hipStream_t)stream);
+  }
+  if (is_dense(geom) && in_dtype == kInF32 && geom->cin % 4 == 0 && geom->ld_in % 4 == 0 && (((uintptr_t)in) & 15) == 0) {
+    DenseWgrad d;
+    d.in = (const float*)in; d.in_relu = in_relu; d.dy = dy;
+    const int M = geom->cin, N = geom->cout;
+    d.init(to_geom(geom), pick_k_per_slice(geom->n_img, tiles_for(M, N)));
+    const int slices = d.slices();
+    d.partial_w = (float*)workspace;
+    d.partial_b = dbias ? (float*)workspace + (size_t)slices * M * N : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    launch_igemm_auto(d, slices, s);
+    reduce_slices(d.partial_w, slices, (long long)M * N, dw, s);
+    if (dbias) reduce_slices(d.partial_b, slices, N, dbias, s);
+    return check_launch("conv2d_bwd_weight(dense)");
   }
   ConvWgrad p;
   p.in = in; p.in_dtype = in_dtype; p.in_relu = in_relu; p.dy = dy;

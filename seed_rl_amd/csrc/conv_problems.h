@@ -294,6 +294,102 @@ struct ConvWgrad {
   SH_HD void store_colsum(int n, float v, int z) const { if (partial_b) partial_b[(long long)z * N + n] = v; }
 };
 
+
+// --------------------------------------------------------------------------- //
+// Dense layers (1x1 kernel on a 1x1 image = plain GEMM): the same three problems with the
+// im2col index arithmetic removed -- the generic accessors spend ~4 VALU instructions per MFMA
+// on div/mod and bounds checks, which a single wave per SIMD cannot hide.
+//   y[r, n] = act( sum_k relu?(x[r*ld_in + k]) * W[k*cout + n] + bias[n] (+ residual) )
+// Requires cin % 4 == 0, ld_in % 4 == 0 (A rows are read as float4).
+// --------------------------------------------------------------------------- //
+struct DenseFwd {
+  static constexpr bool kAVecK = true, kBVecN = true, kColSumB = false;
+  int M, N, K, ld_in, ld_out, cout, in_relu, out_relu, vec_b;
+  const float* in; const float* w; const float* bias; float* out; const float* residual;
+  void init(const ConvGeom& g) {
+    M = g.n_img; N = g.cout; K = g.cin; ld_in = g.ld_in; ld_out = g.ld_out; cout = g.cout;
+    vec_b = (g.cout % 4 == 0);
+  }
+  SH_HD void k_range(int, int& k0, int& k1) const { k0 = 0; k1 = K; }
+  struct ARow { const float* p; };
+  SH_HD ARow a_row(int m, int) const { return ARow{m < M ? in + (long long)m * ld_in : nullptr}; }
+  SH_HD float4 load_a(const ARow& r, int k, int) const {
+    if (!r.p) return f4_zero();
+    const float4 v = ld4(r.p + k);
+    return in_relu ? f4_relu(v) : v;
+  }
+  struct BCol { int n; };
+  SH_HD BCol b_col(int n, int) const { return BCol{n}; }
+  SH_HD float4 load_b(const BCol& c, int k, int) const {
+    if (c.n >= N) return f4_zero();
+    const float* p = w + (long long)k * cout + c.n;
+    if (vec_b) return ld4(p);
+    return make_float4(p[0], c.n + 1 < N ? p[1] : 0.f, c.n + 2 < N ? p[2] : 0.f, c.n + 3 < N ? p[3] : 0.f);
+  }
+  SH_HD void store(int m, int n, float v, int) const {
+    if (bias) v += bias[n];
+    const long long o = (long long)m * ld_out + n;
+    if (residual) v += residual[o];
+    out[o] = relu_if(v, out_relu);
+  }
+  SH_HD void store_colsum(int, float, int) const {}
+};
+
+// dx[r, ci] = sum_co dy[r*ld_out + co] * W[ci*cout + co]; then mask / accumulate.  cout % 4 == 0, ld_out % 4 == 0.
+struct DenseDgrad {
+  static constexpr bool kAVecK = true, kBVecN = false, kColSumB = false;
+  int M, N, K, ld_in, ld_out, cout;
+  const float* dy; const float* w; float* dx; const float* mask; const float* add;
+  void init(const ConvGeom& g) { M = g.n_img; N = g.cin; K = g.cout; ld_in = g.ld_in; ld_out = g.ld_out; cout = g.cout; }
+  int slices() const { return 1; }
+  SH_HD void k_range(int, int& k0, int& k1) const { k0 = 0; k1 = K; }
+  struct ARow { const float* p; };
+  SH_HD ARow a_row(int m, int) const { return ARow{m < M ? dy + (long long)m * ld_out : nullptr}; }
+  SH_HD float4 load_a(const ARow& r, int k, int) const { return r.p ? ld4(r.p + k) : f4_zero(); }
+  struct BCol { const float* p; };
+  SH_HD BCol b_col(int n, int) const { return BCol{n < N ? w + (long long)n * cout : nullptr}; }
+  SH_HD float4 load_b(const BCol& c, int k, int) const { return c.p ? ld4(c.p + k) : f4_zero(); }
+  SH_HD void store(int m, int n, float v, int) const {
+    const long long o = (long long)m * ld_in + n;
+    if (mask && !(mask[o] > 0.f)) v = 0.f;
+    if (add) v += add[o];
+    dx[o] = v;
+  }
+  SH_HD void store_colsum(int, float, int) const {}
+};
+
+// dW[ci, co] = sum_r relu?(x[r*ld_in + ci]) * dy[r*ld_out + co]; db = column sums of dy.  Split over rows.
+struct DenseWgrad {
+  static constexpr bool kAVecK = false, kBVecN = true, kColSumB = true;
+  int M, N, K, ld_in, ld_out, k_per_slice, in_relu, vec_b;
+  const float* in; const float* dy; float* partial_w; float* partial_b;
+  void init(const ConvGeom& g, int k_per_slice_) {
+    M = g.cin; N = g.cout; K = g.n_img; ld_in = g.ld_in; ld_out = g.ld_out; k_per_slice = k_per_slice_;
+    vec_b = (g.cout % 4 == 0) && (g.ld_out % 4 == 0);
+  }
+  int slices() const { return (K + k_per_slice - 1) / k_per_slice; }
+  SH_HD void k_range(int z, int& k0, int& k1) const {
+    k0 = z * k_per_slice; k1 = k0 + k_per_slice; if (k1 > K) k1 = K;
+  }
+  struct ARow { int m; };
+  SH_HD ARow a_row(int m, int) const { return ARow{m}; }
+  SH_HD float4 load_a(const ARow& r, int k, int) const {      // (m..m+3, row k); M % 4 == 0
+    if (r.m >= M) return f4_zero();
+    const float4 v = ld4(in + (long long)k * ld_in + r.m);
+    return in_relu ? f4_relu(v) : v;
+  }
+  struct BCol { int n; };
+  SH_HD BCol b_col(int n, int) const { return BCol{n}; }
+  SH_HD float4 load_b(const BCol& c, int k, int) const {
+    if (c.n >= N) return f4_zero();
+    const float* p = dy + (long long)k * ld_out + c.n;
+    if (vec_b) return ld4(p);
+    return make_float4(p[0], c.n + 1 < N ? p[1] : 0.f, c.n + 2 < N ? p[2] : 0.f, c.n + 3 < N ? p[3] : 0.f);
+  }
+  SH_HD void store(int m, int n, float v, int z) const { partial_w[((long long)z * M + m) * N + n] = v; }
+  SH_HD void store_colsum(int n, float v, int z) const { if (partial_b) partial_b[(long long)z * N + n] = v; }
+};
+
 // --------------------------------------------------------------------------- //
 // Frame-stacked first conv (Atari): image n = t*B + b of an unroll; stack channel c
 // (0 = newest) of step t is uint8 frame (t - c) of frames_ext (see frames.hip),

@@ -270,7 +270,13 @@ inline void launch_igemm_auto(const P& p, int slices, hipStream_t s) {
   if (p.N <= 16) launch_igemm<P, 4, 1, 4, 1, 16>(p, slices, s);          // 256 x 16
   else if (p.N <= 32) launch_igemm<P, 4, 1, 2, 2, 16>(p, slices, s);     // 128 x 32
   else if (p.N <= 48) launch_igemm<P, 4, 1, 2, 3, 16>(p, slices, s);     // 128 x 48
-  else launch_igemm<P, 2, 2, 4, 2, 16>(p, slices, s);                    // 128 x 64 tiles over N
+  else {
+    // 128 x 64 tiles over N; 64 x 64 when that leaves the chip under ~2 workgroups per CU (latency hiding
+    // needs several waves per SIMD: one wave cannot cover its own staging VALU under the 32-cycle MFMAs)
+    const long long wgs = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * slices;
+    if (wgs < 512 && p.M > 64) launch_igemm<P, 2, 2, 2, 2, 16>(p, slices, s);
+    else launch_igemm<P, 2, 2, 4, 2, 16>(p, slices, s);
+  }
 }
 
 #endif  // __HIPCC__
