@@ -44,6 +44,9 @@ def parse():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-batch', type=int, default=64)
   ap.add_argument('--reduction', default='mean', choices=['mean', 'sum'])
+  ap.add_argument('--graph', type=int, default=1,
+                  help='1 (default, single GPU): replay the step from a captured HIP graph (learner.GraphedStep; measured '
+                       '0-2%% over eager on MI355X); 0: eager launches.  Multi-GPU runs launch eagerly.')
   return ap.parse_args()
 
 
@@ -104,7 +107,8 @@ def main():
   A = args.actions or (9 if deep else 18)
   T1 = T + 1
   final_iteration = 10 ** 9 // (T * B * max(world, 1))
-  opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, final_iteration), beta_1=0.0, epsilon=3.125e-7)
+  opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, final_iteration), beta_1=0.0, epsilon=3.125e-7,
+                        capturable=bool(args.graph))
   if r2:
     from seed_rl_amd import r2d2_learner
     agent = networks.DuelingLSTMDQNNet(A, device=dev, seed=0)
@@ -129,7 +133,7 @@ def main():
         observation=ext[3:].view(T1, B, agent._obs[0], agent._obs[1], 1)))
     workload = 'Atari 84x84x4 IMPALA %s ConvNet learner step' % args.torso
   if r2:
-    opt = optimizers.Adam(4.8e-4, epsilon=1e-3)                                 # atari/r2d2_main.py:36-39
+    opt = optimizers.Adam(4.8e-4, epsilon=1e-3, capturable=bool(args.graph))    # atari/r2d2_main.py:36-39
     r2l = r2d2_learner.R2D2Learner(agent, target, opt, r2d2_learner.R2D2Config(), reduction=args.reduction)
 
     class _Step(object):
@@ -153,20 +157,43 @@ def main():
   lrn.minimize(unroll)
   ops.set_profiler(None)
   kern = prof_all.summary()
-  dominant = max(kern, key=lambda k: kern[k]['total_ms'])
+  # dominant kernel = largest share of the step among kernels that run >= 50 us per launch (event pairs around
+  # few-microsecond kernels launched hundreds of times per step -- LSTM gate kernels -- absorb the tail of the
+  # preceding GEMM and are not a reliable ranking; rocprofv3 --stats in profiles/ is the reference view)
+  big = [k for k in kern if kern[k]['avg_ms'] >= 0.05] or list(kern)
+  dominant = max(big, key=lambda k: kern[k]['total_ms'])
   if args.warmup == 0:
     dominant = sorted(kern)[0]
 
   # ---- timed region: exactly K steps, barrier + sync on both sides ----
+  step_fn = lambda: lrn.minimize(unroll)
+  mode = 'eager'
+  if args.graph and world == 1:
+    try:
+      gs = learner.GraphedStep(r2l, unroll, iw, warmup=1) if r2 else learner.GraphedStep(lrn, unroll, warmup=1)
+      step_fn, mode = (lambda: gs()), 'hip-graph'
+      step_fn(); torch.cuda.synchronize()
+    except Exception as e:                       # pylint: disable=broad-except
+      sys.stderr.write('HIP-graph capture unavailable (%s); timing eager launches\n' % e)
+      step_fn, mode = (lambda: lrn.minimize(unroll)), 'eager'
   prof = ops.Profiler(only=[dominant])
-  ops.set_profiler(prof)
+  if mode == 'eager':
+    ops.set_profiler(prof)
   barrier()
   t0 = time.perf_counter()
   for _ in range(args.steps):
-    loss, _ = lrn.minimize(unroll)
+    out = step_fn()
   barrier()
   dt = time.perf_counter() - t0
   ops.set_profiler(None)
+  loss = out[0]
+  if mode != 'eager':
+    # kernel time of the dominant kernel for the roofline: HIP events around it on the launch stream, in a
+    # few eager steps after the timed region (events cannot be recorded inside a replayed graph)
+    ops.set_profiler(prof)
+    for _ in range(min(args.steps, 5)):
+      lrn.minimize(unroll)
+    ops.set_profiler(None)
   if world > 1:
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -198,7 +225,7 @@ def main():
       'config': {'workload': '%s, T=%d B=%d/GPU A=%d, synthetic uint8 frames in HBM, num_action_repeats=1'
                              % (workload, T, B, A),
                  'global_batch': B * world, 'unroll_length': T, 'parallelism': 'dp%d' % world,
-                 'grad_reduction': args.reduction, 'params': agent.flat.num_params()},
+                 'grad_reduction': args.reduction, 'params': agent.flat.num_params(), 'launch': mode},
       'roofline': roofline,
       'loss': round(loss_val, 6),
       'kernels_ms_per_step': {k: round(v['total_ms'], 4) for k, v in kern.items()},

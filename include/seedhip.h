@@ -90,6 +90,11 @@ int seedhip_impala_loss_fwd_bwd(
  * first (1/world for data-parallel mean; 1 for the reference cross-replica SUM). */
 int seedhip_adam_flat(float* params, const float* grads, float* m, float* v, long long n,
                       float lr_t, float beta_1, float beta_2, float epsilon, float grad_scale, void* stream);
+/* Same update with lr_t read from a device scalar, so that a whole train step (whose only per-step host
+ * value is the bias-corrected learning rate) can be captured once in a HIP graph and replayed. */
+int seedhip_adam_flat_dev_lr(float* params, const float* grads, float* m, float* v, long long n,
+                             const float* lr_t_device, float beta_1, float beta_2, float epsilon,
+                             float grad_scale, void* stream);
 /* tf.clip_by_global_norm(grads, clip_norm) of agents/r2d2/learner.py:606-609; sumsq_out[0] = |g|^2.
  * clip_norm <= 0: only compute the norm. */
 size_t seedhip_global_norm_workspace_bytes(void);

@@ -44,6 +44,7 @@ SIGNATURES = {
                  c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float,
                  P, P, P, P, P, P, c_size_t, P]),
     'seedhip_adam_flat': (c_int, [P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, P]),
+    'seedhip_adam_flat_dev_lr': (c_int, [P, P, P, P, c_ll, P, c_float, c_float, c_float, c_float, P]),
     'seedhip_global_norm_workspace_bytes': (c_size_t, []),
     'seedhip_clip_by_global_norm': (c_int, [P, c_ll, c_float, P, P, c_size_t, P]),
     'seedhip_stack_prepare': (c_int, [P, P, c_int, c_int, c_ll, P, P, P]),

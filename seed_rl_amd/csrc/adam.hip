@@ -14,8 +14,9 @@
 namespace {
 __global__ void __launch_bounds__(256)
 adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                 float* __restrict__ v, long long n, float lr_t, float one_minus_b1, float one_minus_b2,
-                 float eps, float grad_scale) {
+                 float* __restrict__ v, long long n, float lr_host, const float* __restrict__ lr_dev,
+                 float one_minus_b1, float one_minus_b2, float eps, float grad_scale) {
+  const float lr_t = lr_dev ? lr_dev[0] : lr_host;   // device scalar: the step can sit in a captured HIP graph
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -85,7 +86,22 @@ extern "C" int seedhip_adam_flat(float* params, const float* grads, float* m, fl
   int blocks = seedhip::cdiv(n / 4 + 1, 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n,
-                     lr_t, 1.0f - beta_1, 1.0f - beta_2, epsilon, grad_scale);
+                     lr_t, (const float*)nullptr, 1.0f - beta_1, 1.0f - beta_2, epsilon, grad_scale);
+  return seedhip::check_launch("adam_flat_kernel");
+}
+
+extern "C" int seedhip_adam_flat_dev_lr(float* params, const float* grads, float* m, float* v, long long n,
+                                        const float* lr_t_device, float beta_1, float beta_2, float epsilon,
+                                        float grad_scale, void* stream) {
+  SEEDHIP_REQUIRE(n >= 0, "adam: negative n");
+  if (n == 0) return SEEDHIP_OK;
+  SEEDHIP_REQUIRE(params && grads && m && v && lr_t_device, "adam: null pointer");
+  SEEDHIP_REQUIRE(((((uintptr_t)params) | ((uintptr_t)grads) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0,
+                  "adam: buffers must be 16-byte aligned");
+  int blocks = seedhip::cdiv(n / 4 + 1, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n,
+                     0.f, lr_t_device, 1.0f - beta_1, 1.0f - beta_2, epsilon, grad_scale);
   return seedhip::check_launch("adam_flat_kernel");
 }
 

@@ -144,14 +144,78 @@ class Learner(object):
     self.agent.backward()
     return loss, session
 
-  def apply_gradients(self):
+  def reduce_gradients(self):
     all_reduce_gradients(self.agent.flat.grads, self.pg)
+
+  def update(self):
     self.optimizer.apply_gradients(self.agent.flat)
 
+  def apply_gradients(self):
+    self.reduce_gradients()
+    self.update()
+
   def minimize(self, unroll):
+    begin = getattr(self.optimizer, 'begin_step', None)
+    if begin is not None and not torch.cuda.is_current_stream_capturing():
+      begin(self.agent.flat.params.device)
     loss, session = self.compute_gradients(unroll)
     self.apply_gradients()
     cb = getattr(self.agent, 'end_of_training_step_callback', None)   # learner.py:277-278
     if cb is not None:
       cb()
     return loss, session
+
+
+class GraphedStep(object):
+  """Captures a train step ONCE into HIP graphs and replays it: the ~25 (Atari) to ~600 (R2D2) kernel launches
+  of a step become one graph launch, removing the host-side launch gaps (HIP graphs in place of the reference's
+  tf.function / XLA step).  Single replica: one graph for the whole step.  Data parallel: graph 1 =
+  compute_gradients, then the RCCL all-reduce launched eagerly, then graph 2 = optimizer update.
+  The unroll's tensors are the graph's static inputs: copy new trajectories into them (the unroll store can
+  write completed unrolls straight into these buffers) and call the object.  Needs an optimizer created with
+  capturable=True; everything else on the step is already free of host reads."""
+
+  def __init__(self, learner, unroll, *extra, warmup=2):
+    if not getattr(learner.optimizer, 'capturable', False):
+      raise ValueError('GraphedStep needs optimizers.Adam(..., capturable=True)')
+    self.learner, self.unroll, self.extra = learner, unroll, extra
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      for _ in range(warmup):                       # allocates every workspace, loads every code object
+        learner.minimize(unroll, *extra)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    opt = learner.optimizer
+    opt.begin_step(learner.agent.flat.params.device)
+    it0 = opt.iterations
+    counters = dict((k, getattr(learner, k)) for k in ('iterations',) if hasattr(learner, k))
+    self.split = getattr(learner, 'world', 1) > 1
+    self.graph = torch.cuda.CUDAGraph()
+    self.graph2 = None
+    if not self.split:
+      with torch.cuda.graph(self.graph, capture_error_mode='relaxed'):
+        self.outputs = learner.compute_gradients(unroll, *extra)
+        learner.update()
+    else:
+      with torch.cuda.graph(self.graph, capture_error_mode='relaxed'):
+        self.outputs = learner.compute_gradients(unroll, *extra)
+      self.graph2 = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(self.graph2, capture_error_mode='relaxed'):
+        learner.update()
+    opt.iterations = it0                            # capture ran the Python bookkeeping, not the kernels
+    for k, v in counters.items():
+      setattr(learner, k, v)
+
+  def __call__(self):
+    opt = self.learner.optimizer
+    opt.begin_step()
+    self.graph.replay()
+    if self.split:
+      self.learner.reduce_gradients()
+      self.graph2.replay()
+    opt.iterations += 1
+    post = getattr(self.learner, 'after_graph_replay', None)
+    if post is not None:
+      post()
+    return self.outputs

@@ -25,12 +25,14 @@ class Profiler(object):
 
   @staticmethod
   def event_overhead_ms(n=50):
-    """Elapsed time HIP reports for an EMPTY (start, end) event pair: subtracted from every region so that
-    kernels launched hundreds of times per step (LSTM steps) are not ranked by event overhead."""
+    """What a (start, end) HIP event pair reports around a TRIVIAL kernel (a 1-element fill): the marker /
+    dispatch overhead that every instrumented region carries.  Subtracted from every region so that kernels
+    launched hundreds of times per step (LSTM steps, a few microseconds each) are not ranked by it."""
+    x = torch.zeros(1, device='cuda')
     pairs = []
     for _ in range(n):
       s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-      s.record(); e.record()
+      s.record(); x.fill_(1.0); e.record()
       pairs.append((s, e))
     torch.cuda.synchronize()
     v = sorted(s.elapsed_time(e) for s, e in pairs)
@@ -205,6 +207,14 @@ def adam_flat(params, grads, m, v, lr_t, beta_1, beta_2, epsilon, grad_scale=1.0
       _lib.check(_lib.lib().seedhip_adam_flat(
           _lib.ptr(params), _lib.ptr(grads), _lib.ptr(m), _lib.ptr(v), params.numel(), lr_t, beta_1, beta_2,
           epsilon, grad_scale, _lib.stream()), 'seedhip_adam_flat')
+
+
+def adam_flat_dev_lr(params, grads, m, v, lr_t_dev, beta_1, beta_2, epsilon, grad_scale=1.0):
+  with _region('adam_flat', 0, params.numel() * 28):
+    with _dev(params):
+      _lib.check(_lib.lib().seedhip_adam_flat_dev_lr(
+          _lib.ptr(params), _lib.ptr(grads), _lib.ptr(m), _lib.ptr(v), params.numel(), _lib.ptr(lr_t_dev), beta_1,
+          beta_2, epsilon, grad_scale, _lib.stream()), 'seedhip_adam_flat_dev_lr')
 
 
 def global_norm_workspace_bytes():

@@ -27,11 +27,27 @@ class PolynomialDecay(object):
 class Adam(object):
   """tf.keras.optimizers.Adam semantics on a FlatParams."""
 
-  def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+  def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, capturable=False):
+    """capturable=True keeps the bias-corrected learning rate in a device scalar (refreshed by `begin_step()`
+    outside any HIP-graph capture), so that apply_gradients() can be captured and replayed."""
     self.learning_rate = learning_rate
     self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
     self.iterations = 0
     self._m = self._v = None
+    self.capturable = capturable
+    self._lr_dev = None
+
+  def lr_t(self):
+    t = self.iterations + 1
+    return self._lr() * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+
+  def begin_step(self, device=None):
+    """Publishes this step's learning rate to the device scalar (capturable mode; no-op otherwise)."""
+    if not self.capturable:
+      return
+    if self._lr_dev is None:
+      self._lr_dev = torch.zeros(1, dtype=torch.float32, device=device or 'cuda')
+    self._lr_dev.fill_(float(self.lr_t()))
 
   def _lr(self):
     return self.learning_rate(self.iterations) if callable(self.learning_rate) else self.learning_rate
@@ -41,9 +57,14 @@ class Adam(object):
       self._m = torch.zeros_like(flat.params)
       self._v = torch.zeros_like(flat.params)
     t = self.iterations + 1
-    lr_t = self._lr() * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
-    ops.adam_flat(flat.params, flat.grads, self._m, self._v, float(lr_t), self.beta_1, self.beta_2,
-                  self.epsilon, float(grad_scale))
+    if self.capturable:
+      if self._lr_dev is None:
+        self.begin_step(flat.params.device)
+      ops.adam_flat_dev_lr(flat.params, flat.grads, self._m, self._v, self._lr_dev, self.beta_1, self.beta_2,
+                           self.epsilon, float(grad_scale))
+    else:
+      ops.adam_flat(flat.params, flat.grads, self._m, self._v, float(self.lr_t()), self.beta_1, self.beta_2,
+                    self.epsilon, float(grad_scale))
     self.iterations = t
 
   def state_dict(self):

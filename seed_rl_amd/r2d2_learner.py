@@ -90,7 +90,14 @@ class R2D2Learner(object):
     """learner.py:856-857 / :640-644: target <- training (one flat copy)."""
     self.target_agent.flat.params.copy_(self.agent.flat.params)
 
-  def minimize(self, unroll, importance_weights=None):
+  def after_graph_replay(self):
+    """Python-side bookkeeping of a step replayed from a HIP graph (learner.GraphedStep)."""
+    self.iterations += 1
+    cfg = self.config
+    if cfg.update_target_every_n_step and self.iterations % cfg.update_target_every_n_step == 0:
+      self.update_target()
+
+  def compute_gradients(self, unroll, importance_weights=None):
     cfg = self.config
     B = unroll.env_outputs.done.shape[1]
     n = B * (self.world if self.reduction == 'mean' else 1)
@@ -98,12 +105,27 @@ class R2D2Learner(object):
         self.agent, self.target_agent, unroll.agent_state, unroll.prev_actions, unroll.env_outputs,
         unroll.agent_outputs, cfg.discounting, cfg.burn_in, cfg, importance_weights, mean_denominator=n)
     self.agent.backward()
+    self._sumsq = self.agent._buf('gnorm_sumsq', (1,))
+    return total, prio, self._sumsq
+
+  def reduce_gradients(self):
+    all_reduce_gradients(self.agent.flat.grads, self.pg)
+
+  def update(self):
     flat = self.agent.flat
-    all_reduce_gradients(flat.grads, self.pg)
-    sumsq = self.agent._buf('gnorm_sumsq', (1,))
     gws = self.agent._buf('gnorm_ws', (ops.global_norm_workspace_bytes() // 4 + 4,))
-    ops.clip_by_global_norm(flat.grads, cfg.clip_norm or 0.0, sumsq, gws)               # learner.py:605-609
+    ops.clip_by_global_norm(flat.grads, self.config.clip_norm or 0.0, self._sumsq, gws)   # learner.py:605-609
     self.optimizer.apply_gradients(flat)
+
+  def minimize(self, unroll, importance_weights=None):
+    """learner.py:572-636.  Returns (loss, new priorities [B], gradient norm before clipping)."""
+    cfg = self.config
+    begin = getattr(self.optimizer, 'begin_step', None)
+    if begin is not None and not torch.cuda.is_current_stream_capturing():
+      begin(self.agent.flat.params.device)
+    total, prio, sumsq = self.compute_gradients(unroll, importance_weights)
+    self.reduce_gradients()
+    self.update()
     self.iterations += 1
     if cfg.update_target_every_n_step and self.iterations % cfg.update_target_every_n_step == 0:
       self.update_target()

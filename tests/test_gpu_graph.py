@@ -1,0 +1,39 @@
+"""HIP-graph replay of the train step (learner.GraphedStep): bitwise the same parameters as eager launches."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(device, kind):
+  from seed_rl_amd import learner, networks, optimizers, parametric_distribution as pd, smoke_step
+  A = 6
+  opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, 50), beta_1=0.0, epsilon=3.125e-7, capturable=True)
+  if kind == 'atari':
+    agent = networks.AtariShallow(A, device=device, seed=0)
+    unroll = smoke_step.make_unroll(agent, 5, 4, A, device, seed=3, done_p=0.2)
+  else:
+    agent = networks.ImpalaDeep(A, observation_shape=(24, 32, 3), device=device, seed=0)
+    unroll = smoke_step.make_deep_unroll(agent, 5, 4, A, device, seed=3, done_p=0.2)
+  return learner.Learner(agent, opt, pd.categorical_distribution(A)), unroll
+
+
+@pytest.mark.parametrize('kind', ['atari', 'deep'])
+def test_graphed_step_matches_eager(device, kind):
+  from seed_rl_amd import learner
+  eager, unroll = _mk(device, kind)
+  losses = []
+  for _ in range(5):                       # 2 warm-up steps inside GraphedStep + 3 replays below
+    l, _ = eager.minimize(unroll)
+    losses.append(float(l))
+  graphed, unroll2 = _mk(device, kind)
+  step = learner.GraphedStep(graphed, unroll2, warmup=2)
+  assert graphed.optimizer.iterations == 2
+  glosses = []
+  for _ in range(3):
+    out = step()
+    torch.cuda.synchronize()
+    glosses.append(float(out[0]))
+  assert graphed.optimizer.iterations == 5
+  assert glosses == losses[2:]
+  assert torch.equal(graphed.agent.flat.params, eager.agent.flat.params)
