@@ -46,26 +46,22 @@ extern "C" int seedhip_conv2d_fwd(const seedhip_conv_geom* geom, const void* in,
   SEEDHIP_REQUIRE(in && w && out, "conv2d_fwd: null pointer");
   SEEDHIP_REQUIRE(in_dtype == kInF32 || in_dtype == kInU8Div255, "conv2d_fwd: bad in_dtype %d", in_dtype);
   {
-    // small-kernel layers: input band staged once in LDS (halo_fwd.h)
-    const halo::FwdPlan pl = halo::plan_fwd(geom->n_img, geom->ih, geom->iw, geom->cin, geom->kh, geom->kw, geom->stride,
-                                            geom->oh, geom->ow, geom->cout, geom->ld_in, geom->ld_out,
-                                            in_dtype == kInU8Div255);
+    // small-kernel layers: input band staged once in LDS (halo_fwd.h).  Measured on MI355X
+    // (tools/bench_kernels.py): the halo forward wins for stride-1 layers with few input channels / small maps;
+    // the implicit-GEMM core stays ahead for stride 2 and for 32 channels on >= 400 pixels.
+    const bool halo_wins = geom->stride == 1 && geom->kh * geom->kw > 1 && !(geom->cin >= 32 && geom->oh * geom->ow >= 400);
     auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
-    // measured on MI355X (tools/bench_kernels.py): the halo forward wins for stride-1 layers with few input
-    // channels / small maps; the implicit-GEMM core stays ahead for stride 2 and for 32 channels on >= 400 pixels
-    const bool halo_wins = geom->stride == 1 && !(geom->cin >= 32 && geom->oh * geom->ow >= 400);
-    if (pl.ok && halo_wins && geom->kh * geom->kw > 1 && al16(out) && al16(bias) && al16(residual) &&
-        (in_dtype == kInU8Div255 || al16(in))) {
+    if (halo_wins && al16(out) && al16(bias) && al16(residual) && (in_dtype == kInU8Div255 || al16(in))) {
       halo::FwdParams hp;
       memset(&hp, 0, sizeof(hp));
       hp.in = in; hp.in_dtype = in_dtype; hp.in_relu = in_relu; hp.w = w; hp.wmode = 0;
       hp.w_kh = geom->kh; hp.w_kw = geom->kw; hp.w_cin = geom->cin; hp.w_cout = geom->cout;
-      hp.n_img = geom->n_img; hp.ih = geom->ih; hp.iw = geom->iw; hp.cin = geom->cin; hp.kh = geom->kh; hp.kw = geom->kw;
-      hp.stride = geom->stride; hp.pad_t = geom->pad_t; hp.pad_l = geom->pad_l; hp.oh = geom->oh; hp.ow = geom->ow;
+      hp.n_img = geom->n_img; hp.ih = geom->ih; hp.iw = geom->iw; hp.cin = geom->cin; hp.stride = geom->stride;
       hp.cout = geom->cout; hp.out = out; hp.OH = geom->oh; hp.OW = geom->ow; hp.ld_out = geom->ld_out; hp.so = 1;
       hp.bias = bias; hp.out_relu = out_relu; hp.residual = residual; hp.ld_in = geom->ld_in;
-      halo::fill_tiling(hp, pl);
-      return halo::launch_fwd_kernel(hp, pl, (hipStream_t)stream);
+      halo::ClassSpec cs = {geom->kh, geom->kw, geom->pad_t, geom->pad_l, geom->oh, geom->ow, 0, 0, 0, 0};
+      const halo::FwdPlan pl = halo::plan_fwd(hp, &cs, 1, in_dtype == kInU8Div255);
+      if (pl.ok) return halo::launch_fwd_kernel(hp, pl, (hipStream_t)stream);
     }
   }
   if (is_dense(geom) && in_dtype == kInF32 && geom->cin % 4 == 0 && geom->ld_in % 4 == 0 && (((uintptr_t)in) & 15) == 0) {
@@ -89,44 +85,37 @@ extern "C" int seedhip_conv2d_bwd_data(const seedhip_conv_geom* geom, const floa
   int rc = check_geom(geom, "conv2d_bwd_data"); if (rc) return rc;
   SEEDHIP_REQUIRE(dy && w && dx, "conv2d_bwd_data: null pointer");
   {
-    // per stride-parity class: a stride-1 halo convolution of dY with the class's taps (halo_fwd.h)
+    // Data gradient as stride-1 halo convolutions of dY, one per stride-parity class of the input pixel, all in
+    // ONE launch sharing the dY tile (halo_fwd.h): dX[q*s + py - pad] = sum_j dY[q - j] W[py + s*j].
     const seedhip_conv_geom* g = geom;
     const int s = g->stride;
-    bool ok = g->kh * g->kw > 1 && s <= 2 && (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)relu_mask | (uintptr_t)add) & 15) == 0;
-    halo::FwdPlan plans[4];
-    halo::FwdParams hps[4];
-    int ncls = 0;
-    for (int py = 0; ok && py < s; ++py) {
-      for (int px = 0; ok && px < s; ++px) {
-        const int JH = (g->kh - py + s - 1) / s, JW = (g->kw - px + s - 1) / s;
-        if (JH < 1 || JW < 1) continue;                            // no tap reaches this class: dx stays... (kh >= s)
-        const int q0y = py >= g->pad_t ? 0 : (g->pad_t - py + s - 1) / s;
-        const int q0x = px >= g->pad_l ? 0 : (g->pad_l - px + s - 1) / s;
-        const int QH = (g->ih - 1 + g->pad_t - py) / s - q0y + 1, QW = (g->iw - 1 + g->pad_l - px) / s - q0x + 1;
-        if (QH < 1 || QW < 1) continue;
-        halo::FwdPlan pl = halo::plan_fwd(g->n_img, g->oh, g->ow, g->cout, JH, JW, 1, QH, QW, g->cin, g->ld_out,
-                                          g->ld_in, false);
-        if (!pl.ok) { ok = false; break; }
+    if (g->kh * g->kw > 1 && s <= 2 && g->kh >= s && g->kw >= s &&
+        (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)relu_mask | (uintptr_t)add) & 15) == 0) {
+      halo::ClassSpec cs[4];
+      int ncls = 0;
+      bool ok = true;
+      for (int py = 0; py < s; ++py) {
+        for (int px = 0; px < s; ++px) {
+          const int JH = (g->kh - py + s - 1) / s, JW = (g->kw - px + s - 1) / s;
+          const int q0y = py >= g->pad_t ? 0 : (g->pad_t - py + s - 1) / s;
+          const int q0x = px >= g->pad_l ? 0 : (g->pad_l - px + s - 1) / s;
+          const int QH = (g->ih - 1 + g->pad_t - py) / s - q0y + 1, QW = (g->iw - 1 + g->pad_l - px) / s - q0x + 1;
+          if (QH < 1 || QW < 1) { ok = false; continue; }
+          cs[ncls++] = halo::ClassSpec{JH, JW, JH - 1 - q0y, JW - 1 - q0x, QH, QW,
+                                       q0y * s + py - g->pad_t, q0x * s + px - g->pad_l, py, px};
+        }
+      }
+      if (ok && ncls == s * s) {
         halo::FwdParams hp;
         memset(&hp, 0, sizeof(hp));
         hp.in = dy; hp.in_dtype = kInF32; hp.in_relu = 0; hp.w = w; hp.wmode = 1;
-        hp.w_kh = g->kh; hp.w_kw = g->kw; hp.w_cin = g->cin; hp.w_cout = g->cout; hp.w_py = py; hp.w_px = px; hp.w_s = s;
-        hp.n_img = g->n_img; hp.ih = g->oh; hp.iw = g->ow; hp.cin = g->cout; hp.kh = JH; hp.kw = JW; hp.stride = 1;
-        hp.pad_t = JH - 1 - q0y; hp.pad_l = JW - 1 - q0x; hp.oh = QH; hp.ow = QW; hp.cout = g->cin;
+        hp.w_kh = g->kh; hp.w_kw = g->kw; hp.w_cin = g->cin; hp.w_cout = g->cout; hp.w_s = s;
+        hp.n_img = g->n_img; hp.ih = g->oh; hp.iw = g->ow; hp.cin = g->cout; hp.stride = 1; hp.cout = g->cin;
         hp.out = dx; hp.OH = g->ih; hp.OW = g->iw; hp.ld_out = g->ld_in; hp.so = s;
-        hp.oy0 = q0y * s + py - g->pad_t; hp.ox0 = q0x * s + px - g->pad_l;
         hp.mask = relu_mask; hp.add = add; hp.ld_in = g->ld_out;
-        halo::fill_tiling(hp, pl);
-        plans[ncls] = pl; hps[ncls] = hp; ++ncls;
+        const halo::FwdPlan pl = halo::plan_fwd(hp, cs, ncls, false);
+        if (pl.ok) return halo::launch_fwd_kernel(hp, pl, (hipStream_t)stream);
       }
-    }
-    // every input pixel must belong to a launched class (true when kh, kw >= stride)
-    if (ok && ncls == s * s && g->kh >= s && g->kw >= s) {
-      for (int c = 0; c < ncls; ++c) {
-        rc = halo::launch_fwd_kernel(hps[c], plans[c], (hipStream_t)stream);
-        if (rc) return rc;
-      }
-      return SEEDHIP_OK;
     }
   }
   if (is_dense(geom) && geom->cout % 4 == 0 && geom->ld_out % 4 == 0 && (((uintptr_t)dy | (uintptr_t)w) & 15) == 0) {

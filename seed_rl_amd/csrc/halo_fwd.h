@@ -30,55 +30,71 @@ namespace halo {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+struct FwdClass {                                  // one launch computes up to 4 "classes" off the same input tile
+  int kh, kw, pad_t, pad_l;                        // the class's kernel and pads (input side)
+  int oh, ow;                                      // its output grid
+  int oy0, ox0;                                    // placement offset: out[n, oy*so + oy0, ox*so + ox0, :]
+  int w_py, w_px;                                  // data-gradient parity (wmode 1)
+  int nslices, w_off;                              // k-slices and start (in slices) inside the LDS weight image
+  int r_off, c_off;                                // tile-row / tile-column of this class's first tap
+  FastDiv d_ow;
+};
+
 struct FwdParams {
   const void* in; int in_dtype, in_relu;        // input [n_img, ih, iw, ld_in]
   const float* w;                                // original Keras kernel [w_kh, w_kw, w_cin, w_cout]
   int wmode;                                     // 0: forward, W_eff[tap][c][co] = w[tap][c][co]
                                                  // 1: data gradient class (w_py, w_px): W_eff[(j,i)][c][co] =
                                                  //    w[w_py + w_s*(kh-1-j)][w_px + w_s*(kw-1-i)][co][c]
-  int w_kh, w_kw, w_cin, w_cout, w_py, w_px, w_s;
-  int n_img, ih, iw, cin, kh, kw, stride, pad_t, pad_l;   // the convolution this launch computes (input side)
-  int oh, ow, cout;                              // its output grid / channels
-  float* out; int OH, OW, ld_out, so, oy0, ox0;  // placement: out[n, oy*so + oy0, ox*so + ox0, :]
+  int w_kh, w_kw, w_cin, w_cout, w_s;
+  int n_img, ih, iw, cin, stride;                // input tensor; stride of the forward conv (1 for data gradients)
+  int cout;
+  float* out; int OH, OW, ld_out, so;            // output tensor and placement stride
   const float* bias; int out_relu; const float* residual;
   const float* mask; const float* add;           // data-gradient epilogue (indexed like out)
   int ld_in;
+  int ncls; FwdClass cls[4];
+  int oh_max;                                    // bands run over max_c oh
+  int tile_pad_t, tile_pad_l;                    // input row/col of tile origin = y0*stride - tile_pad_t, -tile_pad_l
   int TH, bands, ntiles, thp, twp, xs;           // tiling; xs = LDS pixel stride (floats)
   int cgs;                                       // k-groups (of 4 channels) per tap = ceil(cin / 4), power of 2
   int cgs_shift;
-  int nslices;                                   // ceil(kh*kw*cgs / 4)
-  FastDiv d_ow;
+  int total_slices;
 };
 
 template <int MT, int NT>
 __global__ void __launch_bounds__(256)
 halo_fwd_kernel(const FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int w_floats = p.nslices * NT * 256;
+  const int w_floats = p.total_slices * NT * 256;
   float* w_lds = smem;
   float* x_lds = smem + w_floats;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kq = lane >> 4, j = lane & 15;
-  const int ntaps = p.kh * p.kw;
 
-  // ---- weights -> LDS, once per workgroup: [slice][nt][lane][kk] ----
-  for (int idx = tid; idx < w_floats; idx += 256) {
-    const int kk = idx & 3, l = (idx >> 2) & 63, rest = idx >> 8;
-    const int nt = rest % NT, slice = rest / NT;
-    const int G = slice * 4 + (l >> 4);
-    const int tap = G >> p.cgs_shift, c = ((G & (p.cgs - 1)) << 2) + kk;
-    const int co = nt * 16 + (l & 15);
-    float v = 0.f;
-    if (tap < ntaps && c < p.cin && co < p.cout) {
-      const int ty = tap / p.kw, tx = tap - ty * p.kw;
-      if (p.wmode == 0) {
-        v = p.w[((long long)tap * p.w_cin + c) * p.w_cout + co];
-      } else {
-        const int ky = p.w_py + p.w_s * (p.kh - 1 - ty), kx = p.w_px + p.w_s * (p.kw - 1 - tx);
-        v = p.w[((long long)(ky * p.w_kw + kx) * p.w_cin + co) * p.w_cout + c];
+  // ---- weights -> LDS, once per workgroup: per class [slice][nt][lane][kk] ----
+  for (int ci = 0; ci < p.ncls; ++ci) {
+    const FwdClass& c = p.cls[ci];
+    const int ntaps = c.kh * c.kw;
+    float* wl = w_lds + c.w_off * NT * 256;
+    for (int idx = tid; idx < c.nslices * NT * 256; idx += 256) {
+      const int kk = idx & 3, l = (idx >> 2) & 63, rest = idx >> 8;
+      const int nt = rest % NT, slice = rest / NT;
+      const int G = slice * 4 + (l >> 4);
+      const int tap = G >> p.cgs_shift, ch = ((G & (p.cgs - 1)) << 2) + kk;
+      const int co = nt * 16 + (l & 15);
+      float v = 0.f;
+      if (tap < ntaps && ch < p.cin && co < p.cout) {
+        const int ty = tap / c.kw, tx = tap - ty * c.kw;
+        if (p.wmode == 0) {
+          v = p.w[((long long)tap * p.w_cin + ch) * p.w_cout + co];
+        } else {
+          const int ky = c.w_py + p.w_s * (c.kh - 1 - ty), kx = c.w_px + p.w_s * (c.kw - 1 - tx);
+          v = p.w[((long long)(ky * p.w_kw + kx) * p.w_cin + co) * p.w_cout + ch];
+        }
       }
+      wl[idx] = v;
     }
-    w_lds[idx] = v;
   }
 
   // ---- tile pipeline (as halo_wgrad.h) ----
@@ -89,14 +105,14 @@ halo_fwd_kernel(const FwdParams p) {
     n = tile / p.bands;
     const int band = tile - n * p.bands;
     y0 = band * p.TH;
-    th = (y0 + p.TH <= p.oh) ? p.TH : p.oh - y0;
+    th = (y0 + p.TH <= p.oh_max) ? p.TH : p.oh_max - y0;
   };
   auto load_tile = [&](int tile) {
     if (!vec) return;
     int n, y0, th; band_of(tile, n, y0, th);
     const int c4 = p.cin >> 2;
     const int per_row = p.twp * c4;
-    const int nvec = ((th - 1) * p.stride + p.kh) * per_row;
+    const int nvec = (p.thp - (p.TH - th) * p.stride) * per_row;
 #pragma unroll
     for (int u = 0; u < kXV; ++u) {
       const int v = tid + u * 256;
@@ -104,7 +120,7 @@ halo_fwd_kernel(const FwdParams p) {
       if (v < nvec) {
         const int r = v / per_row, rem = v - r * per_row;
         const int xcol = rem / c4, cq = rem - xcol * c4;
-        const int iy = y0 * p.stride - p.pad_t + r, ix = xcol - p.pad_l;
+        const int iy = y0 * p.stride - p.tile_pad_t + r, ix = xcol - p.tile_pad_l;
         if (iy >= 0 && iy < p.ih && ix >= 0 && ix < p.iw)
           val = *reinterpret_cast<const float4*>((const float*)p.in + (((long long)n * p.ih + iy) * p.iw + ix) * p.ld_in + 4 * cq);
       }
@@ -114,7 +130,7 @@ halo_fwd_kernel(const FwdParams p) {
   auto store_tile = [&](int tile) {
     int n, y0, th; band_of(tile, n, y0, th);
     const int rowf = p.twp * p.xs;
-    const int nrows = (th - 1) * p.stride + p.kh;
+    const int nrows = p.thp - (p.TH - th) * p.stride;
     if (vec) {
       const int c4 = p.cin >> 2;
       const int per_row = p.twp * c4;
@@ -134,15 +150,15 @@ halo_fwd_kernel(const FwdParams p) {
       const int per_row = p.twp * cp;
       for (int v = tid; v < nrows * per_row; v += 256) {
         const int r = v / per_row, rem = v - r * per_row;
-        const int xcol = rem / cp, c = rem - xcol * cp;
-        const int iy = y0 * p.stride - p.pad_t + r, ix = xcol - p.pad_l;
+        const int xcol = rem / cp, ch = rem - xcol * cp;
+        const int iy = y0 * p.stride - p.tile_pad_t + r, ix = xcol - p.tile_pad_l;
         float val = 0.f;
-        if (c < p.cin && iy >= 0 && iy < p.ih && ix >= 0 && ix < p.iw) {
-          const long long off = (((long long)n * p.ih + iy) * p.iw + ix) * p.ld_in + c;
+        if (ch < p.cin && iy >= 0 && iy < p.ih && ix >= 0 && ix < p.iw) {
+          const long long off = (((long long)n * p.ih + iy) * p.iw + ix) * p.ld_in + ch;
           val = p.in_dtype == 1 ? (float)((const uint8_t*)p.in)[off] / 255.0f : ((const float*)p.in)[off];
           if (p.in_relu) val = fmaxf(val, 0.f);
         }
-        x_lds[r * rowf + xcol * p.xs + c] = val;
+        x_lds[r * rowf + xcol * p.xs + ch] = val;
       }
     }
   };
@@ -155,67 +171,74 @@ halo_fwd_kernel(const FwdParams p) {
     __syncthreads();
     if (tile + (int)gridDim.x < p.ntiles) load_tile(tile + gridDim.x);
 
-    const int npix = th * p.ow;
-    const int ntile16 = (npix + 15) >> 4;
-    for (int t0 = wave * MT; t0 < ntile16; t0 += 4 * MT) {
-      int xbase[MT];
+    for (int ci = 0; ci < p.ncls; ++ci) {
+      const FwdClass& c = p.cls[ci];
+      const int thc = (y0 + th <= c.oh) ? th : c.oh - y0;      // this class may have fewer rows than the band
+      if (thc <= 0) continue;
+      const int ntaps = c.kh * c.kw;
+      const int npix = thc * c.ow;
+      const int ntile16 = (npix + 15) >> 4;
+      const float* wl = w_lds + c.w_off * NT * 256;
+      for (int t0 = wave * MT; t0 < ntile16; t0 += 4 * MT) {
+        int xbase[MT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        int pix = (t0 + m) * 16 + j;
-        if (pix > npix - 1) pix = npix - 1;
-        uint32_t py, px;
-        p.d_ow.divmod((uint32_t)pix, py, px);
-        xbase[m] = ((int)py * p.stride * p.twp + (int)px * p.stride) * p.xs;
-      }
-      f32x4_t acc[MT][NT];
+        for (int m = 0; m < MT; ++m) {
+          int pix = (t0 + m) * 16 + j;
+          if (pix > npix - 1) pix = npix - 1;
+          uint32_t py, px;
+          c.d_ow.divmod((uint32_t)pix, py, px);
+          xbase[m] = (((int)py * p.stride + c.r_off) * p.twp + (int)px * p.stride + c.c_off) * p.xs;
+        }
+        f32x4_t acc[MT][NT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      for (int s = 0; s < p.nslices; ++s) {
-        const int G = s * 4 + kq;
-        int tap = G >> p.cgs_shift;
-        const int cg = G & (p.cgs - 1);
-        if (tap > ntaps - 1) tap = ntaps - 1;             // padded k-groups carry zero weights
-        const int ty = tap / p.kw, tx = tap - ty * p.kw;
-        const int koff = (ty * p.twp + tx) * p.xs + (cg << 2);
-        f32x4_t a[NT], b[MT];
+          for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < c.nslices; ++s) {
+          const int G = s * 4 + kq;
+          int tap = G >> p.cgs_shift;
+          const int cg = G & (p.cgs - 1);
+          if (tap > ntaps - 1) tap = ntaps - 1;             // padded k-groups carry zero weights
+          const int ty = tap / c.kw, tx = tap - ty * c.kw;
+          const int koff = (ty * p.twp + tx) * p.xs + (cg << 2);
+          f32x4_t a[NT], b[MT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) a[nt] = *reinterpret_cast<const f32x4_t*>(w_lds + ((s * NT + nt) * 64 + lane) * 4);
+          for (int nt = 0; nt < NT; ++nt) a[nt] = *reinterpret_cast<const f32x4_t*>(wl + ((s * NT + nt) * 64 + lane) * 4);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) b[m] = *reinterpret_cast<const f32x4_t*>(x_lds + xbase[m] + koff);
+          for (int m = 0; m < MT; ++m) b[m] = *reinterpret_cast<const f32x4_t*>(x_lds + xbase[m] + koff);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+          for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt][kk], b[m][kk], acc[m][nt], 0, 0, 0);
-      }
-      // ---- epilogue: lane holds channels nt*16 + 4*kq + {0..3} of pixel (t0+m)*16 + j ----
+              for (int nt = 0; nt < NT; ++nt)
+                acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt][kk], b[m][kk], acc[m][nt], 0, 0, 0);
+        }
+        // ---- epilogue: lane holds channels nt*16 + 4*kq + {0..3} of pixel (t0+m)*16 + j ----
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int pix = (t0 + m) * 16 + j;
-        if (t0 + m >= ntile16 || pix >= npix) continue;
-        uint32_t py, px;
-        p.d_ow.divmod((uint32_t)pix, py, px);
-        const int oy = (y0 + (int)py) * p.so + p.oy0, ox = (int)px * p.so + p.ox0;
-        if (oy < 0 || oy >= p.OH || ox < 0 || ox >= p.OW) continue;
-        const long long obase = (((long long)n * p.OH + oy) * p.OW + ox) * p.ld_out;
+        for (int m = 0; m < MT; ++m) {
+          const int pix = (t0 + m) * 16 + j;
+          if (t0 + m >= ntile16 || pix >= npix) continue;
+          uint32_t py, px;
+          c.d_ow.divmod((uint32_t)pix, py, px);
+          const int oy = (y0 + (int)py) * p.so + c.oy0, ox = (int)px * p.so + c.ox0;
+          if (oy < 0 || oy >= p.OH || ox < 0 || ox >= p.OW) continue;
+          const long long obase = (((long long)n * p.OH + oy) * p.OW + ox) * p.ld_out;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int co = nt * 16 + 4 * kq;
-          if (co >= p.cout) continue;
-          f32x4_t v = acc[m][nt];
-          if (p.bias) { const float4 bv = *reinterpret_cast<const float4*>(p.bias + co); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
-          if (p.residual) { const float4 rv = *reinterpret_cast<const float4*>(p.residual + obase + co); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
-          if (p.out_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-          if (p.mask) {
-            const float4 mv = *reinterpret_cast<const float4*>(p.mask + obase + co);
-            if (!(mv.x > 0.f)) v[0] = 0.f; if (!(mv.y > 0.f)) v[1] = 0.f; if (!(mv.z > 0.f)) v[2] = 0.f; if (!(mv.w > 0.f)) v[3] = 0.f;
+          for (int nt = 0; nt < NT; ++nt) {
+            const int co = nt * 16 + 4 * kq;
+            if (co >= p.cout) continue;
+            f32x4_t v = acc[m][nt];
+            if (p.bias) { const float4 bv = *reinterpret_cast<const float4*>(p.bias + co); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
+            if (p.residual) { const float4 rv = *reinterpret_cast<const float4*>(p.residual + obase + co); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
+            if (p.out_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (p.mask) {
+              const float4 mv = *reinterpret_cast<const float4*>(p.mask + obase + co);
+              if (!(mv.x > 0.f)) v[0] = 0.f; if (!(mv.y > 0.f)) v[1] = 0.f; if (!(mv.z > 0.f)) v[2] = 0.f; if (!(mv.w > 0.f)) v[3] = 0.f;
+            }
+            if (p.add) { const float4 av = *reinterpret_cast<const float4*>(p.add + obase + co); v[0] += av.x; v[1] += av.y; v[2] += av.z; v[3] += av.w; }
+            *reinterpret_cast<float4*>(p.out + obase + co) = make_float4(v[0], v[1], v[2], v[3]);
           }
-          if (p.add) { const float4 av = *reinterpret_cast<const float4*>(p.add + obase + co); v[0] += av.x; v[1] += av.y; v[2] += av.z; v[3] += av.w; }
-          *reinterpret_cast<float4*>(p.out + obase + co) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
     }
@@ -223,51 +246,66 @@ halo_fwd_kernel(const FwdParams p) {
 }
 
 // ---- host side ------------------------------------------------------------------------------ //
-struct FwdPlan { bool ok; int MT, NT, TH, grid, xs, cgs, cgs_shift, nslices, thp, twp; size_t lds; };
+struct FwdPlan { bool ok; int MT, NT, TH, grid; size_t lds; };
 
-// The convolution as the kernel sees it: input dims, kernel, stride, pads, output grid, channels.
-inline FwdPlan plan_fwd(int n_img, int ih, int iw, int cin, int kh, int kw, int stride, int oh, int ow, int cout,
-                        int ld_in, int ld_out, bool u8) {
+// Describes one class before tiling.
+struct ClassSpec { int kh, kw, pad_t, pad_l, oh, ow, oy0, ox0, w_py, w_px; };
+
+// Fills p.cls / tiling for `ncls` classes that share the input tensor already described in p
+// (n_img, ih, iw, cin, stride, cout, ld_in, ld_out).  Returns ok=false if the shape is outside the kernel's range.
+inline FwdPlan plan_fwd(FwdParams& p, const ClassSpec* cs, int ncls, bool u8) {
   FwdPlan pl; memset(&pl, 0, sizeof(pl));
-  if (kh > 4 || kw > 4 || stride > 2 || cout > 32 || cout % 4 != 0 || ld_out % 4 != 0 || oh * ow < 16) return pl;
-  if (!u8 && (cin % 4 != 0 || ld_in % 4 != 0) && cin > 4) return pl;
+  if (ncls < 1 || ncls > 4 || p.stride > 2 || p.cout > 32 || p.cout % 4 != 0 || p.ld_out % 4 != 0) return pl;
+  if (!u8 && (p.cin % 4 != 0 || p.ld_in % 4 != 0) && p.cin > 4) return pl;
   int cgs = 1, sh = 0;
-  while (cgs * 4 < cin) { cgs <<= 1; ++sh; }
+  while (cgs * 4 < p.cin) { cgs <<= 1; ++sh; }
   if (cgs > 16) return pl;
-  if (!u8 && cin % 4 == 0 && cin != 4 * cgs) return pl;       // vector fill leaves no zeroed pad channels
-  pl.cgs = cgs; pl.cgs_shift = sh;
-  pl.nslices = (kh * kw * cgs + 3) / 4;
-  pl.NT = (cout + 15) / 16;
-  // LDS pixel stride in 16-B slots: >= cgs and (stride * S) % 4 == 2  => conflict-free ds_read_b128
-  int S = cgs;
-  while ((stride * S) % 4 != 2) ++S;
-  pl.xs = 4 * S;
-  pl.twp = (ow - 1) * stride + kw;
-  const size_t w_b = (size_t)pl.nslices * pl.NT * 1024;
-  int th = (256 + ow - 1) / ow; if (th > oh) th = oh;
-  // prefer a band whose 16-pixel tile count is a multiple of 4 waves x MT
+  if (!u8 && p.cin % 4 == 0 && p.cin != 4 * cgs) return pl;   // vector fill leaves no zeroed pad channels
+  p.cgs = cgs; p.cgs_shift = sh;
+  pl.NT = (p.cout + 15) / 16;
+  int S = cgs;                                                 // LDS pixel stride in 16-B slots
+  while ((p.stride * S) % 4 != 2) ++S;
+  p.xs = 4 * S;
+  int max_pt = 0, max_pl = 0, oh_max = 0, ow_max = 0, total = 0;
+  for (int i = 0; i < ncls; ++i) {
+    if (cs[i].kh > 4 || cs[i].kw > 4 || cs[i].kh < 1 || cs[i].kw < 1 || cs[i].oh < 1 || cs[i].ow < 1) return pl;
+    if (cs[i].pad_t > max_pt) max_pt = cs[i].pad_t;
+    if (cs[i].pad_l > max_pl) max_pl = cs[i].pad_l;
+    if (cs[i].oh > oh_max) oh_max = cs[i].oh;
+    if (cs[i].ow > ow_max) ow_max = cs[i].ow;
+  }
+  if (oh_max * ow_max < 16) return pl;
+  int ext_h = 0, ext_w = 0;                                    // rows/cols the taps reach beyond (q-1)*stride
+  for (int i = 0; i < ncls; ++i) {
+    FwdClass& c = p.cls[i];
+    c.kh = cs[i].kh; c.kw = cs[i].kw; c.pad_t = cs[i].pad_t; c.pad_l = cs[i].pad_l; c.oh = cs[i].oh; c.ow = cs[i].ow;
+    c.oy0 = cs[i].oy0; c.ox0 = cs[i].ox0; c.w_py = cs[i].w_py; c.w_px = cs[i].w_px;
+    c.r_off = max_pt - c.pad_t; c.c_off = max_pl - c.pad_l;
+    c.nslices = (c.kh * c.kw * cgs + 3) / 4; c.w_off = total; total += c.nslices;
+    c.d_ow.init(c.ow);
+    if (c.kh + c.r_off > ext_h) ext_h = c.kh + c.r_off;
+    if (c.kw + c.c_off > ext_w) ext_w = c.kw + c.c_off;
+  }
+  p.ncls = ncls; p.total_slices = total; p.oh_max = oh_max; p.tile_pad_t = max_pt; p.tile_pad_l = max_pl;
+  p.twp = (ow_max - 1) * p.stride + ext_w;
+  const size_t w_b = (size_t)total * pl.NT * 1024;
+  int th = (256 + ow_max - 1) / ow_max; if (th > oh_max) th = oh_max;
   for (;; --th) {
-    const size_t x_b = (size_t)((th - 1) * stride + kh) * pl.twp * pl.xs * 4;
-    const size_t x_src = (size_t)((th - 1) * stride + kh) * pl.twp * cin * 4;       // bytes prefetched in registers
-    const bool fits = w_b + x_b <= 64 * 1024 && (u8 || cin % 4 != 0 || x_src <= 7 * 256 * 16);
+    const int thp = (th - 1) * p.stride + ext_h;
+    const size_t x_b = (size_t)thp * p.twp * p.xs * 4;
+    const size_t x_src = (size_t)thp * p.twp * p.cin * 4;                       // bytes prefetched in registers
+    const bool fits = w_b + x_b <= 64 * 1024 && (u8 || p.cin % 4 != 0 || x_src <= 7 * 256 * 16);
     if (fits || th == 1) { if (!fits) return pl; pl.lds = w_b + x_b; break; }
   }
-  pl.TH = th; pl.thp = (th - 1) * stride + kh;
-  const int tiles16 = (th * ow + 15) / 16;
+  pl.TH = th; p.TH = th; p.thp = (th - 1) * p.stride + ext_h;
+  p.bands = (oh_max + th - 1) / th; p.ntiles = p.n_img * p.bands;
+  const int tiles16 = (th * ow_max + 15) / 16;
   pl.MT = tiles16 >= 12 ? 4 : 2;
-  const int bands = (oh + th - 1) / th;
-  const long long ntiles = (long long)n_img * bands;
   int per_cu = (int)((160 * 1024) / pl.lds); if (per_cu > 3) per_cu = 3; if (per_cu < 1) per_cu = 1;
   const long long mg = 256LL * per_cu;
-  pl.grid = (int)(ntiles < mg ? ntiles : mg);
+  pl.grid = (int)(p.ntiles < mg ? p.ntiles : mg);
   pl.ok = true;
   return pl;
-}
-
-inline void fill_tiling(FwdParams& p, const FwdPlan& pl) {
-  p.TH = pl.TH; p.bands = (p.oh + pl.TH - 1) / pl.TH; p.ntiles = p.n_img * p.bands;
-  p.thp = pl.thp; p.twp = pl.twp; p.xs = pl.xs; p.cgs = pl.cgs; p.cgs_shift = pl.cgs_shift; p.nslices = pl.nslices;
-  p.d_ow.init(p.ow);
 }
 
 inline int launch_fwd_kernel(const FwdParams& p, const FwdPlan& pl, hipStream_t s) {
