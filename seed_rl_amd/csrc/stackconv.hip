@@ -8,11 +8,12 @@
 // Why a dedicated kernel: this layer is 45% of the learner step's flops, its GEMM is
 // skinny (N = 16 output channels) and its A operand is an im2col gather over uint8
 // frames.  The generic implicit-GEMM core spends its time on gather index math; here
-//   * a workgroup owns ONE batch column b and walks the unroll in time, keeping a ring
-//     of 5 raw uint8 frames in LDS (35 KB): every frame byte is read from HBM ONCE
-//     (1 B per pixel per frame -- the algorithmic minimum) and serves the 4 stack
-//     positions it appears in; the next frame is prefetched into registers while the
-//     current step computes;
+//   * a workgroup owns ONE batch column b and walks the unroll in time; each of its 5 waves
+//     keeps ITS 20-row band of the last 4 raw uint8 frames in a private LDS ring (6.7 KB):
+//     frame bytes are read from HBM/L2 about once (1 B per pixel per frame is the algorithmic
+//     minimum; bands overlap by 4 rows) and serve the 4 stack positions they appear in; the
+//     next band is prefetched into registers while the current step computes, and the time
+//     loop contains NO workgroup barrier (waves are autonomous);
 //   * MFMA operands are built straight from the LDS bytes: one ds_read_b32 yields 4
 //     horizontally adjacent pixels = 4 consecutive k of the reduction, converted with
 //     v_cvt_f32_ubyte{0..3}; K is ordered so that a lane's (pixel, k-quad) address
@@ -39,7 +40,6 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kWaves = 5;
 constexpr int kThreads = kWaves * 64;
-constexpr int kRing = 5;       // frame slots in LDS
 constexpr int kMT = 5;         // MFMA tiles in flight per wave (forward)
 constexpr int kWFloats = 64 * 64;   // one 16-channel slice of the kernel: [64 k-steps][64 lanes]
 
@@ -59,23 +59,46 @@ struct Params {
 
 __device__ __forceinline__ float ubyte(uint32_t w, int q) { return (float)((w >> (8 * q)) & 0xFFu); }
 
-// Copies the frames the first step of a chunk needs (ext rows t0 .. t0+3) into the ring.  All
-// global loads are issued before the first LDS store (one memory latency, not eight).
-__device__ __forceinline__ void ring_prologue(const Params& p, unsigned char* ring, int b, int t0, int tid) {
-  const int nvec = p.fsz >> 4;
-  uint4 v[4][2];
+// Geometry of the specialised path: 84x84 frames, 8x8 stride-4 VALID -> 20x20 outputs.  Wave w of a workgroup owns
+// output rows 4w..4w+3 (80 pixels = 5 MFMA tiles / 20 four-pixel groups), which depend on input rows 16w..16w+19
+// only.  Each wave keeps ITS band of the last 4 frames in its own LDS ring and walks time on its own: the t loop has
+// NO workgroup barrier (a per-step barrier costs the fp32 matrix pipe 13-20%: tools/probes/mfma_probe4.hip).
+constexpr int kIW = 84, kIH = 84, kOW = 20, kBandRows = 20, kBandBytes = kBandRows * kIW;   // 1680 B = 105 uint4
+constexpr int kBandVec = kBandBytes / 16;
+constexpr int kSlots = 4;
+constexpr int kWaveRing = kSlots * kBandBytes;                                             // 6720 B per wave
+
+struct BandPrefetch { uint4 v0, v1; };
+
+__device__ __forceinline__ const uint4* band_src(const Params& p, int e, int b, int wave) {
+  return reinterpret_cast<const uint4*>(p.frames_ext + ((long long)e * p.B + b) * p.fsz + wave * 16 * kIW);
+}
+__device__ __forceinline__ BandPrefetch band_load(const uint4* src, int lane) {
+  BandPrefetch r;
+  r.v0 = src[lane];
+  r.v1 = lane + 64 < kBandVec ? src[lane + 64] : make_uint4(0, 0, 0, 0);
+  return r;
+}
+__device__ __forceinline__ void band_store(unsigned char* slot, const BandPrefetch& r, int lane) {
+  uint4* dst = reinterpret_cast<uint4*>(slot);
+  dst[lane] = r.v0;
+  if (lane + 64 < kBandVec) dst[lane + 64] = r.v1;
+}
+// LDS accesses of ONE wave execute in program order; this only stops the compiler from moving the wave's later
+// reads above its stores and drains the LDS queue.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Band of ext rows t0..t0+3 -> the wave's ring (all 8 loads in flight before the first store).
+__device__ __forceinline__ void band_prologue(const Params& p, unsigned char* myring, int b, int t0, int wave, int lane) {
+  BandPrefetch f[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const uint4* src = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t0 + e) * p.B + b) * p.fsz);
-    v[e][0] = tid < nvec ? src[tid] : make_uint4(0, 0, 0, 0);
-    v[e][1] = tid + kThreads < nvec ? src[tid + kThreads] : make_uint4(0, 0, 0, 0);
-  }
+  for (int e = 0; e < 4; ++e) f[e] = band_load(band_src(p, t0 + e, b, wave), lane);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    uint4* dst = reinterpret_cast<uint4*>(ring + ((t0 + e) % kRing) * p.fsz);
-    if (tid < nvec) dst[tid] = v[e][0];
-    if (tid + kThreads < nvec) dst[tid + kThreads] = v[e][1];
-  }
+  for (int e = 0; e < 4; ++e) band_store(myring + ((t0 + e) % kSlots) * kBandBytes, f[e], lane);
+  wave_lds_fence();
 }
 
 // ------------------------------------------------------------------------------------ //
@@ -88,8 +111,8 @@ __global__ void __launch_bounds__(kThreads)
 stackconv_fwd_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* w_lds = reinterpret_cast<float*>(smem);
-  unsigned char* ring = smem + kWFloats * sizeof(float);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char* myring = smem + kWFloats * sizeof(float) + wave * kWaveRing;
   const int kq = lane >> 4, j = lane & 15;
   const int co0 = blockIdx.z * 16;
 
@@ -110,83 +133,68 @@ stackconv_fwd_kernel(const Params p) {
       if (idx < kWFloats) w_lds[idx] = wv[u] / 255.0f;
     }
   }
-  const int P = p.oh * p.ow;
-  const int ntiles = (P + 15) >> 4;
-  const int tpw = (ntiles + kWaves - 1) / kWaves;
-  const int nvec = p.fsz >> 4;
   f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
   if (p.bias) {
     const float4 bv = *reinterpret_cast<const float4*>(p.bias + co0 + 4 * kq);
     bias4 = f32x4_t{bv.x, bv.y, bv.z, bv.w};
   }
+  // per-lane byte offset of (tile m, pixel j, k-quad kq) inside a band slot: fixed for the whole launch
+  int aoff[kMT];
+#pragma unroll
+  for (int m = 0; m < kMT; ++m) {
+    const int pix = m * 16 + j;                       // 0..79 within the band
+    const int oy = pix / kOW, ox = pix - oy * kOW;
+    aoff[m] = (oy * 4 + (kq >> 1)) * kIW + ox * 4 + 4 * (kq & 1);
+  }
+  __syncthreads();                                    // weights visible; the only workgroup barrier
 
   for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
     const int b = item % p.B, chunk = item / p.B;
     const int t0 = chunk * p.spc;
     const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
-    __syncthreads();
-    ring_prologue(p, ring, b, t0, tid);
-    __syncthreads();
+    band_prologue(p, myring, b, t0, wave, lane);
     for (int t = t0; t < t1; ++t) {
-      // Prefetch the frame step t+1 adds (ext row t+4) while this step computes.
+      // Prefetch the band of the frame step t+1 adds (ext row t+4) while this step computes.
       const bool more = t + 1 < t1;
-      uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
-      if (more) {
-        const uint4* src = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t + 4) * p.B + b) * p.fsz);
-        if (tid < nvec) pf0 = src[tid];
-        if (tid + kThreads < nvec) pf1 = src[tid + kThreads];
-      }
+      BandPrefetch pf;
+      if (more) pf = band_load(band_src(p, t + 4, b, wave), lane);
       const int nv = p.nvalid[(long long)t * p.B + b];
-      for (int tc = 0; tc < tpw; tc += kMT) {
-        int aoff[kMT];
+      f32x4_t acc[kMT];
 #pragma unroll
-        for (int m = 0; m < kMT; ++m) {
-          int pix = (wave * tpw + tc + m) * 16 + j;
-          if (pix > P - 1) pix = P - 1;
-          const int oy = pix / p.ow, ox = pix - oy * p.ow;
-          aoff[m] = (oy * 4 + (kq >> 1)) * p.iw + ox * 4 + 4 * (kq & 1);
-        }
-        f32x4_t acc[kMT];
+      for (int m = 0; m < kMT; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < nv; ++c) {
+        const unsigned char* base = myring + ((t + 3 - c) % kSlots) * kBandBytes;
+        const float* wl = w_lds + c * 16 * 64 + lane;
 #pragma unroll
-        for (int m = 0; m < kMT; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < nv; ++c) {
-          const unsigned char* base = ring + ((t + 3 - c) % kRing) * p.fsz;
-          const float* wl = w_lds + c * 16 * 64 + lane;
+        for (int r = 0; r < 4; ++r) {
+          uint32_t a[kMT];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            uint32_t a[kMT];
+          for (int m = 0; m < kMT; ++m)
+            a[m] = *reinterpret_cast<const uint32_t*>(base + aoff[m] + r * 2 * kIW);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float bw = wl[(r * 4 + q) * 64];
 #pragma unroll
             for (int m = 0; m < kMT; ++m)
-              a[m] = *reinterpret_cast<const uint32_t*>(base + aoff[m] + r * 2 * p.iw);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float bw = wl[(r * 4 + q) * 64];
-#pragma unroll
-              for (int m = 0; m < kMT; ++m)
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw, ubyte(a[m], q), acc[m], 0, 0, 0);
-            }
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw, ubyte(a[m], q), acc[m], 0, 0, 0);
           }
         }
+      }
 #pragma unroll
-        for (int m = 0; m < kMT; ++m) {
-          const int tile = wave * tpw + tc + m;
-          const int pix = tile * 16 + j;
-          if (tc + m < tpw && pix < P) {
-            f32x4_t v = acc[m] + bias4;
-            if (p.out_relu) {
-              v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-            }
-            float* o = p.out + (((long long)t * p.B + b) * P + pix) * p.ld_out + co0 + 4 * kq;
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-          }
+      for (int m = 0; m < kMT; ++m) {
+        const int pix = wave * 80 + m * 16 + j;
+        f32x4_t v = acc[m] + bias4;
+        if (p.out_relu) {
+          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
         }
+        float* o = p.out + (((long long)t * p.B + b) * 400 + pix) * p.ld_out + co0 + 4 * kq;
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
       }
       if (more) {
-        uint4* dst = reinterpret_cast<uint4*>(ring + ((t + 4) % kRing) * p.fsz);
-        if (tid < nvec) dst[tid] = pf0;
-        if (tid + kThreads < nvec) dst[tid + kThreads] = pf1;
+        wave_lds_fence();                              // this wave's reads of frame t are done
+        band_store(myring + ((t + 4) % kSlots) * kBandBytes, pf, lane);
+        wave_lds_fence();
       }
-      __syncthreads();
     }
   }
 }
@@ -198,75 +206,75 @@ stackconv_fwd_kernel(const Params p) {
 //          -> ONE ds_read_b32 per channel c yields the bytes of the 4 m-tiles (c, q=0..3)
 //   MFMA B (cols = channels):               dY[pixel 4g+kq][co0 + i]   (256-B coalesced global load)
 // 16 accumulators (m-tile = c*4 + q); D: lane holds k-rows 4*(lane>>4)+{0..3}, channel co0 + (lane&15).
-// Each workgroup accumulates over all the (column, time-chunk) items it is given, then
-// reduces its 5 waves through LDS in a fixed order and writes ONE partial slice.
+// Wave w reduces its band's 20 groups per step; accumulators live in registers across all the
+// (column, time-chunk) items of the persistent workgroup, then the 5 waves are summed through LDS in a
+// fixed order and ONE partial slice per workgroup is written.
 // ------------------------------------------------------------------------------------ //
 __global__ void __launch_bounds__(kThreads, 4)
 stackconv_wgrad_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* red = reinterpret_cast<float*>(smem);                       // [256 k_mem][16]
   float* redb = red + kWFloats;                                      // [kWaves][16]
-  unsigned char* ring = smem + (kWFloats + kWaves * 16) * sizeof(float);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char* myring = smem + (kWFloats + kWaves * 16) * sizeof(float) + wave * kWaveRing;
   const int kq = lane >> 4, i = lane & 15;
   const int co0 = blockIdx.z * 16;
-  const int P = p.oh * p.ow;
-  const int G = (P + 3) >> 2;
-  const int gpw = (((G + kWaves - 1) / kWaves) + 3) & ~3;            // groups per wave, multiple of 4
-  const int nvec = p.fsz >> 4;
+  constexpr int P = 400;
 
   f32x4_t acc[16];
 #pragma unroll
   for (int m = 0; m < 16; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
+  const int wrap = 4 * kIW - 4 * kOW;                                // next output row: +4 input rows, back 20 pixels
 
   for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
     const int b = item % p.B, chunk = item / p.B;
     const int t0 = chunk * p.spc;
     const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
-    __syncthreads();
-    ring_prologue(p, ring, b, t0, tid);
-    __syncthreads();
+    band_prologue(p, myring, b, t0, wave, lane);
+    // B operands of the first batch of the first step
+    float dyn[4];
+    {
+      const float* d0 = p.dy + (((long long)t0 * p.B + b) * P + wave * 80) * p.ld_out + co0 + i;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dyn[u] = d0[(long long)(4 * u + kq) * p.ld_out];
+    }
     for (int t = t0; t < t1; ++t) {
       const bool more = t + 1 < t1;
-      uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
-      if (more) {
-        const uint4* src = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t + 4) * p.B + b) * p.fsz);
-        if (tid < nvec) pf0 = src[tid];
-        if (tid + kThreads < nvec) pf1 = src[tid + kThreads];
-      }
+      BandPrefetch pf;
+      if (more) pf = band_load(band_src(p, t + 4, b, wave), lane);
       const int nv = p.nvalid[(long long)t * p.B + b];
-      const float* dy_img = p.dy + ((long long)t * p.B + b) * P * p.ld_out + co0 + i;
+      const float* dy_band = p.dy + (((long long)t * p.B + b) * P + wave * 80) * p.ld_out + co0 + i;
       const unsigned char* slot[4];
+      uint32_t cmask[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) slot[c] = ring + ((t + 3 - c) % kRing) * p.fsz;
-
-      const int g_begin = wave * gpw, g_end = g_begin + gpw;
-      float dyn[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int pk = 4 * (g_begin + u) + kq;
-        dyn[u] = pk < P ? dy_img[(long long)pk * p.ld_out] : 0.f;
+      for (int c = 0; c < 4; ++c) {
+        slot[c] = myring + ((t + 3 - c) % kSlots) * kBandBytes;
+        cmask[c] = c < nv ? 0xFFFFFFFFu : 0u;              // cumulative-OR done mask: channel c is zero
       }
-      for (int g0 = g_begin; g0 < g_end; g0 += 4) {
+      // lane's pixel walks pk = 4g + kq inside the band; its byte offset advances incrementally
+      int ox = kq;
+      int aoff = (i >> 1) * kIW + ox * 4 + 4 * (i & 1);
+      for (int g0 = 0; g0 < 20; g0 += 4) {
         float dyv[4];
         uint32_t word[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           dyv[u] = dyn[u];
-          int pk = 4 * (g0 + u) + kq;
-          if (pk > P - 1) pk = P - 1;
-          const int oy = pk / p.ow, ox = pk - oy * p.ow;
-          const int aoff = (oy * 4 + (i >> 1)) * p.iw + ox * 4 + 4 * (i & 1);
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            word[u][c] = c < nv ? *reinterpret_cast<const uint32_t*>(slot[c] + aoff) : 0u;
+            word[u][c] = *reinterpret_cast<const uint32_t*>(slot[c] + aoff) & cmask[c];
+          ox += 4; aoff += 16;
+          if (ox >= kOW) { ox -= kOW; aoff += wrap; }
         }
-        if (g0 + 4 < g_end) {
+        // B operands of the next batch (next step's first batch at the end of a step) fly under the 64 MFMAs
+        {
+          const bool last = g0 + 4 >= 20;
+          const float* src = last ? dy_band + (long long)p.B * P * p.ld_out : dy_band;
+          const int gb = last ? 0 : g0 + 4;
+          if (!last || more) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int pk = 4 * (g0 + 4 + u) + kq;
-            dyn[u] = pk < P ? dy_img[(long long)pk * p.ld_out] : 0.f;
+            for (int u = 0; u < 4; ++u) dyn[u] = src[(long long)(4 * (gb + u) + kq) * p.ld_out];
           }
         }
 #pragma unroll
@@ -280,11 +288,10 @@ stackconv_wgrad_kernel(const Params p) {
         }
       }
       if (more) {
-        uint4* dst = reinterpret_cast<uint4*>(ring + ((t + 4) % kRing) * p.fsz);
-        if (tid < nvec) dst[tid] = pf0;
-        if (tid + kThreads < nvec) dst[tid + kThreads] = pf1;
+        wave_lds_fence();
+        band_store(myring + ((t + 4) % kSlots) * kBandBytes, pf, lane);
+        wave_lds_fence();
       }
-      __syncthreads();
     }
   }
 
@@ -323,10 +330,9 @@ stackconv_wgrad_kernel(const Params p) {
 // ------------------------------------------------------------------------------------ //
 bool eligible(const seedhip_stack_conv_geom* g, const void* frames_ext, const void* io) {
   const long long fsz = (long long)g->ih * g->iw;
-  return g->kh == 8 && g->kw == 8 && g->stride == 4 && g->iw % 4 == 0 && fsz % 16 == 0 &&
-         fsz <= 2 * kThreads * 16 && g->cout % 16 == 0 && g->ld_out % 4 == 0 &&
-         (((uintptr_t)frames_ext) & 15) == 0 && (((uintptr_t)io) & 15) == 0 &&
-         (long long)kRing * fsz + (kWFloats + kWaves * 16) * 4 <= 150 * 1024;
+  (void)fsz;
+  return g->kh == 8 && g->kw == 8 && g->stride == 4 && g->ih == kIH && g->iw == kIW && g->oh == 20 && g->ow == 20 &&
+         g->cout % 16 == 0 && g->ld_out % 4 == 0 && (((uintptr_t)frames_ext) & 15) == 0 && (((uintptr_t)io) & 15) == 0;
 }
 
 // Chooses the time chunking so that the persistent grid is evenly loaded.
@@ -368,7 +374,7 @@ int launch_fwd(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, cons
                const float* bias, float* out, int out_relu, hipStream_t s) {
   Params p = make_params(g, frames_ext, nvalid);
   p.w = w; p.bias = bias; p.out = out; p.out_relu = out_relu;
-  const size_t lds = kWFloats * sizeof(float) + (size_t)kRing * p.fsz;
+  const size_t lds = kWFloats * sizeof(float) + (size_t)kWaves * kWaveRing;
   const int per_cu = (int)((160 * 1024) / lds) < 3 ? (int)((160 * 1024) / lds) : 3;
   int grid;
   decompose(p.T1, p.B, max_grid_for(per_cu < 1 ? 1 : per_cu), &p.spc, &p.items, &grid);
@@ -378,7 +384,7 @@ int launch_fwd(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, cons
   return check_launch("stackconv_fwd_kernel");
 }
 
-size_t wgrad_lds(int fsz) { return (kWFloats + kWaves * 16) * sizeof(float) + (size_t)kRing * fsz; }
+size_t wgrad_lds(int fsz) { (void)fsz; return (kWFloats + kWaves * 16) * sizeof(float) + (size_t)kWaves * kWaveRing; }
 
 int wgrad_grid(const seedhip_stack_conv_geom* g, int* spc, int* items) {
   const size_t lds = wgrad_lds(g->ih * g->iw);
@@ -421,8 +427,9 @@ size_t generic_wgrad_ws(const seedhip_stack_conv_geom* g) {
 size_t fast_wgrad_ws(const seedhip_stack_conv_geom* g) {
   // geometry-only eligibility (pointer alignment is checked at launch)
   const long long fsz = (long long)g->ih * g->iw;
-  if (!(g->kh == 8 && g->kw == 8 && g->stride == 4 && g->iw % 4 == 0 && fsz % 16 == 0 &&
-        fsz <= 2 * stackconv::kThreads * 16 && g->cout % 16 == 0)) return 0;
+  (void)fsz;
+  if (!(g->kh == 8 && g->kw == 8 && g->stride == 4 && g->ih == stackconv::kIH && g->iw == stackconv::kIW &&
+        g->cout % 16 == 0)) return 0;
   int spc, items;
   const int grid = stackconv::wgrad_grid(g, &spc, &items);
   return (size_t)grid * ((size_t)256 * g->cout + g->cout) * sizeof(float);
