@@ -389,7 +389,7 @@ size_t wgrad_lds(int fsz) { (void)fsz; return (kWFloats + kWaves * 16) * sizeof(
 int wgrad_grid(const seedhip_stack_conv_geom* g, int* spc, int* items) {
   const size_t lds = wgrad_lds(g->ih * g->iw);
   int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu > 2) per_cu = 2;                     // measured: 2 workgroups per CU beat 3 (0.70 vs 0.81 ms at cfg2)
+  if (per_cu > 2) per_cu = 2;                     // measured: 2 workgroups per CU beat 3 (0.43 vs 0.48 ms at cfg2)
   if (per_cu < 1) per_cu = 1;
   int grid;
   decompose(g->T, g->B, max_grid_for(per_cu), spc, items, &grid);
