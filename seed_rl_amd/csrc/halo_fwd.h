@@ -289,18 +289,36 @@ inline FwdPlan plan_fwd(FwdParams& p, const ClassSpec* cs, int ncls, bool u8) {
   p.ncls = ncls; p.total_slices = total; p.oh_max = oh_max; p.tile_pad_t = max_pt; p.tile_pad_l = max_pl;
   p.twp = (ow_max - 1) * p.stride + ext_w;
   const size_t w_b = (size_t)total * pl.NT * 1024;
-  int th = (256 + ow_max - 1) / ow_max; if (th > oh_max) th = oh_max;
-  for (;; --th) {
+  // Band height TH and pixel tiles per wave MT: maximise the share of MFMA tile slots that carry pixels
+  // (a band's 16-pixel tiles are dealt to 4 waves x MT at a time; e.g. 36x48 maps: TH=6, MT=5 -> 18 of 20
+  // slots, where TH=6, MT=4 would fill 18 of 32), among bands that fit LDS and the register prefetch.
+  int best_th = 0, best_mt = 0;
+  double best_u = -1.0;
+  const int th_hi = (320 + ow_max - 1) / ow_max < oh_max ? (320 + ow_max - 1) / ow_max : oh_max;
+  for (int th = 1; th <= th_hi; ++th) {
     const int thp = (th - 1) * p.stride + ext_h;
     const size_t x_b = (size_t)thp * p.twp * p.xs * 4;
     const size_t x_src = (size_t)thp * p.twp * p.cin * 4;                       // bytes prefetched in registers
-    const bool fits = w_b + x_b <= 64 * 1024 && (u8 || p.cin % 4 != 0 || x_src <= 7 * 256 * 16);
-    if (fits || th == 1) { if (!fits) return pl; pl.lds = w_b + x_b; break; }
+    if (!(w_b + x_b <= 64 * 1024 && (u8 || p.cin % 4 != 0 || x_src <= 7 * 256 * 16))) continue;
+    const int nb = (oh_max + th - 1) / th, last = oh_max - (nb - 1) * th;
+    const int t_full = (th * ow_max + 15) / 16, t_last = (last * ow_max + 15) / 16;
+    for (int mt = 2; mt <= 5; ++mt) {
+      const int round = 4 * mt;
+      const double slots = (double)(nb - 1) * ((t_full + round - 1) / round) * round + (double)((t_last + round - 1) / round) * round;
+      double u = ((double)(nb - 1) * t_full + t_last) / slots;
+      u *= 1.0 - 0.02 * nb / (double)oh_max;                                     // fewer bands: fewer barriers / halo re-reads
+      if (u > best_u + 1e-9) { best_u = u; best_th = th; best_mt = mt; }
+    }
   }
+  if (!best_th) return pl;
+  {
+    const int thp = (best_th - 1) * p.stride + ext_h;
+    pl.lds = w_b + (size_t)thp * p.twp * p.xs * 4;
+  }
+  const int th = best_th;
   pl.TH = th; p.TH = th; p.thp = (th - 1) * p.stride + ext_h;
   p.bands = (oh_max + th - 1) / th; p.ntiles = p.n_img * p.bands;
-  const int tiles16 = (th * ow_max + 15) / 16;
-  pl.MT = tiles16 >= 12 ? 4 : 2;
+  pl.MT = best_mt;
   int per_cu = (int)((160 * 1024) / pl.lds); if (per_cu > 3) per_cu = 3; if (per_cu < 1) per_cu = 1;
   const long long mg = 256LL * per_cu;
   pl.grid = (int)(p.ntiles < mg ? p.ntiles : mg);
@@ -316,7 +334,8 @@ inline int launch_fwd_kernel(const FwdParams& p, const FwdPlan& pl, hipStream_t 
     hipLaunchKernelGGL((halo_fwd_kernel<MT_, NT_>), dim3(pl.grid), dim3(256), pl.lds, s, p);                     \
     return check_launch("halo_fwd_kernel");                                                                      \
   }
-  SEEDHIP_HF(4, 1) SEEDHIP_HF(4, 2) SEEDHIP_HF(2, 1) SEEDHIP_HF(2, 2)
+  SEEDHIP_HF(4, 1) SEEDHIP_HF(4, 2) SEEDHIP_HF(2, 1) SEEDHIP_HF(2, 2) SEEDHIP_HF(3, 1) SEEDHIP_HF(3, 2)
+  SEEDHIP_HF(5, 1) SEEDHIP_HF(5, 2)
 #undef SEEDHIP_HF
   return fail(SEEDHIP_ERR_UNSUPPORTED, "halo_fwd: no kernel for MT=%d NT=%d", pl.MT, pl.NT);
 }
