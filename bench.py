@@ -95,9 +95,12 @@ def main():
   assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the HIP path)'
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
-  if world > 1:
+  distributed = world > 1 or 'RANK' in os.environ       # launched by torch.distributed.run (also at N=1)
+  if distributed:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    torch.distributed.init_process_group('nccl', device_id=dev)
+    os.environ.setdefault('MASTER_PORT', '29500')
+    os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+    torch.distributed.init_process_group('nccl', device_id=dev)          # "nccl" is RCCL on ROCm
   assert world == args.gpus or world == 1, 'launch with torchrun for --gpus > 1'
 
   from seed_rl_amd import learner, networks, ops, optimizers, parametric_distribution as pd, smoke_step
@@ -145,7 +148,7 @@ def main():
     lrn = learner.Learner(agent, opt, pd.categorical_distribution(A), reduction=args.reduction)
 
   def barrier():
-    if world > 1:
+    if distributed:
       torch.distributed.barrier()
     torch.cuda.synchronize()
 
@@ -217,6 +220,8 @@ def main():
                     algorithmic_bytes=nbytes)
 
   if rank != 0:
+    if distributed:
+      torch.distributed.destroy_process_group()
     return
   result = {
       'metric': 'learner env-frames/s (T=%d)' % T, 'value': round(frames_per_s, 1), 'unit': 'env-frames/s',
@@ -253,7 +258,7 @@ def main():
                     'steps, %.2f s/step; host cpu_count=%d' % (T, cb, sec, os.cpu_count())}
       result['speedup_vs_cpu_baseline'] = round(frames_per_s / fps, 1)
   print(json.dumps(result))
-  if world > 1:
+  if distributed:
     torch.distributed.destroy_process_group()
 
 
