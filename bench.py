@@ -62,6 +62,21 @@ def vtrace_checks(dev):
     ref = vtrace_np.from_importance_weights(**inp)
     err = max(err, float(np.max(np.abs(out.vs.cpu().numpy() - ref.vs))),
               float(np.max(np.abs(out.pg_advantages.cpu().numpy() - ref.pg_advantages))))
+  # ... and against the committed outputs of the reference's own common/vtrace.py (tests/golden/make_golden.py),
+  # on the cases run with the learner's clipping (rho_bar = 1)
+  gpath = os.path.join(ROOT, 'tests', 'golden', 'reference_outputs.npz')
+  err_ref = None
+  if os.path.exists(gpath):
+    G = np.load(gpath)
+    err_ref = 0.0
+    for n in range(int(G['vtrace_num_cases'])):
+      seed, stress, lam, cr, cp = G['vtrace_%02d_meta' % n]
+      if cr != 1.0:
+        continue
+      inp = synth.vtrace_inputs(int(seed), 20, 32, 6, stress=bool(stress))
+      out = vtrace.from_importance_weights(**{k: torch.as_tensor(v).to(dev) for k, v in inp.items()}, lambda_=float(lam))
+      err_ref = max(err_ref, float(np.max(np.abs(out.vs.cpu().numpy() - G['vtrace_%02d_vs' % n]))),
+                    float(np.max(np.abs(out.pg_advantages.cpu().numpy() - G['vtrace_%02d_pg' % n]))))
   sweep = []
   for B in (512, 1 << 14, 1 << 17, 1 << 20, 1 << 22):
     T = 20
@@ -84,7 +99,7 @@ def vtrace_checks(dev):
     nbytes = T * B * 28 + B * 4
     sweep.append(dict(B=B, us=round(us, 2), GBs=round(nbytes / us / 1e3, 1),
                       frac_hbm=round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)))
-  return err, sweep
+  return err, err_ref, sweep
 
 
 def main():
@@ -236,8 +251,9 @@ def main():
       'kernels_ms_per_step': {k: round(v['total_ms'], 4) for k, v in kern.items()},
   }
   if world == 1:
-    err, sweep = vtrace_checks(dev)
+    err, err_ref, sweep = vtrace_checks(dev)
     result['vtrace_max_abs_err'] = err
+    result['vtrace_max_abs_err_vs_reference_code'] = err_ref
     result['vtrace_scan_hbm'] = sweep
     if not args.no_cpu_baseline:
       from oracle import cpu_learner
