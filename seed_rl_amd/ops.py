@@ -18,13 +18,16 @@ class Profiler(object):
   """Records (start, end) HIP events around C-ABI calls on torch's current stream.
   `only`: restrict to a set of region names (cheap enough for the timed region)."""
 
-  def __init__(self, only=None):
+  def __init__(self, only=None, serialize=False):
+    """serialize=True drains the device before every region (per-kernel attribution pass: a region then
+    measures its own kernel(s) only, not the tail of the previous launch); never used in a timed region."""
+    self.serialize = serialize
     self.only = set(only) if only is not None else None
     self.events = collections.OrderedDict()
     self.meta = {}
 
   @staticmethod
-  def event_overhead_ms(n=50):
+  def event_overhead_ms(n=50, serialize=False):
     """What a (start, end) HIP event pair reports around a TRIVIAL kernel (a 1-element fill): the marker /
     dispatch overhead that every instrumented region carries.  Subtracted from every region so that kernels
     launched hundreds of times per step (LSTM steps, a few microseconds each) are not ranked by it."""
@@ -32,6 +35,8 @@ class Profiler(object):
     pairs = []
     for _ in range(n):
       s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      if serialize:
+        torch.cuda.synchronize()                     # same idle-device dispatch latency as a serialized region
       s.record(); x.fill_(1.0); e.record()
       pairs.append((s, e))
     torch.cuda.synchronize()
@@ -40,7 +45,7 @@ class Profiler(object):
 
   def summary(self):
     torch.cuda.synchronize()
-    ovh = self.event_overhead_ms()
+    ovh = self.event_overhead_ms(serialize=self.serialize)
     out = collections.OrderedDict()
     for name, evs in self.events.items():
       ms = [max(s.elapsed_time(e) - ovh, 0.0) for s, e in evs]
@@ -64,6 +69,8 @@ def _region(name, flops=0, nbytes=0):
     yield
     return
   s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  if p.serialize:
+    torch.cuda.synchronize()
   s.record()
   yield
   e.record()
