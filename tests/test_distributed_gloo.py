@@ -56,11 +56,8 @@ def _worker(rank, world, port, reduction, out):
     flat = FlatParams([('x', (g.numel(),))], torch.device('cpu'))
     flat.grads.copy_(g)
     learner.all_reduce_gradients(flat.grads)
-    # scatter back into global column order for comparison
-    res = torch.zeros((T + 1) * B * A + (T + 1) * B)
-    if rank == 0:
-      parts = [None] * world
-    # every rank holds the SUM over ranks of its zero-padded shard gradient: rebuild it explicitly
+    # place the shard gradient into global column order (zero elsewhere) and sum over ranks: what a
+    # single replica would have computed on the global batch
     full_l = torch.zeros((T + 1, B, A)); full_b = torch.zeros((T + 1, B))
     per = B // world
     full_l[:, cols] = g[:(T + 1) * per * A].reshape(T + 1, per, A)
