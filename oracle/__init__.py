@@ -14,8 +14,11 @@ Parity pinning (see DESIGN.md "Oracle"):
   * stack_frames / _unroll_cell: pinned by atari/networks_test.py:119-247.
   * n-step Bellman target / value rescaling: pinned by
     agents/r2d2/learner_test.py:114-198.
-  * UnrollStore / Aggregator / make_time_major / batch_apply: pinned by
-    tests/utils_test.py:70-301,585-606.
+  * UnrollStore / Aggregator / make_time_major / batch_apply (oracle/utils_np.py): pinned by
+    tests/utils_test.py:70-301,585-606 (tests/test_oracle_utils.py).
+  * additionally, tests/golden/reference_outputs.npz holds OUTPUTS OF THE REFERENCE'S OWN CODE
+    (common/vtrace.py, tests/vtrace_test.py ground truth, agents/r2d2/learner.py loss math) produced by
+    tests/golden/make_golden.py; tests/test_golden_fixtures.py pins this oracle and the HIP kernels to them.
   * Conv2D / MaxPool2D / LSTMCell / Dense / Adam numerics live in TensorFlow
     2.4.1 + Keras (un-vendored; not importable here: no tensorflow).  They are
     restated from the published Keras semantics.  The

@@ -1,5 +1,14 @@
-// C-ABI entry points for Conv2D / Dense forward, data-gradient and weight-gradient
-// on the fp32-MFMA implicit-GEMM core (igemm.h + conv_problems.h).
+// C-ABI entry points for Conv2D / Dense forward, data-gradient and weight-gradient (fp32 MFMA).
+//
+// Dispatch per layer shape (all paths produce the same results up to fp32 summation order):
+//   * Dense (1x1 on a 1x1 image)            -> Dense{Fwd,Dgrad,Wgrad} accessors on the implicit-GEMM core
+//   * small kernels (<= 4x4, stride <= 2)   -> halo kernels: input band staged once in LDS
+//       forward  : halo_fwd.h   (stride-1 layers where it beats the core; see halo_wins below)
+//       data grad: halo_fwd.h   (all stride-parity classes in one launch)
+//       weight grad: halo_wgrad.h
+//   * everything else                        -> Conv{Fwd,Dgrad,Wgrad} on the implicit-GEMM core
+//     (igemm.h + conv_problems.h; accessor index math unit-tested on the CPU, tests/host/emul.cpp)
+// The first Atari conv fused with frame stacking lives in stackconv.hip.
 #include "common.h"
 #include "conv_problems.h"
 #include "conv_launch.h"

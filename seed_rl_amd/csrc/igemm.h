@@ -14,9 +14,9 @@
 // Tiling (64-wide wavefronts, 4 waves = 256 threads per workgroup):
 //   * workgroup tile BM x BN = (WM*MR*16) x (WN*NR*16); each wave owns MR x NR
 //     16x16 accumulators (4 VGPRs each);
-//   * A/B k-tiles (BK deep) are gathered global -> registers (16 B per lane,
-//     next tile's loads in flight during the MFMAs) -> LDS, double buffered,
-//     ONE barrier per k-tile;
+//   * A/B k-tiles (BK deep) are gathered global -> registers (16 B per lane) -> LDS: LDS is
+//     double buffered and there are TWO register stages, so the loads of tile kt+2 are issued
+//     while tile kt is multiplied and tile kt+1 waits in registers; ONE barrier per k-tile;
 //   * LDS layouts make the MFMA fragment reads bank-conflict free:
 //     A_s[BM][BK+2] (row stride == 2 mod 32 dwords, lanes (i,kq) -> bank 2i+kq),
 //     B_s[BK][LDB] with LDB == 16 mod 32 (lanes (kq,j) -> bank 16kq+j).
