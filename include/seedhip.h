@@ -126,9 +126,20 @@ typedef struct {
 int seedhip_conv2d_fwd(const seedhip_conv_geom* geom, const void* in, int in_dtype, int in_relu,
                        const float* w, const float* bias, float* out, int out_relu,
                        const float* residual, void* stream);
+/* Same, with a caller workspace (seedhip_conv2d_fwd_workspace_bytes, 0 for most shapes): dense layers whose grid
+ * would leave the chip under-filled (inference batches, per-step recurrent GEMMs) split the reduction over
+ * workgroups and finish in a deterministic reduce + epilogue launch.  Without workspace they run unsplit. */
+size_t seedhip_conv2d_fwd_workspace_bytes(const seedhip_conv_geom* geom);
+int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* in, int in_dtype, int in_relu,
+                          const float* w, const float* bias, float* out, int out_relu, const float* residual,
+                          void* workspace, size_t workspace_bytes, void* stream);
 /* dx = conv_transpose(dy, w); then dx *= (relu_mask > 0) if relu_mask; dx += add if add. */
 int seedhip_conv2d_bwd_data(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
                             const float* relu_mask, const float* add, void* stream);
+size_t seedhip_conv2d_bwd_data_workspace_bytes(const seedhip_conv_geom* geom);
+int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
+                               const float* relu_mask, const float* add, void* workspace, size_t workspace_bytes,
+                               void* stream);
 size_t seedhip_conv2d_bwd_weight_workspace_bytes(const seedhip_conv_geom* geom);
 /* dw[kh,kw,cin,cout] and dbias[cout] (dbias may be NULL) are OVERWRITTEN. */
 int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const void* in, int in_dtype, int in_relu,
@@ -207,6 +218,40 @@ int seedhip_r2d2_loss_fwd_bwd(const float* training_q, const float* target_q, co
  * must not alias rows read. */
 int seedhip_rows_move(void* dst, const long long* dst_rows, const void* src, const long long* src_rows,
                       long long n, long long row_bytes, void* stream);
+
+/* ---- batched inference bookkeeping (no host synchronisation, HIP-graph capturable) -----------------------
+ * The small-tensor part of the `inference` function of agents/vtrace/learner.py:350-405 on the device store.
+ * n = inference batch size (<= 1024), ids int64, unique within a call.
+ *  inference_pre : run-id compare / resets (:353-366), episode statistics (:373-378; finished episodes are
+ *                  appended to episode_stats[stats_capacity][3] = (frames, return, raw_return) through *stats_count),
+ *                  previous actions (:381).  Outputs reset_mask u8[n], prev_actions i64[n].
+ *  inference_post: advances the unroll-store index (utils.py:187-194), detects completed unrolls (:229-233), assigns
+ *                  them consecutive columns of a time-major training batch of `batch_capacity` columns
+ *                  (*batch_count += number completed) and emits the row-index lists the row mover needs:
+ *                  append_rows[n], complete u8[n], batch_cols[n], gather_src/dst/mask [full_length*n],
+ *                  last_rows[n] (the step carried to slot 0, utils.py:237-252; overlap 0).  actions_table[e] = action.
+ *  error_flag bits: 1 id out of range, 2 duplicate ids, 4 store overflow, 8 training batch overflow.
+ *  rows_move_masked: seedhip_rows_move with a per-row mask: zero_where_masked = 0 moves only rows with mask != 0;
+ *                  1 moves every row but writes zeros where mask != 0. */
+int seedhip_rows_move_masked(void* dst, const long long* dst_rows, const void* src, const long long* src_rows,
+                             long long n, long long row_bytes, const uint8_t* row_mask, int zero_where_masked,
+                             void* stream);
+/* The same move for up to 16 fields (host arrays of per-field dst / src / row_bytes) in ONE launch; row_mask may be
+ * NULL (plain move). */
+int seedhip_rows_move_multi(int nfields, void* const* dst, const void* const* src, const long long* row_bytes,
+                            const long long* dst_rows, const long long* src_rows, long long n,
+                            const uint8_t* row_mask, int zero_where_masked, void* stream);
+int seedhip_inference_pre(const long long* env_ids, const long long* run_ids, const float* reward,
+                          const float* raw_reward, const uint8_t* done, int n, int num_envs, int num_action_repeats,
+                          long long* run_ids_table, long long* info_frames, float* info_return,
+                          float* info_raw_return, long long* actions_table, long long* store_index,
+                          uint8_t* reset_mask, long long* prev_actions, float* episode_stats, int stats_capacity,
+                          int* stats_count, int* error_flag, void* stream);
+int seedhip_inference_post(const long long* env_ids, const long long* actions, int n, int num_envs, int full_length,
+                           int batch_capacity, long long* store_index, long long* actions_table, int* batch_count,
+                           long long* append_rows, uint8_t* complete, long long* batch_cols, long long* gather_src,
+                           long long* gather_dst, uint8_t* gather_mask, long long* last_rows, int* error_flag,
+                           void* stream);
 
 #ifdef __cplusplus
 }

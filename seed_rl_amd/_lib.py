@@ -52,6 +52,10 @@ SIGNATURES = {
     'seedhip_stack_pack_state': (c_int, [P, P, c_int, c_int, c_ll, P, P]),
     'seedhip_conv2d_fwd': (c_int, [ctypes.POINTER(ConvGeom), P, c_int, c_int, P, P, P, c_int, P, P]),
     'seedhip_conv2d_bwd_data': (c_int, [ctypes.POINTER(ConvGeom), P, P, P, P, P, P]),
+    'seedhip_conv2d_fwd_workspace_bytes': (c_size_t, [ctypes.POINTER(ConvGeom)]),
+    'seedhip_conv2d_fwd_ws': (c_int, [ctypes.POINTER(ConvGeom), P, c_int, c_int, P, P, P, c_int, P, P, c_size_t, P]),
+    'seedhip_conv2d_bwd_data_workspace_bytes': (c_size_t, [ctypes.POINTER(ConvGeom)]),
+    'seedhip_conv2d_bwd_data_ws': (c_int, [ctypes.POINTER(ConvGeom), P, P, P, P, P, P, c_size_t, P]),
     'seedhip_conv2d_bwd_weight_workspace_bytes': (c_size_t, [ctypes.POINTER(ConvGeom)]),
     'seedhip_conv2d_bwd_weight':
         (c_int, [ctypes.POINTER(ConvGeom), P, c_int, c_int, P, P, P, P, c_size_t, P]),
@@ -66,6 +70,10 @@ SIGNATURES = {
     'seedhip_lstm_gates_fwd': (c_int, [P, P, P, c_int, c_int, P, c_int, P, P, P]),
     'seedhip_lstm_gates_bwd': (c_int, [P, P, P, c_int, P, P, P, c_int, c_int, P, P, P]),
     'seedhip_rows_move': (c_int, [P, P, P, P, c_ll, c_ll, P]),
+    'seedhip_rows_move_masked': (c_int, [P, P, P, P, c_ll, c_ll, P, c_int, P]),
+    'seedhip_rows_move_multi': (c_int, [c_int, P, P, P, P, P, c_ll, P, c_int, P]),
+    'seedhip_inference_pre': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P, P]),
+    'seedhip_inference_post': (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P]),
     'seedhip_dueling_fwd': (c_int, [P, c_int, c_ll, c_int, P, P, P]),
     'seedhip_dueling_bwd': (c_int, [P, c_ll, c_int, P, c_int, P]),
     'seedhip_r2d2_loss_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

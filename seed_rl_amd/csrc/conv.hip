@@ -28,6 +28,41 @@ ConvGeom to_geom(const seedhip_conv_geom* g) {
   return c;
 }
 
+// Split-K epilogue of the dense layers: out[m, n] = act(sum_z partial[z][m, n] + bias[n] + residual) (forward) or
+// dx = mask(sum_z partial) + add (data gradient).  Slices summed in order: deterministic.
+__global__ void __launch_bounds__(256)
+dense_epilogue_kernel(const float* __restrict__ partial, int slices, int M, int N, const float* __restrict__ bias,
+                      const float* __restrict__ residual, int out_relu, const float* __restrict__ mask,
+                      const float* __restrict__ add, float* __restrict__ out, int ld) {
+  const long long total = (long long)M * N;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int m = (int)(i / N), n = (int)(i - (long long)m * N);
+    float v = partial[i];
+    for (int z = 1; z < slices; ++z) v += partial[(long long)z * total + i];
+    const long long o = (long long)m * ld + n;
+    if (bias) v += bias[n];
+    if (residual) v += residual[o];
+    if (out_relu && v < 0.f) v = 0.f;
+    if (mask && !(mask[o] > 0.f)) v = 0.f;
+    if (add) v += add[o];
+    out[o] = v;
+  }
+}
+
+// Slices for a dense GEMM [M x N x K]: enough workgroups (64x64 tiles) to give every CU a couple, at least
+// 8 k-tiles of 16 per slice.  1 = no split.
+int dense_slices(int M, int N, int K) {
+  const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
+  if (tiles >= 256) return 1;
+  long long s = (512 + tiles - 1) / tiles;
+  const long long max_by_k = K / 128 > 0 ? K / 128 : 1;
+  if (s > max_by_k) s = max_by_k;
+  if (s > 32) s = 32;
+  return (int)(s < 1 ? 1 : s);
+}
+int slice_k(int K, int slices) { int per = (K + slices - 1) / slices; return (per + 15) / 16 * 16; }
+
 bool is_dense(const seedhip_conv_geom* g) {
   return g->kh == 1 && g->kw == 1 && g->ih == 1 && g->iw == 1 && g->oh == 1 && g->ow == 1 && g->stride == 1 &&
          g->pad_t == 0 && g->pad_l == 0;
@@ -48,9 +83,26 @@ int check_geom(const seedhip_conv_geom* g, const char* what) {
 
 }  // namespace
 
+extern "C" size_t seedhip_conv2d_fwd_workspace_bytes(const seedhip_conv_geom* g) {
+  if (!g || !is_dense(g)) return 0;
+  const int sl = dense_slices(g->n_img, g->cout, g->cin);
+  return sl > 1 ? (size_t)sl * g->n_img * g->cout * sizeof(float) : 0;
+}
+extern "C" size_t seedhip_conv2d_bwd_data_workspace_bytes(const seedhip_conv_geom* g) {
+  if (!g || !is_dense(g)) return 0;
+  const int sl = dense_slices(g->n_img, g->cin, g->cout);
+  return sl > 1 ? (size_t)sl * g->n_img * g->cin * sizeof(float) : 0;
+}
+
 extern "C" int seedhip_conv2d_fwd(const seedhip_conv_geom* geom, const void* in, int in_dtype, int in_relu,
                                   const float* w, const float* bias, float* out, int out_relu,
                                   const float* residual, void* stream) {
+  return seedhip_conv2d_fwd_ws(geom, in, in_dtype, in_relu, w, bias, out, out_relu, residual, nullptr, 0, stream);
+}
+
+extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* in, int in_dtype, int in_relu,
+                                     const float* w, const float* bias, float* out, int out_relu,
+                                     const float* residual, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_geom(geom, "conv2d_fwd"); if (rc) return rc;
   SEEDHIP_REQUIRE(in && w && out, "conv2d_fwd: null pointer");
   SEEDHIP_REQUIRE(in_dtype == kInF32 || in_dtype == kInU8Div255, "conv2d_fwd: bad in_dtype %d", in_dtype);
@@ -78,6 +130,17 @@ extern "C" int seedhip_conv2d_fwd(const seedhip_conv_geom* geom, const void* in,
     d.in = (const float*)in; d.in_relu = in_relu; d.w = w; d.bias = bias; d.out = out; d.out_relu = out_relu;
     d.residual = residual;
     d.init(to_geom(geom));
+    const int sl = dense_slices(d.M, d.N, d.K);
+    if (sl > 1 && workspace && workspace_bytes >= (size_t)sl * d.M * d.N * sizeof(float)) {
+      // under-filled grid (inference batches, recurrent steps): split K, reduce + epilogue in a second launch
+      d.k_per_slice = slice_k(d.K, sl); d.partial = (float*)workspace;
+      const int slices = (d.K + d.k_per_slice - 1) / d.k_per_slice;
+      launch_igemm_auto(d, slices, (hipStream_t)stream);
+      int blocks = cdiv((long long)d.M * d.N, 256); if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(dense_epilogue_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d.partial, slices, d.M,
+                         d.N, bias, residual, out_relu, (const float*)nullptr, (const float*)nullptr, out, d.ld_out);
+      return check_launch("conv2d_fwd(dense, split-K)");
+    }
     launch_igemm_auto(d, 1, (hipStream_t)stream);
     return check_launch("conv2d_fwd(dense)");
   }
@@ -91,6 +154,12 @@ extern "C" int seedhip_conv2d_fwd(const seedhip_conv_geom* geom, const void* in,
 
 extern "C" int seedhip_conv2d_bwd_data(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
                                        const float* relu_mask, const float* add, void* stream) {
+  return seedhip_conv2d_bwd_data_ws(geom, dy, w, dx, relu_mask, add, nullptr, 0, stream);
+}
+
+extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
+                                          const float* relu_mask, const float* add, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
   int rc = check_geom(geom, "conv2d_bwd_data"); if (rc) return rc;
   SEEDHIP_REQUIRE(dy && w && dx, "conv2d_bwd_data: null pointer");
   {
@@ -131,6 +200,16 @@ extern "C" int seedhip_conv2d_bwd_data(const seedhip_conv_geom* geom, const floa
     DenseDgrad d;
     d.dy = dy; d.w = w; d.dx = dx; d.mask = relu_mask; d.add = add;
     d.init(to_geom(geom));
+    const int sl = dense_slices(d.M, d.N, d.K);
+    if (sl > 1 && workspace && workspace_bytes >= (size_t)sl * d.M * d.N * sizeof(float)) {
+      d.k_per_slice = slice_k(d.K, sl); d.partial = (float*)workspace;
+      const int slices = (d.K + d.k_per_slice - 1) / d.k_per_slice;
+      launch_igemm_auto(d, slices, (hipStream_t)stream);
+      int blocks = cdiv((long long)d.M * d.N, 256); if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(dense_epilogue_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d.partial, slices, d.M,
+                         d.N, (const float*)nullptr, (const float*)nullptr, 0, relu_mask, add, dx, d.ld_in);
+      return check_launch("conv2d_bwd_data(dense, split-K)");
+    }
     launch_igemm_auto(d, 1, (hipStream_t)stream);
     return check_launch("conv2d_bwd_data(dense)");
   }

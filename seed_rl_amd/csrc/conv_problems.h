@@ -305,12 +305,15 @@ struct ConvWgrad {
 struct DenseFwd {
   static constexpr bool kAVecK = true, kBVecN = true, kColSumB = false;
   int M, N, K, ld_in, ld_out, cout, in_relu, out_relu, vec_b;
+  int k_per_slice;          // split-K: slice z reduces [z*k_per_slice, ...) into partial[z] (epilogue in dense_epilogue)
+  float* partial;           // [slices][M*N] or null (single slice, fused epilogue)
   const float* in; const float* w; const float* bias; float* out; const float* residual;
   void init(const ConvGeom& g) {
     M = g.n_img; N = g.cout; K = g.cin; ld_in = g.ld_in; ld_out = g.ld_out; cout = g.cout;
     vec_b = (g.cout % 4 == 0);
+    k_per_slice = K; partial = nullptr;
   }
-  SH_HD void k_range(int, int& k0, int& k1) const { k0 = 0; k1 = K; }
+  SH_HD void k_range(int z, int& k0, int& k1) const { k0 = z * k_per_slice; k1 = k0 + k_per_slice; if (k1 > K) k1 = K; }
   struct ARow { const float* p; };
   SH_HD ARow a_row(int m, int) const { return ARow{m < M ? in + (long long)m * ld_in : nullptr}; }
   SH_HD float4 load_a(const ARow& r, int k, int) const {
@@ -326,7 +329,8 @@ struct DenseFwd {
     if (vec_b) return ld4(p);
     return make_float4(p[0], c.n + 1 < N ? p[1] : 0.f, c.n + 2 < N ? p[2] : 0.f, c.n + 3 < N ? p[3] : 0.f);
   }
-  SH_HD void store(int m, int n, float v, int) const {
+  SH_HD void store(int m, int n, float v, int z) const {
+    if (partial) { partial[((long long)z * M + m) * N + n] = v; return; }
     if (bias) v += bias[n];
     const long long o = (long long)m * ld_out + n;
     if (residual) v += residual[o];
@@ -339,17 +343,21 @@ struct DenseFwd {
 struct DenseDgrad {
   static constexpr bool kAVecK = true, kBVecN = false, kColSumB = false;
   int M, N, K, ld_in, ld_out, cout;
+  int k_per_slice; float* partial;
   const float* dy; const float* w; float* dx; const float* mask; const float* add;
-  void init(const ConvGeom& g) { M = g.n_img; N = g.cin; K = g.cout; ld_in = g.ld_in; ld_out = g.ld_out; cout = g.cout; }
-  int slices() const { return 1; }
-  SH_HD void k_range(int, int& k0, int& k1) const { k0 = 0; k1 = K; }
+  void init(const ConvGeom& g) {
+    M = g.n_img; N = g.cin; K = g.cout; ld_in = g.ld_in; ld_out = g.ld_out; cout = g.cout;
+    k_per_slice = K; partial = nullptr;
+  }
+  SH_HD void k_range(int z, int& k0, int& k1) const { k0 = z * k_per_slice; k1 = k0 + k_per_slice; if (k1 > K) k1 = K; }
   struct ARow { const float* p; };
   SH_HD ARow a_row(int m, int) const { return ARow{m < M ? dy + (long long)m * ld_out : nullptr}; }
   SH_HD float4 load_a(const ARow& r, int k, int) const { return r.p ? ld4(r.p + k) : f4_zero(); }
   struct BCol { const float* p; };
   SH_HD BCol b_col(int n, int) const { return BCol{n < N ? w + (long long)n * cout : nullptr}; }
   SH_HD float4 load_b(const BCol& c, int k, int) const { return c.p ? ld4(c.p + k) : f4_zero(); }
-  SH_HD void store(int m, int n, float v, int) const {
+  SH_HD void store(int m, int n, float v, int z) const {
+    if (partial) { partial[((long long)z * M + m) * N + n] = v; return; }
     const long long o = (long long)m * ld_in + n;
     if (mask && !(mask[o] > 0.f)) v = 0.f;
     if (add) v += add[o];

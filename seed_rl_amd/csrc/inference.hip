@@ -1,0 +1,259 @@
+// Bookkeeping kernels of the learner-side batched inference step.
+//
+// Replaces the small-tensor part of the `inference` tf.function of
+// /root/reference/agents/vtrace/learner.py:350-405 -- ~25 gather / scatter / where / boolean-mask ops on
+// [inference_batch_size] tensors, several of which produce data-dependent shapes (tf.where -> tf.gather) -- with
+// TWO launches that keep every shape static, so that the whole step has no host synchronisation and can be
+// replayed from a HIP graph:
+//   inference_pre  : run-id compare + reset bookkeeping (:353-366), episode statistics (:373-378), previous
+//                    action read (:381), unroll-store slot of this step (utils.py:187-194)
+//   inference_post : store index advance, completed-unroll detection (utils.py:229-233), destination columns
+//                    in the time-major training batch (exclusive scan over the batch), index lists for the
+//                    row mover (store.hip) that appends the step, emits completed unrolls and carries the last
+//                    step over (utils.py:237-255), action table update (:403).
+// One workgroup; n = inference batch size <= 1024.  All integer work: exact.
+#include "common.h"
+#include "../../include/seedhip.h"
+
+namespace {
+
+struct PreArgs {
+  const long long* env_ids; const long long* run_ids; const float* reward; const float* raw_reward;
+  const uint8_t* done; int n; int num_envs; int num_action_repeats;
+  long long* run_ids_tab; long long* info_frames; float* info_return; float* info_raw_return;
+  long long* actions_tab; long long* store_index;
+  uint8_t* reset_mask; long long* prev_actions;
+  float* episode_stats; int stats_capacity; int* stats_count; int* error_flag;
+};
+
+__global__ void __launch_bounds__(1024)
+inference_pre_kernel(PreArgs a) {
+  const int i = threadIdx.x;
+  if (i >= a.n) return;
+  const long long e = a.env_ids[i];
+  if (e < 0 || e >= a.num_envs) { atomicOr(a.error_flag, 1); a.reset_mask[i] = 0; a.prev_actions[i] = 0; return; }
+  // duplicate ids in one batch are an error in the reference (utils.py:173-176); flag them (n is small)
+  for (int k = 0; k < i; ++k) if (a.env_ids[k] == e) atomicOr(a.error_flag, 2);
+  const long long prev_run = a.run_ids_tab[e];
+  const long long run = a.run_ids[i];
+  a.run_ids_tab[e] = run;                                              // learner.py:354
+  const bool reset = prev_run != run;                                  // :355-357
+  long long frames = a.info_frames[e];
+  float ret = a.info_return[e], raw = a.info_raw_return[e];
+  long long act = a.actions_tab[e];
+  if (reset) {                                                         // :360-366
+    frames = 0; ret = 0.f; raw = 0.f; act = 0;
+    a.store_index[e] = 0;                                              // UnrollStore.reset, overlap 0 (utils.py:207)
+    a.actions_tab[e] = 0;
+  }
+  ret += a.reward[i]; raw += a.raw_reward[i];                          // :373
+  if (a.done[i]) {                                                     // :374-377: report + reset the episode stats
+    const int slot = atomicAdd(a.stats_count, 1);
+    if (slot < a.stats_capacity) {
+      a.episode_stats[3 * slot + 0] = (float)frames;
+      a.episode_stats[3 * slot + 1] = ret;
+      a.episode_stats[3 * slot + 2] = raw;
+    }
+    frames = 0; ret = 0.f; raw = 0.f;
+  }
+  frames += a.num_action_repeats;                                      // :378
+  a.info_frames[e] = frames; a.info_return[e] = ret; a.info_raw_return[e] = raw;
+  a.reset_mask[i] = reset ? 1 : 0;
+  a.prev_actions[i] = act;                                             // :381
+}
+
+struct PostArgs {
+  const long long* env_ids; const long long* actions; int n; int num_envs; int full_length; int batch_capacity;
+  long long* store_index; long long* actions_tab; int* batch_count;
+  long long* append_rows;      // [n]          store row (idx*E + e) this step is written to
+  uint8_t* complete;           // [n]          1 where the step completed an unroll
+  long long* batch_cols;       // [n]          destination column in the training batch (valid where complete)
+  long long* gather_src;       // [L*n]        t*E + e
+  long long* gather_dst;       // [L*n]        t*capacity + column
+  uint8_t* gather_mask;        // [L*n]
+  long long* last_rows;        // [n]          (L-1)*E + e: the step carried over to slot 0 (utils.py:237-252)
+  int* error_flag;
+};
+
+__global__ void __launch_bounds__(1024)
+inference_post_kernel(PostArgs a) {
+  __shared__ int s_scan[1024];
+  __shared__ int s_base;
+  const int i = threadIdx.x;
+  const int L = a.full_length, E = a.num_envs;
+  long long e = 0;
+  int done = 0;
+  if (i < a.n) {
+    e = a.env_ids[i];
+    const long long idx = a.store_index[e];
+    a.append_rows[i] = idx * E + e;
+    done = (idx + 1 == L) ? 1 : 0;
+    if (idx + 1 > L) atomicOr(a.error_flag, 4);
+    a.store_index[e] = done ? 1 : idx + 1;                             // utils.py:194, 254-255 (overlap 0)
+    a.actions_tab[e] = a.actions[i];                                   // learner.py:403
+    a.last_rows[i] = (long long)(L - 1) * E + e;
+  }
+  // inclusive scan of `done` over the batch (order of env_ids, like tf.gather(env_ids, tf.where(...)))
+  s_scan[i] = done;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = (i >= off) ? s_scan[i - off] : 0;
+    __syncthreads();
+    s_scan[i] += v;
+    __syncthreads();
+  }
+  if (i == 0) {
+    const int total = s_scan[1023];
+    const int base = *a.batch_count;
+    s_base = base;
+    *a.batch_count = base + total;
+    if (base + total > a.batch_capacity) atomicOr(a.error_flag, 8);
+  }
+  __syncthreads();
+  if (i < a.n) {
+    const int col = s_base + s_scan[i] - done;
+    const bool ok = done && col < a.batch_capacity;
+    a.complete[i] = ok ? 1 : 0;
+    a.batch_cols[i] = ok ? col : 0;
+    for (int t = 0; t < L; ++t) {
+      a.gather_src[(long long)t * a.n + i] = (long long)t * E + e;
+      a.gather_dst[(long long)t * a.n + i] = ok ? (long long)t * a.batch_capacity + col : 0;
+      a.gather_mask[(long long)t * a.n + i] = ok ? 1 : 0;
+    }
+  }
+}
+
+template <typename V>
+__global__ void __launch_bounds__(256)
+rows_move_masked_kernel(V* __restrict__ dst, const long long* __restrict__ dst_rows, const V* __restrict__ src,
+                        const long long* __restrict__ src_rows, long long n, long long row_elems,
+                        const uint8_t* __restrict__ mask, int zero_where_masked) {
+  const long long total = n * row_elems;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long r = i / row_elems, el = i - r * row_elems;
+    const bool m = mask[r] != 0;
+    V v{};
+    if (zero_where_masked) {
+      if (!m && src) v = src[(src_rows ? src_rows[r] : r) * row_elems + el];
+    } else {
+      if (!m) continue;
+      if (src) v = src[(src_rows ? src_rows[r] : r) * row_elems + el];
+    }
+    dst[(dst_rows ? dst_rows[r] : r) * row_elems + el] = v;
+  }
+}
+
+
+// All fields of a structure in ONE launch (blockIdx.y = field): the per-field launches of the inference step
+// (10 fields x {append, emit, carry}) collapse to three.
+constexpr int kMaxFields = 16;
+struct MultiArgs {
+  void* dst[kMaxFields]; const void* src[kMaxFields]; long long row_bytes[kMaxFields];
+  const long long* dst_rows; const long long* src_rows; long long n; const uint8_t* mask; int zero_where_masked;
+};
+
+__global__ void __launch_bounds__(256)
+rows_move_multi_kernel(MultiArgs a) {
+  const int f = blockIdx.y;
+  const long long rb = a.row_bytes[f];
+  const uintptr_t al = (uintptr_t)a.dst[f] | (uintptr_t)a.src[f] | (uintptr_t)rb;
+  const int w = (al & 15) == 0 ? 16 : ((al & 3) == 0 ? 4 : 1);       // uniform per field
+  const long long row_elems = rb / w;
+  const long long total = a.n * row_elems;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long r = i / row_elems, el = i - r * row_elems;
+    const bool m = a.mask ? a.mask[r] != 0 : true;
+    bool zero = false;
+    if (a.mask) {
+      if (a.zero_where_masked) zero = m; else if (!m) continue;
+    }
+    const long long so = ((a.src_rows ? a.src_rows[r] : r) * row_elems + el) * w;
+    const long long d_o = ((a.dst_rows ? a.dst_rows[r] : r) * row_elems + el) * w;
+    char* d = (char*)a.dst[f] + d_o;
+    const char* sp = a.src[f] ? (const char*)a.src[f] + so : nullptr;
+    if (w == 16) *reinterpret_cast<uint4*>(d) = (sp && !zero) ? *reinterpret_cast<const uint4*>(sp) : make_uint4(0, 0, 0, 0);
+    else if (w == 4) *reinterpret_cast<uint32_t*>(d) = (sp && !zero) ? *reinterpret_cast<const uint32_t*>(sp) : 0u;
+    else *d = (sp && !zero) ? *sp : (char)0;
+  }
+}
+
+}  // namespace
+
+extern "C" int seedhip_rows_move_masked(void* dst, const long long* dst_rows, const void* src,
+                                        const long long* src_rows, long long n, long long row_bytes,
+                                        const uint8_t* row_mask, int zero_where_masked, void* stream) {
+  SEEDHIP_REQUIRE(n >= 0 && row_bytes >= 1, "rows_move_masked: bad n / row_bytes");
+  if (n == 0) return SEEDHIP_OK;
+  SEEDHIP_REQUIRE(dst && row_mask, "rows_move_masked: null dst / mask");
+  hipStream_t s = (hipStream_t)stream;
+  const uintptr_t al = (uintptr_t)dst | (uintptr_t)src | (uintptr_t)row_bytes;
+  const long long total_bytes = n * row_bytes;
+  auto grid = [](long long elems) { long long g = (elems + 255) / 256; return (int)(g > 8192 ? 8192 : g); };
+  if ((al & 15) == 0)
+    hipLaunchKernelGGL(rows_move_masked_kernel<uint4>, dim3(grid(total_bytes / 16)), dim3(256), 0, s, (uint4*)dst,
+                       dst_rows, (const uint4*)src, src_rows, n, row_bytes / 16, row_mask, zero_where_masked);
+  else if ((al & 3) == 0)
+    hipLaunchKernelGGL(rows_move_masked_kernel<uint32_t>, dim3(grid(total_bytes / 4)), dim3(256), 0, s, (uint32_t*)dst,
+                       dst_rows, (const uint32_t*)src, src_rows, n, row_bytes / 4, row_mask, zero_where_masked);
+  else
+    hipLaunchKernelGGL(rows_move_masked_kernel<uint8_t>, dim3(grid(total_bytes)), dim3(256), 0, s, (uint8_t*)dst,
+                       dst_rows, (const uint8_t*)src, src_rows, n, row_bytes, row_mask, zero_where_masked);
+  return seedhip::check_launch("rows_move_masked_kernel");
+}
+
+extern "C" int seedhip_inference_pre(const long long* env_ids, const long long* run_ids, const float* reward,
+                                     const float* raw_reward, const uint8_t* done, int n, int num_envs,
+                                     int num_action_repeats, long long* run_ids_table, long long* info_frames,
+                                     float* info_return, float* info_raw_return, long long* actions_table,
+                                     long long* store_index, uint8_t* reset_mask, long long* prev_actions,
+                                     float* episode_stats, int stats_capacity, int* stats_count, int* error_flag,
+                                     void* stream) {
+  SEEDHIP_REQUIRE(n >= 1 && n <= 1024 && num_envs >= 1, "inference_pre: need 1 <= n <= 1024");
+  SEEDHIP_REQUIRE(env_ids && run_ids && reward && raw_reward && done && run_ids_table && info_frames && info_return &&
+                  info_raw_return && actions_table && store_index && reset_mask && prev_actions && episode_stats &&
+                  stats_count && error_flag, "inference_pre: null pointer");
+  PreArgs a{env_ids, run_ids, reward, raw_reward, done, n, num_envs, num_action_repeats, run_ids_table, info_frames,
+            info_return, info_raw_return, actions_table, store_index, reset_mask, prev_actions, episode_stats,
+            stats_capacity, stats_count, error_flag};
+  hipLaunchKernelGGL(inference_pre_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  return seedhip::check_launch("inference_pre_kernel");
+}
+
+extern "C" int seedhip_inference_post(const long long* env_ids, const long long* actions, int n, int num_envs,
+                                      int full_length, int batch_capacity, long long* store_index,
+                                      long long* actions_table, int* batch_count, long long* append_rows,
+                                      uint8_t* complete, long long* batch_cols, long long* gather_src,
+                                      long long* gather_dst, uint8_t* gather_mask, long long* last_rows,
+                                      int* error_flag, void* stream) {
+  SEEDHIP_REQUIRE(n >= 1 && n <= 1024 && num_envs >= 1 && full_length >= 2 && batch_capacity >= 1,
+                  "inference_post: bad sizes");
+  SEEDHIP_REQUIRE(env_ids && actions && store_index && actions_table && batch_count && append_rows && complete &&
+                  batch_cols && gather_src && gather_dst && gather_mask && last_rows && error_flag,
+                  "inference_post: null pointer");
+  PostArgs a{env_ids, actions, n, num_envs, full_length, batch_capacity, store_index, actions_table, batch_count,
+             append_rows, complete, batch_cols, gather_src, gather_dst, gather_mask, last_rows, error_flag};
+  hipLaunchKernelGGL(inference_post_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  return seedhip::check_launch("inference_post_kernel");
+}
+
+extern "C" int seedhip_rows_move_multi(int nfields, void* const* dst, const void* const* src, const long long* row_bytes,
+                                       const long long* dst_rows, const long long* src_rows, long long n,
+                                       const uint8_t* row_mask, int zero_where_masked, void* stream) {
+  SEEDHIP_REQUIRE(nfields >= 1 && nfields <= kMaxFields && n >= 0, "rows_move_multi: need 1 <= nfields <= %d", kMaxFields);
+  if (n == 0) return SEEDHIP_OK;
+  SEEDHIP_REQUIRE(dst && src && row_bytes, "rows_move_multi: null descriptor arrays");
+  MultiArgs a;
+  long long max_elems = 1;
+  for (int f = 0; f < nfields; ++f) {
+    SEEDHIP_REQUIRE(dst[f] && row_bytes[f] >= 1, "rows_move_multi: bad field %d", f);
+    a.dst[f] = dst[f]; a.src[f] = src[f]; a.row_bytes[f] = row_bytes[f];
+    const long long e = n * ((row_bytes[f] + 15) / 16);
+    if (e > max_elems) max_elems = e;
+  }
+  a.dst_rows = dst_rows; a.src_rows = src_rows; a.n = n; a.mask = row_mask; a.zero_where_masked = zero_where_masked;
+  long long gx = (max_elems + 255) / 256; if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(rows_move_multi_kernel, dim3((int)gx, nfields), dim3(256), 0, (hipStream_t)stream, a);
+  return seedhip::check_launch("rows_move_multi_kernel");
+}

@@ -112,21 +112,39 @@ def _dev(t):
   return torch.cuda.device(t.device)
 
 
+_SPLITK_WS = {}
+
+
+def _splitk_ws(nbytes, like):
+  """Scratch for the split-K dense paths: one buffer per (device, stream), grown on demand (warm-up), reused by
+  consecutive ops on that stream (stream order makes that safe)."""
+  if nbytes == 0:
+    return None, 0
+  key = (like.device, torch.cuda.current_stream(like.device).cuda_stream)
+  t = _SPLITK_WS.get(key)
+  if t is None or t.numel() * 4 < nbytes:
+    t = torch.empty(max(nbytes // 4 + 4, 1 << 20), dtype=torch.float32, device=like.device)
+    _SPLITK_WS[key] = t
+  return t, t.numel() * 4
+
+
 def conv2d_fwd(g, x, w, bias, out, in_dtype=IN_F32, in_relu=False, out_relu=False, residual=None):
   with _region(_conv_name('conv_fwd', g), *_conv_cost(g, 1 if in_dtype else 4)):
     with _dev(out):
-      _lib.check(_lib.lib().seedhip_conv2d_fwd(
+      ws, wsb = _splitk_ws(int(_lib.lib().seedhip_conv2d_fwd_workspace_bytes(ctypes.byref(g))), out)
+      _lib.check(_lib.lib().seedhip_conv2d_fwd_ws(
           ctypes.byref(g), _lib.ptr(x), in_dtype, int(in_relu), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out),
-          int(out_relu), _lib.ptr(residual), _lib.stream()), 'seedhip_conv2d_fwd')
+          int(out_relu), _lib.ptr(residual), _lib.ptr(ws), wsb, _lib.stream()), 'seedhip_conv2d_fwd')
     return out
 
 
 def conv2d_bwd_data(g, dy, w, dx, relu_mask=None, add=None):
   with _region(_conv_name('conv_dgrad', g), *_conv_cost(g)):
     with _dev(dx):
-      _lib.check(_lib.lib().seedhip_conv2d_bwd_data(
+      ws, wsb = _splitk_ws(int(_lib.lib().seedhip_conv2d_bwd_data_workspace_bytes(ctypes.byref(g))), dx)
+      _lib.check(_lib.lib().seedhip_conv2d_bwd_data_ws(
           ctypes.byref(g), _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(relu_mask), _lib.ptr(add),
-          _lib.stream()), 'seedhip_conv2d_bwd_data')
+          _lib.ptr(ws), wsb, _lib.stream()), 'seedhip_conv2d_bwd_data')
     return dx
 
 
@@ -315,3 +333,54 @@ def rows_move(dst, dst_rows, src, src_rows, n, row_bytes):
   with _dev(dst):
     _lib.check(_lib.lib().seedhip_rows_move(_lib.ptr(dst), _lib.ptr(dst_rows), _lib.ptr(src), _lib.ptr(src_rows), n,
                                             row_bytes, _lib.stream()), 'seedhip_rows_move')
+
+
+def rows_move_masked(dst, dst_rows, src, src_rows, n, row_bytes, mask_u8, zero_where_masked=False):
+  """rows_move with a per-row mask (see seedhip_rows_move_masked)."""
+  if n == 0:
+    return
+  with _dev(dst):
+    _lib.check(_lib.lib().seedhip_rows_move_masked(
+        _lib.ptr(dst), _lib.ptr(dst_rows), _lib.ptr(src), _lib.ptr(src_rows), n, row_bytes, _lib.ptr(mask_u8),
+        int(zero_where_masked), _lib.stream()), 'seedhip_rows_move_masked')
+
+
+def inference_pre(env_ids, run_ids, reward, raw_reward, done_u8, n, num_envs, num_action_repeats, run_ids_tab,
+                  info_frames, info_return, info_raw, actions_tab, store_index, reset_mask, prev_actions,
+                  episode_stats, stats_count, error_flag):
+  with _dev(reset_mask):
+    _lib.check(_lib.lib().seedhip_inference_pre(
+        _lib.ptr(env_ids), _lib.ptr(run_ids), _lib.ptr(reward), _lib.ptr(raw_reward), _lib.ptr(done_u8), n, num_envs,
+        num_action_repeats, _lib.ptr(run_ids_tab), _lib.ptr(info_frames), _lib.ptr(info_return), _lib.ptr(info_raw),
+        _lib.ptr(actions_tab), _lib.ptr(store_index), _lib.ptr(reset_mask), _lib.ptr(prev_actions),
+        _lib.ptr(episode_stats), episode_stats.shape[0], _lib.ptr(stats_count), _lib.ptr(error_flag), _lib.stream()),
+        'seedhip_inference_pre')
+
+
+def inference_post(env_ids, actions, n, num_envs, full_length, batch_capacity, store_index, actions_tab, batch_count,
+                   append_rows, complete, batch_cols, gather_src, gather_dst, gather_mask, last_rows, error_flag):
+  with _dev(complete):
+    _lib.check(_lib.lib().seedhip_inference_post(
+        _lib.ptr(env_ids), _lib.ptr(actions), n, num_envs, full_length, batch_capacity, _lib.ptr(store_index),
+        _lib.ptr(actions_tab), _lib.ptr(batch_count), _lib.ptr(append_rows), _lib.ptr(complete), _lib.ptr(batch_cols),
+        _lib.ptr(gather_src), _lib.ptr(gather_dst), _lib.ptr(gather_mask), _lib.ptr(last_rows), _lib.ptr(error_flag),
+        _lib.stream()), 'seedhip_inference_post')
+
+
+def rows_move_multi(dsts, srcs, row_bytes, dst_rows, src_rows, n, mask_u8=None, zero_where_masked=False):
+  """One launch moving rows of several fields (lists of tensors; src entries may be None = zeros)."""
+  nf = len(dsts)
+  if n == 0 or nf == 0:
+    return
+  for lo in range(0, nf, 16):
+    d, s_, rb = dsts[lo:lo + 16], srcs[lo:lo + 16], row_bytes[lo:lo + 16]
+    k = len(d)
+    PA = ctypes.c_void_p * k
+    da = PA(*[t.data_ptr() for t in d])
+    sa = PA(*[(t.data_ptr() if t is not None else None) for t in s_])
+    ra = (ctypes.c_longlong * k)(*rb)
+    with _dev(d[0]):
+      _lib.check(_lib.lib().seedhip_rows_move_multi(
+          k, ctypes.cast(da, ctypes.c_void_p), ctypes.cast(sa, ctypes.c_void_p), ctypes.cast(ra, ctypes.c_void_p),
+          _lib.ptr(dst_rows), _lib.ptr(src_rows), n, _lib.ptr(mask_u8), int(zero_where_masked), _lib.stream()),
+          'seedhip_rows_move_multi')

@@ -301,6 +301,8 @@ CONV_CASES = [
     (2, 10, 14, 64, 3, 3, 1, 'valid', 64),    # halo wgrad, 4-way row split (ow % 4 == 0)
     (3, 13, 20, 32, 3, 3, 1, 'same', 16),     # halo wgrad, 2-way row split, partial last band
     (70, 9, 12, 32, 3, 3, 1, 'same', 32),     # ImpalaDeep stack2 res conv, many images per workgroup
+    (64, 1, 1, 2592, 1, 1, 1, 'valid', 256),  # inference-batch FC: split-K forward / data gradient
+    (256, 1, 1, 512, 1, 1, 1, 'valid', 2048), # LSTM(512) recurrent step GEMM: split-K
     (3, 11, 13, 8, 3, 3, 2, 'valid', 16),     # stride-2 data gradient: parity classes with different tap counts
     (2, 12, 10, 16, 4, 3, 2, 'valid', 32),    # 4x3 kernel, stride 2
 ]
