@@ -253,6 +253,16 @@ int seedhip_inference_post(const long long* env_ids, const long long* actions, i
                            long long* gather_dst, uint8_t* gather_mask, long long* last_rows, int* error_flag,
                            void* stream);
 
+/* ---- prioritized replay sampling --------------------------------------------------------------------
+ * Replaces PrioritizedReplay.sample of common/utils.py:309-357 for priority_exponent > 0: categorical sampling
+ * (with replacement) proportional to priorities[i]^priority_exponent over the first `limit` slots, driven by
+ * caller-supplied uniforms in [0,1) (one per sample), and the normalised importance weights
+ * ((1/limit)/prob)^importance_sampling_exponent / max.  indices int64[num_samples], weights f32[num_samples]. */
+size_t seedhip_replay_sample_workspace_bytes(long long limit);
+int seedhip_replay_sample(const float* priorities, long long limit, float priority_exponent,
+                          float importance_sampling_exponent, const float* uniforms, int num_samples,
+                          long long* indices, float* weights, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

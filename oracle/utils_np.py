@@ -111,3 +111,53 @@ def batch_apply(fn, inputs):
 def make_time_major(x):
   """utils.py:735-761: swap the two leading axes of every array of the structure."""
   return _map(lambda a: np.swapaxes(a, 0, 1) if a.ndim >= 2 else a, x)
+
+
+class PrioritizedReplay(object):
+  """utils.py:260-370 (restated; sampling takes explicit uniforms so that it is reproducible: the reference draws
+  with tf.random.categorical).  Pinned by tests/utils_test.py:304-405."""
+
+  def __init__(self, size, specs, importance_sampling_exponent):
+    self._priorities = np.zeros([size], np.float32)
+    self._buffer = _map(lambda sd: np.zeros((size,) + tuple(sd.shape), sd.dtype), specs)
+    self.num_inserted = 0
+    self._is_exp = importance_sampling_exponent
+
+  def insert(self, values, priorities):
+    n = _first_leaf(values).shape[0]
+    size = self._priorities.shape[0]
+    idx = np.arange(self.num_inserted, self.num_inserted + n) % size                      # :297
+    def upd(b, v):
+      b[idx] = v
+      return b
+    _zip_apply(upd, self._buffer, values)
+    self.num_inserted += n
+    self._priorities[idx] = priorities
+    return idx
+
+  def sample(self, num_samples, priority_exp, uniforms=None, rng=None):
+    assert self.num_inserted > 0, 'Cannot sample if replay buffer is empty'
+    size = self._priorities.shape[0]
+    limit = min(size, self.num_inserted)
+    rng = rng or np.random.default_rng(0)
+    if priority_exp == 0:
+      indices = rng.integers(0, limit, num_samples)
+      weights = np.ones(num_samples, np.float32)
+    else:
+      prob = self._priorities[:limit].astype(np.float32) ** np.float32(priority_exp)
+      prob = prob / prob.sum(dtype=np.float32)                                           # :342-343
+      u = rng.uniform(size=num_samples).astype(np.float32) if uniforms is None else np.asarray(uniforms, np.float32)
+      cdf = np.cumsum(prob, dtype=np.float64)
+      indices = np.minimum(np.searchsorted(cdf, u.astype(np.float64) * cdf[-1], side='right'), limit - 1)
+      weights = ((np.float32(1.) / np.float32(limit)) / prob[indices]) ** np.float32(self._is_exp)   # :350-352
+      weights = (weights / weights.max()).astype(np.float32)                              # :353
+    return indices.astype(np.int64), weights, _map(lambda b: b[indices].copy(), self._buffer)
+
+  def update_priorities(self, indices, priorities):
+    self._priorities[np.asarray(indices, np.int64)] = priorities
+
+
+def _first_leaf(struct):
+  while not isinstance(struct, np.ndarray):
+    struct = list(struct.values())[0] if isinstance(struct, dict) else struct[0]
+  return struct

@@ -384,3 +384,15 @@ def rows_move_multi(dsts, srcs, row_bytes, dst_rows, src_rows, n, mask_u8=None, 
           k, ctypes.cast(da, ctypes.c_void_p), ctypes.cast(sa, ctypes.c_void_p), ctypes.cast(ra, ctypes.c_void_p),
           _lib.ptr(dst_rows), _lib.ptr(src_rows), n, _lib.ptr(mask_u8), int(zero_where_masked), _lib.stream()),
           'seedhip_rows_move_multi')
+
+
+def replay_sample(priorities, limit, priority_exp, is_exp, uniforms, indices, weights, workspace):
+  with _dev(indices):
+    _lib.check(_lib.lib().seedhip_replay_sample(
+        _lib.ptr(priorities), limit, float(priority_exp), float(is_exp), _lib.ptr(uniforms), uniforms.numel(),
+        _lib.ptr(indices), _lib.ptr(weights), _lib.ptr(workspace), workspace.numel() * workspace.element_size(),
+        _lib.stream()), 'seedhip_replay_sample')
+
+
+def replay_sample_workspace_bytes(limit):
+  return int(_lib.lib().seedhip_replay_sample_workspace_bytes(limit))

@@ -91,3 +91,51 @@ def test_batch_apply_and_time_major():
   tm = utils_np.make_time_major(x)
   np.testing.assert_array_equal(tm['a'], [[1, 3], [2, 4]])
   np.testing.assert_array_equal(tm['b'], [[1, 2]])
+
+
+# ---- PrioritizedReplay (tests/utils_test.py:304-405) ---- #
+def _replay_known_answers(make, to_np, uniforms):
+  """The reference's PrioritizedReplayTest cases, parameterised over the implementation under test."""
+  import collections as c
+  rb = make(2, utils_np.Spec((), np.int32), .5)                                  # test_simple :306-323
+  np.testing.assert_array_equal(to_np(rb.insert(np.array([1, 2], np.int32), np.array([1., 1.], np.float32))), [0, 1])
+  idx, w, vals = rb.sample(2, .5, uniforms(2))
+  np.testing.assert_array_equal(to_np(idx) + 1, to_np(vals)); np.testing.assert_array_equal(to_np(w), [1., 1.])
+  idx, w, vals = rb.sample(2, 0)
+  np.testing.assert_array_equal(to_np(idx) + 1, to_np(vals)); np.testing.assert_array_equal(to_np(w), [1., 1.])
+  rb = make(2, utils_np.Spec((), np.int32), .5)                                  # test_update_priorities :339-354
+  rb.insert(np.array([1, 2], np.int32), np.array([1., 1.], np.float32))
+  rb.update_priorities(np.array([0]), np.array([100.], np.float32))
+  idx, w, vals = rb.sample(2, .5, np.array([0.1, 0.7], np.float32))
+  np.testing.assert_array_equal(to_np(idx), [0, 0]); np.testing.assert_array_equal(to_np(vals), [1, 1])
+  np.testing.assert_array_equal(to_np(w), [1., 1.])
+  rb = make(2, utils_np.Spec((), np.int32), .5)                                  # test_initial_priorities :356-369
+  rb.insert(np.array([1, 2], np.int32), np.array([0.1, 0.9], np.float32))
+  _, _, vals = rb.sample(1000, 1, uniforms(1000))
+  cnt = c.Counter(to_np(vals).tolist())
+  assert 1000 * 0.1 * 0.7 < cnt[1] < 1000 * 0.1 * 1.3
+  for is_exp, p_exp, expected in (                                               # test_importance_sampling_weights1/2
+      (1, 1, np.array([(0.3 + 0.9) / 0.3, (0.3 + 0.9) / 0.9])),
+      (.3, .7, np.array([(0.3 ** .7 + 0.9 ** .7) / 0.3 ** .7, (0.3 ** .7 + 0.9 ** .7) / 0.9 ** .7]) ** .3)):
+    rb = make(2, utils_np.Spec((), np.int32), is_exp)
+    rb.insert(np.array([0, 1], np.int32), np.array([0.3, 0.9], np.float32))
+    _, w, vals = rb.sample(100, p_exp, uniforms(100))
+    expected = expected / expected.max()
+    w, vals = to_np(w), to_np(vals)
+    assert set(vals.tolist()) == {0, 1}
+    for v in (0, 1):
+      np.testing.assert_allclose(w[vals == v], expected[v], rtol=1e-5)
+  # wrap-around FIFO + nests (:325-337)
+  nt = collections.namedtuple('nt', 'a b')
+  rb = make(3, nt(utils_np.Spec((), np.int32), utils_np.Spec((2,), np.int64)), .5)
+  for k in range(5):
+    ids = rb.insert(nt(np.array([k], np.int32), np.array([[k, -k]], np.int64)), np.array([1.], np.float32))
+    assert to_np(ids).tolist() == [k % 3]
+  _, _, vals = rb.sample(64, 1, uniforms(64))
+  a, b = to_np(vals.a), to_np(vals.b)
+  assert set(a.tolist()) <= {2, 3, 4} and np.array_equal(b[:, 0], a) and np.array_equal(b[:, 1], -a)
+
+
+def test_prioritized_replay_oracle():
+  rng = np.random.default_rng(5)
+  _replay_known_answers(utils_np.PrioritizedReplay, np.asarray, lambda n: rng.uniform(size=n).astype(np.float32))
