@@ -14,6 +14,7 @@
 #include "conv_launch.h"
 #include "halo_wgrad.h"
 #include "halo_fwd.h"
+#include "gemm.h"
 #include "../../include/seedhip.h"
 
 using namespace seedhip;
@@ -63,6 +64,22 @@ int dense_slices(int M, int N, int K) {
 }
 int slice_k(int K, int slices) { int per = (K + slices - 1) / slices; return (per + 15) / 16 * 16; }
 
+// Dense layers on gemm.h (see there).  mode bits (SEEDHIP_GEMM, default 7): 1 forward, 2 data gradient, 4 weight
+// gradient; a cleared bit falls back to the Dense accessors of the implicit-GEMM core (A/B measurements).
+int gemm_mode() { static int m = getenv("SEEDHIP_GEMM") ? atoi(getenv("SEEDHIP_GEMM")) : 7; return m; }
+bool al16(const void* q) { return (((uintptr_t)q) & 15) == 0; }
+bool gemm_fwd_ok(const seedhip_conv_geom* g) {
+  return (gemm_mode() & 1) && g->cin % 4 == 0 && g->ld_in % 4 == 0 && g->cout % 4 == 0;
+}
+bool gemm_dgrad_ok(const seedhip_conv_geom* g) { return (gemm_mode() & 2) && g->cout % 4 == 0 && g->ld_out % 4 == 0; }
+bool gemm_wgrad_ok(const seedhip_conv_geom* g) {
+  return (gemm_mode() & 4) && g->cin % 4 == 0 && g->ld_in % 4 == 0 && g->cout % 4 == 0 && g->ld_out % 4 == 0;
+}
+size_t gemm_partial_bytes(int M, int N, int K) {
+  const gemm::Plan pl = gemm::plan(M, N, K);
+  return pl.slices > 1 ? (size_t)pl.slices * M * N * sizeof(float) : 0;
+}
+
 bool is_dense(const seedhip_conv_geom* g) {
   return g->kh == 1 && g->kw == 1 && g->ih == 1 && g->iw == 1 && g->oh == 1 && g->ow == 1 && g->stride == 1 &&
          g->pad_t == 0 && g->pad_l == 0;
@@ -86,12 +103,16 @@ int check_geom(const seedhip_conv_geom* g, const char* what) {
 extern "C" size_t seedhip_conv2d_fwd_workspace_bytes(const seedhip_conv_geom* g) {
   if (!g || !is_dense(g)) return 0;
   const int sl = dense_slices(g->n_img, g->cout, g->cin);
-  return sl > 1 ? (size_t)sl * g->n_img * g->cout * sizeof(float) : 0;
+  const size_t core = sl > 1 ? (size_t)sl * g->n_img * g->cout * sizeof(float) : 0;
+  const size_t mm = gemm_fwd_ok(g) ? gemm_partial_bytes(g->n_img, g->cout, g->cin) : 0;
+  return mm > core ? mm : core;
 }
 extern "C" size_t seedhip_conv2d_bwd_data_workspace_bytes(const seedhip_conv_geom* g) {
   if (!g || !is_dense(g)) return 0;
   const int sl = dense_slices(g->n_img, g->cin, g->cout);
-  return sl > 1 ? (size_t)sl * g->n_img * g->cin * sizeof(float) : 0;
+  const size_t core = sl > 1 ? (size_t)sl * g->n_img * g->cin * sizeof(float) : 0;
+  const size_t mm = gemm_dgrad_ok(g) ? gemm_partial_bytes(g->n_img, g->cin, g->cout) : 0;
+  return mm > core ? mm : core;
 }
 
 extern "C" int seedhip_conv2d_fwd(const seedhip_conv_geom* geom, const void* in, int in_dtype, int in_relu,
@@ -126,6 +147,26 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
     }
   }
   if (is_dense(geom) && in_dtype == kInF32 && geom->cin % 4 == 0 && geom->ld_in % 4 == 0 && (((uintptr_t)in) & 15) == 0) {
+    if (gemm_fwd_ok(geom) && al16(w) && al16(out) && al16(workspace)) {
+      const int M = geom->n_img, N = geom->cout, K = geom->cin;
+      const gemm::Plan pl = gemm::plan(M, N, K);
+      if (pl.slices == 1 || (workspace && workspace_bytes >= (size_t)pl.slices * M * N * sizeof(float))) {
+        hipStream_t s = (hipStream_t)stream;
+        gemm::Params gp;
+        memset(&gp, 0, sizeof(gp));
+        gp.A = (const float*)in; gp.lda = geom->ld_in; gp.a_relu = in_relu; gp.B = w; gp.ldb = N;
+        gp.M = M; gp.N = N; gp.K = K; gp.k_per_slice = pl.k_per_slice; gp.C = out; gp.ldc = geom->ld_out;
+        gp.bias = bias; gp.residual = residual; gp.out_relu = out_relu;
+        if (pl.slices > 1) gp.partial = (float*)workspace;
+        gemm::launch<true, false>(gp, pl, s);
+        if (pl.slices > 1) {
+          int blocks = cdiv((long long)M * N, 256); if (blocks > 2048) blocks = 2048;
+          hipLaunchKernelGGL(dense_epilogue_kernel, dim3(blocks), dim3(256), 0, s, gp.partial, pl.slices, M, N, bias,
+                             residual, out_relu, (const float*)nullptr, (const float*)nullptr, out, geom->ld_out);
+        }
+        return check_launch("conv2d_fwd(dense, gemm)");
+      }
+    }
     DenseFwd d;
     d.in = (const float*)in; d.in_relu = in_relu; d.w = w; d.bias = bias; d.out = out; d.out_relu = out_relu;
     d.residual = residual;
@@ -197,6 +238,25 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
     }
   }
   if (is_dense(geom) && geom->cout % 4 == 0 && geom->ld_out % 4 == 0 && (((uintptr_t)dy | (uintptr_t)w) & 15) == 0) {
+    if (gemm_dgrad_ok(geom)) {
+      const int M = geom->n_img, N = geom->cin, K = geom->cout;
+      const gemm::Plan pl = gemm::plan(M, N, K);
+      if (pl.slices == 1 || (workspace && workspace_bytes >= (size_t)pl.slices * M * N * sizeof(float))) {
+        hipStream_t s = (hipStream_t)stream;
+        gemm::Params gp;
+        memset(&gp, 0, sizeof(gp));
+        gp.A = dy; gp.lda = geom->ld_out; gp.B = w; gp.ldb = K; gp.M = M; gp.N = N; gp.K = K;
+        gp.k_per_slice = pl.k_per_slice; gp.C = dx; gp.ldc = geom->ld_in; gp.mask = relu_mask; gp.add = add;
+        if (pl.slices > 1) gp.partial = (float*)workspace;
+        gemm::launch<true, true>(gp, pl, s);
+        if (pl.slices > 1) {
+          int blocks = cdiv((long long)M * N, 256); if (blocks > 2048) blocks = 2048;
+          hipLaunchKernelGGL(dense_epilogue_kernel, dim3(blocks), dim3(256), 0, s, gp.partial, pl.slices, M, N,
+                             (const float*)nullptr, (const float*)nullptr, 0, relu_mask, add, dx, geom->ld_in);
+        }
+        return check_launch("conv2d_bwd_data(dense, gemm)");
+      }
+    }
     DenseDgrad d;
     d.dy = dy; d.w = w; d.dx = dx; d.mask = relu_mask; d.add = add;
     d.init(to_geom(geom));
@@ -228,7 +288,13 @@ extern "C" size_t seedhip_conv2d_bwd_weight_workspace_bytes(const seedhip_conv_g
   const long long slices = (pixels + per - 1) / per;
   const size_t generic = (size_t)slices * ((size_t)M * N + N) * sizeof(float);
   const halo::WgradPlan pl = halo::plan_wgrad(g);
-  return (pl.ok && pl.ws_bytes > generic) ? pl.ws_bytes : generic;
+  size_t need = (pl.ok && pl.ws_bytes > generic) ? pl.ws_bytes : generic;
+  if (is_dense(g) && gemm_wgrad_ok(g)) {
+    const gemm::Plan gpl = gemm::plan(g->cin, g->cout, g->n_img);
+    const size_t mm = (size_t)gpl.slices * ((size_t)g->cin * g->cout + g->cout) * sizeof(float);
+    if (mm > need) need = mm;
+  }
+  return need;
 }
 
 extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const void* in, int in_dtype, int in_relu,
@@ -246,6 +312,25 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
       return halo::launch_wgrad(geom, pl, in, in_dtype, in_relu, dy, dw, dbias, workspace, (hipStream_t)stream);
   }
   if (is_dense(geom) && in_dtype == kInF32 && geom->cin % 4 == 0 && geom->ld_in % 4 == 0 && (((uintptr_t)in) & 15) == 0) {
+    if (gemm_wgrad_ok(geom) && al16(dy) && al16(workspace)) {
+      const int M = geom->cin, N = geom->cout, K = geom->n_img;
+      const gemm::Plan pl = gemm::plan(M, N, K);
+      hipStream_t s = (hipStream_t)stream;
+      gemm::Params gp;
+      memset(&gp, 0, sizeof(gp));
+      gp.A = (const float*)in; gp.lda = geom->ld_in; gp.a_relu = in_relu; gp.B = dy; gp.ldb = geom->ld_out;
+      gp.M = M; gp.N = N; gp.K = K; gp.k_per_slice = pl.k_per_slice;
+      float* pw = (float*)workspace;
+      float* pb = pw + (size_t)pl.slices * M * N;
+      gp.partial = pl.slices > 1 ? pw : dw;                      // one slice: the raw sums are the result
+      gp.partial_colsum = dbias ? (pl.slices > 1 ? pb : dbias) : nullptr;
+      gemm::launch<false, false>(gp, pl, s);
+      if (pl.slices > 1) {
+        reduce_slices(pw, pl.slices, (long long)M * N, dw, s);
+        if (dbias) reduce_slices(pb, pl.slices, N, dbias, s);
+      }
+      return check_launch("conv2d_bwd_weight(dense, gemm)");
+    }
     DenseWgrad d;
     d.in = (const float*)in; d.in_relu = in_relu; d.dy = dy;
     const int M = geom->cin, N = geom->cout;

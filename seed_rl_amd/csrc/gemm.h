@@ -1,0 +1,307 @@
+// fp32 GEMM on the matrix cores (v_mfma_f32_16x16x4_f32) for the Dense layers and the LSTM projections
+// (dmlab/networks.py:105-124,152-171, atari/networks.py:176-251):
+//     C[m, n] = epilogue( sum_k A(m, k) * B(k, n) )
+// Each operand is either "k-contiguous" (KC: element (x, k) at base[x*ld + k]) or "outer-contiguous"
+// (OC: element (x, k) at base[k*ld + x]).  The three Dense GEMMs in Keras layouts (kernel [in, out]) are
+//     forward        y  = x  W     : A = x  (KC),  B = W  (OC)
+//     data gradient  dx = dy W^T   : A = dy (KC),  B = W  (KC: W[in, out] read as B(k = out, n = in))
+//     weight gradient dW = x^T dy  : A = x  (OC),  B = dy (OC), k = the batch row
+// and in every case each operand moves 16 bytes at a time -- global -> registers -> LDS -> MFMA fragment -- with
+// no transposition anywhere:
+//   * KC operand: LDS rows [x][k] (stride 40 floats: conflict-free b128).  A lane reads 4 consecutive k of its row
+//     as one ds_read_b128 and feeds 4 MFMAs through the k-permutation (lane (x, kq) holds k = 4*kq + kk at step kk;
+//     any bijection of k works as long as A and B agree).
+//   * OC operand: LDS rows [k][x] exactly as in memory.  A lane reads 4 consecutive x of ONE k row as one b128 and
+//     these feed 4 different 16-wide tiles: tile e of a wave owns x = 4*lane_x + e (an x-interleaved tile assignment,
+//     undone in the epilogue).  For C this makes every lane own 4 consecutive n: 16-byte stores.
+// Either way 8 ds_read_b128 feed 64 MFMAs (0.125 LDS reads per MFMA against 0.75 in the generic implicit-GEMM
+// core); that matters because each ds_read costs the fp32 matrix pipe ~14 cycles (tools/probes/mfma_probe2.hip).
+// One LDS buffer + register prefetch of the next k-tile; BK = 32; split-K over blockIdx.z with a deterministic
+// second-pass reduction (fixed slice order).
+#pragma once
+#include "common.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+namespace seedhip {
+namespace gemm {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+struct Params {
+  const float* A; long long lda; int a_relu;
+  const float* B; long long ldb;
+  int M, N, K;
+  int k_per_slice;                          // split-K over blockIdx.z (multiple of BK)
+  float* partial;                           // [slices][M][N] raw sums, or null: fused epilogue below
+  float* partial_colsum;                    // [slices][N]: sum_k B(k, n) (bias gradient; OC B only), or null
+  float* C; long long ldc;
+  const float* bias; const float* residual; int out_relu;      // forward epilogue
+  const float* mask; const float* add;                         // data-gradient epilogue (indexed like C)
+};
+
+constexpr int BK = 32, LD_KC = BK + 8;
+
+// Staging of one operand tile [X rows/cols = BX][BK] through registers into LDS.
+template <int BX, bool KC>
+struct Stager {
+  static constexpr int kVecs = BX * BK / 4 / 256;
+  static constexpr int kLdsFloats = KC ? BX * LD_KC : BK * BX;
+  const float* base[kVecs];   // pointer at k = 0 of this thread's vector (null: out of range in x)
+  int lds_off[kVecs];
+  int krow[kVecs];            // k offset of the vector inside a tile
+  long long kstride;          // floats per unit k
+  float4 r[kVecs];
+
+  __device__ void init(const float* p, long long ld, int x0, int X, int tid) {
+#pragma unroll
+    for (int i = 0; i < kVecs; ++i) {
+      const int v = tid + i * 256;
+      if (KC) {
+        const int row = v >> 3, kc = (v & 7) * 4;
+        krow[i] = kc; lds_off[i] = row * LD_KC + kc;
+        base[i] = (x0 + row < X) ? p + (long long)(x0 + row) * ld + kc : nullptr;
+      } else {
+        const int kr = v / (BX / 4), x4 = (v % (BX / 4)) * 4;
+        krow[i] = kr; lds_off[i] = kr * BX + x4;
+        base[i] = (x0 + x4 < X) ? p + (long long)kr * ld + x0 + x4 : nullptr;     // X % 4 == 0: all in or all out
+      }
+    }
+    kstride = KC ? 1 : ld;
+  }
+  __device__ void load(int k, int k1, bool relu) {
+#pragma unroll
+    for (int i = 0; i < kVecs; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (base[i] && k + krow[i] < k1) {        // KC: K % 4 == 0 so the vector is entirely in or out
+        v = *reinterpret_cast<const float4*>(base[i] + (long long)k * kstride);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      }
+      r[i] = v;
+    }
+  }
+  __device__ void store(float* lds) const {
+#pragma unroll
+    for (int i = 0; i < kVecs; ++i) *reinterpret_cast<float4*>(lds + lds_off[i]) = r[i];
+  }
+};
+
+template <int R> struct FragVec;
+template <> struct FragVec<4> { typedef f32x4_t type; };
+template <> struct FragVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+
+template <int MR, int NR, bool AKC, bool BKC>          // 2 x 2 waves; tile (2*MR*16) x (2*NR*16); MR, NR in {2, 4}
+__global__ void __launch_bounds__(256)
+gemm_kernel(const Params p) {
+  constexpr int BM = 2 * MR * 16, BN = 2 * NR * 16;
+  typedef Stager<BM, AKC> SA;
+  typedef Stager<BN, BKC> SB;
+  __shared__ __attribute__((aligned(16))) float smem[SA::kLdsFloats + SB::kLdsFloats];
+  float* As = smem;
+  float* Bs = smem + SA::kLdsFloats;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lx = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int k0 = blockIdx.z * p.k_per_slice;
+  int k1 = k0 + p.k_per_slice; if (k1 > p.K) k1 = p.K;
+  const int nkt = (k1 - k0 + BK - 1) / BK;
+
+  SA sa; SB sb;
+  sa.init(p.A, p.lda, m0, p.M, tid);
+  sb.init(p.B, p.ldb, n0, p.N, tid);
+  const bool do_colsum = !BKC && p.partial_colsum && blockIdx.x == 0;
+  float4 csum[SB::kVecs];
+#pragma unroll
+  for (int i = 0; i < SB::kVecs; ++i) csum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  f32x4_t acc[MR][NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment base addresses: KC [x][k] rows of this lane's x, 4 consecutive k at 4*kq; OC [k][x] row 4*kq (+kk),
+  // R consecutive x at R*lx
+  const float* a_frag = AKC ? As + (wm * MR * 16 + lx) * LD_KC + 4 * kq : As + (4 * kq) * BM + wm * MR * 16 + MR * lx;
+  const float* b_frag = BKC ? Bs + (wn * NR * 16 + lx) * LD_KC + 4 * kq : Bs + (4 * kq) * BN + wn * NR * 16 + NR * lx;
+
+  if (nkt > 0) { sa.load(k0, k1, p.a_relu != 0); sb.load(k0, k1, false); }
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();                                       // previous tile consumed
+    sa.store(As); sb.store(Bs);
+    if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < SB::kVecs; ++i) { csum[i].x += sb.r[i].x; csum[i].y += sb.r[i].y; csum[i].z += sb.r[i].z; csum[i].w += sb.r[i].w; }
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) { sa.load(k0 + (kt + 1) * BK, k1, p.a_relu != 0); sb.load(k0 + (kt + 1) * BK, k1, false); }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                          // two 16-deep halves; lane (x, kq) holds k = 16h + 4kq + kk
+      f32x4_t a_kc[MR], b_kc[NR];
+      typename FragVec<MR>::type a_oc[4];
+      typename FragVec<NR>::type b_oc[4];
+      if (AKC) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i) a_kc[i] = *reinterpret_cast<const f32x4_t*>(a_frag + i * 16 * LD_KC + h * 16);
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a_oc[kk] = *reinterpret_cast<const typename FragVec<MR>::type*>(a_frag + (h * 16 + kk) * BM);
+      }
+      if (BKC) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) b_kc[j] = *reinterpret_cast<const f32x4_t*>(b_frag + j * 16 * LD_KC + h * 16);
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) b_oc[kk] = *reinterpret_cast<const typename FragVec<NR>::type*>(b_frag + (h * 16 + kk) * BN);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(AKC ? a_kc[i][kk] : a_oc[kk][i], BKC ? b_kc[j][kk] : b_oc[kk][j],
+                                                             acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // bias-gradient column sums of this slice: per-thread partials -> LDS [groups][BN] -> fixed-order sum
+  if (do_colsum) {
+    __syncthreads();
+    constexpr int kPerRow = BN / 4, kGroups = 256 / kPerRow;
+    static_assert(kGroups * BN <= SA::kLdsFloats + SB::kLdsFloats, "colsum scratch");
+    float4 t = csum[0];
+#pragma unroll
+    for (int i = 1; i < SB::kVecs; ++i) { t.x += csum[i].x; t.y += csum[i].y; t.z += csum[i].z; t.w += csum[i].w; }
+    *reinterpret_cast<float4*>(smem + (tid / kPerRow) * BN + (tid % kPerRow) * 4) = t;
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) s += smem[g * BN + tid];
+      p.partial_colsum[(long long)blockIdx.z * p.N + n0 + tid] = s;
+    }
+  }
+
+  // epilogue.  MFMA C layout: row 4*kq + r, column lx of each 16x16 tile; tile (i, j) of the wave covers
+  //   m = wm*MR*16 + (AKC ? 16*i + row : MR*row + i),   n = wn*NR*16 + (BKC ? 16*j + col : NR*col + j)
+#pragma unroll
+  for (int i = 0; i < MR; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * kq + r;
+      const int m = m0 + wm * MR * 16 + (AKC ? 16 * i + row : MR * row + i);
+      if (m >= p.M) continue;
+      float v[NR];
+#pragma unroll
+      for (int j = 0; j < NR; ++j) v[j] = acc[i][j][r];
+      if (BKC) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          const int n = n0 + wn * NR * 16 + 16 * j + lx;
+          if (n >= p.N) continue;
+          float o = v[j];
+          if (p.partial) { p.partial[((long long)blockIdx.z * p.M + m) * p.N + n] = o; continue; }
+          const long long at = (long long)m * p.ldc + n;
+          if (p.bias) o += p.bias[n];
+          if (p.residual) o += p.residual[at];
+          if (p.out_relu && o < 0.f) o = 0.f;
+          if (p.mask && !(p.mask[at] > 0.f)) o = 0.f;
+          if (p.add) o += p.add[at];
+          p.C[at] = o;
+        }
+      } else {
+        const int n = n0 + wn * NR * 16 + NR * lx;        // NR consecutive columns; N % 4 == 0
+        if (n >= p.N) continue;
+        typedef typename FragVec<NR>::type vec_t;
+        if (p.partial) {
+          vec_t o;
+#pragma unroll
+          for (int j = 0; j < NR; ++j) o[j] = v[j];
+          *reinterpret_cast<vec_t*>(p.partial + ((long long)blockIdx.z * p.M + m) * p.N + n) = o;
+          continue;
+        }
+        const long long at = (long long)m * p.ldc + n;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          if (n + j >= p.N) break;
+          float o = v[j];
+          if (p.bias) o += p.bias[n + j];
+          if (p.residual) o += p.residual[at + j];
+          if (p.out_relu && o < 0.f) o = 0.f;
+          if (p.mask && !(p.mask[at + j] > 0.f)) o = 0.f;
+          if (p.add) o += p.add[at + j];
+          v[j] = o;
+        }
+        if ((p.ldc & 3) == 0 && n + NR <= p.N) {
+          vec_t o;
+#pragma unroll
+          for (int j = 0; j < NR; ++j) o[j] = v[j];
+          *reinterpret_cast<vec_t*>(p.C + at) = o;
+        } else {
+#pragma unroll
+          for (int j = 0; j < NR; ++j) if (n + j < p.N) p.C[at + j] = v[j];
+        }
+      }
+    }
+  }
+}
+
+// Tile shape and split-K from a small cost model calibrated on MI355X (tools/bench_kernels.py gemm):
+//   * a workgroup costs (k-tiles + ovh) units of MR*NR work; ovh = prologue + epilogue in k-tile units
+//     (64x64: 2.7, 128x64: 4.7, 128x128: 7) -- short K wants small tiles, long K the 128x128 tile;
+//   * a CU saturates the matrix pipe with `sat` resident workgroups (4 / 2.5 / 2) and holds at most `occ` (5 / 3 / 2);
+//     fewer resident workgroups each run at 1/sat of the CU rate; the busiest CU sets the time;
+//   * split-K adds the reduce pass: (slices + 1) * M * N floats through HBM + one launch.
+struct Plan { int mr, nr, slices, k_per_slice; double model_us; };
+inline Plan plan(int M, int N, int K) {
+  struct Tile { int mr, nr, occ; double sat, ovh; };
+  static const Tile kTiles[3] = {{2, 2, 5, 4.0, 2.7}, {4, 2, 3, 2.5, 4.7}, {4, 4, 2, 2.0, 7.0}};
+  static const int kSlices[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128};
+  static const int force = getenv("SEEDHIP_GEMM_TILE") ? atoi(getenv("SEEDHIP_GEMM_TILE")) : 0;
+  static const int force_s = getenv("SEEDHIP_GEMM_SLICES") ? atoi(getenv("SEEDHIP_GEMM_SLICES")) : 0;
+  Plan best{2, 2, 1, (K + BK - 1) / BK * BK, 1e30};
+  for (const Tile& t : kTiles) {
+    if (force && force != t.mr * 10 + t.nr) continue;
+    const long long tiles = (long long)((M + 32 * t.mr - 1) / (32 * t.mr)) * ((N + 32 * t.nr - 1) / (32 * t.nr));
+    for (int s : kSlices) {
+      if (force_s) { if (s != force_s) continue; }
+      else if (s > 1 && K / s < 4 * BK) break;
+      int per = (K + s - 1) / s; per = (per + BK - 1) / BK * BK;
+      const int slices = (K + per - 1) / per;
+      const double wg_units = (per / BK + t.ovh) * t.mr * t.nr;              // work of one workgroup
+      const double wpc = (double)tiles * slices / 256.0;                     // workgroups per CU
+      const double full = floor(wpc / t.occ), rem = ceil(wpc - full * t.occ - 1e-9);
+      const double serial = full * t.occ + (rem > 0 ? (rem > t.sat ? rem : t.sat) : 0.0);   // workgroup-times, busiest CU
+      // one unit = 32x32x32 MACs; a saturated CU retires 128 MAC/cycle (4 SIMDs x 1024 MACs / 32 cycles) at 2.4 GHz,
+      // of which this kernel sustains ~80%
+      const double unit_us = 32.0 * 32 * 32 / 128.0 / 2400.0 / 0.80;
+      double us = serial * wg_units * unit_us;
+      if (slices > 1) us += 4.0 + (slices + 1.0) * M * N * 4.0 / 3.0e6;
+      if (us < best.model_us) best = Plan{t.mr, t.nr, slices, per, us};
+    }
+  }
+  if (getenv("SEEDHIP_GEMM_DEBUG")) {
+    static long long last = -1;
+    const long long key = ((long long)M << 40) ^ ((long long)N << 20) ^ K;
+    if (key != last) {
+      last = key;
+      fprintf(stderr, "[gemm] M=%d N=%d K=%d -> tile %dx%d slices %d (model %.1f us)\n", M, N, K, 32 * best.mr,
+              32 * best.nr, best.slices, best.model_us);
+    }
+  }
+  return best;
+}
+
+template <bool AKC, bool BKC>
+inline void launch(const Params& p, const Plan& pl, hipStream_t s) {
+  const int bm = 32 * pl.mr, bn = 32 * pl.nr;
+  dim3 grid((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, pl.slices);
+  if (pl.mr == 4 && pl.nr == 4) hipLaunchKernelGGL((gemm_kernel<4, 4, AKC, BKC>), grid, dim3(256), 0, s, p);
+  else if (pl.mr == 4 && pl.nr == 2) hipLaunchKernelGGL((gemm_kernel<4, 2, AKC, BKC>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemm_kernel<2, 2, AKC, BKC>), grid, dim3(256), 0, s, p);
+}
+
+}  // namespace gemm
+}  // namespace seedhip

@@ -305,6 +305,11 @@ CONV_CASES = [
     (256, 1, 1, 512, 1, 1, 1, 'valid', 2048), # LSTM(512) recurrent step GEMM: split-K
     (3, 11, 13, 8, 3, 3, 2, 'valid', 16),     # stride-2 data gradient: parity classes with different tap counts
     (2, 12, 10, 16, 4, 3, 2, 'valid', 32),    # 4x3 kernel, stride 2
+    (2100, 1, 1, 268, 1, 1, 1, 'valid', 1024),# gemm.h: K % 32 != 0, ragged last row tile, 128-wide tiles
+    (2500, 1, 1, 256, 1, 1, 1, 'valid', 20),  # gemm.h: N = 20 < tile, split-K
+    (2060, 1, 1, 2592, 1, 1, 1, 'valid', 256),# gemm.h at the shallow FC shape
+    (300, 1, 1, 256, 1, 1, 1, 'valid', 18),   # cout % 4 != 0: Dense accessors of the implicit-GEMM core
+    (37, 1, 1, 36, 1, 1, 1, 'valid', 44),     # everything ragged
 ]
 
 

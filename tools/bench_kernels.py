@@ -82,6 +82,13 @@ def main():
   if a.what in ('fc', 'all'):
     bench_conv('fc 2592->256', N, 1, 1, 2592, 1, 1, 'valid', 256)
     bench_conv('heads 256->20', N, 1, 1, 256, 1, 1, 'valid', 20)
+  if a.what in ('gemm',):
+    for nm, n, k, c in [('atari fc 2592->256', 21 * 512, 2592, 256), ('atari heads 256->20', 21 * 512, 256, 20),
+                        ('deep fc 3456->256', 21 * 256, 3456, 256), ('deep lstm-x 256->1024', 21 * 256, 256, 1024),
+                        ('r2d2 fc 3136->512', 121 * 256, 3136, 512), ('r2d2 lstm-x 512->2048', 121 * 256, 512, 2048),
+                        ('r2d2 recurrent 512->2048', 256, 512, 2048), ('deep recurrent 256->1024', 256, 256, 1024),
+                        ('inference fc 2592->256', 64, 2592, 256)]:
+      bench_conv(nm, n, 1, 1, k, 1, 1, 'valid', c)
   if a.what in ('deep',):
     n = 21 * 256
     bench_conv('deep s0 3x3 16->16 @36x48', n, 36, 48, 16, 3, 1, 'same', 16)
