@@ -15,6 +15,7 @@
 #include "halo_wgrad.h"
 #include "halo_fwd.h"
 #include "gemm.h"
+#include "wsgemm.h"
 #include "../../include/seedhip.h"
 
 using namespace seedhip;
@@ -64,9 +65,9 @@ int dense_slices(int M, int N, int K) {
 }
 int slice_k(int K, int slices) { int per = (K + slices - 1) / slices; return (per + 15) / 16 * 16; }
 
-// Dense layers on gemm.h (see there).  mode bits (SEEDHIP_GEMM, default 7): 1 forward, 2 data gradient, 4 weight
-// gradient; a cleared bit falls back to the Dense accessors of the implicit-GEMM core (A/B measurements).
-int gemm_mode() { static int m = getenv("SEEDHIP_GEMM") ? atoi(getenv("SEEDHIP_GEMM")) : 7; return m; }
+// Dense layers on gemm.h (see there).  mode bits (SEEDHIP_GEMM, default 31): 1 forward, 2 data gradient, 4 weight
+// gradient (8 / 16: wsgemm.h conv forward / data gradient); a cleared bit falls back to the Dense accessors of the implicit-GEMM core (A/B measurements).
+int gemm_mode() { static int m = getenv("SEEDHIP_GEMM") ? atoi(getenv("SEEDHIP_GEMM")) : 31; return m; }
 bool al16(const void* q) { return (((uintptr_t)q) & 15) == 0; }
 bool gemm_fwd_ok(const seedhip_conv_geom* g) {
   return (gemm_mode() & 1) && g->cin % 4 == 0 && g->ld_in % 4 == 0 && g->cout % 4 == 0;
@@ -127,6 +128,16 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
   int rc = check_geom(geom, "conv2d_fwd"); if (rc) return rc;
   SEEDHIP_REQUIRE(in && w && out, "conv2d_fwd: null pointer");
   SEEDHIP_REQUIRE(in_dtype == kInF32 || in_dtype == kInU8Div255, "conv2d_fwd: bad in_dtype %d", in_dtype);
+  if ((gemm_mode() & 8) && in_dtype == kInF32 && al16(in) && al16(w) && al16(out) && al16(bias) && al16(residual)) {
+    // whole kernel resident in LDS, A rows gathered as 128-byte segments (wsgemm.h): the second Atari conv
+    wsgemm::Params wp;
+    wsgemm::Plan pl = wsgemm::plan_fwd(wp, geom);
+    if (pl.ok) {
+      wp.A = (const float*)in; wp.a_relu = in_relu; wp.W = w; wp.C = out; wp.bias = bias; wp.out_relu = out_relu;
+      wp.residual = residual;
+      return wsgemm::launch(wp, pl, (hipStream_t)stream);
+    }
+  }
   {
     // small-kernel layers: input band staged once in LDS (halo_fwd.h).  Measured on MI355X
     // (tools/bench_kernels.py): the halo forward wins for stride-1 layers with few input channels / small maps;
@@ -203,6 +214,15 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
                                           size_t workspace_bytes, void* stream) {
   int rc = check_geom(geom, "conv2d_bwd_data"); if (rc) return rc;
   SEEDHIP_REQUIRE(dy && w && dx, "conv2d_bwd_data: null pointer");
+  if ((gemm_mode() & 16) && al16(dy) && al16(w) && al16(dx) && al16(relu_mask) && al16(add)) {
+    // all stride-parity classes as ONE weight-stationary GEMM over super-pixels (wsgemm.h)
+    wsgemm::Params wp;
+    wsgemm::Plan pl = wsgemm::plan_dgrad(wp, geom);
+    if (pl.ok) {
+      wp.A = dy; wp.W = w; wp.C = dx; wp.mask = relu_mask; wp.add = add;
+      return wsgemm::launch(wp, pl, (hipStream_t)stream);
+    }
+  }
   {
     // Data gradient as stride-1 halo convolutions of dY, one per stride-parity class of the input pixel, all in
     // ONE launch sharing the dY tile (halo_fwd.h): dX[q*s + py - pad] = sum_j dY[q - j] W[py + s*j].

@@ -1,0 +1,322 @@
+// Weight-stationary gather-GEMM for small strided 'valid' convolutions whose whole kernel fits LDS -- the second
+// Atari conv, Conv2D(32, 4, 2) on the 20x20x16 output of the first (/root/reference/atari/networks.py:236), forward
+// and data gradient.
+//
+//   C[m, n] = sum_k A(m, k) * W'(k, n)        rows m = flat (image, grid-y, grid-x), persistent workgroups over m-tiles
+//
+//   forward        m = output pixel (oy, ox);  k = (ky, kx, ci): each ky contributes kw*cin CONTIGUOUS floats of the
+//                  NHWC input row, so a 32-deep k-tile is one 128-byte segment per row;  n = co;  W' = W as stored.
+//   data gradient  m = "super-pixel" (a, b) = the s x s block of input pixels (s*a+py, s*b+px);  n = (py, px, ci);
+//                  k = (jy, jx, co):  dX[s*a+py, s*b+px, ci] = sum dY[a-jy, b-jx, co] * W[py+s*jy, px+s*jx, ci, co]
+//                  -- ONE GEMM for all stride-parity classes, A rows are again contiguous 128-byte segments of dY
+//                  (zero-filled where a-jy / b-jx leave the map), no structural zeros multiplied.
+// W' [K][N] (<= 40 KB) is written to LDS once per workgroup and stays; only A streams: global -> registers (float4)
+// -> LDS [row][k] (stride 40 floats) -> ds_read_b128 fragments through the k-permutation of gemm.h, while the W'
+// fragments are x-interleaved reads (lane owns NR consecutive n), so the epilogue stores 8/16 bytes per lane.
+// Waves are autonomous after the W' load (each covers all N columns of its own rows): no workgroup barriers in
+// the loop, and the register prefetch (two k-tiles deep) runs across m-tile boundaries.
+// Measured on MI355X (T=20, B=512: 10752 images): forward 0.19 ms (implicit-GEMM core: 0.234), data gradient
+// 0.24 ms (stride-parity halo kernel: 0.377).  Both are within ~2x of their HBM time (386 MB / 661 MB of compulsory
+// traffic: input, output, ReLU mask), so what matters is overlapping many waves' load / MFMA / store phases; a
+// variant holding W' in 128 VGPRs with A fragments loaded straight from global (no LDS at all) was slower at its
+// 2 waves per SIMD.
+#pragma once
+#include "common.h"
+#include "igemm.h"
+#include "../../include/seedhip.h"
+#include <cstdlib>
+
+namespace seedhip {
+namespace wsgemm {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <int R> struct Vec;
+template <> struct Vec<4> { typedef f32x4_t type; };
+template <> struct Vec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+
+constexpr int BK = 32, LDA = BK + 8, kMaxTiles = 16;
+
+struct Params {
+  int mode;                                   // 0 forward, 1 data gradient
+  const float* A; int a_relu;                 // forward: layer input; data gradient: dY
+  const float* W;                             // Keras kernel [kh, kw, cin, cout]
+  int kh, kw, cin, cout, s;
+  int M, N, K, nkt;                           // GEMM extents; nkt = K / 32
+  int gh, gw;                                 // grid of m per image (output pixels | super-pixels)
+  FastDiv d_g, d_gw;                          // m -> (img, rem) -> (a, b)
+  unsigned a_img_stride, a_row_stride, a_col_stride;   // floats: row base = img*.. + a*.. + b*..
+  int tile_off[kMaxTiles];                    // floats added to the row base for k-tile t (may be negative)
+  int tile_dy[kMaxTiles], tile_dx[kMaxTiles]; // k-tile t of row (a, b) is valid iff 0 <= a+dy < vh && 0 <= b+dx < vw
+  int vh, vw;
+  // forward epilogue: out[m*ldc + n] = act(acc + bias[n])
+  float* C; int ldc; const float* bias; int out_relu; const float* residual;
+  // data-gradient epilogue: dx[img, s*a+py, s*b+px, ci] = mask(acc) + add
+  int ih, iw, ld_in; const float* mask; const float* add;
+  int ntiles;
+};
+
+// LDS traffic of one wave is ordered; this only stops the compiler from moving LDS accesses across the point.
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int MR, int NR, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
+ws_kernel(const Params p) {
+  constexpr int N = 16 * NR, LDB = (NR == 2) ? N + 8 : N;     // b64 fragment rows 4 apart: +32 banks
+  constexpr int kThreads = 64 * WAVES;
+  constexpr int VA = 2 * MR;                  // float4 per lane per k-tile of the wave's 16*MR rows
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Bs = smem;                           // [K][LDB]
+  float* As = smem + p.K * LDB;               // [BM][LDA]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lx = lane & 15, kq = lane >> 4;
+
+  // ---- W' -> LDS, once ----
+  if (p.mode == 0) {
+    for (int idx = tid; idx < p.K * N / 4; idx += kThreads) {
+      const int e = idx * 4, k = e / N, n = e - k * N;
+      *reinterpret_cast<float4*>(Bs + k * LDB + n) = *reinterpret_cast<const float4*>(p.W + e);
+    }
+  } else {
+    const int jw = p.kw / p.s;
+    for (int idx = tid; idx < p.K * N; idx += kThreads) {       // idx = k*N + n: conflict-free LDS writes
+      const int k = idx / N, n = idx - k * N;
+      const int co = k % p.cout, tap = k / p.cout, jy = tap / jw, jx = tap - jy * jw;
+      const int ci = n % p.cin, cls = n / p.cin, py = cls / p.s, px = cls - py * p.s;
+      Bs[k * LDB + n] = p.W[(((py + p.s * jy) * p.kw + px + p.s * jx) * p.cin + ci) * p.cout + co];
+    }
+  }
+
+  __syncthreads();                              // the only workgroup barrier: W' visible to all four waves
+
+  // ---- wave-autonomous from here: every wave covers all N columns, so the A rows of its 16*MR-row tile are
+  // private to it.  Each wave stages its own rows into its own LDS region (in-order LDS per wave: a compiler
+  // fence is all the synchronisation needed) and walks its own sequence of m-tiles; the four waves drift apart
+  // and fill each other's load / epilogue phases on the matrix pipe.
+  // vector i of this lane = row (lane >> 3) + 8 i of the wave tile, floats kc .. kc+3 of the k-tile
+  float* Aw = As + wave * (MR * 16 * LDA);
+  const int kc = (lane & 7) * 4;
+  unsigned rowbase[VA], vmask[VA];
+  float4 r0[VA], r1[VA];                       // two register stages: k-tiles q+1 and q+2 of this wave's sequence
+  auto setup_tile = [&](int wt) {
+#pragma unroll
+    for (int i = 0; i < VA; ++i) {
+      const int m = wt * (MR * 16) + (lane >> 3) + 8 * i;
+      unsigned mask = 0, base = 0;
+      if (m < p.M) {
+        uint32_t img, rem, a, b;
+        p.d_g.divmod((uint32_t)m, img, rem);
+        p.d_gw.divmod(rem, a, b);
+        base = img * p.a_img_stride + a * p.a_row_stride + b * p.a_col_stride + kc;
+        if (p.mode == 0) mask = 0xffffffffu;                  // forward: every tap of a 'valid' conv is inside
+        else for (int t = 0; t < p.nkt; ++t) {
+          const int y = (int)a + p.tile_dy[t], x = (int)b + p.tile_dx[t];
+          if (y >= 0 && y < p.vh && x >= 0 && x < p.vw) mask |= 1u << t;
+        }
+      }
+      rowbase[i] = base; vmask[i] = mask;
+    }
+  };
+  const int wstride = gridDim.x * WAVES;
+  int ltile = blockIdx.x * WAVES + wave, lkt = 0;            // load cursor: runs two k-tiles ahead, across m-tiles
+  auto advance_load = [&](float4 (&r)[VA]) {
+    if (ltile >= p.ntiles) return;
+    if (lkt == 0) setup_tile(ltile);
+    const int off = p.tile_off[lkt];
+#pragma unroll
+    for (int i = 0; i < VA; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((vmask[i] >> lkt) & 1u) {
+        v = *reinterpret_cast<const float4*>(p.A + (long long)rowbase[i] + off);
+        if (p.a_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      }
+      r[i] = v;
+    }
+    if (++lkt == p.nkt) { lkt = 0; ltile += wstride; }
+  };
+
+  const float* a_frag = Aw + lx * LDA + 4 * kq;
+  const float* b_frag = Bs + (4 * kq) * LDB + NR * lx;
+  typedef typename Vec<NR>::type bvec_t;
+
+  advance_load(r0);
+  advance_load(r1);
+  for (int tile = blockIdx.x * WAVES + wave; tile < p.ntiles; tile += wstride) {
+    f32x4_t acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // data gradient: output offsets of this lane's MR x 4 rows, and the ReLU-mask values, fetched now so that their
+    // latency hides under the tile's MFMAs instead of stalling the epilogue
+    const int n = NR * lx;
+    unsigned out_at[MR][4];
+    bvec_t mpre[MR][4];
+    if (p.mode == 1) {
+      const int cls = n / p.cin, ci = n - cls * p.cin, py = cls / p.s, px = cls - py * p.s;
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = tile * (MR * 16) + 16 * i + 4 * kq + r;
+          unsigned at = 0xffffffffu;
+          bvec_t mv;
+#pragma unroll
+          for (int j = 0; j < NR; ++j) mv[j] = 1.f;
+          if (m < p.M) {
+            uint32_t img, rem, a, b;
+            p.d_g.divmod((uint32_t)m, img, rem);
+            p.d_gw.divmod(rem, a, b);
+            const int oy = (int)a * p.s + py, ox = (int)b * p.s + px;
+            if (oy < p.ih && ox < p.iw) {
+              at = ((img * p.ih + oy) * p.iw + ox) * p.ld_in + ci;
+              if (p.mask) mv = *reinterpret_cast<const bvec_t*>(p.mask + at);
+            }
+          }
+          out_at[i][r] = at; mpre[i][r] = mv;
+        }
+      }
+    }
+
+    auto step = [&](int kt, float4 (&r)[VA]) {
+      wave_fence();                                         // fragment reads of the previous k-tile are issued
+#pragma unroll
+      for (int i = 0; i < VA; ++i) *reinterpret_cast<float4*>(Aw + ((lane >> 3) + 8 * i) * LDA + kc) = r[i];
+      wave_fence();
+      advance_load(r);                                      // the k-tile two steps ahead, into the set just drained
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4_t a_kc[MR];
+        bvec_t b_oc[4];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) a_kc[i] = *reinterpret_cast<const f32x4_t*>(a_frag + i * 16 * LDA + h * 16);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) b_oc[kk] = *reinterpret_cast<const bvec_t*>(b_frag + (kt * BK + h * 16 + kk) * LDB);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_kc[i][kk], b_oc[kk][j], acc[i][j], 0, 0, 0);
+      }
+    };
+    for (int kt = 0; kt < p.nkt; kt += 2) {                 // nkt is even (plan): register sets alternate statically
+      step(kt, r0);
+      step(kt + 1, r1);
+    }
+
+    // ---- epilogue: lane holds columns n = NR*lx .. +NR-1 of rows 16 i + 4 kq + r ----
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bvec_t v;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) v[j] = acc[i][j][r];
+        if (p.mode == 0) {
+          const int m = tile * (MR * 16) + 16 * i + 4 * kq + r;
+          if (m >= p.M) continue;
+          const long long at = (long long)m * p.ldc + n;
+          if (p.bias) { const bvec_t bv = *reinterpret_cast<const bvec_t*>(p.bias + n); v += bv; }
+          if (p.residual) { const bvec_t rv = *reinterpret_cast<const bvec_t*>(p.residual + at); v += rv; }
+          if (p.out_relu) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          *reinterpret_cast<bvec_t*>(p.C + at) = v;
+        } else {
+          const unsigned at = out_at[i][r];
+          if (at == 0xffffffffu) continue;
+#pragma unroll
+          for (int j = 0; j < NR; ++j) if (!(mpre[i][r][j] > 0.f)) v[j] = 0.f;
+          if (p.add) { const bvec_t av = *reinterpret_cast<const bvec_t*>(p.add + at); v += av; }
+          *reinterpret_cast<bvec_t*>(p.C + at) = v;
+        }
+      }
+    }
+  }
+}
+
+struct Plan { bool ok; int mr, nr, grid; size_t lds; };
+
+// Fills the geometry for the forward of a 'valid' conv; ok = false when the shape is outside this kernel's range.
+inline Plan plan_fwd(Params& p, const seedhip_conv_geom* g) {
+  Plan pl; memset(&pl, 0, sizeof(pl));
+  const int seg = g->kw * g->cin;
+  if (g->pad_t || g->pad_l || g->ld_in != g->cin || seg % BK || (g->cout != 32 && g->cout != 64) || g->ld_out % 4) return pl;
+  const int K = g->kh * seg, N = g->cout, tiles_per_row = seg / BK;
+  if (K / BK > kMaxTiles || (K / BK) % 2 || (long long)K * (N == 32 ? N + 8 : N) * 4 > 40 * 1024) return pl;
+  if ((long long)g->n_img * g->ih * g->iw * g->ld_in >= (1LL << 31)) return pl;
+  memset(&p, 0, sizeof(p));
+  p.mode = 0; p.kh = g->kh; p.kw = g->kw; p.cin = g->cin; p.cout = g->cout; p.s = g->stride;
+  p.M = g->n_img * g->oh * g->ow; p.N = N; p.K = K; p.nkt = K / BK;
+  p.gh = g->oh; p.gw = g->ow; p.d_g.init(g->oh * g->ow); p.d_gw.init(g->ow);
+  p.a_img_stride = (unsigned)(g->ih * g->iw * g->ld_in); p.a_row_stride = (unsigned)(g->stride * g->iw * g->ld_in);
+  p.a_col_stride = (unsigned)(g->stride * g->ld_in);
+  for (int t = 0; t < p.nkt; ++t) {
+    p.tile_off[t] = (t / tiles_per_row) * g->iw * g->ld_in + (t % tiles_per_row) * BK;
+    p.tile_dy[t] = 0; p.tile_dx[t] = 0;
+  }
+  p.vh = g->oh; p.vw = g->ow;
+  p.ldc = g->ld_out;
+  pl.nr = N / 16; pl.ok = true;
+  return pl;
+}
+
+// Data gradient of a 'valid' conv whose kernel extents are multiples of the stride.
+inline Plan plan_dgrad(Params& p, const seedhip_conv_geom* g) {
+  Plan pl; memset(&pl, 0, sizeof(pl));
+  const int s = g->stride;
+  if (g->pad_t || g->pad_l || g->kh % s || g->kw % s || g->cout % BK || g->cin % 4 || g->ld_in % 4 || g->ld_out % 4) return pl;
+  const int N = s * s * g->cin, jh = g->kh / s, jw = g->kw / s, K = jh * jw * g->cout, per_tap = g->cout / BK;
+  if ((N != 32 && N != 64) || K / BK > kMaxTiles || (K / BK) % 2 || (long long)K * (N == 32 ? N + 8 : N) * 4 > 40 * 1024) return pl;
+  if ((long long)g->n_img * g->oh * g->ow * g->ld_out >= (1LL << 31)) return pl;
+  if ((long long)g->n_img * g->ih * g->iw * g->ld_in >= (1LL << 32) - 1) return pl;     // dX offsets are 32-bit
+  memset(&p, 0, sizeof(p));
+  p.mode = 1; p.kh = g->kh; p.kw = g->kw; p.cin = g->cin; p.cout = g->cout; p.s = s;
+  p.gh = (g->ih + s - 1) / s; p.gw = (g->iw + s - 1) / s;
+  p.M = g->n_img * p.gh * p.gw; p.N = N; p.K = K; p.nkt = K / BK;
+  p.d_g.init(p.gh * p.gw); p.d_gw.init(p.gw);
+  p.a_img_stride = (unsigned)(g->oh * g->ow * g->ld_out); p.a_row_stride = (unsigned)(g->ow * g->ld_out);
+  p.a_col_stride = (unsigned)g->ld_out;
+  for (int t = 0; t < p.nkt; ++t) {
+    const int tap = t / per_tap, jy = tap / jw, jx = tap % jw;
+    p.tile_off[t] = -(jy * g->ow + jx) * g->ld_out + (t % per_tap) * BK;
+    p.tile_dy[t] = -jy; p.tile_dx[t] = -jx;
+  }
+  p.vh = g->oh; p.vw = g->ow;
+  p.ih = g->ih; p.iw = g->iw; p.ld_in = g->ld_in;
+  pl.nr = N / 16; pl.ok = true;
+  return pl;
+}
+
+inline int launch(Params& p, Plan& pl, hipStream_t s) {
+  static const int force_mr = getenv("SEEDHIP_WS_MR") ? atoi(getenv("SEEDHIP_WS_MR")) : 0;
+  static const int force_w = getenv("SEEDHIP_WS_WAVES") ? atoi(getenv("SEEDHIP_WS_WAVES")) : 0;
+  pl.mr = force_mr ? force_mr : 1;                           // measured (cfg2 step): 16-row wave tiles, 8 waves per workgroup
+  const int waves = force_w ? force_w : 8;
+  const int ldb = pl.nr == 2 ? p.N + 8 : p.N;
+  pl.lds = ((size_t)p.K * ldb + (size_t)waves * 16 * pl.mr * LDA) * sizeof(float);
+  p.ntiles = (p.M + 16 * pl.mr - 1) / (16 * pl.mr);          // wave tiles
+  int per_cu = (int)((160 * 1024) / (pl.lds + 512)); if (per_cu > 32 / waves) per_cu = 32 / waves; if (per_cu < 1) per_cu = 1;
+  const int wgs = (p.ntiles + waves - 1) / waves;
+  pl.grid = wgs < 256 * per_cu ? wgs : 256 * per_cu;
+#define SEEDHIP_WS(MR_, NR_, W_)                                                                                  \
+  if (pl.mr == MR_ && pl.nr == NR_ && waves == W_) {                                                              \
+    if (pl.lds > 64 * 1024)                                                                                       \
+      (void)hipFuncSetAttribute((const void*)ws_kernel<MR_, NR_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds); \
+    hipLaunchKernelGGL((ws_kernel<MR_, NR_, W_>), dim3(pl.grid), dim3(64 * W_), pl.lds, s, p);                    \
+    return check_launch("ws_kernel");                                                                             \
+  }
+  SEEDHIP_WS(2, 2, 8) SEEDHIP_WS(2, 4, 8) SEEDHIP_WS(1, 2, 8) SEEDHIP_WS(1, 4, 8) SEEDHIP_WS(2, 2, 4) SEEDHIP_WS(2, 4, 4)
+  SEEDHIP_WS(2, 2, 16) SEEDHIP_WS(2, 4, 16) SEEDHIP_WS(4, 2, 8) SEEDHIP_WS(4, 4, 8) SEEDHIP_WS(1, 2, 16) SEEDHIP_WS(1, 4, 16)
+#undef SEEDHIP_WS
+  return fail(SEEDHIP_ERR_UNSUPPORTED, "wsgemm: no kernel for MR=%d NR=%d waves=%d", pl.mr, pl.nr, waves);
+}
+
+}  // namespace wsgemm
+}  // namespace seedhip

@@ -310,6 +310,7 @@ CONV_CASES = [
     (2060, 1, 1, 2592, 1, 1, 1, 'valid', 256),# gemm.h at the shallow FC shape
     (300, 1, 1, 256, 1, 1, 1, 'valid', 18),   # cout % 4 != 0: Dense accessors of the implicit-GEMM core
     (37, 1, 1, 36, 1, 1, 1, 'valid', 44),     # everything ragged
+    (1500, 20, 20, 16, 4, 4, 2, 'valid', 32), # wsgemm.h: persistent workgroups walk several m-tiles
 ]
 
 
