@@ -13,6 +13,7 @@ with num_action_repeats=1 (common/common_flags.py:43; learner.py:236-237).
       --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -238,12 +239,13 @@ def main():
                     algorithmic_bytes=nbytes)
 
   # HBM traffic of the dominant kernel from the committed PMC passes (same config only)
-  tpath = os.path.join(ROOT, 'profiles', 'r01c_cfg2_traffic.json')
-  if args.config == 'atari' and args.torso == 'shallow' and B == 512 and T == 20 and A == 18 and os.path.exists(tpath):
+  tfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_cfg2_traffic.json')))      # latest profiling round
+  tpath = tfiles[-1] if tfiles else ''
+  if args.config == 'atari' and args.torso == 'shallow' and B == 512 and T == 20 and A == 18 and tpath:
     tb = json.load(open(tpath))['traffic_bytes']
     if dominant in tb:
       roofline['traffic'] = tb[dominant]
-      roofline['traffic_source'] = 'profiles/r01c_cfg2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'
+      roofline['traffic_source'] = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)' % os.path.basename(tpath)
   if rank != 0:
     if distributed:
       torch.distributed.destroy_process_group()

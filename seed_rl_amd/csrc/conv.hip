@@ -65,16 +65,18 @@ int dense_slices(int M, int N, int K) {
 }
 int slice_k(int K, int slices) { int per = (K + slices - 1) / slices; return (per + 15) / 16 * 16; }
 
-// Dense layers on gemm.h (see there).  mode bits (SEEDHIP_GEMM, default 31): 1 forward, 2 data gradient, 4 weight
-// gradient (8 / 16: wsgemm.h conv forward / data gradient); a cleared bit falls back to the Dense accessors of the implicit-GEMM core (A/B measurements).
-int gemm_mode() { static int m = getenv("SEEDHIP_GEMM") ? atoi(getenv("SEEDHIP_GEMM")) : 31; return m; }
+// Dense layers on gemm.h (see there).  mode bits (SEEDHIP_GEMM, default 127): 1 forward, 2 data gradient, 4 weight
+// gradient (8 / 16: wsgemm.h conv forward / data gradient; 32 / 64: gather-GEMM conv forward / data gradient); a cleared bit falls back to the Dense accessors of the implicit-GEMM core (A/B measurements).
+int gemm_mode() { static int m = getenv("SEEDHIP_GEMM") ? atoi(getenv("SEEDHIP_GEMM")) : 127; return m; }
 bool al16(const void* q) { return (((uintptr_t)q) & 15) == 0; }
 bool gemm_fwd_ok(const seedhip_conv_geom* g) {
-  return (gemm_mode() & 1) && g->cin % 4 == 0 && g->ld_in % 4 == 0 && g->cout % 4 == 0;
+  // rows may carry up to 3 pad columns (ld_in >= cin rounded up to 4; pads finite): the last k-vector of a row is
+  // read whole and meets zero-filled B rows
+  return (gemm_mode() & 1) && g->ld_in % 4 == 0 && g->ld_in >= (g->cin + 3) / 4 * 4 && g->cout % 4 == 0;
 }
 bool gemm_dgrad_ok(const seedhip_conv_geom* g) { return (gemm_mode() & 2) && g->cout % 4 == 0 && g->ld_out % 4 == 0; }
 bool gemm_wgrad_ok(const seedhip_conv_geom* g) {
-  return (gemm_mode() & 4) && g->cin % 4 == 0 && g->ld_in % 4 == 0 && g->cout % 4 == 0 && g->ld_out % 4 == 0;
+  return (gemm_mode() & 4) && g->ld_in % 4 == 0 && g->ld_in >= (g->cin + 3) / 4 * 4 && g->cout % 4 == 0 && g->ld_out % 4 == 0;
 }
 size_t gemm_partial_bytes(int M, int N, int K) {
   const gemm::Plan pl = gemm::plan(M, N, K);
@@ -138,6 +140,18 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
       return wsgemm::launch(wp, pl, (hipStream_t)stream);
     }
   }
+  if ((gemm_mode() & 32) && !is_dense(geom) && in_dtype == kInF32 && al16(in) && al16(w) && al16(out)) {
+    // 'valid' convs with 128-byte im2col segments on the GEMM core with a gathered A operand (gemm.h)
+    gemm::Params gp;
+    if (gemm::conv_fwd_setup(gp, geom)) {
+      gp.A = (const float*)in; gp.a_relu = in_relu; gp.B = w; gp.C = out; gp.bias = bias; gp.residual = residual;
+      gp.out_relu = out_relu;
+      gemm::Plan pl = gemm::plan(gp.M, gp.N, gp.K);
+      pl.slices = 1; pl.k_per_slice = gp.K;
+      gemm::launch<true, false, true, false, false>(gp, pl, (hipStream_t)stream);
+      return check_launch("conv2d_fwd(gather gemm)");
+    }
+  }
   {
     // small-kernel layers: input band staged once in LDS (halo_fwd.h).  Measured on MI355X
     // (tools/bench_kernels.py): the halo forward wins for stride-1 layers with few input channels / small maps;
@@ -157,7 +171,7 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
       if (pl.ok) return halo::launch_fwd_kernel(hp, pl, (hipStream_t)stream);
     }
   }
-  if (is_dense(geom) && in_dtype == kInF32 && geom->cin % 4 == 0 && geom->ld_in % 4 == 0 && (((uintptr_t)in) & 15) == 0) {
+  if (is_dense(geom) && in_dtype == kInF32 && geom->ld_in % 4 == 0 && (((uintptr_t)in) & 15) == 0) {
     if (gemm_fwd_ok(geom) && al16(w) && al16(out) && al16(workspace)) {
       const int M = geom->n_img, N = geom->cout, K = geom->cin;
       const gemm::Plan pl = gemm::plan(M, N, K);
@@ -178,6 +192,7 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
         return check_launch("conv2d_fwd(dense, gemm)");
       }
     }
+    if (geom->cin % 4 == 0) {
     DenseFwd d;
     d.in = (const float*)in; d.in_relu = in_relu; d.w = w; d.bias = bias; d.out = out; d.out_relu = out_relu;
     d.residual = residual;
@@ -195,6 +210,7 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
     }
     launch_igemm_auto(d, 1, (hipStream_t)stream);
     return check_launch("conv2d_fwd(dense)");
+    }
   }
   ConvFwd p;
   p.in = in; p.in_dtype = in_dtype; p.in_relu = in_relu; p.w = w; p.bias = bias; p.out = out;
@@ -221,6 +237,16 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
     if (pl.ok) {
       wp.A = dy; wp.W = w; wp.C = dx; wp.mask = relu_mask; wp.add = add;
       return wsgemm::launch(wp, pl, (hipStream_t)stream);
+    }
+  }
+  if ((gemm_mode() & 64) && !is_dense(geom) && al16(dy) && al16(w)) {
+    gemm::Params gp;
+    if (gemm::conv_dgrad_setup(gp, geom)) {
+      gp.A = dy; gp.B = w; gp.C = dx; gp.mask = relu_mask; gp.add = add;
+      gemm::Plan pl = gemm::plan(gp.M, gp.N, gp.K);
+      pl.slices = 1; pl.k_per_slice = gp.K;
+      gemm::launch<true, true, true, true, true>(gp, pl, (hipStream_t)stream);
+      return check_launch("conv2d_bwd_data(gather gemm)");
     }
   }
   {
@@ -331,7 +357,7 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
     if (pl.ok && (((uintptr_t)in) & 15) == 0 && (((uintptr_t)dy) & 15) == 0)
       return halo::launch_wgrad(geom, pl, in, in_dtype, in_relu, dy, dw, dbias, workspace, (hipStream_t)stream);
   }
-  if (is_dense(geom) && in_dtype == kInF32 && geom->cin % 4 == 0 && geom->ld_in % 4 == 0 && (((uintptr_t)in) & 15) == 0) {
+  if (is_dense(geom) && in_dtype == kInF32 && geom->ld_in % 4 == 0 && (((uintptr_t)in) & 15) == 0) {
     if (gemm_wgrad_ok(geom) && al16(dy) && al16(workspace)) {
       const int M = geom->cin, N = geom->cout, K = geom->n_img;
       const gemm::Plan pl = gemm::plan(M, N, K);
@@ -351,6 +377,7 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
       }
       return check_launch("conv2d_bwd_weight(dense, gemm)");
     }
+    if (geom->cin % 4 == 0) {
     DenseWgrad d;
     d.in = (const float*)in; d.in_relu = in_relu; d.dy = dy;
     const int M = geom->cin, N = geom->cout;
@@ -363,6 +390,7 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
     reduce_slices(d.partial_w, slices, (long long)M * N, dw, s);
     if (dbias) reduce_slices(d.partial_b, slices, N, dbias, s);
     return check_launch("conv2d_bwd_weight(dense)");
+    }
   }
   ConvWgrad p;
   p.in = in; p.in_dtype = in_dtype; p.in_relu = in_relu; p.dy = dy;

@@ -20,6 +20,8 @@
 // second-pass reduction (fixed slice order).
 #pragma once
 #include "common.h"
+#include "igemm.h"
+#include "../../include/seedhip.h"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +30,19 @@ namespace seedhip {
 namespace gemm {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// A k-contiguous operand whose rows are GATHERED 128-byte segments instead of dense rows: the im2col row of a
+// 'valid' convolution (forward), the dY taps of a super-pixel (data gradient), the Keras kernel re-indexed by
+// (parity class, ci) (data gradient B).  Row x -> (q, a, b) by two divisions; k-tile t adds tile_off[t] and is zero
+// unless (a + tile_dy[t], b + tile_dx[t]) lies inside [0, vh) x [0, vw).
+constexpr int kMaxTiles = 32;
+struct Gather {
+  FastDiv d1, d2;                           // x / d1 -> q, rem; rem / d2 -> a, b
+  long long s0; int s1, s2;                 // floats: row base = q*s0 + a*s1 + b*s2
+  int vh, vw, all_valid;
+  int tile_off[kMaxTiles];
+  signed char tile_dy[kMaxTiles], tile_dx[kMaxTiles];
+};
 
 struct Params {
   const float* A; long long lda; int a_relu;
@@ -39,15 +54,23 @@ struct Params {
   float* C; long long ldc;
   const float* bias; const float* residual; int out_relu;      // forward epilogue
   const float* mask; const float* add;                         // data-gradient epilogue (indexed like C)
+  Gather ga, gb;                            // gathered operands (conv kernels below); unused by the Dense GEMMs
+  int es, eih, eiw;                         // scatter epilogue (conv data gradient): stride, input map extents
 };
 
 constexpr int BK = 32, LD_KC = BK + 8;
 
 // Staging of one operand tile [X rows/cols = BX][BK] through registers into LDS.
+// OC rows are BX floats; with 2-wide fragments (ds_read_b64: lane groups {0-31}, {32-63} = two k rows 4 apart each)
+// the row stride must move 4 rows by 32 banks: BX + 8.  4-wide fragments (b128, 16 lanes = 256 contiguous bytes per
+// group) are conflict free at any stride.
+template <int BX> struct LdOC { static constexpr int value = (BX == 64) ? BX + 8 : BX; };
+
 template <int BX, bool KC>
 struct Stager {
   static constexpr int kVecs = BX * BK / 4 / 256;
-  static constexpr int kLdsFloats = KC ? BX * LD_KC : BK * BX;
+  static constexpr int kLdOC = LdOC<BX>::value;
+  static constexpr int kLdsFloats = KC ? BX * LD_KC : BK * kLdOC;
   const float* base[kVecs];   // pointer at k = 0 of this thread's vector (null: out of range in x)
   int lds_off[kVecs];
   int krow[kVecs];            // k offset of the vector inside a tile
@@ -64,7 +87,7 @@ struct Stager {
         base[i] = (x0 + row < X) ? p + (long long)(x0 + row) * ld + kc : nullptr;
       } else {
         const int kr = v / (BX / 4), x4 = (v % (BX / 4)) * 4;
-        krow[i] = kr; lds_off[i] = kr * BX + x4;
+        krow[i] = kr; lds_off[i] = kr * kLdOC + x4;
         base[i] = (x0 + x4 < X) ? p + (long long)kr * ld + x0 + x4 : nullptr;     // X % 4 == 0: all in or all out
       }
     }
@@ -87,16 +110,72 @@ struct Stager {
   }
 };
 
+template <int BX>
+struct GatherStager {                        // KC only; same interface as Stager
+  static constexpr int kVecs = BX * BK / 4 / 256;
+  static constexpr int kLdOC = BX;
+  static constexpr int kLdsFloats = BX * LD_KC;
+  const float* base[kVecs];
+  unsigned vmask[kVecs];
+  int lds_off[kVecs];
+  const Gather* g;
+  float4 r[kVecs];
+
+  __device__ void init(const float* p, const Gather& gg, int nkt, int x0, int X, int tid) {
+    g = &gg;
+#pragma unroll
+    for (int i = 0; i < kVecs; ++i) {
+      const int v = tid + i * 256, row = v >> 3, kc = (v & 7) * 4;
+      lds_off[i] = row * LD_KC + kc;
+      const float* b = nullptr;
+      unsigned mask = 0;
+      if (x0 + row < X) {
+        uint32_t q, rem, ya, xb;
+        gg.d1.divmod((uint32_t)(x0 + row), q, rem);
+        gg.d2.divmod(rem, ya, xb);
+        b = p + (long long)q * gg.s0 + (long long)ya * gg.s1 + (long long)xb * gg.s2 + kc;
+        if (gg.all_valid) mask = 0xffffffffu;
+        else for (int t = 0; t < nkt; ++t) {
+          const int y = (int)ya + gg.tile_dy[t], x = (int)xb + gg.tile_dx[t];
+          if (y >= 0 && y < gg.vh && x >= 0 && x < gg.vw) mask |= 1u << t;
+        }
+      }
+      base[i] = b; vmask[i] = mask;
+    }
+  }
+  __device__ void load(int k, int k1, bool relu) {       // k is a multiple of BK (no split-K on gathered operands)
+    const int kt = k / BK, off = g->tile_off[kt];
+#pragma unroll
+    for (int i = 0; i < kVecs; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((vmask[i] >> kt) & 1u) {
+        v = *reinterpret_cast<const float4*>(base[i] + off);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      }
+      r[i] = v;
+    }
+  }
+  __device__ void store(float* lds) const {
+#pragma unroll
+    for (int i = 0; i < kVecs; ++i) *reinterpret_cast<float4*>(lds + lds_off[i]) = r[i];
+  }
+};
+
+template <int BX, bool KC, bool G> struct PickStager { typedef Stager<BX, KC> type; };
+template <int BX> struct PickStager<BX, true, true> { typedef GatherStager<BX> type; };
+
 template <int R> struct FragVec;
 template <> struct FragVec<4> { typedef f32x4_t type; };
 template <> struct FragVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
 
-template <int MR, int NR, bool AKC, bool BKC>          // 2 x 2 waves; tile (2*MR*16) x (2*NR*16); MR, NR in {2, 4}
-__global__ void __launch_bounds__(256)
+// AG / BG: the (KC) operand is gathered (struct Gather).  SCATTER: conv data-gradient epilogue, row m = super-pixel
+// (img, a, b), column n = (py, px, ci) -> dx[img, es*a + py, es*b + px, ci].
+template <int MR, int NR, bool AKC, bool BKC, bool AG = false, bool BG = false, bool SCATTER = false>
+__global__ void __launch_bounds__(256)                 // 2 x 2 waves; tile (2*MR*16) x (2*NR*16); MR, NR in {2, 4}
 gemm_kernel(const Params p) {
   constexpr int BM = 2 * MR * 16, BN = 2 * NR * 16;
-  typedef Stager<BM, AKC> SA;
-  typedef Stager<BN, BKC> SB;
+  typedef typename PickStager<BM, AKC, AG>::type SA;
+  typedef typename PickStager<BN, BKC, BG>::type SB;
   __shared__ __attribute__((aligned(16))) float smem[SA::kLdsFloats + SB::kLdsFloats];
   float* As = smem;
   float* Bs = smem + SA::kLdsFloats;
@@ -108,8 +187,8 @@ gemm_kernel(const Params p) {
   const int nkt = (k1 - k0 + BK - 1) / BK;
 
   SA sa; SB sb;
-  sa.init(p.A, p.lda, m0, p.M, tid);
-  sb.init(p.B, p.ldb, n0, p.N, tid);
+  if constexpr (AG) sa.init(p.A, p.ga, nkt, m0, p.M, tid); else sa.init(p.A, p.lda, m0, p.M, tid);
+  if constexpr (BG) sb.init(p.B, p.gb, nkt, n0, p.N, tid); else sb.init(p.B, p.ldb, n0, p.N, tid);
   const bool do_colsum = !BKC && p.partial_colsum && blockIdx.x == 0;
   float4 csum[SB::kVecs];
 #pragma unroll
@@ -123,8 +202,9 @@ gemm_kernel(const Params p) {
 
   // fragment base addresses: KC [x][k] rows of this lane's x, 4 consecutive k at 4*kq; OC [k][x] row 4*kq (+kk),
   // R consecutive x at R*lx
-  const float* a_frag = AKC ? As + (wm * MR * 16 + lx) * LD_KC + 4 * kq : As + (4 * kq) * BM + wm * MR * 16 + MR * lx;
-  const float* b_frag = BKC ? Bs + (wn * NR * 16 + lx) * LD_KC + 4 * kq : Bs + (4 * kq) * BN + wn * NR * 16 + NR * lx;
+  constexpr int LDA_OC = SA::kLdOC, LDB_OC = SB::kLdOC;
+  const float* a_frag = AKC ? As + (wm * MR * 16 + lx) * LD_KC + 4 * kq : As + (4 * kq) * LDA_OC + wm * MR * 16 + MR * lx;
+  const float* b_frag = BKC ? Bs + (wn * NR * 16 + lx) * LD_KC + 4 * kq : Bs + (4 * kq) * LDB_OC + wn * NR * 16 + NR * lx;
 
   if (nkt > 0) { sa.load(k0, k1, p.a_relu != 0); sb.load(k0, k1, false); }
   for (int kt = 0; kt < nkt; ++kt) {
@@ -146,14 +226,14 @@ gemm_kernel(const Params p) {
         for (int i = 0; i < MR; ++i) a_kc[i] = *reinterpret_cast<const f32x4_t*>(a_frag + i * 16 * LD_KC + h * 16);
       } else {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) a_oc[kk] = *reinterpret_cast<const typename FragVec<MR>::type*>(a_frag + (h * 16 + kk) * BM);
+        for (int kk = 0; kk < 4; ++kk) a_oc[kk] = *reinterpret_cast<const typename FragVec<MR>::type*>(a_frag + (h * 16 + kk) * LDA_OC);
       }
       if (BKC) {
 #pragma unroll
         for (int j = 0; j < NR; ++j) b_kc[j] = *reinterpret_cast<const f32x4_t*>(b_frag + j * 16 * LD_KC + h * 16);
       } else {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) b_oc[kk] = *reinterpret_cast<const typename FragVec<NR>::type*>(b_frag + (h * 16 + kk) * BN);
+        for (int kk = 0; kk < 4; ++kk) b_oc[kk] = *reinterpret_cast<const typename FragVec<NR>::type*>(b_frag + (h * 16 + kk) * LDB_OC);
       }
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
@@ -196,7 +276,26 @@ gemm_kernel(const Params p) {
       float v[NR];
 #pragma unroll
       for (int j = 0; j < NR; ++j) v[j] = acc[i][j][r];
-      if (BKC) {
+      if (SCATTER) {
+        uint32_t img, rem, sa_, sb_;
+        p.ga.d1.divmod((uint32_t)m, img, rem);
+        p.ga.d2.divmod(rem, sa_, sb_);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          const int n = n0 + wn * NR * 16 + 16 * j + lx;
+          if (n >= p.N) continue;
+          uint32_t py, rem2, px, ci;
+          p.gb.d1.divmod((uint32_t)n, py, rem2);
+          p.gb.d2.divmod(rem2, px, ci);
+          const int oy = (int)sa_ * p.es + (int)py, ox = (int)sb_ * p.es + (int)px;
+          if (oy >= p.eih || ox >= p.eiw) continue;
+          const long long at = (((long long)img * p.eih + oy) * p.eiw + ox) * p.ldc + ci;
+          float o = v[j];
+          if (p.mask && !(p.mask[at] > 0.f)) o = 0.f;
+          if (p.add) o += p.add[at];
+          p.C[at] = o;
+        }
+      } else if (BKC) {
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
           const int n = n0 + wn * NR * 16 + 16 * j + lx;
@@ -294,13 +393,63 @@ inline Plan plan(int M, int N, int K) {
   return best;
 }
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, bool AG = false, bool BG = false, bool SCATTER = false>
 inline void launch(const Params& p, const Plan& pl, hipStream_t s) {
   const int bm = 32 * pl.mr, bn = 32 * pl.nr;
   dim3 grid((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, pl.slices);
-  if (pl.mr == 4 && pl.nr == 4) hipLaunchKernelGGL((gemm_kernel<4, 4, AKC, BKC>), grid, dim3(256), 0, s, p);
-  else if (pl.mr == 4 && pl.nr == 2) hipLaunchKernelGGL((gemm_kernel<4, 2, AKC, BKC>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((gemm_kernel<2, 2, AKC, BKC>), grid, dim3(256), 0, s, p);
+  if (pl.mr == 4 && pl.nr == 4) hipLaunchKernelGGL((gemm_kernel<4, 4, AKC, BKC, AG, BG, SCATTER>), grid, dim3(256), 0, s, p);
+  else if (pl.mr == 4 && pl.nr == 2) hipLaunchKernelGGL((gemm_kernel<4, 2, AKC, BKC, AG, BG, SCATTER>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemm_kernel<2, 2, AKC, BKC, AG, BG, SCATTER>), grid, dim3(256), 0, s, p);
+}
+
+// ---- 'valid' convolutions as gather-GEMMs (see struct Gather) ---------------------------------------------- //
+// Forward: m = output pixel, k = (ky, kx, ci) -- kw*cin contiguous floats per ky, so every 32-deep k-tile is one
+// 128-byte segment of the NHWC input -- n = co, B = the Keras kernel as stored (OC).  Needs pad 0, ld_in == cin,
+// (kw*cin) % 32 == 0, cout % 4 == 0.
+inline bool conv_fwd_setup(Params& p, const seedhip_conv_geom* g) {
+  const int seg = g->kw * g->cin;
+  if (g->pad_t || g->pad_l || g->ld_in != g->cin || seg % BK || g->cout % 4 || g->ld_out % 4) return false;
+  const int K = g->kh * seg, per_row = seg / BK;
+  if (K / BK > kMaxTiles) return false;
+  memset(&p, 0, sizeof(p));
+  p.M = g->n_img * g->oh * g->ow; p.N = g->cout; p.K = K; p.k_per_slice = K;
+  p.ldb = g->cout; p.ldc = g->ld_out;
+  Gather& a = p.ga;
+  a.d1.init(g->oh * g->ow); a.d2.init(g->ow);
+  a.s0 = (long long)g->ih * g->iw * g->ld_in; a.s1 = g->stride * g->iw * g->ld_in; a.s2 = g->stride * g->ld_in;
+  a.all_valid = 1;
+  for (int t = 0; t < K / BK; ++t) a.tile_off[t] = (t / per_row) * g->iw * g->ld_in + (t % per_row) * BK;
+  return true;
+}
+
+// Data gradient: m = super-pixel (a, b) covering input pixels (s*a+py, s*b+px), n = (py, px, ci), k = (jy, jx, co):
+//   dX[s*a+py, s*b+px, ci] = sum dY[a-jy, b-jx, co] * W[py+s*jy, px+s*jx, ci, co]
+// one GEMM for all stride-parity classes; A rows = 128-byte segments of dY (zero outside the map), B rows = the
+// kernel's co-contiguous rows re-indexed by (py, px, ci).  Needs pad 0, kh % s == kw % s == 0, cout % 32 == 0.
+inline bool conv_dgrad_setup(Params& p, const seedhip_conv_geom* g) {
+  const int s = g->stride;
+  if (g->pad_t || g->pad_l || g->kh % s || g->kw % s || g->cout % BK || g->ld_out % 4) return false;
+  const int jh = g->kh / s, jw = g->kw / s, per_tap = g->cout / BK, K = jh * jw * g->cout, N = s * s * g->cin;
+  if (K / BK > kMaxTiles) return false;
+  memset(&p, 0, sizeof(p));
+  const int gh = (g->ih + s - 1) / s, gw = (g->iw + s - 1) / s;
+  p.M = g->n_img * gh * gw; p.N = N; p.K = K; p.k_per_slice = K;
+  p.ldc = g->ld_in; p.es = s; p.eih = g->ih; p.eiw = g->iw;
+  Gather& a = p.ga;
+  a.d1.init(gh * gw); a.d2.init(gw);
+  a.s0 = (long long)g->oh * g->ow * g->ld_out; a.s1 = g->ow * g->ld_out; a.s2 = g->ld_out;
+  a.vh = g->oh; a.vw = g->ow;
+  Gather& b = p.gb;
+  b.d1.init(s * g->cin); b.d2.init(g->cin);
+  b.s0 = (long long)g->kw * g->cin * g->cout; b.s1 = g->cin * g->cout; b.s2 = g->cout;
+  b.all_valid = 1;
+  for (int t = 0; t < K / BK; ++t) {
+    const int tap = t / per_tap, jy = tap / jw, jx = tap % jw, chunk = t % per_tap;
+    a.tile_off[t] = -(jy * g->ow + jx) * g->ld_out + chunk * BK;
+    a.tile_dy[t] = (signed char)-jy; a.tile_dx[t] = (signed char)-jx;
+    b.tile_off[t] = (s * jy * g->kw + s * jx) * g->cin * g->cout + chunk * BK;
+  }
+  return true;
 }
 
 }  // namespace gemm

@@ -359,6 +359,41 @@ def test_conv_fwd_bwd_parity(device, case):
     assert np.max(np.abs(dx.cpu().numpy() - gx)) <= 2e-4 * max(1.0, np.abs(gx).max())
 
 
+@pytest.mark.parametrize('n,cin,cout', [(300, 531, 2048), (2100, 265, 1024), (64, 19, 36)])
+def test_dense_padded_rows(device, n, cin, cout):
+  """Dense layers whose input rows carry pad columns (the LSTM input [features | reward | one-hot action] has
+  512 + 1 + 18 = 531 columns in rows of 532): forward / weight gradient / data gradient through gemm.h with
+  K % 4 != 0, against torch fp32.  The pad column holds finite junk."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(n + cin)
+  ld = (cin + 3) // 4 * 4
+  xp = rng.normal(size=(n, ld)).astype(np.float32)            # pad columns: finite junk
+  x = xp[:, :cin]
+  w = (rng.normal(size=(cin, cout)) / np.sqrt(cin)).astype(np.float32)
+  b = rng.normal(size=(cout,)).astype(np.float32)
+  xt = torch.tensor(x.copy(), requires_grad=True); wt = torch.tensor(w, requires_grad=True)
+  bt = torch.tensor(b, requires_grad=True)
+  y = xt @ wt + bt
+  dy = rng.normal(size=y.shape).astype(np.float32)
+  y.backward(torch.tensor(dy))
+  g = ops.dense_geom(n, cin, cout, ld_in=ld)
+  xd, wd, bd, dyd = dev(xp, device), dev(w, device), dev(b, device), dev(dy, device)
+  out = torch.full((n, cout), 7.0, device=device)
+  ops.conv2d_fwd(g, xd, wd, bd, out)
+  yr = y.detach().numpy()
+  assert np.max(np.abs(out.cpu().numpy() - yr)) <= 2e-4 * max(1.0, np.abs(yr).max())
+  dw = torch.full(w.shape, 7.0, device=device); db = torch.full(b.shape, 7.0, device=device)
+  ws = torch.empty(ops.conv2d_bwd_weight_workspace_bytes(g) // 4 + 1, device=device)
+  ops.conv2d_bwd_weight(g, xd, dyd, dw, db, ws)
+  gw, gb = wt.grad.numpy(), bt.grad.numpy()
+  assert np.max(np.abs(dw.cpu().numpy() - gw)) <= 3e-4 * max(1.0, np.abs(gw).max())
+  assert np.max(np.abs(db.cpu().numpy() - gb)) <= 3e-4 * max(1.0, np.abs(gb).max())
+  dx = torch.full((n, ld), 7.0, device=device)
+  ops.conv2d_bwd_data(g, dyd, wd, dx)
+  gx = xt.grad.numpy()
+  assert np.max(np.abs(dx.cpu().numpy()[:, :cin] - gx)) <= 2e-4 * max(1.0, np.abs(gx).max())
+
+
 def test_conv_residual_and_accumulate(device):
   """Residual epilogue (dmlab/networks.py:58) and dgrad accumulate-into (skip path)."""
   from seed_rl_amd import ops

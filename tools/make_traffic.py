@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Builds profiles/<tag>_traffic.json (HBM bytes per launch of the cfg2 hot kernels) from the condensed PMC table
+written by tools/prof_summary.py.
+
+  python tools/make_traffic.py profiles/r01d_cfg2_pmc.csv profiles/r01d_cfg2_traffic.json
+
+Region names are bench.py's (ops.Profiler regions); a region's kernel is the matching row with the largest traffic
+(the Dense GEMM template serves the FC layer and the small heads: the FC launch is the big one).  FETCH_SIZE is doubled
+as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (the counter reports half of a wide coalesced read
+stream); WRITE_SIZE is used as reported.
+"""
+import csv
+import json
+import sys
+
+REGIONS = [
+    ('stack_conv_fwd', 'stackconv_fwd_kernel'),
+    ('stack_conv_wgrad', 'stackconv_wgrad_kernel'),
+    ('conv_fwd[4x4/2 16->32 @20x20]', 'wsgemm::ws_kernel<1, 2,'),
+    ('conv_dgrad[4x4/2 16->32 @20x20]', 'wsgemm::ws_kernel<1, 4,'),
+    ('conv_wgrad[4x4/2 16->32 @20x20]', 'halo_wgrad_kernel'),
+    ('conv_fwd[1x1/1 2592->256 @1x1]', 'true, false>(seedhip::gemm::Params)'),
+    ('conv_dgrad[1x1/1 2592->256 @1x1]', 'true, true>(seedhip::gemm::Params)'),
+    ('conv_wgrad[1x1/1 2592->256 @1x1]', 'false, false>(seedhip::gemm::Params)'),
+]
+
+
+def main():
+  src, out = sys.argv[1], sys.argv[2]
+  rows = list(csv.reader(open(src)))[1:]
+  traffic, fetch, write, kernel = {}, {}, {}, {}
+  for region, pat in REGIONS:
+    best = None
+    for r in rows:
+      if pat not in r[0] or not r[3] or not r[4]:
+        continue
+      f, w = float(r[3]), float(r[4])
+      if best is None or 2 * f + w > 2 * best[1] + best[2]:
+        best = (r[0], f, w)
+    if best:
+      kernel[region], fetch[region], write[region] = best[0][:100], best[1], best[2]
+      traffic[region] = int((2 * best[1] + best[2]) * 1024)
+  json.dump({
+      'note': 'HBM bytes per launch from rocprofv3 PMC passes (%s): (2 x FETCH_SIZE + WRITE_SIZE) x 1024; FETCH_SIZE '
+              'doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced read stream)' % src,
+      'config': 'cfg2 Atari shallow T=20 B=512 A=18',
+      'traffic_bytes': traffic, 'fetch_kb_raw': fetch, 'write_kb': write, 'kernel': kernel,
+  }, open(out, 'w'), indent=1)
+  for k, v in traffic.items():
+    print('%-40s %8.1f MB' % (k, v / 1e6))
+
+
+if __name__ == '__main__':
+  main()
