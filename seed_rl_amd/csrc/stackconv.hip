@@ -29,6 +29,7 @@
 //
 // MFMA-bound (fp32 v_mfma_f32_16x16x4_f32): 2*400*256*Cout flops per frame.
 #include "common.h"
+#include <cstdlib>
 #include "conv_problems.h"
 #include "conv_launch.h"
 #include "../../include/seedhip.h"
@@ -121,9 +122,8 @@ stackconv_fwd_kernel(const Params p) {
     float wv[kPer];
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
-      const int idx = tid + u * kThreads;
-      const int l = idx & 63, ks = (idx >> 6) & 63;
-      const int q = ks & 3, r = (ks >> 2) & 3, c = ks >> 4;
+      const int idx = tid + u * kThreads;                 // idx = ((c*4 + r)*64 + lane)*4 + q
+      const int q = idx & 3, l = (idx >> 2) & 63, r = (idx >> 8) & 3, c = (idx >> 10) & 3;
       const int ky = 2 * r + ((l >> 4) >> 1), kx = 4 * ((l >> 4) & 1) + q;
       wv[u] = p.w[((ky * 8 + kx) * 4 + c) * p.cout + co0 + (l & 15)];
     }
@@ -164,19 +164,142 @@ stackconv_fwd_kernel(const Params p) {
       for (int m = 0; m < kMT; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       for (int c = 0; c < nv; ++c) {
         const unsigned char* base = myring + ((t + 3 - c) % kSlots) * kBandBytes;
-        const float* wl = w_lds + c * 16 * 64 + lane;
+        const float* wl = w_lds + (c * 4 * 64 + lane) * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           uint32_t a[kMT];
 #pragma unroll
           for (int m = 0; m < kMT; ++m)
             a[m] = *reinterpret_cast<const uint32_t*>(base + aoff[m] + r * 2 * kIW);
+          const f32x4_t bw = *reinterpret_cast<const f32x4_t*>(wl + r * 256);   // the 4 q-steps: one ds_read_b128
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float bw = wl[(r * 4 + q) * 64];
 #pragma unroll
             for (int m = 0; m < kMT; ++m)
-              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw, ubyte(a[m], q), acc[m], 0, 0, 0);
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[q], ubyte(a[m], q), acc[m], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < kMT; ++m) {
+        const int pix = wave * 80 + m * 16 + j;
+        f32x4_t v = acc[m] + bias4;
+        if (p.out_relu) {
+          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        }
+        float* o = p.out + (((long long)t * p.B + b) * 400 + pix) * p.ld_out + co0 + 4 * kq;
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+      if (more) {
+        wave_lds_fence();                              // this wave's reads of frame t are done
+        band_store(myring + ((t + 4) % kSlots) * kBandBytes, pf, lane);
+        wave_lds_fence();
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ //
+// Forward on the bf16 matrix pipe, exact: "bf16x3".
+// The layer's inputs are uint8 pixels: every value 0..255 is EXACT in bf16 (8 significant bits).  An fp32 weight
+// is the EXACT sum of three bf16 numbers, w = hi + mid + lo (8 + 8 + 8 significant bits, same exponent range as
+// fp32).  So x * w = x*hi + x*mid + x*lo with every product exact (8 x 8 bits) and the accumulation in fp32 inside
+// v_mfma_f32_16x16x32_bf16: the same real-number sum the fp32 MFMA evaluates, up to fp32 summation order -- at
+// 3/16 of its matrix-pipe time (the bf16 MFMA does 16x the MACs per cycle).  This is not a reduced-precision
+// path: no operand is rounded (tests/test_gpu_kernels.py checks it at the fp32 tolerance, tests/test_bf16_split.py
+// checks hi + mid + lo == w bit for bit).
+//   k-group G = (c, half): 32 k = lane group kq (ky = 4*half + kq) x 8 horizontally adjacent pixels (kx = 0..7)
+//   B operand (cols = 16 pixels): 8 consecutive frame bytes = two ds_read_b32 -> 8 bf16 (v_cvt_f32_ubyte + v_perm)
+//   A operand (rows = 16 channels): W/255 split, LDS image [G][split][lane] x 16 bytes, one ds_read_b128 each
+//   3 MFMAs per (G, pixel tile) instead of 8 fp32 MFMAs of twice the duration.
+// ------------------------------------------------------------------------------------ //
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+union Frag8 { uint4 u; bf16x8_t v; };
+constexpr int kGroups = 8;
+constexpr int kWBf16Bytes = kGroups * 3 * 64 * 16;                   // 24 KB
+
+// two bytes (a, b) of w -> packed bf16 pair (low half = byte a): exact, float(n) of n < 256 has zero low mantissa
+template <int A, int B>
+__device__ __forceinline__ uint32_t bf16_pair(uint32_t w) {
+  const uint32_t f0 = __float_as_uint(ubyte(w, A)), f1 = __float_as_uint(ubyte(w, B));
+  return __builtin_amdgcn_perm(f1, f0, 0x07060302u);
+}
+
+__global__ void __launch_bounds__(kThreads)
+stackconv_fwd_bf16_kernel(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* w_lds = reinterpret_cast<uint4*>(smem);                     // [G][split][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char* myring = smem + kWBf16Bytes + wave * kWaveRing;
+  const int kq = lane >> 4, j = lane & 15;
+  const int co0 = blockIdx.z * 16;
+
+  // ---- W/255 -> three bf16 images in LDS (each thread splits whole (G, lane) rows of 8 k) ----
+  for (int idx = tid; idx < kGroups * 64; idx += kThreads) {
+    const int l = idx & 63, G = idx >> 6, c = G >> 1, half = G & 1;
+    const int ky = 4 * half + (l >> 4), co = co0 + (l & 15);
+    uint32_t part[3][4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float w = p.w[((ky * 8 + e) * 4 + c) * p.cout + co] / 255.0f;
+      const uint32_t hi = __float_as_uint(w) >> 16;                   // exact split by truncation (see split3_pack)
+      const float r1 = w - __uint_as_float(hi << 16);
+      const uint32_t mid = __float_as_uint(r1) >> 16;
+      const uint32_t lo = __float_as_uint(r1 - __uint_as_float(mid << 16)) >> 16;
+      const uint32_t v[3] = {hi, mid, lo};
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        if (e & 1) part[s3][e >> 1] |= v[s3] << 16; else part[s3][e >> 1] = v[s3];
+      }
+    }
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+      w_lds[(G * 3 + s3) * 64 + l] = make_uint4(part[s3][0], part[s3][1], part[s3][2], part[s3][3]);
+  }
+  f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+    const float4 bv = *reinterpret_cast<const float4*>(p.bias + co0 + 4 * kq);
+    bias4 = f32x4_t{bv.x, bv.y, bv.z, bv.w};
+  }
+  int aoff[kMT];
+#pragma unroll
+  for (int m = 0; m < kMT; ++m) {
+    const int pix = m * 16 + j;                       // 0..79 within the band
+    const int oy = pix / kOW, ox = pix - oy * kOW;
+    aoff[m] = (oy * 4 + kq) * kIW + ox * 4;
+  }
+  __syncthreads();                                    // weights visible; the only workgroup barrier
+
+  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+    const int b = item % p.B, chunk = item / p.B;
+    const int t0 = chunk * p.spc;
+    const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
+    band_prologue(p, myring, b, t0, wave, lane);
+    for (int t = t0; t < t1; ++t) {
+      const bool more = t + 1 < t1;
+      BandPrefetch pf;
+      if (more) pf = band_load(band_src(p, t + 4, b, wave), lane);
+      const int nv = p.nvalid[(long long)t * p.B + b];
+      f32x4_t acc[kMT];
+#pragma unroll
+      for (int m = 0; m < kMT; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < nv; ++c) {
+        const unsigned char* base = myring + ((t + 3 - c) % kSlots) * kBandBytes;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const uint4* wl = w_lds + ((c * 2 + half) * 3) * 64 + lane;
+          Frag8 wf[3];
+#pragma unroll
+          for (int s3 = 0; s3 < 3; ++s3) wf[s3].u = wl[s3 * 64];
+#pragma unroll
+          for (int m = 0; m < kMT; ++m) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(base + aoff[m] + half * 4 * kIW);
+            const uint32_t d0 = src[0], d1 = src[1];
+            Frag8 xf;
+            xf.u = make_uint4(bf16_pair<0, 1>(d0), bf16_pair<2, 3>(d0), bf16_pair<0, 1>(d1), bf16_pair<2, 3>(d1));
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2].v, xf.v, acc[m], 0, 0, 0);     // lo, mid, hi
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1].v, xf.v, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0].v, xf.v, acc[m], 0, 0, 0);
           }
         }
       }
@@ -326,6 +449,166 @@ stackconv_wgrad_kernel(const Params p) {
 }
 
 // ------------------------------------------------------------------------------------ //
+// Weight gradient on the bf16 matrix pipe, exact ("bf16x3", see the forward): X is uint8 (exact in bf16), each dY
+// value is split into three bf16 parts whose sum is the fp32 value, products are exact, accumulation is fp32.
+// v_mfma_f32_16x16x32_bf16 reduces 32 pixels per instruction: lane group kq owns pixel chunk ch = 4g + kq of the
+// band = 2 output rows x 4 pixels ((2rp + a, 4xc + b), element e = 4a + b; 10 chunks per band, chunks 10 and 11
+// of the third group are zero padding).
+//   A (rows = 16 k-rows of m-tile (c, q); row i = (ky = i>>1, kx = 4(i&1) + q)): byte q of the 8 dwords
+//     frame_{t-c}[(8rp + 4a + ky)*84 + 16xc + 4b + 4(i&1)]: 8 ds_read_b32 serve the four m-tiles q = 0..3
+//   B (cols = 16 channels): dY[pixel e of chunk][co0 + j], 8 global dwords per lane and group, split once and
+//     used by the 16 m-tiles x 3 parts.
+// Channels c >= nvalid are skipped (forward: cumulative-OR done mask).  Accumulators, cross-wave reduction and
+// the partial-slice output are those of the fp32 kernel above.
+// ------------------------------------------------------------------------------------ //
+__device__ __forceinline__ uint32_t bf16_pair2(uint32_t wa, uint32_t wb, int q) {      // byte q of wa (low), wb (high)
+  const uint32_t f0 = __float_as_uint(ubyte(wa, q)), f1 = __float_as_uint(ubyte(wb, q));
+  return __builtin_amdgcn_perm(f1, f0, 0x07060302u);
+}
+// Exact split by TRUNCATION (cheaper than rounding, equally exact): hi = the top 8 significant bits of v, mid = the
+// top 8 of what is left, lo = the remaining <= 8 bits; hi + mid + lo == v bit for bit (tests/test_bf16_split.py).
+__device__ __forceinline__ void split3_pack(const float (&v)[8], Frag8 (&out)[3]) {
+  uint32_t h[8], m[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h[e] = __float_as_uint(v[e]) & 0xFFFF0000u;
+    const float r1 = v[e] - __uint_as_float(h[e]);
+    m[e] = __float_as_uint(r1) & 0xFFFF0000u;
+    l[e] = __float_as_uint(r1 - __uint_as_float(m[e]));            // <= 8 significant bits: low half is zero
+  }
+  uint32_t part[3][4];
+#pragma unroll
+  for (int e2 = 0; e2 < 4; ++e2) {                                  // pack high halves of elements (2*e2, 2*e2 + 1)
+    part[0][e2] = __builtin_amdgcn_perm(h[2 * e2 + 1], h[2 * e2], 0x07060302u);
+    part[1][e2] = __builtin_amdgcn_perm(m[2 * e2 + 1], m[2 * e2], 0x07060302u);
+    part[2][e2] = __builtin_amdgcn_perm(l[2 * e2 + 1], l[2 * e2], 0x07060302u);
+  }
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) out[s3].u = make_uint4(part[s3][0], part[s3][1], part[s3][2], part[s3][3]);
+}
+
+__global__ void __launch_bounds__(kThreads, 2)
+stackconv_wgrad_bf16_kernel(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);                       // [256 k_mem][16]
+  float* redb = red + kWFloats;                                      // [kWaves][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char* myring = smem + (kWFloats + kWaves * 16) * sizeof(float) + wave * kWaveRing;
+  const int kq = lane >> 4, i = lane & 15;
+  const int co0 = blockIdx.z * 16;
+  constexpr int P = 400;
+
+  f32x4_t acc[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  // per-lane chunk geometry of the three pixel groups: fixed for the whole launch
+  int a_off[3], dy_off[3];
+  bool valid[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const int ch = 4 * g + kq;
+    valid[g] = ch < 10;
+    const int rp = valid[g] ? ch / 5 : 0, xc = valid[g] ? ch % 5 : 0;
+    a_off[g] = (8 * rp + (i >> 1)) * kIW + 16 * xc + 4 * (i & 1);
+    dy_off[g] = (2 * rp * kOW + 4 * xc) * p.ld_out;
+  }
+  auto load_dy = [&](const float* band, int g, float (&v)[8]) {      // band: dY of this wave's 80 pixels, channel co0 + i
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        v[4 * a + b] = valid[g] ? band[dy_off[g] + (a * kOW + b) * p.ld_out] : 0.f;
+  };
+
+  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+    const int b = item % p.B, chunk = item / p.B;
+    const int t0 = chunk * p.spc;
+    const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
+    band_prologue(p, myring, b, t0, wave, lane);
+    float dyn[8];
+    load_dy(p.dy + (((long long)t0 * p.B + b) * P + wave * 80) * p.ld_out + co0 + i, 0, dyn);
+    for (int t = t0; t < t1; ++t) {
+      const bool more = t + 1 < t1;
+      BandPrefetch pf;
+      if (more) pf = band_load(band_src(p, t + 4, b, wave), lane);
+      const int nv = p.nvalid[(long long)t * p.B + b];
+      const float* dy_band = p.dy + (((long long)t * p.B + b) * P + wave * 80) * p.ld_out + co0 + i;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        Frag8 bf[3];
+        {
+          float dyv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { dyv[e] = dyn[e]; bsum += dyn[e]; }
+          split3_pack(dyv, bf);
+        }
+        // dY of the next group (next step's first group at the end of a step) flies under this group's MFMAs
+        if (g < 2) load_dy(dy_band, g + 1, dyn);
+        else if (more) load_dy(dy_band + (long long)p.B * P * p.ld_out, 0, dyn);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                       // unrolled: accumulator indices stay static
+          if (c >= nv) continue;                            // wave-uniform
+          const unsigned char* src = myring + ((t + 3 - c) % kSlots) * kBandBytes + a_off[g];
+          uint32_t d[2][4];
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+              d[a][bb] = *reinterpret_cast<const uint32_t*>(src + a * 4 * kIW + 4 * bb);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            Frag8 xa;
+            xa.u = make_uint4(bf16_pair2(d[0][0], d[0][1], q), bf16_pair2(d[0][2], d[0][3], q),
+                              bf16_pair2(d[1][0], d[1][1], q), bf16_pair2(d[1][2], d[1][3], q));
+            f32x4_t v = acc[c * 4 + q];
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v, bf[2].v, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v, bf[1].v, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v, bf[0].v, v, 0, 0, 0);
+            acc[c * 4 + q] = v;
+          }
+        }
+      }
+      if (more) {
+        wave_lds_fence();
+        band_store(myring + ((t + 4) % kSlots) * kBandBytes, pf, lane);
+        wave_lds_fence();
+      }
+    }
+  }
+
+  // Cross-wave reduction in wave order (deterministic), then one partial slice per workgroup.
+  bsum += __shfl_xor(bsum, 16, 64);
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (lane < 16) redb[wave * 16 + lane] = bsum;
+  for (int w = 0; w < kWaves; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int c = m >> 2, q = m & 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * kq + r;                       // k-row within the m-tile
+          const int ky = row >> 1, kx = 4 * (row & 1) + q;
+          const int idx = ((ky * 8 + kx) * 4 + c) * 16 + i;
+          red[idx] = (w == 0) ? acc[m][r] : red[idx] + acc[m][r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* pw = p.partial_w + (long long)blockIdx.x * 256 * p.cout;
+  for (int idx = tid; idx < kWFloats; idx += kThreads)
+    pw[(idx >> 4) * p.cout + co0 + (idx & 15)] = red[idx] / 255.0f;
+  if (p.partial_b && tid < 16) {
+    float s = 0.f;
+    for (int w = 0; w < kWaves; ++w) s += redb[w * 16 + tid];
+    p.partial_b[(long long)blockIdx.x * p.cout + co0 + tid] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------ //
 // Host side: eligibility, work decomposition, launch.
 // ------------------------------------------------------------------------------------ //
 bool eligible(const seedhip_stack_conv_geom* g, const void* frames_ext, const void* io) {
@@ -374,6 +657,15 @@ int launch_fwd(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, cons
                const float* bias, float* out, int out_relu, hipStream_t s) {
   Params p = make_params(g, frames_ext, nvalid);
   p.w = w; p.bias = bias; p.out = out; p.out_relu = out_relu;
+  static const int bf16x3 = getenv("SEEDHIP_STACK_BF16") ? atoi(getenv("SEEDHIP_STACK_BF16")) : 1;
+  if (bf16x3) {
+    const size_t lds = kWBf16Bytes + (size_t)kWaves * kWaveRing;
+    static const int per_cu = getenv("SEEDHIP_STACK_PERCU") ? atoi(getenv("SEEDHIP_STACK_PERCU")) : 2;
+    int grid;
+    decompose(p.T1, p.B, max_grid_for(per_cu), &p.spc, &p.items, &grid);
+    hipLaunchKernelGGL(stackconv_fwd_bf16_kernel, dim3(grid, 1, g->cout / 16), dim3(kThreads), lds, s, p);
+    return check_launch("stackconv_fwd_bf16_kernel");
+  }
   const size_t lds = kWFloats * sizeof(float) + (size_t)kWaves * kWaveRing;
   const int per_cu = (int)((160 * 1024) / lds) < 3 ? (int)((160 * 1024) / lds) : 3;
   int grid;
@@ -475,7 +767,11 @@ extern "C" int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* ge
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(stackconv::stackconv_wgrad_kernel, dim3(grid, 1, N / 16), dim3(stackconv::kThreads), lds, s, p);
+    static const int bf16x3 = getenv("SEEDHIP_STACK_BF16") ? atoi(getenv("SEEDHIP_STACK_BF16")) : 1;
+    if (bf16x3)
+      hipLaunchKernelGGL(stackconv::stackconv_wgrad_bf16_kernel, dim3(grid, 1, N / 16), dim3(stackconv::kThreads), lds, s, p);
+    else
+      hipLaunchKernelGGL(stackconv::stackconv_wgrad_kernel, dim3(grid, 1, N / 16), dim3(stackconv::kThreads), lds, s, p);
     rc = check_launch("stackconv_wgrad_kernel"); if (rc) return rc;
     reduce_slices(p.partial_w, grid, (long long)M * N, dw, s);
     if (dbias) reduce_slices(p.partial_b, grid, N, dbias, s);

@@ -449,3 +449,47 @@ def test_stack_conv_parity(device, T1, B, cout):
   gw = wt.grad.numpy()
   assert np.max(np.abs(dw.cpu().numpy() - gw)) <= 3e-4 * max(1.0, np.abs(gw).max())
   assert np.max(np.abs(db.cpu().numpy() - bt.grad.numpy())) <= 3e-4 * max(1.0, np.abs(bt.grad.numpy()).max())
+
+
+def test_stack_conv_fwd_fp32_accuracy(device):
+  """The bf16x3 forward (exact operand split, fp32 accumulate on the bf16 matrix pipe) must be as close to the
+  fp64 ground truth as an fp32 evaluation is: its max error may not exceed 2x that of torch's fp32 conv on the
+  same inputs (both are fp32-summation-order noise, ~1e-6 of the output scale)."""
+  from seed_rl_amd import ops
+  T1, B, cout = 6, 5, 16
+  u = synth.atari_unroll(3, T1, B, done_p=0.1, zero_state=False)
+  stacked, _ = frames_np.stack_frames(u['frames'], u['frame_state'], u['done'], 4)
+  rng = np.random.default_rng(1)
+  w = (rng.normal(size=(8, 8, 4, cout)) / 16).astype(np.float32)
+  b = rng.normal(size=cout).astype(np.float32)
+  x32 = torch.tensor(stacked / np.float32(255)).reshape(T1 * B, 84, 84, 4)
+  y32 = nets_torch.conv2d(x32, torch.tensor(w), torch.tensor(b), 4, 'valid').numpy()
+  y64 = nets_torch.conv2d(torch.tensor(stacked.astype(np.float64) / 255.0).reshape(T1 * B, 84, 84, 4),
+                          torch.tensor(w.astype(np.float64)), torch.tensor(b.astype(np.float64)), 4, 'valid').numpy()
+  HW = 84 * 84
+  ext = torch.zeros((T1 + 3, B, HW), dtype=torch.uint8, device=device)
+  ext[3:] = dev(u['frames'].reshape(T1, B, HW), device)
+  nv = torch.zeros((T1, B), dtype=torch.uint8, device=device)
+  ops.stack_prepare(dev(u['frame_state'], device), dev(u['done'].astype(np.uint8), device), T1, B, HW, ext, nv)
+  g = ops.StackConvGeom(T1, B, 84, 84, 20, 20, 8, 8, 4, cout, cout)
+  out = torch.empty((T1 * B, 20, 20, cout), device=device)
+  ops.conv2d_stack_fwd(g, ext, nv, dev(w, device), dev(b, device), out, out_relu=False)
+  err_hip = np.max(np.abs(out.cpu().numpy().astype(np.float64) - y64))
+  err_f32 = np.max(np.abs(y32.astype(np.float64) - y64))
+  scale = np.abs(y64).max()
+  assert err_hip <= max(2.0 * err_f32, 2e-6 * scale), (err_hip, err_f32, scale)
+
+  # weight gradient: dW = X^T dY with dY split exactly into three bf16 parts
+  dy = rng.normal(size=y32.shape).astype(np.float32)
+  x64 = torch.tensor(stacked.astype(np.float64) / 255.0).reshape(T1 * B, 84, 84, 4)
+  w64 = torch.tensor(w.astype(np.float64), requires_grad=True)
+  nets_torch.conv2d(x64, w64, None, 4, 'valid').backward(torch.tensor(dy.astype(np.float64)))
+  w32 = torch.tensor(w, requires_grad=True)
+  nets_torch.conv2d(x32, w32, None, 4, 'valid').backward(torch.tensor(dy))
+  dw = torch.empty(w.shape, device=device); db = torch.empty(b.shape, device=device)
+  ws = torch.empty(ops.conv2d_stack_bwd_weight_workspace_bytes(g) // 4 + 1, device=device)
+  ops.conv2d_stack_bwd_weight(g, ext, nv, dev(dy, device), dw, db, ws)
+  g64 = w64.grad.numpy()
+  e_hip = np.max(np.abs(dw.cpu().numpy().astype(np.float64) - g64))
+  e_f32 = np.max(np.abs(w32.grad.numpy().astype(np.float64) - g64))
+  assert e_hip <= max(2.0 * e_f32, 2e-6 * np.abs(g64).max()), (e_hip, e_f32, np.abs(g64).max())
