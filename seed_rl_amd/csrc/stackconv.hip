@@ -283,24 +283,37 @@ stackconv_fwd_bf16_kernel(const Params p) {
       f32x4_t acc[kMT];
 #pragma unroll
       for (int m = 0; m < kMT; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      for (int c = 0; c < nv; ++c) {
-        const unsigned char* base = myring + ((t + 3 - c) % kSlots) * kBandBytes;
+      // k-groups G = 2c + half, c < nv; the LDS reads of group G+1 are issued before the MFMAs of group G
+      const int nG = 2 * nv;
+      Frag8 wfN[3];
+      uint32_t dN[kMT][2];
+      auto fetch = [&](int G) {
+        const unsigned char* base = myring + ((t + 3 - (G >> 1)) % kSlots) * kBandBytes + (G & 1) * 4 * kIW;
+        const uint4* wl = w_lds + (G * 3) * 64 + lane;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const uint4* wl = w_lds + ((c * 2 + half) * 3) * 64 + lane;
-          Frag8 wf[3];
+        for (int s3 = 0; s3 < 3; ++s3) wfN[s3].u = wl[s3 * 64];
 #pragma unroll
-          for (int s3 = 0; s3 < 3; ++s3) wf[s3].u = wl[s3 * 64];
+        for (int m = 0; m < kMT; ++m) {
+          const uint32_t* src = reinterpret_cast<const uint32_t*>(base + aoff[m]);
+          dN[m][0] = src[0]; dN[m][1] = src[1];
+        }
+      };
+      if (nG > 0) fetch(0);
+      for (int G = 0; G < nG; ++G) {
+        Frag8 wf[3];
+        uint32_t d[kMT][2];
 #pragma unroll
-          for (int m = 0; m < kMT; ++m) {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(base + aoff[m] + half * 4 * kIW);
-            const uint32_t d0 = src[0], d1 = src[1];
-            Frag8 xf;
-            xf.u = make_uint4(bf16_pair<0, 1>(d0), bf16_pair<2, 3>(d0), bf16_pair<0, 1>(d1), bf16_pair<2, 3>(d1));
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2].v, xf.v, acc[m], 0, 0, 0);     // lo, mid, hi
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1].v, xf.v, acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0].v, xf.v, acc[m], 0, 0, 0);
-          }
+        for (int s3 = 0; s3 < 3; ++s3) wf[s3] = wfN[s3];
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) { d[m][0] = dN[m][0]; d[m][1] = dN[m][1]; }
+        if (G + 1 < nG) fetch(G + 1);
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) {
+          Frag8 xf;
+          xf.u = make_uint4(bf16_pair<0, 1>(d[m][0]), bf16_pair<2, 3>(d[m][0]), bf16_pair<0, 1>(d[m][1]), bf16_pair<2, 3>(d[m][1]));
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2].v, xf.v, acc[m], 0, 0, 0);     // lo, mid, hi
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1].v, xf.v, acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0].v, xf.v, acc[m], 0, 0, 0);
         }
       }
 #pragma unroll
