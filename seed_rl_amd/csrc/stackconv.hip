@@ -200,7 +200,7 @@ stackconv_fwd_kernel(const Params p) {
 }
 
 // ------------------------------------------------------------------------------------ //
-// Forward on the bf16 matrix pipe, exact: "bf16x3".
+// The bf16 matrix pipe, exact: "bf16x3" (forward kernel further down, weight gradient next).
 // The layer's inputs are uint8 pixels: every value 0..255 is EXACT in bf16 (8 significant bits).  An fp32 weight
 // is the EXACT sum of three bf16 numbers, w = hi + mid + lo (8 + 8 + 8 significant bits, same exponent range as
 // fp32).  So x * w = x*hi + x*mid + x*lo with every product exact (8 x 8 bits) and the accumulation in fp32 inside
@@ -208,131 +208,18 @@ stackconv_fwd_kernel(const Params p) {
 // 3/16 of its matrix-pipe time (the bf16 MFMA does 16x the MACs per cycle).  This is not a reduced-precision
 // path: no operand is rounded (tests/test_gpu_kernels.py checks it at the fp32 tolerance, tests/test_bf16_split.py
 // checks hi + mid + lo == w bit for bit).
-//   k-group G = (c, half): 32 k = lane group kq (ky = 4*half + kq) x 8 horizontally adjacent pixels (kx = 0..7)
-//   B operand (cols = 16 pixels): 8 consecutive frame bytes = two ds_read_b32 -> 8 bf16 (v_cvt_f32_ubyte + v_perm)
-//   A operand (rows = 16 channels): W/255 split, LDS image [G][split][lane] x 16 bytes, one ds_read_b128 each
-//   3 MFMAs per (G, pixel tile) instead of 8 fp32 MFMAs of twice the duration.
+// Measured on MI355X (T=20, B=512): forward 0.43 -> 0.16 ms, weight gradient 0.43 -> 0.31 ms against the fp32-MFMA
+// kernels above (kept: SEEDHIP_STACK_BF16=0 selects them for A/B runs).
 // ------------------------------------------------------------------------------------ //
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 union Frag8 { uint4 u; bf16x8_t v; };
 constexpr int kGroups = 8;
-constexpr int kWBf16Bytes = kGroups * 3 * 64 * 16;                   // 24 KB
 
 // two bytes (a, b) of w -> packed bf16 pair (low half = byte a): exact, float(n) of n < 256 has zero low mantissa
 template <int A, int B>
 __device__ __forceinline__ uint32_t bf16_pair(uint32_t w) {
   const uint32_t f0 = __float_as_uint(ubyte(w, A)), f1 = __float_as_uint(ubyte(w, B));
   return __builtin_amdgcn_perm(f1, f0, 0x07060302u);
-}
-
-__global__ void __launch_bounds__(kThreads)
-stackconv_fwd_bf16_kernel(const Params p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint4* w_lds = reinterpret_cast<uint4*>(smem);                     // [G][split][lane]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned char* myring = smem + kWBf16Bytes + wave * kWaveRing;
-  const int kq = lane >> 4, j = lane & 15;
-  const int co0 = blockIdx.z * 16;
-
-  // ---- W/255 -> three bf16 images in LDS (each thread splits whole (G, lane) rows of 8 k) ----
-  for (int idx = tid; idx < kGroups * 64; idx += kThreads) {
-    const int l = idx & 63, G = idx >> 6, c = G >> 1, half = G & 1;
-    const int ky = 4 * half + (l >> 4), co = co0 + (l & 15);
-    uint32_t part[3][4];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float w = p.w[((ky * 8 + e) * 4 + c) * p.cout + co] / 255.0f;
-      const uint32_t hi = __float_as_uint(w) >> 16;                   // exact split by truncation (see split3_pack)
-      const float r1 = w - __uint_as_float(hi << 16);
-      const uint32_t mid = __float_as_uint(r1) >> 16;
-      const uint32_t lo = __float_as_uint(r1 - __uint_as_float(mid << 16)) >> 16;
-      const uint32_t v[3] = {hi, mid, lo};
-#pragma unroll
-      for (int s3 = 0; s3 < 3; ++s3) {
-        if (e & 1) part[s3][e >> 1] |= v[s3] << 16; else part[s3][e >> 1] = v[s3];
-      }
-    }
-#pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3)
-      w_lds[(G * 3 + s3) * 64 + l] = make_uint4(part[s3][0], part[s3][1], part[s3][2], part[s3][3]);
-  }
-  f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias) {
-    const float4 bv = *reinterpret_cast<const float4*>(p.bias + co0 + 4 * kq);
-    bias4 = f32x4_t{bv.x, bv.y, bv.z, bv.w};
-  }
-  int aoff[kMT];
-#pragma unroll
-  for (int m = 0; m < kMT; ++m) {
-    const int pix = m * 16 + j;                       // 0..79 within the band
-    const int oy = pix / kOW, ox = pix - oy * kOW;
-    aoff[m] = (oy * 4 + kq) * kIW + ox * 4;
-  }
-  __syncthreads();                                    // weights visible; the only workgroup barrier
-
-  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
-    const int b = item % p.B, chunk = item / p.B;
-    const int t0 = chunk * p.spc;
-    const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
-    band_prologue(p, myring, b, t0, wave, lane);
-    for (int t = t0; t < t1; ++t) {
-      const bool more = t + 1 < t1;
-      BandPrefetch pf;
-      if (more) pf = band_load(band_src(p, t + 4, b, wave), lane);
-      const int nv = p.nvalid[(long long)t * p.B + b];
-      f32x4_t acc[kMT];
-#pragma unroll
-      for (int m = 0; m < kMT; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      // k-groups G = 2c + half, c < nv; the LDS reads of group G+1 are issued before the MFMAs of group G
-      const int nG = 2 * nv;
-      Frag8 wfN[3];
-      uint32_t dN[kMT][2];
-      auto fetch = [&](int G) {
-        const unsigned char* base = myring + ((t + 3 - (G >> 1)) % kSlots) * kBandBytes + (G & 1) * 4 * kIW;
-        const uint4* wl = w_lds + (G * 3) * 64 + lane;
-#pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) wfN[s3].u = wl[s3 * 64];
-#pragma unroll
-        for (int m = 0; m < kMT; ++m) {
-          const uint32_t* src = reinterpret_cast<const uint32_t*>(base + aoff[m]);
-          dN[m][0] = src[0]; dN[m][1] = src[1];
-        }
-      };
-      if (nG > 0) fetch(0);
-      for (int G = 0; G < nG; ++G) {
-        Frag8 wf[3];
-        uint32_t d[kMT][2];
-#pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) wf[s3] = wfN[s3];
-#pragma unroll
-        for (int m = 0; m < kMT; ++m) { d[m][0] = dN[m][0]; d[m][1] = dN[m][1]; }
-        if (G + 1 < nG) fetch(G + 1);
-#pragma unroll
-        for (int m = 0; m < kMT; ++m) {
-          Frag8 xf;
-          xf.u = make_uint4(bf16_pair<0, 1>(d[m][0]), bf16_pair<2, 3>(d[m][0]), bf16_pair<0, 1>(d[m][1]), bf16_pair<2, 3>(d[m][1]));
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2].v, xf.v, acc[m], 0, 0, 0);     // lo, mid, hi
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1].v, xf.v, acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0].v, xf.v, acc[m], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int m = 0; m < kMT; ++m) {
-        const int pix = wave * 80 + m * 16 + j;
-        f32x4_t v = acc[m] + bias4;
-        if (p.out_relu) {
-          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-        }
-        float* o = p.out + (((long long)t * p.B + b) * 400 + pix) * p.ld_out + co0 + 4 * kq;
-        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-      }
-      if (more) {
-        wave_lds_fence();                              // this wave's reads of frame t are done
-        band_store(myring + ((t + 4) % kSlots) * kBandBytes, pf, lane);
-        wave_lds_fence();
-      }
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------ //
@@ -622,6 +509,144 @@ stackconv_wgrad_bf16_kernel(const Params p) {
 }
 
 // ------------------------------------------------------------------------------------ //
+// bf16x3 forward.  The wave's band ring holds bf16: each frame byte is converted ONCE, when its band is staged
+// (u8 -> bf16 is exact), instead of at each of its ~16 uses (4 stack positions x 2 x 2 overlapping windows).
+//   k-group G = (c, half): 32 k = lane group kq (ky = 4*half + kq) x 8 horizontally adjacent pixels (kx = 0..7)
+//   B operand (cols = 16 pixels): 8 consecutive bf16 of the band = two ds_read_b64, no conversion in the loop
+//   A operand (rows = 16 channels): W/255 split; hi and mid parts live in registers (8 groups x 2 x 4 VGPRs), the lo
+//     parts in LDS (8 KB, one ds_read_b128 per group) -- all three in registers spill at 3 waves per SIMD
+//   3 MFMAs per (G, pixel tile) instead of 8 fp32 MFMAs of twice the duration.
+// (The weight gradient keeps the uint8 ring and converts at use: its A operand gathers one byte per pixel, and a
+// bf16-ring variant needed 16 more VGPRs than fit next to its 64 accumulator registers.)
+// ------------------------------------------------------------------------------------ //
+constexpr int kBand16 = kBandBytes * 2;                  // 3360 B: one band slot in bf16
+constexpr int kWaveRing16 = kSlots * kBand16;            // 13440 B per wave
+
+// 16 frame bytes -> 16 bf16 (two uint4)
+__device__ __forceinline__ void cvt16(const uint4& v, uint4& lo, uint4& hi) {
+  lo = make_uint4(bf16_pair<0, 1>(v.x), bf16_pair<2, 3>(v.x), bf16_pair<0, 1>(v.y), bf16_pair<2, 3>(v.y));
+  hi = make_uint4(bf16_pair<0, 1>(v.z), bf16_pair<2, 3>(v.z), bf16_pair<0, 1>(v.w), bf16_pair<2, 3>(v.w));
+}
+__device__ __forceinline__ void band_store16(unsigned char* slot, const BandPrefetch& r, int lane) {
+  uint4* dst = reinterpret_cast<uint4*>(slot);
+  uint4 a, b;
+  cvt16(r.v0, a, b);
+  dst[2 * lane] = a; dst[2 * lane + 1] = b;
+  if (lane + 64 < kBandVec) {
+    cvt16(r.v1, a, b);
+    dst[2 * (lane + 64)] = a; dst[2 * (lane + 64) + 1] = b;
+  }
+}
+__device__ __forceinline__ void band_prologue16(const Params& p, unsigned char* myring, int b, int t0, int wave, int lane) {
+  BandPrefetch f[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) f[e] = band_load(band_src(p, t0 + e, b, wave), lane);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) band_store16(myring + ((t0 + e) % kSlots) * kBand16, f[e], lane);
+  wave_lds_fence();
+}
+
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
+stackconv_fwd_bf16r_kernel(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint4* wlo_lds = reinterpret_cast<uint4*>(smem);                   // [G][lane]: the lo parts (8 KB); hi, mid in registers
+  unsigned char* myring = smem + kGroups * 64 * 16 + wave * kWaveRing16;
+  const int kq = lane >> 4, j = lane & 15;
+  const int co0 = blockIdx.z * 16;
+
+  // ---- W/255 -> three bf16 parts, in registers: wreg[G][part] = 8 k (kx = 0..7) of row ky = 4*half + kq ----
+  Frag8 wreg[kGroups][2];
+#pragma unroll
+  for (int G = 0; G < kGroups; ++G) {
+    const int c = G >> 1, ky = 4 * (G & 1) + kq;
+    uint32_t part[3][4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float w = p.w[((ky * 8 + e) * 4 + c) * p.cout + co0 + j] / 255.0f;
+      const uint32_t hi = __float_as_uint(w) >> 16;                   // exact split by truncation (see split3_pack)
+      const float r1 = w - __uint_as_float(hi << 16);
+      const uint32_t mid = __float_as_uint(r1) >> 16;
+      const uint32_t lo = __float_as_uint(r1 - __uint_as_float(mid << 16)) >> 16;
+      const uint32_t v[3] = {hi, mid, lo};
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        if (e & 1) part[s3][e >> 1] |= v[s3] << 16; else part[s3][e >> 1] = v[s3];
+      }
+    }
+#pragma unroll
+    for (int s3 = 0; s3 < 2; ++s3) wreg[G][s3].u = make_uint4(part[s3][0], part[s3][1], part[s3][2], part[s3][3]);
+    if (wave == 0) wlo_lds[G * 64 + lane] = make_uint4(part[2][0], part[2][1], part[2][2], part[2][3]);
+  }
+  f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+    const float4 bv = *reinterpret_cast<const float4*>(p.bias + co0 + 4 * kq);
+    bias4 = f32x4_t{bv.x, bv.y, bv.z, bv.w};
+  }
+  int aoff[kMT];                                      // byte offset of (tile m, pixel j, row kq) inside a bf16 band slot
+#pragma unroll
+  for (int m = 0; m < kMT; ++m) {
+    const int pix = m * 16 + j;
+    const int oy = pix / kOW, ox = pix - oy * kOW;
+    aoff[m] = ((oy * 4 + kq) * kIW + ox * 4) * 2;
+  }
+  __syncthreads();                                    // lo parts visible; the only workgroup barrier
+
+  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+    const int b = item % p.B, chunk = item / p.B;
+    const int t0 = chunk * p.spc;
+    const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
+    band_prologue16(p, myring, b, t0, wave, lane);
+    for (int t = t0; t < t1; ++t) {
+      const bool more = t + 1 < t1;
+      BandPrefetch pf;
+      if (more) pf = band_load(band_src(p, t + 4, b, wave), lane);
+      const int nv = p.nvalid[(long long)t * p.B + b];
+      f32x4_t acc[kMT];
+#pragma unroll
+      for (int m = 0; m < kMT; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      auto group = [&](int G) {                       // G static after unrolling: weights stay in registers
+        const unsigned char* base = myring + ((t + 3 - (G >> 1)) % kSlots) * kBand16 + (G & 1) * 4 * kIW * 2;
+        Frag8 wlo;
+        wlo.u = wlo_lds[G * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) {
+          const uint2* src = reinterpret_cast<const uint2*>(base + aoff[m]);
+          const uint2 x0 = src[0], x1 = src[1];
+          Frag8 xf;
+          xf.u = make_uint4(x0.x, x0.y, x1.x, x1.y);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo.v, xf.v, acc[m], 0, 0, 0);            // lo, mid, hi
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[G][1].v, xf.v, acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[G][0].v, xf.v, acc[m], 0, 0, 0);
+        }
+      };
+      if (nv == 4) {                                   // the common case: one straight-line block of 8 k-groups
+#pragma unroll
+        for (int G = 0; G < kGroups; ++G) group(G);
+      } else {
+#pragma unroll
+        for (int G = 0; G < kGroups; ++G) if (G < 2 * nv) group(G);
+      }
+#pragma unroll
+      for (int m = 0; m < kMT; ++m) {
+        const int pix = wave * 80 + m * 16 + j;
+        f32x4_t v = acc[m] + bias4;
+        if (p.out_relu) {
+          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        }
+        float* o = p.out + (((long long)t * p.B + b) * 400 + pix) * p.ld_out + co0 + 4 * kq;
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+      if (more) {
+        wave_lds_fence();                              // this wave's reads of frame t are done
+        band_store16(myring + ((t + 4) % kSlots) * kBand16, pf, lane);
+        wave_lds_fence();
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ //
 // Host side: eligibility, work decomposition, launch.
 // ------------------------------------------------------------------------------------ //
 bool eligible(const seedhip_stack_conv_geom* g, const void* frames_ext, const void* io) {
@@ -672,12 +697,12 @@ int launch_fwd(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, cons
   p.w = w; p.bias = bias; p.out = out; p.out_relu = out_relu;
   static const int bf16x3 = getenv("SEEDHIP_STACK_BF16") ? atoi(getenv("SEEDHIP_STACK_BF16")) : 1;
   if (bf16x3) {
-    const size_t lds = kWBf16Bytes + (size_t)kWaves * kWaveRing;
-    static const int per_cu = getenv("SEEDHIP_STACK_PERCU") ? atoi(getenv("SEEDHIP_STACK_PERCU")) : 2;
+    const size_t lds = (size_t)kGroups * 64 * 16 + (size_t)kWaves * kWaveRing16;
     int grid;
-    decompose(p.T1, p.B, max_grid_for(per_cu), &p.spc, &p.items, &grid);
-    hipLaunchKernelGGL(stackconv_fwd_bf16_kernel, dim3(grid, 1, g->cout / 16), dim3(kThreads), lds, s, p);
-    return check_launch("stackconv_fwd_bf16_kernel");
+    decompose(p.T1, p.B, max_grid_for(2), &p.spc, &p.items, &grid);
+    (void)hipFuncSetAttribute((const void*)stackconv_fwd_bf16r_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(stackconv_fwd_bf16r_kernel, dim3(grid, 1, g->cout / 16), dim3(kThreads), lds, s, p);
+    return check_launch("stackconv_fwd_bf16r_kernel");
   }
   const size_t lds = kWFloats * sizeof(float) + (size_t)kWaves * kWaveRing;
   const int per_cu = (int)((160 * 1024) / lds) < 3 ? (int)((160 * 1024) / lds) : 3;
