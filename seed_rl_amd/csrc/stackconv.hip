@@ -208,7 +208,7 @@ stackconv_fwd_kernel(const Params p) {
 // 3/16 of its matrix-pipe time (the bf16 MFMA does 16x the MACs per cycle).  This is not a reduced-precision
 // path: no operand is rounded (tests/test_gpu_kernels.py checks it at the fp32 tolerance, tests/test_bf16_split.py
 // checks hi + mid + lo == w bit for bit).
-// Measured on MI355X (T=20, B=512): forward 0.43 -> 0.16 ms, weight gradient 0.43 -> 0.31 ms against the fp32-MFMA
+// Measured on MI355X (T=20, B=512): forward 0.43 -> 0.16 ms, weight gradient 0.43 -> 0.27 ms against the fp32-MFMA
 // kernels above (kept: SEEDHIP_STACK_BF16=0 selects them for A/B runs).
 // ------------------------------------------------------------------------------------ //
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -354,17 +354,15 @@ stackconv_wgrad_kernel(const Params p) {
 // v_mfma_f32_16x16x32_bf16 reduces 32 pixels per instruction: lane group kq owns pixel chunk ch = 4g + kq of the
 // band = 2 output rows x 4 pixels ((2rp + a, 4xc + b), element e = 4a + b; 10 chunks per band, chunks 10 and 11
 // of the third group are zero padding).
-//   A (rows = 16 k-rows of m-tile (c, q); row i = (ky = i>>1, kx = 4(i&1) + q)): byte q of the 8 dwords
-//     frame_{t-c}[(8rp + 4a + ky)*84 + 16xc + 4b + 4(i&1)]: 8 ds_read_b32 serve the four m-tiles q = 0..3
+//   A (rows = 16 k-rows of m-tile (c, q); row i = (ky = i>>1, kx = 4(i&1) + q)): the band ring holds bf16 (converted
+//     once at staging, as in the forward); pixel (a, b) contributes halfword q of the 8 bytes at band element
+//     (8rp + 4a + ky)*84 + 16xc + 4b + 4(i&1): 8 ds_read_b64 serve the four m-tiles q = 0..3, one v_perm joins each
+//     pair of pixels (a uint8 ring with conversion at use was 12% slower)
 //   B (cols = 16 channels): dY[pixel e of chunk][co0 + j], 8 global dwords per lane and group, split once and
 //     used by the 16 m-tiles x 3 parts.
 // Channels c >= nvalid are skipped (forward: cumulative-OR done mask).  Accumulators, cross-wave reduction and
 // the partial-slice output are those of the fp32 kernel above.
 // ------------------------------------------------------------------------------------ //
-__device__ __forceinline__ uint32_t bf16_pair2(uint32_t wa, uint32_t wb, int q) {      // byte q of wa (low), wb (high)
-  const uint32_t f0 = __float_as_uint(ubyte(wa, q)), f1 = __float_as_uint(ubyte(wb, q));
-  return __builtin_amdgcn_perm(f1, f0, 0x07060302u);
-}
 // Exact split by TRUNCATION (cheaper than rounding, equally exact): hi = the top 8 significant bits of v, mid = the
 // top 8 of what is left, lo = the remaining <= 8 bits; hi + mid + lo == v bit for bit (tests/test_bf16_split.py).
 __device__ __forceinline__ void split3_pack(const float (&v)[8], Frag8 (&out)[3]) {
@@ -387,127 +385,6 @@ __device__ __forceinline__ void split3_pack(const float (&v)[8], Frag8 (&out)[3]
   for (int s3 = 0; s3 < 3; ++s3) out[s3].u = make_uint4(part[s3][0], part[s3][1], part[s3][2], part[s3][3]);
 }
 
-__global__ void __launch_bounds__(kThreads, 2)
-stackconv_wgrad_bf16_kernel(const Params p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* red = reinterpret_cast<float*>(smem);                       // [256 k_mem][16]
-  float* redb = red + kWFloats;                                      // [kWaves][16]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned char* myring = smem + (kWFloats + kWaves * 16) * sizeof(float) + wave * kWaveRing;
-  const int kq = lane >> 4, i = lane & 15;
-  const int co0 = blockIdx.z * 16;
-  constexpr int P = 400;
-
-  f32x4_t acc[16];
-#pragma unroll
-  for (int m = 0; m < 16; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
-
-  // per-lane chunk geometry of the three pixel groups: fixed for the whole launch
-  int a_off[3], dy_off[3];
-  bool valid[3];
-#pragma unroll
-  for (int g = 0; g < 3; ++g) {
-    const int ch = 4 * g + kq;
-    valid[g] = ch < 10;
-    const int rp = valid[g] ? ch / 5 : 0, xc = valid[g] ? ch % 5 : 0;
-    a_off[g] = (8 * rp + (i >> 1)) * kIW + 16 * xc + 4 * (i & 1);
-    dy_off[g] = (2 * rp * kOW + 4 * xc) * p.ld_out;
-  }
-  auto load_dy = [&](const float* band, int g, float (&v)[8]) {      // band: dY of this wave's 80 pixels, channel co0 + i
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-        v[4 * a + b] = valid[g] ? band[dy_off[g] + (a * kOW + b) * p.ld_out] : 0.f;
-  };
-
-  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
-    const int b = item % p.B, chunk = item / p.B;
-    const int t0 = chunk * p.spc;
-    const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
-    band_prologue(p, myring, b, t0, wave, lane);
-    float dyn[8];
-    load_dy(p.dy + (((long long)t0 * p.B + b) * P + wave * 80) * p.ld_out + co0 + i, 0, dyn);
-    for (int t = t0; t < t1; ++t) {
-      const bool more = t + 1 < t1;
-      BandPrefetch pf;
-      if (more) pf = band_load(band_src(p, t + 4, b, wave), lane);
-      const int nv = p.nvalid[(long long)t * p.B + b];
-      const float* dy_band = p.dy + (((long long)t * p.B + b) * P + wave * 80) * p.ld_out + co0 + i;
-#pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        Frag8 bf[3];
-        {
-          float dyv[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { dyv[e] = dyn[e]; bsum += dyn[e]; }
-          split3_pack(dyv, bf);
-        }
-        // dY of the next group (next step's first group at the end of a step) flies under this group's MFMAs
-        if (g < 2) load_dy(dy_band, g + 1, dyn);
-        else if (more) load_dy(dy_band + (long long)p.B * P * p.ld_out, 0, dyn);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {                       // unrolled: accumulator indices stay static
-          if (c >= nv) continue;                            // wave-uniform
-          const unsigned char* src = myring + ((t + 3 - c) % kSlots) * kBandBytes + a_off[g];
-          uint32_t d[2][4];
-#pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb)
-              d[a][bb] = *reinterpret_cast<const uint32_t*>(src + a * 4 * kIW + 4 * bb);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            Frag8 xa;
-            xa.u = make_uint4(bf16_pair2(d[0][0], d[0][1], q), bf16_pair2(d[0][2], d[0][3], q),
-                              bf16_pair2(d[1][0], d[1][1], q), bf16_pair2(d[1][2], d[1][3], q));
-            f32x4_t v = acc[c * 4 + q];
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v, bf[2].v, v, 0, 0, 0);
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v, bf[1].v, v, 0, 0, 0);
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v, bf[0].v, v, 0, 0, 0);
-            acc[c * 4 + q] = v;
-          }
-        }
-      }
-      if (more) {
-        wave_lds_fence();
-        band_store(myring + ((t + 4) % kSlots) * kBandBytes, pf, lane);
-        wave_lds_fence();
-      }
-    }
-  }
-
-  // Cross-wave reduction in wave order (deterministic), then one partial slice per workgroup.
-  bsum += __shfl_xor(bsum, 16, 64);
-  bsum += __shfl_xor(bsum, 32, 64);
-  if (lane < 16) redb[wave * 16 + lane] = bsum;
-  for (int w = 0; w < kWaves; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        const int c = m >> 2, q = m & 3;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 4 * kq + r;                       // k-row within the m-tile
-          const int ky = row >> 1, kx = 4 * (row & 1) + q;
-          const int idx = ((ky * 8 + kx) * 4 + c) * 16 + i;
-          red[idx] = (w == 0) ? acc[m][r] : red[idx] + acc[m][r];
-        }
-      }
-    }
-    __syncthreads();
-  }
-  float* pw = p.partial_w + (long long)blockIdx.x * 256 * p.cout;
-  for (int idx = tid; idx < kWFloats; idx += kThreads)
-    pw[(idx >> 4) * p.cout + co0 + (idx & 15)] = red[idx] / 255.0f;
-  if (p.partial_b && tid < 16) {
-    float s = 0.f;
-    for (int w = 0; w < kWaves; ++w) s += redb[w * 16 + tid];
-    p.partial_b[(long long)blockIdx.x * p.cout + co0 + tid] = s;
-  }
-}
-
 // ------------------------------------------------------------------------------------ //
 // bf16x3 forward.  The wave's band ring holds bf16: each frame byte is converted ONCE, when its band is staged
 // (u8 -> bf16 is exact), instead of at each of its ~16 uses (4 stack positions x 2 x 2 overlapping windows).
@@ -516,8 +393,6 @@ stackconv_wgrad_bf16_kernel(const Params p) {
 //   A operand (rows = 16 channels): W/255 split; hi and mid parts live in registers (8 groups x 2 x 4 VGPRs), the lo
 //     parts in LDS (8 KB, one ds_read_b128 per group) -- all three in registers spill at 3 waves per SIMD
 //   3 MFMAs per (G, pixel tile) instead of 8 fp32 MFMAs of twice the duration.
-// (The weight gradient keeps the uint8 ring and converts at use: its A operand gathers one byte per pixel, and a
-// bf16-ring variant needed 16 more VGPRs than fit next to its 64 accumulator registers.)
 // ------------------------------------------------------------------------------------ //
 constexpr int kBand16 = kBandBytes * 2;                  // 3360 B: one band slot in bf16
 constexpr int kWaveRing16 = kSlots * kBand16;            // 13440 B per wave
@@ -646,6 +521,133 @@ stackconv_fwd_bf16r_kernel(const Params p) {
   }
 }
 
+__global__ void __launch_bounds__(kThreads, 2)
+stackconv_wgrad_bf16_kernel(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);                       // overlays the rings after the time loops
+  float* redb = red + kWFloats;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char* myring = smem + wave * kWaveRing16;
+  const int kq = lane >> 4, i = lane & 15;
+  const int co0 = blockIdx.z * 16;
+  constexpr int P = 400;
+
+  f32x4_t acc[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  // per-lane chunk geometry of the three pixel groups: fixed for the whole launch
+  int a_off[3], dy_off[3];
+  bool valid[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const int ch = 4 * g + kq;
+    valid[g] = ch < 10;
+    const int rp = valid[g] ? ch / 5 : 0, xc = valid[g] ? ch % 5 : 0;
+    a_off[g] = ((8 * rp + (i >> 1)) * kIW + 16 * xc + 4 * (i & 1)) * 2;
+    dy_off[g] = (2 * rp * kOW + 4 * xc) * p.ld_out;
+  }
+  auto load_dy = [&](const float* band, int g, float (&v)[8]) {      // band: dY of this wave's 80 pixels, channel co0 + i
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        v[4 * a + b] = valid[g] ? band[dy_off[g] + (a * kOW + b) * p.ld_out] : 0.f;
+  };
+
+  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+    const int b = item % p.B, chunk = item / p.B;
+    const int t0 = chunk * p.spc;
+    const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
+    band_prologue16(p, myring, b, t0, wave, lane);
+    float dyn[8];
+    load_dy(p.dy + (((long long)t0 * p.B + b) * P + wave * 80) * p.ld_out + co0 + i, 0, dyn);
+    for (int t = t0; t < t1; ++t) {
+      const bool more = t + 1 < t1;
+      BandPrefetch pf;
+      if (more) pf = band_load(band_src(p, t + 4, b, wave), lane);
+      const int nv = p.nvalid[(long long)t * p.B + b];
+      const float* dy_band = p.dy + (((long long)t * p.B + b) * P + wave * 80) * p.ld_out + co0 + i;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        Frag8 bf[3];
+        {
+          float dyv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { dyv[e] = dyn[e]; bsum += dyn[e]; }
+          split3_pack(dyv, bf);
+        }
+        // dY of the next group (next step's first group at the end of a step) flies under this group's MFMAs
+        if (g < 2) load_dy(dy_band, g + 1, dyn);
+        else if (more) load_dy(dy_band + (long long)p.B * P * p.ld_out, 0, dyn);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                       // unrolled: accumulator indices stay static
+          if (c >= nv) continue;                            // wave-uniform
+          const unsigned char* src = myring + ((t + 3 - c) % kSlots) * kBand16 + a_off[g];
+          uint2 d[2][4];
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+              d[a][bb] = *reinterpret_cast<const uint2*>(src + (a * 4 * kIW + 4 * bb) * 2);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t sel = (q & 1) ? 0x07060302u : 0x05040100u;
+            Frag8 xa;
+            if (q < 2)
+              xa.u = make_uint4(__builtin_amdgcn_perm(d[0][1].x, d[0][0].x, sel), __builtin_amdgcn_perm(d[0][3].x, d[0][2].x, sel),
+                                __builtin_amdgcn_perm(d[1][1].x, d[1][0].x, sel), __builtin_amdgcn_perm(d[1][3].x, d[1][2].x, sel));
+            else
+              xa.u = make_uint4(__builtin_amdgcn_perm(d[0][1].y, d[0][0].y, sel), __builtin_amdgcn_perm(d[0][3].y, d[0][2].y, sel),
+                                __builtin_amdgcn_perm(d[1][1].y, d[1][0].y, sel), __builtin_amdgcn_perm(d[1][3].y, d[1][2].y, sel));
+            f32x4_t v = acc[c * 4 + q];
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v, bf[2].v, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v, bf[1].v, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v, bf[0].v, v, 0, 0, 0);
+            acc[c * 4 + q] = v;
+          }
+        }
+      }
+      if (more) {
+        wave_lds_fence();
+        band_store16(myring + ((t + 4) % kSlots) * kBand16, pf, lane);
+        wave_lds_fence();
+      }
+    }
+  }
+
+  // Cross-wave reduction in wave order (deterministic), then one partial slice per workgroup.
+  __syncthreads();                                         // every wave is done with its ring: red may overlay it
+  bsum += __shfl_xor(bsum, 16, 64);
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (lane < 16) redb[wave * 16 + lane] = bsum;
+  for (int w = 0; w < kWaves; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int c = m >> 2, q = m & 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * kq + r;                       // k-row within the m-tile
+          const int ky = row >> 1, kx = 4 * (row & 1) + q;
+          const int idx = ((ky * 8 + kx) * 4 + c) * 16 + i;
+          red[idx] = (w == 0) ? acc[m][r] : red[idx] + acc[m][r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* pw = p.partial_w + (long long)blockIdx.x * 256 * p.cout;
+  for (int idx = tid; idx < kWFloats; idx += kThreads)
+    pw[(idx >> 4) * p.cout + co0 + (idx & 15)] = red[idx] / 255.0f;
+  if (p.partial_b && tid < 16) {
+    float s = 0.f;
+    for (int w = 0; w < kWaves; ++w) s += redb[w * 16 + tid];
+    p.partial_b[(long long)blockIdx.x * p.cout + co0 + tid] = s;
+  }
+}
+
 // ------------------------------------------------------------------------------------ //
 // Host side: eligibility, work decomposition, launch.
 // ------------------------------------------------------------------------------------ //
@@ -721,6 +723,9 @@ int wgrad_grid(const seedhip_stack_conv_geom* g, int* spc, int* items) {
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 2) per_cu = 2;                     // measured: 2 workgroups per CU beat 3 (0.43 vs 0.48 ms at cfg2)
   if (per_cu < 1) per_cu = 1;
+  // the bf16x3 kernel needs ~250 VGPRs next to its 64 accumulators: one 5-wave workgroup per CU is resident
+  static const int bf16x3 = getenv("SEEDHIP_STACK_BF16") ? atoi(getenv("SEEDHIP_STACK_BF16")) : 1;
+  if (bf16x3) per_cu = 1;
   int grid;
   decompose(g->T, g->B, max_grid_for(per_cu), spc, items, &grid);
   return grid;
@@ -806,8 +811,12 @@ extern "C" int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* ge
       (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     static const int bf16x3 = getenv("SEEDHIP_STACK_BF16") ? atoi(getenv("SEEDHIP_STACK_BF16")) : 1;
-    if (bf16x3)
-      hipLaunchKernelGGL(stackconv::stackconv_wgrad_bf16_kernel, dim3(grid, 1, N / 16), dim3(stackconv::kThreads), lds, s, p);
+    if (bf16x3) {
+      const size_t lds16 = (size_t)stackconv::kWaves * stackconv::kWaveRing16;
+      (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_bf16_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+      hipLaunchKernelGGL(stackconv::stackconv_wgrad_bf16_kernel, dim3(grid, 1, N / 16), dim3(stackconv::kThreads), lds16, s, p);
+    }
     else
       hipLaunchKernelGGL(stackconv::stackconv_wgrad_kernel, dim3(grid, 1, N / 16), dim3(stackconv::kThreads), lds, s, p);
     rc = check_launch("stackconv_wgrad_kernel"); if (rc) return rc;
