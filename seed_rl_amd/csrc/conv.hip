@@ -140,8 +140,9 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
       return wsgemm::launch(wp, pl, (hipStream_t)stream);
     }
   }
-  if ((gemm_mode() & 32) && !is_dense(geom) && in_dtype == kInF32 && al16(in) && al16(w) && al16(out)) {
-    // 'valid' convs with 128-byte im2col segments on the GEMM core with a gathered A operand (gemm.h)
+  if ((gemm_mode() & 32) && !is_dense(geom) && geom->cout >= 64 && in_dtype == kInF32 && al16(in) && al16(w) && al16(out)) {
+    // convs with >= 64 output channels on the GEMM core with a gathered A operand (gemm.h).  Measured: narrower
+    // layers (the 16 / 32-channel ImpalaDeep convs) lose to the halo kernels below -- a 64-wide N tile is half empty
     gemm::Params gp;
     if (gemm::conv_fwd_setup(gp, geom)) {
       gp.A = (const float*)in; gp.a_relu = in_relu; gp.B = w; gp.C = out; gp.bias = bias; gp.residual = residual;
@@ -239,7 +240,7 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
       return wsgemm::launch(wp, pl, (hipStream_t)stream);
     }
   }
-  if ((gemm_mode() & 64) && !is_dense(geom) && al16(dy) && al16(w)) {
+  if ((gemm_mode() & 64) && !is_dense(geom) && geom->stride * geom->stride * geom->cin >= 64 && al16(dy) && al16(w)) {
     gemm::Params gp;
     if (gemm::conv_dgrad_setup(gp, geom)) {
       gp.A = dy; gp.B = w; gp.C = dx; gp.mask = relu_mask; gp.add = add;

@@ -31,17 +31,20 @@ namespace gemm {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-// A k-contiguous operand whose rows are GATHERED 128-byte segments instead of dense rows: the im2col row of a
-// 'valid' convolution (forward), the dY taps of a super-pixel (data gradient), the Keras kernel re-indexed by
-// (parity class, ci) (data gradient B).  Row x -> (q, a, b) by two divisions; k-tile t adds tile_off[t] and is zero
-// unless (a + tile_dy[t], b + tile_dx[t]) lies inside [0, vh) x [0, vw).
-constexpr int kMaxTiles = 32;
+// A k-contiguous operand whose rows are GATHERED instead of dense: the im2col row of a convolution (forward), the
+// dY taps of a (super-)pixel (data gradient), the Keras kernel re-indexed by (parity class, ci) (data gradient B).
+//   row x -> (u, v, w) by two divisions;  row base = const0 + u*s0 + v*s1 + w*s2
+//   k -> tap = k >> cshift (C = 1 << cshift contiguous floats per tap: the channels), tap -> (ty, tx) = divmod(tap, tw)
+//   element address = row base + ty*tsy + tx*tsx + (k & (C-1)); it reads as zero unless tap < ntaps and
+//   (y0 + ty*ey, x0 + tx*ex) lies inside [0, vh) x [0, vw), with (y0, x0) = (ya*cy + oy0, xb*cx + ox0) and
+//   (ya, xb) = (v, w) (or (u, v) when coord_uv): 'same' padding and map borders cost nothing but the predicate.
+// A 16-byte vector never straddles taps (C is a power of two >= 4).
 struct Gather {
-  FastDiv d1, d2;                           // x / d1 -> q, rem; rem / d2 -> a, b
-  long long s0; int s1, s2;                 // floats: row base = q*s0 + a*s1 + b*s2
-  int vh, vw, all_valid;
-  int tile_off[kMaxTiles];
-  signed char tile_dy[kMaxTiles], tile_dx[kMaxTiles];
+  FastDiv d1, d2, d_tw;
+  long long s0, const0; int s1, s2;
+  int coord_uv, cshift, ntaps;
+  int tsy, tsx;
+  int cy, oy0, ey, cx, ox0, ex, vh, vw, all_valid;
 };
 
 struct Params {
@@ -115,41 +118,47 @@ struct GatherStager {                        // KC only; same interface as Stage
   static constexpr int kVecs = BX * BK / 4 / 256;
   static constexpr int kLdOC = BX;
   static constexpr int kLdsFloats = BX * LD_KC;
-  const float* base[kVecs];
-  unsigned vmask[kVecs];
+  const float* base[kVecs];                  // row base + this thread's k offset inside a tile (null: row out of range)
+  int y0[kVecs], x0[kVecs];
   int lds_off[kVecs];
+  int kc;
   const Gather* g;
   float4 r[kVecs];
 
-  __device__ void init(const float* p, const Gather& gg, int nkt, int x0, int X, int tid) {
+  __device__ void init(const float* p, const Gather& gg, int /*nkt*/, int xbase, int X, int tid) {
     g = &gg;
+    kc = (tid & 7) * 4;
 #pragma unroll
     for (int i = 0; i < kVecs; ++i) {
-      const int v = tid + i * 256, row = v >> 3, kc = (v & 7) * 4;
+      const int v = tid + i * 256, row = v >> 3;
       lds_off[i] = row * LD_KC + kc;
       const float* b = nullptr;
-      unsigned mask = 0;
-      if (x0 + row < X) {
-        uint32_t q, rem, ya, xb;
-        gg.d1.divmod((uint32_t)(x0 + row), q, rem);
-        gg.d2.divmod(rem, ya, xb);
-        b = p + (long long)q * gg.s0 + (long long)ya * gg.s1 + (long long)xb * gg.s2 + kc;
-        if (gg.all_valid) mask = 0xffffffffu;
-        else for (int t = 0; t < nkt; ++t) {
-          const int y = (int)ya + gg.tile_dy[t], x = (int)xb + gg.tile_dx[t];
-          if (y >= 0 && y < gg.vh && x >= 0 && x < gg.vw) mask |= 1u << t;
-        }
+      int yy = 0, xx = 0;
+      if (xbase + row < X) {
+        uint32_t u, rem, vv, ww;
+        gg.d1.divmod((uint32_t)(xbase + row), u, rem);
+        gg.d2.divmod(rem, vv, ww);
+        b = p + gg.const0 + (long long)u * gg.s0 + (long long)vv * gg.s1 + (long long)ww * gg.s2;
+        yy = (int)(gg.coord_uv ? u : vv) * gg.cy + gg.oy0;
+        xx = (int)(gg.coord_uv ? vv : ww) * gg.cx + gg.ox0;
       }
-      base[i] = b; vmask[i] = mask;
+      base[i] = b; y0[i] = yy; x0[i] = xx;
     }
   }
-  __device__ void load(int k, int k1, bool relu) {       // k is a multiple of BK (no split-K on gathered operands)
-    const int kt = k / BK, off = g->tile_off[kt];
+  __device__ void load(int k, int k1, bool relu) {
+    const int kk = k + kc;                                  // same tap for all of this thread's vectors
+    const int tap = kk >> g->cshift, kin = kk & ((1 << g->cshift) - 1);
+    uint32_t ty, tx;
+    g->d_tw.divmod((uint32_t)tap, ty, tx);
+    const int toff = (int)ty * g->tsy + (int)tx * g->tsx + kin;
+    const int dy = (int)ty * g->ey, dx = (int)tx * g->ex;
+    const bool tap_ok = tap < g->ntaps;
 #pragma unroll
     for (int i = 0; i < kVecs; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((vmask[i] >> kt) & 1u) {
-        v = *reinterpret_cast<const float4*>(base[i] + off);
+      const int y = y0[i] + dy, x = x0[i] + dx;
+      if (base[i] && tap_ok && (g->all_valid || (y >= 0 && y < g->vh && x >= 0 && x < g->vw))) {
+        v = *reinterpret_cast<const float4*>(base[i] + toff);
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       }
       r[i] = v;
@@ -402,53 +411,52 @@ inline void launch(const Params& p, const Plan& pl, hipStream_t s) {
   else hipLaunchKernelGGL((gemm_kernel<2, 2, AKC, BKC, AG, BG, SCATTER>), grid, dim3(256), 0, s, p);
 }
 
-// ---- 'valid' convolutions as gather-GEMMs (see struct Gather) ---------------------------------------------- //
-// Forward: m = output pixel, k = (ky, kx, ci) -- kw*cin contiguous floats per ky, so every 32-deep k-tile is one
-// 128-byte segment of the NHWC input -- n = co, B = the Keras kernel as stored (OC).  Needs pad 0, ld_in == cin,
-// (kw*cin) % 32 == 0, cout % 4 == 0.
+// ---- convolutions as gather-GEMMs (see struct Gather) ------------------------------------------------------ //
+inline int log2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
+
+// Forward: m = output pixel, k = (ky, kx, ci), n = co, B = the Keras kernel as stored (OC).  Any stride and padding;
+// needs cin a power of two >= 4, ld_in % 4 == 0, cout % 4 == 0.
 inline bool conv_fwd_setup(Params& p, const seedhip_conv_geom* g) {
-  const int seg = g->kw * g->cin;
-  if (g->pad_t || g->pad_l || g->ld_in != g->cin || seg % BK || g->cout % 4 || g->ld_out % 4) return false;
-  const int K = g->kh * seg, per_row = seg / BK;
-  if (K / BK > kMaxTiles) return false;
+  const int cs = log2_exact(g->cin);
+  if (cs < 2 || g->ld_in % 4 || g->cout % 4 || g->ld_out % 4) return false;
   memset(&p, 0, sizeof(p));
-  p.M = g->n_img * g->oh * g->ow; p.N = g->cout; p.K = K; p.k_per_slice = K;
+  p.M = g->n_img * g->oh * g->ow; p.N = g->cout; p.K = g->kh * g->kw * g->cin; p.k_per_slice = (p.K + BK - 1) / BK * BK;
   p.ldb = g->cout; p.ldc = g->ld_out;
   Gather& a = p.ga;
-  a.d1.init(g->oh * g->ow); a.d2.init(g->ow);
+  a.d1.init(g->oh * g->ow); a.d2.init(g->ow); a.d_tw.init(g->kw);
   a.s0 = (long long)g->ih * g->iw * g->ld_in; a.s1 = g->stride * g->iw * g->ld_in; a.s2 = g->stride * g->ld_in;
-  a.all_valid = 1;
-  for (int t = 0; t < K / BK; ++t) a.tile_off[t] = (t / per_row) * g->iw * g->ld_in + (t % per_row) * BK;
+  a.const0 = -((long long)g->pad_t * g->iw + g->pad_l) * g->ld_in;
+  a.cshift = cs; a.ntaps = g->kh * g->kw; a.tsy = g->iw * g->ld_in; a.tsx = g->ld_in;
+  a.cy = g->stride; a.oy0 = -g->pad_t; a.ey = 1; a.cx = g->stride; a.ox0 = -g->pad_l; a.ex = 1; a.vh = g->ih; a.vw = g->iw;
+  a.all_valid = g->pad_t == 0 && g->pad_l == 0 && (g->oh - 1) * g->stride + g->kh <= g->ih &&
+                (g->ow - 1) * g->stride + g->kw <= g->iw;
   return true;
 }
 
 // Data gradient: m = super-pixel (a, b) covering input pixels (s*a+py, s*b+px), n = (py, px, ci), k = (jy, jx, co):
-//   dX[s*a+py, s*b+px, ci] = sum dY[a-jy, b-jx, co] * W[py+s*jy, px+s*jx, ci, co]
-// one GEMM for all stride-parity classes; A rows = 128-byte segments of dY (zero outside the map), B rows = the
-// kernel's co-contiguous rows re-indexed by (py, px, ci).  Needs pad 0, kh % s == kw % s == 0, cout % 32 == 0.
+//   dX[s*a+py, s*b+px, ci] = sum dY[a-jy, b-jx, co] * W[py+s*jy, px+s*jx, ci, co]                  (pad 0)
+// one GEMM for all stride-parity classes; for stride 1 with padding the same with dY[y+pad-jy, x+pad-jx].
+// A rows = dY taps (zero outside the map), B rows = the kernel's co-contiguous rows re-indexed by (py, px, ci).
+// Needs kh % s == kw % s == 0, cout a power of two >= 4, and pad 0 unless s == 1.
 inline bool conv_dgrad_setup(Params& p, const seedhip_conv_geom* g) {
-  const int s = g->stride;
-  if (g->pad_t || g->pad_l || g->kh % s || g->kw % s || g->cout % BK || g->ld_out % 4) return false;
-  const int jh = g->kh / s, jw = g->kw / s, per_tap = g->cout / BK, K = jh * jw * g->cout, N = s * s * g->cin;
-  if (K / BK > kMaxTiles) return false;
+  const int s = g->stride, cs = log2_exact(g->cout);
+  if (cs < 2 || g->kh % s || g->kw % s || g->ld_out % 4 || ((g->pad_t || g->pad_l) && s != 1)) return false;
+  const int jh = g->kh / s, jw = g->kw / s;
   memset(&p, 0, sizeof(p));
   const int gh = (g->ih + s - 1) / s, gw = (g->iw + s - 1) / s;
-  p.M = g->n_img * gh * gw; p.N = N; p.K = K; p.k_per_slice = K;
+  p.M = g->n_img * gh * gw; p.N = s * s * g->cin; p.K = jh * jw * g->cout; p.k_per_slice = (p.K + BK - 1) / BK * BK;
   p.ldc = g->ld_in; p.es = s; p.eih = g->ih; p.eiw = g->iw;
   Gather& a = p.ga;
-  a.d1.init(gh * gw); a.d2.init(gw);
+  a.d1.init(gh * gw); a.d2.init(gw); a.d_tw.init(jw);
   a.s0 = (long long)g->oh * g->ow * g->ld_out; a.s1 = g->ow * g->ld_out; a.s2 = g->ld_out;
-  a.vh = g->oh; a.vw = g->ow;
+  a.const0 = ((long long)g->pad_t * g->ow + g->pad_l) * g->ld_out;
+  a.cshift = cs; a.ntaps = jh * jw; a.tsy = -g->ow * g->ld_out; a.tsx = -g->ld_out;
+  a.cy = 1; a.oy0 = g->pad_t; a.ey = -1; a.cx = 1; a.ox0 = g->pad_l; a.ex = -1; a.vh = g->oh; a.vw = g->ow;
   Gather& b = p.gb;
-  b.d1.init(s * g->cin); b.d2.init(g->cin);
+  b.d1.init(s * g->cin); b.d2.init(g->cin); b.d_tw.init(jw);
   b.s0 = (long long)g->kw * g->cin * g->cout; b.s1 = g->cin * g->cout; b.s2 = g->cout;
+  b.cshift = cs; b.ntaps = jh * jw; b.tsy = s * g->kw * g->cin * g->cout; b.tsx = s * g->cin * g->cout;
   b.all_valid = 1;
-  for (int t = 0; t < K / BK; ++t) {
-    const int tap = t / per_tap, jy = tap / jw, jx = tap % jw, chunk = t % per_tap;
-    a.tile_off[t] = -(jy * g->ow + jx) * g->ld_out + chunk * BK;
-    a.tile_dy[t] = (signed char)-jy; a.tile_dx[t] = (signed char)-jx;
-    b.tile_off[t] = (s * jy * g->kw + s * jx) * g->cin * g->cout + chunk * BK;
-  }
   return true;
 }
 
