@@ -14,14 +14,14 @@ import json
 import sys
 
 REGIONS = [
-    ('stack_conv_fwd', 'stackconv_fwd_kernel'),
-    ('stack_conv_wgrad', 'stackconv_wgrad_kernel'),
+    ('stack_conv_fwd', 'stackconv::stackconv_fwd'),
+    ('stack_conv_wgrad', 'stackconv::stackconv_wgrad'),
     ('conv_fwd[4x4/2 16->32 @20x20]', 'wsgemm::ws_kernel<1, 2,'),
     ('conv_dgrad[4x4/2 16->32 @20x20]', 'wsgemm::ws_kernel<1, 4,'),
     ('conv_wgrad[4x4/2 16->32 @20x20]', 'halo_wgrad_kernel'),
-    ('conv_fwd[1x1/1 2592->256 @1x1]', 'true, false>(seedhip::gemm::Params)'),
-    ('conv_dgrad[1x1/1 2592->256 @1x1]', 'true, true>(seedhip::gemm::Params)'),
-    ('conv_wgrad[1x1/1 2592->256 @1x1]', 'false, false>(seedhip::gemm::Params)'),
+    ('conv_fwd[1x1/1 2592->256 @1x1]', 'true, false, false, false, false>(seedhip::gemm::Params)'),
+    ('conv_dgrad[1x1/1 2592->256 @1x1]', 'true, true, false, false, false>(seedhip::gemm::Params)'),
+    ('conv_wgrad[1x1/1 2592->256 @1x1]', 'false, false, false, false, false>(seedhip::gemm::Params)'),
 ]
 
 
