@@ -166,6 +166,19 @@ int seedhip_maxpool3x3s2_same_fwd(int n, int ih, int iw, int c, const float* x, 
 int seedhip_maxpool3x3s2_same_bwd(int n, int ih, int iw, int c, const float* dy, const uint8_t* argmax, float* dx,
                                   void* stream);
 
+/* ---- first ImpalaDeep stage fused: Conv2D(16, 3, 'same') on uint8 frames (x/255) + MaxPool2D(3, 2, 'same') ----
+ * Replaces dmlab/networks.py:31-37 for stack 0 (with the x/255 of :98-100) and the autodiff of that pair wrt the conv
+ * kernel and bias; the 72x96x16 pre-pool activation (2.4 GB at T=20, B=256) and its gradient are never written.
+ * x u8 [n, ih, iw, 3]; w [3,3,3,16] (Keras layout); pooled fp32 / argmax u8 [n, ceil(ih/2), ceil(iw/2), 16] with the
+ * argmax byte code of seedhip_maxpool3x3s2_same_fwd.  cin must be 3, cout 16, iw <= 114.
+ * bwd: dpooled = gradient wrt `pooled`; dw [3,3,3,16], dbias [16] or null; workspace from the _workspace_bytes call. */
+int seedhip_conv3x3_u8_pool_fwd(const uint8_t* x, int n, int ih, int iw, int cin, const float* w, const float* bias,
+                                int cout, float* pooled, uint8_t* argmax, void* stream);
+size_t seedhip_conv3x3_u8_pool_bwd_workspace_bytes(int n, int ih, int iw);
+int seedhip_conv3x3_u8_pool_bwd(const uint8_t* x, int n, int ih, int iw, int cin, const float* dpooled,
+                                const uint8_t* argmax, int cout, float* dw, float* dbias, void* workspace,
+                                size_t workspace_bytes, void* stream);
+
 /* ---- LSTM core with done-reset ---------------------------------------------------------------
  * Replace the time loop of dmlab/networks.py:152-171 / atari/networks.py:176-218 (_unroll_cell)
  * around tf.keras.layers.LSTMCell (gate order i,f,g,o; one bias) and its autodiff; the dense

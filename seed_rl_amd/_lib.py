@@ -65,6 +65,9 @@ SIGNATURES = {
         (c_int, [ctypes.POINTER(StackConvGeom), P, P, P, P, P, P, c_size_t, P]),
     'seedhip_maxpool3x3s2_same_fwd': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
     'seedhip_maxpool3x3s2_same_bwd': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
+    'seedhip_conv3x3_u8_pool_fwd': (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P]),
+    'seedhip_conv3x3_u8_pool_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'seedhip_conv3x3_u8_pool_bwd': (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P, c_size_t, P]),
     'seedhip_lstm_assemble_inputs': (c_int, [P, c_int, c_int, c_int, P, P, c_int, c_int, c_ll, P]),
     'seedhip_lstm_mask_state': (c_int, [P, P, P, c_int, c_int, P, P, P]),
     'seedhip_lstm_gates_fwd': (c_int, [P, P, P, c_int, c_int, P, c_int, P, P, P]),

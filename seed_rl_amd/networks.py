@@ -484,6 +484,8 @@ class ImpalaDeep(_Agent):
     self._obs = (h, w, c)
     self._channels, self._fc, self._H = tuple(channels), fc, lstm
     self._entropy_cost = entropy_cost
+    # csrc/convpool.hip is built for the reference's first stage: 3-channel uint8 frames -> 16 channels
+    self._fused_first_stage = (c == 3 and self._channels[0] == 16 and w <= 114 and h >= 3 and w >= 3)
     spec, cin = [], c
     self._stack_shapes = []                    # (ih, iw, cin, ch, oh, ow)
     for i, ch in enumerate(self._channels):
@@ -528,12 +530,17 @@ class ImpalaDeep(_Agent):
     saved = []
     for i, (ih, iw, cin, ch, oh, ow) in enumerate(self._stack_shapes):
       g = ops.conv_geom(N, ih, iw, cin, 3, 3, 1, 'same', ch)
-      a = self._buf('s%d_a' % i, (N, ih, iw, ch))
-      ops.conv2d_fwd(g, x, fl.p('stack%d/conv/kernel' % i), fl.p('stack%d/conv/bias' % i), a,
-                     in_dtype=ops.IN_U8_DIV255 if i == 0 else ops.IN_F32)          # dmlab/networks.py:98-100
       p = self._buf('s%d_p' % i, (N, oh, ow, ch))
       arg = self._buf('s%d_arg' % i, (N, oh, ow, ch), torch.uint8)
-      ops.maxpool_fwd(a, p, arg)
+      fused = i == 0 and self._fused_first_stage
+      if fused:
+        # conv + max-pool of the uint8 stage in one kernel: the [N, 72, 96, 16] pre-pool tensor is never written
+        ops.conv3x3_u8_pool_fwd(x, fl.p('stack0/conv/kernel'), fl.p('stack0/conv/bias'), p, arg)
+      else:
+        a = self._buf('s%d_a' % i, (N, ih, iw, ch))
+        ops.conv2d_fwd(g, x, fl.p('stack%d/conv/kernel' % i), fl.p('stack%d/conv/bias' % i), a,
+                       in_dtype=ops.IN_U8_DIV255 if i == 0 else ops.IN_F32)        # dmlab/networks.py:98-100
+        ops.maxpool_fwd(a, p, arg)
       gres = ops.conv_geom(N, oh, ow, ch, 3, 3, 1, 'same', ch)
       blocks = []
       for b in range(2):                                                             # dmlab/networks.py:52-59
@@ -545,7 +552,7 @@ class ImpalaDeep(_Agent):
                        fl.p('stack%d/res_%d/conv2d_1/bias' % (i, b)), r2, in_relu=True, residual=p)
         blocks.append((p, r1))
         p = r2
-      saved.append(dict(g=g, gres=gres, x=x, arg=arg, a_shape=(N, ih, iw, ch), blocks=blocks))
+      saved.append(dict(g=g, gres=gres, x=x, arg=arg, a_shape=(N, ih, iw, ch), blocks=blocks, fused=fused))
       x = p
     flat = x.view(N, self._flat_dim)
     ldx = self._ldx
@@ -595,9 +602,14 @@ class ImpalaDeep(_Agent):
         d_pin = self._buf('d_s%d_b%d_p' % (i, b), tuple(p_in.shape))
         ops.conv2d_bwd_data(gres, d_r1, fl.p(k0 + '/kernel'), d_pin, relu_mask=p_in, add=dp)   # + skip path
         dp = d_pin
+      kc = 'stack%d/conv' % i
+      if S['fused']:
+        n0, ih0, iw0, _ = S['a_shape']
+        ws0 = self._buf('convpool_ws', (ops.conv3x3_u8_pool_bwd_workspace_bytes(n0, ih0, iw0) // 4 + 4,))
+        ops.conv3x3_u8_pool_bwd(S['x'], dp, S['arg'], fl.g(kc + '/kernel'), fl.g(kc + '/bias'), ws0)
+        continue
       d_a = self._buf('d_s%d_a' % i, S['a_shape'])
       ops.maxpool_bwd(dp, S['arg'], d_a)
-      kc = 'stack%d/conv' % i
       ops.conv2d_bwd_weight(S['g'], S['x'], d_a, fl.g(kc + '/kernel'), fl.g(kc + '/bias'), wsb,
                             in_dtype=ops.IN_U8_DIV255 if i == 0 else ops.IN_F32)
       if i > 0:

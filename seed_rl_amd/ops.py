@@ -253,6 +253,35 @@ def clip_by_global_norm(grads, clip_norm, sumsq_out, workspace):
         workspace.numel() * workspace.element_size(), _lib.stream()), 'seedhip_clip_by_global_norm')
 
 
+def conv3x3_u8_pool_fwd(x_u8, w, bias, pooled, argmax):
+  """Fused Conv2D(16, 3, 'same')(x/255) + MaxPool2D(3, 2, 'same') of ImpalaDeep's first stage
+  (dmlab/networks.py:31-37, :98-100).  x_u8 [n, ih, iw, 3]; pooled / argmax [n, ceil(ih/2), ceil(iw/2), 16]."""
+  n, ih, iw, cin = x_u8.shape
+  cout = pooled.shape[-1]
+  with _region('convpool_fwd[%dx%dx%d->%d]' % (ih, iw, cin, cout), 2.0 * n * ih * iw * cout * 9 * cin,
+               x_u8.numel() + pooled.numel() * 5):
+    with _dev(pooled):
+      _lib.check(_lib.lib().seedhip_conv3x3_u8_pool_fwd(
+          _lib.ptr(x_u8), n, ih, iw, cin, _lib.ptr(w), _lib.ptr(bias), cout, _lib.ptr(pooled), _lib.ptr(argmax),
+          _lib.stream()), 'seedhip_conv3x3_u8_pool_fwd')
+
+
+def conv3x3_u8_pool_bwd_workspace_bytes(n, ih, iw):
+  return int(_lib.lib().seedhip_conv3x3_u8_pool_bwd_workspace_bytes(n, ih, iw))
+
+
+def conv3x3_u8_pool_bwd(x_u8, dpooled, argmax, dw, dbias, workspace):
+  n, ih, iw, cin = x_u8.shape
+  cout = dpooled.shape[-1]
+  with _region('convpool_bwd[%dx%dx%d->%d]' % (ih, iw, cin, cout), 2.0 * n * ih * iw * cout * 9 * cin,
+               x_u8.numel() + dpooled.numel() * 5):
+    with _dev(dw):
+      _lib.check(_lib.lib().seedhip_conv3x3_u8_pool_bwd(
+          _lib.ptr(x_u8), n, ih, iw, cin, _lib.ptr(dpooled), _lib.ptr(argmax), cout, _lib.ptr(dw), _lib.ptr(dbias),
+          _lib.ptr(workspace), workspace.numel() * workspace.element_size(), _lib.stream()),
+                 'seedhip_conv3x3_u8_pool_bwd')
+
+
 def maxpool_fwd(x, y, argmax):
   """MaxPool2D(3, 2, 'same') on NHWC fp32 (dmlab/networks.py:36-37)."""
   n, ih, iw, c = x.shape

@@ -497,3 +497,37 @@ def test_stack_conv_fwd_fp32_accuracy(device):
   e_hip = np.max(np.abs(dw.cpu().numpy().astype(np.float64) - g64))
   e_f32 = np.max(np.abs(w32.grad.numpy().astype(np.float64) - g64))
   assert e_hip <= max(2.0 * e_f32, 2e-6 * np.abs(g64).max()), (e_hip, e_f32, np.abs(g64).max())
+
+
+@pytest.mark.parametrize('n,ih,iw', [(3, 72, 96), (2, 11, 9), (5, 8, 12), (1, 3, 3)])
+def test_convpool_fused_parity(device, n, ih, iw):
+  """Fused Conv2D(16, 3, 'same')(x/255) + MaxPool2D(3, 2, 'same') of ImpalaDeep's first stage
+  (dmlab/networks.py:31-37) vs the oracle conv -> max-pool and torch autograd through both: pooled output,
+  and dW / db of the conv for a random gradient on the pooled tensor.  Even, odd and minimum map sizes (TF 'SAME'
+  pads differ), partial last band."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(ih * 100 + iw)
+  x = rng.integers(0, 256, (n, ih, iw, 3)).astype(np.uint8)
+  w = (rng.normal(size=(3, 3, 3, 16)) / np.sqrt(27)).astype(np.float32)
+  b = rng.normal(size=(16,)).astype(np.float32)
+  wt = torch.tensor(w, requires_grad=True); bt = torch.tensor(b, requires_grad=True)
+  a = nets_torch.conv2d(torch.tensor(x).float() / 255, wt, bt, 1, 'same')
+  y = nets_torch.max_pool_3x3_s2_same(a)
+  dy = rng.normal(size=tuple(y.shape)).astype(np.float32)
+  y.backward(torch.tensor(dy))
+  ph, pw = (ih + 1) // 2, (iw + 1) // 2
+  xd = dev(x, device)
+  pooled = torch.full((n, ph, pw, 16), 7.0, device=device)
+  arg = torch.full((n, ph, pw, 16), 99, dtype=torch.uint8, device=device)
+  ops.conv3x3_u8_pool_fwd(xd, dev(w, device), dev(b, device), pooled, arg)
+  yr = y.detach().numpy()
+  assert np.max(np.abs(pooled.cpu().numpy() - yr)) <= 2e-5 * max(1.0, np.abs(yr).max())
+  assert int(arg.max()) <= 8
+  dw = torch.full(w.shape, 7.0, device=device); db = torch.full(b.shape, 7.0, device=device)
+  ws = torch.empty(ops.conv3x3_u8_pool_bwd_workspace_bytes(n, ih, iw) // 4 + 1, device=device)
+  ops.conv3x3_u8_pool_bwd(xd, dev(dy, device), arg, dw, db, ws)
+  gw, gb = wt.grad.numpy(), bt.grad.numpy()
+  # a near-tie inside a pooling window may pick a different (equal up to fp32 rounding) maximum than the oracle's
+  # summation order does: such a flip moves one dY entry between two pixels, bounded by |dy|max * |x|max per entry
+  assert np.max(np.abs(db.cpu().numpy() - gb)) <= 1e-4 * max(1.0, np.abs(gb).max())
+  assert np.max(np.abs(dw.cpu().numpy() - gw)) <= 2e-3 * max(1.0, np.abs(gw).max())
