@@ -152,16 +152,19 @@ convpool_fwd_kernel(const Geom g, const uint8_t* __restrict__ x, const float* __
             a23 = pk_fma(xv[c], wr[ky][kx][c][1], a23);
           }
         }
-      *reinterpret_cast<float4*>(cbuf + (r * g.iw + xc) * COUT + 4 * wave) = make_float4(a01[0], a01[1], a23[0], a23[1]);
+      // cbuf is channel-quad major [quad][row][x] x 16 B: lanes (consecutive x) write consecutive 16-byte slots
+      reinterpret_cast<float4*>(cbuf)[(wave * kConvRows + r) * g.iw + xc] = make_float4(a01[0], a01[1], a23[0], a23[1]);
     }
     __syncthreads();
     // ---- 3x3 / 2 max-pool of the band out of LDS: item = (pooled pixel, channel quad) ----
     const int rows = (i0 + PB <= g.ph) ? PB : g.ph - i0;
     for (int item = tid; item < rows * g.pw * 4; item += 256) {
-      const int cq = item & 3, pp = item >> 2;
-      uint32_t upi, upj;
-      g.d_pw.divmod((uint32_t)pp, upi, upj);
-      const int pi = (int)upi, pj = (int)upj;
+      uint32_t ucq, pp, upi, upj;                          // item = (quad, pooled row, pooled col): lanes share the quad
+      g.d_pw.divmod((uint32_t)item, pp, upj);              // pp = quad * rows + pi
+      const int pj = (int)upj;
+      ucq = pp / (uint32_t)rows;
+      upi = pp - ucq * (uint32_t)rows;
+      const int cq = (int)ucq, pi = (int)upi;
       float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
       int bi0 = 0, bi1 = 0, bi2 = 0, bi3 = 0;
 #pragma unroll
@@ -172,7 +175,7 @@ convpool_fwd_kernel(const Geom g, const uint8_t* __restrict__ x, const float* __
         for (int kx = 0; kx < 3; ++kx) {
           const int ix = 2 * pj - g.pl + kx;
           if (ix < 0 || ix >= g.iw) continue;
-          const float4 v = *reinterpret_cast<const float4*>(cbuf + ((iy - cy0) * g.iw + ix) * COUT + 4 * cq);
+          const float4 v = reinterpret_cast<const float4*>(cbuf)[(cq * kConvRows + (iy - cy0)) * g.iw + ix];
           const int code = ky * 3 + kx;
           if (v.x > best.x) { best.x = v.x; bi0 = code; }
           if (v.y > best.y) { best.y = v.y; bi1 = code; }
@@ -255,9 +258,10 @@ convpool_bwd_kernel(const Geom g, const uint8_t* __restrict__ x, const float* __
 #pragma unroll
     for (int u = 0; u < kInPre; ++u) {
       const int idx = tid + u * 256;
-      if (idx < (PB + 1) * g.pw * 4) {
-        reinterpret_cast<float4*>(dyp)[idx] = pd[u];
-        reinterpret_cast<uchar4*>(argl)[idx] = pa[u];
+      if (idx < (PB + 1) * g.pw * 4) {                      // global order (row, col, quad) -> LDS [quad][row][col]
+        const int q = idx & 3, rc = idx >> 2;
+        reinterpret_cast<float4*>(dyp)[q * (PB + 1) * g.pw + rc] = pd[u];
+        reinterpret_cast<uchar4*>(argl)[q * (PB + 1) * g.pw + rc] = pa[u];
       }
     }
     __syncthreads();
@@ -278,7 +282,7 @@ convpool_bwd_kernel(const Geom g, const uint8_t* __restrict__ x, const float* __
           if (ox < 0 || ox >= g.pw) continue;
           const int kx = x0 - 2 * ox;
           if (kx < 0 || kx > 2) continue;
-          const int o = ((oy - (i0 - 1)) * g.pw + ox) * 4 + wave;
+          const int o = (wave * (PB + 1) + oy - (i0 - 1)) * g.pw + ox;
           const uchar4 am = reinterpret_cast<const uchar4*>(argl)[o];
           const float4 dv = reinterpret_cast<const float4*>(dyp)[o];
           const int code = ky * 3 + kx;
