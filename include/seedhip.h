@@ -197,6 +197,14 @@ int seedhip_lstm_assemble_inputs(float* x, int ldx, int feat, int num_actions, c
                                  void* stream);
 int seedhip_lstm_mask_state(const float* h0, const float* c0, const uint8_t* done0, int B, int H, float* hin,
                             float* cin, void* stream);
+/* One whole LSTM step in one launch (recurrent GEMM + gates + done-reset): z = zx + hin * U, then as
+ * seedhip_lstm_gates_fwd.  `up` is U [H, 4H] re-laid out by seedhip_lstm_permute_u (column 4*unit + gate), once per
+ * forward pass.  Needs H % 128 == 0 (seedhip_lstm_step_supported); hin / up 16-byte aligned.  zx, z [B, 4H]. */
+int seedhip_lstm_permute_u(const float* u, int H, float* up, void* stream);
+int seedhip_lstm_step_supported(int B, int H);
+int seedhip_lstm_step_fwd(const float* hin, const float* up, const float* zx, const float* cin,
+                          const uint8_t* done_next, int B, int H, float* z, float* h_out, int ld_h, float* hin_next,
+                          float* cin_next, void* stream);
 int seedhip_lstm_gates_fwd(const float* z, const float* cin, const uint8_t* done_next, int B, int H, float* h_out,
                            int ld_h, float* hin_next, float* cin_next, void* stream);
 int seedhip_lstm_gates_bwd(const float* z, const float* cin, const float* dh_out, int ld_dh, const float* dh_rec,

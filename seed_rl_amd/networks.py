@@ -186,10 +186,17 @@ class _Agent(object):
     gu = ops.dense_geom(B, H, 4 * H)
     U = fl.p(prefix + '/recurrent_kernel')
     Zx3, Hout3 = Zx.view(T1, B, 4 * H), Hout.view(T1, B, H)
+    fused_step = ops.lstm_step_supported(B, H)
+    if fused_step:                                # recurrent GEMM + gates + reset in one launch per step
+      Up = self._buf(prefix + '_u_perm', (H, 4 * H))
+      ops.lstm_permute_u(U, H, Up)
     for t in range(T1):
-      ops.conv2d_fwd(gu, Hin[t], U, None, Z[t], residual=Zx3[t])
-      ops.lstm_gates_fwd(Z[t], Cin[t], done_u8[t + 1] if t + 1 < T1 else None, B, H, Hout3[t], H, Hin[t + 1],
-                         Cin[t + 1])
+      done_next = done_u8[t + 1] if t + 1 < T1 else None
+      if fused_step:
+        ops.lstm_step_fwd(Hin[t], Up, Zx3[t], Cin[t], done_next, B, H, Z[t], Hout3[t], H, Hin[t + 1], Cin[t + 1])
+      else:
+        ops.conv2d_fwd(gu, Hin[t], U, None, Z[t], residual=Zx3[t])
+        ops.lstm_gates_fwd(Z[t], Cin[t], done_next, B, H, Hout3[t], H, Hin[t + 1], Cin[t + 1])
     self._last_lstm = dict(X=X, ldx=ldx, in_dim=in_dim, H=H, T1=T1, B=B, done=done_u8, gx=gx, gu=gu, Z=Z, Hin=Hin,
                            Cin=Cin, Hout=Hout, prefix=prefix)
     return Hout, (Hin[T1].clone(), Cin[T1].clone())

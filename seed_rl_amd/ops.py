@@ -312,6 +312,24 @@ def lstm_mask_state(h0, c0, done0_u8, B, H, hin, cin):
                                                   _lib.ptr(cin), _lib.stream()), 'seedhip_lstm_mask_state')
 
 
+def lstm_step_supported(B, H):
+  return bool(_lib.lib().seedhip_lstm_step_supported(B, H))
+
+
+def lstm_permute_u(u, H, up):
+  with _dev(up):
+    _lib.check(_lib.lib().seedhip_lstm_permute_u(_lib.ptr(u), H, _lib.ptr(up), _lib.stream()), 'seedhip_lstm_permute_u')
+
+
+def lstm_step_fwd(hin, up, zx, cin, done_next_u8, B, H, z, h_out, ld_h, hin_next, cin_next):
+  """One LSTM step in one launch: z = zx + hin U, gates, done-reset of the next state (dmlab/networks.py:152-171)."""
+  with _region('lstm_step_fwd', 2.0 * B * H * 4 * H, (H * 4 * H + B * H * 12) * 4):
+    with _dev(z):
+      _lib.check(_lib.lib().seedhip_lstm_step_fwd(
+          _lib.ptr(hin), _lib.ptr(up), _lib.ptr(zx), _lib.ptr(cin), _lib.ptr(done_next_u8), B, H, _lib.ptr(z),
+          _lib.ptr(h_out), ld_h, _lib.ptr(hin_next), _lib.ptr(cin_next), _lib.stream()), 'seedhip_lstm_step_fwd')
+
+
 def lstm_gates_fwd(z, cin, done_next_u8, B, H, h_out, ld_h, hin_next, cin_next):
   with _region('lstm_gates_fwd', 0, B * H * 4 * 8):
     with _dev(h_out):

@@ -531,3 +531,32 @@ def test_convpool_fused_parity(device, n, ih, iw):
   # summation order does: such a flip moves one dY entry between two pixels, bounded by |dy|max * |x|max per entry
   assert np.max(np.abs(db.cpu().numpy() - gb)) <= 1e-4 * max(1.0, np.abs(gb).max())
   assert np.max(np.abs(dw.cpu().numpy() - gw)) <= 2e-3 * max(1.0, np.abs(gw).max())
+
+
+@pytest.mark.parametrize('B,H', [(70, 128), (256, 512), (33, 1024), (256, 256)])
+def test_lstm_step_fused(device, B, H):
+  """One-launch LSTM step (recurrent GEMM + gates + done-reset, csrc/lstm_step.hip) vs the Keras LSTMCell formulas
+  in torch fp32 (dmlab/networks.py:152-171): pre-activations, h, and the masked next-step state; ragged last row tile."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(B + H)
+  hin = rng.normal(size=(B, H)).astype(np.float32)
+  cin = rng.normal(size=(B, H)).astype(np.float32)
+  U = (rng.normal(size=(H, 4 * H)) / np.sqrt(H)).astype(np.float32)
+  zx = rng.normal(size=(B, 4 * H)).astype(np.float32)
+  done_next = (rng.uniform(size=B) < 0.3).astype(np.uint8)
+  z_ref = torch.tensor(zx) + torch.tensor(hin) @ torch.tensor(U)
+  i, f, g, o = [z_ref[:, k * H:(k + 1) * H] for k in range(4)]
+  c_ref = torch.sigmoid(f) * torch.tensor(cin) + torch.sigmoid(i) * torch.tanh(g)
+  h_ref = torch.sigmoid(o) * torch.tanh(c_ref)
+  keep = torch.tensor(1.0 - done_next.astype(np.float32))[:, None]
+  assert ops.lstm_step_supported(B, H)
+  up = torch.empty((H, 4 * H), device=device)
+  ops.lstm_permute_u(dev(U, device), H, up)
+  z = torch.full((B, 4 * H), 7.0, device=device); h = torch.full((B, H), 7.0, device=device)
+  hn = torch.full((B, H), 7.0, device=device); cn = torch.full((B, H), 7.0, device=device)
+  ops.lstm_step_fwd(dev(hin, device), up, dev(zx, device), dev(cin, device), dev(done_next, device), B, H, z, h, H, hn, cn)
+  tol = 2e-5 * max(1.0, float(z_ref.abs().max()))
+  assert float((z.cpu() - z_ref).abs().max()) <= tol
+  assert float((h.cpu() - h_ref).abs().max()) <= 2e-5
+  assert float((hn.cpu() - h_ref * keep).abs().max()) <= 2e-5
+  assert float((cn.cpu() - c_ref * keep).abs().max()) <= 5e-5
