@@ -128,6 +128,16 @@ class _Agent(object):
     return collections.OrderedDict((n, self._ref_view(self.flat.g, n)) for n, _, _ in self._ref_spec)
 
   # -- workspaces ---------------------------------------------------------------- #
+  grad_ready_hook = None   # set by the learner: callable(lo, hi) on ranges of flat.grads that are final
+
+  def _grads_ready_from(self, first_name, upto=None):
+    """Reports flat.grads[offset(first_name) : upto or end] as final (everything after `first_name` in creation
+    order must already have its gradient)."""
+    hook = self.grad_ready_hook
+    if hook is not None:
+      lo = self.flat.offsets[first_name] if first_name is not None else 0
+      hook(lo, self.flat.size if upto is None else self.flat.offsets[upto])
+
   def _buf(self, key, shape, dtype=torch.float32, zero=False):
     k = (key, tuple(shape), dtype)
     t = self._ws.get(k)
@@ -302,6 +312,9 @@ class _AtariTorso(object):
     acts, geoms, gfc = ctx['acts'], ctx['geoms'], ctx['gfc']
     a_last = acts[-1]
     ops.conv2d_bwd_weight(gfc, a_last, dz, fl.g(tp + 'fc/kernel'), fl.g(tp + 'fc/bias'), wsb)
+    # the torso is created first and back-propagated last: everything from its Dense layer to the end of the flat
+    # buffer is final now -- its exchange overlaps the conv backward
+    self._grads_ready_from(tp + 'fc/kernel')
     da = self._buf('d_act%d' % (len(acts) - 1), tuple(a_last.shape))
     ops.conv2d_bwd_data(gfc, dz, fl.p(tp + 'fc/kernel'), da, relu_mask=a_last)
     for i in range(len(acts) - 1, 0, -1):
@@ -314,6 +327,7 @@ class _AtariTorso(object):
     ws0 = self._buf('stack_ws', (ops.conv2d_stack_bwd_weight_workspace_bytes(geoms[0]) // 4 + 4,))
     ops.conv2d_stack_bwd_weight(geoms[0], ctx['ext'], ctx['nvalid'], da, fl.g(tp + 'conv0/kernel'),
                                 fl.g(tp + 'conv0/bias'), ws0)
+    self._grads_ready_from(None, upto=tp + 'fc/kernel')
 
   def _torso_ws_bytes(self, ctx):
     need = ops.conv2d_bwd_weight_workspace_bytes(ctx['gfc'])
@@ -593,6 +607,7 @@ class ImpalaDeep(_Agent):
     # Dense 256 (its ReLU mask was applied to dX by the LSTM input-projection dgrad)
     ops.conv2d_bwd_weight(L['gfc'], L['flat'], dX, fl.g('conv_to_linear/kernel'), fl.g('conv_to_linear/bias'), wsb,
                           in_relu=True)
+    self._grads_ready_from('conv_to_linear/kernel')        # Dense + LSTM + heads: exchanged under the conv backward
     d_flat = self._buf('d_flat', tuple(L['flat'].shape))
     ops.conv2d_bwd_data(L['gfc'], dX, fl.p('conv_to_linear/kernel'), d_flat, relu_mask=L['flat'])
     dp = d_flat
@@ -623,6 +638,7 @@ class ImpalaDeep(_Agent):
         dx = self._buf('d_s%d_x' % i, tuple(S['x'].shape))
         ops.conv2d_bwd_data(S['g'], d_a, fl.p(kc + '/kernel'), dx)
         dp = dx
+    self._grads_ready_from(None, upto='conv_to_linear/kernel')
 
   def _wgrad_ws(self):
     L = self._last

@@ -112,6 +112,61 @@ def test_minimize_sum_semantics_like_reference(tmp_path):
     assert abs(float(torch.load(out + str(r))[0]) - (1.0 - world * 0.2)) < 1e-6
 
 
+def _overlap_worker(rank, world, port, mode, out):
+  sys.path.insert(0, ROOT)
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from seed_rl_amd import learner
+    from seed_rl_amd.flat import FlatParams
+
+    class _Agent(object):
+      """Stand-in with the agents' protocol: backward() fills flat.grads and reports final ranges through
+      grad_ready_hook(lo, hi) -- 'two': tail first then head (as the torsos do), 'tail': only the tail (the rest
+      must be exchanged by reduce_gradients), 'none': no reports at all."""
+      grad_ready_hook = None
+
+      def __init__(self):
+        self.flat = FlatParams([('conv', (37,)), ('fc', (101,)), ('heads', (9,))], torch.device('cpu'))
+
+      def backward(self):
+        g = torch.arange(self.flat.size, dtype=torch.float32) * (rank + 1) + rank
+        self.flat.grads.copy_(g)
+        hook, split = self.grad_ready_hook, self.flat.offsets['fc']
+        if hook is not None and mode in ('two', 'tail'):
+          hook(split, self.flat.size)
+        if hook is not None and mode == 'two':
+          hook(0, split)
+
+    agent = _Agent()
+    lrn = learner.Learner(agent, None, None)
+    assert lrn.world == world
+    agent.grad_ready_hook = lrn._on_grads_ready
+    agent.backward()
+    agent.grad_ready_hook = None
+    assert len(lrn._pending) == {'two': 2, 'tail': 1, 'none': 0}[mode]
+    lrn.reduce_gradients()
+    base = torch.arange(agent.flat.size, dtype=torch.float32)
+    want = sum(base * (r + 1) + r for r in range(world))
+    assert torch.equal(agent.flat.grads, want)
+    assert lrn._pending == []
+    if rank == 0:
+      open(out, 'w').write('ok')
+  finally:
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('mode', ['two', 'tail', 'none'])
+def test_overlapped_gradient_exchange_gloo(tmp_path, mode):
+  """The gradient exchange overlapped with the backward pass (Learner._on_grads_ready / reduce_gradients): ranges the
+  agent reports are all-reduced asynchronously, unreported ranges by reduce_gradients; the result is the SUM of the
+  whole flat bucket in every case."""
+  out = str(tmp_path / 'ok.txt')
+  mp.spawn(_overlap_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
+  assert open(out).read() == 'ok'
+
+
 def test_shard_columns():
   from seed_rl_amd import learner
   assert learner.shard_columns(4096, 3, 8) == slice(1536, 2048)
