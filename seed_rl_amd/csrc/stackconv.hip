@@ -208,7 +208,7 @@ stackconv_fwd_kernel(const Params p) {
 // 3/16 of its matrix-pipe time (the bf16 MFMA does 16x the MACs per cycle).  This is not a reduced-precision
 // path: no operand is rounded (tests/test_gpu_kernels.py checks it at the fp32 tolerance, tests/test_bf16_split.py
 // checks hi + mid + lo == w bit for bit).
-// Measured on MI355X (T=20, B=512): forward 0.43 -> 0.16 ms, weight gradient 0.43 -> 0.27 ms against the fp32-MFMA
+// Measured on MI355X (T=20, B=512): forward 0.43 -> 0.15 ms, weight gradient 0.43 -> 0.24 ms against the fp32-MFMA
 // kernels above (kept: SEEDHIP_STACK_BF16=0 selects them for A/B runs).
 // ------------------------------------------------------------------------------------ //
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -349,19 +349,14 @@ stackconv_wgrad_kernel(const Params p) {
 }
 
 // ------------------------------------------------------------------------------------ //
-// Weight gradient on the bf16 matrix pipe, exact ("bf16x3", see the forward): X is uint8 (exact in bf16), each dY
-// value is split into three bf16 parts whose sum is the fp32 value, products are exact, accumulation is fp32.
-// v_mfma_f32_16x16x32_bf16 reduces 32 pixels per instruction: lane group kq owns pixel chunk ch = 4g + kq of the
-// band = 2 output rows x 4 pixels ((2rp + a, 4xc + b), element e = 4a + b; 10 chunks per band, chunks 10 and 11
-// of the third group are zero padding).
-//   A (rows = 16 k-rows of m-tile (c, q); row i = (ky = i>>1, kx = 4(i&1) + q)): the band ring holds bf16 (converted
-//     once at staging, as in the forward); pixel (a, b) contributes halfword q of the 8 bytes at band element
-//     (8rp + 4a + ky)*84 + 16xc + 4b + 4(i&1): 8 ds_read_b64 serve the four m-tiles q = 0..3, one v_perm joins each
-//     pair of pixels (a uint8 ring with conversion at use was 12% slower)
-//   B (cols = 16 channels): dY[pixel e of chunk][co0 + j], 8 global dwords per lane and group, split once and
-//     used by the 16 m-tiles x 3 parts.
-// Channels c >= nvalid are skipped (forward: cumulative-OR done mask).  Accumulators, cross-wave reduction and
-// the partial-slice output are those of the fp32 kernel above.
+// Weight gradient on the bf16 matrix pipe, exact ("bf16x3"): X is uint8 (exact in bf16), each dY value is split into
+// three bf16 parts whose sum is the fp32 value, products are exact, accumulation is fp32 (kernel: channel-per-wave
+// decomposition further down).  v_mfma_f32_16x16x32_bf16 reduces 32 pixels per instruction: lane group kq owns an
+// 8-pixel chunk = 2 output rows x 4 pixels ((2rp + a, 4xc + b), element e = 4a + b).
+//   A (rows = 16 k-rows of m-tile (c, q); row i = (ky = i>>1, kx = 4(i&1) + q)): frames are held in LDS as bf16;
+//     pixel (a, b) contributes halfword q of the 8 bytes at element (8rp + 4a + ky)*84 + 16xc + 4b + 4(i&1):
+//     8 ds_read_b64 serve the four m-tiles q = 0..3, one v_perm joins each pair of pixels
+//   B (cols = 16 channels): dY[pixel e of chunk][co0 + j], 8 global dwords per lane and group.
 // ------------------------------------------------------------------------------------ //
 // Exact split by TRUNCATION (cheaper than rounding, equally exact): hi = the top 8 significant bits of v, mid = the
 // top 8 of what is left, lo = the remaining <= 8 bits; hi + mid + lo == v bit for bit (tests/test_bf16_split.py).
@@ -521,130 +516,151 @@ stackconv_fwd_bf16r_kernel(const Params p) {
   }
 }
 
-__global__ void __launch_bounds__(kThreads, 2)
-stackconv_wgrad_bf16_kernel(const Params p) {
+// ------------------------------------------------------------------------------------ //
+// bf16x3 weight gradient, channel-per-wave decomposition.
+// A band-per-wave kernel (as the fp32 one) keeps all 16 m-tiles (256 k-rows x 16 channels = 64 accumulator VGPRs) in
+// every wave and ended up at ~250 VGPRs: one 5-wave workgroup per CU, the matrix pipe idling on LDS latency (0.27 ms).
+// Here the OUTPUT is split instead (0.24 ms): wave (c, half) owns stack channel c -- the four m-tiles (c, q = 0..3),
+// 16 accumulator VGPRs -- and walks half of the frame's 13 pixel groups; its A operand is frame t - c, whole, from a
+// workgroup-shared ring of bf16 frames (5 slots: frame t+4 is staged while step t computes, ONE barrier per step).
+// 124 VGPRs, 8 waves per workgroup, 2 workgroups per CU.  dY fragments are loaded and split per wave (the 4 channel
+// waves repeat it: 44 VALU per 12 MFMAs), no cross-channel reduction exists, the two halves of a channel are summed
+// through LDS at the end.  Channels c >= nvalid skip the step (forward: cumulative-OR done mask).
+// ------------------------------------------------------------------------------------ //
+constexpr int kFrame16 = kIH * kIW * 2;                  // 14112 B: one frame in bf16
+constexpr int kFrameSlots = 5;
+constexpr int kChunks = 50, kGroups32 = 13;              // 8-pixel chunks (2 rows x 4) and 32-pixel MFMA groups per frame
+constexpr int kCW = 8;                                   // waves: (channel c = w & 3, half = w >> 2)
+
+__device__ __forceinline__ void frame_store16(unsigned char* slot, const uint4& v, int idx) {   // 16 bytes -> 16 bf16
+  uint4 a, b;
+  cvt16(v, a, b);
+  reinterpret_cast<uint4*>(slot)[2 * idx] = a;
+  reinterpret_cast<uint4*>(slot)[2 * idx + 1] = b;
+}
+
+__global__ void __launch_bounds__(64 * kCW)
+stackconv_wgrad_cw_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* red = reinterpret_cast<float*>(smem);                       // overlays the rings after the time loops
-  float* redb = red + kWFloats;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned char* myring = smem + wave * kWaveRing16;
+  const int c = wave & 3, half = wave >> 2;
   const int kq = lane >> 4, i = lane & 15;
   const int co0 = blockIdx.z * 16;
-  constexpr int P = 400;
+  constexpr int P = 400, kVec = kIH * kIW / 16;           // 441 uint4 per uint8 frame
 
-  f32x4_t acc[16];
+  f32x4_t acc[4];
 #pragma unroll
-  for (int m = 0; m < 16; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < 4; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-
-  // per-lane chunk geometry of the three pixel groups: fixed for the whole launch
-  int a_off[3], dy_off[3];
-  bool valid[3];
-#pragma unroll
-  for (int g = 0; g < 3; ++g) {
-    const int ch = 4 * g + kq;
-    valid[g] = ch < 10;
-    const int rp = valid[g] ? ch / 5 : 0, xc = valid[g] ? ch % 5 : 0;
-    a_off[g] = ((8 * rp + (i >> 1)) * kIW + 16 * xc + 4 * (i & 1)) * 2;
-    dy_off[g] = (2 * rp * kOW + 4 * xc) * p.ld_out;
-  }
-  auto load_dy = [&](const float* band, int g, float (&v)[8]) {      // band: dY of this wave's 80 pixels, channel co0 + i
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-        v[4 * a + b] = valid[g] ? band[dy_off[g] + (a * kOW + b) * p.ld_out] : 0.f;
-  };
 
   for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
     const int b = item % p.B, chunk = item / p.B;
     const int t0 = chunk * p.spc;
     const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
-    band_prologue16(p, myring, b, t0, wave, lane);
-    float dyn[8];
-    load_dy(p.dy + (((long long)t0 * p.B + b) * P + wave * 80) * p.ld_out + co0 + i, 0, dyn);
+    __syncthreads();                                      // previous item's last step is done with the ring
+    for (int e = 0; e < 4; ++e) {                         // ext rows t0 .. t0+3 -> slots
+      const uint4* src = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t0 + e) * p.B + b) * p.fsz);
+      for (int idx = tid; idx < kVec; idx += 64 * kCW) frame_store16(smem + ((t0 + e) % kFrameSlots) * kFrame16, src[idx], idx);
+    }
+    __syncthreads();
     for (int t = t0; t < t1; ++t) {
       const bool more = t + 1 < t1;
-      BandPrefetch pf;
-      if (more) pf = band_load(band_src(p, t + 4, b, wave), lane);
+      uint4 pf = make_uint4(0, 0, 0, 0);                  // 441 vectors over 512 threads: one each
+      if (more && tid < kVec)
+        pf = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t + 4) * p.B + b) * p.fsz)[tid];
       const int nv = p.nvalid[(long long)t * p.B + b];
-      const float* dy_band = p.dy + (((long long)t * p.B + b) * P + wave * 80) * p.ld_out + co0 + i;
+      if (c < nv) {
+        const unsigned char* frame = smem + ((t + 3 - c) % kFrameSlots) * kFrame16;
+        const float* dy_t = p.dy + ((long long)t * p.B + b) * P * p.ld_out + co0 + i;
+        auto chunk_geom = [&](int g, bool& ok, int& aoff, int& doff) {
+          const int ch = 4 * g + kq;
+          ok = ch < kChunks;
+          const int cc = ok ? ch : 0, rp = cc / 5, xc = cc - rp * 5;
+          aoff = ((8 * rp + (i >> 1)) * kIW + 16 * xc + 4 * (i & 1)) * 2;
+          doff = (2 * rp * kOW + 4 * xc) * p.ld_out;
+        };
+        float dyn[8];
+        bool ok; int aoff, doff;
+        chunk_geom(half, ok, aoff, doff);
 #pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        Frag8 bf[3];
-        {
-          float dyv[8];
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { dyv[e] = dyn[e]; bsum += dyn[e]; }
-          split3_pack(dyv, bf);
-        }
-        // dY of the next group (next step's first group at the end of a step) flies under this group's MFMAs
-        if (g < 2) load_dy(dy_band, g + 1, dyn);
-        else if (more) load_dy(dy_band + (long long)p.B * P * p.ld_out, 0, dyn);
+          for (int bb = 0; bb < 4; ++bb) { const float tv = dy_t[doff + (a * kOW + bb) * p.ld_out]; dyn[4 * a + bb] = ok ? tv : 0.f; }
+        for (int g = half; g < kGroups32; g += 2) {
+          Frag8 bf[3];
+          {
+            float dyv[8];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {                       // unrolled: accumulator indices stay static
-          if (c >= nv) continue;                            // wave-uniform
-          const unsigned char* src = myring + ((t + 3 - c) % kSlots) * kBand16 + a_off[g];
+            for (int e = 0; e < 8; ++e) { dyv[e] = dyn[e]; if (c == 0) bsum += dyn[e]; }
+            split3_pack(dyv, bf);
+          }
+          const unsigned char* src = frame + aoff;
+          if (g + 2 < kGroups32) {                        // next group's geometry and dY: in flight under the MFMAs
+            chunk_geom(g + 2, ok, aoff, doff);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int bb = 0; bb < 4; ++bb) { const float tv = dy_t[doff + (a * kOW + bb) * p.ld_out]; dyn[4 * a + bb] = ok ? tv : 0.f; }
+          }
           uint2 d[2][4];
 #pragma unroll
           for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb)
               d[a][bb] = *reinterpret_cast<const uint2*>(src + (a * 4 * kIW + 4 * bb) * 2);
+          Frag8 xa[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const uint32_t sel = (q & 1) ? 0x07060302u : 0x05040100u;
-            Frag8 xa;
             if (q < 2)
-              xa.u = make_uint4(__builtin_amdgcn_perm(d[0][1].x, d[0][0].x, sel), __builtin_amdgcn_perm(d[0][3].x, d[0][2].x, sel),
-                                __builtin_amdgcn_perm(d[1][1].x, d[1][0].x, sel), __builtin_amdgcn_perm(d[1][3].x, d[1][2].x, sel));
+              xa[q].u = make_uint4(__builtin_amdgcn_perm(d[0][1].x, d[0][0].x, sel), __builtin_amdgcn_perm(d[0][3].x, d[0][2].x, sel),
+                                   __builtin_amdgcn_perm(d[1][1].x, d[1][0].x, sel), __builtin_amdgcn_perm(d[1][3].x, d[1][2].x, sel));
             else
-              xa.u = make_uint4(__builtin_amdgcn_perm(d[0][1].y, d[0][0].y, sel), __builtin_amdgcn_perm(d[0][3].y, d[0][2].y, sel),
-                                __builtin_amdgcn_perm(d[1][1].y, d[1][0].y, sel), __builtin_amdgcn_perm(d[1][3].y, d[1][2].y, sel));
-            f32x4_t v = acc[c * 4 + q];
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v, bf[2].v, v, 0, 0, 0);
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v, bf[1].v, v, 0, 0, 0);
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v, bf[0].v, v, 0, 0, 0);
-            acc[c * 4 + q] = v;
+              xa[q].u = make_uint4(__builtin_amdgcn_perm(d[0][1].y, d[0][0].y, sel), __builtin_amdgcn_perm(d[0][3].y, d[0][2].y, sel),
+                                   __builtin_amdgcn_perm(d[1][1].y, d[1][0].y, sel), __builtin_amdgcn_perm(d[1][3].y, d[1][2].y, sel));
           }
+#pragma unroll
+          for (int s3 = 2; s3 >= 0; --s3)                   // lo, mid, hi; the four accumulators alternate
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[q].v, bf[s3].v, acc[q], 0, 0, 0);
         }
       }
       if (more) {
-        wave_lds_fence();
-        band_store16(myring + ((t + 4) % kSlots) * kBand16, pf, lane);
-        wave_lds_fence();
+        if (tid < kVec) frame_store16(smem + ((t + 4) % kFrameSlots) * kFrame16, pf, tid);   // a slot no wave reads in step t
+        __syncthreads();                                  // frame t+4 visible; every wave is done with step t
       }
     }
   }
 
-  // Cross-wave reduction in wave order (deterministic), then one partial slice per workgroup.
-  __syncthreads();                                         // every wave is done with its ring: red may overlay it
-  bsum += __shfl_xor(bsum, 16, 64);
-  bsum += __shfl_xor(bsum, 32, 64);
-  if (lane < 16) redb[wave * 16 + lane] = bsum;
-  for (int w = 0; w < kWaves; ++w) {
-    if (wave == w) {
+  // ---- the two halves of a channel -> one tile (half 1 through LDS), written straight into the partial slice ----
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);            // [c][q][lane][4]
+  if (half == 1) {
 #pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        const int c = m >> 2, q = m & 3;
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4_t*>(red + ((c * 4 + q) * 64 + lane) * 4) = acc[q];
+  }
+  __syncthreads();
+  if (half == 0) {
+    float* pw = p.partial_w + (long long)blockIdx.x * 256 * p.cout;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 4 * kq + r;                       // k-row within the m-tile
-          const int ky = row >> 1, kx = 4 * (row & 1) + q;
-          const int idx = ((ky * 8 + kx) * 4 + c) * 16 + i;
-          red[idx] = (w == 0) ? acc[m][r] : red[idx] + acc[m][r];
-        }
+    for (int q = 0; q < 4; ++q) {
+      const f32x4_t o = *reinterpret_cast<const f32x4_t*>(red + ((c * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * kq + r;                       // k-row within the m-tile
+        const int ky = row >> 1, kx = 4 * (row & 1) + q;
+        pw[((ky * 8 + kx) * 4 + c) * p.cout + co0 + i] = (acc[q][r] + o[r]) / 255.0f;
       }
     }
-    __syncthreads();
   }
-  float* pw = p.partial_w + (long long)blockIdx.x * 256 * p.cout;
-  for (int idx = tid; idx < kWFloats; idx += kThreads)
-    pw[(idx >> 4) * p.cout + co0 + (idx & 15)] = red[idx] / 255.0f;
-  if (p.partial_b && tid < 16) {
-    float s = 0.f;
-    for (int w = 0; w < kWaves; ++w) s += redb[w * 16 + tid];
-    p.partial_b[(long long)blockIdx.x * p.cout + co0 + tid] = s;
+  if (p.partial_b) {                                      // sum over the pixels of dY: the two c = 0 waves hold it
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    float* redb = red + 16 * 64 * 4;
+    if (c == 0 && lane < 16) redb[half * 16 + lane] = bsum;
+    __syncthreads();
+    if (tid < 16) p.partial_b[(long long)blockIdx.x * p.cout + co0 + tid] = redb[tid] + redb[16 + tid];
   }
 }
 
@@ -723,9 +739,8 @@ int wgrad_grid(const seedhip_stack_conv_geom* g, int* spc, int* items) {
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 2) per_cu = 2;                     // measured: 2 workgroups per CU beat 3 (0.43 vs 0.48 ms at cfg2)
   if (per_cu < 1) per_cu = 1;
-  // the bf16x3 kernel needs ~250 VGPRs next to its 64 accumulators: one 5-wave workgroup per CU is resident
   static const int bf16x3 = getenv("SEEDHIP_STACK_BF16") ? atoi(getenv("SEEDHIP_STACK_BF16")) : 1;
-  if (bf16x3) per_cu = 1;
+  if (bf16x3) per_cu = 2;                             // channel-per-wave kernel: 70 KB LDS, 124 VGPRs x 8 waves
   int grid;
   decompose(g->T, g->B, max_grid_for(per_cu), spc, items, &grid);
   return grid;
@@ -812,10 +827,10 @@ extern "C" int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* ge
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     static const int bf16x3 = getenv("SEEDHIP_STACK_BF16") ? atoi(getenv("SEEDHIP_STACK_BF16")) : 1;
     if (bf16x3) {
-      const size_t lds16 = (size_t)stackconv::kWaves * stackconv::kWaveRing16;
-      (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_bf16_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
-      hipLaunchKernelGGL(stackconv::stackconv_wgrad_bf16_kernel, dim3(grid, 1, N / 16), dim3(stackconv::kThreads), lds16, s, p);
+      const size_t ldsc = (size_t)stackconv::kFrameSlots * stackconv::kFrame16;
+      (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_cw_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);
+      hipLaunchKernelGGL(stackconv::stackconv_wgrad_cw_kernel, dim3(grid, 1, N / 16), dim3(64 * stackconv::kCW), ldsc, s, p);
     }
     else
       hipLaunchKernelGGL(stackconv::stackconv_wgrad_kernel, dim3(grid, 1, N / 16), dim3(stackconv::kThreads), lds, s, p);
