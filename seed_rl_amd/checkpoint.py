@@ -1,0 +1,61 @@
+"""Learner checkpoints in the reference's variable naming.
+
+The reference saves `agent`, `optimizer` and the step counter through tf.train.Checkpoint
+(/root/reference/agents/vtrace/learner.py:286-296).  TensorFlow is not a dependency here, so the container is a plain
+.npz, but the CONTENT is reference-shaped: one array per trainable variable under the Keras variable name and in the
+Keras layout (`agent.trainable_variables`: e.g. the 39 tensors of ImpalaDeep in creation order, policy / baseline heads
+unpacked), Adam's first / second moments under the same names, and `iterations`.  Arrays exported from a TF checkpoint
+with the same names load through `restore(..., strict=False)` (parameters only).
+"""
+import collections
+
+import numpy as np
+import torch
+
+
+def _ref_views(agent, flat_tensor):
+  """Reference-named views into a flat buffer laid out like agent.flat.params."""
+  def getter(name):
+    o = agent.flat.offsets[name]
+    shape = agent.flat.p(name).shape
+    return flat_tensor[o:o + int(np.prod(shape))].view(shape)
+  return collections.OrderedDict((n, agent._ref_view(getter, n)) for n, _, _ in agent._ref_spec)   # pylint: disable=protected-access
+
+
+def save(path, agent, optimizer=None):
+  """Writes `path` (.npz): agent/<name>, and with an optimizer adam_m/<name>, adam_v/<name>, iterations."""
+  out = collections.OrderedDict()
+  for name, view in agent.trainable_variables:
+    out['agent/' + name] = view.detach().cpu().numpy()
+  if optimizer is not None:
+    sd = optimizer.state_dict()
+    out['iterations'] = np.asarray(sd['iterations'], np.int64)
+    if sd['m'] is not None:
+      for key, buf in (('adam_m/', sd['m']), ('adam_v/', sd['v'])):
+        for name, view in _ref_views(agent, buf).items():
+          out[key + name] = view.detach().cpu().numpy()
+  np.savez(path, **out)
+  return list(out)
+
+
+def restore(path, agent, optimizer=None, strict=True):
+  """Loads what `save` wrote.  strict=False: parameters only are required (e.g. arrays exported from a reference
+  checkpoint); the optimizer then starts fresh."""
+  data = np.load(path)
+  agent.load_reference_params(dict((n, data['agent/' + n]) for n, _, _ in agent._ref_spec))   # pylint: disable=protected-access
+  if optimizer is None:
+    return
+  have_opt = 'iterations' in data.files
+  if not have_opt:
+    if strict:
+      raise KeyError('checkpoint %s holds no optimizer state' % path)
+    return
+  m = torch.zeros_like(agent.flat.params)
+  v = torch.zeros_like(agent.flat.params)
+  if any(k.startswith('adam_m/') for k in data.files):
+    for key, buf in (('adam_m/', m), ('adam_v/', v)):
+      for name, view in _ref_views(agent, buf).items():
+        view.copy_(torch.as_tensor(data[key + name]).to(buf.device).reshape(view.shape))
+    optimizer.load_state_dict(dict(iterations=int(data['iterations']), m=m, v=v))
+  else:
+    optimizer.load_state_dict(dict(iterations=int(data['iterations']), m=None, v=None))

@@ -104,3 +104,31 @@ def test_atari_shallow_single_step_inference(device):
   from oracle import frames_np
   _, ns = frames_np.stack_frames(u['frames'][:1], u['frame_state'], u['done'][:1], 4)
   np.testing.assert_array_equal(st1.frame_stacking_state.cpu().numpy(), ns)
+
+
+def test_checkpoint_roundtrip(device, tmp_path):
+  """seed_rl_amd.checkpoint: save after two train steps, restore into a FRESH agent + optimizer, and the third step
+  of both runs is bitwise identical (parameters, Adam moments and step counter all carried; arrays are stored under
+  the reference's variable names in Keras layouts)."""
+  from seed_rl_amd import checkpoint, learner, networks, optimizers, smoke_step
+  from seed_rl_amd import parametric_distribution as pd
+  A, T, B = 6, 5, 8
+
+  def make(seed):
+    agent = networks.AtariShallow(A, device=device, seed=seed)
+    opt = optimizers.Adam(optimizers.PolynomialDecay(1e-3, 100), beta_1=0.0, epsilon=3.125e-7)
+    return agent, opt, learner.Learner(agent, opt, pd.categorical_distribution(A))
+
+  agent, opt, lrn = make(0)
+  unroll = smoke_step.make_unroll(agent, T + 1, B, A, device, seed=3)
+  lrn.minimize(unroll); lrn.minimize(unroll)
+  path = str(tmp_path / 'ckpt.npz')
+  names = checkpoint.save(path, agent, opt)
+  assert 'agent/policy_logits/kernel' in names and 'adam_v/baseline/bias' in names and 'iterations' in names
+  agent2, opt2, lrn2 = make(123)                          # different init: everything must come from the file
+  checkpoint.restore(path, agent2, opt2)
+  assert opt2.iterations == 2
+  l1, _ = lrn.minimize(unroll)
+  l2, _ = lrn2.minimize(unroll)
+  assert float(l1) == float(l2)
+  assert torch.equal(agent.flat.params, agent2.flat.params)
