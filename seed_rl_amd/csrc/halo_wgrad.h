@@ -14,6 +14,10 @@
 //   A: rows = 16 consecutive rows of dW viewed as [9*cin, cout] (row = tap*cin + c),
 //      lane (i, kq) supplies X[pixel 4g+kq shifted by the row's tap][c];
 //   B: cols = 16 output channels, lane (kq, j) supplies dY[pixel 4g+kq][co].
+// Fragments are x-interleaved where the layout allows (fp32 input, cin % 4 == 0; see gemm.h): a lane reads 4
+// consecutive channels of its pixel as ONE ds_read_b128 and feeds 4 row-tiles (tile e of a quad owns rows 4*lane + e),
+// and NT consecutive output channels of dY as one b64 / b128 -- 4 LDS reads per 18 MFMAs for a 3x3 layer with 32
+// output channels instead of 11 (every ds_read costs the fp32 matrix pipe ~14 cycles).
 // The dW rows are split over MSPLIT waves (each MTW row-tiles), pixel groups over the other
 // 4/MSPLIT waves; accumulators stay in registers across all tiles of the persistent workgroup,
 // then waves are summed through LDS in a fixed order and ONE partial slice per workgroup goes
@@ -22,6 +26,7 @@
 #include "common.h"
 #include "igemm.h"
 #include "conv_launch.h"
+#include <cstdlib>
 #include "../../include/seedhip.h"
 
 namespace seedhip {
@@ -40,6 +45,7 @@ struct WgradParams {
   int ntiles;                  // n_img * bands
   int rows;                    // kh * kw * cin
   int xs;                      // LDS pixel stride of the X tile (floats)
+  int ilv;                     // x-interleaved fragments (fp32 input, cin % 4 == 0)
   int twp;                     // tile width incl. halo = (ow - 1) * stride + kw
   int thp;                     // tile rows incl. halo for a full band = (TH - 1) * stride + kh
   FastDiv d_ow;
@@ -58,12 +64,17 @@ halo_wgrad_kernel(const WgradParams p) {
   const int ms = wave % MSPLIT, pp = wave / MSPLIT;
   const int coutp = NT * 16;
 
-  // per-lane LDS offset of each of this wave's dW rows (tap shift + channel)
+  // per-lane LDS offset of each of this wave's dW rows (tap shift + channel).  Interleaved mode (p.ilv): the first
+  // 4*NQ row-tiles form quads, tile e of quad Q owns rows base + 64 Q + 4 i + e and lane i reads them as one float4;
+  // lane_off[4Q] is that quad's offset.  The remaining tiles (and everything when !p.ilv) own rows base + 16 mt + i.
+  constexpr int NQ = MTW / 4;
+  const bool ilv = p.ilv != 0;
   int lane_off[MTW];
   bool row_ok[MTW];
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt) {
-    const int R = (ms * MTW + mt) * 16 + i;
+    const bool quad = ilv && mt < 4 * NQ;
+    const int R = quad ? (ms * MTW + (mt & ~3)) * 16 + 4 * i + (mt & 3) : (ms * MTW + mt) * 16 + i;
     row_ok[mt] = R < p.rows;
     const int Rc = row_ok[mt] ? R : 0;
     const int tap = Rc / p.cin, c = Rc - tap * p.cin;
@@ -182,14 +193,37 @@ halo_wgrad_kernel(const WgradParams p) {
       p.d_ow.divmod((uint32_t)(pv ? pix : 0), py, px);
       const float* xb = xs_lds + ((int)py * p.stride * p.twp + (int)px * p.stride) * p.xs;
       float b[NT];
+      if (ilv) {                                         // NT consecutive channels NT*i .. : one read
+        if constexpr (NT == 1) {
+          b[0] = pv ? dy_lds[pix * coutp + i] : 0.f;
+        } else {
+          typedef float bvec_t __attribute__((ext_vector_type(NT)));
+          const bvec_t bv = *reinterpret_cast<const bvec_t*>(dy_lds + (pv ? pix : 0) * coutp + NT * i);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        b[nt] = pv ? dy_lds[pix * coutp + nt * 16 + i] : 0.f;
-        if (ms == 0) bsum[nt] += b[nt];
+          for (int nt = 0; nt < NT; ++nt) b[nt] = pv ? bv[nt] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = pv ? dy_lds[pix * coutp + nt * 16 + i] : 0.f;
+      }
+      if (ms == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bsum[nt] += b[nt];
       }
       float a[MTW];
+      if (ilv) {
 #pragma unroll
-      for (int mt = 0; mt < MTW; ++mt) a[mt] = row_ok[mt] ? xb[lane_off[mt]] : 0.f;
+        for (int Q = 0; Q < NQ; ++Q) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (row_ok[4 * Q]) v = *reinterpret_cast<const float4*>(xb + lane_off[4 * Q]);   // rows % 4 == 0: all 4 or none
+          a[4 * Q] = v.x; a[4 * Q + 1] = v.y; a[4 * Q + 2] = v.z; a[4 * Q + 3] = v.w;
+        }
+#pragma unroll
+        for (int mt = 4 * NQ; mt < MTW; ++mt) a[mt] = row_ok[mt] ? xb[lane_off[mt]] : 0.f;
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) a[mt] = row_ok[mt] ? xb[lane_off[mt]] : 0.f;
+      }
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -209,8 +243,11 @@ halo_wgrad_kernel(const WgradParams p) {
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = (ms * MTW + mt) * 16 + 4 * kq + r;
-            float* d = red + row * coutp + nt * 16 + i;
+            const int lr = 4 * kq + r;                                  // MFMA row of the tile = the A lane index
+            const bool quad = ilv && mt < 4 * NQ;
+            const int row = quad ? (ms * MTW + (mt & ~3)) * 16 + 4 * lr + (mt & 3) : (ms * MTW + mt) * 16 + lr;
+            const int col = ilv ? NT * i + nt : nt * 16 + i;
+            float* d = red + row * coutp + col;
             *d = (q == 0) ? acc[mt][nt][r] : *d + acc[mt][nt][r];
           }
     }
@@ -229,7 +266,7 @@ halo_wgrad_kernel(const WgradParams p) {
       float s = bsum[nt];
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
-      if (lane < 16) rb[wave * coutp + nt * 16 + lane] = s;
+      if (lane < 16) rb[wave * coutp + (ilv ? NT * lane + nt : nt * 16 + lane)] = s;
     }
     __syncthreads();
     if (tid < p.cout) {
@@ -293,6 +330,8 @@ inline int launch_wgrad(const seedhip_conv_geom* g, const WgradPlan& pl, const v
   p.kh = g->kh; p.kw = g->kw; p.stride = g->stride;
   p.TH = pl.TH; p.bands = (g->oh + pl.TH - 1) / pl.TH; p.ntiles = g->n_img * p.bands;
   p.rows = g->kh * g->kw * g->cin; p.xs = g->cin;
+  static const int ilv_on = getenv("SEEDHIP_HALO_ILV") ? atoi(getenv("SEEDHIP_HALO_ILV")) : 1;
+  p.ilv = (ilv_on && in_dtype == 0 && g->cin % 4 == 0 && g->ld_in % 4 == 0) ? 1 : 0;
   p.twp = (g->ow - 1) * g->stride + g->kw; p.thp = (pl.TH - 1) * g->stride + g->kh;
   p.d_ow.init(g->ow);
   p.partial_w = (float*)workspace;
