@@ -313,7 +313,8 @@ inline WgradPlan plan_wgrad(const seedhip_conv_geom* g) {
   pl.TH = th;
   const int bands = (g->oh + th - 1) / th;
   const long long ntiles = (long long)g->n_img * bands;
-  int per_cu = (int)((160 * 1024) / pl.lds); if (per_cu > 2) per_cu = 2; if (per_cu < 1) per_cu = 1;
+  static const int cap = getenv("SEEDHIP_HALO_PERCU") ? atoi(getenv("SEEDHIP_HALO_PERCU")) : 2;
+  int per_cu = (int)((160 * 1024) / pl.lds); if (per_cu > cap) per_cu = cap; if (per_cu < 1) per_cu = 1;
   const long long mg = 256LL * per_cu;
   pl.grid = (int)(ntiles < mg ? ntiles : mg);
   pl.ws_bytes = (size_t)pl.grid * ((size_t)rows * g->cout + g->cout) * sizeof(float);
