@@ -181,11 +181,13 @@ def main():
   ops.set_profiler(None)
   kern = prof_all.summary()
   # dominant kernel = largest share of the step in the attribution pass (device drained before every region),
-  # among the MFMA kernels and the HBM kernels that move >= 32 MB, and only those averaging >= 50 us per launch:
+  # among the MFMA kernels and the HBM kernels that move >= 32 MB, and only those averaging >= 50 us per launch and
+  # launched at most 64 times per step:
   # event pairs around few-microsecond kernels launched hundreds of times per step (LSTM gates, the per-step
   # recurrent GEMM) are not a reliable ranking -- the rocprofv3 --stats tables under profiles/ are the reference
   # view and agree with this choice
-  big = [k for k in kern if (kern[k]['flops'] > 0 or kern[k]['bytes'] >= (1 << 25)) and kern[k]['avg_ms'] >= 0.05]
+  big = [k for k in kern if (kern[k]['flops'] > 0 or kern[k]['bytes'] >= (1 << 25)) and kern[k]['avg_ms'] >= 0.05
+         and kern[k]['calls'] <= 64]
   big = big or list(kern)
   dominant = max(big, key=lambda k: kern[k]['total_ms'])
   if args.warmup == 0:
