@@ -65,9 +65,9 @@ int dense_slices(int M, int N, int K) {
 }
 int slice_k(int K, int slices) { int per = (K + slices - 1) / slices; return (per + 15) / 16 * 16; }
 
-// Dense layers on gemm.h (see there).  mode bits (SEEDHIP_GEMM, default 127): 1 forward, 2 data gradient, 4 weight
-// gradient (8 / 16: wsgemm.h conv forward / data gradient; 32 / 64: gather-GEMM conv forward / data gradient); a cleared bit falls back to the Dense accessors of the implicit-GEMM core (A/B measurements).
-int gemm_mode() { static int m = getenv("SEEDHIP_GEMM") ? atoi(getenv("SEEDHIP_GEMM")) : 127; return m; }
+// Dense layers on gemm.h (see there).  mode bits (SEEDHIP_GEMM, default 255): 1 forward, 2 data gradient, 4 weight
+// gradient (8 / 16: wsgemm.h conv forward / data gradient; 32 / 64 / 128: gather-GEMM conv forward / data gradient / weight gradient); a cleared bit falls back to the Dense accessors of the implicit-GEMM core (A/B measurements).
+int gemm_mode() { static int m = getenv("SEEDHIP_GEMM") ? atoi(getenv("SEEDHIP_GEMM")) : 255; return m; }
 bool al16(const void* q) { return (((uintptr_t)q) & 15) == 0; }
 bool gemm_fwd_ok(const seedhip_conv_geom* g) {
   // rows may carry up to 3 pad columns (ld_in >= cin rounded up to 4; pads finite): the last k-vector of a row is
@@ -81,6 +81,22 @@ bool gemm_wgrad_ok(const seedhip_conv_geom* g) {
 size_t gemm_partial_bytes(int M, int N, int K) {
   const gemm::Plan pl = gemm::plan(M, N, K);
   return pl.slices > 1 ? (size_t)pl.slices * M * N * sizeof(float) : 0;
+}
+
+bool is_dense(const seedhip_conv_geom* g);
+// convs with >= 64 output channels: weight gradient as a gather-GEMM over output pixels (gemm.h, bit 128)
+bool conv_wgrad_gemm_ok(const seedhip_conv_geom* g) {
+  gemm::Params tmp;
+  return (gemm_mode() & 128) && !is_dense(g) && g->cout >= 64 && gemm::conv_wgrad_setup(tmp, g);
+}
+gemm::Plan conv_wgrad_plan(const seedhip_conv_geom* g) {
+  const int M = g->kh * g->kw * g->cin, N = g->cout;
+  const long long pixels = (long long)g->n_img * g->oh * g->ow;
+  gemm::Plan pl = gemm::plan(M, N, (int)(pixels < (1LL << 30) ? pixels : (1LL << 30)));
+  if (pl.slices < 2) {                                    // always through the partial buffer: >= 2 slices
+    pl.slices = 2; pl.k_per_slice = (int)(((pixels + 1) / 2 + gemm::BK - 1) / gemm::BK * gemm::BK);
+  }
+  return pl;
 }
 
 bool is_dense(const seedhip_conv_geom* g) {
@@ -341,6 +357,11 @@ extern "C" size_t seedhip_conv2d_bwd_weight_workspace_bytes(const seedhip_conv_g
     const size_t mm = (size_t)gpl.slices * ((size_t)g->cin * g->cout + g->cout) * sizeof(float);
     if (mm > need) need = mm;
   }
+  if (conv_wgrad_gemm_ok(g)) {
+    const gemm::Plan gpl = conv_wgrad_plan(g);
+    const size_t mm = (size_t)gpl.slices * ((size_t)M * N + N) * sizeof(float);
+    if (mm > need) need = mm;
+  }
   return need;
 }
 
@@ -352,6 +373,21 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
   SEEDHIP_REQUIRE(in_dtype == kInF32 || in_dtype == kInU8Div255, "conv2d_bwd_weight: bad in_dtype %d", in_dtype);
   SEEDHIP_REQUIRE(workspace_bytes >= seedhip_conv2d_bwd_weight_workspace_bytes(geom),
                   "conv2d_bwd_weight: workspace too small");
+  if (in_dtype == kInF32 && conv_wgrad_gemm_ok(geom) && al16(in) && al16(dy) && al16(workspace)) {
+    gemm::Params gp;
+    gemm::conv_wgrad_setup(gp, geom);
+    const gemm::Plan pl = conv_wgrad_plan(geom);
+    const int M = gp.M, N = gp.N;
+    hipStream_t s = (hipStream_t)stream;
+    gp.A = (const float*)in; gp.a_relu = in_relu; gp.B = dy; gp.k_per_slice = pl.k_per_slice;
+    float* pw = (float*)workspace;
+    float* pb = pw + (size_t)pl.slices * M * N;
+    gp.partial = pw; gp.partial_colsum = dbias ? pb : nullptr;
+    gemm::launch<false, false, true, false, false>(gp, pl, s);
+    reduce_slices(pw, pl.slices, (long long)M * N, dw, s);
+    if (dbias) reduce_slices(pb, pl.slices, N, dbias, s);
+    return check_launch("conv2d_bwd_weight(gather gemm)");
+  }
   {
     // 3x3 stride-1 layers: input band + halo staged once per tile in LDS (halo_wgrad.h)
     const halo::WgradPlan pl = halo::plan_wgrad(geom);

@@ -170,7 +170,66 @@ struct GatherStager {                        // KC only; same interface as Stage
   }
 };
 
+// Outer-contiguous gathered operand: the im2col matrix of a convolution read TRANSPOSED, for the weight gradient
+// dW[(ky, kx, c), co] = sum_pixels X[pixel; ky, kx, c] * dY[pixel, co].  The GEMM row x is the dW row (tap, channel):
+// 4 consecutive channels of one tap are one float4 of the NHWC input; the reduction index k is the output pixel.
+// Geometry = the forward conv's `Gather` (pixel -> (img, a, b), tap offsets, border predicate); the per-thread tap
+// part is fixed for the whole launch, only the pixel part changes from k-tile to k-tile.
+template <int BX>
+struct GatherOCStager {
+  static constexpr int kVecs = BX * BK / 4 / 256;
+  static constexpr int kLdOC = LdOC<BX>::value;
+  static constexpr int kLdsFloats = BK * kLdOC;
+  int lds_off[kVecs], krow[kVecs];
+  int toff, tdy, tdx;                        // this thread's tap: offset and border shift (same x4 for all its vectors)
+  bool x_ok;
+  const float* p0;
+  const Gather* g;
+  float4 r[kVecs];
+
+  __device__ void init(const float* p, const Gather& gg, int /*nkt*/, int xbase, int X, int tid) {
+    g = &gg; p0 = p + gg.const0;
+    const int x4 = (tid % (BX / 4)) * 4, xg = xbase + x4;
+    x_ok = xg < X;
+    const int xc = x_ok ? xg : 0;
+    const int tap = xc >> gg.cshift, kin = xc & ((1 << gg.cshift) - 1);
+    uint32_t ty, tx;
+    gg.d_tw.divmod((uint32_t)tap, ty, tx);
+    toff = (int)ty * gg.tsy + (int)tx * gg.tsx + kin;
+    tdy = (int)ty * gg.ey + gg.oy0; tdx = (int)tx * gg.ex + gg.ox0;
+#pragma unroll
+    for (int i = 0; i < kVecs; ++i) {
+      const int v = tid + i * 256;
+      krow[i] = v / (BX / 4);
+      lds_off[i] = krow[i] * kLdOC + x4;
+    }
+  }
+  __device__ void load(int k, int k1, bool relu) {
+#pragma unroll
+    for (int i = 0; i < kVecs; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int pix = k + krow[i];
+      if (x_ok && pix < k1) {
+        uint32_t u, rem, a, b;
+        g->d1.divmod((uint32_t)pix, u, rem);
+        g->d2.divmod(rem, a, b);
+        const int y = (int)a * g->cy + tdy, x = (int)b * g->cx + tdx;
+        if (g->all_valid || (y >= 0 && y < g->vh && x >= 0 && x < g->vw)) {
+          v = *reinterpret_cast<const float4*>(p0 + (long long)u * g->s0 + (long long)a * g->s1 + (long long)b * g->s2 + toff);
+          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
+      }
+      r[i] = v;
+    }
+  }
+  __device__ void store(float* lds) const {
+#pragma unroll
+    for (int i = 0; i < kVecs; ++i) *reinterpret_cast<float4*>(lds + lds_off[i]) = r[i];
+  }
+};
+
 template <int BX, bool KC, bool G> struct PickStager { typedef Stager<BX, KC> type; };
+template <int BX> struct PickStager<BX, false, true> { typedef GatherOCStager<BX> type; };
 template <int BX> struct PickStager<BX, true, true> { typedef GatherStager<BX> type; };
 
 template <int R> struct FragVec;
@@ -457,6 +516,18 @@ inline bool conv_dgrad_setup(Params& p, const seedhip_conv_geom* g) {
   b.s0 = (long long)g->kw * g->cin * g->cout; b.s1 = g->cin * g->cout; b.s2 = g->cout;
   b.cshift = cs; b.ntaps = jh * jw; b.tsy = s * g->kw * g->cin * g->cout; b.tsx = s * g->cin * g->cout;
   b.all_valid = 1;
+  return true;
+}
+
+// Weight gradient: m = dW row (ky, kx, c), n = co, k = output pixel; A = the input gathered per tap (OC, above),
+// B = dY [pixel, co] as stored.  Same geometry requirements as the forward.
+inline bool conv_wgrad_setup(Params& p, const seedhip_conv_geom* g) {
+  Params f;
+  if (!conv_fwd_setup(f, g)) return false;
+  memset(&p, 0, sizeof(p));
+  p.ga = f.ga;
+  p.M = g->kh * g->kw * g->cin; p.N = g->cout; p.K = g->n_img * g->oh * g->ow;
+  p.ldb = g->ld_out;
   return true;
 }
 
