@@ -67,6 +67,7 @@ int slice_k(int K, int slices) { int per = (K + slices - 1) / slices; return (pe
 
 // Dense layers on gemm.h (see there).  mode bits (SEEDHIP_GEMM, default 255): 1 forward, 2 data gradient, 4 weight
 // gradient (8 / 16: wsgemm.h conv forward / data gradient; 32 / 64 / 128: gather-GEMM conv forward / data gradient / weight gradient); a cleared bit falls back to the Dense accessors of the implicit-GEMM core (A/B measurements).
+int conv_min_n() { static int v = getenv("SEEDHIP_CONV_MINN") ? atoi(getenv("SEEDHIP_CONV_MINN")) : 64; return v; }
 int gemm_mode() { static int m = getenv("SEEDHIP_GEMM") ? atoi(getenv("SEEDHIP_GEMM")) : 255; return m; }
 bool al16(const void* q) { return (((uintptr_t)q) & 15) == 0; }
 bool gemm_fwd_ok(const seedhip_conv_geom* g) {
@@ -87,7 +88,7 @@ bool is_dense(const seedhip_conv_geom* g);
 // convs with >= 64 output channels: weight gradient as a gather-GEMM over output pixels (gemm.h, bit 128)
 bool conv_wgrad_gemm_ok(const seedhip_conv_geom* g) {
   gemm::Params tmp;
-  return (gemm_mode() & 128) && !is_dense(g) && g->cout >= 64 && gemm::conv_wgrad_setup(tmp, g);
+  return (gemm_mode() & 128) && !is_dense(g) && g->cout >= conv_min_n() && gemm::conv_wgrad_setup(tmp, g);
 }
 gemm::Plan conv_wgrad_plan(const seedhip_conv_geom* g) {
   const int M = g->kh * g->kw * g->cin, N = g->cout;
@@ -156,7 +157,7 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
       return wsgemm::launch(wp, pl, (hipStream_t)stream);
     }
   }
-  if ((gemm_mode() & 32) && !is_dense(geom) && geom->cout >= 64 && in_dtype == kInF32 && al16(in) && al16(w) && al16(out)) {
+  if ((gemm_mode() & 32) && !is_dense(geom) && geom->cout >= conv_min_n() && in_dtype == kInF32 && al16(in) && al16(w) && al16(out)) {
     // convs with >= 64 output channels on the GEMM core with a gathered A operand (gemm.h).  Measured: narrower
     // layers (the 16 / 32-channel ImpalaDeep convs) lose to the halo kernels below -- a 64-wide N tile is half empty
     gemm::Params gp;
@@ -256,7 +257,12 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
       return wsgemm::launch(wp, pl, (hipStream_t)stream);
     }
   }
-  if ((gemm_mode() & 64) && !is_dense(geom) && geom->stride * geom->stride * geom->cin >= 64 && al16(dy) && al16(w)) {
+  // measured (ImpalaDeep 32 -> 32 @18x24: 3.74 -> 3.05 ms): with the 4x1-wave 32-column tiles the data gradient of
+  // 32-channel layers on maps of >= 400 pixels also goes to the gather-GEMM; forward and weight gradient of such
+  // layers stay on the halo kernels (equal / 2.7x slower there)
+  const int dgrad_n = geom->stride * geom->stride * geom->cin;
+  if ((gemm_mode() & 64) && !is_dense(geom) && al16(dy) && al16(w) &&
+      (dgrad_n >= conv_min_n() || (dgrad_n == 32 && geom->ih * geom->iw >= 400 && geom->stride == 1))) {
     gemm::Params gp;
     if (gemm::conv_dgrad_setup(gp, geom)) {
       gp.A = dy; gp.B = w; gp.C = dx; gp.mask = relu_mask; gp.add = add;

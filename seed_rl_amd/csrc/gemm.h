@@ -67,7 +67,7 @@ constexpr int BK = 32, LD_KC = BK + 8;
 // OC rows are BX floats; with 2-wide fragments (ds_read_b64: lane groups {0-31}, {32-63} = two k rows 4 apart each)
 // the row stride must move 4 rows by 32 banks: BX + 8.  4-wide fragments (b128, 16 lanes = 256 contiguous bytes per
 // group) are conflict free at any stride.
-template <int BX> struct LdOC { static constexpr int value = (BX == 64) ? BX + 8 : BX; };
+template <int BX> struct LdOC { static constexpr int value = (BX == 64 || BX == 32) ? BX + 8 : BX; };
 
 template <int BX, bool KC>
 struct Stager {
@@ -238,17 +238,20 @@ template <> struct FragVec<2> { typedef float type __attribute__((ext_vector_typ
 
 // AG / BG: the (KC) operand is gathered (struct Gather).  SCATTER: conv data-gradient epilogue, row m = super-pixel
 // (img, a, b), column n = (py, px, ci) -> dx[img, es*a + py, es*b + px, ci].
-template <int MR, int NR, bool AKC, bool BKC, bool AG = false, bool BG = false, bool SCATTER = false>
-__global__ void __launch_bounds__(256)                 // 2 x 2 waves; tile (2*MR*16) x (2*NR*16); MR, NR in {2, 4}
+// WN: waves along N -- 2: 2 x 2 waves, tile (2*MR*16) x (2*NR*16); 1: 4 x 1 waves, tile (4*MR*16) x (NR*16) for
+// N <= 32 (the 32-channel conv layers).  MR, NR in {2, 4}.
+template <int MR, int NR, bool AKC, bool BKC, bool AG = false, bool BG = false, bool SCATTER = false, int WN = 2>
+__global__ void __launch_bounds__(256)
 gemm_kernel(const Params p) {
-  constexpr int BM = 2 * MR * 16, BN = 2 * NR * 16;
+  constexpr int WM = 4 / WN;
+  constexpr int BM = WM * MR * 16, BN = WN * NR * 16;
   typedef typename PickStager<BM, AKC, AG>::type SA;
   typedef typename PickStager<BN, BKC, BG>::type SB;
   __shared__ __attribute__((aligned(16))) float smem[SA::kLdsFloats + SB::kLdsFloats];
   float* As = smem;
   float* Bs = smem + SA::kLdsFloats;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, lx = lane & 15, kq = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN, lx = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int k0 = blockIdx.z * p.k_per_slice;
   int k1 = k0 + p.k_per_slice; if (k1 > p.K) k1 = p.K;
@@ -421,17 +424,21 @@ gemm_kernel(const Params p) {
 //   * a CU saturates the matrix pipe with `sat` resident workgroups (4 / 2.5 / 2) and holds at most `occ` (5 / 3 / 2);
 //     fewer resident workgroups each run at 1/sat of the CU rate; the busiest CU sets the time;
 //   * split-K adds the reduce pass: (slices + 1) * M * N floats through HBM + one launch.
-struct Plan { int mr, nr, slices, k_per_slice; double model_us; };
+struct Plan { int mr, nr, slices, k_per_slice; double model_us; int wn; };
 inline Plan plan(int M, int N, int K) {
-  struct Tile { int mr, nr, occ; double sat, ovh; };
-  static const Tile kTiles[3] = {{2, 2, 5, 4.0, 2.7}, {4, 2, 3, 2.5, 4.7}, {4, 4, 2, 2.0, 7.0}};
+  struct Tile { int mr, nr, occ; double sat, ovh; int wn; };
+  // 2x2-wave tiles 64x64 / 128x64 / 128x128, and for N <= 32 the 4x1-wave tiles 128x32 / 256x32
+  static const Tile kTiles[5] = {{2, 2, 5, 4.0, 2.7, 2}, {4, 2, 3, 2.5, 4.7, 2}, {4, 4, 2, 2.0, 7.0, 2},
+                                 {2, 2, 5, 4.0, 2.7, 1}, {4, 2, 3, 2.5, 4.7, 1}};
   static const int kSlices[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128};
   static const int force = getenv("SEEDHIP_GEMM_TILE") ? atoi(getenv("SEEDHIP_GEMM_TILE")) : 0;
   static const int force_s = getenv("SEEDHIP_GEMM_SLICES") ? atoi(getenv("SEEDHIP_GEMM_SLICES")) : 0;
-  Plan best{2, 2, 1, (K + BK - 1) / BK * BK, 1e30};
+  Plan best{2, 2, 1, (K + BK - 1) / BK * BK, 1e30, 2};
   for (const Tile& t : kTiles) {
-    if (force && force != t.mr * 10 + t.nr) continue;
-    const long long tiles = (long long)((M + 32 * t.mr - 1) / (32 * t.mr)) * ((N + 32 * t.nr - 1) / (32 * t.nr));
+    if (force && force != t.mr * 10 + t.nr + 100 * (t.wn == 1)) continue;
+    if (t.wn == 1 && N > 16 * t.nr) continue;                                // 4x1 tiles are one column tile wide
+    const int bm = (4 / t.wn) * t.mr * 16, bn = t.wn * t.nr * 16;
+    const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     for (int s : kSlices) {
       if (force_s) { if (s != force_s) continue; }
       else if (s > 1 && K / s < 4 * BK) break;
@@ -446,7 +453,7 @@ inline Plan plan(int M, int N, int K) {
       const double unit_us = 32.0 * 32 * 32 / 128.0 / 2400.0 / 0.80;
       double us = serial * wg_units * unit_us;
       if (slices > 1) us += 4.0 + (slices + 1.0) * M * N * 4.0 / 3.0e6;
-      if (us < best.model_us) best = Plan{t.mr, t.nr, slices, per, us};
+      if (us < best.model_us) best = Plan{t.mr, t.nr, slices, per, us, t.wn};
     }
   }
   if (getenv("SEEDHIP_GEMM_DEBUG")) {
@@ -454,8 +461,8 @@ inline Plan plan(int M, int N, int K) {
     const long long key = ((long long)M << 40) ^ ((long long)N << 20) ^ K;
     if (key != last) {
       last = key;
-      fprintf(stderr, "[gemm] M=%d N=%d K=%d -> tile %dx%d slices %d (model %.1f us)\n", M, N, K, 32 * best.mr,
-              32 * best.nr, best.slices, best.model_us);
+      fprintf(stderr, "[gemm] M=%d N=%d K=%d -> tile %dx%d slices %d (model %.1f us)\n", M, N, K,
+              (4 / best.wn) * best.mr * 16, best.wn * best.nr * 16, best.slices, best.model_us);
     }
   }
   return best;
@@ -463,9 +470,11 @@ inline Plan plan(int M, int N, int K) {
 
 template <bool AKC, bool BKC, bool AG = false, bool BG = false, bool SCATTER = false>
 inline void launch(const Params& p, const Plan& pl, hipStream_t s) {
-  const int bm = 32 * pl.mr, bn = 32 * pl.nr;
+  const int bm = (4 / pl.wn) * pl.mr * 16, bn = pl.wn * pl.nr * 16;
   dim3 grid((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, pl.slices);
-  if (pl.mr == 4 && pl.nr == 4) hipLaunchKernelGGL((gemm_kernel<4, 4, AKC, BKC, AG, BG, SCATTER>), grid, dim3(256), 0, s, p);
+  if (pl.wn == 1 && pl.mr == 4) hipLaunchKernelGGL((gemm_kernel<4, 2, AKC, BKC, AG, BG, SCATTER, 1>), grid, dim3(256), 0, s, p);
+  else if (pl.wn == 1) hipLaunchKernelGGL((gemm_kernel<2, 2, AKC, BKC, AG, BG, SCATTER, 1>), grid, dim3(256), 0, s, p);
+  else if (pl.mr == 4 && pl.nr == 4) hipLaunchKernelGGL((gemm_kernel<4, 4, AKC, BKC, AG, BG, SCATTER>), grid, dim3(256), 0, s, p);
   else if (pl.mr == 4 && pl.nr == 2) hipLaunchKernelGGL((gemm_kernel<4, 2, AKC, BKC, AG, BG, SCATTER>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((gemm_kernel<2, 2, AKC, BKC, AG, BG, SCATTER>), grid, dim3(256), 0, s, p);
 }
