@@ -157,9 +157,11 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
       return wsgemm::launch(wp, pl, (hipStream_t)stream);
     }
   }
-  if ((gemm_mode() & 32) && !is_dense(geom) && geom->cout >= conv_min_n() && in_dtype == kInF32 && al16(in) && al16(w) && al16(out)) {
-    // convs with >= 64 output channels on the GEMM core with a gathered A operand (gemm.h).  Measured: narrower
-    // layers (the 16 / 32-channel ImpalaDeep convs) lose to the halo kernels below -- a 64-wide N tile is half empty
+  if ((gemm_mode() & 32) && !is_dense(geom) && in_dtype == kInF32 && al16(in) && al16(w) && al16(out) &&
+      (geom->cout >= conv_min_n() || (geom->cout == 32 && geom->cin == 32 && geom->stride == 1 && geom->oh * geom->ow >= 400))) {
+    // convs with >= 64 output channels on the GEMM core with a gathered A operand (gemm.h), and 32 -> 32 layers on
+    // maps of >= 400 pixels through the 4x1-wave 32-column tiles (3.71 -> 3.52 ms for ImpalaDeep's five @18x24 convs,
+    // which the halo kernel does not take).  Measured: the other 16 / 32-channel layers are faster on the halo kernels
     gemm::Params gp;
     if (gemm::conv_fwd_setup(gp, geom)) {
       gp.A = (const float*)in; gp.a_relu = in_relu; gp.B = w; gp.C = out; gp.bias = bias; gp.residual = residual;
