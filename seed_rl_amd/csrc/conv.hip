@@ -88,7 +88,10 @@ bool is_dense(const seedhip_conv_geom* g);
 // convs with >= 64 output channels: weight gradient as a gather-GEMM over output pixels (gemm.h, bit 128)
 bool conv_wgrad_gemm_ok(const seedhip_conv_geom* g) {
   gemm::Params tmp;
-  return (gemm_mode() & 128) && !is_dense(g) && g->cout >= conv_min_n() && gemm::conv_wgrad_setup(tmp, g);
+  // >= 64 output channels always; 32 channels only for unpadded layers (the second Atari conv: 0.237 -> 0.211 ms on
+  // 128x32 tiles with ~500 pixel slices; the padded 3x3 ImpalaDeep layers are 1.8x slower here than on halo_wgrad.h)
+  const bool wide = g->cout >= conv_min_n() || (g->cout == 32 && g->pad_t == 0 && g->pad_l == 0 && g->cin % 16 == 0);
+  return (gemm_mode() & 128) && !is_dense(g) && wide && gemm::conv_wgrad_setup(tmp, g);
 }
 gemm::Plan conv_wgrad_plan(const seedhip_conv_geom* g) {
   const int M = g->kh * g->kw * g->cin, N = g->cout;

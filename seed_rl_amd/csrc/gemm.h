@@ -430,7 +430,7 @@ inline Plan plan(int M, int N, int K) {
   // 2x2-wave tiles 64x64 / 128x64 / 128x128, and for N <= 32 the 4x1-wave tiles 128x32 / 256x32
   static const Tile kTiles[5] = {{2, 2, 5, 4.0, 2.7, 2}, {4, 2, 3, 2.5, 4.7, 2}, {4, 4, 2, 2.0, 6.0, 2},
                                  {2, 2, 5, 4.0, 2.7, 1}, {4, 2, 3, 2.5, 4.7, 1}};
-  static const int kSlices[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128};
+  static const int kSlices[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512};
   static const int force = getenv("SEEDHIP_GEMM_TILE") ? atoi(getenv("SEEDHIP_GEMM_TILE")) : 0;
   static const int force_s = getenv("SEEDHIP_GEMM_SLICES") ? atoi(getenv("SEEDHIP_GEMM_SLICES")) : 0;
   Plan best{2, 2, 1, (K + BK - 1) / BK * BK, 1e30, 2};
