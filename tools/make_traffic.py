@@ -2,7 +2,7 @@
 """Builds profiles/<tag>_traffic.json (HBM bytes per launch of the cfg2 hot kernels) from the condensed PMC table
 written by tools/prof_summary.py.
 
-  python tools/make_traffic.py profiles/r01g_cfg2_pmc.csv profiles/r01g_cfg2_traffic.json
+  python tools/make_traffic.py profiles/r01h_cfg2_pmc.csv profiles/r01h_cfg2_traffic.json
 
 Region names are bench.py's (ops.Profiler regions); a region's kernel is the matching row with the largest traffic
 (the Dense GEMM template serves the FC layer and the small heads: the FC launch is the big one).  FETCH_SIZE is doubled
@@ -18,10 +18,10 @@ REGIONS = [
     ('stack_conv_wgrad', 'stackconv::stackconv_wgrad'),
     ('conv_fwd[4x4/2 16->32 @20x20]', 'wsgemm::ws_kernel<1, 2,'),
     ('conv_dgrad[4x4/2 16->32 @20x20]', 'wsgemm::ws_kernel<1, 4,'),
-    ('conv_wgrad[4x4/2 16->32 @20x20]', 'halo_wgrad_kernel'),
-    ('conv_fwd[1x1/1 2592->256 @1x1]', 'true, false, false, false, false>(seedhip::gemm::Params)'),
-    ('conv_dgrad[1x1/1 2592->256 @1x1]', 'true, true, false, false, false>(seedhip::gemm::Params)'),
-    ('conv_wgrad[1x1/1 2592->256 @1x1]', 'false, false, false, false, false>(seedhip::gemm::Params)'),
+    ('conv_wgrad[4x4/2 16->32 @20x20]', 'false, false, true, false, false, 1>(seedhip::gemm::Params)'),
+    ('conv_fwd[1x1/1 2592->256 @1x1]', 'true, false, false, false, false, 2>(seedhip::gemm::Params)'),
+    ('conv_dgrad[1x1/1 2592->256 @1x1]', 'true, true, false, false, false, 2>(seedhip::gemm::Params)'),
+    ('conv_wgrad[1x1/1 2592->256 @1x1]', 'false, false, false, false, false, 2>(seedhip::gemm::Params)'),
 ]
 
 
