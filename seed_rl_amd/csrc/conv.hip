@@ -96,7 +96,7 @@ bool conv_wgrad_gemm_ok(const seedhip_conv_geom* g) {
 gemm::Plan conv_wgrad_plan(const seedhip_conv_geom* g) {
   const int M = g->kh * g->kw * g->cin, N = g->cout;
   const long long pixels = (long long)g->n_img * g->oh * g->ow;
-  gemm::Plan pl = gemm::plan(M, N, (int)(pixels < (1LL << 30) ? pixels : (1LL << 30)));
+  gemm::Plan pl = gemm::plan(M, N, (int)(pixels < (1LL << 30) ? pixels : (1LL << 30)), 0.8);
   if (pl.slices < 2) {                                    // always through the partial buffer: >= 2 slices
     pl.slices = 2; pl.k_per_slice = (int)(((pixels + 1) / 2 + gemm::BK - 1) / gemm::BK * gemm::BK);
   }
@@ -364,7 +364,7 @@ extern "C" size_t seedhip_conv2d_bwd_weight_workspace_bytes(const seedhip_conv_g
   const halo::WgradPlan pl = halo::plan_wgrad(g);
   size_t need = (pl.ok && pl.ws_bytes > generic) ? pl.ws_bytes : generic;
   if (is_dense(g) && gemm_wgrad_ok(g)) {
-    const gemm::Plan gpl = gemm::plan(g->cin, g->cout, g->n_img);
+    const gemm::Plan gpl = gemm::plan(g->cin, g->cout, g->n_img, 0.8);
     const size_t mm = (size_t)gpl.slices * ((size_t)g->cin * g->cout + g->cout) * sizeof(float);
     if (mm > need) need = mm;
   }
@@ -408,7 +408,7 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
   if (is_dense(geom) && in_dtype == kInF32 && geom->ld_in % 4 == 0 && (((uintptr_t)in) & 15) == 0) {
     if (gemm_wgrad_ok(geom) && al16(dy) && al16(workspace)) {
       const int M = geom->cin, N = geom->cout, K = geom->n_img;
-      const gemm::Plan pl = gemm::plan(M, N, K);
+      const gemm::Plan pl = gemm::plan(M, N, K, 0.8);
       hipStream_t s = (hipStream_t)stream;
       gemm::Params gp;
       memset(&gp, 0, sizeof(gp));
