@@ -315,6 +315,12 @@ CONV_CASES = [
     (2, 8, 9, 64, 3, 3, 1, 'same', 64),       # gather-GEMM forward + data gradient with padding
     (2, 11, 9, 64, 5, 5, 1, 'same', 128),     # 5x5: 25 taps, K = 1600
     (3, 13, 11, 16, 4, 4, 2, 'valid', 64),    # stride 2, odd map: super-pixels past the dY border
+    (2, 9, 7, 4, 3, 3, 1, 'same', 64),        # gather-GEMM, 4 channels per tap: 8 taps per k-tile, K = 36 (ragged)
+    (2, 12, 9, 8, 5, 3, 1, 'valid', 72),      # 8 channels per tap, non-square kernel, cout % 16 != 0
+    (3, 14, 14, 16, 6, 6, 3, 'valid', 64),    # stride 3: nine parity classes in the super-pixel data gradient
+    (2, 7, 5, 128, 1, 1, 1, 'valid', 64),     # 1x1 conv on a map (not Dense: ih, iw > 1)
+    (1, 6, 6, 32, 2, 2, 2, 'valid', 256),     # 2x2/2 (non-overlapping), wide output
+    (2, 8, 8, 64, 3, 3, 1, 'same', 192),      # cout = 3 column tiles of 64
 ]
 
 
