@@ -27,7 +27,11 @@
 // 5 waves per workgroup: 400 output pixels = 5 waves x 5 MFMA tiles (fwd) /
 // 5 waves x 20 four-pixel groups (wgrad) -- perfectly balanced for 84x84 frames.
 //
-// MFMA-bound (fp32 v_mfma_f32_16x16x4_f32): 2*400*256*Cout flops per frame.
+// The description above is the fp32-MFMA pair of kernels (v_mfma_f32_16x16x4_f32, 2*400*256*Cout flops per frame),
+// kept for A/B runs (SEEDHIP_STACK_BF16=0).  The DEFAULT kernels further down evaluate the same fp32 arithmetic on
+// the bf16 matrix pipe through an exact three-way operand split ("bf16x3": uint8 pixels are exact in bf16, an fp32
+// weight / gradient is the exact sum of three bf16 numbers): forward with the same band-per-wave organisation and
+// the ring held in bf16, weight gradient with a channel-per-wave organisation.
 #include "common.h"
 #include <cstdlib>
 #include "conv_problems.h"
