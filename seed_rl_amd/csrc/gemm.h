@@ -20,8 +20,7 @@
 // second-pass reduction (fixed slice order).
 #pragma once
 #include "common.h"
-#include "igemm.h"
-#include "../../include/seedhip.h"
+#include "gemm_geom.h"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,38 +29,6 @@ namespace seedhip {
 namespace gemm {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-
-// A k-contiguous operand whose rows are GATHERED instead of dense: the im2col row of a convolution (forward), the
-// dY taps of a (super-)pixel (data gradient), the Keras kernel re-indexed by (parity class, ci) (data gradient B).
-//   row x -> (u, v, w) by two divisions;  row base = const0 + u*s0 + v*s1 + w*s2
-//   k -> tap = k >> cshift (C = 1 << cshift contiguous floats per tap: the channels), tap -> (ty, tx) = divmod(tap, tw)
-//   element address = row base + ty*tsy + tx*tsx + (k & (C-1)); it reads as zero unless tap < ntaps and
-//   (y0 + ty*ey, x0 + tx*ex) lies inside [0, vh) x [0, vw), with (y0, x0) = (ya*cy + oy0, xb*cx + ox0) and
-//   (ya, xb) = (v, w) (or (u, v) when coord_uv): 'same' padding and map borders cost nothing but the predicate.
-// A 16-byte vector never straddles taps (C is a power of two >= 4).
-struct Gather {
-  FastDiv d1, d2, d_tw;
-  long long s0, const0; int s1, s2;
-  int coord_uv, cshift, ntaps;
-  int tsy, tsx;
-  int cy, oy0, ey, cx, ox0, ex, vh, vw, all_valid;
-};
-
-struct Params {
-  const float* A; long long lda; int a_relu;
-  const float* B; long long ldb;
-  int M, N, K;
-  int k_per_slice;                          // split-K over blockIdx.z (multiple of BK)
-  float* partial;                           // [slices][M][N] raw sums, or null: fused epilogue below
-  float* partial_colsum;                    // [slices][N]: sum_k B(k, n) (bias gradient; OC B only), or null
-  float* C; long long ldc;
-  const float* bias; const float* residual; int out_relu;      // forward epilogue
-  const float* mask; const float* add;                         // data-gradient epilogue (indexed like C)
-  Gather ga, gb;                            // gathered operands (conv kernels below); unused by the Dense GEMMs
-  int es, eih, eiw;                         // scatter epilogue (conv data gradient): stride, input map extents
-};
-
-constexpr int BK = 32, LD_KC = BK + 8;
 
 // Staging of one operand tile [X rows/cols = BX][BK] through registers into LDS.
 // OC rows are BX floats; with 2-wide fragments (ds_read_b64: lane groups {0-31}, {32-63} = two k rows 4 apart each)
@@ -135,29 +102,22 @@ struct GatherStager {                        // KC only; same interface as Stage
       const float* b = nullptr;
       int yy = 0, xx = 0;
       if (xbase + row < X) {
-        uint32_t u, rem, vv, ww;
-        gg.d1.divmod((uint32_t)(xbase + row), u, rem);
-        gg.d2.divmod(rem, vv, ww);
-        b = p + gg.const0 + (long long)u * gg.s0 + (long long)vv * gg.s1 + (long long)ww * gg.s2;
-        yy = (int)(gg.coord_uv ? u : vv) * gg.cy + gg.oy0;
-        xx = (int)(gg.coord_uv ? vv : ww) * gg.cx + gg.ox0;
+        long long off;
+        gather_row(gg, xbase + row, off, yy, xx);
+        b = p + off;
       }
       base[i] = b; y0[i] = yy; x0[i] = xx;
     }
   }
   __device__ void load(int k, int k1, bool relu) {
-    const int kk = k + kc;                                  // same tap for all of this thread's vectors
-    const int tap = kk >> g->cshift, kin = kk & ((1 << g->cshift) - 1);
-    uint32_t ty, tx;
-    g->d_tw.divmod((uint32_t)tap, ty, tx);
-    const int toff = (int)ty * g->tsy + (int)tx * g->tsx + kin;
-    const int dy = (int)ty * g->ey, dx = (int)tx * g->ex;
-    const bool tap_ok = tap < g->ntaps;
+    int toff, dy, dx;                                        // same tap for all of this thread's vectors
+    bool tap_ok;
+    gather_tap(*g, k + kc, toff, dy, dx, tap_ok);
 #pragma unroll
     for (int i = 0; i < kVecs; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int y = y0[i] + dy, x = x0[i] + dx;
-      if (base[i] && tap_ok && (g->all_valid || (y >= 0 && y < g->vh && x >= 0 && x < g->vw))) {
+      if (base[i] && tap_ok && gather_inside(*g, y, x)) {
         v = *reinterpret_cast<const float4*>(base[i] + toff);
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       }
@@ -188,15 +148,13 @@ struct GatherOCStager {
   float4 r[kVecs];
 
   __device__ void init(const float* p, const Gather& gg, int /*nkt*/, int xbase, int X, int tid) {
-    g = &gg; p0 = p + gg.const0;
+    g = &gg; p0 = p;
     const int x4 = (tid % (BX / 4)) * 4, xg = xbase + x4;
     x_ok = xg < X;
     const int xc = x_ok ? xg : 0;
-    const int tap = xc >> gg.cshift, kin = xc & ((1 << gg.cshift) - 1);
-    uint32_t ty, tx;
-    gg.d_tw.divmod((uint32_t)tap, ty, tx);
-    toff = (int)ty * gg.tsy + (int)tx * gg.tsx + kin;
-    tdy = (int)ty * gg.ey + gg.oy0; tdx = (int)tx * gg.ex + gg.ox0;
+    bool tap_ok;
+    gather_tap(gg, xc, toff, tdy, tdx, tap_ok);
+    x_ok = x_ok && tap_ok;
 #pragma unroll
     for (int i = 0; i < kVecs; ++i) {
       const int v = tid + i * 256;
@@ -210,12 +168,11 @@ struct GatherOCStager {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int pix = k + krow[i];
       if (x_ok && pix < k1) {
-        uint32_t u, rem, a, b;
-        g->d1.divmod((uint32_t)pix, u, rem);
-        g->d2.divmod(rem, a, b);
-        const int y = (int)a * g->cy + tdy, x = (int)b * g->cx + tdx;
-        if (g->all_valid || (y >= 0 && y < g->vh && x >= 0 && x < g->vw)) {
-          v = *reinterpret_cast<const float4*>(p0 + (long long)u * g->s0 + (long long)a * g->s1 + (long long)b * g->s2 + toff);
+        long long off;
+        int y0, x0;
+        gather_row(*g, pix, off, y0, x0);
+        if (gather_inside(*g, y0 + tdy, x0 + tdx)) {
+          v = *reinterpret_cast<const float4*>(p0 + off + toff);
           if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         }
       }
@@ -348,19 +305,11 @@ gemm_kernel(const Params p) {
 #pragma unroll
       for (int j = 0; j < NR; ++j) v[j] = acc[i][j][r];
       if (SCATTER) {
-        uint32_t img, rem, sa_, sb_;
-        p.ga.d1.divmod((uint32_t)m, img, rem);
-        p.ga.d2.divmod(rem, sa_, sb_);
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
           const int n = n0 + wn * NR * 16 + 16 * j + lx;
-          if (n >= p.N) continue;
-          uint32_t py, rem2, px, ci;
-          p.gb.d1.divmod((uint32_t)n, py, rem2);
-          p.gb.d2.divmod(rem2, px, ci);
-          const int oy = (int)sa_ * p.es + (int)py, ox = (int)sb_ * p.es + (int)px;
-          if (oy >= p.eih || ox >= p.eiw) continue;
-          const long long at = (((long long)img * p.eih + oy) * p.eiw + ox) * p.ldc + ci;
+          long long at;
+          if (n >= p.N || !scatter_addr(p.ga, p.gb, p.es, p.eih, p.eiw, p.ldc, m, n, at)) continue;
           float o = v[j];
           if (p.mask && !(p.mask[at] > 0.f)) o = 0.f;
           if (p.add) o += p.add[at];
@@ -480,67 +429,6 @@ inline void launch(const Params& p, const Plan& pl, hipStream_t s) {
   else if (pl.mr == 4 && pl.nr == 4) hipLaunchKernelGGL((gemm_kernel<4, 4, AKC, BKC, AG, BG, SCATTER>), grid, dim3(256), 0, s, p);
   else if (pl.mr == 4 && pl.nr == 2) hipLaunchKernelGGL((gemm_kernel<4, 2, AKC, BKC, AG, BG, SCATTER>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((gemm_kernel<2, 2, AKC, BKC, AG, BG, SCATTER>), grid, dim3(256), 0, s, p);
-}
-
-// ---- convolutions as gather-GEMMs (see struct Gather) ------------------------------------------------------ //
-inline int log2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
-
-// Forward: m = output pixel, k = (ky, kx, ci), n = co, B = the Keras kernel as stored (OC).  Any stride and padding;
-// needs cin a power of two >= 4, ld_in % 4 == 0, cout % 4 == 0.
-inline bool conv_fwd_setup(Params& p, const seedhip_conv_geom* g) {
-  const int cs = log2_exact(g->cin);
-  if (cs < 2 || g->ld_in % 4 || g->cout % 4 || g->ld_out % 4) return false;
-  memset(&p, 0, sizeof(p));
-  p.M = g->n_img * g->oh * g->ow; p.N = g->cout; p.K = g->kh * g->kw * g->cin; p.k_per_slice = (p.K + BK - 1) / BK * BK;
-  p.ldb = g->cout; p.ldc = g->ld_out;
-  Gather& a = p.ga;
-  a.d1.init(g->oh * g->ow); a.d2.init(g->ow); a.d_tw.init(g->kw);
-  a.s0 = (long long)g->ih * g->iw * g->ld_in; a.s1 = g->stride * g->iw * g->ld_in; a.s2 = g->stride * g->ld_in;
-  a.const0 = -((long long)g->pad_t * g->iw + g->pad_l) * g->ld_in;
-  a.cshift = cs; a.ntaps = g->kh * g->kw; a.tsy = g->iw * g->ld_in; a.tsx = g->ld_in;
-  a.cy = g->stride; a.oy0 = -g->pad_t; a.ey = 1; a.cx = g->stride; a.ox0 = -g->pad_l; a.ex = 1; a.vh = g->ih; a.vw = g->iw;
-  a.all_valid = g->pad_t == 0 && g->pad_l == 0 && (g->oh - 1) * g->stride + g->kh <= g->ih &&
-                (g->ow - 1) * g->stride + g->kw <= g->iw;
-  return true;
-}
-
-// Data gradient: m = super-pixel (a, b) covering input pixels (s*a+py, s*b+px), n = (py, px, ci), k = (jy, jx, co):
-//   dX[s*a+py, s*b+px, ci] = sum dY[a-jy, b-jx, co] * W[py+s*jy, px+s*jx, ci, co]                  (pad 0)
-// one GEMM for all stride-parity classes; for stride 1 with padding the same with dY[y+pad-jy, x+pad-jx].
-// A rows = dY taps (zero outside the map), B rows = the kernel's co-contiguous rows re-indexed by (py, px, ci).
-// Needs kh % s == kw % s == 0, cout a power of two >= 4, and pad 0 unless s == 1.
-inline bool conv_dgrad_setup(Params& p, const seedhip_conv_geom* g) {
-  const int s = g->stride, cs = log2_exact(g->cout);
-  if (cs < 2 || g->kh % s || g->kw % s || g->ld_out % 4 || ((g->pad_t || g->pad_l) && s != 1)) return false;
-  const int jh = g->kh / s, jw = g->kw / s;
-  memset(&p, 0, sizeof(p));
-  const int gh = (g->ih + s - 1) / s, gw = (g->iw + s - 1) / s;
-  p.M = g->n_img * gh * gw; p.N = s * s * g->cin; p.K = jh * jw * g->cout; p.k_per_slice = (p.K + BK - 1) / BK * BK;
-  p.ldc = g->ld_in; p.es = s; p.eih = g->ih; p.eiw = g->iw;
-  Gather& a = p.ga;
-  a.d1.init(gh * gw); a.d2.init(gw); a.d_tw.init(jw);
-  a.s0 = (long long)g->oh * g->ow * g->ld_out; a.s1 = g->ow * g->ld_out; a.s2 = g->ld_out;
-  a.const0 = ((long long)g->pad_t * g->ow + g->pad_l) * g->ld_out;
-  a.cshift = cs; a.ntaps = jh * jw; a.tsy = -g->ow * g->ld_out; a.tsx = -g->ld_out;
-  a.cy = 1; a.oy0 = g->pad_t; a.ey = -1; a.cx = 1; a.ox0 = g->pad_l; a.ex = -1; a.vh = g->oh; a.vw = g->ow;
-  Gather& b = p.gb;
-  b.d1.init(s * g->cin); b.d2.init(g->cin); b.d_tw.init(jw);
-  b.s0 = (long long)g->kw * g->cin * g->cout; b.s1 = g->cin * g->cout; b.s2 = g->cout;
-  b.cshift = cs; b.ntaps = jh * jw; b.tsy = s * g->kw * g->cin * g->cout; b.tsx = s * g->cin * g->cout;
-  b.all_valid = 1;
-  return true;
-}
-
-// Weight gradient: m = dW row (ky, kx, c), n = co, k = output pixel; A = the input gathered per tap (OC, above),
-// B = dY [pixel, co] as stored.  Same geometry requirements as the forward.
-inline bool conv_wgrad_setup(Params& p, const seedhip_conv_geom* g) {
-  Params f;
-  if (!conv_fwd_setup(f, g)) return false;
-  memset(&p, 0, sizeof(p));
-  p.ga = f.ga;
-  p.M = g->kh * g->kw * g->cin; p.N = g->cout; p.K = g->n_img * g->oh * g->ow;
-  p.ldb = g->ld_out;
-  return true;
 }
 
 }  // namespace gemm

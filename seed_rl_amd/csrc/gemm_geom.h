@@ -1,0 +1,145 @@
+// Geometry of the GEMM core (gemm.h) that is shared by the device kernels and the HOST: operand descriptors, the
+// launch parameters, and the index arithmetic of gathered (convolution) operands as plain HOST+DEVICE functions --
+// tests/host/emul.cpp executes convolutions through exactly these functions on the CPU, so the address / predicate
+// math the GPU stagers use is unit-tested without a GPU (as conv_problems.h is for the implicit-GEMM core).
+#pragma once
+#include <string.h>
+#include "igemm.h"                              // FastDiv, SH_HD
+#include "../../include/seedhip.h"
+
+namespace seedhip {
+namespace gemm {
+
+// A k-contiguous operand whose rows are GATHERED instead of dense: the im2col row of a convolution (forward), the
+// dY taps of a (super-)pixel (data gradient), the Keras kernel re-indexed by (parity class, ci) (data gradient B).
+//   row x -> (u, v, w) by two divisions;  row base = const0 + u*s0 + v*s1 + w*s2
+//   k -> tap = k >> cshift (C = 1 << cshift contiguous floats per tap: the channels), tap -> (ty, tx) = divmod(tap, tw)
+//   element address = row base + ty*tsy + tx*tsx + (k & (C-1)); it reads as zero unless tap < ntaps and
+//   (y0 + ty*ey, x0 + tx*ex) lies inside [0, vh) x [0, vw), with (y0, x0) = (ya*cy + oy0, xb*cx + ox0) and
+//   (ya, xb) = (v, w) (or (u, v) when coord_uv): 'same' padding and map borders cost nothing but the predicate.
+// A 16-byte vector never straddles taps (C is a power of two >= 4).
+struct Gather {
+  FastDiv d1, d2, d_tw;
+  long long s0, const0; int s1, s2;
+  int coord_uv, cshift, ntaps;
+  int tsy, tsx;
+  int cy, oy0, ey, cx, ox0, ex, vh, vw, all_valid;
+};
+
+struct Params {
+  const float* A; long long lda; int a_relu;
+  const float* B; long long ldb;
+  int M, N, K;
+  int k_per_slice;                          // split-K over blockIdx.z (multiple of BK)
+  float* partial;                           // [slices][M][N] raw sums, or null: fused epilogue below
+  float* partial_colsum;                    // [slices][N]: sum_k B(k, n) (bias gradient; OC B only), or null
+  float* C; long long ldc;
+  const float* bias; const float* residual; int out_relu;      // forward epilogue
+  const float* mask; const float* add;                         // data-gradient epilogue (indexed like C)
+  Gather ga, gb;                            // gathered operands (conv kernels below); unused by the Dense GEMMs
+  int es, eih, eiw;                         // scatter epilogue (conv data gradient): stride, input map extents
+};
+
+constexpr int BK = 32, LD_KC = BK + 8;
+
+
+// ---- index arithmetic of a gathered operand (see struct Gather) -------------------------------------------- //
+// Row part: float offset of the row base (relative to the operand pointer) and the border coordinates (y0, x0).
+SH_HD void gather_row(const Gather& g, int x, long long& base, int& y0, int& x0) {
+  uint32_t u, rem, v, w;
+  g.d1.divmod((uint32_t)x, u, rem);
+  g.d2.divmod(rem, v, w);
+  base = g.const0 + (long long)u * g.s0 + (long long)v * g.s1 + (long long)w * g.s2;
+  y0 = (int)(g.coord_uv ? u : v) * g.cy + g.oy0;
+  x0 = (int)(g.coord_uv ? v : w) * g.cx + g.ox0;
+}
+// Tap part of reduction / row index k: float offset added to the row base, border shift, and whether the tap exists.
+SH_HD void gather_tap(const Gather& g, int k, int& toff, int& dy, int& dx, bool& tap_ok) {
+  const int tap = k >> g.cshift, kin = k & ((1 << g.cshift) - 1);
+  uint32_t ty, tx;
+  g.d_tw.divmod((uint32_t)tap, ty, tx);
+  toff = (int)ty * g.tsy + (int)tx * g.tsx + kin;
+  dy = (int)ty * g.ey; dx = (int)tx * g.ex;
+  tap_ok = tap < g.ntaps;
+}
+SH_HD bool gather_inside(const Gather& g, int y, int x) {
+  return g.all_valid || (y >= 0 && y < g.vh && x >= 0 && x < g.vw);
+}
+// Scatter epilogue of the conv data gradient: GEMM element (m = super-pixel, n = (py, px, ci)) -> offset into dX
+// (returns false when the pixel lies outside the input map: odd extents).
+SH_HD bool scatter_addr(const Gather& ga, const Gather& gb, int es, int eih, int eiw, long long ldc, int m, int n,
+                        long long& at) {
+  uint32_t img, rem, sa, sb, py, rem2, px, ci;
+  ga.d1.divmod((uint32_t)m, img, rem);
+  ga.d2.divmod(rem, sa, sb);
+  gb.d1.divmod((uint32_t)n, py, rem2);
+  gb.d2.divmod(rem2, px, ci);
+  const int oy = (int)sa * es + (int)py, ox = (int)sb * es + (int)px;
+  if (oy >= eih || ox >= eiw) return false;
+  at = (((long long)img * eih + oy) * eiw + ox) * ldc + ci;
+  return true;
+}
+
+// ---- convolutions as gather-GEMMs (see struct Gather) ------------------------------------------------------ //
+inline int log2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
+
+// Forward: m = output pixel, k = (ky, kx, ci), n = co, B = the Keras kernel as stored (OC).  Any stride and padding;
+// needs cin a power of two >= 4, ld_in % 4 == 0, cout % 4 == 0.
+inline bool conv_fwd_setup(Params& p, const seedhip_conv_geom* g) {
+  const int cs = log2_exact(g->cin);
+  if (cs < 2 || g->ld_in % 4 || g->cout % 4 || g->ld_out % 4) return false;
+  memset(&p, 0, sizeof(p));
+  p.M = g->n_img * g->oh * g->ow; p.N = g->cout; p.K = g->kh * g->kw * g->cin; p.k_per_slice = (p.K + BK - 1) / BK * BK;
+  p.ldb = g->cout; p.ldc = g->ld_out;
+  Gather& a = p.ga;
+  a.d1.init(g->oh * g->ow); a.d2.init(g->ow); a.d_tw.init(g->kw);
+  a.s0 = (long long)g->ih * g->iw * g->ld_in; a.s1 = g->stride * g->iw * g->ld_in; a.s2 = g->stride * g->ld_in;
+  a.const0 = -((long long)g->pad_t * g->iw + g->pad_l) * g->ld_in;
+  a.cshift = cs; a.ntaps = g->kh * g->kw; a.tsy = g->iw * g->ld_in; a.tsx = g->ld_in;
+  a.cy = g->stride; a.oy0 = -g->pad_t; a.ey = 1; a.cx = g->stride; a.ox0 = -g->pad_l; a.ex = 1; a.vh = g->ih; a.vw = g->iw;
+  a.all_valid = g->pad_t == 0 && g->pad_l == 0 && (g->oh - 1) * g->stride + g->kh <= g->ih &&
+                (g->ow - 1) * g->stride + g->kw <= g->iw;
+  return true;
+}
+
+// Data gradient: m = super-pixel (a, b) covering input pixels (s*a+py, s*b+px), n = (py, px, ci), k = (jy, jx, co):
+//   dX[s*a+py, s*b+px, ci] = sum dY[a-jy, b-jx, co] * W[py+s*jy, px+s*jx, ci, co]                  (pad 0)
+// one GEMM for all stride-parity classes; for stride 1 with padding the same with dY[y+pad-jy, x+pad-jx].
+// A rows = dY taps (zero outside the map), B rows = the kernel's co-contiguous rows re-indexed by (py, px, ci).
+// Needs kh % s == kw % s == 0, cout a power of two >= 4, and pad 0 unless s == 1.
+inline bool conv_dgrad_setup(Params& p, const seedhip_conv_geom* g) {
+  const int s = g->stride, cs = log2_exact(g->cout);
+  if (cs < 2 || g->kh % s || g->kw % s || g->ld_out % 4 || ((g->pad_t || g->pad_l) && s != 1)) return false;
+  const int jh = g->kh / s, jw = g->kw / s;
+  memset(&p, 0, sizeof(p));
+  const int gh = (g->ih + s - 1) / s, gw = (g->iw + s - 1) / s;
+  p.M = g->n_img * gh * gw; p.N = s * s * g->cin; p.K = jh * jw * g->cout; p.k_per_slice = (p.K + BK - 1) / BK * BK;
+  p.ldc = g->ld_in; p.es = s; p.eih = g->ih; p.eiw = g->iw;
+  Gather& a = p.ga;
+  a.d1.init(gh * gw); a.d2.init(gw); a.d_tw.init(jw);
+  a.s0 = (long long)g->oh * g->ow * g->ld_out; a.s1 = g->ow * g->ld_out; a.s2 = g->ld_out;
+  a.const0 = ((long long)g->pad_t * g->ow + g->pad_l) * g->ld_out;
+  a.cshift = cs; a.ntaps = jh * jw; a.tsy = -g->ow * g->ld_out; a.tsx = -g->ld_out;
+  a.cy = 1; a.oy0 = g->pad_t; a.ey = -1; a.cx = 1; a.ox0 = g->pad_l; a.ex = -1; a.vh = g->oh; a.vw = g->ow;
+  Gather& b = p.gb;
+  b.d1.init(s * g->cin); b.d2.init(g->cin); b.d_tw.init(jw);
+  b.s0 = (long long)g->kw * g->cin * g->cout; b.s1 = g->cin * g->cout; b.s2 = g->cout;
+  b.cshift = cs; b.ntaps = jh * jw; b.tsy = s * g->kw * g->cin * g->cout; b.tsx = s * g->cin * g->cout;
+  b.all_valid = 1;
+  return true;
+}
+
+// Weight gradient: m = dW row (ky, kx, c), n = co, k = output pixel; A = the input gathered per tap (OC, above),
+// B = dY [pixel, co] as stored.  Same geometry requirements as the forward.
+inline bool conv_wgrad_setup(Params& p, const seedhip_conv_geom* g) {
+  Params f;
+  if (!conv_fwd_setup(f, g)) return false;
+  memset(&p, 0, sizeof(p));
+  p.ga = f.ga;
+  p.M = g->kh * g->kw * g->cin; p.N = g->cout; p.K = g->n_img * g->oh * g->ow;
+  p.ldb = g->ld_out;
+  return true;
+}
+
+}  // namespace gemm
+}  // namespace seedhip

@@ -8,6 +8,7 @@
 #include <string.h>
 #include <vector>
 #include "../../seed_rl_amd/csrc/conv_problems.h"
+#include "../../seed_rl_amd/csrc/gemm_geom.h"
 
 using namespace seedhip;
 
@@ -97,6 +98,74 @@ void emul_stack_wgrad(const sgeom_c* g, const uint8_t* frames_ext, const uint8_t
   run_problem(p, s);
   reduce_slices(pw.data(), s, (long long)p.M * p.N, dw);
   reduce_slices(pb.data(), s, p.N, dbias);
+}
+
+
+// ---- gather-GEMM convolutions (gemm.h): the SAME row / tap / border / scatter arithmetic the GPU stagers call ---- //
+static seedhip_conv_geom to_abi(const geom_c* g) {
+  seedhip_conv_geom a;
+  a.n_img = g->n_img; a.ih = g->ih; a.iw = g->iw; a.cin = g->cin; a.oh = g->oh; a.ow = g->ow; a.kh = g->kh; a.kw = g->kw;
+  a.stride = g->stride; a.pad_t = g->pad_t; a.pad_l = g->pad_l; a.cout = g->cout; a.ld_in = g->ld_in; a.ld_out = g->ld_out;
+  return a;
+}
+// element (x, k) of a gathered operand, zero outside
+static float gathered(const float* base, const gemm::Gather& g, int x, int k, int relu) {
+  long long off; int y0, x0, toff, dy, dx; bool ok;
+  gemm::gather_row(g, x, off, y0, x0);
+  gemm::gather_tap(g, k, toff, dy, dx, ok);
+  if (!ok || !gemm::gather_inside(g, y0 + dy, x0 + dx)) return 0.f;
+  const float v = base[off + toff];
+  return (relu && v < 0.f) ? 0.f : v;
+}
+int emul_gather_fwd(const geom_c* g, const float* in, int in_relu, const float* w, const float* bias, float* out,
+                    int out_relu) {
+  const seedhip_conv_geom a = to_abi(g);
+  gemm::Params p;
+  if (!gemm::conv_fwd_setup(p, &a)) return 0;
+  for (int m = 0; m < p.M; ++m)
+    for (int n = 0; n < p.N; ++n) {
+      double acc = 0.0;
+      for (int k = 0; k < p.K; ++k) acc += (double)gathered(in, p.ga, m, k, in_relu) * w[(long long)k * p.ldb + n];
+      float v = (float)acc + (bias ? bias[n] : 0.f);
+      if (out_relu && v < 0.f) v = 0.f;
+      out[(long long)m * p.ldc + n] = v;
+    }
+  return 1;
+}
+int emul_gather_dgrad(const geom_c* g, const float* dy, const float* w, float* dx, const float* mask, const float* add) {
+  const seedhip_conv_geom a = to_abi(g);
+  gemm::Params p;
+  if (!gemm::conv_dgrad_setup(p, &a)) return 0;
+  for (int m = 0; m < p.M; ++m)
+    for (int n = 0; n < p.N; ++n) {
+      long long at;
+      if (!gemm::scatter_addr(p.ga, p.gb, p.es, p.eih, p.eiw, p.ldc, m, n, at)) continue;
+      double acc = 0.0;
+      for (int k = 0; k < p.K; ++k) acc += (double)gathered(dy, p.ga, m, k, 0) * gathered(w, p.gb, n, k, 0);
+      float v = (float)acc;
+      if (mask && !(mask[at] > 0.f)) v = 0.f;
+      if (add) v += add[at];
+      dx[at] = v;
+    }
+  return 1;
+}
+int emul_gather_wgrad(const geom_c* g, const float* in, int in_relu, const float* dy, float* dw, float* dbias) {
+  const seedhip_conv_geom a = to_abi(g);
+  gemm::Params p;
+  if (!gemm::conv_wgrad_setup(p, &a)) return 0;
+  // the transposed im2col operand: reduction index = output pixel (the Gather's row), GEMM row = (tap, channel)
+  for (int x = 0; x < p.M; ++x)
+    for (int n = 0; n < p.N; ++n) {
+      double acc = 0.0;
+      for (int pix = 0; pix < p.K; ++pix) acc += (double)gathered(in, p.ga, pix, x, in_relu) * dy[(long long)pix * p.ldb + n];
+      dw[(long long)x * p.N + n] = (float)acc;
+    }
+  for (int n = 0; n < p.N; ++n) {
+    double sacc = 0.0;
+    for (int pix = 0; pix < p.K; ++pix) sacc += dy[(long long)pix * p.ldb + n];
+    dbias[n] = (float)sacc;
+  }
+  return 1;
 }
 
 }  // extern "C"

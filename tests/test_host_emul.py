@@ -124,6 +124,53 @@ def test_conv_fwd_dgrad_wgrad(emul, case, variant):
     np.testing.assert_allclose(dx, ref, rtol=1e-4, atol=1e-4)
 
 
+GATHER_CASES = [
+    (2, 9, 10, 16, 3, 3, 1, 'same', 32),     # ImpalaDeep residual conv: taps predicated at the border
+    (2, 12, 12, 16, 4, 4, 2, 'valid', 32),   # second Atari conv: four parity classes in one data-gradient GEMM
+    (2, 9, 9, 32, 3, 3, 1, 'valid', 64),     # DQN conv3: 'valid' stride 1, dY smaller than the input map
+    (1, 13, 11, 8, 4, 4, 2, 'valid', 16),    # odd map: super-pixels beyond the dY border and beyond the input
+    (2, 7, 8, 4, 3, 3, 1, 'same', 8),        # 4 channels per tap (8 taps per 32-deep k-tile), K = 36
+    (1, 12, 12, 16, 6, 6, 3, 'valid', 16),   # stride 3: nine parity classes
+]
+
+
+@pytest.mark.parametrize('case', GATHER_CASES)
+def test_gather_gemm_index_math(emul, case):
+  """The gathered-operand arithmetic of the GEMM core (seed_rl_amd/csrc/gemm_geom.h: gather_row / gather_tap /
+  gather_inside / scatter_addr and the conv_*_setup geometry) executed on the CPU, element by element, against the
+  torch oracle: forward, super-pixel data gradient (with ReLU mask and accumulate), transposed-im2col weight gradient."""
+  n, ih, iw, cin, kh, kw, stride, padding, cout = case
+  rng = np.random.default_rng(abs(hash(case)) % 1000)
+  x_raw = rng.normal(size=(n, ih, iw, cin)).astype(np.float32)
+  w = rng.normal(size=(kh, kw, cin, cout)).astype(np.float32) * 0.2
+  b = rng.normal(size=(cout,)).astype(np.float32)
+  g = make_geom(n, ih, iw, cin, kh, kw, stride, padding, cout)
+  x = torch.tensor(x_raw, requires_grad=True)
+  wt = torch.tensor(w, requires_grad=True); bt = torch.tensor(b, requires_grad=True)
+  y = F.relu(nets_torch.conv2d(F.relu(x), wt, bt, stride, padding))
+  dy = rng.normal(size=y.shape).astype(np.float32)
+  y.backward(torch.tensor(dy))
+  for f in (emul.emul_gather_fwd, emul.emul_gather_dgrad, emul.emul_gather_wgrad):
+    f.restype = ctypes.c_int
+
+  out = np.zeros((n, g.oh, g.ow, cout), np.float32)
+  assert emul.emul_gather_fwd(ctypes.byref(g), ptr(x_raw), 1, ptr(w), ptr(b), ptr(out), 1)
+  np.testing.assert_allclose(out, y.detach().numpy(), rtol=1e-4, atol=1e-5)
+
+  dz = np.ascontiguousarray(dy * (y.detach().numpy() > 0), np.float32)
+  dw = np.zeros_like(w); db = np.zeros_like(b)
+  assert emul.emul_gather_wgrad(ctypes.byref(g), ptr(x_raw), 1, ptr(dz), ptr(dw), ptr(db))
+  np.testing.assert_allclose(dw, wt.grad.numpy(), rtol=1e-4, atol=1e-4)
+  np.testing.assert_allclose(db, bt.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+  dx = np.full((n, ih, iw, cin), 7.0, np.float32)        # every element must be overwritten
+  add = rng.normal(size=dx.shape).astype(np.float32)
+  ok = emul.emul_gather_dgrad(ctypes.byref(g), ptr(dz), ptr(w), ptr(dx), ptr(x_raw), ptr(add))
+  if kh % stride == 0 and kw % stride == 0 and (stride == 1 or padding == 'valid'):
+    assert ok
+    np.testing.assert_allclose(dx, x.grad.numpy() + add, rtol=1e-4, atol=1e-4)
+
+
 def test_conv_strided_ld(emul):
   """Dense with padded row strides (LSTM input concat buffer / head output)."""
   rng = np.random.default_rng(0)
