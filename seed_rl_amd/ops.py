@@ -139,7 +139,9 @@ def conv2d_fwd(g, x, w, bias, out, in_dtype=IN_F32, in_relu=False, out_relu=Fals
 
 
 def conv2d_bwd_data(g, dy, w, dx, relu_mask=None, add=None):
-  with _region(_conv_name('conv_dgrad', g), *_conv_cost(g)):
+  flops, nbytes = _conv_cost(g)
+  nbytes += 4 * g.n_img * g.ih * g.iw * g.cin * ((relu_mask is not None) + (add is not None))   # mask / accumulate reads
+  with _region(_conv_name('conv_dgrad', g), flops, nbytes):
     with _dev(dx):
       ws, wsb = _splitk_ws(int(_lib.lib().seedhip_conv2d_bwd_data_workspace_bytes(ctypes.byref(g))), dx)
       _lib.check(_lib.lib().seedhip_conv2d_bwd_data_ws(
