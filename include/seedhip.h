@@ -205,6 +205,19 @@ int seedhip_lstm_step_supported(int B, int H);
 int seedhip_lstm_step_fwd(const float* hin, const float* up, const float* zx, const float* cin,
                           const uint8_t* done_next, int B, int H, float* z, float* h_out, int ld_h, float* hin_next,
                           float* cin_next, void* stream);
+/* The whole unroll of T1 steps in ONE launch (the `for t` loop of dmlab/networks.py:152-171 itself): workgroups stay
+ * resident, keep their slice of U in LDS and the cell state in registers; h_t is exchanged through hin with
+ * agent-scope stores / loads and is its own ready flag (the call pre-fills hin[1..T1] with a sentinel bit pattern and
+ * consumers re-read until none is left).  Bit-identical to T1 calls of seedhip_lstm_step_fwd.  zx, z [T1, B, 4H];
+ * done [T1, B] (done[0] is NOT applied here: hin[0] / cin[0] hold the already-masked initial state,
+ * seedhip_lstm_mask_state); hin, cin [T1 + 1, B, H] (slot t + 1 = state after step t, reset where done[t + 1]);
+ * h_out [T1 * B, ld_h].  sync_ws: 8 bytes of device memory, zeroed by the call; every wait is bounded, and after the
+ * launch completes int32 sync_ws[1] != 0 means one timed out (the workgroups were not co-resident) and the outputs
+ * are invalid.  seedhip_lstm_seq_supported: T1 >= 2, H % 128 == 0, H <= 512, and the grid of ceil(B / 32) * H / 16
+ * workgroups fits the device's CUs (needs a current HIP device). */
+int seedhip_lstm_seq_supported(int T1, int B, int H);
+int seedhip_lstm_seq_fwd(const float* up, const float* zx, const uint8_t* done, int T1, int B, int H, float* z,
+                         float* h_out, int ld_h, float* hin, float* cin, void* sync_ws, void* stream);
 int seedhip_lstm_gates_fwd(const float* z, const float* cin, const uint8_t* done_next, int B, int H, float* h_out,
                            int ld_h, float* hin_next, float* cin_next, void* stream);
 int seedhip_lstm_gates_bwd(const float* z, const float* cin, const float* dh_out, int ld_dh, const float* dh_rec,

@@ -185,6 +185,199 @@ lstm_step_fwd_kernel(const StepParams p) {
   }
 }
 
+// ---- the whole unroll in ONE launch ---------------------------------------------------------------------------------
+// Same tiling and the same arithmetic (bit-identical results) as lstm_step_fwd_kernel, but the time loop runs inside
+// the kernel: every workgroup is resident (one per CU), keeps ITS 16 units' slice of U in LDS for the whole sequence
+// (H x 64 floats: 128 KB at H = 512) and its cell state in registers, and the steps are separated by a grid barrier
+// (monotonic counter in global memory: agent-scope release of h_t, one lane polls with agent-scope acquire loads).
+// Per step a workgroup then only reads its 32 rows of h_{t-1} and zx_t; no launch, no U traffic.  Every spin is
+// bounded: a workgroup that waits too long (the grid was not co-resident) raises the abort flag and all leave.
+struct SeqParams {
+  const float* up; const float* zx; const uint8_t* done; int T1, B, H;
+  float* z; float* h_out; int ld_h; float* hin; float* cin;          // hin / cin [T1 + 1, B, H]; slot 0 = initial state
+  int* abort_flag; int fault;
+};
+
+constexpr unsigned kMaxSpins = 200000;                    // x (one agent-scope round trip): a few hundred ms
+constexpr unsigned kSentinel = 0xffffffffu;               // "not written yet" (a NaN no arithmetic produces)
+
+__global__ void __launch_bounds__(64 * kWaves)
+lstm_seq_fwd_kernel(const SeqParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];       // U slabs [H][64] | staging / partial sums (24 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lx = lane & 15, kq = lane >> 4;
+  const int nrow = (p.B + kRows - 1) / kRows, ncol = p.H / kUnits;
+  int rt, ct;
+  if ((ncol & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = ncol >> 3;
+    ct = xcd * per + j / nrow; rt = j - (j / nrow) * nrow;
+  } else {
+    ct = blockIdx.x / nrow; rt = blockIdx.x - ct * nrow;
+  }
+  const int m0 = rt * kRows, u0 = ct * kUnits;
+  const int H = p.H, ld_u = 4 * H, kper = H / kWaves, k0 = wave * kper, nkt = kper / BK;    // nkt <= 4 (H <= 512)
+  const long long BH = (long long)p.B * H;
+  float* Us = smem + wave * kper * kCols;                 // this wave's K slice of the tile's U columns: [kper][64]
+  float* stage = smem + H * kCols;
+  float* As = stage + wave * kRows * LDA;                 // [32 rows][LDA], wave-private
+  float4* part = reinterpret_cast<float4*>(stage);       // [owner 4][source 3][2][64 lanes] float4, overlays the A stages
+
+  {
+    const float* b_src = p.up + (long long)k0 * ld_u + 4 * u0;
+#pragma unroll 8
+    for (int v = lane; v < kper * 16; v += 64) {
+      const int kr = v >> 4, c4 = (v & 15) * 4;
+      *reinterpret_cast<float4*>(Us + kr * kCols + c4) = *reinterpret_cast<const float4*>(b_src + (long long)kr * ld_u + c4);
+    }
+  }
+  // this thread's two (row, unit) items: the quarter of the tile wave `wave` reduces -- rows 16 i + 4 kq + r0 + {0, 1}
+  const int own_i = wave >> 1, own_r0 = 2 * (wave & 1);
+  const int e_unit = u0 + lx;
+  int e_b[2]; float cst[2];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    e_b[rr] = m0 + 16 * own_i + 4 * kq + own_r0 + rr;
+    cst[rr] = e_b[rr] < p.B ? p.cin[(long long)e_b[rr] * H + e_unit] : 0.f;
+  }
+  const float* a_src[4]; int a_lds[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int v = lane + 64 * i, row = v >> 3, kc = (v & 7) * 4;
+    a_lds[i] = row * LDA + kc;
+    a_src[i] = (m0 + row < p.B) ? p.hin + (long long)(m0 + row) * H + k0 + kc : nullptr;
+  }
+  const float* a_frag = As + lx * LDA + 4 * kq;
+  const float* b_frag = Us + (4 * kq) * kCols + 4 * lx;
+
+  bool dead = false;                                      // a wait timed out: stop polling, finish with garbage
+  for (int t = 0; t < p.T1; ++t) {
+    // epilogue operands first: their latency hides under the wait / the GEMM
+    float zxv[2][4], keep[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      keep[rr] = 1.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) zxv[rr][g] = 0.f;
+      if (e_b[rr] < p.B) {
+        const float* zp = p.zx + ((long long)t * p.B + e_b[rr]) * 4 * H + e_unit;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) zxv[rr][g] = zp[g * H];
+        if (t + 1 < p.T1 && p.done[(long long)(t + 1) * p.B + e_b[rr]]) keep[rr] = 0.f;
+      }
+    }
+    // h_{t-1}: this wave's [32 rows] x [its K quarter], straight into registers with agent-scope (sc1) loads.  The
+    // data is its own ready flag: slot t of hin was filled with kSentinel before the launch and every producer
+    // stores each word exactly once, so the wave re-reads until no word is the sentinel.  No counter, no fence, and
+    // no workgroup barrier here -- each wave waits only for the 8 workgroups that produce its columns.
+    f32x4_t ra[4][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra[kt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (unsigned spins = 0;;) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        if (kt < nkt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (a_src[i]) {
+              const float* q = a_src[i] + t * BH + kt * BK;
+              asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(ra[kt][i]) : "v"(q) : "memory");
+            }
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[0][2]), "+v"(ra[0][3]), "+v"(ra[1][0]), "+v"(ra[1][1]),
+                     "+v"(ra[1][2]), "+v"(ra[1][3]), "+v"(ra[2][0]), "+v"(ra[2][1]), "+v"(ra[2][2]), "+v"(ra[2][3]),
+                     "+v"(ra[3][0]), "+v"(ra[3][1]), "+v"(ra[3][2]), "+v"(ra[3][3])
+                   :: "memory");
+      if (t == 0 || dead) break;                          // slot 0 was written by the previous kernel
+      bool stale = false;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) stale |= __float_as_uint(ra[kt][i][e]) == kSentinel;
+      if (!__any(stale)) break;
+      ++spins;
+      if (spins > kMaxSpins || ((spins & 31) == 0 && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        if (lane == 0) __hip_atomic_store(p.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dead = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    f32x4_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      if (kt >= nkt) break;
+      wave_fence();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4_t*>(As + a_lds[i]) = ra[kt][i];
+      wave_fence();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4_t af[2], bf[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4_t*>(a_frag + i * 16 * LDA + h * 16);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) bf[kk] = *reinterpret_cast<const f32x4_t*>(b_frag + (kt * BK + h * 16 + kk) * kCols);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bf[kk][j], acc[i][j], 0, 0, 0);
+      }
+    }
+    // ---- cross-wave sum: wave q reduces quarter q = (i, r0); the others hand it their partials through LDS ----
+    __syncthreads();                                      // every wave is done with its A stage (part overlays them)
+    float own[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = q >> 1, r0 = 2 * (q & 1);
+      const bool mine = q == wave;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) own[rr][g] = mine ? acc[i][g][r0 + rr] : own[rr][g];
+        if (!mine)
+          part[((q * 3 + (wave < q ? wave : wave - 1)) * 2 + rr) * 64 + lane] =
+              make_float4(acc[i][0][r0 + rr], acc[i][1][r0 + rr], acc[i][2][r0 + rr], acc[i][3][r0 + rr]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {                  // wave order, as lstm_step_fwd_kernel sums
+        const float4 v = (w == wave) ? make_float4(own[rr][0], own[rr][1], own[rr][2], own[rr][3]) : part[((wave * 3 + (w < wave ? w : w - 1)) * 2 + rr) * 64 + lane];
+        if (w == 0) s = v; else { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+      }
+      if (e_b[rr] >= p.B) continue;
+      const long long row = (long long)t * p.B + e_b[rr];
+      float* zo = p.z + row * 4 * H + e_unit;
+      const float zi = zxv[rr][0] + s.x, zf = zxv[rr][1] + s.y, zg = zxv[rr][2] + s.z, zoo = zxv[rr][3] + s.w;
+      zo[0] = zi; zo[H] = zf; zo[2 * H] = zg; zo[3 * H] = zoo;
+      const float ig = sigm(zi), fg = sigm(zf), gg = tanhf(zg), og = sigm(zoo);
+      const float c = fg * cst[rr] + ig * gg;
+      const float hh = og * tanhf(c);
+      p.h_out[row * p.ld_h + e_unit] = hh;
+      float hn = hh * keep[rr];
+      if (__float_as_uint(hn) == kSentinel) hn = __uint_as_float(0x7fc00000u);       // a NaN that happens to be the sentinel
+      if (!(p.fault && blockIdx.x == 0 && t == 1))       // test hook: a producer that never delivers
+        __hip_atomic_store(p.hin + (t + 1) * BH + (long long)e_b[rr] * H + e_unit, hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cst[rr] = c * keep[rr];
+      p.cin[(t + 1) * BH + (long long)e_b[rr] * H + e_unit] = cst[rr];
+    }
+    __syncthreads();                                      // partial-sum reads are done before the next A stage
+  }
+}
+
 }  // namespace
 
 extern "C" int seedhip_lstm_permute_u(const float* u, int H, float* up, void* stream) {
@@ -215,4 +408,52 @@ extern "C" int seedhip_lstm_step_fwd(const float* hin, const float* up, const fl
   hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3(((B + kRows - 1) / kRows) * (H / kUnits)), dim3(64 * kWaves), lds,
                      (hipStream_t)stream, p);
   return seedhip::check_launch("lstm_step_fwd_kernel");
+}
+
+
+namespace {
+int seq_resident_limit(size_t lds) {                       // workgroups that are surely co-resident on this device
+  int dev = 0, cus = 0, lds_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || lds_cu <= 0)
+    lds_cu = 160 * 1024;
+  long long per = (long long)lds_cu / (long long)(lds + 64);
+  if (per > 2) per = 2;                                    // 256 threads x <= 128 VGPRs: registers allow at least this
+  return (int)(cus * per);
+}
+size_t seq_lds_bytes(int H) { return (size_t)H * kCols * sizeof(float) + 24 * 1024; }
+}  // namespace
+
+extern "C" int seedhip_lstm_seq_supported(int T1, int B, int H) {
+  if (!(T1 >= 2 && seedhip_lstm_step_supported(B, H) && H <= 512)) return 0;
+  const int grid = ((B + kRows - 1) / kRows) * (H / kUnits);
+  return grid <= seq_resident_limit(seq_lds_bytes(H));
+}
+
+extern "C" int seedhip_lstm_seq_fwd(const float* up, const float* zx, const uint8_t* done, int T1, int B, int H,
+                                    float* z, float* h_out, int ld_h, float* hin, float* cin, void* sync_ws,
+                                    void* stream) {
+  SEEDHIP_REQUIRE(up && zx && done && z && h_out && hin && cin && sync_ws, "lstm_seq_fwd: null pointer");
+  SEEDHIP_REQUIRE(seedhip_lstm_seq_supported(T1, B, H),
+                  "lstm_seq_fwd: unsupported (T1 = %d, B = %d, H = %d): need T1 >= 2, H %% 128 == 0, H <= 512 and a co-resident grid",
+                  T1, B, H);
+  SEEDHIP_REQUIRE(ld_h >= H, "lstm_seq_fwd: ld_h < H");
+  SEEDHIP_REQUIRE(((((uintptr_t)hin) | ((uintptr_t)up)) & 15) == 0, "lstm_seq_fwd: hin / up must be 16-byte aligned");
+  SeqParams p;
+  p.up = up; p.zx = zx; p.done = done; p.T1 = T1; p.B = B; p.H = H; p.z = z; p.h_out = h_out; p.ld_h = ld_h;
+  p.hin = hin; p.cin = cin; p.abort_flag = (int*)sync_ws + 1;
+  { const char* e = getenv("SEEDHIP_LSTM_SEQ_FAULT"); p.fault = e ? atoi(e) : 0; }   // tests: exercise the bounded wait
+  const size_t lds = seq_lds_bytes(H);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_lds_bytes(512));
+    attr_set = true;
+  }
+  if (hipMemsetAsync(sync_ws, 0, 8, (hipStream_t)stream) != hipSuccess ||
+      hipMemsetAsync(hin + (size_t)B * H, 0xff, (size_t)T1 * B * H * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return seedhip::check_launch("lstm_seq_fwd memset");
+  hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(((B + kRows - 1) / kRows) * (H / kUnits)), dim3(64 * kWaves), lds,
+                     (hipStream_t)stream, p);
+  return seedhip::check_launch("lstm_seq_fwd_kernel");
 }

@@ -18,6 +18,7 @@ body (atari/networks.py:233-242).
 """
 import collections
 import math
+import os
 
 import numpy as np
 import torch
@@ -200,7 +201,16 @@ class _Agent(object):
     if fused_step:                                # recurrent GEMM + gates + reset in one launch per step
       Up = self._buf(prefix + '_u_perm', (H, 4 * H))
       ops.lstm_permute_u(U, H, Up)
-    for t in range(T1):
+    fused_seq = fused_step and os.environ.get('SEEDHIP_LSTM_SEQ', '1') != '0' and ops.lstm_seq_supported(T1, B, H)
+    if fused_seq:                                 # the whole unroll in one launch (resident workgroups + grid barrier)
+      capturing = torch.cuda.is_current_stream_capturing()
+      if not capturing:
+        self._lstm_seq_check()
+      ops.lstm_seq_fwd(Up, Zx3, done_u8, T1, B, H, Z, Hout, H, Hin, Cin, self._buf('lstm_seq_sync', (2,), torch.int32))
+      if not capturing:
+        self._seq_flag.copy_(self._buf('lstm_seq_sync', (2,), torch.int32)[1:2], non_blocking=True)
+        self._seq_event.record()
+    for t in range(0 if not fused_seq else T1, T1):
       done_next = done_u8[t + 1] if t + 1 < T1 else None
       if fused_step:
         ops.lstm_step_fwd(Hin[t], Up, Zx3[t], Cin[t], done_next, B, H, Z[t], Hout3[t], H, Hin[t + 1], Cin[t + 1])
@@ -210,6 +220,20 @@ class _Agent(object):
     self._last_lstm = dict(X=X, ldx=ldx, in_dim=in_dim, H=H, T1=T1, B=B, done=done_u8, gx=gx, gu=gu, Z=Z, Hin=Hin,
                            Cin=Cin, Hout=Hout, prefix=prefix)
     return Hout, (Hin[T1].clone(), Cin[T1].clone())
+
+  def _lstm_seq_check(self, wait=False):
+    """lstm_seq_fwd reports a timed-out grid barrier through a device flag; it is mirrored into pinned host memory
+    after every launch and looked at here -- before the next launch (by then the previous copy has landed: no sync)
+    or, with wait=True, after waiting for the copy."""
+    if getattr(self, '_seq_flag', None) is None:
+      self._seq_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+      self._seq_event = torch.cuda.Event()
+      return
+    if wait:
+      self._seq_event.synchronize()
+    if self._seq_event.query() and int(self._seq_flag[0]) != 0:
+      raise RuntimeError('seedhip_lstm_seq_fwd: grid barrier timed out (workgroups were not co-resident); the LSTM '
+                         'outputs of that step are invalid.  Set SEEDHIP_LSTM_SEQ=0 to use the per-step kernel.')
 
   def _lstm_bwd(self, dHout, wsb):
     """dHout [T1*B, H]: gradient wrt the core outputs.  Fills the core's weight gradients and returns

@@ -332,6 +332,20 @@ def lstm_step_fwd(hin, up, zx, cin, done_next_u8, B, H, z, h_out, ld_h, hin_next
           _lib.ptr(h_out), ld_h, _lib.ptr(hin_next), _lib.ptr(cin_next), _lib.stream()), 'seedhip_lstm_step_fwd')
 
 
+def lstm_seq_supported(T1, B, H):
+  return bool(_lib.lib().seedhip_lstm_seq_supported(T1, B, H))
+
+
+def lstm_seq_fwd(up, zx, done_u8, T1, B, H, z, h_out, ld_h, hin, cin, sync_ws):
+  """All T1 LSTM steps in one launch (resident workgroups + grid barrier); bit-identical to T1 lstm_step_fwd calls.
+  sync_ws: int32[2] device tensor; sync_ws[1] != 0 afterwards = barrier timed out, outputs invalid."""
+  with _region('lstm_seq_fwd', 2.0 * T1 * B * H * 4 * H, (H * 4 * H + T1 * B * H * 12) * 4):
+    with _dev(z):
+      _lib.check(_lib.lib().seedhip_lstm_seq_fwd(
+          _lib.ptr(up), _lib.ptr(zx), _lib.ptr(done_u8), T1, B, H, _lib.ptr(z), _lib.ptr(h_out), ld_h, _lib.ptr(hin),
+          _lib.ptr(cin), _lib.ptr(sync_ws), _lib.stream()), 'seedhip_lstm_seq_fwd')
+
+
 def lstm_gates_fwd(z, cin, done_next_u8, B, H, h_out, ld_h, hin_next, cin_next):
   with _region('lstm_gates_fwd', 0, B * H * 4 * 8):
     with _dev(h_out):

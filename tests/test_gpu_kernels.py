@@ -566,3 +566,70 @@ def test_lstm_step_fused(device, B, H):
   assert float((h.cpu() - h_ref).abs().max()) <= 2e-5
   assert float((hn.cpu() - h_ref * keep).abs().max()) <= 2e-5
   assert float((cn.cpu() - c_ref * keep).abs().max()) <= 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('T1,B,H', [(7, 256, 512), (5, 70, 256), (3, 32, 128), (121, 256, 512)])
+def test_lstm_seq_matches_steps(device, T1, B, H):
+  """Whole-unroll LSTM kernel (resident workgroups + grid barrier, csrc/lstm_step.hip lstm_seq_fwd_kernel) is
+  BIT-identical to T1 launches of the per-step kernel (same tiling, same summation order), including done-resets,
+  a ragged last row tile, and the R2D2 unroll length; the barrier's abort flag stays clear."""
+  from seed_rl_amd import ops
+  if not ops.lstm_seq_supported(T1, B, H):
+    pytest.skip('grid of %d workgroups is not co-resident on this device' % (((B + 31) // 32) * (H // 16)))
+  rng = np.random.default_rng(T1 * 1000 + B + H)
+  U = dev((rng.normal(size=(H, 4 * H)) / np.sqrt(H)).astype(np.float32), device)
+  zx = dev(rng.normal(size=(T1, B, 4 * H)).astype(np.float32), device)
+  done = dev((rng.uniform(size=(T1, B)) < 0.1).astype(np.uint8), device)
+  h0 = dev(rng.normal(size=(B, H)).astype(np.float32), device)
+  c0 = dev(rng.normal(size=(B, H)).astype(np.float32), device)
+  up = torch.empty((H, 4 * H), device=device)
+  ops.lstm_permute_u(U, H, up)
+  outs = []
+  for mode in ('step', 'seq'):
+    hin = torch.full((T1 + 1, B, H), 7.0, device=device); cin = torch.full((T1 + 1, B, H), 7.0, device=device)
+    z = torch.full((T1, B, 4 * H), 7.0, device=device); hout = torch.full((T1, B, H), 7.0, device=device)
+    ops.lstm_mask_state(h0, c0, done[0], B, H, hin[0], cin[0])
+    if mode == 'step':
+      for t in range(T1):
+        ops.lstm_step_fwd(hin[t], up, zx[t], cin[t], done[t + 1] if t + 1 < T1 else None, B, H, z[t], hout[t], H,
+                          hin[t + 1], cin[t + 1])
+    else:
+      sync = torch.full((2,), 5, dtype=torch.int32, device=device)
+      ops.lstm_seq_fwd(up, zx, done, T1, B, H, z, hout.view(T1 * B, H), H, hin, cin, sync)
+      torch.cuda.synchronize()
+      assert int(sync[1]) == 0, 'grid barrier timed out'
+    outs.append((z, hout, hin, cin))
+  for a, b in zip(*outs):
+    assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_lstm_seq_bounded_wait(device, monkeypatch):
+  """A producer that never delivers (test hook SEEDHIP_LSTM_SEQ_FAULT) must not hang the GPU: every wait in the
+  whole-unroll kernel is bounded, the kernel finishes, and the abort flag reports it."""
+  import time
+  from seed_rl_amd import ops
+  T1, B, H = 4, 64, 128
+  if not ops.lstm_seq_supported(T1, B, H):
+    pytest.skip('not co-resident')
+  rng = np.random.default_rng(3)
+  U = dev((rng.normal(size=(H, 4 * H)) / np.sqrt(H)).astype(np.float32), device)
+  zx = dev(rng.normal(size=(T1, B, 4 * H)).astype(np.float32), device)
+  done = torch.zeros((T1, B), dtype=torch.uint8, device=device)
+  up = torch.empty((H, 4 * H), device=device)
+  ops.lstm_permute_u(U, H, up)
+  hin = torch.zeros((T1 + 1, B, H), device=device); cin = torch.zeros((T1 + 1, B, H), device=device)
+  z = torch.empty((T1, B, 4 * H), device=device); hout = torch.empty((T1 * B, H), device=device)
+  sync = torch.zeros(2, dtype=torch.int32, device=device)
+  monkeypatch.setenv('SEEDHIP_LSTM_SEQ_FAULT', '1')
+  torch.cuda.synchronize()
+  t0 = time.time()
+  ops.lstm_seq_fwd(up, zx, done, T1, B, H, z, hout, H, hin, cin, sync)
+  torch.cuda.synchronize()
+  assert time.time() - t0 < 20.0
+  assert int(sync[1]) == 1
+  monkeypatch.delenv('SEEDHIP_LSTM_SEQ_FAULT')
+  ops.lstm_seq_fwd(up, zx, done, T1, B, H, z, hout, H, hin, cin, sync)
+  torch.cuda.synchronize()
+  assert int(sync[1]) == 0 and bool(torch.isfinite(hout).all())

@@ -34,3 +34,16 @@ for B, H in [(256, 512), (256, 256)]:
     g2.replay(); torch.cuda.synchronize()
     e0.record(); g2.replay(); e1.record(); torch.cuda.synchronize()
     print('B=%d H=%d gemm + gates: %.2f us per step (graph of 100)' % (B, H, e0.elapsed_time(e1) * 10))
+    T1 = 100
+    if ops.lstm_seq_supported(T1, B, H):
+        zx3 = torch.randn(T1, B, 4 * H, device=dev); z3 = torch.empty_like(zx3); h3 = torch.empty(T1 * B, H, device=dev)
+        hin3 = torch.randn(T1 + 1, B, H, device=dev); cin3 = torch.randn(T1 + 1, B, H, device=dev)
+        done3 = torch.zeros(T1, B, dtype=torch.uint8, device=dev); sync = torch.zeros(2, dtype=torch.int32, device=dev)
+        for mode in os.environ.get('SEQ_MODES', '1').split(','):
+            os.environ['SEEDHIP_LSTM_SEQ_MODE'] = mode
+            for _ in range(3): ops.lstm_seq_fwd(up, zx3, done3, T1, B, H, z3, h3, H, hin3, cin3, sync)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10): ops.lstm_seq_fwd(up, zx3, done3, T1, B, H, z3, h3, H, hin3, cin3, sync)
+            e1.record(); torch.cuda.synchronize()
+            print('B=%d H=%d whole-unroll kernel mode %s: %.2f us per step (T1 = 100, abort flag %d)' % (B, H, mode, e0.elapsed_time(e1), int(sync[1])))
