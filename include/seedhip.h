@@ -218,6 +218,18 @@ int seedhip_lstm_step_fwd(const float* hin, const float* up, const float* zx, co
 int seedhip_lstm_seq_supported(int T1, int B, int H);
 int seedhip_lstm_seq_fwd(const float* up, const float* zx, const uint8_t* done, int T1, int B, int H, float* z,
                          float* h_out, int ld_h, float* hin, float* cin, void* sync_ws, void* stream);
+/* The whole BACKWARD recurrence in one launch: for t = T1-1 .. 0, dz_t = cell backward of step t (as
+ * seedhip_lstm_gates_bwd: dh = dh_out_t + keep_{t+1} * dh_rec, dc = keep_{t+1} * dc_rec) and dh_rec = dz_t U^T (the
+ * per-step seedhip_conv2d_bwd_data of the dense geometry [B, H] -> [B, 4H]).  Same residency / tiling as
+ * seedhip_lstm_seq_fwd (and the same `up`); partial dh_rec sums travel through ring_ws
+ * (seedhip_lstm_seq_bwd_workspace_bytes, 16-byte aligned, filled by the call) and are added in a fixed order:
+ * deterministic, equal to the per-step path up to fp32 summation order.  z, dz [T1, B, 4H] (gate-major columns);
+ * cin [>= T1, B, H] (slot t = cell state entering step t); dh_out [T1 * B, ld_dh]; done [T1, B].  sync_ws as in
+ * seedhip_lstm_seq_fwd.  Supported exactly when seedhip_lstm_seq_supported(T1, B, H). */
+size_t seedhip_lstm_seq_bwd_workspace_bytes(int B, int H);
+int seedhip_lstm_seq_bwd(const float* up, const float* z, const float* cin, const float* dh_out, int ld_dh,
+                         const uint8_t* done, int T1, int B, int H, float* dz, void* ring_ws, void* sync_ws,
+                         void* stream);
 int seedhip_lstm_gates_fwd(const float* z, const float* cin, const uint8_t* done_next, int B, int H, float* h_out,
                            int ld_h, float* hin_next, float* cin_next, void* stream);
 int seedhip_lstm_gates_bwd(const float* z, const float* cin, const float* dh_out, int ld_dh, const float* dh_rec,

@@ -76,6 +76,8 @@ SIGNATURES = {
     'seedhip_lstm_step_fwd': (c_int, [P, P, P, P, P, c_int, c_int, P, P, c_int, P, P, P]),
     'seedhip_lstm_seq_supported': (c_int, [c_int, c_int, c_int]),
     'seedhip_lstm_seq_fwd': (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_int, P, P, P, P]),
+    'seedhip_lstm_seq_bwd_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'seedhip_lstm_seq_bwd': (c_int, [P, P, P, P, c_int, P, c_int, c_int, c_int, P, P, P, P]),
     'seedhip_lstm_gates_bwd': (c_int, [P, P, P, c_int, P, P, P, c_int, c_int, P, P, P]),
     'seedhip_rows_move': (c_int, [P, P, P, P, c_ll, c_ll, P]),
     'seedhip_rows_move_masked': (c_int, [P, P, P, P, c_ll, c_ll, P, c_int, P]),

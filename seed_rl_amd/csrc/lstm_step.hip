@@ -192,6 +192,15 @@ lstm_step_fwd_kernel(const StepParams p) {
 // (monotonic counter in global memory: agent-scope release of h_t, one lane polls with agent-scope acquire loads).
 // Per step a workgroup then only reads its 32 rows of h_{t-1} and zx_t; no launch, no U traffic.  Every spin is
 // bounded: a workgroup that waits too long (the grid was not co-resident) raises the abort flag and all leave.
+// Arms an exchange buffer with the sentinel and clears the 8-byte sync word, as ONE ordinary kernel (a captured
+// hipMemsetAsync node misbehaved under HIP-graph replay on ROCm 7.2: see DESIGN.md).
+__global__ void __launch_bounds__(256)
+seq_arm_kernel(uint4* __restrict__ buf, long long n16, unsigned* __restrict__ sync_ws) {
+  const uint4 s = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) buf[i] = s;
+  if (blockIdx.x == 0 && threadIdx.x < 2) sync_ws[threadIdx.x] = 0u;
+}
+
 struct SeqParams {
   const float* up; const float* zx; const uint8_t* done; int T1, B, H;
   float* z; float* h_out; int ld_h; float* hin; float* cin;          // hin / cin [T1 + 1, B, H]; slot 0 = initial state
@@ -369,12 +378,193 @@ lstm_seq_fwd_kernel(const SeqParams p) {
       p.h_out[row * p.ld_h + e_unit] = hh;
       float hn = hh * keep[rr];
       if (__float_as_uint(hn) == kSentinel) hn = __uint_as_float(0x7fc00000u);       // a NaN that happens to be the sentinel
-      if (!(p.fault && blockIdx.x == 0 && t == 1))       // test hook: a producer that never delivers
+      if (!((p.fault & 1) && blockIdx.x == 0 && t == 1)) // test hook: a producer that never delivers
         __hip_atomic_store(p.hin + (t + 1) * BH + (long long)e_b[rr] * H + e_unit, hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       cst[rr] = c * keep[rr];
       p.cin[(t + 1) * BH + (long long)e_b[rr] * H + e_unit] = cst[rr];
     }
     __syncthreads();                                      // partial-sum reads are done before the next A stage
+  }
+}
+
+// ---- the whole BACKWARD recurrence in one launch --------------------------------------------------------------------
+// Per step (t = T1-1 .. 0): dz_t = cell'(z_t, c_{t-1}; dh_out_t + keep * dh_rec, keep * dc_rec), dh_rec = dz_t U^T --
+// lstm_gates_bwd_kernel + one [B, 4H] x [4H, H] GEMM (+ its split-K reduce) per step as separate launches.  Here the
+// workgroup that owns (32 rows, 16 units) in the forward kernel owns them again: it keeps the SAME 64 columns of Up in
+// LDS, computes dz for its tile (cell-state gradient in registers), and multiplies that [32 x 64] slice of dz with its
+// [64 x H] slice of U^T: a PARTIAL dh_rec for every unit, K-split over the column tiles.  The partials are exchanged
+// through a three-slot ring in global memory -- chunk (producer, consumer) = 16 units x 32 rows, agent-scope stores and
+// loads, the data is its own ready flag (sentinel as in the forward kernel; the consumer re-arms a chunk right after
+// reading it) -- and summed by the consumer in producer order: deterministic, 64 KB in + 64 KB out per workgroup and
+// step instead of a full re-read of dz.
+struct SeqBwdParams {
+  const float* up; const float* z; const float* cin; const float* dh_out; int ld_dh; const uint8_t* done;
+  int T1, B, H;
+  float* dz; float* ring; int* abort_flag; int fault;
+};
+
+constexpr int LDT = kCols + 4;                            // dz tile row stride (bank spread for the b128 fragment reads)
+constexpr int LDR = kRows + 4;                            // half-sum row stride
+
+template <int NT>                                         // output column tiles per wave: H = 64 NT
+__global__ void __launch_bounds__(64 * kWaves)
+lstm_seq_bwd_kernel(const SeqBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];       // Up slab [H][64] (16-byte chunks XOR-swizzled) | dz tile | half sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lx = lane & 15, kq = lane >> 4;
+  constexpr int H = 64 * NT, ncol = H / kUnits, NP = ncol / 2;
+  const int nrow = (p.B + kRows - 1) / kRows;
+  int rt, ct;
+  if ((ncol & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = ncol >> 3;
+    ct = xcd * per + j / nrow; rt = j - (j / nrow) * nrow;
+  } else {
+    ct = blockIdx.x / nrow; rt = blockIdx.x - ct * nrow;
+  }
+  const int m0 = rt * kRows, u0 = ct * kUnits;
+  float* slab = smem;
+  float* At = smem + H * kCols;                           // [32][LDT]: row, then 4 * unit + gate
+  float* red = At + kRows * LDT;                          // [2 halves][16 units][LDR]: sums of the producers' partials
+  for (int v = tid; v < H * 16; v += 64 * kWaves) {
+    const int j = v >> 4, c = v & 15;
+    *reinterpret_cast<float4*>(slab + j * kCols + ((c ^ (j & 15)) << 2)) =
+        *reinterpret_cast<const float4*>(p.up + (long long)j * 4 * H + 4 * u0 + 4 * c);
+  }
+  // gate items of this thread: (row, unit) x 2
+  const int ul = tid & 15, unit = u0 + ul;
+  int row_l[2], e_b[2]; float dcst[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) { row_l[it] = (tid >> 4) + 16 * it; e_b[it] = m0 + row_l[it]; dcst[it] = 0.f; }
+  // partial-sum reader role: (half of the producers, row, unit quad)
+  const int half = wave >> 1, rd_unit = (tid & 127) >> 3, rd_rq = tid & 7;        // chunk layout: [unit][row]
+  const long long chunk = kRows * kUnits;                 // floats per (producer, consumer) chunk
+  const long long slot_floats = (long long)nrow * ncol * ncol * chunk;
+  bool dead = false;
+  const f32x4_t sentinel4 = {__uint_as_float(kSentinel), __uint_as_float(kSentinel), __uint_as_float(kSentinel), __uint_as_float(kSentinel)};
+  __syncthreads();
+
+  for (int t = p.T1 - 1; t >= 0; --t) {
+    float zv[2][4], cp[2], dho[2], keep[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      zv[it][0] = zv[it][1] = zv[it][2] = zv[it][3] = cp[it] = dho[it] = 0.f; keep[it] = 1.f;
+      if (e_b[it] < p.B) {
+        const long long row = (long long)t * p.B + e_b[it];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) zv[it][g] = p.z[row * 4 * H + g * H + unit];
+        cp[it] = p.cin[row * H + unit];
+        dho[it] = p.dh_out[row * p.ld_dh + unit];
+        if (t + 1 < p.T1 && p.done[(long long)(t + 1) * p.B + e_b[it]]) keep[it] = 0.f;
+      }
+    }
+    float rec[2] = {0.f, 0.f};
+    if (t + 1 < p.T1) {                                   // dh_rec of step t + 1: sum the producers' partials
+      float* src = p.ring + ((t + 1) % 3) * slot_floats + (((long long)rt * ncol + half * NP) * ncol + ct) * chunk +
+                   rd_unit * kRows + rd_rq * 4;
+      f32x4_t v[NP];
+      for (unsigned spins = 0;;) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          const float* q = src + (long long)i * ncol * chunk;
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[i]) : "v"(q) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bool stale = false;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          asm volatile("" : "+v"(v[i]));                  // the loads above have landed: keep uses below the wait
+#pragma unroll
+          for (int e = 0; e < 4; ++e) stale |= __float_as_uint(v[i][e]) == kSentinel;
+        }
+        if (dead || !__any(stale) || (p.fault & 8)) break;
+        ++spins;
+        if (spins > kMaxSpins || ((spins & 31) == 0 && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          if (lane == 0) __hip_atomic_store(p.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          dead = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {                      // re-arm the chunks: this slot is written again at step t - 2
+        float* q = src + (long long)i * ncol * chunk;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(q), "v"(sentinel4) : "memory");
+      }
+      f32x4_t sum = v[0];
+#pragma unroll
+      for (int i = 1; i < NP; ++i) sum += v[i];
+      *reinterpret_cast<f32x4_t*>(red + (half * kUnits + rd_unit) * LDR + rd_rq * 4) = sum;
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 2; ++it) rec[it] = red[ul * LDR + row_l[it]] + red[(kUnits + ul) * LDR + row_l[it]];
+    }
+    // cell backward (the arithmetic of lstm_gates_bwd_kernel), dz to global (gate-major, for the weight gradients)
+    // and to the LDS tile (unit-major: the k order of the Up slab)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const float dh = dho[it] + keep[it] * rec[it], dc = keep[it] * dcst[it];
+      const float ig = sigm(zv[it][0]), fg = sigm(zv[it][1]), gg = tanhf(zv[it][2]), og = sigm(zv[it][3]);
+      const float c = fg * cp[it] + ig * gg; const float tc = tanhf(c);
+      const float d_o = dh * tc; const float d_c = dc + dh * og * (1.0f - tc * tc);
+      float4 d;
+      d.x = d_c * gg * ig * (1.0f - ig); d.y = d_c * cp[it] * fg * (1.0f - fg);
+      d.z = d_c * ig * (1.0f - gg * gg); d.w = d_o * og * (1.0f - og);
+      dcst[it] = d_c * fg;
+      if (e_b[it] < p.B) {
+        float* dr = p.dz + ((long long)t * p.B + e_b[it]) * 4 * H + unit;
+        dr[0] = d.x; dr[H] = d.y; dr[2 * H] = d.z; dr[3 * H] = d.w;
+      } else {
+        d = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      *reinterpret_cast<float4*>(At + row_l[it] * LDT + ul * 4) = d;
+    }
+    // Ring depth 3: the chunks re-armed at step t (slot (t + 1) % 3) are next written by their producers at step
+    // t - 2, i.e. after those have consumed what this workgroup publishes at the end of step t - 1 -- and every wave
+    // here passes the s_waitcnt vmcnt(0) of step t - 1's wait loop (its re-arming stores are acknowledged) and the
+    // barrier after it before any wave publishes.  With two slots the acknowledgement would have to be waited for
+    // right here, on the critical path.
+    __syncthreads();
+    if (t > 0) {                                          // partial dh_rec = dz tile [32 x 64] x Up slab^T [64 x H]
+      f32x4_t acc[2][NT];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        if (p.fault & 2) break;
+        f32x4_t af[2], bf[NT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4_t*>(At + (16 * i + lx) * LDT + (4 * h + kq) * 4);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          bf[j] = *reinterpret_cast<const f32x4_t*>(slab + ((wave * NT + j) * 16 + lx) * kCols + (((4 * h + kq) ^ lx) << 2));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+      }
+      if (!((p.fault & 1) && blockIdx.x == 0 && t == p.T1 - 2) && !(p.fault & 4)) {                 // test hook: a producer that never delivers
+        float* dst = p.ring + (t % 3) * slot_floats + (((long long)rt * ncol + ct) * ncol + wave * NT) * chunk +
+                     lx * kRows + 4 * kq;                 // lane: unit lx, rows 16 i + 4 kq + (0..3) -- 16-byte stores
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            f32x4_t v = acc[i][j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (__float_as_uint(v[r]) == kSentinel) v[r] = __uint_as_float(0x7fc00000u);
+            float* q = dst + j * chunk + 16 * i;
+            // s_nop: a >64-bit store reads its data registers a cycle after issue, and the hazard recogniser cannot
+            // see into inline asm (without it the next tile's v_mov landed in v[0] first)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(q), "v"(v) : "memory");
+          }
+      }
+    }
+    __syncthreads();                                      // dz tile / half sums are reused by the next step
   }
 }
 
@@ -450,10 +640,69 @@ extern "C" int seedhip_lstm_seq_fwd(const float* up, const float* zx, const uint
     (void)hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_lds_bytes(512));
     attr_set = true;
   }
-  if (hipMemsetAsync(sync_ws, 0, 8, (hipStream_t)stream) != hipSuccess ||
-      hipMemsetAsync(hin + (size_t)B * H, 0xff, (size_t)T1 * B * H * sizeof(float), (hipStream_t)stream) != hipSuccess)
-    return seedhip::check_launch("lstm_seq_fwd memset");
+  {
+    const long long n16 = (long long)T1 * B * H / 4;       // H % 128 == 0: whole 16-byte words
+    long long blocks = (n16 + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(seq_arm_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<uint4*>(hin + (size_t)B * H), n16, (unsigned*)sync_ws);
+    if (int rc = seedhip::check_launch("seq_arm_kernel")) return rc;
+  }
   hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(((B + kRows - 1) / kRows) * (H / kUnits)), dim3(64 * kWaves), lds,
                      (hipStream_t)stream, p);
   return seedhip::check_launch("lstm_seq_fwd_kernel");
+}
+
+
+namespace {
+size_t seq_bwd_lds_bytes(int H) { return ((size_t)H * kCols + kRows * LDT + 2 * kUnits * LDR) * sizeof(float); }
+size_t seq_bwd_ring_bytes(int B, int H) {
+  const size_t nrow = (B + kRows - 1) / kRows, ncol = H / kUnits;
+  return 3 * nrow * ncol * ncol * kRows * kUnits * sizeof(float);
+}
+template <int NT>
+int launch_seq_bwd(const SeqBwdParams& p, int grid, hipStream_t stream) {
+  const size_t lds = seq_bwd_lds_bytes(64 * NT);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lstm_seq_bwd_kernel<NT>, dim3(grid), dim3(64 * kWaves), lds, stream, p);
+  return seedhip::check_launch("lstm_seq_bwd_kernel");
+}
+}  // namespace
+
+extern "C" size_t seedhip_lstm_seq_bwd_workspace_bytes(int B, int H) {
+  return (B >= 1 && H >= 128 && H % 128 == 0) ? seq_bwd_ring_bytes(B, H) : 0;
+}
+
+extern "C" int seedhip_lstm_seq_bwd(const float* up, const float* z, const float* cin, const float* dh_out, int ld_dh,
+                                    const uint8_t* done, int T1, int B, int H, float* dz, void* ring_ws, void* sync_ws,
+                                    void* stream) {
+  SEEDHIP_REQUIRE(up && z && cin && dh_out && done && dz && ring_ws && sync_ws, "lstm_seq_bwd: null pointer");
+  SEEDHIP_REQUIRE(seedhip_lstm_seq_supported(T1, B, H),
+                  "lstm_seq_bwd: unsupported (T1 = %d, B = %d, H = %d): need T1 >= 2, H %% 128 == 0, H <= 512 and a co-resident grid",
+                  T1, B, H);
+  SEEDHIP_REQUIRE(ld_dh >= H, "lstm_seq_bwd: ld_dh < H");
+  SEEDHIP_REQUIRE((((uintptr_t)up) | ((uintptr_t)ring_ws)) % 16 == 0, "lstm_seq_bwd: up / ring_ws must be 16-byte aligned");
+  SeqBwdParams p;
+  p.up = up; p.z = z; p.cin = cin; p.dh_out = dh_out; p.ld_dh = ld_dh; p.done = done; p.T1 = T1; p.B = B; p.H = H;
+  p.dz = dz; p.ring = (float*)ring_ws; p.abort_flag = (int*)sync_ws + 1;
+  // bit 0: tests, exercise the bounded wait; bits 1-3: timing attribution only (tools/bench_lstm_step.py SEQ_DBG):
+  // 2 = no MFMA, 4 = no partial stores, 8 = do not wait for the partials -- results are garbage with any of them
+  { const char* e = getenv("SEEDHIP_LSTM_SEQ_FAULT"); p.fault = e ? atoi(e) : 0; }
+  {
+    const long long n16 = (long long)(seq_bwd_ring_bytes(B, H) / 16);
+    long long blocks = (n16 + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(seq_arm_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<uint4*>(ring_ws), n16, (unsigned*)sync_ws);
+    if (int rc = seedhip::check_launch("seq_arm_kernel")) return rc;
+  }
+  const int grid = ((B + kRows - 1) / kRows) * (H / kUnits);
+  switch (H / 64) {
+    case 2: return launch_seq_bwd<2>(p, grid, (hipStream_t)stream);
+    case 4: return launch_seq_bwd<4>(p, grid, (hipStream_t)stream);
+    case 6: return launch_seq_bwd<6>(p, grid, (hipStream_t)stream);
+    default: return launch_seq_bwd<8>(p, grid, (hipStream_t)stream);
+  }
 }

@@ -201,14 +201,15 @@ class _Agent(object):
     if fused_step:                                # recurrent GEMM + gates + reset in one launch per step
       Up = self._buf(prefix + '_u_perm', (H, 4 * H))
       ops.lstm_permute_u(U, H, Up)
-    fused_seq = fused_step and os.environ.get('SEEDHIP_LSTM_SEQ', '1') != '0' and ops.lstm_seq_supported(T1, B, H)
+    seq_ok = fused_step and os.environ.get('SEEDHIP_LSTM_SEQ', '1') != '0' and ops.lstm_seq_supported(T1, B, H)
+    fused_seq = seq_ok and os.environ.get('SEEDHIP_LSTM_SEQ_FWD', '1') != '0'
     if fused_seq:                                 # the whole unroll in one launch (resident workgroups + grid barrier)
       capturing = torch.cuda.is_current_stream_capturing()
       if not capturing:
         self._lstm_seq_check()
       ops.lstm_seq_fwd(Up, Zx3, done_u8, T1, B, H, Z, Hout, H, Hin, Cin, self._buf('lstm_seq_sync', (2,), torch.int32))
       if not capturing:
-        self._seq_flag.copy_(self._buf('lstm_seq_sync', (2,), torch.int32)[1:2], non_blocking=True)
+        self._seq_flag[0:1].copy_(self._buf('lstm_seq_sync', (2,), torch.int32)[1:2], non_blocking=True)
         self._seq_event.record()
     for t in range(0 if not fused_seq else T1, T1):
       done_next = done_u8[t + 1] if t + 1 < T1 else None
@@ -218,7 +219,7 @@ class _Agent(object):
         ops.conv2d_fwd(gu, Hin[t], U, None, Z[t], residual=Zx3[t])
         ops.lstm_gates_fwd(Z[t], Cin[t], done_next, B, H, Hout3[t], H, Hin[t + 1], Cin[t + 1])
     self._last_lstm = dict(X=X, ldx=ldx, in_dim=in_dim, H=H, T1=T1, B=B, done=done_u8, gx=gx, gu=gu, Z=Z, Hin=Hin,
-                           Cin=Cin, Hout=Hout, prefix=prefix)
+                           Cin=Cin, Hout=Hout, prefix=prefix, fused_seq=seq_ok)
     return Hout, (Hin[T1].clone(), Cin[T1].clone())
 
   def _lstm_seq_check(self, wait=False):
@@ -226,14 +227,14 @@ class _Agent(object):
     after every launch and looked at here -- before the next launch (by then the previous copy has landed: no sync)
     or, with wait=True, after waiting for the copy."""
     if getattr(self, '_seq_flag', None) is None:
-      self._seq_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+      self._seq_flag = torch.zeros(2, dtype=torch.int32).pin_memory()    # forward, backward
       self._seq_event = torch.cuda.Event()
       return
     if wait:
       self._seq_event.synchronize()
-    if self._seq_event.query() and int(self._seq_flag[0]) != 0:
-      raise RuntimeError('seedhip_lstm_seq_fwd: grid barrier timed out (workgroups were not co-resident); the LSTM '
-                         'outputs of that step are invalid.  Set SEEDHIP_LSTM_SEQ=0 to use the per-step kernel.')
+    if self._seq_event.query() and int(self._seq_flag.max()) != 0:
+      raise RuntimeError('seedhip_lstm_seq_fwd / _bwd: a wait timed out (workgroups were not co-resident); the LSTM '
+                         'results of that step are invalid.  Set SEEDHIP_LSTM_SEQ=0 to use the per-step kernel.')
 
   def _lstm_bwd(self, dHout, wsb):
     """dHout [T1*B, H]: gradient wrt the core outputs.  Fills the core's weight gradients and returns
@@ -248,7 +249,19 @@ class _Agent(object):
     dhb = self._buf('lstm_dh', (B, H))
     dH3 = dHout.view(T1, B, H)
     dh_rec = dc_rec = None
-    for t in range(T1 - 1, -1, -1):
+    fused_seq = L['fused_seq'] and os.environ.get('SEEDHIP_LSTM_SEQ_BWD', '1') != '0'
+    if fused_seq:                                 # the whole recurrence in one launch (same residency as the forward)
+      capturing = torch.cuda.is_current_stream_capturing()
+      if not capturing:
+        self._lstm_seq_check()
+      ring = self._buf('lstm_seq_ring', (ops.lstm_seq_bwd_workspace_bytes(B, H) // 4,))
+      sync = self._buf('lstm_seq_sync_bwd', (2,), torch.int32)
+      ops.lstm_seq_bwd(self._buf(prefix + '_u_perm', (H, 4 * H)), L['Z'], L['Cin'], dHout, H, L['done'], T1, B, H, dZ,
+                       ring, sync)
+      if not capturing:
+        self._seq_flag[1:2].copy_(sync[1:2], non_blocking=True)
+        self._seq_event.record()
+    for t in range(T1 - 1, -1 if not fused_seq else T1 - 1, -1):
       ops.lstm_gates_bwd(L['Z'][t], L['Cin'][t], dH3[t], H, dh_rec, dc_rec,
                          L['done'][t + 1] if t + 1 < T1 else None, B, H, dZ[t], dcb[t & 1])
       dc_rec = dcb[t & 1]

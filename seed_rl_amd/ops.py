@@ -346,6 +346,19 @@ def lstm_seq_fwd(up, zx, done_u8, T1, B, H, z, h_out, ld_h, hin, cin, sync_ws):
           _lib.ptr(cin), _lib.ptr(sync_ws), _lib.stream()), 'seedhip_lstm_seq_fwd')
 
 
+def lstm_seq_bwd_workspace_bytes(B, H):
+  return int(_lib.lib().seedhip_lstm_seq_bwd_workspace_bytes(B, H))
+
+
+def lstm_seq_bwd(up, z, cin, dh_out, ld_dh, done_u8, T1, B, H, dz, ring_ws, sync_ws):
+  """The whole backward recurrence (cell backward + dh_rec = dz U^T per step) in one launch."""
+  with _region('lstm_seq_bwd', 2.0 * (T1 - 1) * B * H * 4 * H, (H * 4 * H + T1 * B * H * 11) * 4):
+    with _dev(dz):
+      _lib.check(_lib.lib().seedhip_lstm_seq_bwd(
+          _lib.ptr(up), _lib.ptr(z), _lib.ptr(cin), _lib.ptr(dh_out), ld_dh, _lib.ptr(done_u8), T1, B, H, _lib.ptr(dz),
+          _lib.ptr(ring_ws), _lib.ptr(sync_ws), _lib.stream()), 'seedhip_lstm_seq_bwd')
+
+
 def lstm_gates_fwd(z, cin, done_next_u8, B, H, h_out, ld_h, hin_next, cin_next):
   with _region('lstm_gates_fwd', 0, B * H * 4 * 8):
     with _dev(h_out):

@@ -629,7 +629,65 @@ def test_lstm_seq_bounded_wait(device, monkeypatch):
   torch.cuda.synchronize()
   assert time.time() - t0 < 20.0
   assert int(sync[1]) == 1
+  ring = torch.empty(ops.lstm_seq_bwd_workspace_bytes(B, H) // 4, device=device)
+  dz = torch.empty_like(z)
+  t0 = time.time()
+  ops.lstm_seq_bwd(up, zx, cin, hout, H, done, T1, B, H, dz, ring, sync)
+  torch.cuda.synchronize()
+  assert time.time() - t0 < 20.0
+  assert int(sync[1]) == 1
   monkeypatch.delenv('SEEDHIP_LSTM_SEQ_FAULT')
+  ops.lstm_seq_bwd(up, zx, cin, hout, H, done, T1, B, H, dz, ring, sync)
+  torch.cuda.synchronize()
+  assert int(sync[1]) == 0
   ops.lstm_seq_fwd(up, zx, done, T1, B, H, z, hout, H, hin, cin, sync)
   torch.cuda.synchronize()
   assert int(sync[1]) == 0 and bool(torch.isfinite(hout).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('T1,B,H', [(6, 256, 512), (5, 70, 256), (3, 32, 128), (121, 256, 512), (21, 32, 256), (6, 3, 256),
+                                    (40, 64, 384)])
+def test_lstm_seq_bwd_matches_steps(device, T1, B, H):
+  """Whole-recurrence LSTM backward kernel (csrc/lstm_step.hip lstm_seq_bwd_kernel: cell backward + dh_rec = dz U^T
+  with the partial sums exchanged through the ring) vs the per-step path (lstm_gates_bwd + dense data gradient):
+  same dz up to fp32 summation order, over done-resets, a ragged row tile and the R2D2 unroll length; run twice to
+  show it is deterministic and that the ring re-arms correctly."""
+  from seed_rl_amd import ops
+  if not ops.lstm_seq_supported(T1, B, H):
+    pytest.skip('not co-resident on this device')
+  rng = np.random.default_rng(T1 * 77 + B + H)
+  U = dev((rng.normal(size=(H, 4 * H)) / np.sqrt(H)).astype(np.float32), device)
+  Z = dev(rng.normal(size=(T1, B, 4 * H)).astype(np.float32), device)
+  Cin = dev(rng.normal(size=(T1 + 1, B, H)).astype(np.float32), device)
+  dH = dev(rng.normal(size=(T1 * B, H)).astype(np.float32), device)
+  done = dev((rng.uniform(size=(T1, B)) < 0.1).astype(np.uint8), device)
+  up = torch.empty((H, 4 * H), device=device)
+  ops.lstm_permute_u(U, H, up)
+  # per-step reference path
+  dZ_ref = torch.empty((T1, B, 4 * H), device=device)
+  dcb = [torch.empty((B, H), device=device), torch.empty((B, H), device=device)]
+  dhb = torch.empty((B, H), device=device)
+  gu = ops.dense_geom(B, H, 4 * H)
+  dh_rec = dc_rec = None
+  dH3 = dH.view(T1, B, H)
+  for t in range(T1 - 1, -1, -1):
+    ops.lstm_gates_bwd(Z[t], Cin[t], dH3[t], H, dh_rec, dc_rec, done[t + 1] if t + 1 < T1 else None, B, H, dZ_ref[t],
+                       dcb[t & 1])
+    dc_rec = dcb[t & 1]
+    if t > 0:
+      ops.conv2d_bwd_data(gu, dZ_ref[t], U, dhb)
+      dh_rec = dhb
+  ring = torch.empty(ops.lstm_seq_bwd_workspace_bytes(B, H) // 4, device=device)
+  outs = []
+  for _ in range(4):
+    dZ = torch.full((T1, B, 4 * H), 7.0, device=device)
+    sync = torch.full((2,), 5, dtype=torch.int32, device=device)
+    ops.lstm_seq_bwd(up, Z, Cin, dH, H, done, T1, B, H, dZ, ring, sync)
+    torch.cuda.synchronize()
+    assert int(sync[1]) == 0, 'a wait timed out'
+    outs.append(dZ)
+  for o in outs[1:]:
+    assert torch.equal(outs[0], o)
+  scale = float(dZ_ref.abs().max())
+  assert float((outs[0] - dZ_ref).abs().max()) <= 2e-5 * max(1.0, scale)

@@ -47,3 +47,14 @@ for B, H in [(256, 512), (256, 256)]:
             for _ in range(10): ops.lstm_seq_fwd(up, zx3, done3, T1, B, H, z3, h3, H, hin3, cin3, sync)
             e1.record(); torch.cuda.synchronize()
             print('B=%d H=%d whole-unroll kernel mode %s: %.2f us per step (T1 = 100, abort flag %d)' % (B, H, mode, e0.elapsed_time(e1), int(sync[1])))
+        ring = torch.empty(ops.lstm_seq_bwd_workspace_bytes(B, H) // 4, device=dev)
+        dz3 = torch.empty_like(zx3); dh3 = torch.randn(T1 * B, H, device=dev) * 0.01
+        for dbg in os.environ.get('SEQ_DBG', '0').split(','):
+            os.environ['SEEDHIP_LSTM_SEQ_FAULT'] = dbg
+            for _ in range(3): ops.lstm_seq_bwd(up, zx3, cin3, dh3, H, done3, T1, B, H, dz3, ring, sync)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10): ops.lstm_seq_bwd(up, zx3, cin3, dh3, H, done3, T1, B, H, dz3, ring, sync)
+            e1.record(); torch.cuda.synchronize()
+            print('B=%d H=%d whole-recurrence backward dbg %s: %.2f us per step (T1 = 100, abort flag %d)' % (B, H, dbg, e0.elapsed_time(e1), int(sync[1])))
+        os.environ.pop('SEEDHIP_LSTM_SEQ_FAULT', None)
