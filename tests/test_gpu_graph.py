@@ -13,12 +13,15 @@ def _mk(device, kind):
     agent = networks.AtariShallow(A, device=device, seed=0)
     unroll = smoke_step.make_unroll(agent, 5, 4, A, device, seed=3, done_p=0.2)
   else:
+    # 'deep_long': an unroll long / wide enough that the whole-unroll LSTM kernels' exchange buffers are megabytes
+    # (replayed hipMemsetAsync nodes of that size corrupted memory on ROCm 7.2; they are armed by a kernel now)
+    T1, B = (21, 32) if kind == 'deep_long' else (5, 4)
     agent = networks.ImpalaDeep(A, observation_shape=(24, 32, 3), device=device, seed=0)
-    unroll = smoke_step.make_deep_unroll(agent, 5, 4, A, device, seed=3, done_p=0.2)
+    unroll = smoke_step.make_deep_unroll(agent, T1, B, A, device, seed=3, done_p=0.2)
   return learner.Learner(agent, opt, pd.categorical_distribution(A)), unroll
 
 
-@pytest.mark.parametrize('kind', ['atari', 'deep'])
+@pytest.mark.parametrize('kind', ['atari', 'deep', 'deep_long'])
 def test_graphed_step_matches_eager(device, kind):
   from seed_rl_amd import learner
   eager, unroll = _mk(device, kind)
