@@ -395,8 +395,7 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
     float* pb = pw + (size_t)pl.slices * M * N;
     gp.partial = pw; gp.partial_colsum = dbias ? pb : nullptr;
     gemm::launch<false, false, true, false, false>(gp, pl, s);
-    reduce_slices(pw, pl.slices, (long long)M * N, dw, s);
-    if (dbias) reduce_slices(pb, pl.slices, N, dbias, s);
+    reduce_slices2(pw, (long long)M * N, dw, pb, N, dbias, pl.slices, s);
     return check_launch("conv2d_bwd_weight(gather gemm)");
   }
   {
@@ -420,8 +419,7 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
       gp.partial_colsum = dbias ? (pl.slices > 1 ? pb : dbias) : nullptr;
       gemm::launch<false, false>(gp, pl, s);
       if (pl.slices > 1) {
-        reduce_slices(pw, pl.slices, (long long)M * N, dw, s);
-        if (dbias) reduce_slices(pb, pl.slices, N, dbias, s);
+        reduce_slices2(pw, (long long)M * N, dw, pb, N, dbias, pl.slices, s);
       }
       return check_launch("conv2d_bwd_weight(dense, gemm)");
     }
@@ -435,8 +433,7 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
     d.partial_b = dbias ? (float*)workspace + (size_t)slices * M * N : nullptr;
     hipStream_t s = (hipStream_t)stream;
     launch_igemm_auto(d, slices, s);
-    reduce_slices(d.partial_w, slices, (long long)M * N, dw, s);
-    if (dbias) reduce_slices(d.partial_b, slices, N, dbias, s);
+    reduce_slices2(d.partial_w, (long long)M * N, dw, d.partial_b, N, dbias, slices, s);
     return check_launch("conv2d_bwd_weight(dense)");
     }
   }
@@ -450,8 +447,7 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
   p.partial_b = dbias ? (float*)workspace + (size_t)slices * M * N : nullptr;
   hipStream_t s = (hipStream_t)stream;
   launch_igemm_auto(p, slices, s);
-  reduce_slices(p.partial_w, slices, (long long)M * N, dw, s);
-  if (dbias) reduce_slices(p.partial_b, slices, N, dbias, s);
+  reduce_slices2(p.partial_w, (long long)M * N, dw, p.partial_b, N, dbias, slices, s);
   return check_launch("conv2d_bwd_weight");
 }
 

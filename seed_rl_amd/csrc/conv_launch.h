@@ -4,12 +4,21 @@
 
 namespace seedhip {
 
-// out[i] = sum_z partial[z][i]  (fixed order => deterministic), float4 vectorised.
+// One reduction job: out[i] = sum_z partial[z][i], i < n (fixed order => deterministic).  The kernels below take TWO
+// jobs with the same slice count -- a weight gradient and its bias gradient -- so that the pair costs one launch
+// (each of these launches is a few microseconds of drain + dispatch against ~1 us of work).
+struct ReduceJob { const float* partial; long long n; float* out; };
+
+// float4 vectorised, one thread walks all slices of its columns.  Blocks [0, blocks_a) serve job a, the rest job b.
 static __global__ void __launch_bounds__(256)
-reduce_slices_kernel(const float* __restrict__ partial, int slices, long long n, float* __restrict__ out) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
+reduce_slices_kernel(const ReduceJob ja, const ReduceJob jb, int blocks_a, int slices) {
+  const bool first = (int)blockIdx.x < blocks_a;
+  const ReduceJob j = first ? ja : jb;
+  const long long bx = first ? blockIdx.x : blockIdx.x - blocks_a, nb = first ? blocks_a : gridDim.x - blocks_a;
+  const float* __restrict__ partial = j.partial; float* __restrict__ out = j.out; const long long n = j.n;
+  const long long stride = nb * blockDim.x;
   const long long n4 = n >> 2;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+  for (long long i = bx * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float4 a = reinterpret_cast<const float4*>(partial)[i];
     for (int z = 1; z < slices; ++z) {
       const float4 b = reinterpret_cast<const float4*>(partial + (long long)z * n)[i];
@@ -17,7 +26,7 @@ reduce_slices_kernel(const float* __restrict__ partial, int slices, long long n,
     }
     reinterpret_cast<float4*>(out)[i] = a;
   }
-  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  for (long long i = (n4 << 2) + bx * blockDim.x + threadIdx.x; i < n; i += stride) {
     float a = partial[i];
     for (int z = 1; z < slices; ++z) a += partial[(long long)z * n + i];
     out[i] = a;
@@ -28,11 +37,15 @@ reduce_slices_kernel(const float* __restrict__ partial, int slices, long long n,
 // block; lane q sums slices q, q+16, ... (independent loads in flight), then the 16 lanes are combined through
 // LDS in a fixed order.  Deterministic, and 16x more parallel than one thread walking all slices of a column.
 static __global__ void __launch_bounds__(256)
-reduce_slices_wide_kernel(const float* __restrict__ partial, int slices, long long n, float* __restrict__ out) {
+reduce_slices_wide_kernel(const ReduceJob ja, const ReduceJob jb, int blocks_a, int slices) {
   __shared__ float4 red[16][17];
+  const bool first = (int)blockIdx.x < blocks_a;
+  const ReduceJob j = first ? ja : jb;
+  const long long bx = first ? blockIdx.x : blockIdx.x - blocks_a;
+  const float* __restrict__ partial = j.partial; float* __restrict__ out = j.out; const long long n = j.n;
   const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const long long n4 = n >> 2;
-  const long long c4 = (long long)blockIdx.x * 16 + col;
+  const long long c4 = bx * 16 + col;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c4 < n4) {
     for (int z = sl; z < slices; z += 16) {
@@ -49,13 +62,33 @@ reduce_slices_wide_kernel(const float* __restrict__ partial, int slices, long lo
   }
 }
 
-static inline void reduce_slices(const float* partial, int slices, long long n, float* out, hipStream_t s) {
-  if (slices >= 32 && (n & 3) == 0 && ((((uintptr_t)partial) | ((uintptr_t)out)) & 15) == 0) {
-    hipLaunchKernelGGL(reduce_slices_wide_kernel, dim3(cdiv(n >> 2, 16)), dim3(256), 0, s, partial, slices, n, out);
+// (pw, nw, dw) and, when db != nullptr, (pb, nb, db): same slice count; one launch when both jobs take the same
+// kernel (so every output keeps the summation order it had as a separate launch).
+static inline void reduce_slices2(const float* pw, long long nw, float* dw, const float* pb, long long nb, float* db,
+                                  int slices, hipStream_t s) {
+  auto wide_ok = [&](const float* p, long long n, const float* o) {
+    return slices >= 32 && (n & 3) == 0 && ((((uintptr_t)p) | ((uintptr_t)o)) & 15) == 0;
+  };
+  const bool wa = wide_ok(pw, nw, dw);
+  if (db && wide_ok(pb, nb, db) != wa) {                       // mixed: two launches, as before
+    reduce_slices2(pw, nw, dw, nullptr, 0, nullptr, slices, s);
+    reduce_slices2(pb, nb, db, nullptr, 0, nullptr, slices, s);
     return;
   }
-  int blocks = cdiv(n / 4 + 1, 256); if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(reduce_slices_kernel, dim3(blocks), dim3(256), 0, s, partial, slices, n, out);
+  const ReduceJob ja{pw, nw, dw};
+  const ReduceJob jb{db ? pb : pw, db ? nb : 0, db ? db : dw};
+  if (wa) {
+    const int ba = cdiv(nw >> 2, 16), bb = jb.n ? cdiv(jb.n >> 2, 16) : 0;
+    hipLaunchKernelGGL(reduce_slices_wide_kernel, dim3(ba + bb), dim3(256), 0, s, ja, jb, ba, slices);
+    return;
+  }
+  int ba = cdiv(nw / 4 + 1, 256); if (ba > 1024) ba = 1024;
+  int bb = jb.n ? cdiv(jb.n / 4 + 1, 256) : 0; if (bb > 1024) bb = 1024;
+  hipLaunchKernelGGL(reduce_slices_kernel, dim3(ba + bb), dim3(256), 0, s, ja, jb, ba, slices);
+}
+
+static inline void reduce_slices(const float* partial, int slices, long long n, float* out, hipStream_t s) {
+  reduce_slices2(partial, n, out, nullptr, 0, nullptr, slices, s);
 }
 
 // pixels per split-K slice for weight gradients: enough slices to fill the chip,

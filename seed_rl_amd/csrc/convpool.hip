@@ -391,7 +391,6 @@ extern "C" int seedhip_conv3x3_u8_pool_bwd(const uint8_t* x, int n, int ih, int 
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(convpool_bwd_kernel, dim3(grid), dim3(256), lds, s, g, x, dpooled, argmax, pw, pb);
   rc = seedhip::check_launch("convpool_bwd_kernel"); if (rc) return rc;
-  seedhip::reduce_slices(pw, grid, 27LL * COUT, dw, s);
-  if (dbias) seedhip::reduce_slices(pb, grid, COUT, dbias, s);
+  seedhip::reduce_slices2(pw, 27LL * COUT, dw, pb, COUT, dbias, grid, s);
   return seedhip::check_launch("conv3x3_u8_pool_bwd");
 }

@@ -356,8 +356,7 @@ inline int launch_wgrad(const seedhip_conv_geom* g, const WgradPlan& pl, const v
   if (!launched) return fail(SEEDHIP_ERR_UNSUPPORTED, "halo_wgrad: no kernel for MTW=%d NT=%d MSPLIT=%d", pl.MTW, pl.NT, pl.MSPLIT);
 #undef SEEDHIP_HALO_LAUNCH
   int rc = check_launch("halo_wgrad_kernel"); if (rc) return rc;
-  reduce_slices(p.partial_w, pl.grid, (long long)p.rows * g->cout, dw, s);
-  if (dbias) reduce_slices(p.partial_b, pl.grid, g->cout, dbias, s);
+  reduce_slices2(p.partial_w, (long long)p.rows * g->cout, dw, p.partial_b, g->cout, dbias, pl.grid, s);
   return check_launch("halo_wgrad reduce");
 }
 

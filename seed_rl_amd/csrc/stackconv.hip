@@ -839,8 +839,7 @@ extern "C" int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* ge
     else
       hipLaunchKernelGGL(stackconv::stackconv_wgrad_kernel, dim3(grid, 1, N / 16), dim3(stackconv::kThreads), lds, s, p);
     rc = check_launch("stackconv_wgrad_kernel"); if (rc) return rc;
-    reduce_slices(p.partial_w, grid, (long long)M * N, dw, s);
-    if (dbias) reduce_slices(p.partial_b, grid, N, dbias, s);
+    reduce_slices2(p.partial_w, (long long)M * N, dw, p.partial_b, N, dbias, grid, s);
     return check_launch("conv2d_stack_bwd_weight");
   }
   ConvStackWgrad p;
@@ -851,7 +850,6 @@ extern "C" int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* ge
   p.partial_w = (float*)workspace;
   p.partial_b = dbias ? (float*)workspace + (size_t)slices * M * N : nullptr;
   launch_igemm_auto(p, slices, s);
-  reduce_slices(p.partial_w, slices, (long long)M * N, dw, s);
-  if (dbias) reduce_slices(p.partial_b, slices, N, dbias, s);
+  reduce_slices2(p.partial_w, (long long)M * N, dw, p.partial_b, N, dbias, slices, s);
   return check_launch("conv2d_stack_bwd_weight");
 }

@@ -151,7 +151,7 @@ class FusedInferenceState(object):
     n = ids.numel()
     b = self._bufs(n)
     reward = env_outputs.reward.to(torch.float32).contiguous()
-    done_u8 = env_outputs.done.to(torch.uint8).contiguous()
+    done_u8 = ops.as_u8(env_outputs.done)
     ops.inference_pre(ids, runs, reward, raw_rewards.to(torch.float32).contiguous(), done_u8, n, self.E,
                       self.num_action_repeats, self.run_ids_tab, self.info_frames, self.info_return, self.info_raw,
                       self.actions_tab, self.store_index, b['reset'], b['prev_actions'], self.episode_stats,

@@ -59,7 +59,8 @@ def compute_loss(logger, parametric_action_distribution, agent, agent_state, pre
   Returns (total_loss: 0-d device tensor, log_session)."""
   cfg = config or LossConfig()
   logger = logger or DictLogger()
-  learner_outputs, _ = agent(prev_actions, env_outputs, agent_state, unroll=True, is_training=True)  # :75-79
+  kw = dict(need_state=False) if getattr(agent, 'accepts_need_state', False) else {}       # the new state is discarded
+  learner_outputs, _ = agent(prev_actions, env_outputs, agent_state, unroll=True, is_training=True, **kw)  # :75-79
   head, d_head, ldh = agent.head_buffers()
   T1, B = env_outputs.done.shape[0], env_outputs.done.shape[1]
   T = T1 - 1
@@ -70,7 +71,7 @@ def compute_loss(logger, parametric_action_distribution, agent, agent_state, pre
   if actions.dtype not in (torch.int32, torch.int64):
     actions = actions.to(torch.int64)
   rewards = env_outputs.reward.to(torch.float32).contiguous()
-  done_u8 = env_outputs.done.to(torch.uint8).contiguous()
+  done_u8 = ops.as_u8(env_outputs.done)
   scalars = agent._buf('loss_scalars', (16,))
   ws = agent._buf('loss_ws', (ops.impala_loss_workspace_bytes(T, B) // 4 + 4,))
   vs = agent._buf('vs', (T, B)) if want_vtrace else None

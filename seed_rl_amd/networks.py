@@ -310,7 +310,7 @@ class _AtariTorso(object):
     and pass that view as env_outputs.observation: no copy is made then."""
     return self._buf('frames_ext', (T1 + 3, B, self._obs[0] * self._obs[1]), torch.uint8, zero=True)
 
-  def _torso_fwd(self, obs, done_u8, frame_state, out, ld_out):
+  def _torso_fwd(self, obs, done_u8, frame_state, out, ld_out, need_state=True):
     """obs uint8 [T1,B,H,W,1]; writes relu(fc) into out[:, :fc] (row stride ld_out).  Returns the new
     frame-stacking state and the context the backward needs."""
     T1, B = done_u8.shape[0], done_u8.shape[1]
@@ -339,8 +339,10 @@ class _AtariTorso(object):
       acts.append(a2); geoms.append(g); a = a2
     gfc = ops.dense_geom(N, self._flat_dim, self._fc, ld_out=ld_out)
     ops.conv2d_fwd(gfc, a, fl.p(tp + 'fc/kernel'), fl.p(tp + 'fc/bias'), out, out_relu=True)
-    new_fs = torch.empty_like(frame_state)
-    ops.stack_pack_state(ext, nvalid, T1, B, HW, new_fs)
+    new_fs = None
+    if need_state:                                # the learner discards it (agents/vtrace/learner.py:75-79 `learner_outputs, _ =`)
+      new_fs = torch.empty_like(frame_state)
+      ops.stack_pack_state(ext, nvalid, T1, B, HW, new_fs)
     return new_fs, dict(ext=ext, nvalid=nvalid, acts=acts, geoms=geoms, gfc=gfc)
 
   def _torso_bwd(self, ctx, dz, wsb):
@@ -396,16 +398,18 @@ class AtariShallow(_Agent, _AtariTorso):
     return AgentState(core_state=(), frame_stacking_state=torch.zeros((batch_size, hw), dtype=torch.int32,
                                                                       device=self.device))
 
-  def __call__(self, prev_actions, env_outputs, agent_state, unroll=False, is_training=False):
+  accepts_need_state = True      # need_state=False: skip re-packing the frame-stacking state the caller will not use
+
+  def __call__(self, prev_actions, env_outputs, agent_state, unroll=False, is_training=False, need_state=True):
     del prev_actions   # the feed-forward agent does not consume it
     obs, done = env_outputs.observation, env_outputs.done
     if not unroll:
       obs, done = obs[None], done[None]
     T1, B = done.shape[0], done.shape[1]
     N = T1 * B
-    done_u8 = done.to(torch.uint8).contiguous()
+    done_u8 = ops.as_u8(done)
     hfc = self._buf('fc_out', (N, self._fc))
-    new_fs, ctx = self._torso_fwd(obs, done_u8, agent_state.frame_stacking_state, hfc, self._fc)
+    new_fs, ctx = self._torso_fwd(obs, done_u8, agent_state.frame_stacking_state, hfc, self._fc, need_state)
     head = self._head_fwd(hfc, N, self._fc)
     self._last = dict(T1=T1, B=B, N=N, ctx=ctx, hfc=hfc, head=head)
     out = self._agent_output(head, T1, B, sample=not is_training)
@@ -469,7 +473,7 @@ class DuelingLSTMDQNNet(_Agent, _AtariTorso):
     T1, B = done.shape[0], done.shape[1]
     N, A, H = T1 * B, self._num_actions, self._H
     fl = self.flat
-    done_u8 = done.to(torch.uint8).contiguous()
+    done_u8 = ops.as_u8(done)
     ldx = self._ldx
     X = self._buf('lstm_x', (N, ldx))
     new_fs, ctx = self._torso_fwd(obs, done_u8, agent_state.frame_stacking_state, X, ldx)
@@ -620,7 +624,7 @@ class ImpalaDeep(_Agent):
                    out_relu=True)                                                    # :105-109
     ops.lstm_assemble_inputs(X, ldx, self._fc, self._num_actions, reward.to(torch.float32).contiguous(),
                              prev_actions.contiguous(), True, N)                     # :112-114
-    done_u8 = done.to(torch.uint8).contiguous()
+    done_u8 = ops.as_u8(done)
     Hout, new_state = self._lstm_fwd(X, ldx, self._in_dim, self._H, T1, B, done_u8, core_state)
     head = self._head_fwd(Hout, N, self._H)
     self._last = dict(T1=T1, B=B, N=N, saved=saved, flat=flat, gfc=gfc, X=X, Hout=Hout, head=head)

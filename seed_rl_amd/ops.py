@@ -308,6 +308,12 @@ def lstm_assemble_inputs(x, ldx, feat, num_actions, reward, prev_actions, clip_r
         int(clip_reward), rows, _lib.stream()), 'seedhip_lstm_assemble_inputs')
 
 
+def as_u8(t):
+  """bool -> uint8 without a copy (torch stores bool as one byte holding 0 / 1); anything else is converted."""
+  t = t.contiguous()
+  return t.view(torch.uint8) if t.dtype == torch.bool else t.to(torch.uint8)
+
+
 def lstm_mask_state(h0, c0, done0_u8, B, H, hin, cin):
   with _dev(hin):
     _lib.check(_lib.lib().seedhip_lstm_mask_state(_lib.ptr(h0), _lib.ptr(c0), _lib.ptr(done0_u8), B, H, _lib.ptr(hin),

@@ -65,7 +65,7 @@ def compute_loss_and_priorities(training_agent, target_agent, agent_state, prev_
   ops.r2d2_loss_fwd_bwd(
       training_out.q_values.contiguous(), target_out.q_values.contiguous(),
       ao_suf.action.to(torch.int32).contiguous(), env_suf.reward.to(torch.float32).contiguous(),
-      env_suf.done.to(torch.uint8).contiguous(), iw, T, B, A, gamma, cfg.n_steps, cfg.eta,
+      ops.as_u8(env_suf.done), iw, T, B, A, gamma, cfg.n_steps, cfg.eta,
       cfg.value_function_rescaling_epsilon, B if mean_denominator is None else mean_denominator,
       loss_b, prio_b, dq, total, ws)
   ag._last['dq'] = dq
