@@ -241,6 +241,186 @@ ws_kernel(const Params p) {
   }
 }
 
+
+// Same algorithm with everything the shape fixes made static: NKT (k-tiles per row tile), MR = 1, 8 waves.  The generic
+// kernel above spends ~2 000 scalar / vector integer instructions per 16-row tile around its 128 MFMAs (run-time k-tile
+// cursor indexing kernarg arrays, per-load branches, two divisions per row, 64-bit addresses) and that skeleton does
+// NOT hide under the other waves' MFMAs (measured: 86 us of the data gradient's 268 with every MFMA and every global
+// access removed).  Here the k loop is unrolled, the k-tile offsets live in SGPRs, loads are 32-bit offsets from the
+// uniform base with a select instead of a branch, and rows after the first of a lane are stepped, not divided.
+template <int NR, int NKT, int MODE>
+__global__ void __launch_bounds__(512)
+ws_fast_kernel(const Params p) {
+  constexpr int WAVES = 8, N = 16 * NR, LDB = (NR == 2) ? N + 8 : N, kThreads = 64 * WAVES;
+  static_assert(NKT <= kMaxTiles, "k-tile tables");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Bs = smem;                           // [K][LDB]
+  float* As = smem + p.K * LDB;               // [WAVES][16][LDA]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lx = lane & 15, kq = lane >> 4;
+
+  if (MODE == 0) {
+    for (int idx = tid; idx < p.K * N / 4; idx += kThreads) {
+      const int e = idx * 4, k = e / N, n = e - k * N;
+      *reinterpret_cast<float4*>(Bs + k * LDB + n) = *reinterpret_cast<const float4*>(p.W + e);
+    }
+  } else {
+    const int jw = p.kw / p.s;
+    for (int idx = tid; idx < p.K * N; idx += kThreads) {
+      const int k = idx / N, n = idx - k * N;
+      const int co = k % p.cout, tap = k / p.cout, jy = tap / jw, jx = tap - jy * jw;
+      const int ci = n % p.cin, cls = n / p.cin, py = cls / p.s, px = cls - py * p.s;
+      Bs[k * LDB + n] = p.W[(((py + p.s * jy) * p.kw + px + p.s * jx) * p.cin + ci) * p.cout + co];
+    }
+  }
+  __syncthreads();
+
+  float* Aw = As + wave * (16 * LDA);
+  const int kc = (lane & 7) * 4, srow = lane >> 3;            // this lane stages rows srow and srow + 8, floats kc..kc+3
+  int toff[NKT], tdy[NKT], tdx[NKT];                          // uniform: SGPRs
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) { toff[t] = p.tile_off[t]; tdy[t] = p.tile_dy[t]; tdx[t] = p.tile_dx[t]; }
+  const uint32_t gw = (uint32_t)p.gw, gh = (uint32_t)p.gh;
+
+  // (img, a, b) of row m, then of m + step (step < gw): one division pair per lane and tile, the rest is stepped
+  auto locate = [&](uint32_t m, uint32_t& img, uint32_t& a, uint32_t& b) {
+    uint32_t rem;
+    p.d_g.divmod(m, img, rem);
+    p.d_gw.divmod(rem, a, b);
+  };
+  auto advance = [&](uint32_t step, uint32_t& img, uint32_t& a, uint32_t& b) {
+    b += step;
+    if (b >= gw) { b -= gw; if (++a >= gh) { a = 0; ++img; } }
+  };
+
+  unsigned lbase[2], lmask[2];                                // load cursor: row bases and k-tile validity of the tile being fetched
+  auto setup = [&](int wt) {
+    uint32_t img, a, b;
+    const uint32_t m0 = (uint32_t)wt * 16u + (uint32_t)srow;
+    locate(m0, img, a, b);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i) advance(8u, img, a, b);
+      unsigned mask = 0;
+      if (MODE == 0) mask = 0xffffffffu;
+      else {
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+          const int y = (int)a + tdy[t], x = (int)b + tdx[t];
+          mask |= (unsigned)(y >= 0 && y < p.vh && x >= 0 && x < p.vw) << t;
+        }
+      }
+      if (m0 + 8u * i >= (uint32_t)p.M) mask = 0;
+      lbase[i] = img * p.a_img_stride + a * p.a_row_stride + b * p.a_col_stride + kc;
+      lmask[i] = mask;
+    }
+  };
+  float4 rg[NKT][2];                                          // one register stage per k-tile x two rows: a whole tile ahead
+  auto fetch = [&](int stage, int ktl) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = (lmask[i] >> ktl) & 1u;
+      const unsigned idx = ok ? lbase[i] + (unsigned)toff[ktl] : 0u;
+      float4 v = *reinterpret_cast<const float4*>(p.A + idx);
+      if (p.a_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      rg[stage][i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  const float* a_frag = Aw + lx * LDA + 4 * kq;
+  const float* b_frag = Bs + (4 * kq) * LDB + NR * lx;
+  typedef typename Vec<NR>::type bvec_t;
+  const int wstride = gridDim.x * WAVES;
+  const int n = NR * lx;
+  int e_py = 0, e_px = 0, e_ci = 0;
+  if (MODE == 1) { const int cls = n / p.cin; e_ci = n - cls * p.cin; e_py = cls / p.s; e_px = cls - e_py * p.s; }
+
+  // Loads run ONE WHOLE TILE ahead: k-tile kt of the next tile is requested right after k-tile kt of this one went to
+  // LDS, i.e. before this tile's epilogue stores.  A wave's memory operations retire in issue order, so a load issued
+  // behind those stores would also wait for their acknowledgement (with the two-k-tile distance of the generic kernel
+  // every tile stalled on that: MFMA time and memory time simply added up).
+  int tile = blockIdx.x * WAVES + wave;
+  setup(tile);
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) fetch(kt, kt);
+  for (; tile < p.ntiles; tile += wstride) {
+    setup(tile + wstride);                                    // the load cursor: this wave's next tile
+    f32x4_t acc[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // epilogue addresses (and the ReLU-mask values: their latency hides under the tile's MFMAs)
+    unsigned out_at[4];
+    bvec_t mpre[4];
+    {
+      uint32_t img, a, b;
+      const uint32_t m0 = (uint32_t)tile * 16u + 4u * (uint32_t)kq;
+      locate(m0, img, a, b);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r) advance(1u, img, a, b);
+        unsigned at = 0xffffffffu;
+        bvec_t mv;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) mv[j] = 1.f;
+        if (m0 + r < (uint32_t)p.M) {
+          if (MODE == 0) at = (m0 + r) * (unsigned)p.ldc + n;
+          else {
+            const int oy = (int)a * p.s + e_py, ox = (int)b * p.s + e_px;
+            if (oy < p.ih && ox < p.iw) {
+              at = ((img * p.ih + oy) * p.iw + ox) * p.ld_in + e_ci;
+              if (p.mask) mv = *reinterpret_cast<const bvec_t*>(p.mask + at);
+            }
+          }
+        }
+        out_at[r] = at; mpre[r] = mv;
+      }
+    }
+
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      wave_fence();                                           // fragment reads of the previous k-tile are issued
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(Aw + (srow + 8 * i) * LDA + kc) = rg[kt][i];
+      wave_fence();
+      fetch(kt, kt);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4_t a_kc = *reinterpret_cast<const f32x4_t*>(a_frag + h * 16);
+        bvec_t b_oc[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) b_oc[kk] = *reinterpret_cast<const bvec_t*>(b_frag + (kt * BK + h * 16 + kk) * LDB);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int j = 0; j < NR; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_kc[kk], b_oc[kk][j], acc[j], 0, 0, 0);
+      }
+    }
+
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned at = out_at[r];
+      if (at == 0xffffffffu) continue;
+      bvec_t v;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) v[j] = acc[j][r];
+      if (MODE == 0) {
+        if (p.bias) { const bvec_t bv = *reinterpret_cast<const bvec_t*>(p.bias + n); v += bv; }
+        if (p.residual) { const bvec_t rv = *reinterpret_cast<const bvec_t*>(p.residual + at); v += rv; }
+        if (p.out_relu) {
+#pragma unroll
+          for (int j = 0; j < NR; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) if (!(mpre[r][j] > 0.f)) v[j] = 0.f;
+        if (p.add) { const bvec_t av = *reinterpret_cast<const bvec_t*>(p.add + at); v += av; }
+      }
+      *reinterpret_cast<bvec_t*>(p.C + at) = v;
+    }
+  }
+}
+
 struct Plan { bool ok; int mr, nr, grid; size_t lds; };
 
 // Fills the geometry for the forward of a 'valid' conv; ok = false when the shape is outside this kernel's range.
@@ -305,6 +485,21 @@ inline int launch(Params& p, Plan& pl, hipStream_t s) {
   int per_cu = (int)((160 * 1024) / (pl.lds + 512)); if (per_cu > 32 / waves) per_cu = 32 / waves; if (per_cu < 1) per_cu = 1;
   const int wgs = (p.ntiles + waves - 1) / waves;
   pl.grid = wgs < 256 * per_cu ? wgs : 256 * per_cu;
+  // the specialised kernel: MR = 1, 8 waves, static k-tile count
+  static const int fast = getenv("SEEDHIP_WS_FAST") ? atoi(getenv("SEEDHIP_WS_FAST")) : 1;
+  // measured (cfg2): data gradient 0.255 -> 0.240 ms; the forward (NKT = 8, 16 MFMAs per k-tile) is 12 % SLOWER in this
+  // form (0.195 -> 0.219 ms) and stays on the generic kernel
+  if (fast && pl.mr == 1 && waves == 8 && p.gw >= 8 && p.mode == 1) {
+#define SEEDHIP_WSF(NR_, NKT_, MODE_)                                                                             \
+    if (pl.nr == NR_ && p.nkt == NKT_ && p.mode == MODE_) {                                                       \
+      if (pl.lds > 64 * 1024)                                                                                     \
+        (void)hipFuncSetAttribute((const void*)ws_fast_kernel<NR_, NKT_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds); \
+      hipLaunchKernelGGL((ws_fast_kernel<NR_, NKT_, MODE_>), dim3(pl.grid), dim3(512), pl.lds, s, p);             \
+      return check_launch("ws_fast_kernel");                                                                      \
+    }
+    SEEDHIP_WSF(4, 4, 1) SEEDHIP_WSF(2, 4, 1) SEEDHIP_WSF(4, 8, 1) SEEDHIP_WSF(2, 8, 1)
+#undef SEEDHIP_WSF
+  }
 #define SEEDHIP_WS(MR_, NR_, W_)                                                                                  \
   if (pl.mr == MR_ && pl.nr == NR_ && waves == W_) {                                                              \
     if (pl.lds > 64 * 1024)                                                                                       \
