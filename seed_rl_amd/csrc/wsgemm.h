@@ -53,6 +53,7 @@ struct Params {
   // data-gradient epilogue: dx[img, s*a+py, s*b+px, ci] = mask(acc) + add
   int ih, iw, ld_in; const float* mask; const float* add;
   int ntiles;
+  long long a_bytes;                          // extent of A in bytes (buffer-resource range of the specialised kernel)
 };
 
 // LDS traffic of one wave is ordered; this only stops the compiler from moving LDS accesses across the point.
@@ -242,16 +243,22 @@ ws_kernel(const Params p) {
 }
 
 
-// Same algorithm with everything the shape fixes made static: NKT (k-tiles per row tile), MR = 1, 8 waves.  The generic
-// kernel above spends ~2 000 scalar / vector integer instructions per 16-row tile around its 128 MFMAs (run-time k-tile
-// cursor indexing kernarg arrays, per-load branches, two divisions per row, 64-bit addresses) and that skeleton does
-// NOT hide under the other waves' MFMAs (measured: 86 us of the data gradient's 268 with every MFMA and every global
-// access removed).  Here the k loop is unrolled, the k-tile offsets live in SGPRs, loads are 32-bit offsets from the
-// uniform base with a select instead of a branch, and rows after the first of a lane are stepped, not divided.
+// Same algorithm on a VALU diet.  On gfx950 a SIMD's VALU instructions and MFMAs do not overlap (SQ counters on the
+// cfg2 step: SQ_VALU_MFMA_COEXEC_CYCLES = 0; kernel times follow 32 cycles per fp32 MFMA + ~4 per VALU instruction),
+// and the generic kernel above issues 3.7 (forward) to 5 (data gradient) VALU instructions per MFMA: run-time k-tile
+// cursor, per-load branches / selects, two divisions per row, 64-bit addresses, a ReLU select that is never taken.
+// Here everything the shape fixes is static (NKT k-tiles unrolled, MR = 1, 8 waves, no input ReLU) and:
+//   * A is read through a buffer resource: per load ONE byte offset register (set to an out-of-range value for
+//     border taps / tail rows: the hardware returns zeros) and the k-tile offset in an SGPR -- no address arithmetic,
+//     no select on the data;
+//   * rows after the first of a lane are stepped instead of divided; bounds checks that the shape makes vacuous
+//     (full tiles, map sizes that are multiples of the stride) are skipped by uniform branches;
+//   * loads run ONE WHOLE TILE ahead (see the tile loop).
 template <int NR, int NKT, int MODE>
 __global__ void __launch_bounds__(512)
 ws_fast_kernel(const Params p) {
   constexpr int WAVES = 8, N = 16 * NR, LDB = (NR == 2) ? N + 8 : N, kThreads = 64 * WAVES;
+  constexpr unsigned kOOB = 0x80000000u;                      // beyond num_records of any buffer we bind (< 2 GB)
   static_assert(NKT <= kMaxTiles, "k-tile tables");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Bs = smem;                           // [K][LDB]
@@ -276,23 +283,38 @@ ws_fast_kernel(const Params p) {
 
   float* Aw = As + wave * (16 * LDA);
   const int kc = (lane & 7) * 4, srow = lane >> 3;            // this lane stages rows srow and srow + 8, floats kc..kc+3
-  int toff[NKT], tdy[NKT], tdx[NKT];                          // uniform: SGPRs
+  // buffer view of A starting at the most negative k-tile offset, so that every k-tile offset is an unsigned SGPR
+  int minoff = 0;
 #pragma unroll
-  for (int t = 0; t < NKT; ++t) { toff[t] = p.tile_off[t]; tdy[t] = p.tile_dy[t]; tdx[t] = p.tile_dx[t]; }
+  for (int t = 0; t < NKT; ++t) minoff = p.tile_off[t] < minoff ? p.tile_off[t] : minoff;
+  unsigned soff[NKT]; int tdy[NKT], tdx[NKT];                 // uniform: SGPRs
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    soff[t] = __builtin_amdgcn_readfirstlane((unsigned)(p.tile_off[t] - minoff) * 4u);
+    tdy[t] = p.tile_dy[t]; tdx[t] = p.tile_dx[t];
+  }
+  // (readfirstlane: the descriptor and the offsets are uniform by construction; saying so keeps them in SGPRs and the
+  // loads free of waterfall loops)
+  const uint64_t abase = reinterpret_cast<uint64_t>(p.A + minoff);
+  const uint64_t sbase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(abase >> 32)) << 32) |
+                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)abase);   // (the builtin returns int)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(sbase), 0, __builtin_amdgcn_readfirstlane((int)p.a_bytes - minoff * 4), 0x00020000);
   const uint32_t gw = (uint32_t)p.gw, gh = (uint32_t)p.gh;
 
-  // (img, a, b) of row m, then of m + step (step < gw): one division pair per lane and tile, the rest is stepped
   auto locate = [&](uint32_t m, uint32_t& img, uint32_t& a, uint32_t& b) {
     uint32_t rem;
     p.d_g.divmod(m, img, rem);
     p.d_gw.divmod(rem, a, b);
   };
-  auto advance = [&](uint32_t step, uint32_t& img, uint32_t& a, uint32_t& b) {
+  auto advance = [&](uint32_t step, uint32_t& img, uint32_t& a, uint32_t& b) {      // step < gw
     b += step;
     if (b >= gw) { b -= gw; if (++a >= gh) { a = 0; ++img; } }
   };
 
-  unsigned lbase[2], lmask[2];                                // load cursor: row bases and k-tile validity of the tile being fetched
+  // load cursor: byte offset of (row, k-tile) or kOOB -- forward: one per row (every tap of a 'valid' conv is inside)
+  constexpr int NV = MODE == 0 ? 1 : NKT;
+  unsigned voff[2][NV];
   auto setup = [&](int wt) {
     uint32_t img, a, b;
     const uint32_t m0 = (uint32_t)wt * 16u + (uint32_t)srow;
@@ -300,30 +322,24 @@ ws_fast_kernel(const Params p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (i) advance(8u, img, a, b);
-      unsigned mask = 0;
-      if (MODE == 0) mask = 0xffffffffu;
+      const unsigned byte = (img * p.a_img_stride + a * p.a_row_stride + b * p.a_col_stride + kc) * 4u;
+      const bool row_ok = m0 + 8u * i < (uint32_t)p.M;
+      if (MODE == 0) voff[i][0] = row_ok ? byte : kOOB;
       else {
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
-          const int y = (int)a + tdy[t], x = (int)b + tdx[t];
-          mask |= (unsigned)(y >= 0 && y < p.vh && x >= 0 && x < p.vw) << t;
+          const bool ok = row_ok && (unsigned)((int)a + tdy[t]) < (unsigned)p.vh && (unsigned)((int)b + tdx[t]) < (unsigned)p.vw;
+          voff[i][t] = ok ? byte : kOOB;
         }
       }
-      if (m0 + 8u * i >= (uint32_t)p.M) mask = 0;
-      lbase[i] = img * p.a_img_stride + a * p.a_row_stride + b * p.a_col_stride + kc;
-      lmask[i] = mask;
     }
   };
-  float4 rg[NKT][2];                                          // one register stage per k-tile x two rows: a whole tile ahead
-  auto fetch = [&](int stage, int ktl) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t rg[NKT][2];                                         // one register stage per k-tile x two rows: a whole tile ahead
+  auto fetch = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool ok = (lmask[i] >> ktl) & 1u;
-      const unsigned idx = ok ? lbase[i] + (unsigned)toff[ktl] : 0u;
-      float4 v = *reinterpret_cast<const float4*>(p.A + idx);
-      if (p.a_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      rg[stage][i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int i = 0; i < 2; ++i)
+      rg[kt][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i][MODE == 0 ? 0 : kt], soff[kt], 0);
   };
 
   const float* a_frag = Aw + lx * LDA + 4 * kq;
@@ -331,17 +347,28 @@ ws_fast_kernel(const Params p) {
   typedef typename Vec<NR>::type bvec_t;
   const int wstride = gridDim.x * WAVES;
   const int n = NR * lx;
-  int e_py = 0, e_px = 0, e_ci = 0;
-  if (MODE == 1) { const int cls = n / p.cin; e_ci = n - cls * p.cin; e_py = cls / p.s; e_px = cls - e_py * p.s; }
+  // data gradient: dx offset of super-pixel (img, a, b), class (py, px), channel ci is linear in (img, a, b)
+  unsigned e_const = 0;
+  const unsigned e_img = (unsigned)(p.ih * p.iw * p.ld_in), e_a = (unsigned)(p.s * p.iw * p.ld_in), e_b = (unsigned)(p.s * p.ld_in);
+  int e_py = 0, e_px = 0;
+  if (MODE == 1) {
+    const int cls = n / p.cin, ci = n - cls * p.cin;
+    e_py = cls / p.s; e_px = cls - e_py * p.s;
+    e_const = (unsigned)((e_py * p.iw + e_px) * p.ld_in + ci);
+  }
+  const bool exact = MODE == 1 && p.gh * p.s == p.ih && p.gw * p.s == p.iw;   // no super-pixel hangs over the map
+  bvec_t bias_v;
+#pragma unroll
+  for (int j = 0; j < NR; ++j) bias_v[j] = 0.f;
+  if (MODE == 0 && p.bias) bias_v = *reinterpret_cast<const bvec_t*>(p.bias + n);
 
   // Loads run ONE WHOLE TILE ahead: k-tile kt of the next tile is requested right after k-tile kt of this one went to
   // LDS, i.e. before this tile's epilogue stores.  A wave's memory operations retire in issue order, so a load issued
-  // behind those stores would also wait for their acknowledgement (with the two-k-tile distance of the generic kernel
-  // every tile stalled on that: MFMA time and memory time simply added up).
+  // behind those stores would also wait for their acknowledgement.
   int tile = blockIdx.x * WAVES + wave;
   setup(tile);
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) fetch(kt, kt);
+  for (int kt = 0; kt < NKT; ++kt) fetch(kt);
   for (; tile < p.ntiles; tile += wstride) {
     setup(tile + wstride);                                    // the load cursor: this wave's next tile
     f32x4_t acc[NR];
@@ -349,30 +376,26 @@ ws_fast_kernel(const Params p) {
     for (int j = 0; j < NR; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // epilogue addresses (and the ReLU-mask values: their latency hides under the tile's MFMAs)
+    const uint32_t m0 = (uint32_t)tile * 16u + 4u * (uint32_t)kq;
+    const bool full = (uint32_t)tile * 16u + 16u <= (uint32_t)p.M;              // uniform
     unsigned out_at[4];
     bvec_t mpre[4];
-    {
+    if (MODE == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out_at[r] = (full || m0 + r < (uint32_t)p.M) ? (m0 + r) * (unsigned)p.ldc + n : 0xffffffffu;
+    } else {
       uint32_t img, a, b;
-      const uint32_t m0 = (uint32_t)tile * 16u + 4u * (uint32_t)kq;
       locate(m0, img, a, b);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (r) advance(1u, img, a, b);
-        unsigned at = 0xffffffffu;
-        bvec_t mv;
+        unsigned at = img * e_img + a * e_a + b * e_b + e_const;
+        if (!full && m0 + r >= (uint32_t)p.M) at = 0xffffffffu;
+        if (!exact && ((int)a * p.s + e_py >= p.ih || (int)b * p.s + e_px >= p.iw)) at = 0xffffffffu;
+        out_at[r] = at;
 #pragma unroll
-        for (int j = 0; j < NR; ++j) mv[j] = 1.f;
-        if (m0 + r < (uint32_t)p.M) {
-          if (MODE == 0) at = (m0 + r) * (unsigned)p.ldc + n;
-          else {
-            const int oy = (int)a * p.s + e_py, ox = (int)b * p.s + e_px;
-            if (oy < p.ih && ox < p.iw) {
-              at = ((img * p.ih + oy) * p.iw + ox) * p.ld_in + e_ci;
-              if (p.mask) mv = *reinterpret_cast<const bvec_t*>(p.mask + at);
-            }
-          }
-        }
-        out_at[r] = at; mpre[r] = mv;
+        for (int j = 0; j < NR; ++j) mpre[r][j] = 1.f;
+        if (p.mask && at != 0xffffffffu) mpre[r] = *reinterpret_cast<const bvec_t*>(p.mask + at);
       }
     }
 
@@ -380,9 +403,9 @@ ws_fast_kernel(const Params p) {
     for (int kt = 0; kt < NKT; ++kt) {
       wave_fence();                                           // fragment reads of the previous k-tile are issued
 #pragma unroll
-      for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(Aw + (srow + 8 * i) * LDA + kc) = rg[kt][i];
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4_t*>(Aw + (srow + 8 * i) * LDA + kc) = rg[kt][i];
       wave_fence();
-      fetch(kt, kt);
+      fetch(kt);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const f32x4_t a_kc = *reinterpret_cast<const f32x4_t*>(a_frag + h * 16);
@@ -405,7 +428,7 @@ ws_fast_kernel(const Params p) {
 #pragma unroll
       for (int j = 0; j < NR; ++j) v[j] = acc[j][r];
       if (MODE == 0) {
-        if (p.bias) { const bvec_t bv = *reinterpret_cast<const bvec_t*>(p.bias + n); v += bv; }
+        v += bias_v;
         if (p.residual) { const bvec_t rv = *reinterpret_cast<const bvec_t*>(p.residual + at); v += rv; }
         if (p.out_relu) {
 #pragma unroll
@@ -413,7 +436,7 @@ ws_fast_kernel(const Params p) {
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < NR; ++j) if (!(mpre[r][j] > 0.f)) v[j] = 0.f;
+        for (int j = 0; j < NR; ++j) v[j] = mpre[r][j] > 0.f ? v[j] : 0.f;
         if (p.add) { const bvec_t av = *reinterpret_cast<const bvec_t*>(p.add + at); v += av; }
       }
       *reinterpret_cast<bvec_t*>(p.C + at) = v;
@@ -443,6 +466,7 @@ inline Plan plan_fwd(Params& p, const seedhip_conv_geom* g) {
   }
   p.vh = g->oh; p.vw = g->ow;
   p.ldc = g->ld_out;
+  p.a_bytes = (long long)g->n_img * g->ih * g->iw * g->ld_in * 4;
   pl.nr = N / 16; pl.ok = true;
   return pl;
 }
@@ -470,6 +494,7 @@ inline Plan plan_dgrad(Params& p, const seedhip_conv_geom* g) {
   }
   p.vh = g->oh; p.vw = g->ow;
   p.ih = g->ih; p.iw = g->iw; p.ld_in = g->ld_in;
+  p.a_bytes = (long long)g->n_img * g->oh * g->ow * g->ld_out * 4;
   pl.nr = N / 16; pl.ok = true;
   return pl;
 }
@@ -487,9 +512,8 @@ inline int launch(Params& p, Plan& pl, hipStream_t s) {
   pl.grid = wgs < 256 * per_cu ? wgs : 256 * per_cu;
   // the specialised kernel: MR = 1, 8 waves, static k-tile count
   static const int fast = getenv("SEEDHIP_WS_FAST") ? atoi(getenv("SEEDHIP_WS_FAST")) : 1;
-  // measured (cfg2): data gradient 0.255 -> 0.240 ms; the forward (NKT = 8, 16 MFMAs per k-tile) is 12 % SLOWER in this
-  // form (0.195 -> 0.219 ms) and stays on the generic kernel
-  if (fast && pl.mr == 1 && waves == 8 && p.gw >= 8 && p.mode == 1) {
+  if (fast && pl.mr == 1 && waves == 8 && p.gw >= 8 && !p.a_relu && p.a_bytes < (1LL << 31) - (1 << 20) &&
+      (p.mode == 1 || (long long)p.M * p.ldc < (1LL << 32) - 64)) {
 #define SEEDHIP_WSF(NR_, NKT_, MODE_)                                                                             \
     if (pl.nr == NR_ && p.nkt == NKT_ && p.mode == MODE_) {                                                       \
       if (pl.lds > 64 * 1024)                                                                                     \
@@ -497,7 +521,7 @@ inline int launch(Params& p, Plan& pl, hipStream_t s) {
       hipLaunchKernelGGL((ws_fast_kernel<NR_, NKT_, MODE_>), dim3(pl.grid), dim3(512), pl.lds, s, p);             \
       return check_launch("ws_fast_kernel");                                                                      \
     }
-    SEEDHIP_WSF(4, 4, 1) SEEDHIP_WSF(2, 4, 1) SEEDHIP_WSF(4, 8, 1) SEEDHIP_WSF(2, 8, 1)
+    SEEDHIP_WSF(2, 8, 0) SEEDHIP_WSF(4, 8, 0) SEEDHIP_WSF(4, 4, 1) SEEDHIP_WSF(2, 4, 1) SEEDHIP_WSF(4, 8, 1) SEEDHIP_WSF(2, 8, 1)
 #undef SEEDHIP_WSF
   }
 #define SEEDHIP_WS(MR_, NR_, W_)                                                                                  \
