@@ -140,12 +140,20 @@ struct GatherOCStager {
   static constexpr int kVecs = BX * BK / 4 / 256;
   static constexpr int kLdOC = LdOC<BX>::value;
   static constexpr int kLdsFloats = BK * kLdOC;
+  static constexpr int kRowStep = 256 / (BX / 4);       // k rows between a thread's consecutive vectors
   int lds_off[kVecs], krow[kVecs];
   int toff, tdy, tdx;                        // this thread's tap: offset and border shift (same x4 for all its vectors)
   bool x_ok;
   const float* p0;
   const Gather* g;
   float4 r[kVecs];
+  // VALU diet (a SIMD's VALU work does not overlap its MFMAs; this stager used to cost 6 VALU per MFMA): when the
+  // tensor fits a 2 GB buffer view the loads go through a buffer resource -- ONE 32-bit byte offset per vector, set
+  // out of range for border taps / tail rows (the hardware returns zeros: no select, no branch) -- and the rows after
+  // a thread's first are stepped through (u, v, w) instead of divided.
+  bool fast, step_ok;
+  uint32_t rows_v;                           // extent of v (d1.d / d2.d)
+  __amdgpu_buffer_rsrc_t rsrc;
 
   __device__ void init(const float* p, const Gather& gg, int /*nkt*/, int xbase, int X, int tid) {
     g = &gg; p0 = p;
@@ -161,8 +169,43 @@ struct GatherOCStager {
       krow[i] = v / (BX / 4);
       lds_off[i] = krow[i] * kLdOC + x4;
     }
+    fast = gg.extent > 0 && gg.extent < (1LL << 29) && !gg.coord_uv;
+    rows_v = gg.d2.div(gg.d1.d);
+    step_ok = (uint32_t)kRowStep <= gg.d2.d;
+    const uint64_t ab = reinterpret_cast<uint64_t>(p);
+    const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(ab >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)ab);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(sb), 0,
+                                             __builtin_amdgcn_readfirstlane((int)(fast ? gg.extent * 4 : 0)), 0x00020000);
   }
   __device__ void load(int k, int k1, bool relu) {
+    if (fast) {
+      typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+      uint32_t u, v, w;
+      { uint32_t rem; g->d1.divmod((uint32_t)(k + krow[0]), u, rem); g->d2.divmod(rem, v, w); }
+      const int s0 = (int)g->s0, c0 = (int)g->const0 + toff;
+#pragma unroll
+      for (int i = 0; i < kVecs; ++i) {
+        if (i) {
+          if (step_ok) {
+            w += kRowStep;
+            if (w >= g->d2.d) { w -= g->d2.d; if (++v >= rows_v) { v = 0; ++u; } }
+          } else {
+            uint32_t rem; g->d1.divmod((uint32_t)(k + krow[i]), u, rem); g->d2.divmod(rem, v, w);
+          }
+        }
+        const int y = (int)v * g->cy + g->oy0 + tdy, x = (int)w * g->cx + g->ox0 + tdx;
+        const bool ok = x_ok && k + krow[i] < k1 && (g->all_valid || ((unsigned)y < (unsigned)g->vh && (unsigned)x < (unsigned)g->vw));
+        const unsigned off = (unsigned)(c0 + (int)u * s0 + (int)v * g->s1 + (int)w * g->s2) * 4u;
+        const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off : 0x80000000u, 0, 0);
+        r[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
+      }
+      if (relu) {
+#pragma unroll
+        for (int i = 0; i < kVecs; ++i) { r[i].x = fmaxf(r[i].x, 0.f); r[i].y = fmaxf(r[i].y, 0.f); r[i].z = fmaxf(r[i].z, 0.f); r[i].w = fmaxf(r[i].w, 0.f); }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < kVecs; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);

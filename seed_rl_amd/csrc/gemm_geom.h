@@ -24,6 +24,7 @@ struct Gather {
   int coord_uv, cshift, ntaps;
   int tsy, tsx;
   int cy, oy0, ey, cx, ox0, ex, vh, vw, all_valid;
+  long long extent;                         // floats in the gathered tensor (0 = unknown): bounds of the buffer view
 };
 
 struct Params {
@@ -99,6 +100,7 @@ inline bool conv_fwd_setup(Params& p, const seedhip_conv_geom* g) {
   a.cy = g->stride; a.oy0 = -g->pad_t; a.ey = 1; a.cx = g->stride; a.ox0 = -g->pad_l; a.ex = 1; a.vh = g->ih; a.vw = g->iw;
   a.all_valid = g->pad_t == 0 && g->pad_l == 0 && (g->oh - 1) * g->stride + g->kh <= g->ih &&
                 (g->ow - 1) * g->stride + g->kw <= g->iw;
+  a.extent = (long long)g->n_img * g->ih * g->iw * g->ld_in;
   return true;
 }
 
