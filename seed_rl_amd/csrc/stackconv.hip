@@ -543,8 +543,10 @@ __device__ __forceinline__ void frame_store16(unsigned char* slot, const uint4& 
   reinterpret_cast<uint4*>(slot)[2 * idx + 1] = b;
 }
 
+template <int LD>                                        // row stride of dY (floats) when it is 16 or 32, else 0 = run time
 __global__ void __launch_bounds__(64 * kCW)
 stackconv_wgrad_cw_kernel(const Params p) {
+  const int ld_out = LD ? LD : p.ld_out;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = wave & 3, half = wave >> 2;
@@ -575,37 +577,44 @@ stackconv_wgrad_cw_kernel(const Params p) {
       const int nv = p.nvalid[(long long)t * p.B + b];
       if (c < nv) {
         const unsigned char* frame = smem + ((t + 3 - c) % kFrameSlots) * kFrame16;
-        const float* dy_t = p.dy + ((long long)t * p.B + b) * P * p.ld_out + co0 + i;
-        auto chunk_geom = [&](int g, bool& ok, int& aoff, int& doff) {
+        // dY of this step as 32-bit offsets from the uniform base (saddr + voffset loads: no 64-bit VALU adds)
+        const char* dy_base = reinterpret_cast<const char*>(p.dy);
+        const unsigned dy_t = ((unsigned)(((long long)t * p.B + b) * P * ld_out) + (unsigned)(co0 + i)) * 4u;   // bytes
+        auto chunk_geom = [&](int g, bool& ok, int& aoff, unsigned& doff) {
           const int ch = 4 * g + kq;
           ok = ch < kChunks;
           const int cc = ok ? ch : 0, rp = cc / 5, xc = cc - rp * 5;
           aoff = ((8 * rp + (i >> 1)) * kIW + 16 * xc + 4 * (i & 1)) * 2;
-          doff = (2 * rp * kOW + 4 * xc) * p.ld_out;
+          doff = dy_t + (unsigned)((2 * rp * kOW + 4 * xc) * ld_out) * 4u;
         };
-        float dyn[8];
-        bool ok; int aoff, doff;
-        chunk_geom(half, ok, aoff, doff);
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int bb = 0; bb < 4; ++bb) { const float tv = dy_t[doff + (a * kOW + bb) * p.ld_out]; dyn[4 * a + bb] = ok ? tv : 0.f; }
-        for (int g = half; g < kGroups32; g += 2) {
-          Frag8 bf[3];
-          {
-            float dyv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { dyv[e] = dyn[e]; if (c == 0) bsum += dyn[e]; }
-            split3_pack(dyv, bf);
-          }
-          const unsigned char* src = frame + aoff;
-          if (g + 2 < kGroups32) {                        // next group's geometry and dY: in flight under the MFMAs
-            chunk_geom(g + 2, ok, aoff, doff);
+        // dY of a group: 8 pixels (2 rows x 4) of this lane's output channel.  Only the last group has lanes without a
+        // chunk (50 chunks = 12.5 groups): the zero-select is confined to it by a uniform branch.
+        auto load_dy = [&](int g, float (&dst)[8], int& aoff) {
+          bool ok; unsigned doff;
+          chunk_geom(g, ok, aoff, doff);
+          if (g == kGroups32 - 1) {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-              for (int bb = 0; bb < 4; ++bb) { const float tv = dy_t[doff + (a * kOW + bb) * p.ld_out]; dyn[4 * a + bb] = ok ? tv : 0.f; }
+              for (int bb = 0; bb < 4; ++bb) { const float tv = *reinterpret_cast<const float*>(dy_base + (doff + (unsigned)((a * kOW + bb) * ld_out) * 4u)); dst[4 * a + bb] = ok ? tv : 0.f; }
+          } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int bb = 0; bb < 4; ++bb) dst[4 * a + bb] = *reinterpret_cast<const float*>(dy_base + (doff + (unsigned)((a * kOW + bb) * ld_out) * 4u));
           }
+        };
+        // one group: split this group's dY, request the next group's (in flight under the MFMAs), 12 MFMAs.  The two
+        // dY register sets alternate STATICALLY (the loop below is unrolled by two): no copies.
+        auto group = [&](int g, const float (&cur)[8], int aoff_cur, float (&nxt)[8], int& aoff_nxt) {
+          Frag8 bf[3];
+          if (c == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum += cur[e];
+          }
+          split3_pack(cur, bf);
+          const unsigned char* src = frame + aoff_cur;
+          if (g + 2 < kGroups32) load_dy(g + 2, nxt, aoff_nxt);
           uint2 d[2][4];
 #pragma unroll
           for (int a = 0; a < 2; ++a)
@@ -628,6 +637,13 @@ stackconv_wgrad_cw_kernel(const Params p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
               acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[q].v, bf[s3].v, acc[q], 0, 0, 0);
+        };
+        float dyA[8], dyB[8];
+        int aoffA, aoffB = 0;
+        load_dy(half, dyA, aoffA);
+        for (int g = half; g < kGroups32; g += 4) {
+          group(g, dyA, aoffA, dyB, aoffB);
+          if (g + 2 < kGroups32) group(g + 2, dyB, aoffB, dyA, aoffA);
         }
       }
       if (more) {
@@ -675,7 +691,8 @@ bool eligible(const seedhip_stack_conv_geom* g, const void* frames_ext, const vo
   const long long fsz = (long long)g->ih * g->iw;
   (void)fsz;
   return g->kh == 8 && g->kw == 8 && g->stride == 4 && g->ih == kIH && g->iw == kIW && g->oh == 20 && g->ow == 20 &&
-         g->cout % 16 == 0 && g->ld_out % 4 == 0 && (((uintptr_t)frames_ext) & 15) == 0 && (((uintptr_t)io) & 15) == 0;
+         g->cout % 16 == 0 && g->ld_out % 4 == 0 && (((uintptr_t)frames_ext) & 15) == 0 && (((uintptr_t)io) & 15) == 0 &&
+         (long long)g->T * g->B * g->oh * g->ow * g->ld_out < (1LL << 30);      // 32-bit BYTE offsets into the conv output
 }
 
 // Chooses the time chunking so that the persistent grid is evenly loaded.
@@ -832,9 +849,14 @@ extern "C" int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* ge
     static const int bf16x3 = getenv("SEEDHIP_STACK_BF16") ? atoi(getenv("SEEDHIP_STACK_BF16")) : 1;
     if (bf16x3) {
       const size_t ldsc = (size_t)stackconv::kFrameSlots * stackconv::kFrame16;
-      (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_cw_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);
-      hipLaunchKernelGGL(stackconv::stackconv_wgrad_cw_kernel, dim3(grid, 1, N / 16), dim3(64 * stackconv::kCW), ldsc, s, p);
+#define SEEDHIP_CW(LD_)                                                                                            \
+      {                                                                                                           \
+        (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_cw_kernel<LD_>,                          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);                         \
+        hipLaunchKernelGGL(stackconv::stackconv_wgrad_cw_kernel<LD_>, dim3(grid, 1, N / 16), dim3(64 * stackconv::kCW), ldsc, s, p); \
+      }
+      if (geom->ld_out == 16) SEEDHIP_CW(16) else if (geom->ld_out == 32) SEEDHIP_CW(32) else SEEDHIP_CW(0)
+#undef SEEDHIP_CW
     }
     else
       hipLaunchKernelGGL(stackconv::stackconv_wgrad_kernel, dim3(grid, 1, N / 16), dim3(stackconv::kThreads), lds, s, p);
