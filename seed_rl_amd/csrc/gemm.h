@@ -36,6 +36,20 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // group) are conflict free at any stride.
 template <int BX> struct LdOC { static constexpr int value = (BX == 64 || BX == 32) ? BX + 8 : BX; };
 
+// (uniform pointer -> buffer resource over `bytes`; readfirstlane keeps the descriptor in SGPRs)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_view(const float* p, long long bytes) {
+  const uint64_t ab = reinterpret_cast<uint64_t>(p);
+  const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(ab >> 32)) << 32) |
+                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)ab);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(sb), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+__device__ __forceinline__ float4 view_load(const __amdgpu_buffer_rsrc_t& r, unsigned byte_off) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  return make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
+}
+constexpr unsigned kViewOOB = 0x80000000u;                 // past num_records of any view (< 2 GB): the load returns zeros
+
 template <int BX, bool KC>
 struct Stager {
   static constexpr int kVecs = BX * BK / 4 / 256;
@@ -46,8 +60,19 @@ struct Stager {
   int krow[kVecs];            // k offset of the vector inside a tile
   long long kstride;          // floats per unit k
   float4 r[kVecs];
+  // VALU diet (a SIMD's VALU work does not overlap its MFMAs): when the operand fits a 2 GB buffer view, a vector
+  // costs one 32-bit multiply-add for its byte offset and -- only in a ragged last k-tile -- one select that pushes
+  // it out of range (the hardware returns zeros); no 64-bit pointer arithmetic, no branch, no select on the data.
+  bool fast;
+  unsigned boff[kVecs];       // byte offset at k = 0, or kViewOOB: out of range in x
+  unsigned kstep;             // bytes per unit k
+  __amdgpu_buffer_rsrc_t rsrc;
 
-  __device__ void init(const float* p, long long ld, int x0, int X, int tid) {
+  // extent_k: the operand's extent along k (rows of an outer-contiguous operand); X its extent along x
+  __device__ void init(const float* p, long long ld, int x0, int X, int tid, int extent_k = 0, bool allow = false) {
+    const long long bytes = (KC ? (long long)X * ld : (long long)extent_k * ld) * 4;
+    fast = allow && bytes > 0 && bytes < (1LL << 31) - 64;
+    rsrc = make_view(p, fast ? bytes : 0);
 #pragma unroll
     for (int i = 0; i < kVecs; ++i) {
       const int v = tid + i * 256;
@@ -55,15 +80,33 @@ struct Stager {
         const int row = v >> 3, kc = (v & 7) * 4;
         krow[i] = kc; lds_off[i] = row * LD_KC + kc;
         base[i] = (x0 + row < X) ? p + (long long)(x0 + row) * ld + kc : nullptr;
+        boff[i] = (x0 + row < X) ? (unsigned)(((long long)(x0 + row) * ld + kc) * 4) : kViewOOB;
       } else {
         const int kr = v / (BX / 4), x4 = (v % (BX / 4)) * 4;
         krow[i] = kr; lds_off[i] = kr * kLdOC + x4;
         base[i] = (x0 + x4 < X) ? p + (long long)kr * ld + x0 + x4 : nullptr;     // X % 4 == 0: all in or all out
+        boff[i] = (x0 + x4 < X) ? (unsigned)(((long long)kr * ld + x0 + x4) * 4) : kViewOOB;
       }
     }
     kstride = KC ? 1 : ld;
+    kstep = (unsigned)(KC ? 4 : ld * 4);
   }
   __device__ void load(int k, int k1, bool relu) {
+    if (fast) {
+      const unsigned kb = (unsigned)k * kstep;
+      if (k + BK <= k1) {                       // uniform: a full k-tile needs no per-vector k check
+#pragma unroll
+        for (int i = 0; i < kVecs; ++i) r[i] = view_load(rsrc, boff[i] == kViewOOB ? kViewOOB : boff[i] + kb);
+      } else {
+#pragma unroll
+        for (int i = 0; i < kVecs; ++i) r[i] = view_load(rsrc, (boff[i] == kViewOOB || k + krow[i] >= k1) ? kViewOOB : boff[i] + kb);
+      }
+      if (relu) {
+#pragma unroll
+        for (int i = 0; i < kVecs; ++i) { r[i].x = fmaxf(r[i].x, 0.f); r[i].y = fmaxf(r[i].y, 0.f); r[i].z = fmaxf(r[i].z, 0.f); r[i].w = fmaxf(r[i].w, 0.f); }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < kVecs; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -172,11 +215,7 @@ struct GatherOCStager {
     fast = gg.extent > 0 && gg.extent < (1LL << 29) && !gg.coord_uv;
     rows_v = gg.d2.div(gg.d1.d);
     step_ok = (uint32_t)kRowStep <= gg.d2.d;
-    const uint64_t ab = reinterpret_cast<uint64_t>(p);
-    const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(ab >> 32)) << 32) |
-                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)ab);
-    rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(sb), 0,
-                                             __builtin_amdgcn_readfirstlane((int)(fast ? gg.extent * 4 : 0)), 0x00020000);
+    rsrc = make_view(p, fast ? gg.extent * 4 : 0);
   }
   __device__ void load(int k, int k1, bool relu) {
     if (fast) {
@@ -258,8 +297,11 @@ gemm_kernel(const Params p) {
   const int nkt = (k1 - k0 + BK - 1) / BK;
 
   SA sa; SB sb;
-  if constexpr (AG) sa.init(p.A, p.ga, nkt, m0, p.M, tid); else sa.init(p.A, p.lda, m0, p.M, tid);
-  if constexpr (BG) sb.init(p.B, p.gb, nkt, n0, p.N, tid); else sb.init(p.B, p.ldb, n0, p.N, tid);
+  // buffer-view staging (see Stager) for the Dense GEMMs, where it measured faster (cfg2 FC trio: 0.482 -> 0.466 ms);
+  // next to a gathered A (conv forward, cfg5) the weights as a buffer-view B measured 16-18 % SLOWER than pointer loads
+  constexpr bool kView = !AG && !BG;
+  if constexpr (AG) sa.init(p.A, p.ga, nkt, m0, p.M, tid); else sa.init(p.A, p.lda, m0, p.M, tid, p.K, kView);
+  if constexpr (BG) sb.init(p.B, p.gb, nkt, n0, p.N, tid); else sb.init(p.B, p.ldb, n0, p.N, tid, p.K, kView);
   const bool do_colsum = !BKC && p.partial_colsum && blockIdx.x == 0;
   float4 csum[SB::kVecs];
 #pragma unroll
