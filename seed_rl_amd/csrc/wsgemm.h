@@ -54,6 +54,7 @@ struct Params {
   int ih, iw, ld_in; const float* mask; const float* add;
   int ntiles;
   long long a_bytes;                          // extent of A in bytes (buffer-resource range of the specialised kernel)
+  int pow2, l_cout, l_cin, l_s, l_jw;         // data gradient: cout, cin, s, kw / s all powers of two -> W' index math by shifts
 };
 
 // LDS traffic of one wave is ordered; this only stops the compiler from moving LDS accesses across the point.
@@ -258,7 +259,8 @@ template <int NR, int NKT, int MODE>
 __global__ void __launch_bounds__(512)
 ws_fast_kernel(const Params p) {
   constexpr int WAVES = 8, N = 16 * NR, LDB = (NR == 2) ? N + 8 : N, kThreads = 64 * WAVES;
-  constexpr unsigned kOOB = 0x80000000u;                      // beyond num_records of any buffer we bind (< 2 GB)
+  constexpr unsigned kOOB = 0xC0800000u;                      // beyond num_records of any buffer we bind (< 2 GB); the bit
+                                                              // pattern of -4.0f: an inline constant, free as an operand
   static_assert(NKT <= kMaxTiles, "k-tile tables");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Bs = smem;                           // [K][LDB]
@@ -269,6 +271,15 @@ ws_fast_kernel(const Params p) {
     for (int idx = tid; idx < p.K * N / 4; idx += kThreads) {
       const int e = idx * 4, k = e / N, n = e - k * N;
       *reinterpret_cast<float4*>(Bs + k * LDB + n) = *reinterpret_cast<const float4*>(p.W + e);
+    }
+  } else if (p.pow2) {
+    // run-time integer divisions cost ~20 VALU each and this loop runs in EVERY workgroup: with power-of-two channel
+    // counts / stride the re-indexing is shifts and masks (measured: a third of the kernel's VALU work went here)
+    for (int idx = tid; idx < p.K * N; idx += kThreads) {
+      const int k = idx / N, n = idx - k * N;                 // N is a compile-time power of two
+      const int co = k & (p.cout - 1), tap = k >> p.l_cout, jy = tap >> p.l_jw, jx = tap & ((1 << p.l_jw) - 1);
+      const int ci = n & (p.cin - 1), cls = n >> p.l_cin, py = cls >> p.l_s, px = cls & (p.s - 1);
+      Bs[k * LDB + n] = p.W[(((((py + (jy << p.l_s)) * p.kw + px + (jx << p.l_s)) << p.l_cin) + ci) << p.l_cout) + co];
     }
   } else {
     const int jw = p.kw / p.s;
@@ -322,7 +333,7 @@ ws_fast_kernel(const Params p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (i) advance(8u, img, a, b);
-      const unsigned byte = (img * p.a_img_stride + a * p.a_row_stride + b * p.a_col_stride + kc) * 4u;
+      const unsigned byte = (img * p.a_img_stride + __umul24(a, p.a_row_stride) + __umul24(b, p.a_col_stride) + kc) * 4u;
       const bool row_ok = m0 + 8u * i < (uint32_t)p.M;
       if (MODE == 0) voff[i][0] = row_ok ? byte : kOOB;
       else {
@@ -371,9 +382,7 @@ ws_fast_kernel(const Params p) {
   for (int kt = 0; kt < NKT; ++kt) fetch(kt);
   for (; tile < p.ntiles; tile += wstride) {
     setup(tile + wstride);                                    // the load cursor: this wave's next tile
-    f32x4_t acc[NR];
-#pragma unroll
-    for (int j = 0; j < NR; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[NR];                                          // first written by the first MFMA of the tile (C = 0)
 
     // epilogue addresses (and the ReLU-mask values: their latency hides under the tile's MFMAs)
     const uint32_t m0 = (uint32_t)tile * 16u + 4u * (uint32_t)kq;
@@ -389,7 +398,7 @@ ws_fast_kernel(const Params p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (r) advance(1u, img, a, b);
-        unsigned at = img * e_img + a * e_a + b * e_b + e_const;
+        unsigned at = img * e_img + __umul24(a, e_a) + __umul24(b, e_b) + e_const;
         if (!full && m0 + r >= (uint32_t)p.M) at = 0xffffffffu;
         if (!exact && ((int)a * p.s + e_py >= p.ih || (int)b * p.s + e_px >= p.iw)) at = 0xffffffffu;
         out_at[r] = at;
@@ -416,7 +425,8 @@ ws_fast_kernel(const Params p) {
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
           for (int j = 0; j < NR; ++j)
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_kc[kk], b_oc[kk][j], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_kc[kk], b_oc[kk][j],
+                                                          (kt == 0 && h == 0 && kk == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[j], 0, 0, 0);
       }
     }
 
@@ -495,6 +505,11 @@ inline Plan plan_dgrad(Params& p, const seedhip_conv_geom* g) {
   p.vh = g->oh; p.vw = g->ow;
   p.ih = g->ih; p.iw = g->iw; p.ld_in = g->ld_in;
   p.a_bytes = (long long)g->n_img * g->oh * g->ow * g->ld_out * 4;
+  {
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    p.l_cout = lg(g->cout); p.l_cin = lg(g->cin); p.l_s = lg(s); p.l_jw = lg(jw);
+    p.pow2 = p.l_cout >= 0 && p.l_cin >= 0 && p.l_s >= 0 && p.l_jw >= 0;
+  }
   pl.nr = N / 16; pl.ok = true;
   return pl;
 }
