@@ -684,6 +684,167 @@ stackconv_wgrad_cw_kernel(const Params p) {
   }
 }
 
+// Channel-PAIR variant of the kernel above: a wave owns two stack channels and a quarter of the pixel groups, so the
+// exact three-way bf16 split of a group's dY (5.5 VALU per element -- and VALU work does not overlap MFMAs) is done
+// once for 24 MFMAs instead of once for 12: wave = (cp = w & 1, quarter = w >> 1), 32 accumulator VGPRs.
+template <int LD>                                        // row stride of dY (floats) when it is 16 or 32, else 0 = run time
+__global__ void __launch_bounds__(64 * kCW) __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: two workgroups per CU
+stackconv_wgrad_cp_kernel(const Params p) {
+  const int ld_out = LD ? LD : p.ld_out;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cp = wave & 1, quarter = wave >> 1;          // stack channels 2cp, 2cp + 1; pixel groups quarter, quarter + 4, ...
+  const int kq = lane >> 4, i = lane & 15;
+  const int co0 = blockIdx.z * 16;
+  constexpr int P = 400, kVec = kIH * kIW / 16;           // 441 uint4 per uint8 frame
+
+  f32x4_t acc[2][4];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[ch][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+    const int b = item % p.B, chunk = item / p.B;
+    const int t0 = chunk * p.spc;
+    const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
+    __syncthreads();                                      // previous item's last step is done with the ring
+    for (int e = 0; e < 4; ++e) {                         // ext rows t0 .. t0+3 -> slots
+      const uint4* src = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t0 + e) * p.B + b) * p.fsz);
+      for (int idx = tid; idx < kVec; idx += 64 * kCW) frame_store16(smem + ((t0 + e) % kFrameSlots) * kFrame16, src[idx], idx);
+    }
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+      const bool more = t + 1 < t1;
+      uint4 pf = make_uint4(0, 0, 0, 0);                  // 441 vectors over 512 threads: one each
+      if (more && tid < kVec)
+        pf = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t + 4) * p.B + b) * p.fsz)[tid];
+      const int nv = p.nvalid[(long long)t * p.B + b];
+      if (2 * cp < nv) {
+        const bool two = 2 * cp + 1 < nv;                   // the pair's second channel is inside the episode too
+        const unsigned char* frame0 = smem + ((t + 3 - 2 * cp) % kFrameSlots) * kFrame16;
+        const unsigned char* frame1 = smem + ((t + 2 - 2 * cp) % kFrameSlots) * kFrame16;
+        // dY of this step as 32-bit offsets from the uniform base (saddr + voffset loads: no 64-bit VALU adds)
+        const char* dy_base = reinterpret_cast<const char*>(p.dy);
+        const unsigned dy_t = ((unsigned)(((long long)t * p.B + b) * P * ld_out) + (unsigned)(co0 + i)) * 4u;   // bytes
+        auto chunk_geom = [&](int g, bool& ok, int& aoff, unsigned& doff) {
+          const int ch = 4 * g + kq;
+          ok = ch < kChunks;
+          const int cc = ok ? ch : 0, rp = cc / 5, xc = cc - rp * 5;
+          aoff = ((8 * rp + (i >> 1)) * kIW + 16 * xc + 4 * (i & 1)) * 2;
+          doff = dy_t + (unsigned)((2 * rp * kOW + 4 * xc) * ld_out) * 4u;
+        };
+        // dY of a group: 8 pixels (2 rows x 4) of this lane's output channel.  Only the last group has lanes without a
+        // chunk (50 chunks = 12.5 groups): the zero-select is confined to it by a uniform branch.
+        auto load_dy = [&](int g, float (&dst)[8], int& aoff) {
+          bool ok; unsigned doff;
+          chunk_geom(g, ok, aoff, doff);
+          if (g == kGroups32 - 1) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int bb = 0; bb < 4; ++bb) { const float tv = *reinterpret_cast<const float*>(dy_base + (doff + (unsigned)((a * kOW + bb) * ld_out) * 4u)); dst[4 * a + bb] = ok ? tv : 0.f; }
+          } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int bb = 0; bb < 4; ++bb) dst[4 * a + bb] = *reinterpret_cast<const float*>(dy_base + (doff + (unsigned)((a * kOW + bb) * ld_out) * 4u));
+          }
+        };
+        // one group: split this group's dY, request the next group's (in flight under the MFMAs), 12 MFMAs.  The two
+        // dY register sets alternate STATICALLY (the loop below is unrolled by two): no copies.
+        auto group = [&](int g, const float (&cur)[8], int aoff_cur, float (&nxt)[8], int& aoff_nxt) {
+          Frag8 bf[3];
+          if (cp == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum += cur[e];
+          }
+          split3_pack(cur, bf);                           // ONCE for both channels of the pair
+          const int ao = aoff_cur;
+          if (g + 4 < kGroups32) load_dy(g + 4, nxt, aoff_nxt);
+#pragma unroll
+          for (int ch = 0; ch < 2; ++ch) {
+            if (ch == 1 && !two) break;
+            const unsigned char* src = (ch ? frame1 : frame0) + ao;
+            uint2 d[2][4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int bb = 0; bb < 4; ++bb)
+                d[a][bb] = *reinterpret_cast<const uint2*>(src + (a * 4 * kIW + 4 * bb) * 2);
+            Frag8 xa[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t sel = (q & 1) ? 0x07060302u : 0x05040100u;
+              if (q < 2)
+                xa[q].u = make_uint4(__builtin_amdgcn_perm(d[0][1].x, d[0][0].x, sel), __builtin_amdgcn_perm(d[0][3].x, d[0][2].x, sel),
+                                     __builtin_amdgcn_perm(d[1][1].x, d[1][0].x, sel), __builtin_amdgcn_perm(d[1][3].x, d[1][2].x, sel));
+              else
+                xa[q].u = make_uint4(__builtin_amdgcn_perm(d[0][1].y, d[0][0].y, sel), __builtin_amdgcn_perm(d[0][3].y, d[0][2].y, sel),
+                                     __builtin_amdgcn_perm(d[1][1].y, d[1][0].y, sel), __builtin_amdgcn_perm(d[1][3].y, d[1][2].y, sel));
+            }
+#pragma unroll
+            for (int s3 = 2; s3 >= 0; --s3)                 // lo, mid, hi; the four accumulators alternate
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                acc[ch][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[q].v, bf[s3].v, acc[ch][q], 0, 0, 0);
+          }
+        };
+        float dyA[8], dyB[8];
+        int aoffA, aoffB = 0;
+        load_dy(quarter, dyA, aoffA);
+        for (int g = quarter; g < kGroups32; g += 8) {
+          group(g, dyA, aoffA, dyB, aoffB);
+          if (g + 4 < kGroups32) group(g + 4, dyB, aoffB, dyA, aoffA);
+        }
+      }
+      if (more) {
+        if (tid < kVec) frame_store16(smem + ((t + 4) % kFrameSlots) * kFrame16, pf, tid);   // a slot no wave reads in step t
+        __syncthreads();                                  // frame t+4 visible; every wave is done with step t
+      }
+    }
+  }
+
+  // ---- the four pixel quarters of a channel pair -> one tile per channel (quarters 1..3 through LDS, fixed order),
+  // written straight into the partial slice ----
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);            // [cp][quarter - 1][ch][q][lane][4]: 48 KB of the 70 KB ring
+  if (quarter > 0) {
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4_t*>(red + ((((cp * 3 + quarter - 1) * 2 + ch) * 4 + q) * 64 + lane) * 4) = acc[ch][q];
+  }
+  __syncthreads();
+  if (quarter == 0) {
+    float* pw = p.partial_w + (long long)blockIdx.x * 256 * p.cout;
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4_t o = acc[ch][q];
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) o += *reinterpret_cast<const f32x4_t*>(red + ((((cp * 3 + qq) * 2 + ch) * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * kq + r;                     // k-row within the m-tile
+          const int ky = row >> 1, kx = 4 * (row & 1) + q;
+          pw[((ky * 8 + kx) * 4 + 2 * cp + ch) * p.cout + co0 + i] = o[r] / 255.0f;
+        }
+      }
+  }
+  if (p.partial_b) {                                      // sum over the pixels of dY: the four cp = 0 waves hold it
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    float* redb = red + 2 * 3 * 2 * 4 * 64 * 4;
+    if (cp == 0 && lane < 16) redb[quarter * 16 + lane] = bsum;
+    __syncthreads();
+    if (tid < 16) p.partial_b[(long long)blockIdx.x * p.cout + co0 + tid] = (redb[tid] + redb[16 + tid]) + (redb[32 + tid] + redb[48 + tid]);
+  }
+}
+
 // ------------------------------------------------------------------------------------ //
 // Host side: eligibility, work decomposition, launch.
 // ------------------------------------------------------------------------------------ //
@@ -855,8 +1016,17 @@ extern "C" int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* ge
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);                         \
         hipLaunchKernelGGL(stackconv::stackconv_wgrad_cw_kernel<LD_>, dim3(grid, 1, N / 16), dim3(64 * stackconv::kCW), ldsc, s, p); \
       }
-      if (geom->ld_out == 16) SEEDHIP_CW(16) else if (geom->ld_out == 32) SEEDHIP_CW(32) else SEEDHIP_CW(0)
+#define SEEDHIP_CP(LD_)                                                                                            \
+      {                                                                                                           \
+        (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_cp_kernel<LD_>,                          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);                         \
+        hipLaunchKernelGGL(stackconv::stackconv_wgrad_cp_kernel<LD_>, dim3(grid, 1, N / 16), dim3(64 * stackconv::kCW), ldsc, s, p); \
+      }
+      static const int pair = getenv("SEEDHIP_STACK_PAIR") ? atoi(getenv("SEEDHIP_STACK_PAIR")) : 1;
+      if (pair) { if (geom->ld_out == 16) SEEDHIP_CP(16) else if (geom->ld_out == 32) SEEDHIP_CP(32) else SEEDHIP_CP(0) }
+      else if (geom->ld_out == 16) SEEDHIP_CW(16) else if (geom->ld_out == 32) SEEDHIP_CW(32) else SEEDHIP_CW(0)
 #undef SEEDHIP_CW
+#undef SEEDHIP_CP
     }
     else
       hipLaunchKernelGGL(stackconv::stackconv_wgrad_kernel, dim3(grid, 1, N / 16), dim3(stackconv::kThreads), lds, s, p);
