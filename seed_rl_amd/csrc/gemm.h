@@ -221,22 +221,17 @@ struct GatherOCStager {
     if (fast) {
       typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
       uint32_t u, v, w;
-      { uint32_t rem; g->d1.divmod((uint32_t)(k + krow[0]), u, rem); g->d2.divmod(rem, v, w); }
-      const int s0 = (int)g->s0, c0 = (int)g->const0 + toff;
+      gather_decode(*g, (uint32_t)(k + krow[0]), u, v, w);
 #pragma unroll
       for (int i = 0; i < kVecs; ++i) {
         if (i) {
-          if (step_ok) {
-            w += kRowStep;
-            if (w >= g->d2.d) { w -= g->d2.d; if (++v >= rows_v) { v = 0; ++u; } }
-          } else {
-            uint32_t rem; g->d1.divmod((uint32_t)(k + krow[i]), u, rem); g->d2.divmod(rem, v, w);
-          }
+          if (step_ok) gather_step(*g, rows_v, kRowStep, u, v, w);
+          else gather_decode(*g, (uint32_t)(k + krow[i]), u, v, w);
         }
-        const int y = (int)v * g->cy + g->oy0 + tdy, x = (int)w * g->cx + g->ox0 + tdx;
-        const bool ok = x_ok && k + krow[i] < k1 && (g->all_valid || ((unsigned)y < (unsigned)g->vh && (unsigned)x < (unsigned)g->vw));
-        const unsigned off = (unsigned)(c0 + (int)u * s0 + (int)v * g->s1 + (int)w * g->s2) * 4u;
-        const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off : 0x80000000u, 0, 0);
+        unsigned off;
+        const bool inside = gather_elem32(*g, u, v, w, toff, tdy, tdx, off);
+        const bool ok = x_ok && k + krow[i] < k1 && inside;
+        const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off : kViewOOB, 0, 0);
         r[i] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
       }
       if (relu) {

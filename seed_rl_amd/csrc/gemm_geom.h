@@ -63,6 +63,24 @@ SH_HD void gather_tap(const Gather& g, int k, int& toff, int& dy, int& dx, bool&
   dy = (int)ty * g.ey; dx = (int)tx * g.ex;
   tap_ok = tap < g.ntaps;
 }
+// The same row arithmetic in the form the VALU-lean stagers use (gemm.h GatherOCStager): one division pair per k-tile
+// (gather_decode), the following rows STEPPED (gather_step, step <= extent of w), element offset as 32-bit bytes
+// (gather_elem32; valid when the tensor is < 2 GB and !coord_uv).  tests/host/emul.cpp walks the weight gradient's
+// reduction index with these and checks them against gather_row / gather_inside.
+SH_HD void gather_decode(const Gather& g, uint32_t x, uint32_t& u, uint32_t& v, uint32_t& w) {
+  uint32_t rem;
+  g.d1.divmod(x, u, rem);
+  g.d2.divmod(rem, v, w);
+}
+SH_HD void gather_step(const Gather& g, uint32_t rows_v, uint32_t step, uint32_t& u, uint32_t& v, uint32_t& w) {
+  w += step;
+  if (w >= g.d2.d) { w -= g.d2.d; if (++v >= rows_v) { v = 0; ++u; } }
+}
+SH_HD bool gather_elem32(const Gather& g, uint32_t u, uint32_t v, uint32_t w, int toff, int tdy, int tdx, unsigned& byte_off) {
+  const int y = (int)v * g.cy + g.oy0 + tdy, x = (int)w * g.cx + g.ox0 + tdx;
+  byte_off = (unsigned)((int)g.const0 + toff + (int)u * (int)g.s0 + (int)v * g.s1 + (int)w * g.s2) * 4u;
+  return g.all_valid || ((unsigned)y < (unsigned)g.vh && (unsigned)x < (unsigned)g.vw);
+}
 SH_HD bool gather_inside(const Gather& g, int y, int x) {
   return g.all_valid || (y >= 0 && y < g.vh && x >= 0 && x < g.vw);
 }

@@ -160,6 +160,33 @@ int emul_gather_wgrad(const geom_c* g, const float* in, int in_relu, const float
       for (int pix = 0; pix < p.K; ++pix) acc += (double)gathered(in, p.ga, pix, x, in_relu) * dy[(long long)pix * p.ldb + n];
       dw[(long long)x * p.N + n] = (float)acc;
     }
+  // the stepped 32-bit form of the same index math (what the GPU stager executes): every pixel reached by stepping
+  // from a decoded start must give the element gather_row / gather_tap / gather_inside give
+  const gemm::Gather& ga = p.ga;
+  if (!ga.coord_uv && ga.extent > 0 && ga.extent < (1LL << 29)) {
+    const uint32_t rows_v = ga.d2.div(ga.d1.d);
+    for (uint32_t step : {1u, 4u, 8u}) {
+      if (step > ga.d2.d) continue;
+      for (uint32_t start = 0; start < step && (int)start < p.K; ++start) {
+        uint32_t u, v, w;
+        gemm::gather_decode(ga, start, u, v, w);
+        for (uint32_t pix = start; (int)pix < p.K; pix += step) {
+          if (pix != start) gemm::gather_step(ga, rows_v, step, u, v, w);
+          for (int x = 0; x < p.M; x += 4) {
+            int toff, tdy, tdx; bool tap_ok;
+            gemm::gather_tap(ga, x, toff, tdy, tdx, tap_ok);
+            unsigned byte_off;
+            const bool inside = gemm::gather_elem32(ga, u, v, w, toff, tdy, tdx, byte_off) && tap_ok;
+            long long off; int y0, x0;
+            gemm::gather_row(ga, (int)pix, off, y0, x0);
+            const bool ref_inside = tap_ok && gemm::gather_inside(ga, y0 + tdy, x0 + tdx);
+            if (inside != ref_inside) return 0;
+            if (inside && (long long)byte_off != (off + toff) * 4) return 0;
+          }
+        }
+      }
+    }
+  }
   for (int n = 0; n < p.N; ++n) {
     double sacc = 0.0;
     for (int pix = 0; pix < p.K; ++pix) sacc += dy[(long long)pix * p.ldb + n];
