@@ -54,6 +54,7 @@ struct Params {
   int ih, iw, ld_in; const float* mask; const float* add;
   int ntiles;
   long long a_bytes;                          // extent of A in bytes (buffer-resource range of the specialised kernel)
+  long long c_bytes;                          // extent of C (and of mask / add / residual, which are indexed like C) in bytes
   int pow2, l_cout, l_cin, l_s, l_jw;         // data gradient: cout, cin, s, kw / s all powers of two -> W' index math by shifts
 };
 
@@ -311,6 +312,15 @@ ws_fast_kernel(const Params p) {
                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)abase);   // (the builtin returns int)
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<void*>(sbase), 0, __builtin_amdgcn_readfirstlane((int)p.a_bytes - minoff * 4), 0x00020000);
+  // the epilogue's tensors (indexed alike) as buffer views too: 32-bit byte offsets, no 64-bit address arithmetic
+  auto view = [&](const void* q) {
+    const uint64_t qb = reinterpret_cast<uint64_t>(q);
+    const uint64_t sq = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(qb >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)qb);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(sq), 0, __builtin_amdgcn_readfirstlane((int)p.c_bytes), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t c_rsrc = view(p.C), m_rsrc = view(MODE == 1 ? (const void*)p.mask : (const void*)p.residual),
+                               add_rsrc = view(p.add);
   const uint32_t gw = (uint32_t)p.gw, gh = (uint32_t)p.gh;
 
   auto locate = [&](uint32_t m, uint32_t& img, uint32_t& a, uint32_t& b) {
@@ -356,6 +366,15 @@ ws_fast_kernel(const Params p) {
   const float* a_frag = Aw + lx * LDA + 4 * kq;
   const float* b_frag = Bs + (4 * kq) * LDB + NR * lx;
   typedef typename Vec<NR>::type bvec_t;
+  typedef unsigned uvec_t __attribute__((ext_vector_type(NR)));
+  auto ld_vec = [&](const __amdgpu_buffer_rsrc_t& r, unsigned byte_off) -> bvec_t {
+    if constexpr (NR == 4) return __builtin_bit_cast(bvec_t, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+    else return __builtin_bit_cast(bvec_t, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
+  };
+  auto st_vec = [&](const bvec_t& v, unsigned byte_off) {
+    if constexpr (NR == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec_t, v), c_rsrc, byte_off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec_t, v), c_rsrc, byte_off, 0, 0);
+  };
   const int wstride = gridDim.x * WAVES;
   const int n = NR * lx;
   // data gradient: dx offset of super-pixel (img, a, b), class (py, px), channel ci is linear in (img, a, b)
@@ -402,9 +421,7 @@ ws_fast_kernel(const Params p) {
         if (!full && m0 + r >= (uint32_t)p.M) at = 0xffffffffu;
         if (!exact && ((int)a * p.s + e_py >= p.ih || (int)b * p.s + e_px >= p.iw)) at = 0xffffffffu;
         out_at[r] = at;
-#pragma unroll
-        for (int j = 0; j < NR; ++j) mpre[r][j] = 1.f;
-        if (p.mask && at != 0xffffffffu) mpre[r] = *reinterpret_cast<const bvec_t*>(p.mask + at);
+        if (p.mask) mpre[r] = ld_vec(m_rsrc, at == 0xffffffffu ? kOOB : at * 4u);    // (an invalid row is never stored)
       }
     }
 
@@ -439,17 +456,19 @@ ws_fast_kernel(const Params p) {
       for (int j = 0; j < NR; ++j) v[j] = acc[j][r];
       if (MODE == 0) {
         v += bias_v;
-        if (p.residual) { const bvec_t rv = *reinterpret_cast<const bvec_t*>(p.residual + at); v += rv; }
+        if (p.residual) v += ld_vec(m_rsrc, at * 4u);
         if (p.out_relu) {
 #pragma unroll
           for (int j = 0; j < NR; ++j) v[j] = fmaxf(v[j], 0.f);
         }
       } else {
+        if (p.mask) {
 #pragma unroll
-        for (int j = 0; j < NR; ++j) v[j] = mpre[r][j] > 0.f ? v[j] : 0.f;
-        if (p.add) { const bvec_t av = *reinterpret_cast<const bvec_t*>(p.add + at); v += av; }
+          for (int j = 0; j < NR; ++j) v[j] = mpre[r][j] > 0.f ? v[j] : 0.f;
+        }
+        if (p.add) v += ld_vec(add_rsrc, at * 4u);
       }
-      *reinterpret_cast<bvec_t*>(p.C + at) = v;
+      st_vec(v, at * 4u);
     }
   }
 }
@@ -477,6 +496,7 @@ inline Plan plan_fwd(Params& p, const seedhip_conv_geom* g) {
   p.vh = g->oh; p.vw = g->ow;
   p.ldc = g->ld_out;
   p.a_bytes = (long long)g->n_img * g->ih * g->iw * g->ld_in * 4;
+  p.c_bytes = (long long)g->n_img * g->oh * g->ow * g->ld_out * 4;
   pl.nr = N / 16; pl.ok = true;
   return pl;
 }
@@ -505,6 +525,7 @@ inline Plan plan_dgrad(Params& p, const seedhip_conv_geom* g) {
   p.vh = g->oh; p.vw = g->ow;
   p.ih = g->ih; p.iw = g->iw; p.ld_in = g->ld_in;
   p.a_bytes = (long long)g->n_img * g->oh * g->ow * g->ld_out * 4;
+  p.c_bytes = (long long)g->n_img * g->ih * g->iw * g->ld_in * 4;
   {
     auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
     p.l_cout = lg(g->cout); p.l_cin = lg(g->cin); p.l_s = lg(s); p.l_jw = lg(jw);
@@ -527,7 +548,7 @@ inline int launch(Params& p, Plan& pl, hipStream_t s) {
   pl.grid = wgs < 256 * per_cu ? wgs : 256 * per_cu;
   // the specialised kernel: MR = 1, 8 waves, static k-tile count
   static const int fast = getenv("SEEDHIP_WS_FAST") ? atoi(getenv("SEEDHIP_WS_FAST")) : 1;
-  if (fast && pl.mr == 1 && waves == 8 && p.gw >= 8 && !p.a_relu && p.a_bytes < (1LL << 31) - (1 << 20) &&
+  if (fast && pl.mr == 1 && waves == 8 && p.gw >= 8 && !p.a_relu && p.a_bytes < (1LL << 31) - (1 << 20) && p.c_bytes < (1LL << 31) &&
       (p.mode == 1 || (long long)p.M * p.ldc < (1LL << 32) - 64)) {
 #define SEEDHIP_WSF(NR_, NKT_, MODE_)                                                                             \
     if (pl.nr == NR_ && p.nkt == NKT_ && p.mode == MODE_) {                                                       \
