@@ -23,6 +23,7 @@
 #pragma once
 #include "common.h"
 #include "igemm.h"
+#include "wsgemm_geom.h"
 #include "../../include/seedhip.h"
 #include <cstdlib>
 
@@ -33,30 +34,6 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <int R> struct Vec;
 template <> struct Vec<4> { typedef f32x4_t type; };
 template <> struct Vec<2> { typedef float type __attribute__((ext_vector_type(2))); };
-
-constexpr int BK = 32, LDA = BK + 8, kMaxTiles = 16;
-
-struct Params {
-  int mode;                                   // 0 forward, 1 data gradient
-  const float* A; int a_relu;                 // forward: layer input; data gradient: dY
-  const float* W;                             // Keras kernel [kh, kw, cin, cout]
-  int kh, kw, cin, cout, s;
-  int M, N, K, nkt;                           // GEMM extents; nkt = K / 32
-  int gh, gw;                                 // grid of m per image (output pixels | super-pixels)
-  FastDiv d_g, d_gw;                          // m -> (img, rem) -> (a, b)
-  unsigned a_img_stride, a_row_stride, a_col_stride;   // floats: row base = img*.. + a*.. + b*..
-  int tile_off[kMaxTiles];                    // floats added to the row base for k-tile t (may be negative)
-  int tile_dy[kMaxTiles], tile_dx[kMaxTiles]; // k-tile t of row (a, b) is valid iff 0 <= a+dy < vh && 0 <= b+dx < vw
-  int vh, vw;
-  // forward epilogue: out[m*ldc + n] = act(acc + bias[n])
-  float* C; int ldc; const float* bias; int out_relu; const float* residual;
-  // data-gradient epilogue: dx[img, s*a+py, s*b+px, ci] = mask(acc) + add
-  int ih, iw, ld_in; const float* mask; const float* add;
-  int ntiles;
-  long long a_bytes;                          // extent of A in bytes (buffer-resource range of the specialised kernel)
-  long long c_bytes;                          // extent of C (and of mask / add / residual, which are indexed like C) in bytes
-  int pow2, l_cout, l_cin, l_s, l_jw;         // data gradient: cout, cin, s, kw / s all powers of two -> W' index math by shifts
-};
 
 // LDS traffic of one wave is ordered; this only stops the compiler from moving LDS accesses across the point.
 __device__ __forceinline__ void wave_fence() {
@@ -273,22 +250,12 @@ ws_fast_kernel(const Params p) {
       const int e = idx * 4, k = e / N, n = e - k * N;
       *reinterpret_cast<float4*>(Bs + k * LDB + n) = *reinterpret_cast<const float4*>(p.W + e);
     }
-  } else if (p.pow2) {
+  } else {
     // run-time integer divisions cost ~20 VALU each and this loop runs in EVERY workgroup: with power-of-two channel
-    // counts / stride the re-indexing is shifts and masks (measured: a third of the kernel's VALU work went here)
+    // counts / stride the re-indexing (ws_wprime_src) is shifts and masks
     for (int idx = tid; idx < p.K * N; idx += kThreads) {
       const int k = idx / N, n = idx - k * N;                 // N is a compile-time power of two
-      const int co = k & (p.cout - 1), tap = k >> p.l_cout, jy = tap >> p.l_jw, jx = tap & ((1 << p.l_jw) - 1);
-      const int ci = n & (p.cin - 1), cls = n >> p.l_cin, py = cls >> p.l_s, px = cls & (p.s - 1);
-      Bs[k * LDB + n] = p.W[(((((py + (jy << p.l_s)) * p.kw + px + (jx << p.l_s)) << p.l_cin) + ci) << p.l_cout) + co];
-    }
-  } else {
-    const int jw = p.kw / p.s;
-    for (int idx = tid; idx < p.K * N; idx += kThreads) {
-      const int k = idx / N, n = idx - k * N;
-      const int co = k % p.cout, tap = k / p.cout, jy = tap / jw, jx = tap - jy * jw;
-      const int ci = n % p.cin, cls = n / p.cin, py = cls / p.s, px = cls - py * p.s;
-      Bs[k * LDB + n] = p.W[(((py + p.s * jy) * p.kw + px + p.s * jx) * p.cin + ci) * p.cout + co];
+      Bs[k * LDB + n] = p.W[ws_wprime_src(p, k, n)];
     }
   }
   __syncthreads();
@@ -321,17 +288,8 @@ ws_fast_kernel(const Params p) {
   };
   const __amdgpu_buffer_rsrc_t c_rsrc = view(p.C), m_rsrc = view(MODE == 1 ? (const void*)p.mask : (const void*)p.residual),
                                add_rsrc = view(p.add);
-  const uint32_t gw = (uint32_t)p.gw, gh = (uint32_t)p.gh;
-
-  auto locate = [&](uint32_t m, uint32_t& img, uint32_t& a, uint32_t& b) {
-    uint32_t rem;
-    p.d_g.divmod(m, img, rem);
-    p.d_gw.divmod(rem, a, b);
-  };
-  auto advance = [&](uint32_t step, uint32_t& img, uint32_t& a, uint32_t& b) {      // step < gw
-    b += step;
-    if (b >= gw) { b -= gw; if (++a >= gh) { a = 0; ++img; } }
-  };
+  auto locate = [&](uint32_t m, uint32_t& img, uint32_t& a, uint32_t& b) { ws_locate(p, m, img, a, b); };
+  auto advance = [&](uint32_t step, uint32_t& img, uint32_t& a, uint32_t& b) { ws_advance(p, step, img, a, b); };      // step < gw
 
   // load cursor: byte offset of (row, k-tile) or kOOB -- forward: one per row (every tap of a 'valid' conv is inside)
   constexpr int NV = MODE == 0 ? 1 : NKT;
@@ -343,13 +301,13 @@ ws_fast_kernel(const Params p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (i) advance(8u, img, a, b);
-      const unsigned byte = (img * p.a_img_stride + __umul24(a, p.a_row_stride) + __umul24(b, p.a_col_stride) + kc) * 4u;
+      const unsigned byte = ws_row_byte(p, img, a, b, kc);
       const bool row_ok = m0 + 8u * i < (uint32_t)p.M;
       if (MODE == 0) voff[i][0] = row_ok ? byte : kOOB;
       else {
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
-          const bool ok = row_ok && (unsigned)((int)a + tdy[t]) < (unsigned)p.vh && (unsigned)((int)b + tdx[t]) < (unsigned)p.vw;
+          const bool ok = row_ok && ws_tap_ok(p, a, b, tdy[t], tdx[t]);
           voff[i][t] = ok ? byte : kOOB;
         }
       }
@@ -379,13 +337,8 @@ ws_fast_kernel(const Params p) {
   const int n = NR * lx;
   // data gradient: dx offset of super-pixel (img, a, b), class (py, px), channel ci is linear in (img, a, b)
   unsigned e_const = 0;
-  const unsigned e_img = (unsigned)(p.ih * p.iw * p.ld_in), e_a = (unsigned)(p.s * p.iw * p.ld_in), e_b = (unsigned)(p.s * p.ld_in);
   int e_py = 0, e_px = 0;
-  if (MODE == 1) {
-    const int cls = n / p.cin, ci = n - cls * p.cin;
-    e_py = cls / p.s; e_px = cls - e_py * p.s;
-    e_const = (unsigned)((e_py * p.iw + e_px) * p.ld_in + ci);
-  }
+  if (MODE == 1) e_const = ws_dgrad_col(p, n, e_py, e_px);
   const bool exact = MODE == 1 && p.gh * p.s == p.ih && p.gw * p.s == p.iw;   // no super-pixel hangs over the map
   bvec_t bias_v;
 #pragma unroll
@@ -417,9 +370,8 @@ ws_fast_kernel(const Params p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (r) advance(1u, img, a, b);
-        unsigned at = img * e_img + __umul24(a, e_a) + __umul24(b, e_b) + e_const;
+        unsigned at = ws_dgrad_at(p, img, a, b, e_const, e_py, e_px, exact);
         if (!full && m0 + r >= (uint32_t)p.M) at = 0xffffffffu;
-        if (!exact && ((int)a * p.s + e_py >= p.ih || (int)b * p.s + e_px >= p.iw)) at = 0xffffffffu;
         out_at[r] = at;
         if (p.mask) mpre[r] = ld_vec(m_rsrc, at == 0xffffffffu ? kOOB : at * 4u);    // (an invalid row is never stored)
       }
@@ -471,68 +423,6 @@ ws_fast_kernel(const Params p) {
       st_vec(v, at * 4u);
     }
   }
-}
-
-struct Plan { bool ok; int mr, nr, grid; size_t lds; };
-
-// Fills the geometry for the forward of a 'valid' conv; ok = false when the shape is outside this kernel's range.
-inline Plan plan_fwd(Params& p, const seedhip_conv_geom* g) {
-  Plan pl; memset(&pl, 0, sizeof(pl));
-  const int seg = g->kw * g->cin;
-  if (g->pad_t || g->pad_l || g->ld_in != g->cin || seg % BK || (g->cout != 32 && g->cout != 64) || g->ld_out % 4) return pl;
-  const int K = g->kh * seg, N = g->cout, tiles_per_row = seg / BK;
-  if (K / BK > kMaxTiles || (K / BK) % 2 || (long long)K * (N == 32 ? N + 8 : N) * 4 > 40 * 1024) return pl;
-  if ((long long)g->n_img * g->ih * g->iw * g->ld_in >= (1LL << 31)) return pl;
-  memset(&p, 0, sizeof(p));
-  p.mode = 0; p.kh = g->kh; p.kw = g->kw; p.cin = g->cin; p.cout = g->cout; p.s = g->stride;
-  p.M = g->n_img * g->oh * g->ow; p.N = N; p.K = K; p.nkt = K / BK;
-  p.gh = g->oh; p.gw = g->ow; p.d_g.init(g->oh * g->ow); p.d_gw.init(g->ow);
-  p.a_img_stride = (unsigned)(g->ih * g->iw * g->ld_in); p.a_row_stride = (unsigned)(g->stride * g->iw * g->ld_in);
-  p.a_col_stride = (unsigned)(g->stride * g->ld_in);
-  for (int t = 0; t < p.nkt; ++t) {
-    p.tile_off[t] = (t / tiles_per_row) * g->iw * g->ld_in + (t % tiles_per_row) * BK;
-    p.tile_dy[t] = 0; p.tile_dx[t] = 0;
-  }
-  p.vh = g->oh; p.vw = g->ow;
-  p.ldc = g->ld_out;
-  p.a_bytes = (long long)g->n_img * g->ih * g->iw * g->ld_in * 4;
-  p.c_bytes = (long long)g->n_img * g->oh * g->ow * g->ld_out * 4;
-  pl.nr = N / 16; pl.ok = true;
-  return pl;
-}
-
-// Data gradient of a 'valid' conv whose kernel extents are multiples of the stride.
-inline Plan plan_dgrad(Params& p, const seedhip_conv_geom* g) {
-  Plan pl; memset(&pl, 0, sizeof(pl));
-  const int s = g->stride;
-  if (g->pad_t || g->pad_l || g->kh % s || g->kw % s || g->cout % BK || g->cin % 4 || g->ld_in % 4 || g->ld_out % 4) return pl;
-  const int N = s * s * g->cin, jh = g->kh / s, jw = g->kw / s, K = jh * jw * g->cout, per_tap = g->cout / BK;
-  if ((N != 32 && N != 64) || K / BK > kMaxTiles || (K / BK) % 2 || (long long)K * (N == 32 ? N + 8 : N) * 4 > 40 * 1024) return pl;
-  if ((long long)g->n_img * g->oh * g->ow * g->ld_out >= (1LL << 31)) return pl;
-  if ((long long)g->n_img * g->ih * g->iw * g->ld_in >= (1LL << 32) - 1) return pl;     // dX offsets are 32-bit
-  memset(&p, 0, sizeof(p));
-  p.mode = 1; p.kh = g->kh; p.kw = g->kw; p.cin = g->cin; p.cout = g->cout; p.s = s;
-  p.gh = (g->ih + s - 1) / s; p.gw = (g->iw + s - 1) / s;
-  p.M = g->n_img * p.gh * p.gw; p.N = N; p.K = K; p.nkt = K / BK;
-  p.d_g.init(p.gh * p.gw); p.d_gw.init(p.gw);
-  p.a_img_stride = (unsigned)(g->oh * g->ow * g->ld_out); p.a_row_stride = (unsigned)(g->ow * g->ld_out);
-  p.a_col_stride = (unsigned)g->ld_out;
-  for (int t = 0; t < p.nkt; ++t) {
-    const int tap = t / per_tap, jy = tap / jw, jx = tap % jw;
-    p.tile_off[t] = -(jy * g->ow + jx) * g->ld_out + (t % per_tap) * BK;
-    p.tile_dy[t] = -jy; p.tile_dx[t] = -jx;
-  }
-  p.vh = g->oh; p.vw = g->ow;
-  p.ih = g->ih; p.iw = g->iw; p.ld_in = g->ld_in;
-  p.a_bytes = (long long)g->n_img * g->oh * g->ow * g->ld_out * 4;
-  p.c_bytes = (long long)g->n_img * g->ih * g->iw * g->ld_in * 4;
-  {
-    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
-    p.l_cout = lg(g->cout); p.l_cin = lg(g->cin); p.l_s = lg(s); p.l_jw = lg(jw);
-    p.pow2 = p.l_cout >= 0 && p.l_cin >= 0 && p.l_s >= 0 && p.l_jw >= 0;
-  }
-  pl.nr = N / 16; pl.ok = true;
-  return pl;
 }
 
 inline int launch(Params& p, Plan& pl, hipStream_t s) {

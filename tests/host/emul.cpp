@@ -9,6 +9,7 @@
 #include <vector>
 #include "../../seed_rl_amd/csrc/conv_problems.h"
 #include "../../seed_rl_amd/csrc/gemm_geom.h"
+#include "../../seed_rl_amd/csrc/wsgemm_geom.h"
 
 using namespace seedhip;
 
@@ -196,3 +197,86 @@ int emul_gather_wgrad(const geom_c* g, const float* in, int in_relu, const float
 }
 
 }  // extern "C"
+
+// ---- weight-stationary conv kernels (wsgemm.h ws_fast_kernel): the tile walk of the GPU kernel with the SAME helpers
+// (wsgemm_geom.h): row decode by one division + stepping, A byte offsets and tap validity (out-of-range = zero),
+// W' re-indexing, dX scatter offsets.  Returns 0 when the shape is outside the kernel's range. ----
+extern "C" int emul_ws_fwd(const geom_c* g, const float* in, const float* w, const float* bias, float* out, int out_relu) {
+  const seedhip_conv_geom a = to_abi(g);
+  wsgemm::Params p;
+  wsgemm::Plan pl = wsgemm::plan_fwd(p, &a);
+  if (!pl.ok || p.gw < 8) return 0;
+  const int N = p.N, ntiles = (p.M + 15) / 16;
+  for (int tile = 0; tile < ntiles; ++tile)
+    for (int srow = 0; srow < 8; ++srow) {                 // the two staging rows of a lane: srow and srow + 8 (stepped)
+      uint32_t img, ya, xb;
+      wsgemm::ws_locate(p, (uint32_t)tile * 16u + srow, img, ya, xb);
+      for (int i = 0; i < 2; ++i) {
+        if (i) wsgemm::ws_advance(p, 8u, img, ya, xb);
+        const uint32_t m = (uint32_t)tile * 16u + srow + 8u * i;
+        if (m >= (uint32_t)p.M) continue;
+        for (int n = 0; n < N; ++n) {
+          double acc = 0.0;
+          for (int t = 0; t < p.nkt; ++t)
+            for (int kc = 0; kc < wsgemm::BK; ++kc) {
+              const unsigned byte = wsgemm::ws_row_byte(p, img, ya, xb, kc) + 4u * (unsigned)p.tile_off[t];
+              if ((long long)byte + 4 > p.a_bytes) return 0;                       // a 'valid' conv never leaves the map
+              acc += (double)in[byte / 4] * w[(long long)(t * wsgemm::BK + kc) * N + n];
+            }
+          float v = (float)acc + (bias ? bias[n] : 0.f);
+          if (out_relu && v < 0.f) v = 0.f;
+          out[(long long)m * p.ldc + n] = v;
+        }
+      }
+    }
+  return 1;
+}
+extern "C" int emul_ws_dgrad(const geom_c* g, const float* dy, const float* w, float* dx, const float* mask, const float* add) {
+  const seedhip_conv_geom a = to_abi(g);
+  wsgemm::Params p;
+  wsgemm::Plan pl = wsgemm::plan_dgrad(p, &a);
+  if (!pl.ok || p.gw < 8) return 0;
+  const int N = p.N, ntiles = (p.M + 15) / 16;
+  const bool exact = p.gh * p.s == p.ih && p.gw * p.s == p.iw;
+  int minoff = 0;
+  for (int t = 0; t < p.nkt; ++t) minoff = p.tile_off[t] < minoff ? p.tile_off[t] : minoff;
+  std::vector<float> wp((size_t)p.K * N);
+  for (int k = 0; k < p.K; ++k) for (int n = 0; n < N; ++n) wp[(size_t)k * N + n] = w[wsgemm::ws_wprime_src(p, k, n)];
+  for (int tile = 0; tile < ntiles; ++tile)
+    for (int kq = 0; kq < 4; ++kq) {                       // epilogue rows of a lane group: 4 kq + r, stepped from r = 0
+      uint32_t img, ya, xb;
+      wsgemm::ws_locate(p, (uint32_t)tile * 16u + 4u * kq, img, ya, xb);
+      for (int r = 0; r < 4; ++r) {
+        if (r) wsgemm::ws_advance(p, 1u, img, ya, xb);
+        const uint32_t m = (uint32_t)tile * 16u + 4u * kq + r;
+        if (m >= (uint32_t)p.M) continue;
+        // the same row through the load cursor's decode (division at the tile's first staging row + step of 8)
+        { uint32_t i2, a2, b2; const uint32_t lr = (4u * kq + r) & 7u, hi = (4u * kq + r) >> 3;
+          wsgemm::ws_locate(p, (uint32_t)tile * 16u + lr, i2, a2, b2);
+          if (hi) wsgemm::ws_advance(p, 8u, i2, a2, b2);
+          if (i2 != img || a2 != ya || b2 != xb) return 0; }
+        for (int n = 0; n < N; ++n) {
+          double acc = 0.0;
+          for (int t = 0; t < p.nkt; ++t) {
+            if (!wsgemm::ws_tap_ok(p, ya, xb, p.tile_dy[t], p.tile_dx[t])) continue;          // hardware zero fill
+            for (int kc = 0; kc < wsgemm::BK; ++kc) {
+              // the kernel's view starts at A + minoff: byte offset relative to it, k-tile offset rebased
+              const long long rel = (long long)wsgemm::ws_row_byte(p, img, ya, xb, kc) + 4LL * (p.tile_off[t] - minoff);
+              const long long abs_f = rel / 4 + minoff;
+              if (abs_f < 0 || abs_f * 4 + 4 > p.a_bytes) return 0;                          // a valid tap is inside dY
+              acc += (double)dy[abs_f] * wp[(size_t)(t * wsgemm::BK + kc) * N + n];
+            }
+          }
+          int py, px;
+          const unsigned e_const = wsgemm::ws_dgrad_col(p, n, py, px);
+          const unsigned at = wsgemm::ws_dgrad_at(p, img, ya, xb, e_const, py, px, exact);
+          if (at == 0xffffffffu) continue;
+          float v = (float)acc;
+          if (mask && !(mask[at] > 0.f)) v = 0.f;
+          if (add) v += add[at];
+          dx[at] = v;
+        }
+      }
+    }
+  return 1;
+}

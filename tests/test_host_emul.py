@@ -243,3 +243,41 @@ def test_stack_conv_matches_oracle(emul, kw_, stride):
   emul.emul_stack_wgrad(ctypes.byref(g), ptr(ext), ptr(nv), ptr(dz), ptr(dw), ptr(db), 128)
   np.testing.assert_allclose(dw, wt.grad.numpy(), rtol=1e-4, atol=1e-4)
   np.testing.assert_allclose(db, bt.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+WS_CASES = [
+    (3, 20, 20, 16, 4, 4, 2, 'valid', 32),   # the second Atari conv (cfg2): the shape the specialised kernel runs
+    (2, 20, 22, 16, 4, 4, 2, 'valid', 32),   # non-square map
+    (2, 19, 21, 16, 4, 4, 2, 'valid', 32),   # odd extents: super-pixels hang over the input map and over dY
+    (2, 20, 20, 8, 4, 4, 2, 'valid', 64),    # 64 output channels (NR = 4 forward), 32-column data gradient
+]
+
+
+@pytest.mark.parametrize('case', WS_CASES)
+def test_ws_kernel_index_math(emul, case):
+  """The index arithmetic of the weight-stationary conv kernels (seed_rl_amd/csrc/wsgemm_geom.h: row decode by
+  division + stepping, A byte offsets, tap validity, W' re-indexing, dX scatter offsets -- the helpers
+  ws_fast_kernel calls) executed on the CPU in the kernel's own tile order, against the torch oracle."""
+  n, ih, iw, cin, kh, kw, stride, padding, cout = case
+  rng = np.random.default_rng(abs(hash(case)) % 1000)
+  x_raw = np.abs(rng.normal(size=(n, ih, iw, cin))).astype(np.float32)
+  x_raw[rng.uniform(size=x_raw.shape) < 0.3] = 0.0                         # post-ReLU input: also the dgrad's mask
+  w = rng.normal(size=(kh, kw, cin, cout)).astype(np.float32) * 0.2
+  b = rng.normal(size=(cout,)).astype(np.float32)
+  g = make_geom(n, ih, iw, cin, kh, kw, stride, padding, cout)
+  x = torch.tensor(x_raw, requires_grad=True)
+  wt = torch.tensor(w); bt = torch.tensor(b)
+  y = F.relu(nets_torch.conv2d(x, wt, bt, stride, padding))
+  dy = rng.normal(size=y.shape).astype(np.float32)
+  y.backward(torch.tensor(dy))
+  emul.emul_ws_fwd.restype = ctypes.c_int; emul.emul_ws_dgrad.restype = ctypes.c_int
+  out = np.zeros((n, g.oh, g.ow, cout), np.float32)
+  ok = emul.emul_ws_fwd(ctypes.byref(g), ptr(x_raw), ptr(w), ptr(b), ptr(out), 1)
+  assert ok                                                                 # all WS_CASES are inside the kernel's range
+  np.testing.assert_allclose(out, y.detach().numpy(), rtol=1e-4, atol=1e-5)
+  dz = np.ascontiguousarray(dy * (y.detach().numpy() > 0), np.float32)
+  dx = np.full((n, ih, iw, cin), 7.0, np.float32)                           # every element must be overwritten
+  add = rng.normal(size=dx.shape).astype(np.float32)
+  ok = emul.emul_ws_dgrad(ctypes.byref(g), ptr(dz), ptr(w), ptr(dx), ptr(x_raw), ptr(add))
+  assert ok
+  np.testing.assert_allclose(dx, x.grad.numpy() * (x_raw > 0) + add, rtol=1e-4, atol=1e-4)
