@@ -311,6 +311,8 @@ CONV_CASES = [
     (300, 1, 1, 256, 1, 1, 1, 'valid', 18),   # cout % 4 != 0: Dense accessors of the implicit-GEMM core
     (37, 1, 1, 36, 1, 1, 1, 'valid', 44),     # everything ragged
     (1500, 20, 20, 16, 4, 4, 2, 'valid', 32), # wsgemm.h: persistent workgroups walk several m-tiles
+    (37, 19, 21, 16, 4, 4, 2, 'valid', 32),   # wsgemm.h specialised kernel, odd map: super-pixels hang over dX and dY, ragged last tile
+    (21, 20, 22, 8, 4, 4, 2, 'valid', 64),    # wsgemm.h specialised kernel: 64 output channels forward, 32-column data gradient (NKT = 4 / 8)
     (3, 10, 12, 16, 3, 3, 1, 'same', 64),     # gather-GEMM forward with 'same' padding (taps predicated at the border)
     (2, 8, 9, 64, 3, 3, 1, 'same', 64),       # gather-GEMM forward + data gradient with padding
     (2, 11, 9, 64, 5, 5, 1, 'same', 128),     # 5x5: 25 taps, K = 1600
