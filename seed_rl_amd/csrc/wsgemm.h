@@ -440,6 +440,9 @@ inline int launch(Params& p, Plan& pl, hipStream_t s) {
   static const int fast = getenv("SEEDHIP_WS_FAST") ? atoi(getenv("SEEDHIP_WS_FAST")) : 1;
   if (fast && pl.mr == 1 && waves == 8 && p.gw >= 8 && !p.a_relu && p.a_bytes < (1LL << 31) - (1 << 20) && p.c_bytes < (1LL << 31) &&
       (p.mode == 1 || (long long)p.M * p.ldc < (1LL << 32) - 64)) {
+    // 100-128 VGPRs: four waves per SIMD, i.e. two 8-wave workgroups per CU are resident whatever LDS allows; a
+    // persistent grid of exactly the resident workgroups avoids a second, ragged round (data gradient 0.196 -> 0.189 ms)
+    if (wgs > 256 * 2) pl.grid = 256 * 2;
 #define SEEDHIP_WSF(NR_, NKT_, MODE_)                                                                             \
     if (pl.nr == NR_ && p.nkt == NKT_ && p.mode == MODE_) {                                                       \
       if (pl.lds > 64 * 1024)                                                                                     \
