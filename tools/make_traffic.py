@@ -2,7 +2,7 @@
 """Builds profiles/<tag>_traffic.json (HBM bytes per launch of the cfg2 hot kernels) from the condensed PMC table
 written by tools/prof_summary.py.
 
-  python tools/make_traffic.py profiles/r01l_cfg2_pmc.csv profiles/r01l_cfg2_traffic.json
+  python tools/make_traffic.py profiles/r01m_cfg2_pmc.csv profiles/r01m_cfg2_traffic.json
 
 Region names are bench.py's (ops.Profiler regions); a region's kernel is the matching row with the largest traffic
 (the Dense GEMM template serves the FC layer and the small heads: the FC launch is the big one).  FETCH_SIZE is doubled
