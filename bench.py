@@ -11,8 +11,17 @@ with num_action_repeats=1 (common/common_flags.py:43; learner.py:236-237).
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
+
+The default single-GPU run also reports, outside the timed region and in the same JSON line:
+  parity         one train step at the bench shape against the CPU oracle (tests/parity.py)
+  other_configs  BASELINE configs[2] (DMLab ImpalaDeep+LSTM) and configs[4] (R2D2), a few steps each
+  inference      central-inference step (learner.py:350-405) at n = 64 / 256 / 1024
+  ingest         the same step with the NEXT unroll's host->device copy in flight on its own stream
+  cpu_baseline   the oracle's eager PyTorch-CPU learner step on the host cores
+(--quick skips them.)
 """
 import argparse
+import gc
 import glob
 import json
 import os
@@ -32,6 +41,8 @@ MFMA_BF16_PEAK_TF = 2500.0 # bf16 dense MFMA peak (MI355X_MICROARCH.md; no spars
 # Kernels that evaluate their fp32 algorithm on the bf16 pipe through the exact three-way operand split
 # (csrc/stackconv.hip): every algorithmic MAC costs three bf16 MACs, so their ceiling for ALGORITHMIC flops is peak / 3.
 BF16X3_KERNELS = ('stack_conv_fwd', 'stack_conv_wgrad')
+PARITY_NOTE = ('oracle = torch-CPU fp32 restatement of the reference graph (oracle/nets_torch.py); V-trace / R2D2 loss '
+               'math pinned to outputs of the reference code, Keras Conv2D/LSTMCell/Dense/Adam numerics UNPINNED (no TF here)')
 
 
 def parse():
@@ -52,6 +63,11 @@ def parse():
   ap.add_argument('--graph', type=int, default=1,
                   help='1 (default, single GPU): replay the step from a captured HIP graph (learner.GraphedStep; measured '
                        '0-2%% over eager on MI355X); 0: eager launches.  Multi-GPU runs launch eagerly.')
+  ap.add_argument('--ingest', default='resident', choices=['resident', 'pinned'],
+                  help="resident (headline): the unroll is in HBM when the timed region starts; pinned: every step's "
+                       'unroll comes from pinned host memory, the copy of step i+1 on its own stream under step i')
+  ap.add_argument('--quick', action='store_true',
+                  help='only the timed learner step: no parity / other_configs / inference / ingest / cpu_baseline records')
   return ap.parse_args()
 
 
@@ -107,6 +123,278 @@ def vtrace_checks(dev):
   return err, err_ref, sweep
 
 
+def _peak(kernel):
+  bf16x3 = kernel in BF16X3_KERNELS and os.environ.get('SEEDHIP_STACK_BF16', '1') != '0'
+  return (MFMA_BF16_PEAK_TF / 3.0 if bf16x3 else MFMA_F32_PEAK_TF), bf16x3
+
+
+def _release():
+  from seed_rl_amd import ops
+  ops._SPLITK_WS.clear()            # pylint: disable=protected-access
+  gc.collect()
+  torch.cuda.empty_cache()
+
+
+def build_workload(config, torso, T, B, A, dev, reduction, graph, world, seed):
+  """Agent + learner + one synthetic unroll resident in HBM for a BASELINE config."""
+  from seed_rl_amd import learner, networks, optimizers, parametric_distribution as pd, smoke_step
+  T1 = T + 1
+  final_iteration = 10 ** 9 // (T * B * max(world, 1))
+  extra = ()
+  if config == 'r2d2':
+    from seed_rl_amd import r2d2_learner
+    agent = networks.DuelingLSTMDQNNet(A, device=dev, seed=0)
+    target = networks.DuelingLSTMDQNNet(A, device=dev, seed=0)
+    u0 = smoke_step.make_unroll(agent, T1, B, A, dev, seed=seed)
+    unroll = r2d2_learner.Unroll(agent.initial_state(B), None, u0.prev_actions, u0.env_outputs,
+                                 networks.R2D2AgentOutput(u0.agent_outputs.action.to(torch.int32), None))
+    extra = (torch.rand(B, device=dev) * 0.9 + 0.1,)                          # importance weights
+    opt = optimizers.Adam(4.8e-4, epsilon=1e-3, capturable=bool(graph))       # atari/r2d2_main.py:36-39
+    lrn = r2d2_learner.R2D2Learner(agent, target, opt, r2d2_learner.R2D2Config(), reduction=reduction)
+    workload = 'Atari R2D2 DuelingLSTMDQNNet (conv 32/64/64, FC512, LSTM512, dueling heads) learner step on replayed ' \
+               'sequences, burn-in 40, n-step(5) double-Q target, training + target network'
+    return agent, lrn, unroll, extra, workload
+  opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, final_iteration), beta_1=0.0, epsilon=3.125e-7,
+                        capturable=bool(graph))
+  if config == 'dmlab':
+    agent = networks.ImpalaDeep(A, device=dev, seed=0)                        # identical params on all ranks
+    unroll = smoke_step.make_deep_unroll(agent, T1, B, A, dev, seed=seed)
+    workload = 'DeepMind Lab 72x96x3 IMPALA deep ResNet + LSTM(256) learner step'
+  else:
+    agent = networks.AtariShallow(A, torso=torso, device=dev, seed=0)
+    unroll = smoke_step.make_unroll(agent, T1, B, A, dev, seed=seed)
+    # place the frames directly in the agent's extended trajectory buffer (no per-step copy)
+    ext = agent.frames_buffer(T1, B)
+    ext[3:].copy_(unroll.env_outputs.observation.reshape(T1, B, -1))
+    unroll = unroll._replace(env_outputs=unroll.env_outputs._replace(
+        observation=ext[3:].view(T1, B, agent._obs[0], agent._obs[1], 1)))
+    workload = 'Atari 84x84x4 IMPALA %s ConvNet learner step' % torso
+  lrn = learner.Learner(agent, opt, pd.categorical_distribution(A), reduction=reduction)
+  return agent, lrn, unroll, extra, workload
+
+
+def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, torso='shallow', batch=0, unroll_len=0,
+                actions=0, reduction='mean', graph=1, attribution_steps=3):
+  """Times `steps` learner steps of one BASELINE config; returns the record the JSON line is built from."""
+  from seed_rl_amd import learner, ops
+  T = unroll_len or (120 if config == 'r2d2' else 20)
+  B = batch or (256 if config in ('dmlab', 'r2d2') else 512)
+  A = actions or (9 if config == 'dmlab' else 18)
+  agent, lrn, unroll, extra, workload = build_workload(config, torso, T, B, A, dev, reduction, graph, world, 1000 + rank)
+
+  def barrier():
+    if distributed:
+      torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+  # ---- warmup, then the per-kernel attribution pass: the device is drained before every region, i.e. every kernel
+  # is timed the way rocprofv3 times it (serialised dispatches) -- profiles/*_kernel_stats.csv is the same view ----
+  for _ in range(max(warmup - attribution_steps, 1 if warmup else 0)):
+    lrn.minimize(unroll, *extra)
+  prof_all = ops.Profiler(serialize=True)
+  ops.set_profiler(prof_all)
+  for _ in range(min(attribution_steps, max(warmup, 1))):
+    lrn.minimize(unroll, *extra)
+  ops.set_profiler(None)
+  kern = prof_all.summary()
+  nattr = min(attribution_steps, max(warmup, 1))
+  for v in kern.values():
+    v['total_ms'] /= nattr; v['calls'] //= nattr
+  # dominant kernel = largest share of the step in that pass (averaged over the attribution steps so that two kernels
+  # a few microseconds apart do not swap places between runs), among the MFMA kernels and the HBM kernels that move
+  # >= 32 MB, averaging >= 50 us per launch and launched at most 64 times per step: event pairs around
+  # few-microsecond kernels launched hundreds of times per step are not a reliable ranking
+  big = [k for k in kern if (kern[k]['flops'] > 0 or kern[k]['bytes'] >= (1 << 25)) and kern[k]['avg_ms'] >= 0.05
+         and kern[k]['calls'] <= 64]
+  big = big or list(kern)
+  dominant = max(big, key=lambda k: kern[k]['total_ms'])
+
+  # ---- timed region: exactly K steps, barrier + sync on both sides ----
+  step_fn = lambda: lrn.minimize(unroll, *extra)
+  mode = 'eager'
+  if graph and world == 1:
+    try:
+      gs = learner.GraphedStep(lrn, unroll, *extra, warmup=1)
+      step_fn, mode = (lambda: gs()), 'hip-graph'
+      step_fn(); torch.cuda.synchronize()
+    except Exception as e:                       # pylint: disable=broad-except
+      sys.stderr.write('HIP-graph capture unavailable (%s); timing eager launches\n' % e)
+      step_fn, mode = (lambda: lrn.minimize(unroll, *extra)), 'eager'
+  prof = ops.Profiler(only=[dominant])
+  if mode == 'eager':
+    ops.set_profiler(prof)
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    out = step_fn()
+  barrier()
+  dt = time.perf_counter() - t0
+  ops.set_profiler(None)
+  loss = out[0]
+  if mode != 'eager':
+    # free-running kernel time of the dominant kernel: HIP events around it on the launch stream, in a few eager
+    # steps after the timed region (events cannot be recorded inside a replayed graph)
+    ops.set_profiler(prof)
+    for _ in range(min(steps, 5)):
+      lrn.minimize(unroll, *extra)
+    ops.set_profiler(None)
+  if world > 1:
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tt[0])
+  loss_val = float(loss)
+  assert np.isfinite(loss_val)
+  if hasattr(agent, 'check_errors'):
+    agent.check_errors()
+
+  free = prof.summary()[dominant]
+  d = kern[dominant]
+  flops, nbytes = d['flops'], d['bytes']
+  if flops > 0:
+    peak, bf16x3 = _peak(dominant)
+    ach, ach_free = flops / (d['avg_ms'] * 1e-3) / 1e12, flops / (free['avg_ms'] * 1e-3) / 1e12
+    roofline = dict(bound='mfma', kernel=dominant, achieved=round(ach, 2), peak=round(peak, 1),
+                    unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
+                    pipe=('bf16 MFMA, exact 3-way split of the fp32 operand: peak = 2500 / 3 algorithmic TFLOP/s'
+                          if bf16x3 else 'fp32 MFMA (v_mfma_f32_16x16x4_f32)'),
+                    algorithmic_flops=flops, algorithmic_bytes=nbytes)
+  else:
+    peak = HBM_PEAK_GBS
+    ach, ach_free = nbytes / (d['avg_ms'] * 1e-3) / 1e9, nbytes / (free['avg_ms'] * 1e-3) / 1e9
+    roofline = dict(bound='hbm', kernel=dominant, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, algorithmic_bytes=nbytes)
+  # two clocks, both reported: `frac` / `frac_serialized` divide by the kernel's duration with the device drained before
+  # it (what rocprofv3 --kernel-trace --stats shows: profiles/ must agree with THIS one); `frac_free_running` by its
+  # duration in back-to-back steps, where it starts behind its producer with operands still in L2 / MALL
+  roofline.update(frac_serialized=round(ach / peak, 4), avg_kernel_ms=round(d['avg_ms'], 4),
+                  frac_free_running=round(ach_free / peak, 4), avg_kernel_ms_free_running=round(free['avg_ms'], 4),
+                  clock='HIP events on the launch stream; serialized = device drained before the kernel (rocprofv3 view)')
+  rec = dict(
+      T=T, B=B, A=A, workload=workload, mode=mode, params=agent.flat.num_params(), loss=loss_val,
+      ms_per_step=dt / steps * 1e3, frames_per_s=world * B * T / (dt / steps), roofline=roofline, dominant=dominant,
+      kernels_ms_per_step={k: round(v['total_ms'], 4) for k, v in kern.items()},
+      # the other MFMA kernels of the attribution pass (>= 50 us per launch), same (serialized) accounting as `roofline`
+      mfma_kernels={
+          k: dict(avg_ms=round(v['avg_ms'], 4), tflops=round(v['flops'] / (v['avg_ms'] * 1e-3) / 1e12, 1),
+                  frac=round(v['flops'] / (v['avg_ms'] * 1e-3) / 1e12 / _peak(k)[0], 3))
+          for k, v in kern.items() if v['flops'] > 0 and v['avg_ms'] >= 0.05})
+  del agent, lrn, unroll, extra
+  _release()
+  return rec
+
+
+def inference_record(dev, sizes=(64, 256, 1024), unroll_len=20, calls=200):
+  """Central inference (agents/vtrace/learner.py:350-405) on the device-resident store, Atari agent: env steps per
+  second through FusedInferenceState for a few inference batch sizes, the whole call replayed from a HIP graph
+  (run-id bookkeeping, single-step agent forward, action sampling, store append, completed unrolls written
+  time-major into the training batch).  Inputs (one request batch) are copied into the graph's static buffers on every
+  call, as the transport layer would."""
+  from seed_rl_amd import inference, networks, utils
+  from seed_rl_amd.unroll_store import Spec
+  A, obs = 18, (84, 84, 1)
+  out = {}
+  for n in sizes:
+    envs = max(512, 2 * n)
+    agent = networks.AtariShallow(A, device=dev)
+    env_specs = utils.EnvOutput(Spec((), torch.float32), Spec((), torch.bool), Spec(obs, torch.uint8),
+                                Spec((), torch.bool), Spec((), torch.int32))
+    ao_specs = networks.AgentOutput(Spec((), torch.int64), Spec((A,), torch.float32), Spec((), torch.float32))
+    g = torch.Generator(device='cpu').manual_seed(0)
+    groups = [torch.arange(i, i + n, dtype=torch.int64).to(dev) for i in range(0, envs, n)]
+    reqs = [utils.EnvOutput(
+        reward=torch.randn(n, generator=g).to(dev), done=(torch.rand(n, generator=g) < 0.01).to(dev),
+        observation=torch.randint(0, 256, (n,) + obs, dtype=torch.uint8, generator=g).to(dev),
+        abandoned=torch.zeros(n, dtype=torch.bool, device=dev), episode_step=torch.zeros(n, dtype=torch.int32, device=dev))
+            for _ in groups]
+    run_ids = torch.full((n,), 7, dtype=torch.int64, device=dev)
+    fused = inference.FusedInferenceState(agent, envs, unroll_len, env_specs, ao_specs, batch_capacity=2 * envs, device=dev)
+    fn = fused.graphed(n, obs)
+    per_round = len(groups) * (unroll_len + 1)
+
+    def call(i):
+      k = i % len(groups)
+      fn(groups[k], run_ids, reqs[k], reqs[k].reward)
+      if (i + 1) % per_round == 0:
+        fused.batch_count.zero_()             # the learner took the filled training batch
+    for i in range(2 * len(groups)):
+      call(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(calls):
+      call(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fused.check_errors()
+    out['n%d' % n] = dict(us_per_call=round(dt / calls * 1e6, 1), env_steps_per_s=round(calls * n / dt, 0), envs=envs)
+    del fused, fn, agent, reqs, groups
+    _release()
+  out['note'] = ('FusedInferenceState.graphed(): one HIP-graph replay per inference batch incl. the copy of the request '
+                 'into the static inputs; Atari shallow agent, A=18, unroll 20')
+  return out
+
+
+def ingest_record(dev, steps, T=20, B=512, A=18):
+  """The cfg2 step fed from PINNED HOST memory: the whole unroll of step i+1 (frames = 98.7 % of its bytes) is copied
+  host->device on a copy stream while step i computes (double-buffered device unrolls, eager launches)."""
+  from seed_rl_amd import learner, networks, optimizers, parametric_distribution as pd, smoke_step, utils
+  T1 = T + 1
+  agent = networks.AtariShallow(A, device=dev, seed=0)
+  opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, 10 ** 5), beta_1=0.0, epsilon=3.125e-7)
+  lrn = learner.Learner(agent, opt, pd.categorical_distribution(A))
+  slots, hosts = [], []
+  for s in range(2):
+    agent.frames_slot = s
+    u = smoke_step.make_unroll(agent, T1, B, A, dev, seed=2000 + s)
+    ext = agent.frames_buffer(T1, B)
+    ext[3:].copy_(u.env_outputs.observation.reshape(T1, B, -1))
+    u = u._replace(env_outputs=u.env_outputs._replace(observation=ext[3:].view(T1, B, agent._obs[0], agent._obs[1], 1)))
+    leaves = [t for t in utils.flatten(u) if t is not None and t.numel() > 0]
+    slots.append((u, leaves))
+    hosts.append([t.cpu().pin_memory() for t in leaves])
+  nbytes = sum(t.numel() * t.element_size() for t in hosts[0])
+  copy_stream = torch.cuda.Stream()
+  ready = [torch.cuda.Event(), torch.cuda.Event()]
+  free = [torch.cuda.Event(), torch.cuda.Event()]
+  cur = torch.cuda.current_stream()
+
+  def prefetch(k):
+    with torch.cuda.stream(copy_stream):
+      copy_stream.wait_event(free[k & 1])
+      for d, h in zip(slots[k & 1][1], hosts[k & 1]):
+        d.copy_(h, non_blocking=True)
+      ready[k & 1].record(copy_stream)
+
+  def run(n):
+    free[0].record(cur); free[1].record(cur)
+    prefetch(0)
+    for i in range(n):
+      agent.frames_slot = i & 1
+      cur.wait_event(ready[i & 1])
+      prefetch(i + 1)
+      lrn.minimize(slots[i & 1][0])
+      free[i & 1].record(cur)
+    torch.cuda.synchronize()
+
+  run(3)
+  t0 = time.perf_counter()
+  run(steps)
+  dt = time.perf_counter() - t0
+  # the copy alone, for reference
+  torch.cuda.synchronize()
+  t1 = time.perf_counter()
+  for k in range(4):
+    prefetch(k)
+  torch.cuda.synchronize()
+  copy_ms = (time.perf_counter() - t1) / 4 * 1e3
+  agent.frames_slot = 0
+  rec = dict(mode='pinned host unrolls, H2D of step i+1 on a copy stream under step i (eager launches)',
+             ms_per_step=round(dt / steps * 1e3, 4), env_frames_per_s=round(B * T / (dt / steps), 1),
+             h2d_bytes_per_step=nbytes, h2d_ms_alone=round(copy_ms, 4), h2d_GBs=round(nbytes / copy_ms / 1e6, 1))
+  del agent, lrn, slots, hosts
+  _release()
+  return rec
+
+
 def main():
   args = parse()
   rank = int(os.environ.get('RANK', '0'))
@@ -122,187 +410,100 @@ def main():
     os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
     torch.distributed.init_process_group('nccl', device_id=dev)          # "nccl" is RCCL on ROCm
   assert world == args.gpus or world == 1, 'launch with torchrun for --gpus > 1'
-
-  from seed_rl_amd import learner, networks, ops, optimizers, parametric_distribution as pd, smoke_step
   deep, r2 = args.config == 'dmlab', args.config == 'r2d2'
-  T = args.unroll or (120 if r2 else 20)
-  B = args.batch or (256 if (deep or r2) else 512)
-  A = args.actions or (9 if deep else 18)
-  T1 = T + 1
-  final_iteration = 10 ** 9 // (T * B * max(world, 1))
-  opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, final_iteration), beta_1=0.0, epsilon=3.125e-7,
-                        capturable=bool(args.graph))
-  if r2:
-    from seed_rl_amd import r2d2_learner
-    agent = networks.DuelingLSTMDQNNet(A, device=dev, seed=0)
-    target = networks.DuelingLSTMDQNNet(A, device=dev, seed=0)
-    u0 = smoke_step.make_unroll(agent, T1, B, A, dev, seed=1000 + rank)
-    unroll = r2d2_learner.Unroll(agent.initial_state(B), None, u0.prev_actions, u0.env_outputs,
-                                 networks.R2D2AgentOutput(u0.agent_outputs.action.to(torch.int32), None))
-    iw = torch.rand(B, device=dev) * 0.9 + 0.1
-    workload = 'Atari R2D2 DuelingLSTMDQNNet (conv 32/64/64, FC512, LSTM512, dueling heads) learner step on replayed ' \
-               'sequences, burn-in 40, n-step(5) double-Q target, training + target network'
-  elif deep:
-    agent = networks.ImpalaDeep(A, device=dev, seed=0)                          # identical params on all ranks
-    unroll = smoke_step.make_deep_unroll(agent, T1, B, A, dev, seed=1000 + rank)
-    workload = 'DeepMind Lab 72x96x3 IMPALA deep ResNet + LSTM(256) learner step'
-  else:
-    agent = networks.AtariShallow(A, torso=args.torso, device=dev, seed=0)
-    unroll = smoke_step.make_unroll(agent, T1, B, A, dev, seed=1000 + rank)
-    # place the frames directly in the agent's extended trajectory buffer (no per-step copy)
-    ext = agent.frames_buffer(T1, B)
-    ext[3:].copy_(unroll.env_outputs.observation.reshape(T1, B, -1))
-    unroll = unroll._replace(env_outputs=unroll.env_outputs._replace(
-        observation=ext[3:].view(T1, B, agent._obs[0], agent._obs[1], 1)))
-    workload = 'Atari 84x84x4 IMPALA %s ConvNet learner step' % args.torso
-  if r2:
-    opt = optimizers.Adam(4.8e-4, epsilon=1e-3, capturable=bool(args.graph))    # atari/r2d2_main.py:36-39
-    r2l = r2d2_learner.R2D2Learner(agent, target, opt, r2d2_learner.R2D2Config(), reduction=args.reduction)
 
-    class _Step(object):
-      def minimize(self, unroll):
-        total, _, _ = r2l.minimize(unroll, iw)
-        return total, None
-    lrn = _Step()
-  else:
-    lrn = learner.Learner(agent, opt, pd.categorical_distribution(A), reduction=args.reduction)
+  rec = run_learner(args.config, args.steps, args.warmup, dev, rank, world, distributed, args.torso, args.batch,
+                    args.unroll, args.actions, args.reduction, args.graph)
+  T, B, A = rec['T'], rec['B'], rec['A']
+  roofline = rec['roofline']
+  headline = args.config == 'atari' and args.torso == 'shallow' and B == 512 and T == 20 and A == 18
 
-  def barrier():
-    if distributed:
-      torch.distributed.barrier()
-    torch.cuda.synchronize()
-
-  # ---- warmup (+ per-kernel profile pass to find the dominant kernel) ----
-  for _ in range(max(args.warmup - 1, 0)):
-    lrn.minimize(unroll)
-  prof_all = ops.Profiler(serialize=True)
-  ops.set_profiler(prof_all)
-  lrn.minimize(unroll)
-  ops.set_profiler(None)
-  kern = prof_all.summary()
-  # dominant kernel = largest share of the step in the attribution pass (device drained before every region),
-  # among the MFMA kernels and the HBM kernels that move >= 32 MB, and only those averaging >= 50 us per launch and
-  # launched at most 64 times per step:
-  # event pairs around few-microsecond kernels launched hundreds of times per step (LSTM gates, the per-step
-  # recurrent GEMM) are not a reliable ranking -- the rocprofv3 --stats tables under profiles/ are the reference
-  # view and agree with this choice
-  big = [k for k in kern if (kern[k]['flops'] > 0 or kern[k]['bytes'] >= (1 << 25)) and kern[k]['avg_ms'] >= 0.05
-         and kern[k]['calls'] <= 64]
-  big = big or list(kern)
-  dominant = max(big, key=lambda k: kern[k]['total_ms'])
-  if args.warmup == 0:
-    dominant = sorted(kern)[0]
-
-  # ---- timed region: exactly K steps, barrier + sync on both sides ----
-  step_fn = lambda: lrn.minimize(unroll)
-  mode = 'eager'
-  if args.graph and world == 1:
-    try:
-      gs = learner.GraphedStep(r2l, unroll, iw, warmup=1) if r2 else learner.GraphedStep(lrn, unroll, warmup=1)
-      step_fn, mode = (lambda: gs()), 'hip-graph'
-      step_fn(); torch.cuda.synchronize()
-    except Exception as e:                       # pylint: disable=broad-except
-      sys.stderr.write('HIP-graph capture unavailable (%s); timing eager launches\n' % e)
-      step_fn, mode = (lambda: lrn.minimize(unroll)), 'eager'
-  prof = ops.Profiler(only=[dominant])
-  if mode == 'eager':
-    ops.set_profiler(prof)
-  barrier()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    out = step_fn()
-  barrier()
-  dt = time.perf_counter() - t0
-  ops.set_profiler(None)
-  loss = out[0]
-  if mode != 'eager':
-    # kernel time of the dominant kernel for the roofline: HIP events around it on the launch stream, in a
-    # few eager steps after the timed region (events cannot be recorded inside a replayed graph)
-    ops.set_profiler(prof)
-    for _ in range(min(args.steps, 5)):
-      lrn.minimize(unroll)
-    ops.set_profiler(None)
-  if world > 1:
-    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-    torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tt[0])
-  loss_val = float(loss)
-  assert np.isfinite(loss_val)
-
-  ms_per_step = dt / args.steps * 1e3
-  frames_per_s = world * B * T / (dt / args.steps)
-  d = prof.summary()[dominant]
-  flops, nbytes = d['flops'], d['bytes']
-  if flops > 0:
-    ach = flops / (d['avg_ms'] * 1e-3) / 1e12
-    bf16x3 = dominant in BF16X3_KERNELS and os.environ.get('SEEDHIP_STACK_BF16', '1') != '0'
-    peak = round(MFMA_BF16_PEAK_TF / 3.0, 1) if bf16x3 else MFMA_F32_PEAK_TF
-    roofline = dict(bound='mfma', kernel=dominant, achieved=round(ach, 2), peak=peak,
-                    unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
-                    pipe=('bf16 MFMA, exact 3-way split of the fp32 operand: peak = 2500 / 3 algorithmic TFLOP/s'
-                          if bf16x3 else 'fp32 MFMA (v_mfma_f32_16x16x4_f32)'),
-                    avg_kernel_ms=round(d['avg_ms'], 4), algorithmic_flops=flops, algorithmic_bytes=nbytes)
-  else:
-    ach = nbytes / (d['avg_ms'] * 1e-3) / 1e9
-    roofline = dict(bound='hbm', kernel=dominant, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, avg_kernel_ms=round(d['avg_ms'], 4),
-                    algorithmic_bytes=nbytes)
-
-  # HBM traffic of the dominant kernel from the committed PMC passes (same config only)
-  tfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_cfg2_traffic.json')))      # latest profiling round
-  tpath = tfiles[-1] if tfiles else ''
-  if args.config == 'atari' and args.torso == 'shallow' and B == 512 and T == 20 and A == 18 and tpath:
-    tb = json.load(open(tpath))['traffic_bytes']
-    if dominant in tb:
-      roofline['traffic'] = tb[dominant]
-      roofline['traffic_source'] = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)' % os.path.basename(tpath)
+  # HBM traffic of the dominant kernel from the committed PMC passes (same config only; latest profiling round)
+  tfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_cfg2_traffic.json')))
+  if headline and tfiles:
+    tb = json.load(open(tfiles[-1]))['traffic_bytes']
+    if rec['dominant'] in tb:
+      roofline['traffic'] = tb[rec['dominant']]
+      roofline['traffic_source'] = ('profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'
+                                    % os.path.basename(tfiles[-1]))
   if rank != 0:
     if distributed:
       torch.distributed.destroy_process_group()
     return
   result = {
-      'metric': 'learner env-frames/s (T=%d)' % T, 'value': round(frames_per_s, 1), 'unit': 'env-frames/s',
-      'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+      'metric': 'learner env-frames/s (T=%d)' % T, 'value': round(rec['frames_per_s'], 1), 'unit': 'env-frames/s',
+      'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(rec['ms_per_step'], 4),
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
       'config': {'workload': '%s, T=%d B=%d/GPU A=%d, synthetic uint8 frames in HBM, num_action_repeats=1'
-                             % (workload, T, B, A),
+                             % (rec['workload'], T, B, A),
                  'global_batch': B * world, 'unroll_length': T, 'parallelism': 'dp%d' % world,
-                 'grad_reduction': args.reduction, 'params': agent.flat.num_params(), 'launch': mode},
+                 'grad_reduction': args.reduction, 'params': rec['params'], 'launch': rec['mode'],
+                 'ingest': 'resident (unroll in HBM before the timed region)'},
       'roofline': roofline,
-      'loss': round(loss_val, 6),
-      'kernels_ms_per_step': {k: round(v['total_ms'], 4) for k, v in kern.items()},
-      # the other MFMA kernels of the attribution pass (>= 50 us per launch), same accounting as `roofline`
-      'mfma_kernels': {
-          k: dict(avg_ms=round(v['avg_ms'], 4), tflops=round(v['flops'] / (v['avg_ms'] * 1e-3) / 1e12, 1),
-                  frac=round(v['flops'] / (v['avg_ms'] * 1e-3) / 1e12 /
-                             (MFMA_BF16_PEAK_TF / 3.0 if (k in BF16X3_KERNELS and
-                                                          os.environ.get('SEEDHIP_STACK_BF16', '1') != '0')
-                              else MFMA_F32_PEAK_TF), 3))
-          for k, v in kern.items() if v['flops'] > 0 and v['avg_ms'] >= 0.05},
+      'loss': round(rec['loss'], 6),
+      'kernels_ms_per_step': rec['kernels_ms_per_step'],
+      'mfma_kernels': rec['mfma_kernels'],
   }
   if world == 1:
     err, err_ref, sweep = vtrace_checks(dev)
     result['vtrace_max_abs_err'] = err
     result['vtrace_max_abs_err_vs_reference_code'] = err_ref
     result['vtrace_scan_hbm'] = sweep
-    if not args.no_cpu_baseline:
-      from oracle import cpu_learner
-      if r2:
-        cb = args.cpu_batch if args.cpu_batch != 64 else 8
-        fps, sec, thr = cpu_learner.time_cpu_r2d2_learner(A, T1, cb, steps=2, warmup=1)
-      elif deep:
-        cb = args.cpu_batch if args.cpu_batch != 64 else 16
-        fps, sec, thr = cpu_learner.time_cpu_deep_learner(A, T1, cb, steps=2, warmup=1)
-      else:
-        cb = args.cpu_batch
-        kind = 'atari_shallow' if args.torso == 'shallow' else 'atari_dqn_body'
-        fps, sec, thr = cpu_learner.time_cpu_learner(kind, A, T1, cb, steps=3, warmup=1)
-      result['cpu_baseline'] = {
-          'value': round(fps, 1), 'unit': 'env-frames/s', 'cores': thr, 'kind': 'port',
-          'sample': 'same learner step as eager PyTorch-CPU fp32 restatement of the reference graph '
-                    '(oracle/cpu_learner.py), T=%d B=%d (per-frame cost is B-independent), median of timed '
-                    'steps, %.2f s/step; host cpu_count=%d' % (T, cb, sec, os.cpu_count())}
-      result['speedup_vs_cpu_baseline'] = round(frames_per_s / fps, 1)
+  if world == 1 and not args.quick:
+    from tests import parity
+    # one train step at the bench shape against the CPU oracle (outside the timed region; same code as
+    # tests/test_gpu_fullsize.py)
+    if r2:
+      p = parity.r2d2_step(dev, T1=T + 1, B=min(B, 4), A=A)
+    elif deep:
+      p = parity.deep_step(dev, T1=T + 1, B=min(B, 16), A=A)
+    else:
+      p = parity.atari_step(dev, T1=T + 1, B=B, A=A, torso=args.torso)
+    result['parity'] = dict(parity.public(p), note=PARITY_NOTE)
+    _release()
+    if headline:
+      others = {}
+      for name, cfg in (('dmlab', 'dmlab'), ('r2d2', 'r2d2')):
+        try:
+          r = run_learner(cfg, 5, 3, dev, graph=args.graph, attribution_steps=1)
+          others[name] = dict(
+              workload='%s, T=%d B=%d A=%d' % (r['workload'], r['T'], r['B'], r['A']), steps=5,
+              ms_per_step=round(r['ms_per_step'], 3), env_frames_per_s=round(r['frames_per_s'], 1), launch=r['mode'],
+              roofline={k: r['roofline'][k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
+                                                      'frac_free_running', 'avg_kernel_ms')},
+              loss=round(r['loss'], 6))
+        except Exception as e:                   # pylint: disable=broad-except
+          others[name] = dict(error=repr(e))
+      result['other_configs'] = others
+      try:
+        result['inference'] = inference_record(dev)
+      except Exception as e:                     # pylint: disable=broad-except
+        result['inference'] = dict(error=repr(e))
+      try:
+        result['ingest'] = ingest_record(dev, args.steps)
+      except Exception as e:                     # pylint: disable=broad-except
+        result['ingest'] = dict(error=repr(e))
+  elif world == 1 and args.ingest == 'pinned' and headline:
+    result['ingest'] = ingest_record(dev, args.steps)
+  if world == 1 and not args.no_cpu_baseline and not args.quick:
+    from oracle import cpu_learner
+    T1 = T + 1
+    if r2:
+      cb = args.cpu_batch if args.cpu_batch != 64 else 8
+      fps, sec, thr = cpu_learner.time_cpu_r2d2_learner(A, T1, cb, steps=2, warmup=1)
+    elif deep:
+      cb = args.cpu_batch if args.cpu_batch != 64 else 16
+      fps, sec, thr = cpu_learner.time_cpu_deep_learner(A, T1, cb, steps=2, warmup=1)
+    else:
+      cb = args.cpu_batch
+      kind = 'atari_shallow' if args.torso == 'shallow' else 'atari_dqn_body'
+      fps, sec, thr = cpu_learner.time_cpu_learner(kind, A, T1, cb, steps=5, warmup=2)
+    result['cpu_baseline'] = {
+        'value': round(fps, 1), 'unit': 'env-frames/s', 'cores': thr, 'kind': 'port',
+        'sample': 'same learner step as eager PyTorch-CPU fp32 restatement of the reference graph '
+                  '(oracle/cpu_learner.py; NOT the reference\'s TF graph), T=%d B=%d (per-frame cost is B-independent), '
+                  'median of timed steps, %.2f s/step; host cpu_count=%d' % (T, cb, sec, os.cpu_count())}
+    result['speedup_vs_cpu_baseline'] = round(rec['frames_per_s'] / fps, 1)
   print(json.dumps(result))
   if distributed:
     torch.distributed.destroy_process_group()

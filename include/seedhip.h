@@ -71,6 +71,8 @@ enum {
   SEEDHIP_LOSS_VALUE_MEAN = 7,  /* logged :139-140 */
   SEEDHIP_LOSS_V_L2_ERROR = 8,  /* logged :141 */
   SEEDHIP_LOSS_MAX_ACTION_ABS = 9, /* logged :152-153 */
+  SEEDHIP_LOSS_ENTROPY_COST = 10,  /* logged :155 (agent.entropy_cost()) */
+  SEEDHIP_LOSS_ENTROPY_ADJUSTMENT = 11, /* :128-132 */
   SEEDHIP_LOSS_NUM = 16
 };
 size_t seedhip_impala_loss_workspace_bytes(int T, int B);
@@ -82,19 +84,41 @@ int seedhip_impala_loss_fwd_bwd(
     float max_abs_reward, float clip_rho_threshold, float clip_pg_rho_threshold,
     float mean_denominator, float* d_policy_logits, float* d_baseline, float* vs, float* pg_advantages,
     float* scalars, void* workspace, size_t workspace_bytes, void* stream);
+/* The same head with the learner's LEARNABLE entropy cost (agents/vtrace/learner.py:225-234: the learner attaches
+ * entropy_cost_param = log(FLAGS.entropy_cost) / speed to every agent without an entropy_cost() of its own, and
+ * entropy_cost = exp(speed * param)) and the Lagrange-style adjustment loss of :127-135:
+ *   has_target_entropy: total += cost * stop_gradient(mean(H) - target_entropy),
+ *                       d_entropy_cost_param[0] = speed * cost * (mean(H) - target_entropy);
+ *   otherwise           the term is 0 * cost and the gradient 0 (never "None", :131-132).
+ * entropy_cost_param / d_entropy_cost_param are device scalars (the parameter lives in the flat parameter buffer, its
+ * gradient in the flat gradient buffer).  For the data-parallel 'mean' reduction pass target_entropy / world (each
+ * replica's mean(H) is already its share of the global mean). */
+int seedhip_impala_loss_fwd_bwd_adaptive(
+    const float* learner_policy_logits, int logits_ld, const float* learner_baseline, int baseline_ld,
+    const float* behaviour_policy_logits, const void* actions, int action_elem_size,
+    const float* rewards, const uint8_t* done, int T, int B, int A,
+    const float* entropy_cost_param, float entropy_cost_adjustment_speed, int has_target_entropy,
+    float target_entropy, float* d_entropy_cost_param,
+    float baseline_cost, float kl_cost, float discounting, float lambda_,
+    float max_abs_reward, float clip_rho_threshold, float clip_pg_rho_threshold,
+    float mean_denominator, float* d_policy_logits, float* d_baseline, float* vs, float* pg_advantages,
+    float* scalars, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- optimizer --------------------------------------------------------------------
  * Replaces the Keras Adam apply_gradients of agents/vtrace/learner.py:272-275
  * (dmlab/vtrace_main.py:46-51) over ONE flat parameter buffer.  lr_t already
  * includes the bias correction (host, fp64).  grad_scale multiplies the gradient
- * first (1/world for data-parallel mean; 1 for the reference cross-replica SUM). */
+ * first (1/world for data-parallel mean; 1 for the reference cross-replica SUM).
+ * clamp_index >= 0: params[clamp_index] carries a Keras variable constraint (the entropy-cost parameter's
+ * clip_by_value(v, -20/speed, 20/speed), learner.py:228-230), applied after its update; -1: none. */
 int seedhip_adam_flat(float* params, const float* grads, float* m, float* v, long long n,
-                      float lr_t, float beta_1, float beta_2, float epsilon, float grad_scale, void* stream);
+                      float lr_t, float beta_1, float beta_2, float epsilon, float grad_scale,
+                      long long clamp_index, float clamp_lo, float clamp_hi, void* stream);
 /* Same update with lr_t read from a device scalar, so that a whole train step (whose only per-step host
  * value is the bias-corrected learning rate) can be captured once in a HIP graph and replayed. */
 int seedhip_adam_flat_dev_lr(float* params, const float* grads, float* m, float* v, long long n,
                              const float* lr_t_device, float beta_1, float beta_2, float epsilon,
-                             float grad_scale, void* stream);
+                             float grad_scale, long long clamp_index, float clamp_lo, float clamp_hi, void* stream);
 /* tf.clip_by_global_norm(grads, clip_norm) of agents/r2d2/learner.py:606-609; sumsq_out[0] = |g|^2.
  * clip_norm <= 0: only compute the norm. */
 size_t seedhip_global_norm_workspace_bytes(void);

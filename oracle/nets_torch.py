@@ -317,8 +317,11 @@ def vtrace_torch(tgt_lp, beh_lp, discounts, rewards, values, bootstrap,
 
 def impala_loss_torch(logits, baseline, beh_logits, actions, rewards, done,
                       entropy_cost=0.00025, baseline_cost=0.5, kl_cost=0.0,
-                      discounting=0.99, lambda_=1.0, max_abs_reward=0.0):
-  """agents/vtrace/learner.py:82-135, unfused eager ops."""
+                      discounting=0.99, lambda_=1.0, max_abs_reward=0.0,
+                      entropy_cost_param=None, entropy_cost_adjustment_speed=10.0, target_entropy=None):
+  """agents/vtrace/learner.py:82-135, unfused eager ops.  entropy_cost_param (a 0-d tensor, usually with
+  requires_grad): the learner's learnable entropy cost exp(speed * param) (learner.py:225-234) with the
+  Lagrange-style adjustment loss of :127-132 when target_entropy is set."""
   bootstrap = baseline[-1]
   tl, bl, vals = logits[:-1], beh_logits[:-1], baseline[:-1]
   act = actions[:-1].long()
@@ -335,9 +338,18 @@ def impala_loss_torch(logits, baseline, beh_logits, actions, rewards, done,
   v_loss = baseline_cost * 0.5 * ((vs - vals) ** 2).mean()
   entropy = (-(tls.exp() * tls).sum(-1)).mean()
   kl_loss = kl_cost * (beh_lp - tgt_lp).mean()
-  total = policy_loss + v_loss + entropy_cost * -entropy + kl_loss
+  adjustment = 0.0
+  if entropy_cost_param is not None:
+    cost = torch.exp(entropy_cost_adjustment_speed * entropy_cost_param)          # learner.py:233
+    entropy_cost = cost.detach()                                                  # :121 stop_gradient
+    if target_entropy:
+      adjustment = cost * (entropy.detach() - target_entropy)                     # :128-130
+    else:
+      adjustment = 0. * cost                                                      # :131-132
+  total = policy_loss + v_loss + entropy_cost * -entropy + kl_loss + adjustment
   return total, dict(policy_loss=policy_loss, v_loss=v_loss, entropy=entropy,
-                     kl_loss=kl_loss, vs=vs, pg_advantages=pg)
+                     kl_loss=kl_loss, vs=vs, pg_advantages=pg, entropy_cost=entropy_cost,
+                     entropy_adjustment_loss=adjustment)
 
 
 class KerasAdam:

@@ -43,8 +43,15 @@ SIGNATURES = {
         (c_int, [P, c_int, P, c_int, P, P, c_int, P, P, c_int, c_int, c_int,
                  c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float,
                  P, P, P, P, P, P, c_size_t, P]),
-    'seedhip_adam_flat': (c_int, [P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, P]),
-    'seedhip_adam_flat_dev_lr': (c_int, [P, P, P, P, c_ll, P, c_float, c_float, c_float, c_float, P]),
+    'seedhip_impala_loss_fwd_bwd_adaptive':
+        (c_int, [P, c_int, P, c_int, P, P, c_int, P, P, c_int, c_int, c_int,
+                 P, c_float, c_int, c_float, P,
+                 c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float,
+                 P, P, P, P, P, P, c_size_t, P]),
+    'seedhip_adam_flat': (c_int, [P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float,
+                                  c_ll, c_float, c_float, P]),
+    'seedhip_adam_flat_dev_lr': (c_int, [P, P, P, P, c_ll, P, c_float, c_float, c_float, c_float,
+                                         c_ll, c_float, c_float, P]),
     'seedhip_global_norm_workspace_bytes': (c_size_t, []),
     'seedhip_clip_by_global_norm': (c_int, [P, c_ll, c_float, P, P, c_size_t, P]),
     'seedhip_stack_prepare': (c_int, [P, P, c_int, c_int, c_ll, P, P, P]),

@@ -7,6 +7,8 @@
 //   m += (g - m)(1 - b1);  v += (g*g - v)(1 - b2);  p -= lr_t * m / (sqrt(v) + eps)
 // with lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) computed by the host in fp64.
 // `grad_scale` folds the data-parallel 1/world (mean) or 1 (reference SUM) in.
+// `clamp_index` (>= 0) names ONE element that carries a Keras variable constraint (the learner's entropy-cost
+// parameter, agents/vtrace/learner.py:225-232: clip to [-20/speed, 20/speed]), applied after its update; -1 = none.
 // HBM-bound: 16 B read + 12 B written per parameter.
 #include "common.h"
 #include "../../include/seedhip.h"
@@ -15,7 +17,8 @@ namespace {
 __global__ void __launch_bounds__(256)
 adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                  float* __restrict__ v, long long n, float lr_host, const float* __restrict__ lr_dev,
-                 float one_minus_b1, float one_minus_b2, float eps, float grad_scale) {
+                 float one_minus_b1, float one_minus_b2, float eps, float grad_scale,
+                 long long clamp_index, float clamp_lo, float clamp_hi) {
   const float lr_t = lr_dev ? lr_dev[0] : lr_host;   // device scalar: the step can sit in a captured HIP graph
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long n4 = n >> 2;
@@ -31,6 +34,12 @@ adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __re
       pp.c -= lr_t * mm.c / (sqrtf(vv.c) + eps); }
     UPD(x) UPD(y) UPD(z) UPD(w)
 #undef UPD
+    if (i == (clamp_index >> 2)) {                 // Keras variable constraint, applied after the update
+      float q[4] = {pp.x, pp.y, pp.z, pp.w};
+      const int c = (int)(clamp_index & 3);
+      q[c] = fminf(fmaxf(q[c], clamp_lo), clamp_hi);
+      pp = make_float4(q[0], q[1], q[2], q[3]);
+    }
     reinterpret_cast<float4*>(p)[i] = pp;
     reinterpret_cast<float4*>(m)[i] = mm;
     reinterpret_cast<float4*>(v)[i] = vv;
@@ -41,7 +50,9 @@ adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __re
     float mm = m[i], vv = v[i];
     mm += (gs - mm) * one_minus_b1;
     vv += (gs * gs - vv) * one_minus_b2;
-    p[i] -= lr_t * mm / (sqrtf(vv) + eps);
+    float pn = p[i] - lr_t * mm / (sqrtf(vv) + eps);
+    if (i == clamp_index) pn = fminf(fmaxf(pn, clamp_lo), clamp_hi);
+    p[i] = pn;
     m[i] = mm; v[i] = vv;
   }
 }
@@ -77,8 +88,9 @@ constexpr int kSumsqBlocks = 512;
 
 extern "C" int seedhip_adam_flat(float* params, const float* grads, float* m, float* v, long long n,
                                  float lr_t, float beta_1, float beta_2, float epsilon, float grad_scale,
-                                 void* stream) {
+                                 long long clamp_index, float clamp_lo, float clamp_hi, void* stream) {
   SEEDHIP_REQUIRE(n >= 0, "adam: negative n");
+  SEEDHIP_REQUIRE(clamp_index < n, "adam: clamp_index %lld out of range", clamp_index);
   if (n == 0) return SEEDHIP_OK;
   SEEDHIP_REQUIRE(params && grads && m && v, "adam: null pointer");
   SEEDHIP_REQUIRE(((((uintptr_t)params) | ((uintptr_t)grads) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0,
@@ -86,14 +98,17 @@ extern "C" int seedhip_adam_flat(float* params, const float* grads, float* m, fl
   int blocks = seedhip::cdiv(n / 4 + 1, 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n,
-                     lr_t, (const float*)nullptr, 1.0f - beta_1, 1.0f - beta_2, epsilon, grad_scale);
+                     lr_t, (const float*)nullptr, 1.0f - beta_1, 1.0f - beta_2, epsilon, grad_scale, clamp_index,
+                     clamp_lo, clamp_hi);
   return seedhip::check_launch("adam_flat_kernel");
 }
 
 extern "C" int seedhip_adam_flat_dev_lr(float* params, const float* grads, float* m, float* v, long long n,
                                         const float* lr_t_device, float beta_1, float beta_2, float epsilon,
-                                        float grad_scale, void* stream) {
+                                        float grad_scale, long long clamp_index, float clamp_lo, float clamp_hi,
+                                        void* stream) {
   SEEDHIP_REQUIRE(n >= 0, "adam: negative n");
+  SEEDHIP_REQUIRE(clamp_index < n, "adam: clamp_index %lld out of range", clamp_index);
   if (n == 0) return SEEDHIP_OK;
   SEEDHIP_REQUIRE(params && grads && m && v && lr_t_device, "adam: null pointer");
   SEEDHIP_REQUIRE(((((uintptr_t)params) | ((uintptr_t)grads) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0,
@@ -101,7 +116,8 @@ extern "C" int seedhip_adam_flat_dev_lr(float* params, const float* grads, float
   int blocks = seedhip::cdiv(n / 4 + 1, 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n,
-                     0.f, lr_t_device, 1.0f - beta_1, 1.0f - beta_2, epsilon, grad_scale);
+                     0.f, lr_t_device, 1.0f - beta_1, 1.0f - beta_2, epsilon, grad_scale, clamp_index, clamp_lo,
+                     clamp_hi);
   return seedhip::check_launch("adam_flat_kernel");
 }
 

@@ -61,6 +61,8 @@ struct LossParams {
   float entropy_cost, baseline_cost, kl_cost, discounting, lambda_, max_abs_reward;
   float clip_rho, clip_pg_rho;
   float inv_n;               // 1 / mean_denominator
+  const float* ec_param;     // learnable entropy cost: cost = exp(ec_mul * ec_param[0]) (learner.py:225-234); null = fixed
+  float ec_mul;
   float* d_logits;           // [T+1,B,A]
   float* d_baseline;         // [T+1,B]
   float* vs;                 // [T,B] or null
@@ -168,6 +170,9 @@ impala_loss_kernel(LossParams p) {
   __syncthreads();
 
   // ---------------- phase 3: gradients + loss partial sums ----------------- //
+  // entropy cost: a flag value, or exp(speed * param) of the learner's Lagrange-style parameter; either way a constant
+  // for these gradients (stop_gradient, learner.py:121)
+  const float ec = p.ec_param ? expf(p.ec_mul * p.ec_param[0]) : p.entropy_cost;
   float acc_pg = 0.f, acc_v2 = 0.f, acc_ent = 0.f, acc_kl = 0.f, acc_val = 0.f, acc_maxa = 0.f;
   for (int r = grp; r < nrows; r += kGroups) {
     const int t = r / CB, c = r - t * CB;
@@ -184,7 +189,7 @@ impala_loss_kernel(LossParams p) {
     const long long act = load_action(p.actions, p.action_elem_size, tb);
     const float lse = s_lse[r], ent = s_ent[r], pg = s_pg[r], vs = s_vs[r], v = s_val[r];
     const float coef = (pg + p.kl_cost) * p.inv_n;  // policy-gradient + KL terms share (1[j=a]-p_j)
-    const float ecn = p.entropy_cost * p.inv_n;
+    const float ecn = ec * p.inv_n;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
       const int a = sub + e * kLPR;
@@ -226,8 +231,13 @@ impala_loss_kernel(LossParams p) {
 }
 
 // scalars[]: see SEEDHIP_LOSS_* indices in seedhip.h.
+// Entropy-cost adjustment (learner.py:127-135, :225-234): with a learnable parameter theta the cost is
+// c = exp(speed * theta); entropy_adjustment_loss = c * stop_gradient(mean(H) - target) when a target entropy is set
+// (its only gradient: d/dtheta = speed * c * (mean(H) - target)), and 0 * c otherwise (gradient 0, never None).
 __global__ void impala_loss_finalize_kernel(const float* __restrict__ partials, int nblocks, float inv_n,
                                             float entropy_cost, float baseline_cost, float kl_cost,
+                                            const float* __restrict__ ec_param, float ec_mul, int has_target,
+                                            float target_entropy_share, float* __restrict__ d_ec_param,
                                             float* __restrict__ scalars) {
   // One wave; each lane sums a strided subset in fixed order, then a shuffle tree.
   float o[6] = {0, 0, 0, 0, 0, 0};
@@ -238,6 +248,7 @@ __global__ void impala_loss_finalize_kernel(const float* __restrict__ partials, 
   for (int k = 0; k < 5; ++k) o[k] = seedhip::wave_sum(o[k]);
   o[5] = seedhip::wave_max(o[5]);
   if (threadIdx.x == 0) {
+    if (ec_param) entropy_cost = expf(ec_mul * ec_param[0]);
     const float policy_loss = -(o[0] * inv_n);                        // learner.py:111-112
     const float mse = o[1] * inv_n;
     const float v_loss = baseline_cost * 0.5f * mse;                  // :115-116
@@ -245,7 +256,10 @@ __global__ void impala_loss_finalize_kernel(const float* __restrict__ partials, 
     const float entropy_loss = entropy_cost * -entropy;               // :121
     const float kl_mean = o[3] * inv_n;
     const float kl_loss = kl_cost * kl_mean;                          // :124-125
-    scalars[SEEDHIP_LOSS_TOTAL] = policy_loss + v_loss + entropy_loss + kl_loss;  // :134-135
+    float adjustment = 0.f;                                           // :128-132
+    if (has_target) adjustment = entropy_cost * (entropy - target_entropy_share);
+    if (d_ec_param) d_ec_param[0] = has_target ? ec_mul * entropy_cost * (entropy - target_entropy_share) : 0.f;
+    scalars[SEEDHIP_LOSS_TOTAL] = policy_loss + v_loss + entropy_loss + kl_loss + adjustment;  // :134-135
     scalars[SEEDHIP_LOSS_POLICY] = policy_loss;
     scalars[SEEDHIP_LOSS_V] = v_loss;
     scalars[SEEDHIP_LOSS_ENTROPY] = entropy_loss;
@@ -255,6 +269,8 @@ __global__ void impala_loss_finalize_kernel(const float* __restrict__ partials, 
     scalars[SEEDHIP_LOSS_VALUE_MEAN] = o[4] * inv_n;                  // :138-140
     scalars[SEEDHIP_LOSS_V_L2_ERROR] = sqrtf(mse);                    // :141
     scalars[SEEDHIP_LOSS_MAX_ACTION_ABS] = o[5];                      // :152-153
+    scalars[SEEDHIP_LOSS_ENTROPY_COST] = entropy_cost;                // :155
+    scalars[SEEDHIP_LOSS_ENTROPY_ADJUSTMENT] = adjustment;
   }
 }
 
@@ -273,14 +289,16 @@ extern "C" size_t seedhip_impala_loss_workspace_bytes(int T, int B) {
   return (size_t)nblocks * kNumPartials * sizeof(float);
 }
 
-extern "C" int seedhip_impala_loss_fwd_bwd(
+namespace {
+int impala_loss_impl(
     const float* learner_policy_logits, int logits_ld, const float* learner_baseline, int baseline_ld,
     const float* behaviour_policy_logits, const void* actions, int action_elem_size,
     const float* rewards, const uint8_t* done, int T, int B, int A,
     float entropy_cost, float baseline_cost, float kl_cost, float discounting, float lambda_,
     float max_abs_reward, float clip_rho_threshold, float clip_pg_rho_threshold,
     float mean_denominator, float* d_policy_logits, float* d_baseline, float* vs, float* pg_advantages,
-    float* scalars, void* workspace, size_t workspace_bytes, void* stream) {
+    float* scalars, void* workspace, size_t workspace_bytes, void* stream,
+    const float* ec_param, float ec_mul, int has_target, float target_share, float* d_ec_param) {
   SEEDHIP_REQUIRE(T >= 1 && B >= 1 && A >= 1, "impala_loss: need T>=1,B>=1,A>=1 (got %d,%d,%d)", T, B, A);
   SEEDHIP_REQUIRE(A <= kLPR * 16, "impala_loss: A=%d > %d unsupported", A, kLPR * 16);
   SEEDHIP_REQUIRE(logits_ld >= A && baseline_ld >= 1, "impala_loss: bad row strides");
@@ -301,6 +319,7 @@ extern "C" int seedhip_impala_loss_fwd_bwd(
   p.inv_n = 1.0f / mean_denominator;
   p.d_logits = d_policy_logits; p.d_baseline = d_baseline; p.vs = vs; p.pg_adv = pg_advantages;
   p.partials = (float*)workspace;
+  p.ec_param = ec_param; p.ec_mul = ec_mul;
   hipStream_t s = (hipStream_t)stream;
   const int nblocks = (B + kCB - 1) / kCB;
   if (lds > 48 * 1024) {
@@ -319,8 +338,44 @@ extern "C" int seedhip_impala_loss_fwd_bwd(
   int rc = seedhip::check_launch("impala_loss_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(impala_loss_finalize_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, nblocks,
-                     p.inv_n, entropy_cost, baseline_cost, kl_cost, scalars);
+                     p.inv_n, entropy_cost, baseline_cost, kl_cost, ec_param, ec_mul, has_target, target_share,
+                     d_ec_param, scalars);
   return seedhip::check_launch("impala_loss_finalize_kernel");
+}
+}  // namespace
+
+extern "C" int seedhip_impala_loss_fwd_bwd(
+    const float* learner_policy_logits, int logits_ld, const float* learner_baseline, int baseline_ld,
+    const float* behaviour_policy_logits, const void* actions, int action_elem_size,
+    const float* rewards, const uint8_t* done, int T, int B, int A,
+    float entropy_cost, float baseline_cost, float kl_cost, float discounting, float lambda_,
+    float max_abs_reward, float clip_rho_threshold, float clip_pg_rho_threshold,
+    float mean_denominator, float* d_policy_logits, float* d_baseline, float* vs, float* pg_advantages,
+    float* scalars, void* workspace, size_t workspace_bytes, void* stream) {
+  return impala_loss_impl(learner_policy_logits, logits_ld, learner_baseline, baseline_ld, behaviour_policy_logits,
+                          actions, action_elem_size, rewards, done, T, B, A, entropy_cost, baseline_cost, kl_cost,
+                          discounting, lambda_, max_abs_reward, clip_rho_threshold, clip_pg_rho_threshold,
+                          mean_denominator, d_policy_logits, d_baseline, vs, pg_advantages, scalars, workspace,
+                          workspace_bytes, stream, nullptr, 0.f, 0, 0.f, nullptr);
+}
+
+extern "C" int seedhip_impala_loss_fwd_bwd_adaptive(
+    const float* learner_policy_logits, int logits_ld, const float* learner_baseline, int baseline_ld,
+    const float* behaviour_policy_logits, const void* actions, int action_elem_size,
+    const float* rewards, const uint8_t* done, int T, int B, int A,
+    const float* entropy_cost_param, float entropy_cost_adjustment_speed, int has_target_entropy,
+    float target_entropy, float* d_entropy_cost_param,
+    float baseline_cost, float kl_cost, float discounting, float lambda_,
+    float max_abs_reward, float clip_rho_threshold, float clip_pg_rho_threshold,
+    float mean_denominator, float* d_policy_logits, float* d_baseline, float* vs, float* pg_advantages,
+    float* scalars, void* workspace, size_t workspace_bytes, void* stream) {
+  SEEDHIP_REQUIRE(entropy_cost_param && d_entropy_cost_param, "impala_loss_adaptive: null entropy-cost parameter");
+  return impala_loss_impl(learner_policy_logits, logits_ld, learner_baseline, baseline_ld, behaviour_policy_logits,
+                          actions, action_elem_size, rewards, done, T, B, A, 0.f, baseline_cost, kl_cost,
+                          discounting, lambda_, max_abs_reward, clip_rho_threshold, clip_pg_rho_threshold,
+                          mean_denominator, d_policy_logits, d_baseline, vs, pg_advantages, scalars, workspace,
+                          workspace_bytes, stream, entropy_cost_param, entropy_cost_adjustment_speed,
+                          has_target_entropy, target_entropy, d_entropy_cost_param);
 }
 
 // ---- categorical log_prob / entropy (common/parametric_distribution.py:69-74) ---- //

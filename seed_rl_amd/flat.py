@@ -24,6 +24,7 @@ class FlatParams(object):
       off += (int(np.prod(s)) + 3) // 4 * 4
     self.size = off
     self.device = device
+    self.constraint = None      # (flat index, lo, hi): one element with a Keras variable constraint (optimizers.Adam)
     self.params = torch.zeros(off, dtype=torch.float32, device=device)
     self.grads = torch.zeros(off, dtype=torch.float32, device=device)
     self._views = {}

@@ -76,19 +76,33 @@ def compute_loss(logger, parametric_action_distribution, agent, agent_state, pre
   ws = agent._buf('loss_ws', (ops.impala_loss_workspace_bytes(T, B) // 4 + 4,))
   vs = agent._buf('vs', (T, B)) if want_vtrace else None
   pg = agent._buf('pg', (T, B)) if want_vtrace else None
-  entropy_cost = float(agent.entropy_cost())
+  # entropy cost: the agent's own constant, or the learner's learnable parameter (learner.py:121, 127-135, 225-234)
+  ecp = agent.entropy_cost_param() if hasattr(agent, 'entropy_cost_param') else None
+  own = agent.entropy_cost() if ecp is None else None
+  if ecp is not None:
+    share = None
+    if cfg.target_entropy:
+      # data-parallel 'mean': every replica's mean(H) is its SHARE of the global mean, so it takes its share of the target
+      share = cfg.target_entropy * float(T * B) / float(mean_denominator or T * B)
+    ekw = dict(entropy_cost_param=ecp[0], d_entropy_cost_param=ecp[1], entropy_cost_adjustment_speed=ecp[2],
+              target_entropy=share)
+  else:
+    if cfg.target_entropy:
+      raise ValueError('target_entropy needs the learnable entropy cost: construct the agent without its own '
+                       'entropy_cost and pass it to a Learner (agents/vtrace/learner.py:225-234)')
+    ekw = dict(entropy_cost=float(cfg.entropy_cost if own is None else own))
   flat_head = head.view(-1)
   flat_dhead = d_head.view(-1)
   ops.impala_loss_fwd_bwd(
       flat_head, ldh, flat_head[A:], ldh, beh_logits, actions, rewards, done_u8, T, B, A,
       flat_dhead, flat_dhead[A:], scalars, ws, vs, pg,
-      entropy_cost=entropy_cost, baseline_cost=cfg.baseline_cost, kl_cost=cfg.kl_cost,
+      baseline_cost=cfg.baseline_cost, kl_cost=cfg.kl_cost,
       discounting=cfg.discounting, lambda_=cfg.lambda_, max_abs_reward=cfg.max_abs_reward,
-      mean_denominator=mean_denominator)
+      mean_denominator=mean_denominator, **ekw)
   session = logger.log_session()
   for name, idx in LOGGED.items():
     logger.log(session, name, scalars[idx])
-  logger.log(session, 'policy/entropy_cost', entropy_cost)
+  logger.log(session, 'policy/entropy_cost', scalars[10])
   if want_vtrace:
     session['vtrace/vs'] = vs
     session['vtrace/pg_advantages'] = pg
@@ -137,6 +151,10 @@ class Learner(object):
     if torch.distributed.is_available() and torch.distributed.is_initialized():
       self.world = torch.distributed.get_world_size(process_group)
     self._pending = []
+    # learner.py:225-234: an agent without an entropy_cost of its own gets the learnable one
+    if hasattr(agent, 'has_own_entropy_cost') and not agent.has_own_entropy_cost():
+      if agent.entropy_cost_param() is None:
+        agent.attach_entropy_cost_param(self.config.entropy_cost, self.config.entropy_cost_adjustment_speed)
 
   def compute_gradients(self, unroll):
     T1, B = unroll.env_outputs.done.shape[0], unroll.env_outputs.done.shape[1]
@@ -213,6 +231,17 @@ class GraphedStep(object):
     if not getattr(learner.optimizer, 'capturable', False):
       raise ValueError('GraphedStep needs optimizers.Adam(..., capturable=True)')
     self.learner, self.unroll, self.extra = learner, unroll, extra
+    # The warm-up below runs REAL optimizer steps on whatever the static unroll buffers hold: everything they touch
+    # is put back after the capture, so that a graphed learner starts from exactly the state an eager one would
+    # (parameters, Adam moments and step counter -- with it the LR-schedule position --, R2D2 target network and
+    # target-update phase).
+    opt = learner.optimizer
+    agents = [a for a in (learner.agent, getattr(learner, 'target_agent', None)) if a is not None]
+    saved_params = [a.flat.params.clone() for a in agents]
+    sd0 = opt.state_dict()
+    saved_opt = dict(iterations=sd0['iterations'], m=None if sd0['m'] is None else sd0['m'].clone(),
+                     v=None if sd0['v'] is None else sd0['v'].clone())
+    counters = dict((k, getattr(learner, k)) for k in ('iterations',) if hasattr(learner, k))
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -220,10 +249,7 @@ class GraphedStep(object):
         learner.minimize(unroll, *extra)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    opt = learner.optimizer
     opt.begin_step(learner.agent.flat.params.device)
-    it0 = opt.iterations
-    counters = dict((k, getattr(learner, k)) for k in ('iterations',) if hasattr(learner, k))
     self.split = getattr(learner, 'world', 1) > 1
     self.graph = torch.cuda.CUDAGraph()
     self.graph2 = None
@@ -237,9 +263,22 @@ class GraphedStep(object):
       self.graph2 = torch.cuda.CUDAGraph()
       with torch.cuda.graph(self.graph2, capture_error_mode='relaxed'):
         learner.update()
-    opt.iterations = it0                            # capture ran the Python bookkeeping, not the kernels
+    # undo the warm-up (in place: the graphs hold these buffers' addresses); the capture itself ran only the Python
+    # bookkeeping, not the kernels
+    for a, p0 in zip(agents, saved_params):
+      a.flat.params.copy_(p0)
+    sd = opt.state_dict()
+    for k in ('m', 'v'):
+      if sd[k] is not None:
+        if saved_opt[k] is None:
+          sd[k].zero_()
+        else:
+          sd[k].copy_(saved_opt[k])
+    opt.iterations = saved_opt['iterations']
     for k, v in counters.items():
       setattr(learner, k, v)
+    self._agents = agents
+    torch.cuda.synchronize()
 
   def __call__(self):
     opt = self.learner.optimizer
@@ -252,4 +291,15 @@ class GraphedStep(object):
     post = getattr(self.learner, 'after_graph_replay', None)
     if post is not None:
       post()
+    # the persistent LSTM kernels' abort flags: mirrored to pinned host memory after every replay and looked at
+    # before the next one (by then the copy has landed: no sync) -- a wait that timed out during a replay raises here
+    for a in self._agents:
+      if getattr(a, '_last_lstm', None) is not None:
+        a._lstm_seq_check()                         # pylint: disable=protected-access
+        a.mirror_error_flags()
     return self.outputs
+
+  def check_errors(self):
+    """Blocking: raises if any replayed step's LSTM sequence kernel aborted."""
+    for a in self._agents:
+      a.check_errors()

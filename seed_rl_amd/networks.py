@@ -87,14 +87,52 @@ class _Agent(object):
       feat = shapes['policy_logits/kernel'][0]
       internal.append(('heads/kernel', (feat, self._ldh)))
       internal.append(('heads/bias', (self._ldh,)))
+      # slot of the learner's learnable entropy cost (agents/vtrace/learner.py:225-234); inert (value 0, gradient 0)
+      # until a Learner attaches it: attach_entropy_cost_param()
+      internal.append(('entropy_cost_param', (1,)))
     self.flat = FlatParams(internal, self.device)
     self.load_reference_params(keras_init(ref_spec, seed))
+    self._ec_speed = None
+
+  # -- entropy cost (agents/vtrace/learner.py:121,127-135,225-234) ----------------------------------------------- #
+  def has_own_entropy_cost(self):
+    """True for an agent constructed with an explicit entropy_cost (the reference's `hasattr(agent, 'entropy_cost')`):
+    the learner then leaves it alone; otherwise it attaches the learnable parameter."""
+    return getattr(self, '_entropy_cost', None) is not None
+
+  def attach_entropy_cost_param(self, entropy_cost, adjustment_speed):
+    """learner.py:225-234: entropy_cost_param = log(FLAGS.entropy_cost) / speed, a TRAINABLE scalar constrained to
+    [-20/speed, 20/speed]; entropy_cost() = exp(speed * param).  The parameter is one more element of the flat buffer
+    (Adam and the gradient all-reduce see it like any other), its constraint is applied by the Adam kernel."""
+    mul = np.float32(adjustment_speed)
+    if self._ec_speed is None:
+      self._ref_spec = list(self._ref_spec) + [('entropy_cost_param', (1,), 'zeros')]
+    self._ec_speed = float(mul)
+    with torch.no_grad():
+      self.flat.p('entropy_cost_param').fill_(float(np.log(np.float32(entropy_cost)) / mul))
+    self.flat.constraint = (self.flat.offsets['entropy_cost_param'], float(-20.0 / mul), float(20.0 / mul))
+
+  def entropy_cost_param(self):
+    """(param, d_param, speed) device scalars of the attached learnable entropy cost, or None."""
+    if self._ec_speed is None:
+      return None
+    return self.flat.p('entropy_cost_param'), self.flat.g('entropy_cost_param'), self._ec_speed
+
+  def entropy_cost(self):
+    """agent.entropy_cost() of the reference: the agent's own constant, or exp(speed * param) as a device tensor."""
+    if self.has_own_entropy_cost():
+      return self._entropy_cost
+    if self._ec_speed is not None:
+      return torch.exp(self._ec_speed * self.flat.p('entropy_cost_param'))[0]
+    return None
 
   def load_reference_params(self, values):
     """values: {reference variable name: numpy array} (Keras layouts)."""
     A = self._num_actions
     with torch.no_grad():
       for name, shape, _ in self._ref_spec:
+        if name == 'entropy_cost_param' and name not in values:
+          continue                                   # checkpoints written before the parameter was attached
         v = torch.as_tensor(np.asarray(values[name], np.float32)).to(self.device)
         if name == 'policy_logits/kernel':
           self.flat.p('heads/kernel')[:, :A] = v
@@ -146,9 +184,6 @@ class _Agent(object):
       t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=self.device)
       self._ws[k] = t
     return t
-
-  def entropy_cost(self):
-    raise NotImplementedError
 
   def get_action(self, *args, **kwargs):
     return self.__call__(*args, **kwargs)
@@ -209,8 +244,7 @@ class _Agent(object):
         self._lstm_seq_check()
       ops.lstm_seq_fwd(Up, Zx3, done_u8, T1, B, H, Z, Hout, H, Hin, Cin, self._buf('lstm_seq_sync', (2,), torch.int32))
       if not capturing:
-        self._seq_flag[0:1].copy_(self._buf('lstm_seq_sync', (2,), torch.int32)[1:2], non_blocking=True)
-        self._seq_event.record()
+        self.mirror_error_flags()
     for t in range(0 if not fused_seq else T1, T1):
       done_next = done_u8[t + 1] if t + 1 < T1 else None
       if fused_step:
@@ -221,6 +255,25 @@ class _Agent(object):
     self._last_lstm = dict(X=X, ldx=ldx, in_dim=in_dim, H=H, T1=T1, B=B, done=done_u8, gx=gx, gu=gu, Z=Z, Hin=Hin,
                            Cin=Cin, Hout=Hout, prefix=prefix, fused_seq=seq_ok)
     return Hout, (Hin[T1].clone(), Cin[T1].clone())
+
+  def mirror_error_flags(self):
+    """Asynchronous device -> pinned-host copy of the sequence kernels' abort flags (forward, backward) on the current
+    stream.  Called after every eager launch, and by learner.GraphedStep after every graph replay (inside a captured
+    graph the launches cannot do it themselves): `_lstm_seq_check()` / `check_errors()` then see a timed-out wait of a
+    REPLAYED step too, one step late and without a host sync."""
+    if getattr(self, '_seq_flag', None) is None:
+      return
+    for slot, key in ((0, 'lstm_seq_sync'), (1, 'lstm_seq_sync_bwd')):
+      t = self._ws.get((key, (2,), torch.int32))
+      if t is not None:
+        self._seq_flag[slot:slot + 1].copy_(t[1:2], non_blocking=True)
+    self._seq_event.record()
+
+  def check_errors(self):
+    """Blocking check of the LSTM sequence kernels' abort flags (raises RuntimeError if a bounded wait timed out)."""
+    if getattr(self, '_seq_flag', None) is not None:
+      self.mirror_error_flags()
+      self._lstm_seq_check(wait=True)
 
   def _lstm_seq_check(self, wait=False):
     """lstm_seq_fwd reports a timed-out grid barrier through a device flag; it is mirrored into pinned host memory
@@ -259,8 +312,7 @@ class _Agent(object):
       ops.lstm_seq_bwd(self._buf(prefix + '_u_perm', (H, 4 * H)), L['Z'], L['Cin'], dHout, H, L['done'], T1, B, H, dZ,
                        ring, sync)
       if not capturing:
-        self._seq_flag[1:2].copy_(sync[1:2], non_blocking=True)
-        self._seq_event.record()
+        self.mirror_error_flags()
     for t in range(T1 - 1, -1 if not fused_seq else T1 - 1, -1):
       ops.lstm_gates_bwd(L['Z'][t], L['Cin'][t], dH3[t], H, dh_rec, dc_rec,
                          L['done'][t + 1] if t + 1 < T1 else None, B, H, dZ[t], dcb[t & 1])
@@ -308,7 +360,9 @@ class _AtariTorso(object):
     """uint8 [3+T1, B, H*W] trajectory buffer; rows 3.. are the unroll's frames.  A data
     pipeline can write observations straight into `frames_buffer(T1,B)[3:]` (time-major)
     and pass that view as env_outputs.observation: no copy is made then."""
-    return self._buf('frames_ext', (T1 + 3, B, self._obs[0] * self._obs[1]), torch.uint8, zero=True)
+    slot = getattr(self, 'frames_slot', 0)      # double buffering: a copy stream fills slot 1 - s while slot s is read
+    return self._buf('frames_ext' if not slot else 'frames_ext%d' % slot, (T1 + 3, B, self._obs[0] * self._obs[1]),
+                     torch.uint8, zero=True)
 
   def _torso_fwd(self, obs, done_u8, frame_state, out, ld_out, need_state=True):
     """obs uint8 [T1,B,H,W,1]; writes relu(fc) into out[:, :fc] (row stride ld_out).  Returns the new
@@ -379,7 +433,7 @@ class AtariShallow(_Agent, _AtariTorso):
   """Frame-stacked Atari policy/value agent (see module docstring, D1)."""
 
   def __init__(self, num_actions, observation_shape=(84, 84, 1), torso='shallow', device='cuda', seed=0,
-               entropy_cost=0.00025):
+               entropy_cost=None):
     super(AtariShallow, self).__init__(num_actions, device)
     convs = [(8, 4, 16), (4, 2, 32)] if torso == 'shallow' else [(8, 4, 32), (4, 2, 64), (3, 1, 64)]
     fc = 256 if torso == 'shallow' else 512
@@ -389,9 +443,6 @@ class AtariShallow(_Agent, _AtariTorso):
              ('baseline/kernel', (fc, 1), 'glorot'), ('baseline/bias', (1,), 'zeros')]
     self._build_params(spec, seed)
     self._last = None
-
-  def entropy_cost(self):
-    return self._entropy_cost
 
   def initial_state(self, batch_size):
     hw = self._obs[0] * self._obs[1]
@@ -539,7 +590,7 @@ class ImpalaDeep(_Agent):
   [features, clip(reward), one_hot(prev_action)]; policy / baseline heads).  39 trainable tensors in the
   reference's creation order (tests/agents_test.py:45)."""
 
-  def __init__(self, num_actions, observation_shape=(72, 96, 3), device='cuda', seed=0, entropy_cost=0.00025,
+  def __init__(self, num_actions, observation_shape=(72, 96, 3), device='cuda', seed=0, entropy_cost=None,
                channels=(16, 32, 32), fc=256, lstm=256):
     super(ImpalaDeep, self).__init__(num_actions, device)
     h, w, c = observation_shape
@@ -570,9 +621,6 @@ class ImpalaDeep(_Agent):
              ('baseline/kernel', (H, 1), 'glorot'), ('baseline/bias', (1,), 'zeros')]
     self._build_params(spec, seed)
     self._last = None
-
-  def entropy_cost(self):
-    return self._entropy_cost
 
   def initial_state(self, batch_size):
     z = torch.zeros((batch_size, self._H), dtype=torch.float32, device=self.device)

@@ -215,10 +215,24 @@ def impala_loss_fwd_bwd(logits, logits_ld, baseline, baseline_ld, beh_logits, ac
                         T, B, A, d_logits, d_baseline, scalars, workspace, vs=None, pg=None,
                         entropy_cost=0.00025, baseline_cost=0.5, kl_cost=0.0, discounting=0.99,
                         lambda_=1.0, max_abs_reward=0.0, clip_rho=1.0, clip_pg_rho=1.0,
-                        mean_denominator=None):
+                        mean_denominator=None, entropy_cost_param=None, d_entropy_cost_param=None,
+                        entropy_cost_adjustment_speed=10.0, target_entropy=None):
+  """entropy_cost_param (device scalar) given: the learner's learnable entropy cost exp(speed * param) and, with
+  target_entropy, the adjustment loss of learner.py:127-135 (seedhip_impala_loss_fwd_bwd_adaptive)."""
   n = float(T * B if mean_denominator is None else mean_denominator)
   with _region('impala_loss', 0, T * B * (12 * A + 29)):
     with _dev(scalars):
+      if entropy_cost_param is not None:
+        _lib.check(_lib.lib().seedhip_impala_loss_fwd_bwd_adaptive(
+            _lib.ptr(logits), logits_ld, _lib.ptr(baseline), baseline_ld, _lib.ptr(beh_logits), _lib.ptr(actions),
+            actions.element_size(), _lib.ptr(rewards), _lib.ptr(done_u8), T, B, A,
+            _lib.ptr(entropy_cost_param), float(entropy_cost_adjustment_speed), int(bool(target_entropy)),
+            float(target_entropy or 0.0), _lib.ptr(d_entropy_cost_param),
+            baseline_cost, kl_cost, discounting, lambda_, max_abs_reward, clip_rho, clip_pg_rho,
+            n, _lib.ptr(d_logits), _lib.ptr(d_baseline), _lib.ptr(vs), _lib.ptr(pg), _lib.ptr(scalars),
+            _lib.ptr(workspace), workspace.numel() * workspace.element_size(), _lib.stream()),
+            'seedhip_impala_loss_fwd_bwd_adaptive')
+        return
       _lib.check(_lib.lib().seedhip_impala_loss_fwd_bwd(
           _lib.ptr(logits), logits_ld, _lib.ptr(baseline), baseline_ld, _lib.ptr(beh_logits), _lib.ptr(actions),
           actions.element_size(), _lib.ptr(rewards), _lib.ptr(done_u8), T, B, A,
@@ -228,20 +242,23 @@ def impala_loss_fwd_bwd(logits, logits_ld, baseline, baseline_ld, beh_logits, ac
           'seedhip_impala_loss_fwd_bwd')
 
 
-def adam_flat(params, grads, m, v, lr_t, beta_1, beta_2, epsilon, grad_scale=1.0):
+def adam_flat(params, grads, m, v, lr_t, beta_1, beta_2, epsilon, grad_scale=1.0, clamp=None):
+  """clamp = (index, lo, hi): params[index] is clipped to [lo, hi] after its update (Keras variable constraint)."""
+  ci, lo, hi = clamp if clamp is not None else (-1, 0.0, 0.0)
   with _region('adam_flat', 0, params.numel() * 28):
     with _dev(params):
       _lib.check(_lib.lib().seedhip_adam_flat(
           _lib.ptr(params), _lib.ptr(grads), _lib.ptr(m), _lib.ptr(v), params.numel(), lr_t, beta_1, beta_2,
-          epsilon, grad_scale, _lib.stream()), 'seedhip_adam_flat')
+          epsilon, grad_scale, int(ci), float(lo), float(hi), _lib.stream()), 'seedhip_adam_flat')
 
 
-def adam_flat_dev_lr(params, grads, m, v, lr_t_dev, beta_1, beta_2, epsilon, grad_scale=1.0):
+def adam_flat_dev_lr(params, grads, m, v, lr_t_dev, beta_1, beta_2, epsilon, grad_scale=1.0, clamp=None):
+  ci, lo, hi = clamp if clamp is not None else (-1, 0.0, 0.0)
   with _region('adam_flat', 0, params.numel() * 28):
     with _dev(params):
       _lib.check(_lib.lib().seedhip_adam_flat_dev_lr(
           _lib.ptr(params), _lib.ptr(grads), _lib.ptr(m), _lib.ptr(v), params.numel(), _lib.ptr(lr_t_dev), beta_1,
-          beta_2, epsilon, grad_scale, _lib.stream()), 'seedhip_adam_flat_dev_lr')
+          beta_2, epsilon, grad_scale, int(ci), float(lo), float(hi), _lib.stream()), 'seedhip_adam_flat_dev_lr')
 
 
 def global_norm_workspace_bytes():

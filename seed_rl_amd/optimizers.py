@@ -61,10 +61,10 @@ class Adam(object):
       if self._lr_dev is None:
         self.begin_step(flat.params.device)
       ops.adam_flat_dev_lr(flat.params, flat.grads, self._m, self._v, self._lr_dev, self.beta_1, self.beta_2,
-                           self.epsilon, float(grad_scale))
+                           self.epsilon, float(grad_scale), clamp=getattr(flat, 'constraint', None))
     else:
       ops.adam_flat(flat.params, flat.grads, self._m, self._v, float(self.lr_t()), self.beta_1, self.beta_2,
-                    self.epsilon, float(grad_scale))
+                    self.epsilon, float(grad_scale), clamp=getattr(flat, 'constraint', None))
     self.iterations = t
 
   def state_dict(self):

@@ -1,0 +1,208 @@
+"""Whole-train-step parity of the HIP path against the CPU oracle at ANY size, with numbers instead of asserts.
+
+Used by tests/test_gpu_fullsize.py (BASELINE configs at their real sizes) and by bench.py's `parity` record (the
+bench shape, outside the timed region).  Test infrastructure: imports oracle/.
+
+Each function runs ONE learner step (agent unroll -> loss -> backward -> Adam) on seeded synthetic trajectories
+ through `seed_rl_amd` and through the torch-CPU fp32 restatement of the same graph
+(oracle/nets_torch.py; reference agents/vtrace/learner.py:73-159,255-280, agents/r2d2/learner.py:333-384,572-636) and
+returns the error metrics:
+  loss_rel_err        |loss - ref| / max(1, |ref|)
+  grad_max_rel_err    max over parameter tensors of max|g - g_ref| / max(max|g_ref|, floor)
+  grad_worst          the tensor that sets it
+  param_max_abs_err   max |theta' - theta'_ref| after one Adam step
+  param_frac_gt_5e5   fraction of parameter elements further than 5e-5 from the oracle after that step
+                      (Adam with beta_1 = 0 moves every element by ~lr * sign(g): an element whose gradient is
+                      at the fp32 noise floor may legitimately land 2 lr apart)
+  oracle_s            seconds the CPU oracle took
+"""
+import time
+
+import numpy as np
+import torch
+
+from oracle import nets_torch
+from tests import synth
+
+
+def _to(device, a):
+  return torch.as_tensor(np.ascontiguousarray(a)).to(device)
+
+
+def _grad_errs(agent, p, floor=1e-3):
+  grads = agent.reference_gradients()
+  worst, worst_name, per = 0.0, None, {}
+  for n, t in p.items():
+    g, r = grads[n].cpu().numpy(), t.grad.numpy()
+    e = float(np.max(np.abs(g - r)) / max(float(np.abs(r).max()), floor))
+    per[n] = e
+    if e >= worst:
+      worst, worst_name = e, n
+  return worst, worst_name, per
+
+
+def _param_errs(agent, p):
+  mx, cnt, tot = 0.0, 0, 0
+  for (n, v), t in zip(agent.trainable_variables, p.values()):
+    d = np.abs(v.cpu().numpy() - t.detach().numpy())
+    mx = max(mx, float(d.max()))
+    cnt += int((d > 5e-5).sum())
+    tot += d.size
+  return mx, cnt / float(tot)
+
+
+def atari_step(device, T1=21, B=512, A=18, seed=3, torso='shallow', lr=4.8e-4, loss_kw=None, done_p=0.01,
+               zero_state=True, learner_kw=None):
+  """cfg2 (BASELINE configs[1]): Atari 84x84x4 shallow ConvNet; flag-default loss (learner.py:51-62) unless loss_kw."""
+  from seed_rl_amd import learner, networks, optimizers, utils, parametric_distribution as pd
+  kind = 'atari_shallow' if torso == 'shallow' else 'atari_dqn_body'
+  loss_kw = dict(loss_kw or {})
+  u = synth.atari_unroll(seed, T1, B, A, done_p=done_p, zero_state=zero_state)
+  agent = networks.AtariShallow(A, torso=torso, device=device, seed=5)
+  ref_params = nets_torch.init_params(nets_torch.param_spec(kind, A), seed=5)
+  cfg = learner.LossConfig(**loss_kw)
+  opt = optimizers.Adam(optimizers.PolynomialDecay(lr, 100), beta_1=0.0, epsilon=3.125e-7)
+  lrn = learner.Learner(agent, opt, pd.categorical_distribution(A), config=cfg, **(learner_kw or {}))
+  env = utils.EnvOutput(_to(device, u['reward']), _to(device, u['done']), _to(device, u['frames']), None, None)
+  ao = networks.AgentOutput(_to(device, u['actions']), _to(device, u['behaviour_logits']),
+                            _to(device, u['behaviour_baseline']))
+  unroll = learner.Unroll(networks.AgentState((), _to(device, u['frame_state'])), _to(device, u['prev_actions']), env, ao)
+  loss, _ = lrn.compute_gradients(unroll)
+  loss = float(loss)
+
+  t0 = time.perf_counter()
+  p = nets_torch.to_torch(ref_params, requires_grad=True)
+  t = lambda a: torch.tensor(a)
+  logits, baseline, _, _ = nets_torch.atari_shallow_unroll(
+      p, kind, A, t(u['prev_actions']), t(u['reward']), t(u['done']), t(u['frames']), t(u['frame_state']))
+  total, _ = nets_torch.impala_loss_torch(logits, baseline, t(u['behaviour_logits']), t(u['actions']), t(u['reward']),
+                                          t(u['done']), entropy_cost=0.00025, **loss_kw)
+  total.backward()
+  ref = float(total.detach())
+  head, _, ldh = agent.head_buffers()
+  head = head.cpu().numpy().reshape(T1, B, ldh)
+  out = dict(loss=loss, loss_ref=ref, loss_rel_err=abs(loss - ref) / max(1.0, abs(ref)),
+             logits_max_abs_err=float(np.max(np.abs(head[..., :A] - logits.detach().numpy()))),
+             baseline_max_abs_err=float(np.max(np.abs(head[..., A] - baseline.detach().numpy()))))
+  out['grad_max_rel_err'], out['grad_worst'], out['grad_rel_err'] = _grad_errs(agent, p)
+  lrn.apply_gradients()
+  kopt = nets_torch.KerasAdam(list(p.values()), nets_torch.polynomial_decay(lr, 100), beta_1=0.0, epsilon=3.125e-7)
+  kopt.apply_gradients([x.grad for x in p.values()])
+  out['param_max_abs_err'], out['param_frac_gt_5e5'] = _param_errs(agent, p)
+  out['oracle_s'] = round(time.perf_counter() - t0, 2)
+  out['shape'] = dict(T=T1 - 1, B=B, A=A)
+  return out
+
+
+def deep_step(device, T1=21, B=16, A=9, seed=7, obs=(72, 96, 3), lr=4.8e-4, loss_kw=None, done_p=0.05):
+  """cfg3 (BASELINE configs[2]): ImpalaDeep + LSTM(256) (dmlab/networks.py:63-171)."""
+  from seed_rl_amd import learner, networks, optimizers, utils, parametric_distribution as pd
+  loss_kw = dict(loss_kw or {})
+  u = synth.dmlab_unroll(seed, T1, B, A, H=obs[0], W=obs[1], done_p=done_p)
+  agent = networks.ImpalaDeep(A, observation_shape=obs, device=device, seed=3)
+  ref_params = nets_torch.init_params(nets_torch.param_spec('impala_deep', A, obs), seed=3)
+  cfg = learner.LossConfig(**loss_kw)
+  opt = optimizers.Adam(optimizers.PolynomialDecay(lr, 100), beta_1=0.0, epsilon=3.125e-7)
+  lrn = learner.Learner(agent, opt, pd.categorical_distribution(A), config=cfg)
+  env = utils.EnvOutput(_to(device, u['reward']), _to(device, u['done']), _to(device, u['frames']), None, None)
+  ao = networks.AgentOutput(_to(device, u['actions']), _to(device, u['behaviour_logits']),
+                            _to(device, u['behaviour_baseline']))
+  unroll = learner.Unroll((_to(device, u['h0']), _to(device, u['c0'])), _to(device, u['prev_actions']), env, ao)
+  loss, _ = lrn.compute_gradients(unroll)
+  loss = float(loss)
+
+  t0 = time.perf_counter()
+  p = nets_torch.to_torch(ref_params, requires_grad=True)
+  t = lambda a: torch.tensor(a)
+  logits, baseline, _ = nets_torch.impala_deep_unroll(
+      p, A, t(u['prev_actions']), t(u['reward']), t(u['done']), t(u['frames']), (t(u['h0']), t(u['c0'])))
+  total, _ = nets_torch.impala_loss_torch(logits, baseline, t(u['behaviour_logits']), t(u['actions']), t(u['reward']),
+                                          t(u['done']), entropy_cost=0.00025, **loss_kw)
+  total.backward()
+  ref = float(total.detach())
+  head, _, ldh = agent.head_buffers()
+  head = head.cpu().numpy().reshape(T1, B, ldh)
+  out = dict(loss=loss, loss_ref=ref, loss_rel_err=abs(loss - ref) / max(1.0, abs(ref)),
+             logits_max_abs_err=float(np.max(np.abs(head[..., :A] - logits.detach().numpy()))),
+             baseline_max_abs_err=float(np.max(np.abs(head[..., A] - baseline.detach().numpy()))))
+  out['grad_max_rel_err'], out['grad_worst'], out['grad_rel_err'] = _grad_errs(agent, p)
+  # layers after the last max-pool: no discrete argmax routing between them and the loss
+  post = [e for n, e in out['grad_rel_err'].items()
+          if not (n.startswith('stack0/') or n.startswith('stack1/') or n.startswith('stack2/conv/'))]
+  out['grad_max_rel_err_post_pool'] = max(post)
+  lrn.apply_gradients()
+  kopt = nets_torch.KerasAdam(list(p.values()), nets_torch.polynomial_decay(lr, 100), beta_1=0.0, epsilon=3.125e-7)
+  kopt.apply_gradients([x.grad for x in p.values()])
+  out['param_max_abs_err'], out['param_frac_gt_5e5'] = _param_errs(agent, p)
+  out['oracle_s'] = round(time.perf_counter() - t0, 2)
+  out['shape'] = dict(T=T1 - 1, B=B, A=A)
+  return out
+
+
+def r2d2_step(device, T1=121, B=4, A=18, seed=5, burn_in=40, n_steps=5, done_p=0.01):
+  """cfg5 (BASELINE configs[4]): DuelingLSTMDQNNet training + target network, burn-in, n-step double-Q loss,
+  global-norm clip 40, Adam(eps 1e-3) (agents/r2d2/learner.py:333-384,572-636; atari/r2d2_main.py:36-39)."""
+  from seed_rl_amd import networks, optimizers, r2d2_learner, utils
+  u = synth.atari_unroll(seed, T1, B, A, done_p=done_p, zero_state=False)
+  rng = np.random.default_rng(1)
+  h0 = (0.1 * rng.normal(size=(B, 512))).astype(np.float32)
+  c0 = (0.1 * rng.normal(size=(B, 512))).astype(np.float32)
+  iw = rng.uniform(0.2, 1.0, B).astype(np.float32)
+  agent = networks.DuelingLSTMDQNNet(A, device=device, seed=2)
+  target = networks.DuelingLSTMDQNNet(A, device=device, seed=9)
+  ref = nets_torch.init_params(nets_torch.param_spec('r2d2', A), seed=2)
+  ref_t = nets_torch.init_params(nets_torch.param_spec('r2d2', A), seed=9)
+  agent.load_reference_params(ref)
+  cfg = r2d2_learner.R2D2Config(burn_in=burn_in, n_steps=n_steps, update_target_every_n_step=0)
+  opt = optimizers.Adam(4.8e-4, epsilon=1e-3)
+  lrn = r2d2_learner.R2D2Learner(agent, target, opt, cfg)
+  target.load_reference_params(ref_t)                      # undo the constructor's target <- training copy
+  env = utils.EnvOutput(_to(device, u['reward']), _to(device, u['done']), _to(device, u['frames']), None, None)
+  ao = networks.R2D2AgentOutput(_to(device, u['actions'].astype(np.int32)), None)
+  st = networks.AgentState((_to(device, h0), _to(device, c0)), _to(device, u['frame_state']))
+  unroll = r2d2_learner.Unroll(st, None, _to(device, u['prev_actions']), env, ao)
+  total, prio, sumsq = lrn.compute_gradients(unroll, _to(device, iw))
+  total = float(total)
+  prio = prio.cpu().numpy().copy()
+
+  t0 = time.perf_counter()
+  p = nets_torch.to_torch(ref, requires_grad=True)
+  pt = nets_torch.to_torch(ref_t)
+  t = lambda a: torch.tensor(a)
+
+  def run(pp, lo, hi, fs, core):
+    return nets_torch.r2d2_unroll(pp, A, t(u['prev_actions'][lo:hi]), t(u['reward'][lo:hi]), t(u['done'][lo:hi]),
+                                  t(u['frames'][lo:hi]), fs, core)
+  with torch.no_grad():
+    _, fs1, core1 = run(p, 0, burn_in, t(u['frame_state']), (t(h0), t(c0)))
+    _, fs1t, core1t = run(pt, 0, burn_in, t(u['frame_state']), (t(h0), t(c0)))
+    out_t, _, _ = run(pt, burn_in, T1, fs1t, core1t)
+  o, _, _ = run(p, burn_in, T1, fs1, tuple(x.detach() for x in core1))
+  total_ref, _, prio_ref = nets_torch.r2d2_loss_torch(
+      o.q_values, out_t.q_values, t(u['actions'][burn_in:]), t(u['reward'][burn_in:]), t(u['done'][burn_in:]),
+      t(iw), cfg.discounting, cfg.n_steps)
+  total_ref.backward()
+  refv = float(total_ref.detach())
+  q_gpu = agent._buf('q', ((T1 - burn_in) * B, A)).cpu().numpy().reshape(T1 - burn_in, B, A)
+  pr = prio_ref.detach().numpy()
+  out = dict(loss=total, loss_ref=refv, loss_rel_err=abs(total - refv) / max(1.0, abs(refv)),
+             q_max_abs_err=float(np.max(np.abs(q_gpu - o.q_values.detach().numpy()))),
+             priority_max_rel_err=float(np.max(np.abs(prio - pr) / np.maximum(np.abs(pr), 1e-1))))
+  out['grad_max_rel_err'], out['grad_worst'], out['grad_rel_err'] = _grad_errs(agent, p, floor=1e-4)
+  lrn.reduce_gradients()
+  lrn.update()
+  gn = float(torch.sqrt(sumsq[0]))
+  gn_ref = float(torch.sqrt(sum((x.grad ** 2).sum() for x in p.values())))
+  out['grad_norm_rel_err'] = abs(gn - gn_ref) / gn_ref
+  scale = min(1.0, cfg.clip_norm / gn_ref)
+  kopt = nets_torch.KerasAdam(list(p.values()), lambda step: 4.8e-4, epsilon=1e-3)
+  kopt.apply_gradients([x.grad * scale for x in p.values()])
+  out['param_max_abs_err'], out['param_frac_gt_5e5'] = _param_errs(agent, p)
+  out['oracle_s'] = round(time.perf_counter() - t0, 2)
+  out['shape'] = dict(T=T1 - 1, B=B, A=A, burn_in=burn_in)
+  return out
+
+
+def public(rec):
+  """The fields that go into bench.py's JSON line (drops the per-tensor table)."""
+  return {k: (round(v, 9) if isinstance(v, float) else v) for k, v in rec.items() if k != 'grad_rel_err'}

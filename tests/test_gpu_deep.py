@@ -61,7 +61,7 @@ def test_impala_deep_train_step_parity(device, T1, B, A, obs):
   agent = networks.ImpalaDeep(A, observation_shape=obs, device=device, seed=3)
   assert len(agent.trainable_variables) == 39                       # tests/agents_test.py:45
   if obs == (72, 96, 3) and A == 9:
-    assert agent.flat.num_params() - (agent._ldh - A - 1) * (agent._H + 1) == 1520714
+    assert agent.flat.num_params() - (agent._ldh - A - 1) * (agent._H + 1) - 1 == 1520714   # SURVEY 8(a) a4 (+1: entropy-cost slot)
   ref_params = nets_torch.init_params(nets_torch.param_spec('impala_deep', A, obs), seed=3)
   for (n, v) in agent.trainable_variables:
     np.testing.assert_array_equal(v.cpu().numpy(), ref_params[n])

@@ -11,14 +11,14 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-B="python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --graph 0"
+B="python $R/bench.py --steps 5 --warmup 3 --quick --graph 0"
 rocprofv3 --kernel-trace --stats -d $OUT -o ${TAG}_cfg2 --output-format csv -- $B > $OUT/${TAG}_cfg2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT -o ${TAG}_cfg2_fetch --output-format csv -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT -o ${TAG}_cfg2_write --output-format csv -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT -o ${TAG}_cfg3 --output-format csv -- $B --config dmlab > $OUT/${TAG}_cfg3.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT -o ${TAG}_cfg5 --output-format csv -- $B --config r2d2 > $OUT/${TAG}_cfg5.log 2>&1
 # the unprofiled bench lines of the same build (HIP-graph launch, default K / W)
-python $R/bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_cfg2_bench.json
-python $R/bench.py --no-cpu-baseline --config dmlab 2>/dev/null | tail -1 > $OUT/${TAG}_cfg3_bench.json
-python $R/bench.py --no-cpu-baseline --config r2d2 2>/dev/null | tail -1 > $OUT/${TAG}_cfg5_bench.json
+python $R/bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_cfg2_bench.json
+python $R/bench.py --quick --config dmlab 2>/dev/null | tail -1 > $OUT/${TAG}_cfg3_bench.json
+python $R/bench.py --quick --config r2d2 2>/dev/null | tail -1 > $OUT/${TAG}_cfg5_bench.json
 ls -la $OUT | head -40
