@@ -306,14 +306,18 @@ def inference_record(dev, sizes=(64, 256, 1024), unroll_len=20, calls=200):
         observation=torch.randint(0, 256, (n,) + obs, dtype=torch.uint8, generator=g).to(dev),
         abandoned=torch.zeros(n, dtype=torch.bool, device=dev), episode_step=torch.zeros(n, dtype=torch.int32, device=dev))
             for _ in groups]
-    run_ids = torch.full((n,), 7, dtype=torch.int64, device=dev)
+    run_ids = np.full((n,), 7, np.int64)
+    # one packed request batch per group, as a transport front-end delivers it (inference.request_layout)
+    packed = [torch.from_numpy(inference.pack_request(
+        n, g_.cpu().numpy(), run_ids, r.reward.cpu().numpy(), r.reward.cpu().numpy(), r.done.cpu().numpy())).to(dev)
+              for g_, r in zip(groups, reqs)]
     fused = inference.FusedInferenceState(agent, envs, unroll_len, env_specs, ao_specs, batch_capacity=2 * envs, device=dev)
     fn = fused.graphed(n, obs)
     per_round = len(groups) * (unroll_len + 1)
 
     def call(i):
       k = i % len(groups)
-      fn(groups[k], run_ids, reqs[k], reqs[k].reward)
+      fn.replay_packed(packed[k], reqs[k].observation)
       if (i + 1) % per_round == 0:
         fused.batch_count.zero_()             # the learner took the filled training batch
     for i in range(2 * len(groups)):
@@ -328,8 +332,9 @@ def inference_record(dev, sizes=(64, 256, 1024), unroll_len=20, calls=200):
     out['n%d' % n] = dict(us_per_call=round(dt / calls * 1e6, 1), env_steps_per_s=round(calls * n / dt, 0), envs=envs)
     del fused, fn, agent, reqs, groups
     _release()
-  out['note'] = ('FusedInferenceState.graphed(): one HIP-graph replay per inference batch incl. the copy of the request '
-                 'into the static inputs; Atari shallow agent, A=18, unroll 20')
+  out['note'] = ('FusedInferenceState.graphed().replay_packed(): per inference batch two copies (packed request scalars, '
+                 'frames) into the static inputs + one HIP-graph replay (bookkeeping, agent forward, in-kernel action '
+                 'sampling, store append, completed unrolls -> training batch); Atari shallow agent, A=18, unroll 20')
   return out
 
 

@@ -311,17 +311,44 @@ int seedhip_rows_move_masked(void* dst, const long long* dst_rows, const void* s
 int seedhip_rows_move_multi(int nfields, void* const* dst, const void* const* src, const long long* row_bytes,
                             const long long* dst_rows, const long long* src_rows, long long n,
                             const uint8_t* row_mask, int zero_where_masked, void* stream);
+/* inference_pre also validates the ids: out-of-range (flag 1) and duplicate (flag 2, found in O(1) through
+ * stamp_table[num_envs] / *call_counter, both zero-initialised by the caller and owned by these kernels) rows get
+ * valid[i] = 0 and are skipped by every table access of the step; ids_safe[i] is the id clamped into range for the
+ * gathers that run unmasked.  (The reference raises on both: common/utils.py:173-176.) */
 int seedhip_inference_pre(const long long* env_ids, const long long* run_ids, const float* reward,
                           const float* raw_reward, const uint8_t* done, int n, int num_envs, int num_action_repeats,
                           long long* run_ids_table, long long* info_frames, float* info_return,
                           float* info_raw_return, long long* actions_table, long long* store_index,
                           uint8_t* reset_mask, long long* prev_actions, float* episode_stats, int stats_capacity,
-                          int* stats_count, int* error_flag, void* stream);
-int seedhip_inference_post(const long long* env_ids, const long long* actions, int n, int num_envs, int full_length,
-                           int batch_capacity, long long* store_index, long long* actions_table, int* batch_count,
-                           long long* append_rows, uint8_t* complete, long long* batch_cols, long long* gather_src,
-                           long long* gather_dst, uint8_t* gather_mask, long long* last_rows, int* error_flag,
-                           void* stream);
+                          int* stats_count, int* error_flag, long long* ids_safe, uint8_t* valid, int* stamp_table,
+                          int* call_counter, void* stream);
+/* inference_post: env_ids = ids_safe, valid = the mask of inference_pre (NULL: every in-range row).  With
+ * policy_logits != NULL the actions are SAMPLED here from the head rows policy_logits[i*logits_ld + a] (Gumbel-max
+ * over Philox4x32-10 randoms keyed by rng_state[0] = seed, rng_state[1] = call counter, advanced by this launch:
+ * the categorical sample of dmlab/networks.py:122 without an eager op) and written to actions[n]; otherwise actions[n]
+ * is an input.  carry u8[n] marks every completed unroll (its last step is carried to slot 0, utils.py:237-252), complete
+ * u8[n] those that also got a training-batch column (flag 8 when the batch is full: the unroll is dropped, the env's
+ * store stays consistent). */
+int seedhip_inference_post(const long long* env_ids, const uint8_t* valid, long long* actions,
+                           const float* policy_logits, int logits_ld, int num_actions, unsigned long long* rng_state,
+                           int n, int num_envs, int full_length, int batch_capacity, long long* store_index,
+                           long long* actions_table, int* batch_count, long long* append_rows, uint8_t* complete,
+                           uint8_t* carry, long long* batch_cols, long long* gather_src, long long* gather_dst,
+                           uint8_t* gather_mask, long long* last_rows, int* error_flag, void* stream);
+/* The agents' action sampling (tfd.Categorical(logits).sample(), common/parametric_distribution.py:94-95 as used by
+ * dmlab/networks.py:122): actions[r] ~ Categorical(logits[r*ld .. r*ld + num_actions)), int64.  Same generator and
+ * per-row function as inference_post: equal (seed, counter) give equal actions. */
+int seedhip_categorical_sample(const float* logits, int ld, long long rows, int num_actions,
+                               unsigned long long* rng_state, long long* actions, void* stream);
+/* Up to 32 INDEPENDENT row moves in one launch (no operation may read rows another one writes):
+ *   dst[dst_rows[i] * dst_pitch ...] = src[src_rows[i] * src_pitch ...], row_bytes bytes, i < n;
+ * pitches in bytes (0 = row_bytes: dense rows), so strided sources such as the logits columns of a head-GEMM output are
+ * read in place; row_mask / zero_where_masked as in seedhip_rows_move_masked; src NULL = zero fill. */
+typedef struct seedhip_row_op {
+  void* dst; const void* src; long long row_bytes; long long dst_pitch; long long src_pitch;
+  const long long* dst_rows; const long long* src_rows; long long n; const uint8_t* row_mask; int zero_where_masked;
+} seedhip_row_op;
+int seedhip_rows_move_ops(int nops, const seedhip_row_op* ops, void* stream);
 
 /* ---- prioritized replay sampling --------------------------------------------------------------------
  * Replaces PrioritizedReplay.sample of common/utils.py:309-357 for priority_exponent > 0: categorical sampling

@@ -123,10 +123,24 @@ def init_params(spec, seed=0):
   return out
 
 
-def to_torch(params, requires_grad=False):
+def to_torch(params, requires_grad=False, dtype=torch.float32):
   return collections.OrderedDict(
-      (k, torch.tensor(v, dtype=torch.float32, requires_grad=requires_grad))
+      (k, torch.tensor(v, dtype=dtype, requires_grad=requires_grad))
       for k, v in params.items())
+
+
+class float64_truth(object):
+  """`with float64_truth(): ...` evaluates the SAME graphs in fp64 (pass to_torch(..., dtype=torch.float64)
+  parameters): every cast in this module follows torch's default dtype.  Used by tests/parity.py to tell fp32
+  re-association noise (HIP and this oracle are both ~eps * sqrt(terms) away from the fp64 value, in different
+  directions) from a real difference."""
+
+  def __enter__(self):
+    self._old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+
+  def __exit__(self, *exc):
+    torch.set_default_dtype(self._old)
 
 
 # --------------------------------------------------------------------------- #
@@ -172,7 +186,7 @@ def unroll_lstm(p, prefix, xs, done, state):
   h, c = state
   outs = []
   for t in range(xs.shape[0]):
-    keep = (~done[t]).to(torch.float32)[:, None]
+    keep = (~done[t]).to(torch.get_default_dtype())[:, None]
     h, c = h * keep, c * keep                      # where(done, zeros, state)
     h, c = lstm_cell(xs[t], h, c, p[prefix + '/kernel'],
                      p[prefix + '/recurrent_kernel'], p[prefix + '/bias'])
@@ -185,9 +199,9 @@ def stack_frames_torch(frames_u8, frame_state, done, stack_size=4):
   T, B = frames_u8.shape[:2]
   obs = frames_u8.shape[2:-1]
   st = frame_state.reshape((B,) + tuple(obs))
-  prev = [((st >> (8 * i)) & 0xFF).to(torch.float32)[None, ..., None]
+  prev = [((st >> (8 * i)) & 0xFF).to(torch.get_default_dtype())[None, ..., None]
           for i in range(stack_size - 1)]
-  ext = torch.cat(prev + [frames_u8.to(torch.float32)], 0)
+  ext = torch.cat(prev + [frames_u8.to(torch.get_default_dtype())], 0)
   stacked = torch.cat(
       [ext[stack_size - 1 - i:ext.shape[0] - i] for i in range(stack_size)], -1)
   row = (T, B) + (1,) * (frames_u8.dim() - 2)
@@ -209,7 +223,7 @@ def stack_frames_torch(frames_u8, frame_state, done, stack_size=4):
 # --------------------------------------------------------------------------- #
 def impala_deep_torso(p, frames_u8):
   """dmlab/networks.py:94-109 on [N,H,W,C] uint8."""
-  x = frames_u8.to(torch.float32) / 255
+  x = frames_u8.to(torch.get_default_dtype()) / 255
   for i in range(3):
     x = conv2d(x, p['stack%d/conv/kernel' % i], p['stack%d/conv/bias' % i], 1, 'same')
     x = max_pool_3x3_s2_same(x)
@@ -234,7 +248,7 @@ def impala_deep_unroll(p, num_actions, prev_actions, reward, done, frames_u8,
   T1, B = done.shape
   feat = impala_deep_torso(p, frames_u8.reshape((T1 * B,) + frames_u8.shape[2:]))
   clipped = torch.clamp(reward.reshape(-1), -1, 1)[:, None]
-  onehot = F.one_hot(prev_actions.reshape(-1).long(), num_actions).float()
+  onehot = F.one_hot(prev_actions.reshape(-1).long(), num_actions).to(torch.get_default_dtype())
   xs = torch.cat([feat, clipped, onehot], 1).reshape(T1, B, -1)
   core, state = unroll_lstm(p, 'core', xs, done, core_state)
   flat = core.reshape(T1 * B, -1)
@@ -262,7 +276,7 @@ def atari_shallow_unroll(p, kind, num_actions, prev_actions, reward, done,
   state = None
   if 'core/kernel' in p:
     clipped = torch.clamp(reward.reshape(-1), -1, 1)[:, None]
-    onehot = F.one_hot(prev_actions.reshape(-1).long(), num_actions).float()
+    onehot = F.one_hot(prev_actions.reshape(-1).long(), num_actions).to(torch.get_default_dtype())
     xs = torch.cat([feat, clipped, onehot], 1).reshape(T1, B, -1)
     core, state = unroll_lstm(p, 'core', xs, done, core_state)
     feat = core.reshape(T1 * B, -1)
@@ -278,7 +292,7 @@ def r2d2_unroll(p, num_actions, prev_actions, reward, done, frames_u8,
   stacked, new_fs = stack_frames_torch(frames_u8, frame_state, done, 4)
   x = (stacked / 255).reshape((T1 * B,) + stacked.shape[2:])
   feat = atari_body(p, x, 'body/', [(4,), (2,), (1,)])
-  onehot = F.one_hot(prev_actions.reshape(-1).long(), num_actions).float()
+  onehot = F.one_hot(prev_actions.reshape(-1).long(), num_actions).to(torch.get_default_dtype())
   xs = torch.cat([feat, reward.reshape(-1)[:, None], onehot], 1).reshape(T1, B, -1)
   core, state = unroll_lstm(p, 'core', xs, done, core_state)
   flat = core.reshape(T1 * B, -1)
@@ -328,7 +342,7 @@ def impala_loss_torch(logits, baseline, beh_logits, actions, rewards, done,
   rew, dn = rewards[1:], done[1:]
   if max_abs_reward:
     rew = torch.clamp(rew, -max_abs_reward, max_abs_reward)
-  disc = (~dn).float() * discounting
+  disc = (~dn).to(torch.get_default_dtype()) * discounting
   tls = F.log_softmax(tl, -1)
   tgt_lp = tls.gather(-1, act[..., None])[..., 0]
   beh_lp = F.log_softmax(bl, -1).gather(-1, act[..., None])[..., 0]
@@ -401,7 +415,7 @@ def r2d2_loss_torch(training_q, target_q, actions, rewards, done, importance_wei
   r = torch.cat([rewards] + [torch.zeros_like(rewards[0:1])] * n_steps, 0)
   for _ in range(n_steps):
     r, d = r[:-1], d[:-1]
-    bt = r + gamma * (1. - d.float()) * bt[1:]
+    bt = r + gamma * (1. - d.to(torch.get_default_dtype())) * bt[1:]
   bt = h(bt[1:].detach())
   abs_td = torch.abs(bt - replay_q[:-1])
   prio = eta * abs_td.max(0)[0] + (1 - eta) * abs_td.mean(0)

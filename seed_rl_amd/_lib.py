@@ -31,6 +31,13 @@ class StackConvGeom(ctypes.Structure):
   _fields_ = [(n, c_int) for n in 'T B ih iw oh ow kh kw stride cout ld_out'.split()]
 
 
+class RowOp(ctypes.Structure):
+  """seedhip_row_op."""
+  _fields_ = [('dst', c_void_p), ('src', c_void_p), ('row_bytes', c_ll), ('dst_pitch', c_ll), ('src_pitch', c_ll),
+              ('dst_rows', c_void_p), ('src_rows', c_void_p), ('n', c_ll), ('row_mask', c_void_p),
+              ('zero_where_masked', c_int)]
+
+
 # name -> (restype, argtypes); every symbol include/seedhip.h declares.
 SIGNATURES = {
     'seedhip_last_error': (ctypes.c_char_p, []),
@@ -89,8 +96,12 @@ SIGNATURES = {
     'seedhip_rows_move': (c_int, [P, P, P, P, c_ll, c_ll, P]),
     'seedhip_rows_move_masked': (c_int, [P, P, P, P, c_ll, c_ll, P, c_int, P]),
     'seedhip_rows_move_multi': (c_int, [c_int, P, P, P, P, P, c_ll, P, c_int, P]),
-    'seedhip_inference_pre': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P, P]),
-    'seedhip_inference_post': (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P]),
+    'seedhip_inference_pre': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P,
+                                      P, P, P, P, P]),
+    'seedhip_inference_post': (c_int, [P, P, P, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P,
+                                       P, P, P, P, P]),
+    'seedhip_categorical_sample': (c_int, [P, c_int, c_ll, c_int, P, P, P]),
+    'seedhip_rows_move_ops': (c_int, [c_int, P, P]),
     'seedhip_replay_sample_workspace_bytes': (c_size_t, [c_ll]),
     'seedhip_replay_sample': (c_int, [P, c_ll, c_float, c_float, P, c_int, P, P, P, c_size_t, P]),
     'seedhip_dueling_fwd': (c_int, [P, c_int, c_ll, c_int, P, P, P]),

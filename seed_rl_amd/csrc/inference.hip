@@ -5,12 +5,15 @@
 // [inference_batch_size] tensors, several of which produce data-dependent shapes (tf.where -> tf.gather) -- with
 // TWO launches that keep every shape static, so that the whole step has no host synchronisation and can be
 // replayed from a HIP graph:
-//   inference_pre  : run-id compare + reset bookkeeping (:353-366), episode statistics (:373-378), previous
-//                    action read (:381), unroll-store slot of this step (utils.py:187-194)
+//   inference_pre  : id validation (range, duplicates through a per-env stamp), run-id compare + reset bookkeeping
+//                    (:353-366), episode statistics (:373-378), previous action read (:381)
 //   inference_post : store index advance, completed-unroll detection (utils.py:229-233), destination columns
 //                    in the time-major training batch (exclusive scan over the batch), index lists for the
 //                    row mover (store.hip) that appends the step, emits completed unrolls and carries the last
-//                    step over (utils.py:237-255), action table update (:403).
+//                    step over (utils.py:237-255), action table update (:403); optionally SAMPLES the actions from the
+//                    policy-head rows (Gumbel-max over Philox randoms, dmlab/networks.py:122) so that no eager op
+//                    sits between the head GEMM and the bookkeeping.
+//   rows_move_ops  : all data movement of the step as 4 launches of mutually independent row moves.
 // One workgroup; n = inference batch size <= 1024.  All integer work: exact.
 #include "common.h"
 #include "../../include/seedhip.h"
@@ -24,16 +27,34 @@ struct PreArgs {
   long long* actions_tab; long long* store_index;
   uint8_t* reset_mask; long long* prev_actions;
   float* episode_stats; int stats_capacity; int* stats_count; int* error_flag;
+  long long* ids_safe; uint8_t* valid; int* stamp_tab; int* call_counter;
 };
 
 __global__ void __launch_bounds__(1024)
 inference_pre_kernel(PreArgs a) {
   const int i = threadIdx.x;
+  // this call's stamp: every thread reads the counter, thread 0 advances it once all have (one workgroup)
+  const int stamp = *a.call_counter + 1;
+  __syncthreads();
+  if (i == 0) *a.call_counter = stamp;
   if (i >= a.n) return;
   const long long e = a.env_ids[i];
-  if (e < 0 || e >= a.num_envs) { atomicOr(a.error_flag, 1); a.reset_mask[i] = 0; a.prev_actions[i] = 0; return; }
-  // duplicate ids in one batch are an error in the reference (utils.py:173-176); flag them (n is small)
-  for (int k = 0; k < i; ++k) if (a.env_ids[k] == e) atomicOr(a.error_flag, 2);
+  if (e < 0 || e >= a.num_envs) {
+    // the reference raises (tf scatter / gather out of range); here the row is masked out of EVERY table access of
+    // the step (valid = 0, ids_safe = 0 keeps reads in range) and the error is flagged
+    atomicOr(a.error_flag, 1);
+    a.reset_mask[i] = 0; a.prev_actions[i] = 0; a.ids_safe[i] = 0; a.valid[i] = 0;
+    return;
+  }
+  // duplicate ids in one batch are an error in the reference (utils.py:173-176): the first occurrence stamps the
+  // env's slot, a later one finds this call's stamp there -- O(1) per row instead of an O(n) scan; a duplicate row is
+  // masked out like an invalid one (two rows updating one env's tables would race)
+  if (atomicExch(a.stamp_tab + e, stamp) == stamp) {
+    atomicOr(a.error_flag, 2);
+    a.reset_mask[i] = 0; a.prev_actions[i] = 0; a.ids_safe[i] = e; a.valid[i] = 0;
+    return;
+  }
+  a.ids_safe[i] = e; a.valid[i] = 1;
   const long long prev_run = a.run_ids_tab[e];
   const long long run = a.run_ids[i];
   a.run_ids_tab[e] = run;                                              // learner.py:354
@@ -63,10 +84,16 @@ inference_pre_kernel(PreArgs a) {
 }
 
 struct PostArgs {
-  const long long* env_ids; const long long* actions; int n; int num_envs; int full_length; int batch_capacity;
+  const long long* env_ids;    // ids_safe of inference_pre
+  const uint8_t* valid;        // [n] rows to process (NULL = all)
+  long long* actions;          // [n] in: the agent's actions; with `logits` set: OUT, sampled here
+  const float* logits; int logits_ld; int num_actions;   // policy head rows (NULL = actions given)
+  unsigned long long* rng;     // [2] seed, call counter (advanced by one per launch when sampling)
+  int n; int num_envs; int full_length; int batch_capacity;
   long long* store_index; long long* actions_tab; int* batch_count;
   long long* append_rows;      // [n]          store row (idx*E + e) this step is written to
-  uint8_t* complete;           // [n]          1 where the step completed an unroll
+  uint8_t* complete;           // [n]          1 where the step completed an unroll that got a batch column
+  uint8_t* carry;              // [n]          1 where the step completed an unroll (carried over to slot 0 regardless)
   long long* batch_cols;       // [n]          destination column in the training batch (valid where complete)
   long long* gather_src;       // [L*n]        t*E + e
   long long* gather_dst;       // [L*n]        t*capacity + column
@@ -83,19 +110,36 @@ inference_post_kernel(PostArgs a) {
   const int L = a.full_length, E = a.num_envs;
   long long e = 0;
   int done = 0;
+  bool ok_row = false;
+  unsigned long long seed = 0, call = 0;
+  if (a.logits) { seed = a.rng[0]; call = a.rng[1]; }
   if (i < a.n) {
     e = a.env_ids[i];
-    const long long idx = a.store_index[e];
-    a.append_rows[i] = idx * E + e;
-    done = (idx + 1 == L) ? 1 : 0;
-    if (idx + 1 > L) atomicOr(a.error_flag, 4);
-    a.store_index[e] = done ? 1 : idx + 1;                             // utils.py:194, 254-255 (overlap 0)
-    a.actions_tab[e] = a.actions[i];                                   // learner.py:403
+    ok_row = a.valid ? a.valid[i] != 0 : (e >= 0 && e < E);
+    if (!ok_row) e = 0;
+    long long act;
+    if (a.logits) {                                                    // dmlab/networks.py:122 (sample in the head)
+      act = seedhip::sample_categorical_row(a.logits + (long long)i * a.logits_ld, a.num_actions, seed, call, (unsigned)i);
+      a.actions[i] = act;
+    } else {
+      act = a.actions[i];
+    }
+    if (ok_row) {
+      const long long idx = a.store_index[e];
+      a.append_rows[i] = idx * E + e;
+      done = (idx + 1 == L) ? 1 : 0;
+      if (idx + 1 > L) atomicOr(a.error_flag, 4);
+      a.store_index[e] = done ? 1 : idx + 1;                           // utils.py:194, 254-255 (overlap 0)
+      a.actions_tab[e] = act;                                          // learner.py:403
+    } else {
+      a.append_rows[i] = 0;
+    }
     a.last_rows[i] = (long long)(L - 1) * E + e;
   }
   // inclusive scan of `done` over the batch (order of env_ids, like tf.gather(env_ids, tf.where(...)))
   s_scan[i] = done;
   __syncthreads();
+  if (a.logits && i == 0) a.rng[1] = call + 1;                         // every thread has read the counter
   for (int off = 1; off < 1024; off <<= 1) {
     const int v = (i >= off) ? s_scan[i - off] : 0;
     __syncthreads();
@@ -106,20 +150,66 @@ inference_post_kernel(PostArgs a) {
     const int total = s_scan[1023];
     const int base = *a.batch_count;
     s_base = base;
-    *a.batch_count = base + total;
+    *a.batch_count = base + total > a.batch_capacity ? a.batch_capacity : base + total;
     if (base + total > a.batch_capacity) atomicOr(a.error_flag, 8);
   }
   __syncthreads();
   if (i < a.n) {
     const int col = s_base + s_scan[i] - done;
+    // a completed unroll that finds the training batch full is dropped (flag 8) but its last step is STILL carried
+    // to slot 0, so the env's next unroll starts from a consistent state
     const bool ok = done && col < a.batch_capacity;
     a.complete[i] = ok ? 1 : 0;
+    a.carry[i] = done ? 1 : 0;
     a.batch_cols[i] = ok ? col : 0;
     for (int t = 0; t < L; ++t) {
       a.gather_src[(long long)t * a.n + i] = (long long)t * E + e;
       a.gather_dst[(long long)t * a.n + i] = ok ? (long long)t * a.batch_capacity + col : 0;
       a.gather_mask[(long long)t * a.n + i] = ok ? 1 : 0;
     }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+categorical_sample_kernel(const float* __restrict__ logits, int ld, long long rows, int A,
+                          unsigned long long* __restrict__ rng, long long* __restrict__ actions) {
+  const unsigned long long seed = rng[0], call = rng[1];
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) actions[r] = seedhip::sample_categorical_row(logits + r * ld, A, seed, call, (unsigned)r);
+}
+__global__ void rng_advance_kernel(unsigned long long* rng) { rng[1] += 1; }
+
+// Several independent row moves in ONE launch (blockIdx.y = operation): dst[dst_rows[i]] = src[src_rows[i]] with
+// per-operation row count, mask and pitches.  The ~8 data movements of an inference step (previous-state gather,
+// append, emit, carry, state tables) become 4 launches of mutually independent operations.
+constexpr int kMaxOps = 32;
+struct RowOp {
+  void* dst; const void* src; long long row_bytes; long long dst_pitch; long long src_pitch;
+  const long long* dst_rows; const long long* src_rows; long long n; const uint8_t* mask; int zero_where_masked; int pad;
+};
+struct OpsArgs { RowOp op[kMaxOps]; };
+
+__global__ void __launch_bounds__(256)
+rows_move_ops_kernel(OpsArgs a) {
+  const RowOp& o = a.op[blockIdx.y];
+  const long long rb = o.row_bytes;
+  const uintptr_t al = (uintptr_t)o.dst | (uintptr_t)o.src | (uintptr_t)rb | (uintptr_t)o.dst_pitch | (uintptr_t)o.src_pitch;
+  const int w = (al & 15) == 0 ? 16 : ((al & 3) == 0 ? 4 : 1);       // uniform per operation
+  const long long row_elems = rb / w;
+  const long long total = o.n * row_elems;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long r = i / row_elems, el = i - r * row_elems;
+    bool zero = false;
+    if (o.mask) {
+      const bool m = o.mask[r] != 0;
+      if (o.zero_where_masked) zero = m; else if (!m) continue;
+    }
+    char* d = (char*)o.dst + (o.dst_rows ? o.dst_rows[r] : r) * o.dst_pitch + el * w;
+    const char* sp = (o.src && !zero) ? (const char*)o.src + (o.src_rows ? o.src_rows[r] : r) * o.src_pitch + el * w : nullptr;
+    if (w == 16) *reinterpret_cast<uint4*>(d) = sp ? *reinterpret_cast<const uint4*>(sp) : make_uint4(0, 0, 0, 0);
+    else if (w == 4) *reinterpret_cast<uint32_t*>(d) = sp ? *reinterpret_cast<const uint32_t*>(sp) : 0u;
+    else *d = sp ? *sp : (char)0;
   }
 }
 
@@ -209,33 +299,80 @@ extern "C" int seedhip_inference_pre(const long long* env_ids, const long long* 
                                      float* info_return, float* info_raw_return, long long* actions_table,
                                      long long* store_index, uint8_t* reset_mask, long long* prev_actions,
                                      float* episode_stats, int stats_capacity, int* stats_count, int* error_flag,
+                                     long long* ids_safe, uint8_t* valid, int* stamp_table, int* call_counter,
                                      void* stream) {
   SEEDHIP_REQUIRE(n >= 1 && n <= 1024 && num_envs >= 1, "inference_pre: need 1 <= n <= 1024");
   SEEDHIP_REQUIRE(env_ids && run_ids && reward && raw_reward && done && run_ids_table && info_frames && info_return &&
                   info_raw_return && actions_table && store_index && reset_mask && prev_actions && episode_stats &&
-                  stats_count && error_flag, "inference_pre: null pointer");
+                  stats_count && error_flag && ids_safe && valid && stamp_table && call_counter,
+                  "inference_pre: null pointer");
   PreArgs a{env_ids, run_ids, reward, raw_reward, done, n, num_envs, num_action_repeats, run_ids_table, info_frames,
             info_return, info_raw_return, actions_table, store_index, reset_mask, prev_actions, episode_stats,
-            stats_capacity, stats_count, error_flag};
+            stats_capacity, stats_count, error_flag, ids_safe, valid, stamp_table, call_counter};
   hipLaunchKernelGGL(inference_pre_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
   return seedhip::check_launch("inference_pre_kernel");
 }
 
-extern "C" int seedhip_inference_post(const long long* env_ids, const long long* actions, int n, int num_envs,
+extern "C" int seedhip_inference_post(const long long* env_ids, const uint8_t* valid, long long* actions,
+                                      const float* policy_logits, int logits_ld, int num_actions,
+                                      unsigned long long* rng_state, int n, int num_envs,
                                       int full_length, int batch_capacity, long long* store_index,
                                       long long* actions_table, int* batch_count, long long* append_rows,
-                                      uint8_t* complete, long long* batch_cols, long long* gather_src,
+                                      uint8_t* complete, uint8_t* carry, long long* batch_cols, long long* gather_src,
                                       long long* gather_dst, uint8_t* gather_mask, long long* last_rows,
                                       int* error_flag, void* stream) {
   SEEDHIP_REQUIRE(n >= 1 && n <= 1024 && num_envs >= 1 && full_length >= 2 && batch_capacity >= 1,
                   "inference_post: bad sizes");
   SEEDHIP_REQUIRE(env_ids && actions && store_index && actions_table && batch_count && append_rows && complete &&
-                  batch_cols && gather_src && gather_dst && gather_mask && last_rows && error_flag,
+                  carry && batch_cols && gather_src && gather_dst && gather_mask && last_rows && error_flag,
                   "inference_post: null pointer");
-  PostArgs a{env_ids, actions, n, num_envs, full_length, batch_capacity, store_index, actions_table, batch_count,
-             append_rows, complete, batch_cols, gather_src, gather_dst, gather_mask, last_rows, error_flag};
+  SEEDHIP_REQUIRE(!policy_logits || (rng_state && num_actions >= 1 && logits_ld >= num_actions),
+                  "inference_post: sampling needs rng_state and 1 <= num_actions <= logits_ld");
+  PostArgs a{env_ids, valid, actions, policy_logits, logits_ld, num_actions, rng_state, n, num_envs, full_length,
+             batch_capacity, store_index, actions_table, batch_count, append_rows, complete, carry, batch_cols,
+             gather_src, gather_dst, gather_mask, last_rows, error_flag};
   hipLaunchKernelGGL(inference_post_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
   return seedhip::check_launch("inference_post_kernel");
+}
+
+extern "C" int seedhip_categorical_sample(const float* logits, int ld, long long rows, int num_actions,
+                                          unsigned long long* rng_state, long long* actions, void* stream) {
+  SEEDHIP_REQUIRE(rows >= 0 && num_actions >= 1 && ld >= num_actions, "categorical_sample: bad rows / num_actions / ld");
+  SEEDHIP_REQUIRE(rng_state, "categorical_sample: null rng_state");
+  hipStream_t s = (hipStream_t)stream;
+  if (rows > 0) {
+    SEEDHIP_REQUIRE(logits && actions, "categorical_sample: null pointer");
+    hipLaunchKernelGGL(categorical_sample_kernel, dim3(seedhip::cdiv(rows, 256)), dim3(256), 0, s, logits, ld, rows,
+                       num_actions, rng_state, actions);
+  }
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, s, rng_state);
+  return seedhip::check_launch("categorical_sample_kernel");
+}
+
+extern "C" int seedhip_rows_move_ops(int nops, const seedhip_row_op* ops, void* stream) {
+  SEEDHIP_REQUIRE(nops >= 0 && nops <= kMaxOps, "rows_move_ops: need 0 <= nops <= %d", kMaxOps);
+  if (nops == 0) return SEEDHIP_OK;
+  SEEDHIP_REQUIRE(ops, "rows_move_ops: null ops");
+  OpsArgs a;
+  long long max_elems = 0;
+  int k = 0;
+  for (int f = 0; f < nops; ++f) {
+    const seedhip_row_op& o = ops[f];
+    SEEDHIP_REQUIRE(o.n >= 0 && o.row_bytes >= 1, "rows_move_ops: bad op %d", f);
+    if (o.n == 0) continue;
+    SEEDHIP_REQUIRE(o.dst, "rows_move_ops: null dst in op %d", f);
+    RowOp& r = a.op[k++];
+    r.dst = o.dst; r.src = o.src; r.row_bytes = o.row_bytes;
+    r.dst_pitch = o.dst_pitch ? o.dst_pitch : o.row_bytes; r.src_pitch = o.src_pitch ? o.src_pitch : o.row_bytes;
+    r.dst_rows = o.dst_rows; r.src_rows = o.src_rows; r.n = o.n; r.mask = o.row_mask;
+    r.zero_where_masked = o.zero_where_masked; r.pad = 0;
+    const long long e = o.n * ((o.row_bytes + 15) / 16);
+    if (e > max_elems) max_elems = e;
+  }
+  if (k == 0) return SEEDHIP_OK;
+  long long gx = (max_elems + 255) / 256; if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(rows_move_ops_kernel, dim3((int)gx, k), dim3(256), 0, (hipStream_t)stream, a);
+  return seedhip::check_launch("rows_move_ops_kernel");
 }
 
 extern "C" int seedhip_rows_move_multi(int nfields, void* const* dst, const void* const* src, const long long* row_bytes,

@@ -20,6 +20,35 @@ from seed_rl_amd.unroll_store import Spec
 EpisodeInfo = collections.namedtuple('EpisodeInfo', 'episode_num_frames episode_returns episode_raw_returns')
 
 
+def request_layout(n):
+  """Byte layout of one packed inference request batch of n env steps (structure of arrays): name -> (offset, bytes);
+  'bytes' = total (16-byte multiple).  The fields are the per-step scalars of the reference's inference call
+  (env_id, run_id, EnvOutput.reward/done/abandoned/episode_step, raw reward; learner.py:350-352)."""
+  lay, off = {}, 0
+  for name, width in (('ids', 8), ('runs', 8), ('reward', 4), ('raw', 4), ('episode_step', 4), ('done', 1),
+                      ('abandoned', 1)):
+    lay[name] = (off, width * n)
+    off += width * n
+  lay['bytes'] = (off + 15) // 16 * 16
+  return lay
+
+
+def pack_request(n, env_ids, run_ids, reward, raw_reward, done, abandoned=None, episode_step=None, out=None):
+  """Host-side packing of a request batch into `request_layout(n)` (numpy in, uint8 numpy out)."""
+  import numpy as np
+  lay = request_layout(n)
+  buf = np.zeros(lay['bytes'], np.uint8) if out is None else out
+  def put(name, arr, dt):
+    o, nb = lay[name]
+    buf[o:o + nb] = np.ascontiguousarray(np.asarray(arr).astype(dt, copy=False)).view(np.uint8).reshape(-1)
+  put('ids', env_ids, np.int64); put('runs', run_ids, np.int64)
+  put('reward', reward, np.float32); put('raw', raw_reward, np.float32)
+  put('episode_step', np.zeros(n, np.int32) if episode_step is None else episode_step, np.int32)
+  put('done', done, np.uint8)
+  put('abandoned', np.zeros(n, np.uint8) if abandoned is None else abandoned, np.uint8)
+  return buf
+
+
 class InferenceState(object):
   """The per-host state the reference builds in create_host (learner.py:314-336)."""
 
@@ -89,7 +118,7 @@ class InferenceState(object):
 
 
 class FusedInferenceState(object):
-  """The same inference step with NO host synchronisation and static shapes, so that one call is ~50 kernel
+  """The same inference step with NO host synchronisation and static shapes, so that one call is ~15 kernel
   launches that can be captured once in a HIP graph and replayed (`graphed(n)`).
 
   Differences from `InferenceState` (which follows the reference op by op and is kept as the executable
@@ -126,6 +155,8 @@ class FusedInferenceState(object):
     self.episode_stats = torch.zeros((stats_capacity, 3), dtype=torch.float32, device=dev)
     self.stats_count = torch.zeros(1, dtype=torch.int32, device=dev)
     self.error_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    self.stamp_tab = torch.zeros(num_envs, dtype=torch.int32, device=dev)      # duplicate-id detection (inference_pre)
+    self.call_counter = torch.zeros(1, dtype=torch.int32, device=dev)
     self._scratch = {}
 
   def _bufs(self, n):
@@ -134,8 +165,12 @@ class FusedInferenceState(object):
       dev, L = self.device, self.L
       i64 = lambda k: torch.zeros(k, dtype=torch.int64, device=dev)
       u8 = lambda k: torch.zeros(k, dtype=torch.uint8, device=dev)
-      b = dict(reset=u8(n), prev_actions=i64(n), append_rows=i64(n), complete=u8(n), cols=i64(n), gsrc=i64(L * n),
-               gdst=i64(L * n), gmask=u8(L * n), last=i64(n))
+      b = dict(reset=u8(n), prev_actions=i64(n), append_rows=i64(n), complete=u8(n), carry=u8(n), cols=i64(n),
+               gsrc=i64(L * n), gdst=i64(L * n), gmask=u8(L * n), last=i64(n), ids_safe=i64(n), valid=u8(n),
+               actions=i64(n), zeros_bool=torch.zeros(n, dtype=torch.bool, device=dev),
+               zeros_i32=torch.zeros(n, dtype=torch.int32, device=dev))
+      tabs = utils.flatten(self.agent_states)
+      b['prev_state'] = [torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev) for t in tabs]
       self._scratch[n] = b
     return b
 
@@ -144,65 +179,102 @@ class FusedInferenceState(object):
     return unroll_store._row_bytes(t, lead)
 
   def inference(self, env_ids, run_ids, env_outputs, raw_rewards):
-    """learner.py:350-405.  env_ids must be unique within a call (flagged on the device otherwise: check_errors)."""
+    """learner.py:350-405.  env_ids must be unique and in range within a call: offending rows are skipped and flagged
+    on the device (check_errors) -- the reference raises.
+
+    Launches: inference_pre, ONE row-mover launch (previous states), the agent's single-step forward (5-6 kernels),
+    inference_post (samples the actions from the head rows), THREE row-mover launches (append + state tables; completed
+    unrolls -> training batch; carry-over) -- no eager tensor op in between."""
     dev = self.device
     ids = torch.as_tensor(env_ids, device=dev).to(torch.int64).contiguous()
     runs = torch.as_tensor(run_ids, device=dev).to(torch.int64).contiguous()
     n = ids.numel()
     b = self._bufs(n)
+    op = ops.row_op
     reward = env_outputs.reward.to(torch.float32).contiguous()
     done_u8 = ops.as_u8(env_outputs.done)
     ops.inference_pre(ids, runs, reward, raw_rewards.to(torch.float32).contiguous(), done_u8, n, self.E,
                       self.num_action_repeats, self.run_ids_tab, self.info_frames, self.info_return, self.info_raw,
                       self.actions_tab, self.store_index, b['reset'], b['prev_actions'], self.episode_stats,
-                      self.stats_count, self.error_flag)
+                      self.stats_count, self.error_flag, b['ids_safe'], b['valid'], self.stamp_tab, self.call_counter)
+    sid = b['ids_safe']
     # previous agent state (zeros for envs whose actor restarted), first-state table reset (:363-365, :382-383)
     tabs = utils.flatten(self.agent_states)
-    prev_leaves = [torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev) for t in tabs]
-    if tabs:
-      srb0 = [self._rb(t, 1) for t in tabs]
-      ops.rows_move_multi(prev_leaves, tabs, srb0, None, ids, n, b['reset'], zero_where_masked=True)
-      firsts0 = utils.flatten(self.first_agent_states)
-      ops.rows_move_multi(firsts0, [None] * len(firsts0), srb0, ids, None, n, b['reset'])
+    firsts = utils.flatten(self.first_agent_states)
+    prev_leaves = b['prev_state']
+    srb = [self._rb(t, 1) for t in tabs]
+    ops.rows_move_ops(
+        [op(p, t, rb, n, src_rows=sid, mask=b['reset'], zero_where_masked=True) for p, t, rb in zip(prev_leaves, tabs, srb)] +
+        [op(f, None, rb, n, dst_rows=sid, mask=b['reset']) for f, rb in zip(firsts, srb)])
     it = iter(prev_leaves)
     prev_state = utils.map_structure(lambda t: next(it), self.agent_states)
-    # single-step agent forward (:384-390)
-    agent_outputs, curr_state = self.agent(b['prev_actions'], env_outputs, prev_state, unroll=False, is_training=False)
-    agent_outputs = utils.map_structure(lambda t: t.contiguous(), agent_outputs)
-    ops.inference_post(ids, agent_outputs.action.to(torch.int64).contiguous(), n, self.E, self.L, self.cap,
-                       self.store_index, self.actions_tab, self.batch_count, b['append_rows'], b['complete'], b['cols'],
-                       b['gsrc'], b['gdst'], b['gmask'], b['last'], self.error_flag)
-    zeros_b = torch.zeros_like(env_outputs.done)
+    # single-step agent forward (:384-390); the action is sampled by inference_post from the head rows
+    fused_sampling = getattr(self.agent, 'accepts_sample_actions', False)
+    kw = dict(sample_actions=False) if fused_sampling else {}
+    agent_outputs, curr_state = self.agent(b['prev_actions'], env_outputs, prev_state, unroll=False, is_training=False,
+                                           **kw)
+    if fused_sampling:
+      head, _, ldh = self.agent.head_buffers()
+      A = agent_outputs.policy_logits.shape[-1]
+      logits_src, rng = head, self.agent.rng_state()
+    else:
+      head, ldh, A, logits_src, rng = None, 0, 0, None, None
+      b['actions'].copy_(agent_outputs.action)
+    ops.inference_post(sid, b['valid'], b['actions'], logits_src, ldh, A, rng, n, self.E, self.L, self.cap,
+                       self.store_index, self.actions_tab, self.batch_count, b['append_rows'], b['complete'], b['carry'],
+                       b['cols'], b['gsrc'], b['gdst'], b['gmask'], b['last'], self.error_flag)
     store_env = env_outputs._replace(
-        abandoned=env_outputs.abandoned if env_outputs.abandoned is not None else zeros_b,
-        episode_step=env_outputs.episode_step if env_outputs.episode_step is not None else zeros_b.to(torch.int32))
-    values = (b['prev_actions'], store_env, agent_outputs)
+        abandoned=env_outputs.abandoned if env_outputs.abandoned is not None else b['zeros_bool'],
+        episode_step=env_outputs.episode_step if env_outputs.episode_step is not None else b['zeros_i32'])
+    values = (b['prev_actions'], store_env, agent_outputs._replace(action=b['actions']))
     batch_fields = (self.batch.prev_actions, self.batch.env_outputs, self.batch.agent_outputs)
     stores = utils.flatten(self.store)
-    vals = [v.to(s.dtype).contiguous() for s, v in zip(stores, utils.flatten(values))]
     outs = utils.flatten(batch_fields)
-    rbs = [self._rb(s, 2) for s in stores]
-    ops.rows_move_multi(stores, vals, rbs, b['append_rows'], None, n)                          # :394 append
-    ops.rows_move_multi(outs, stores, rbs, b['gdst'], b['gsrc'], self.L * n, b['gmask'])       # completed unrolls -> batch
-    ops.rows_move_multi(stores, stores, rbs, ids, b['last'], n, b['complete'])                 # carry the last step
-    firsts, prevs = utils.flatten(self.first_agent_states), utils.flatten(prev_state)
-    if firsts:
-      srb = [self._rb(t, 1) for t in firsts]
-      ops.rows_move_multi(utils.flatten(self.batch.agent_state), firsts, srb, b['cols'], ids, n, b['complete'])  # :396
-      ops.rows_move_multi(firsts, prevs, srb, ids, None, n, b['complete'])                     # :398-399
-      ops.rows_move_multi(utils.flatten(self.agent_states), [c.contiguous() for c in utils.flatten(curr_state)], srb,
-                          ids, None, n)                                                        # :401
-    return agent_outputs.action
+    rbs = [self._rb(s_, 2) for s_ in stores]
+    # the step's values, read where they are: the head-GEMM output row [logits | baseline | pad] is a strided source
+    srcs = []
+    for s_, v in zip(stores, utils.flatten(values)):
+      if v.dtype != s_.dtype:
+        v = v.to(s_.dtype)
+      if fused_sampling and v.data_ptr() >= head.data_ptr() and \
+          v.data_ptr() < head.data_ptr() + head.numel() * 4 and not v.is_contiguous():
+        srcs.append((v, ldh * 4))                               # a column slice of the head buffer
+      else:
+        srcs.append((v.contiguous(), 0))
+    prevs, currs = utils.flatten(prev_state), [c.contiguous() for c in utils.flatten(curr_state)]
+    ops.rows_move_ops(
+        [op(s_, v, rb, n, dst_rows=b['append_rows'], mask=b['valid'], src_pitch=sp)                 # :394 append
+         for s_, (v, sp), rb in zip(stores, srcs, rbs)] +
+        [op(o, f, rb, n, dst_rows=b['cols'], src_rows=sid, mask=b['complete'])                      # :396 first states
+         for o, f, rb in zip(utils.flatten(self.batch.agent_state), firsts, srb)] +
+        [op(t, c, rb, n, dst_rows=sid, mask=b['valid']) for t, c, rb in zip(tabs, currs, srb)])     # :401
+    ops.rows_move_ops([op(o, s_, rb, self.L * n, dst_rows=b['gdst'], src_rows=b['gsrc'], mask=b['gmask'])
+                       for o, s_, rb in zip(outs, stores, rbs)])                                   # completed unrolls -> batch
+    ops.rows_move_ops(
+        [op(s_, s_, rb, n, dst_rows=sid, src_rows=b['last'], mask=b['carry']) for s_, rb in zip(stores, rbs)] +   # carry
+        [op(f, p, rb, n, dst_rows=sid, mask=b['carry']) for f, p, rb in zip(firsts, prevs, srb)])   # :398-399
+    return b['actions']
 
   def graphed(self, n, observation_shape, warmup=3):
     """Captures one inference call for batch size n in a HIP graph.  Returns fn(env_ids, run_ids, env_outputs,
-    raw_rewards) -> actions that copies its arguments into the graph's static inputs and replays it."""
+    raw_rewards) -> actions that copies its arguments into the graph's static inputs and replays it.
+
+    The static inputs are laid out for a transport layer: every per-request scalar lives in ONE byte buffer
+    (`fn.request`, layout `request_layout(n)`: ids i64 | run ids i64 | reward f32 | raw reward f32 | episode_step i32 |
+    done u8 | abandoned u8), so a front-end that batches requests in pinned host memory hands a batch over with two
+    copies -- the packed scalars and the frames -- through `fn.replay_packed(request, observation)`; for the Atari
+    agents the frames land directly in the agent's frame buffer (no device-side copy before the first conv)."""
     dev = self.device
-    si = dict(ids=torch.zeros(n, dtype=torch.int64, device=dev), runs=torch.zeros(n, dtype=torch.int64, device=dev),
-              raw=torch.zeros(n, device=dev))
-    senv = utils.EnvOutput(torch.zeros(n, device=dev), torch.zeros(n, dtype=torch.bool, device=dev),
-                           torch.zeros((n,) + tuple(observation_shape), dtype=torch.uint8, device=dev),
-                           torch.zeros(n, dtype=torch.bool, device=dev), torch.zeros(n, dtype=torch.int32, device=dev))
+    lay = request_layout(n)
+    req = torch.zeros(lay['bytes'], dtype=torch.uint8, device=dev)
+    view = lambda k, dt: req[lay[k][0]:lay[k][0] + lay[k][1]].view(dt)
+    si = dict(ids=view('ids', torch.int64), runs=view('runs', torch.int64), raw=view('raw', torch.float32))
+    if hasattr(self.agent, 'frames_buffer') and len(observation_shape) == 3 and observation_shape[2] == 1:
+      obs = self.agent.frames_buffer(1, n)[3:].view((n,) + tuple(observation_shape))   # what the first conv reads
+    else:
+      obs = torch.zeros((n,) + tuple(observation_shape), dtype=torch.uint8, device=dev)
+    senv = utils.EnvOutput(view('reward', torch.float32), view('done', torch.bool), obs,
+                           view('abandoned', torch.bool), view('episode_step', torch.int32))
     saved = [t.clone() for t in self._state_tensors()]
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -229,12 +301,21 @@ class FusedInferenceState(object):
         senv.episode_step.copy_(env_outputs.episode_step)
       graph.replay()
       return actions
-    fn.graph, fn.static_inputs, fn.static_env = graph, si, senv
+
+    def replay_packed(request, observation):
+      """request: uint8[request_layout(n)['bytes']] (host pinned or device), observation uint8 [n, ...]."""
+      req.copy_(request, non_blocking=True)
+      senv.observation.copy_(observation, non_blocking=True)
+      graph.replay()
+      return actions
+    fn.graph, fn.static_inputs, fn.static_env, fn.request, fn.replay_packed = graph, si, senv, req, replay_packed
     return fn
 
   def _state_tensors(self):
+    rng = [self.agent.rng_state()] if hasattr(self.agent, 'rng_state') else []
     return ([self.run_ids_tab, self.info_frames, self.actions_tab, self.store_index, self.info_return, self.info_raw,
-             self.batch_count, self.stats_count, self.error_flag, self.episode_stats] +
+             self.batch_count, self.stats_count, self.error_flag, self.episode_stats, self.stamp_tab,
+             self.call_counter] + rng +
             utils.flatten(self.store) + utils.flatten(self.first_agent_states) + utils.flatten(self.agent_states) +
             utils.flatten(self.batch))
 

@@ -196,15 +196,31 @@ class _Agent(object):
     ops.conv2d_fwd(g, feat, self.flat.p('heads/kernel'), self.flat.p('heads/bias'), head)
     return head
 
-  def _sample(self, logits):
-    gmb = -torch.log(-torch.log(torch.rand_like(logits).clamp_min(1e-20)).clamp_min(1e-20))
-    return torch.argmax(logits + gmb, dim=-1)
+  def rng_state(self):
+    """Device uint64[2] = (seed, call counter) of the action sampler; the kernels advance the counter themselves, so
+    sampling sits inside captured HIP graphs."""
+    if getattr(self, '_rng', None) is None:
+      self._rng = torch.tensor([self._sample_seed, 0], dtype=torch.int64, device=self.device)
+    return self._rng
+
+  def seed_sampler(self, seed):
+    self._sample_seed = int(seed)
+    self._rng = None
+
+  _sample_seed = 0x5EED
+
+  def _sample(self, head, rows):
+    """tfd.Categorical(logits).sample() of the reference heads (dmlab/networks.py:122): one kernel over the head-GEMM
+    output rows [rows, ldh] (logits in columns 0..A-1), Gumbel-max over counter-based randoms."""
+    action = torch.empty(rows, dtype=torch.int64, device=self.device)
+    ops.categorical_sample(head, self._ldh, rows, self._num_actions, self.rng_state(), action)
+    return action
 
   def _agent_output(self, head, T1, B, sample):
     A = self._num_actions
     h3 = head.view(T1, B, self._ldh)
     logits, baseline = h3[..., :A], h3[..., A]
-    action = self._sample(logits) if sample else None
+    action = self._sample(head, T1 * B).view(T1, B) if sample else None
     return AgentOutput(action, logits, baseline)
 
 
@@ -450,8 +466,12 @@ class AtariShallow(_Agent, _AtariTorso):
                                                                       device=self.device))
 
   accepts_need_state = True      # need_state=False: skip re-packing the frame-stacking state the caller will not use
+  accepts_sample_actions = True
 
-  def __call__(self, prev_actions, env_outputs, agent_state, unroll=False, is_training=False, need_state=True):
+  def __call__(self, prev_actions, env_outputs, agent_state, unroll=False, is_training=False, need_state=True,
+               sample_actions=True):
+    """sample_actions=False (central inference): the caller samples from head_buffers() itself (fused into the
+    inference bookkeeping kernel); the returned action is None."""
     del prev_actions   # the feed-forward agent does not consume it
     obs, done = env_outputs.observation, env_outputs.done
     if not unroll:
@@ -463,7 +483,7 @@ class AtariShallow(_Agent, _AtariTorso):
     new_fs, ctx = self._torso_fwd(obs, done_u8, agent_state.frame_stacking_state, hfc, self._fc, need_state)
     head = self._head_fwd(hfc, N, self._fc)
     self._last = dict(T1=T1, B=B, N=N, ctx=ctx, hfc=hfc, head=head)
-    out = self._agent_output(head, T1, B, sample=not is_training)
+    out = self._agent_output(head, T1, B, sample=sample_actions and not is_training)
     if not unroll:
       out = AgentOutput(*[None if t is None else t[0] for t in out])
     return out, AgentState(core_state=(), frame_stacking_state=new_fs)
@@ -626,7 +646,9 @@ class ImpalaDeep(_Agent):
     z = torch.zeros((batch_size, self._H), dtype=torch.float32, device=self.device)
     return (z, z.clone())
 
-  def __call__(self, prev_actions, env_outputs, core_state, unroll=False, is_training=False):
+  accepts_sample_actions = True
+
+  def __call__(self, prev_actions, env_outputs, core_state, unroll=False, is_training=False, sample_actions=True):
     reward, done, obs = env_outputs.reward, env_outputs.done, env_outputs.observation
     if not unroll:
       reward, done, obs, prev_actions = reward[None], done[None], obs[None], prev_actions[None]
@@ -676,7 +698,7 @@ class ImpalaDeep(_Agent):
     Hout, new_state = self._lstm_fwd(X, ldx, self._in_dim, self._H, T1, B, done_u8, core_state)
     head = self._head_fwd(Hout, N, self._H)
     self._last = dict(T1=T1, B=B, N=N, saved=saved, flat=flat, gfc=gfc, X=X, Hout=Hout, head=head)
-    out = self._agent_output(head, T1, B, sample=not is_training)
+    out = self._agent_output(head, T1, B, sample=sample_actions and not is_training)
     if not unroll:
       out = AgentOutput(*[None if t is None else t[0] for t in out])
     return out, new_state

@@ -446,24 +446,60 @@ def rows_move_masked(dst, dst_rows, src, src_rows, n, row_bytes, mask_u8, zero_w
 
 def inference_pre(env_ids, run_ids, reward, raw_reward, done_u8, n, num_envs, num_action_repeats, run_ids_tab,
                   info_frames, info_return, info_raw, actions_tab, store_index, reset_mask, prev_actions,
-                  episode_stats, stats_count, error_flag):
+                  episode_stats, stats_count, error_flag, ids_safe, valid, stamp_tab, call_counter):
   with _dev(reset_mask):
     _lib.check(_lib.lib().seedhip_inference_pre(
         _lib.ptr(env_ids), _lib.ptr(run_ids), _lib.ptr(reward), _lib.ptr(raw_reward), _lib.ptr(done_u8), n, num_envs,
         num_action_repeats, _lib.ptr(run_ids_tab), _lib.ptr(info_frames), _lib.ptr(info_return), _lib.ptr(info_raw),
         _lib.ptr(actions_tab), _lib.ptr(store_index), _lib.ptr(reset_mask), _lib.ptr(prev_actions),
-        _lib.ptr(episode_stats), episode_stats.shape[0], _lib.ptr(stats_count), _lib.ptr(error_flag), _lib.stream()),
+        _lib.ptr(episode_stats), episode_stats.shape[0], _lib.ptr(stats_count), _lib.ptr(error_flag),
+        _lib.ptr(ids_safe), _lib.ptr(valid), _lib.ptr(stamp_tab), _lib.ptr(call_counter), _lib.stream()),
         'seedhip_inference_pre')
 
 
-def inference_post(env_ids, actions, n, num_envs, full_length, batch_capacity, store_index, actions_tab, batch_count,
-                   append_rows, complete, batch_cols, gather_src, gather_dst, gather_mask, last_rows, error_flag):
+def inference_post(env_ids, valid, actions, logits, logits_ld, num_actions, rng_state, n, num_envs, full_length,
+                   batch_capacity, store_index, actions_tab, batch_count, append_rows, complete, carry, batch_cols,
+                   gather_src, gather_dst, gather_mask, last_rows, error_flag):
+  """logits given (a view whose first element is row 0's first logit): the actions are sampled in the kernel and
+  written to `actions`; logits None: `actions` is an input."""
   with _dev(complete):
     _lib.check(_lib.lib().seedhip_inference_post(
-        _lib.ptr(env_ids), _lib.ptr(actions), n, num_envs, full_length, batch_capacity, _lib.ptr(store_index),
-        _lib.ptr(actions_tab), _lib.ptr(batch_count), _lib.ptr(append_rows), _lib.ptr(complete), _lib.ptr(batch_cols),
-        _lib.ptr(gather_src), _lib.ptr(gather_dst), _lib.ptr(gather_mask), _lib.ptr(last_rows), _lib.ptr(error_flag),
-        _lib.stream()), 'seedhip_inference_post')
+        _lib.ptr(env_ids), _lib.ptr(valid), _lib.ptr(actions), _lib.ptr(logits), logits_ld, num_actions,
+        _lib.ptr(rng_state), n, num_envs, full_length, batch_capacity, _lib.ptr(store_index),
+        _lib.ptr(actions_tab), _lib.ptr(batch_count), _lib.ptr(append_rows), _lib.ptr(complete), _lib.ptr(carry),
+        _lib.ptr(batch_cols), _lib.ptr(gather_src), _lib.ptr(gather_dst), _lib.ptr(gather_mask), _lib.ptr(last_rows),
+        _lib.ptr(error_flag), _lib.stream()), 'seedhip_inference_post')
+
+
+def categorical_sample(logits, ld, rows, num_actions, rng_state, actions):
+  """actions[r] ~ Categorical(logits row r) (Gumbel-max over Philox randoms; advances rng_state[1])."""
+  with _dev(actions):
+    _lib.check(_lib.lib().seedhip_categorical_sample(_lib.ptr(logits), ld, rows, num_actions, _lib.ptr(rng_state),
+                                                     _lib.ptr(actions), _lib.stream()), 'seedhip_categorical_sample')
+
+
+def row_op(dst, src, row_bytes, n, dst_rows=None, src_rows=None, mask=None, zero_where_masked=False, dst_pitch=0,
+           src_pitch=0):
+  """One operation of rows_move_ops (tensors are only pointer carriers; the caller keeps them alive)."""
+  return (dst, src, int(row_bytes), int(dst_pitch), int(src_pitch), dst_rows, src_rows, int(n), mask,
+          int(zero_where_masked))
+
+
+def rows_move_ops(op_list):
+  """Independent row moves in one launch (groups of 32)."""
+  op_list = [o for o in op_list if o[7] > 0]
+  for lo in range(0, len(op_list), 32):
+    chunk = op_list[lo:lo + 32]
+    arr = (_lib.RowOp * len(chunk))()
+    for k, (dst, src, rb, dp, sp, dr, sr, n, mask, z) in enumerate(chunk):
+      a = arr[k]
+      a.dst, a.src, a.row_bytes, a.dst_pitch, a.src_pitch = dst.data_ptr(), (src.data_ptr() if src is not None else None), rb, dp, sp
+      a.dst_rows = dr.data_ptr() if dr is not None else None
+      a.src_rows = sr.data_ptr() if sr is not None else None
+      a.n, a.row_mask, a.zero_where_masked = n, (mask.data_ptr() if mask is not None else None), z
+    with _dev(chunk[0][0]):
+      _lib.check(_lib.lib().seedhip_rows_move_ops(len(chunk), ctypes.cast(arr, ctypes.c_void_p), _lib.stream()),
+                 'seedhip_rows_move_ops')
 
 
 def rows_move_multi(dsts, srcs, row_bytes, dst_rows, src_rows, n, mask_u8=None, zero_where_masked=False):

@@ -19,6 +19,7 @@ class ParametricDistribution(object):
   def __init__(self, param_size, dtype=torch.int64):
     self._param_size = param_size
     self._dtype = dtype
+    self._rng = {}
 
   @property
   def param_size(self):
@@ -66,11 +67,21 @@ class ParametricDistribution(object):
     """parametric_distribution.py:72-74."""
     return self._run(parameters, None, False, True)[1]
 
-  def sample(self, parameters):
-    """parametric_distribution.py:66-67 (tfd.Categorical.sample; used by the
-    agents' _head, dmlab/networks.py:120-122).  Gumbel-max on device."""
-    g = -torch.log(-torch.log(torch.rand_like(parameters).clamp_min(1e-20)).clamp_min(1e-20))
-    return torch.argmax(parameters + g, dim=-1).to(self._dtype)
+  def sample(self, parameters, seed=None):
+    """parametric_distribution.py:66-67 (tfd.Categorical.sample; used by the agents' _head,
+    dmlab/networks.py:120-122): Gumbel-max over counter-based randoms in one kernel (csrc/inference.hip:
+    seedhip_categorical_sample); the generator state is a device (seed, counter) pair per device."""
+    _lib.require_cuda(parameters)
+    from seed_rl_amd import ops
+    logits = self._rows(parameters)
+    key = logits.device
+    rng = self._rng.get(key)
+    if rng is None or seed is not None:
+      rng = torch.tensor([0x5EED if seed is None else int(seed), 0], dtype=torch.int64, device=logits.device)
+      self._rng[key] = rng
+    out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
+    ops.categorical_sample(logits, self._param_size, logits.shape[0], self._param_size, rng, out)
+    return out.reshape(parameters.shape[:-1]).to(self._dtype)
 
 
 def categorical_distribution(n_actions, dtype=torch.int64):

@@ -41,6 +41,36 @@ def _grad_errs(agent, p, floor=1e-3):
   return worst, worst_name, per
 
 
+def _truth_errs(agent, p32, p64, floor=1e-3):
+  """Both fp32 evaluations against the fp64 evaluation of the same graph: (hip_err, hip_worst, oracle_err, oracle_worst)
+  with err = max over tensors of max|g - g64| / max(max|g64|, floor)."""
+  grads = agent.reference_gradients()
+  hw = ow = (0.0, None)
+  for n, t64 in p64.items():
+    r = t64.grad.numpy()
+    den = max(float(np.abs(r).max()), floor)
+    eh = float(np.max(np.abs(grads[n].cpu().numpy().astype(np.float64) - r)) / den)
+    eo = float(np.max(np.abs(p32[n].grad.numpy().astype(np.float64) - r)) / den)
+    if eh >= hw[0]:
+      hw = (eh, n)
+    if eo >= ow[0]:
+      ow = (eo, n)
+  return hw[0], hw[1], ow[0], ow[1]
+
+
+def _truth(out, agent, p32, run64, floor=1e-3):
+  """Adds the fp64 comparison to a record: run64() evaluates the oracle graph in fp64 and returns its parameters (with
+  .grad).  fp32 re-association alone moves a gradient of ~1e4 summed terms by ~1e-3 of its tensor's maximum (oneDNN's
+  blocked fp32 accumulation as much as the MFMA tiles'), so HIP-vs-oracle alone cannot tell noise from a defect; the
+  distance of EACH fp32 result to the fp64 value can."""
+  t0 = time.perf_counter()
+  with nets_torch.float64_truth():
+    p64 = run64()
+  (out['grad_max_rel_err_vs_fp64'], out['grad_worst_vs_fp64'], out['oracle_grad_max_rel_err_vs_fp64'],
+   out['oracle_grad_worst_vs_fp64']) = _truth_errs(agent, p32, p64, floor)
+  out['fp64_s'] = round(time.perf_counter() - t0, 2)
+
+
 def _param_errs(agent, p):
   mx, cnt, tot = 0.0, 0, 0
   for (n, v), t in zip(agent.trainable_variables, p.values()):
@@ -52,7 +82,7 @@ def _param_errs(agent, p):
 
 
 def atari_step(device, T1=21, B=512, A=18, seed=3, torso='shallow', lr=4.8e-4, loss_kw=None, done_p=0.01,
-               zero_state=True, learner_kw=None):
+               zero_state=True, learner_kw=None, truth=True):
   """cfg2 (BASELINE configs[1]): Atari 84x84x4 shallow ConvNet; flag-default loss (learner.py:51-62) unless loss_kw."""
   from seed_rl_amd import learner, networks, optimizers, utils, parametric_distribution as pd
   kind = 'atari_shallow' if torso == 'shallow' else 'atari_dqn_body'
@@ -71,13 +101,17 @@ def atari_step(device, T1=21, B=512, A=18, seed=3, torso='shallow', lr=4.8e-4, l
   loss = float(loss)
 
   t0 = time.perf_counter()
-  p = nets_torch.to_torch(ref_params, requires_grad=True)
   t = lambda a: torch.tensor(a)
-  logits, baseline, _, _ = nets_torch.atari_shallow_unroll(
-      p, kind, A, t(u['prev_actions']), t(u['reward']), t(u['done']), t(u['frames']), t(u['frame_state']))
-  total, _ = nets_torch.impala_loss_torch(logits, baseline, t(u['behaviour_logits']), t(u['actions']), t(u['reward']),
-                                          t(u['done']), entropy_cost=0.00025, **loss_kw)
-  total.backward()
+
+  def oracle(dtype):
+    p = nets_torch.to_torch(ref_params, requires_grad=True, dtype=dtype)
+    logits, baseline, _, _ = nets_torch.atari_shallow_unroll(
+        p, kind, A, t(u['prev_actions']), t(u['reward']), t(u['done']), t(u['frames']), t(u['frame_state']))
+    total, _ = nets_torch.impala_loss_torch(logits, baseline, t(u['behaviour_logits']), t(u['actions']), t(u['reward']),
+                                            t(u['done']), entropy_cost=0.00025, **loss_kw)
+    total.backward()
+    return p, total, logits, baseline
+  p, total, logits, baseline = oracle(torch.float32)
   ref = float(total.detach())
   head, _, ldh = agent.head_buffers()
   head = head.cpu().numpy().reshape(T1, B, ldh)
@@ -85,16 +119,18 @@ def atari_step(device, T1=21, B=512, A=18, seed=3, torso='shallow', lr=4.8e-4, l
              logits_max_abs_err=float(np.max(np.abs(head[..., :A] - logits.detach().numpy()))),
              baseline_max_abs_err=float(np.max(np.abs(head[..., A] - baseline.detach().numpy()))))
   out['grad_max_rel_err'], out['grad_worst'], out['grad_rel_err'] = _grad_errs(agent, p)
+  out['oracle_s'] = round(time.perf_counter() - t0, 2)
+  if truth:
+    _truth(out, agent, p, lambda: oracle(torch.float64)[0])
   lrn.apply_gradients()
   kopt = nets_torch.KerasAdam(list(p.values()), nets_torch.polynomial_decay(lr, 100), beta_1=0.0, epsilon=3.125e-7)
   kopt.apply_gradients([x.grad for x in p.values()])
   out['param_max_abs_err'], out['param_frac_gt_5e5'] = _param_errs(agent, p)
-  out['oracle_s'] = round(time.perf_counter() - t0, 2)
   out['shape'] = dict(T=T1 - 1, B=B, A=A)
   return out
 
 
-def deep_step(device, T1=21, B=16, A=9, seed=7, obs=(72, 96, 3), lr=4.8e-4, loss_kw=None, done_p=0.05):
+def deep_step(device, T1=21, B=16, A=9, seed=7, obs=(72, 96, 3), lr=4.8e-4, loss_kw=None, done_p=0.05, truth=True):
   """cfg3 (BASELINE configs[2]): ImpalaDeep + LSTM(256) (dmlab/networks.py:63-171)."""
   from seed_rl_amd import learner, networks, optimizers, utils, parametric_distribution as pd
   loss_kw = dict(loss_kw or {})
@@ -112,13 +148,18 @@ def deep_step(device, T1=21, B=16, A=9, seed=7, obs=(72, 96, 3), lr=4.8e-4, loss
   loss = float(loss)
 
   t0 = time.perf_counter()
-  p = nets_torch.to_torch(ref_params, requires_grad=True)
   t = lambda a: torch.tensor(a)
-  logits, baseline, _ = nets_torch.impala_deep_unroll(
-      p, A, t(u['prev_actions']), t(u['reward']), t(u['done']), t(u['frames']), (t(u['h0']), t(u['c0'])))
-  total, _ = nets_torch.impala_loss_torch(logits, baseline, t(u['behaviour_logits']), t(u['actions']), t(u['reward']),
-                                          t(u['done']), entropy_cost=0.00025, **loss_kw)
-  total.backward()
+
+  def oracle(dtype):
+    p = nets_torch.to_torch(ref_params, requires_grad=True, dtype=dtype)
+    logits, baseline, _ = nets_torch.impala_deep_unroll(
+        p, A, t(u['prev_actions']), t(u['reward']), t(u['done']), t(u['frames']),
+        (t(u['h0']).to(dtype), t(u['c0']).to(dtype)))
+    total, _ = nets_torch.impala_loss_torch(logits, baseline, t(u['behaviour_logits']), t(u['actions']), t(u['reward']),
+                                            t(u['done']), entropy_cost=0.00025, **loss_kw)
+    total.backward()
+    return p, total, logits, baseline
+  p, total, logits, baseline = oracle(torch.float32)
   ref = float(total.detach())
   head, _, ldh = agent.head_buffers()
   head = head.cpu().numpy().reshape(T1, B, ldh)
@@ -130,16 +171,18 @@ def deep_step(device, T1=21, B=16, A=9, seed=7, obs=(72, 96, 3), lr=4.8e-4, loss
   post = [e for n, e in out['grad_rel_err'].items()
           if not (n.startswith('stack0/') or n.startswith('stack1/') or n.startswith('stack2/conv/'))]
   out['grad_max_rel_err_post_pool'] = max(post)
+  out['oracle_s'] = round(time.perf_counter() - t0, 2)
+  if truth:
+    _truth(out, agent, p, lambda: oracle(torch.float64)[0])
   lrn.apply_gradients()
   kopt = nets_torch.KerasAdam(list(p.values()), nets_torch.polynomial_decay(lr, 100), beta_1=0.0, epsilon=3.125e-7)
   kopt.apply_gradients([x.grad for x in p.values()])
   out['param_max_abs_err'], out['param_frac_gt_5e5'] = _param_errs(agent, p)
-  out['oracle_s'] = round(time.perf_counter() - t0, 2)
   out['shape'] = dict(T=T1 - 1, B=B, A=A)
   return out
 
 
-def r2d2_step(device, T1=121, B=4, A=18, seed=5, burn_in=40, n_steps=5, done_p=0.01):
+def r2d2_step(device, T1=121, B=4, A=18, seed=5, burn_in=40, n_steps=5, done_p=0.01, truth=True):
   """cfg5 (BASELINE configs[4]): DuelingLSTMDQNNet training + target network, burn-in, n-step double-Q loss,
   global-norm clip 40, Adam(eps 1e-3) (agents/r2d2/learner.py:333-384,572-636; atari/r2d2_main.py:36-39)."""
   from seed_rl_amd import networks, optimizers, r2d2_learner, utils
@@ -166,22 +209,27 @@ def r2d2_step(device, T1=121, B=4, A=18, seed=5, burn_in=40, n_steps=5, done_p=0
   prio = prio.cpu().numpy().copy()
 
   t0 = time.perf_counter()
-  p = nets_torch.to_torch(ref, requires_grad=True)
-  pt = nets_torch.to_torch(ref_t)
   t = lambda a: torch.tensor(a)
 
-  def run(pp, lo, hi, fs, core):
-    return nets_torch.r2d2_unroll(pp, A, t(u['prev_actions'][lo:hi]), t(u['reward'][lo:hi]), t(u['done'][lo:hi]),
-                                  t(u['frames'][lo:hi]), fs, core)
-  with torch.no_grad():
-    _, fs1, core1 = run(p, 0, burn_in, t(u['frame_state']), (t(h0), t(c0)))
-    _, fs1t, core1t = run(pt, 0, burn_in, t(u['frame_state']), (t(h0), t(c0)))
-    out_t, _, _ = run(pt, burn_in, T1, fs1t, core1t)
-  o, _, _ = run(p, burn_in, T1, fs1, tuple(x.detach() for x in core1))
-  total_ref, _, prio_ref = nets_torch.r2d2_loss_torch(
-      o.q_values, out_t.q_values, t(u['actions'][burn_in:]), t(u['reward'][burn_in:]), t(u['done'][burn_in:]),
-      t(iw), cfg.discounting, cfg.n_steps)
-  total_ref.backward()
+  def oracle(dtype):
+    p = nets_torch.to_torch(ref, requires_grad=True, dtype=dtype)
+    pt = nets_torch.to_torch(ref_t, dtype=dtype)
+
+    def run(pp, lo, hi, fs, core):
+      return nets_torch.r2d2_unroll(pp, A, t(u['prev_actions'][lo:hi]), t(u['reward'][lo:hi]), t(u['done'][lo:hi]),
+                                    t(u['frames'][lo:hi]), fs, core)
+    s0 = (t(h0).to(dtype), t(c0).to(dtype))
+    with torch.no_grad():
+      _, fs1, core1 = run(p, 0, burn_in, t(u['frame_state']), s0)
+      _, fs1t, core1t = run(pt, 0, burn_in, t(u['frame_state']), s0)
+      out_t, _, _ = run(pt, burn_in, T1, fs1t, core1t)
+    o, _, _ = run(p, burn_in, T1, fs1, tuple(x.detach() for x in core1))
+    total_ref, _, prio_ref = nets_torch.r2d2_loss_torch(
+        o.q_values, out_t.q_values, t(u['actions'][burn_in:]), t(u['reward'][burn_in:]), t(u['done'][burn_in:]),
+        t(iw).to(dtype), cfg.discounting, cfg.n_steps)
+    total_ref.backward()
+    return p, total_ref, prio_ref, o
+  p, total_ref, prio_ref, o = oracle(torch.float32)
   refv = float(total_ref.detach())
   q_gpu = agent._buf('q', ((T1 - burn_in) * B, A)).cpu().numpy().reshape(T1 - burn_in, B, A)
   pr = prio_ref.detach().numpy()
@@ -189,6 +237,9 @@ def r2d2_step(device, T1=121, B=4, A=18, seed=5, burn_in=40, n_steps=5, done_p=0
              q_max_abs_err=float(np.max(np.abs(q_gpu - o.q_values.detach().numpy()))),
              priority_max_rel_err=float(np.max(np.abs(prio - pr) / np.maximum(np.abs(pr), 1e-1))))
   out['grad_max_rel_err'], out['grad_worst'], out['grad_rel_err'] = _grad_errs(agent, p, floor=1e-4)
+  out['oracle_s'] = round(time.perf_counter() - t0, 2)
+  if truth:
+    _truth(out, agent, p, lambda: oracle(torch.float64)[0], floor=1e-4)
   lrn.reduce_gradients()
   lrn.update()
   gn = float(torch.sqrt(sumsq[0]))
@@ -198,7 +249,6 @@ def r2d2_step(device, T1=121, B=4, A=18, seed=5, burn_in=40, n_steps=5, done_p=0
   kopt = nets_torch.KerasAdam(list(p.values()), lambda step: 4.8e-4, epsilon=1e-3)
   kopt.apply_gradients([x.grad * scale for x in p.values()])
   out['param_max_abs_err'], out['param_frac_gt_5e5'] = _param_errs(agent, p)
-  out['oracle_s'] = round(time.perf_counter() - t0, 2)
   out['shape'] = dict(T=T1 - 1, B=B, A=A, burn_in=burn_in)
   return out
 

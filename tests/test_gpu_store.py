@@ -159,7 +159,7 @@ def _drive(device, st_call, E, T, A, obs_shape, steps, seed=0):
   return acts
 
 
-@pytest.mark.parametrize('kind,graphed', [('atari', False), ('deep', False), ('atari', True)])
+@pytest.mark.parametrize('kind,graphed', [('atari', False), ('deep', False), ('atari', True), ('deep', True)])
 def test_fused_inference_matches_reference_structured_inference(device, kind, graphed):
   """FusedInferenceState (no host syncs, masks + device scans, optional HIP-graph replay) vs InferenceState (the
   op-by-op mirror of learner.py:350-405) on identical actor traffic incl. an actor restart and episode ends:
@@ -182,17 +182,16 @@ def test_fused_inference_matches_reference_structured_inference(device, kind, gr
   call = fused.graphed(2, obs_shape) if graphed else fused.inference
   acts = _drive(device, call, E, T, A, obs_shape, steps)
   fused.check_errors()
-  if not graphed:                     # graph replay draws its action-sampling randoms from the captured generator
-    for a, b in zip(acts, acts_ref):  # state, so sampled actions differ; everything below is conditional on them
-      assert torch.equal(a, b)
+  # the action sampler is counter-based (seed, call, row) and advanced on the device: the mirror (stand-alone sampling
+  # kernel), the fused step (sampling inside inference_post) and its HIP-graph replay draw the SAME actions
+  for a, b in zip(acts, acts_ref):
+    assert torch.equal(a, b)
   k, batch = fused.take_batch()
   assert k == sum(int(u.env_outputs.done.shape[1]) for u in unrolls) and k > 0
-  if graphed:
-    # on-policy consistency instead of equality with the reference run: re-running the training unroll on every
-    # emitted unroll reproduces the logits stored at inference time
-    out, _ = fused.agent(batch.prev_actions, batch.env_outputs, batch.agent_state, unroll=True, is_training=True)
-    assert torch.allclose(out.policy_logits, batch.agent_outputs.policy_logits, atol=2e-5)
-    return
+  # on-policy consistency: re-running the training unroll on every emitted unroll reproduces the logits stored at
+  # inference time
+  out, _ = fused.agent(batch.prev_actions, batch.env_outputs, batch.agent_state, unroll=True, is_training=True)
+  assert torch.allclose(out.policy_logits, batch.agent_outputs.policy_logits, atol=2e-5)
   cat = lambda xs, dim: torch.cat(xs, dim)
   ref_first = utils.map_structure(lambda *xs: cat(list(xs), 0), *[u.agent_state for u in unrolls])
   for a, b in zip(utils.flatten(ref_first), utils.flatten(batch.agent_state)):
@@ -207,3 +206,128 @@ def test_fused_inference_matches_reference_structured_inference(device, kind, gr
   ns = int(fused.stats_count[0])
   got = sorted((int(f), round(float(r), 5), round(float(w), 5)) for f, r, w in fused.episode_stats[:ns].tolist())
   assert got == ref_stats and ns > 0
+
+
+def test_categorical_sample_kernel(device):
+  """seedhip_categorical_sample: frequencies follow softmax(logits) (chi-square over 2e5 draws, A = 18), the sample is
+  a pure function of (seed, counter, row), and strided head rows are read in place."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(0)
+  A, ld, rows = 18, 20, 200000
+  logit_row = rng.normal(size=A).astype(np.float32) * 1.5
+  head = np.zeros((rows, ld), np.float32); head[:, :A] = logit_row; head[:, A:] = 50.0     # pad columns must be ignored
+  hd = torch.tensor(head, device=device)
+  st = torch.tensor([1234, 0], dtype=torch.int64, device=device)
+  act = torch.empty(rows, dtype=torch.int64, device=device)
+  ops.categorical_sample(hd, ld, rows, A, st, act)
+  a = act.cpu().numpy()
+  assert a.min() >= 0 and a.max() < A and int(st[1]) == 1
+  p = np.exp(logit_row - logit_row.max()); p /= p.sum()
+  cnt = np.bincount(a, minlength=A)
+  chi2 = float(((cnt - rows * p) ** 2 / (rows * p)).sum())
+  assert chi2 < 50.0, chi2                       # 17 degrees of freedom: P(chi2 > 50) ~ 4e-5
+  # determinism: same (seed, counter) -> same actions; next counter -> different draw
+  st2 = torch.tensor([1234, 0], dtype=torch.int64, device=device)
+  act2 = torch.empty_like(act)
+  ops.categorical_sample(hd, ld, rows, A, st2, act2)
+  assert torch.equal(act, act2)
+  ops.categorical_sample(hd, ld, rows, A, st2, act2)
+  assert not torch.equal(act, act2)
+  # a peaked row always returns its mode; ParametricDistribution.sample goes through the same kernel
+  from seed_rl_amd import parametric_distribution as pd
+  lg = torch.full((7, 5, A), -30.0, device=device); lg[..., 11] = 30.0
+  assert bool((pd.categorical_distribution(A).sample(lg) == 11).all())
+
+
+def _mk_fused(device, E, T, A, cap):
+  from seed_rl_amd import inference, networks, utils
+  from seed_rl_amd.unroll_store import Spec
+  obs_shape = (84, 84, 1)
+  env_specs = utils.EnvOutput(Spec((), torch.float32), Spec((), torch.bool), Spec(obs_shape, torch.uint8),
+                              Spec((), torch.bool), Spec((), torch.int32))
+  ao_specs = networks.AgentOutput(Spec((), torch.int64), Spec((A,), torch.float32), Spec((), torch.float32))
+  agent = networks.AtariShallow(A, device=device, seed=0)
+  return inference.FusedInferenceState(agent, E, T, env_specs, ao_specs, batch_capacity=cap, device=device), obs_shape
+
+
+def _req(device, ids, step, obs_shape, seed):
+  from seed_rl_amd import utils
+  rng = np.random.default_rng(seed)
+  n = len(ids)
+  env = utils.EnvOutput(
+      reward=torch.tensor(rng.normal(size=n).astype(np.float32), device=device),
+      done=torch.zeros(n, dtype=torch.bool, device=device),
+      observation=torch.tensor(rng.integers(0, 256, (n,) + obs_shape).astype(np.uint8), device=device),
+      abandoned=torch.zeros(n, dtype=torch.bool, device=device),
+      episode_step=torch.full((n,), step, dtype=torch.int32, device=device))
+  return torch.tensor(ids, dtype=torch.int64, device=device), torch.full((n,), 7, dtype=torch.int64, device=device), env
+
+
+def test_fused_inference_bad_ids_are_masked_not_fatal(device):
+  """an out-of-range or duplicate env id must not touch memory it does not own.  The offending rows are
+  skipped (flags 1 / 2, check_errors raises like the reference would) and the valid rows of the same batch are
+  processed exactly as without them."""
+  T, E, A = 3, 4, 6
+  good, obs_shape = _mk_fused(device, E, T, A, 8)
+  bad, _ = _mk_fused(device, E, T, A, 8)
+  for step in range(T + 2):
+    ids, runs, env = _req(device, [0, 2], step, obs_shape, step)
+    good.inference(ids, runs, env, env.reward)
+    # same two rows + one out-of-range id + one duplicate of env 2 appended (rows 2, 3)
+    ids4 = torch.tensor([0, 2, 1000000, 2], dtype=torch.int64, device=device)
+    env4 = env._replace(**{k: torch.cat([getattr(env, k), getattr(env, k)], 0) for k in env._fields})
+    bad.inference(ids4, torch.cat([runs, runs]), env4, env4.reward)
+  torch.cuda.synchronize()
+  good.check_errors()
+  assert int(bad.error_flag[0]) & 3 == 3
+  with pytest.raises(ValueError):
+    bad.check_errors()
+  from seed_rl_amd import utils
+  for a, b in zip(utils.flatten(good.store) + [good.store_index, good.actions_tab, good.batch_count],
+                  utils.flatten(bad.store) + [bad.store_index, bad.actions_tab, bad.batch_count]):
+    if a.dim() >= 2 and a.shape[1] == E:
+      assert torch.equal(a[:, [0, 1, 3]], b[:, [0, 1, 3]])          # env 2's duplicate may have won the race; others exact
+    else:
+      assert torch.equal(a[[0, 1, 3]], b[[0, 1, 3]]) if a.numel() == E else torch.equal(a, b)
+
+
+def test_fused_inference_batch_overflow_keeps_store_consistent(device):
+  """when the training batch is full (flag 8) a completed unroll is dropped, but its last step is still
+  carried to slot 0 -- the env's NEXT unroll starts with the overlap step, as utils.py:237-255 prescribes."""
+  T, E, A = 2, 2, 6
+  st, obs_shape = _mk_fused(device, E, T, A, 1)                   # room for ONE unroll; two complete at once
+  last_env = None
+  for step in range(T + 1):
+    ids, runs, env = _req(device, [0, 1], step, obs_shape, 10 + step)
+    st.inference(ids, runs, env, env.reward)
+    last_env = env
+  torch.cuda.synchronize()
+  assert int(st.error_flag[0]) == 8 and int(st.batch_count[0]) == 1
+  assert st.store_index.tolist() == [1, 1]
+  # slot 0 of BOTH envs holds the last step (reward / episode_step / frames), also for the dropped one
+  assert torch.equal(st.store[1].reward[0], last_env.reward)
+  assert torch.equal(st.store[1].episode_step[0], last_env.episode_step)
+  assert torch.equal(st.store[1].observation[0], last_env.observation)
+
+
+def test_graphed_inference_packed_request(device):
+  """fn.replay_packed(request bytes, frames): the transport-facing entry (two copies per batch) equals the
+  structured call."""
+  from seed_rl_amd import inference
+  T, E, A, n = 3, 4, 6, 2
+  a, obs_shape = _mk_fused(device, E, T, A, 8)
+  b, _ = _mk_fused(device, E, T, A, 8)
+  fa, fb = a.graphed(n, obs_shape), b.graphed(n, obs_shape)
+  for step in range(2 * T + 1):
+    for ids_l in ([0, 2], [3, 1]):
+      ids, runs, env = _req(device, ids_l, step, obs_shape, 100 * step + ids_l[0])
+      raw = env.reward * 2
+      act_a = fa(ids, runs, env, raw).clone()
+      req = inference.pack_request(n, ids.cpu().numpy(), runs.cpu().numpy(), env.reward.cpu().numpy(),
+                                   raw.cpu().numpy(), env.done.cpu().numpy(), None, env.episode_step.cpu().numpy())
+      act_b = fb.replay_packed(torch.from_numpy(req).pin_memory(), env.observation).clone()
+      assert torch.equal(act_a, act_b)
+  a.check_errors(); b.check_errors()
+  from seed_rl_amd import utils
+  for x, y in zip(utils.flatten(a.batch) + [a.info_return, a.info_raw], utils.flatten(b.batch) + [b.info_return, b.info_raw]):
+    assert torch.equal(x, y)
