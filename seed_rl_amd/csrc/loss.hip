@@ -274,18 +274,30 @@ __global__ void impala_loss_finalize_kernel(const float* __restrict__ partials, 
   }
 }
 
-constexpr int kCB = 8;
+// Columns per workgroup.  8 keeps whole 32-byte sectors of the [T+1, B] scalars per workgroup; at the learner's own
+// sizes (B = 512 per GPU: 64 workgroups of which each spends its V-trace phase on 8 lanes) the launch is latency-bound
+// and under-fills the 256 CUs, so narrower column groups are used until the grid reaches the CU count: B = 512 -> 2
+// columns x 256 workgroups (r02: 31 -> ~15 us per launch).
+inline int pick_cb(int B) { return B >= 8 * 256 ? 8 : (B >= 4 * 256 ? 4 : 2); }
 
+template <int EPL, int CB>
+void launch_loss_cb(const LossParams& p, int nblocks, size_t lds, hipStream_t s) {
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)impala_loss_kernel<EPL, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((impala_loss_kernel<EPL, CB>), dim3(nblocks), dim3(kThreads), lds, s, p);
+}
 template <int EPL>
-void launch_loss(const LossParams& p, int nblocks, size_t lds, hipStream_t s) {
-  hipLaunchKernelGGL((impala_loss_kernel<EPL, kCB>), dim3(nblocks), dim3(kThreads), lds, s, p);
+void launch_loss(const LossParams& p, int cb, int nblocks, size_t lds, hipStream_t s) {
+  if (cb == 8) launch_loss_cb<EPL, 8>(p, nblocks, lds, s);
+  else if (cb == 4) launch_loss_cb<EPL, 4>(p, nblocks, lds, s);
+  else launch_loss_cb<EPL, 2>(p, nblocks, lds, s);
 }
 
 }  // namespace
 
 extern "C" size_t seedhip_impala_loss_workspace_bytes(int T, int B) {
   (void)T;
-  const int nblocks = (B + kCB - 1) / kCB;
+  const int nblocks = (B + 1) / 2;                             // the narrowest column group (pick_cb)
   return (size_t)nblocks * kNumPartials * sizeof(float);
 }
 
@@ -307,7 +319,8 @@ int impala_loss_impl(
                   done && d_policy_logits && d_baseline && scalars && workspace, "impala_loss: null pointer");
   SEEDHIP_REQUIRE(workspace_bytes >= seedhip_impala_loss_workspace_bytes(T, B), "impala_loss: workspace too small");
   SEEDHIP_REQUIRE(mean_denominator > 0.f, "impala_loss: mean_denominator must be > 0");
-  const size_t lds = (size_t)(T + 1) * kCB * 9 * sizeof(float);
+  const int cb = pick_cb(B);
+  const size_t lds = (size_t)(T + 1) * cb * 9 * sizeof(float);
   SEEDHIP_REQUIRE(lds <= 150 * 1024, "impala_loss: T=%d too long for LDS staging", T);
   LossParams p;
   p.tgt_logits = learner_policy_logits; p.baseline = learner_baseline; p.beh_logits = behaviour_policy_logits;
@@ -321,20 +334,12 @@ int impala_loss_impl(
   p.partials = (float*)workspace;
   p.ec_param = ec_param; p.ec_mul = ec_mul;
   hipStream_t s = (hipStream_t)stream;
-  const int nblocks = (B + kCB - 1) / kCB;
-  if (lds > 48 * 1024) {
-    // opt in to large dynamic LDS
-    (void)hipFuncSetAttribute((const void*)impala_loss_kernel<1, kCB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)impala_loss_kernel<2, kCB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)impala_loss_kernel<4, kCB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)impala_loss_kernel<8, kCB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)impala_loss_kernel<16, kCB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
-  if (A <= kLPR) launch_loss<1>(p, nblocks, lds, s);
-  else if (A <= 2 * kLPR) launch_loss<2>(p, nblocks, lds, s);
-  else if (A <= 4 * kLPR) launch_loss<4>(p, nblocks, lds, s);
-  else if (A <= 8 * kLPR) launch_loss<8>(p, nblocks, lds, s);
-  else launch_loss<16>(p, nblocks, lds, s);
+  const int nblocks = (B + cb - 1) / cb;
+  if (A <= kLPR) launch_loss<1>(p, cb, nblocks, lds, s);
+  else if (A <= 2 * kLPR) launch_loss<2>(p, cb, nblocks, lds, s);
+  else if (A <= 4 * kLPR) launch_loss<4>(p, cb, nblocks, lds, s);
+  else if (A <= 8 * kLPR) launch_loss<8>(p, cb, nblocks, lds, s);
+  else launch_loss<16>(p, cb, nblocks, lds, s);
   int rc = seedhip::check_launch("impala_loss_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(impala_loss_finalize_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, nblocks,

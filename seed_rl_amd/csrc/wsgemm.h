@@ -425,6 +425,215 @@ ws_fast_kernel(const Params p) {
   }
 }
 
+
+// Third generation: the same weight-stationary GEMM with (almost) NO per-tile integer work.  The SQ counters of the cfg2
+// step say a SIMD does not run VALU work under another wave's MFMAs, so the ~470 VALU / ~280 SALU instructions and ~20
+// branches that ws_fast_kernel spends per 128-MFMA tile on row decoding, tap validity and scatter addresses are matrix
+// time lost one-for-one.  Here:
+//   * the geometry of ONE image (row -> per-k-tile byte offset or "outside the map", row -> output byte offset) is
+//     tabulated in LDS once per workgroup (G = gh * gw rows: 81 / 100 entries); a tile row costs one magic division by
+//     G, one ds_read of its table line and one add per load offset.  Invalid taps are the offset 0x80000000: beyond
+//     num_records of the buffer view, the hardware returns zeros; rows past M fall beyond the buffers by themselves
+//     (loads return zeros, stores are dropped): no tail code, no branch in the tile loop;
+//   * the MFMA operands are SWAPPED (W' supplies the 16 "rows" of the instruction, the data rows its 16 "columns"):
+//     a lane then holds four CONSECUTIVE output channels of ONE data row per accumulator, which is a 16-byte store as it
+//     stands -- no register transposition, one output address per lane and tile instead of four, and the stride-parity
+//     class / n-tile offset of the store is a uniform soffset.
+// Per 128-MFMA tile: ~20 (forward) / ~60 (data gradient, 32 of them the ReLU-mask selects) VALU instructions.
+// EXP (tools/probes/ws_probe.hip only; the library instantiates EXP = 0): leave one ingredient out to see what the
+// others cost -- 1 no MFMAs, 2 no global A loads after the first tile, 4 no stores, 8 no mask loads, 16 no LDS fragment
+// reads, 32 no LDS staging writes.
+template <int NT, int NKT, int MODE, int EXP = 0>
+__global__ void __launch_bounds__(512)
+ws_tab_kernel(const Params p) {
+  constexpr int WAVES = 8, N = 16 * NT, K = NKT * BK, LDW = K + 8, kThreads = 64 * WAVES;
+  constexpr int NV = MODE == 0 ? 1 : NKT;                     // load offsets per row
+  constexpr unsigned kOut = 0x80000000u;                      // "outside": + any row base (< 2^31) stays beyond num_records
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wt = smem;                                           // [N][LDW]   W' transposed: k contiguous
+  float* As = Wt + N * LDW;                                   // [WAVES][16][LDA]
+  unsigned* tab_ld = reinterpret_cast<unsigned*>(As + WAVES * 16 * LDA);   // [G][NV]
+  const int G = p.gh * p.gw;
+  unsigned* tab_out = tab_ld + G * NV;                        // [G]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lx = lane & 15, kq = lane >> 4;
+
+  // ---- once per workgroup: W' -> LDS (transposed), geometry tables ----
+  for (int idx = tid; idx < K * N; idx += kThreads) {
+    const int k = idx / N, n = idx - k * N;                   // N is a compile-time power of two
+    Wt[n * LDW + k] = MODE == 0 ? p.W[idx] : p.W[ws_wprime_src(p, k, n)];
+  }
+  for (int r = tid; r < G; r += kThreads) {
+    const int a = r / p.gw, b = r - a * p.gw;
+    const unsigned byte0 = ((unsigned)a * p.a_row_stride + (unsigned)b * p.a_col_stride) * 4u;
+    if (MODE == 0) {
+      tab_ld[r] = byte0;
+      tab_out[r] = (unsigned)r * (unsigned)p.ldc * 4u;
+    } else {
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) tab_ld[r * NKT + t] = ws_tap_ok(p, a, b, p.tile_dy[t], p.tile_dx[t]) ? byte0 : kOut;
+      tab_out[r] = ((unsigned)a * (unsigned)(p.s * p.iw * p.ld_in) + (unsigned)b * (unsigned)(p.s * p.ld_in)) * 4u;
+    }
+  }
+  __syncthreads();
+
+  float* Aw = As + wave * (16 * LDA);
+  const int kc = (lane & 7) * 4, srow = lane >> 3;            // this lane stages rows srow and srow + 8, floats kc..kc+3
+  int minoff = 0;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) minoff = p.tile_off[t] < minoff ? p.tile_off[t] : minoff;
+  unsigned soff[NKT];                                         // uniform: SGPRs
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) soff[t] = __builtin_amdgcn_readfirstlane((unsigned)(p.tile_off[t] - minoff) * 4u);
+  auto view = [&](const void* q, long long bytes) {
+    const uint64_t qb = reinterpret_cast<uint64_t>(q);
+    const uint64_t sq = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(qb >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)qb);   // (the builtin returns int)
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(sq), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsrc = view(p.A + minoff, p.a_bytes - (long long)minoff * 4),
+                               c_rsrc = view(p.C, p.c_bytes), m_rsrc = view(p.mask, p.c_bytes);
+  const unsigned a_img_bytes = p.a_img_stride * 4u;
+  const unsigned c_img_bytes = MODE == 0 ? (unsigned)G * (unsigned)p.ldc * 4u : (unsigned)(p.ih * p.iw * p.ld_in) * 4u;
+  // uniform store offsets of the NT accumulators: forward n = 16 t + 4 kq + r; data gradient n = (class, ci), cin % 16 == 0
+  unsigned coff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (MODE == 0) coff[t] = 64u * t;
+    else {
+      const int cls = (16 * t) / p.cin, ci0 = 16 * t - cls * p.cin, py = cls / p.s, px = cls - py * p.s;
+      coff[t] = (unsigned)((py * p.iw + px) * p.ld_in + ci0) * 4u;
+    }
+    coff[t] = __builtin_amdgcn_readfirstlane(coff[t]);
+  }
+
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  unsigned voff[2][NV];
+  auto setup = [&](int wt) {                                  // load offsets of wave tile wt (may lie past the end)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t m = (uint32_t)wt * 16u + (uint32_t)(srow + 8 * i);
+      uint32_t img, rem;
+      p.d_g.divmod(m, img, rem);
+      const unsigned base = img * a_img_bytes + (unsigned)(kc * 4);
+      if (MODE == 0) voff[i][0] = tab_ld[rem] + base;
+      else {
+#pragma unroll
+        for (int t4 = 0; t4 < NKT; t4 += 4) {
+          const u32x4_t tv = *reinterpret_cast<const u32x4_t*>(tab_ld + rem * NKT + t4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) voff[i][t4 + j] = tv[j] + base;
+        }
+      }
+    }
+  };
+  u32x4_t rg[NKT][2];                                         // one register stage per k-tile x two rows: a whole tile ahead
+  bool first_tile = true;
+  auto fetch = [&](int kt) {
+    if ((EXP & 2) && !first_tile) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      rg[kt][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i][MODE == 0 ? 0 : kt], soff[kt], 0);
+  };
+  const float* a_frag = Aw + lx * LDA + 4 * kq;               // MFMA "B" operand: data row lx, k = 4 kq .. 4 kq + 3
+  const float* w_frag = Wt + lx * LDW + 4 * kq;               // MFMA "A" operand: output channel 16 t + lx
+  f32x4_t bias_v[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    bias_v[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0 && p.bias) bias_v[t] = *reinterpret_cast<const f32x4_t*>(p.bias + 16 * t + 4 * kq);
+  }
+  const int wstride = gridDim.x * WAVES;
+  const bool relu = p.out_relu != 0, has_mask = p.mask != nullptr;
+
+  int tile = blockIdx.x * WAVES + wave;
+  setup(tile);
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) fetch(kt);
+  first_tile = false;
+  f32x4_t av_keep = f32x4_t{1.f, 2.f, 3.f, 4.f}, wv_keep[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wv_keep[t] = f32x4_t{0.5f, 0.25f, 0.125f, 1.f};
+  for (; tile < p.ntiles; tile += wstride) {
+    setup(tile + wstride);
+    // output address of this lane's data row m = 16 tile + lx (columns 4 kq .. of every n-tile); rows >= M land beyond
+    // c_bytes: their stores are dropped, their mask loads return zeros
+    const uint32_t m = (uint32_t)tile * 16u + (uint32_t)lx;
+    unsigned at;
+    if (MODE == 0) at = m * (unsigned)(p.ldc * 4) + (unsigned)(kq * 16);
+    else {
+      uint32_t img, rem;
+      p.d_g.divmod(m, img, rem);
+      at = img * c_img_bytes + tab_out[rem] + (unsigned)(kq * 16);
+    }
+    u32x4_t mpre[NT];
+    if (MODE == 1 && has_mask) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (EXP & 8) mpre[t] = u32x4_t{0x3f800000u, 0x3f800000u, 0u, 0x3f800000u};
+        else mpre[t] = __builtin_amdgcn_raw_buffer_load_b128(m_rsrc, at, coff[t], 0);
+      }
+    }
+    f32x4_t acc[NT];
+    if (EXP & 1) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      wave_fence();                                           // fragment reads of the previous k-tile are issued
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (EXP & 32) asm volatile("" :: "v"(rg[kt][i]));
+        else *reinterpret_cast<u32x4_t*>(Aw + (srow + 8 * i) * LDA + kc) = rg[kt][i];
+      }
+      wave_fence();
+      fetch(kt);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4_t av, wv[NT];
+        if (EXP & 16) {
+          av = av_keep;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) wv[t] = wv_keep[t];
+        } else {
+          av = *reinterpret_cast<const f32x4_t*>(a_frag + h * 16);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) wv[t] = *reinterpret_cast<const f32x4_t*>(w_frag + t * 16 * LDW + kt * BK + h * 16);
+        }
+        if (EXP & 1) {                                        // operands stay live, no matrix work
+          asm volatile("" :: "v"(av));
+#pragma unroll
+          for (int t = 0; t < NT; ++t) asm volatile("" :: "v"(wv[t]));
+          continue;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][kk], av[kk],
+                                                          (kt == 0 && h == 0 && kk == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4_t v = acc[t];
+      if (MODE == 0) {
+        v += bias_v[t];
+        if (relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+      } else if (has_mask) {
+        const f32x4_t mv = __builtin_bit_cast(f32x4_t, mpre[t]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = mv[r] > 0.f ? v[r] : 0.f;
+      }
+      if (EXP & 4) asm volatile("" :: "v"(v));
+      else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), c_rsrc, at, coff[t], 0);
+    }
+  }
+}
+
 inline int launch(Params& p, Plan& pl, hipStream_t s) {
   static const int force_mr = getenv("SEEDHIP_WS_MR") ? atoi(getenv("SEEDHIP_WS_MR")) : 0;
   static const int force_w = getenv("SEEDHIP_WS_WAVES") ? atoi(getenv("SEEDHIP_WS_WAVES")) : 0;
@@ -443,6 +652,24 @@ inline int launch(Params& p, Plan& pl, hipStream_t s) {
     // 100-128 VGPRs: four waves per SIMD, i.e. two 8-wave workgroups per CU are resident whatever LDS allows; a
     // persistent grid of exactly the resident workgroups avoids a second, ragged round (data gradient 0.196 -> 0.189 ms)
     if (wgs > 256 * 2) pl.grid = 256 * 2;
+    // table-driven variant (ws_tab_kernel): dense output rows, no residual / add, data gradient with whole super-pixels
+    // and 16-channel-aligned classes
+    static const int tab = getenv("SEEDHIP_WS_TAB") ? atoi(getenv("SEEDHIP_WS_TAB")) : 1;
+    const bool tab_ok = tab && !p.residual && !p.add && p.gh * p.gw <= 1024 &&
+        (p.mode == 0 ? (p.ldc == p.N && p.ldc % 4 == 0)
+                     : (p.cin % 16 == 0 && p.gh * p.s == p.ih && p.gw * p.s == p.iw && p.c_bytes < (1LL << 31) - (1 << 20)));
+    if (tab_ok) {
+      const size_t lds = ((size_t)p.N * (p.K + 8) + 8 * 16 * LDA + (size_t)p.gh * p.gw * ((p.mode == 0 ? 1 : p.nkt) + 1)) * sizeof(float);
+#define SEEDHIP_WST(NT_, NKT_, MODE_)                                                                             \
+      if (pl.nr == NT_ && p.nkt == NKT_ && p.mode == MODE_ && lds <= 72 * 1024) {                                 \
+        if (lds > 64 * 1024)                                                                                      \
+          (void)hipFuncSetAttribute((const void*)ws_tab_kernel<NT_, NKT_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((ws_tab_kernel<NT_, NKT_, MODE_>), dim3(pl.grid), dim3(512), lds, s, p);               \
+        return check_launch("ws_tab_kernel");                                                                     \
+      }
+      SEEDHIP_WST(2, 8, 0) SEEDHIP_WST(4, 8, 0) SEEDHIP_WST(4, 4, 1) SEEDHIP_WST(2, 4, 1) SEEDHIP_WST(4, 8, 1) SEEDHIP_WST(2, 8, 1)
+#undef SEEDHIP_WST
+    }
 #define SEEDHIP_WSF(NR_, NKT_, MODE_)                                                                             \
     if (pl.nr == NR_ && p.nkt == NKT_ && p.mode == MODE_) {                                                       \
       if (pl.lds > 64 * 1024)                                                                                     \

@@ -42,32 +42,39 @@ def _grad_errs(agent, p, floor=1e-3):
 
 
 def _truth_errs(agent, p32, p64, floor=1e-3):
-  """Both fp32 evaluations against the fp64 evaluation of the same graph: (hip_err, hip_worst, oracle_err, oracle_worst)
-  with err = max over tensors of max|g - g64| / max(max|g64|, floor)."""
+  """Both fp32 evaluations against the fp64 evaluation of the same graph, per tensor as max and as 99th percentile of
+  |g - g64| / max(max|g64|, floor); returns the worst tensor of each."""
   grads = agent.reference_gradients()
-  hw = ow = (0.0, None)
+  out = dict(hip_max=(0.0, None), hip_q99=(0.0, None), oracle_max=(0.0, None), oracle_q99=(0.0, None))
   for n, t64 in p64.items():
     r = t64.grad.numpy()
     den = max(float(np.abs(r).max()), floor)
-    eh = float(np.max(np.abs(grads[n].cpu().numpy().astype(np.float64) - r)) / den)
-    eo = float(np.max(np.abs(p32[n].grad.numpy().astype(np.float64) - r)) / den)
-    if eh >= hw[0]:
-      hw = (eh, n)
-    if eo >= ow[0]:
-      ow = (eo, n)
-  return hw[0], hw[1], ow[0], ow[1]
+    dh = np.abs(grads[n].cpu().numpy().astype(np.float64) - r) / den
+    do = np.abs(p32[n].grad.numpy().astype(np.float64) - r) / den
+    for key, v in (('hip_max', dh.max()), ('hip_q99', np.quantile(dh, 0.99)), ('oracle_max', do.max()),
+                   ('oracle_q99', np.quantile(do, 0.99))):
+      if v >= out[key][0]:
+        out[key] = (float(v), n)
+  return out
 
 
 def _truth(out, agent, p32, run64, floor=1e-3):
   """Adds the fp64 comparison to a record: run64() evaluates the oracle graph in fp64 and returns its parameters (with
-  .grad).  fp32 re-association alone moves a gradient of ~1e4 summed terms by ~1e-3 of its tensor's maximum (oneDNN's
-  blocked fp32 accumulation as much as the MFMA tiles'), so HIP-vs-oracle alone cannot tell noise from a defect; the
-  distance of EACH fp32 result to the fp64 value can."""
+  .grad).  Two effects make HIP-vs-fp32-oracle alone a poor yardstick at full size: (1) fp32 re-association moves a
+  gradient of ~1e4 summed terms by a few 1e-4 of its tensor's maximum on EITHER side (oneDNN's blocked accumulation as
+  much as the MFMA tiles'); (2) a ReLU pre-activation (or max-pool pair) within fp32 rounding of a tie resolves
+  differently -- a discrete, legitimate difference that moves one whole column of the following weight gradient (r02:
+  ONE such unit among the 2.75 M Dense outputs of cfg2, z = 1.3e-7 in fp64, <= 0 on the GPU: 3.3e-3 on fc/kernel column
+  18, tools/diag_parity.py).  So the record carries, for both fp32 results, the distance to the fp64 value as maximum
+  (sees the flips) and as 99th percentile per tensor (does not)."""
   t0 = time.perf_counter()
   with nets_torch.float64_truth():
     p64 = run64()
-  (out['grad_max_rel_err_vs_fp64'], out['grad_worst_vs_fp64'], out['oracle_grad_max_rel_err_vs_fp64'],
-   out['oracle_grad_worst_vs_fp64']) = _truth_errs(agent, p32, p64, floor)
+  e = _truth_errs(agent, p32, p64, floor)
+  out['grad_max_rel_err_vs_fp64'], out['grad_worst_vs_fp64'] = e['hip_max']
+  out['grad_q99_rel_err_vs_fp64'], out['grad_q99_worst_vs_fp64'] = e['hip_q99']
+  out['oracle_grad_max_rel_err_vs_fp64'], out['oracle_grad_worst_vs_fp64'] = e['oracle_max']
+  out['oracle_grad_q99_rel_err_vs_fp64'] = e['oracle_q99'][0]
   out['fp64_s'] = round(time.perf_counter() - t0, 2)
 
 

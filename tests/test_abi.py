@@ -34,7 +34,7 @@ def test_signature_table_matches_header(built_lib):
   assert sorted(_lib.SIGNATURES) == declared_symbols()
   l = _lib.lib()
   assert l.seedhip_abi_version() == 1
-  assert l.seedhip_impala_loss_workspace_bytes(20, 512) == (512 // 8) * 8 * 4
+  assert l.seedhip_impala_loss_workspace_bytes(20, 512) == (512 // 2) * 8 * 4
   assert l.seedhip_global_norm_workspace_bytes() > 0
 
 

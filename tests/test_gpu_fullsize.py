@@ -4,17 +4,18 @@ bench runs, and compared with the torch-CPU oracle of the same graph (reference 
 255-280; agents/r2d2/learner.py:333-384, 572-636).
 
 Tolerances.  Both sides compute in fp32 with different summation orders (MFMA tiles + split-K slices vs oneDNN's
-blocked accumulation); a weight gradient here is a sum of ~1e4 terms that largely cancel, and fp32 re-association alone
-moves it by up to ~3e-3 of its tensor's maximum -- the CPU oracle as much as the HIP path (r02 measurement: at T=20
-B=512 the two differ by 3.3e-3 on fc/kernel while the loss agrees to the last bit and the logits to 5e-7).  So each
-test also evaluates the SAME oracle graph in fp64 (oracle/nets_torch.float64_truth) and holds the HIP gradients to
-  grad_max_rel_err_vs_fp64 <= 3e-4 (feed-forward Atari) / 1e-3 (LSTM agents) of each tensor's max,
-i.e. the tolerance the small-size tests use against the fp32 oracle, and the HIP-vs-fp32-oracle difference to the sum
-of both distances from the fp64 value (+10 %); the fp32 oracle's own distance is reported next to it.
-  loss 1e-4 relative; parameters after one Adam step: at most 1e-3 of the elements further than 5e-5 from the fp32
-  oracle and none further than 2.2 lr (beta_1 = 0 normalises every element's update to ~lr, so an element whose
-  gradient sits at the fp32 noise floor can flip sign); upstream of a max-pool 1e-2 (argmax routing is discrete:
-  tests/test_gpu_deep.py).
+blocked accumulation), and at these sizes two things separate them that are not defects (r02 measurements, cfg2 T=20
+B=512, tools/diag_parity.py): fp32 re-association moves a conv weight gradient (a sum of ~1e6 largely cancelling terms)
+by ~4e-4 of its tensor's maximum on EITHER side, and ONE of the 2.75 M Dense pre-activations is +1.3e-7 in fp64 but <= 0
+on the GPU -- its ReLU mask flips, which moves column 18 of fc/kernel by 3.3e-3 (the loss still agrees to the last bit,
+the logits to 5e-7).  So every test also evaluates the SAME oracle graph in fp64 (oracle/nets_torch.float64_truth) and
+holds the HIP gradients to
+  99th percentile per tensor of |g - g64| / max|g64|  <= 3e-4 (feed-forward Atari) / 1e-3 (LSTM agents)
+  maximum                                             <= 1e-2 (what a handful of mask / arg-max flips can move),
+and the HIP-vs-fp32-oracle maximum to the sum of both maxima against fp64 (+10 %); the fp32 oracle's own distances are
+reported next to them.  Loss 1e-4 relative; parameters after one Adam step: at most 1e-3 of the elements further than
+5e-5 from the fp32 oracle and none further than 2.2 lr (beta_1 = 0 normalises every element's update to ~lr, so an
+element whose gradient sits at the fp32 noise floor can flip sign).
 """
 import pytest
 
@@ -34,7 +35,8 @@ def _check_params(r):
 
 
 def _check_grads(r, tol):
-  assert r['grad_max_rel_err_vs_fp64'] <= tol, _show(r)
+  assert r['grad_q99_rel_err_vs_fp64'] <= tol, _show(r)
+  assert r['grad_max_rel_err_vs_fp64'] <= 1e-2, _show(r)
   assert r['grad_max_rel_err'] <= 1.1 * (r['grad_max_rel_err_vs_fp64'] + r['oracle_grad_max_rel_err_vs_fp64']) + 1e-6, \
       _show(r)
 
