@@ -42,7 +42,11 @@ MFMA_BF16_PEAK_TF = 2500.0 # bf16 dense MFMA peak (MI355X_MICROARCH.md; no spars
 # (csrc/stackconv.hip): every algorithmic MAC costs three bf16 MACs, so their ceiling for ALGORITHMIC flops is peak / 3.
 BF16X3_KERNELS = ('stack_conv_fwd', 'stack_conv_wgrad')
 PARITY_NOTE = ('oracle = torch-CPU fp32 restatement of the reference graph (oracle/nets_torch.py); V-trace / R2D2 loss '
-               'math pinned to outputs of the reference code, Keras Conv2D/LSTMCell/Dense/Adam numerics UNPINNED (no TF here)')
+               'math pinned to outputs of the reference code, Keras Conv2D/LSTMCell/Dense/Adam numerics UNPINNED (no TF here). '
+               'grad_q99 = worst tensor\'s 99th-percentile |g - g_ref| / max|g_ref|; grad_max additionally sees the ReLU units '
+               'whose pre-activation is within fp32 rounding of 0 and resolves differently (cfg2: ONE of 2.75 M Dense outputs '
+               '-> 3.3e-3 on one fc/kernel column; against an fp64 evaluation the fp32 oracle itself is 3.4e-4 / 4.7e-4 away, '
+               'the HIP path 3.7e-4 at q99: tests/test_gpu_fullsize.py, tools/diag_parity.py)')
 
 
 def parse():
@@ -458,12 +462,13 @@ def main():
     from tests import parity
     # one train step at the bench shape against the CPU oracle (outside the timed region; same code as
     # tests/test_gpu_fullsize.py)
+    # (fp32 oracle only: its fp64 evaluation -- tests/test_gpu_fullsize.py -- takes minutes of host time at this size)
     if r2:
-      p = parity.r2d2_step(dev, T1=T + 1, B=min(B, 4), A=A)
+      p = parity.r2d2_step(dev, T1=T + 1, B=min(B, 4), A=A, truth=False)
     elif deep:
-      p = parity.deep_step(dev, T1=T + 1, B=min(B, 16), A=A)
+      p = parity.deep_step(dev, T1=T + 1, B=min(B, 16), A=A, truth=False)
     else:
-      p = parity.atari_step(dev, T1=T + 1, B=B, A=A, torso=args.torso)
+      p = parity.atari_step(dev, T1=T + 1, B=B, A=A, torso=args.torso, truth=False)
     result['parity'] = dict(parity.public(p), note=PARITY_NOTE)
     _release()
     if headline:

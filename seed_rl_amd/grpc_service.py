@@ -143,9 +143,9 @@ def _as_array(value, dt=None):
   a = np.asarray(value)
   if a.dtype.kind in ('U', 'S'):
     a = np.array([x.encode() if isinstance(x, str) else bytes(x) for x in a.reshape(-1)], dtype=np.object_).reshape(a.shape)
-  elif a.dtype == np.float64 and dt is None and not isinstance(value, np.ndarray):
+  elif a.dtype == np.float64 and dt is None and not isinstance(value, (np.ndarray, np.generic)):
     a = a.astype(np.float32)                         # Python floats are float32 tensors in TF
-  elif a.dtype == np.int64 and dt is None and not isinstance(value, np.ndarray):
+  elif a.dtype == np.int64 and dt is None and not isinstance(value, (np.ndarray, np.generic)):
     a = a.astype(np.int32)                           # Python ints are int32 tensors in TF
   if dt is not None and a.dtype.kind != 'O':
     a = a.astype(_NP_OF[dt], copy=False)

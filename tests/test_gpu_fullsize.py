@@ -9,13 +9,14 @@ B=512, tools/diag_parity.py): fp32 re-association moves a conv weight gradient (
 by ~4e-4 of its tensor's maximum on EITHER side, and ONE of the 2.75 M Dense pre-activations is +1.3e-7 in fp64 but <= 0
 on the GPU -- its ReLU mask flips, which moves column 18 of fc/kernel by 3.3e-3 (the loss still agrees to the last bit,
 the logits to 5e-7).  So every test also evaluates the SAME oracle graph in fp64 (oracle/nets_torch.float64_truth) and
-holds the HIP gradients to
-  99th percentile per tensor of |g - g64| / max|g64|  <= 3e-4 (feed-forward Atari) / 1e-3 (LSTM agents)
+holds the HIP gradients, for the headline configuration, to
+  99th percentile per tensor of |g - g64| / max|g64|  <= 1e-3 AND <= 3x the fp32 oracle's own + 1e-4
   maximum                                             <= 1e-2 (what a handful of mask / arg-max flips can move),
-and the HIP-vs-fp32-oracle maximum to the sum of both maxima against fp64 (+10 %); the fp32 oracle's own distances are
-reported next to them.  Loss 1e-4 relative; parameters after one Adam step: at most 1e-3 of the elements further than
-5e-5 from the fp32 oracle and none further than 2.2 lr (beta_1 = 0 normalises every element's update to ~lr, so an
-element whose gradient sits at the fp32 noise floor can flip sign).
+and the HIP-vs-fp32-oracle maximum to the sum of both maxima against fp64 (+10 %).  (The fp64 evaluation takes ~45 s of
+host time per case -- oneDNN has no fp64 convolution -- so the other cases compare with the fp32 oracle only: 99th
+percentile <= 1.5e-3, maximum <= 1e-2.)  Loss 1e-4 relative; parameters after one Adam step: at most 1e-3 of the elements
+further than 5e-5 from the fp32 oracle and none further than 2.2 lr (beta_1 = 0 normalises every element's update to ~lr,
+so an element whose gradient sits at the fp32 noise floor can flip sign).
 """
 import pytest
 
@@ -34,11 +35,17 @@ def _check_params(r):
   assert r['param_max_abs_err'] <= 2.2 * LR, _show(r)
 
 
-def _check_grads(r, tol):
-  assert r['grad_q99_rel_err_vs_fp64'] <= tol, _show(r)
+def _check_grads_fp64(r):
+  assert r['grad_q99_rel_err_vs_fp64'] <= 1e-3, _show(r)
+  assert r['grad_q99_rel_err_vs_fp64'] <= 3 * r['oracle_grad_q99_rel_err_vs_fp64'] + 1e-4, _show(r)
   assert r['grad_max_rel_err_vs_fp64'] <= 1e-2, _show(r)
   assert r['grad_max_rel_err'] <= 1.1 * (r['grad_max_rel_err_vs_fp64'] + r['oracle_grad_max_rel_err_vs_fp64']) + 1e-6, \
       _show(r)
+
+
+def _check_grads_fp32(r, q99=1.5e-3, mx=1e-2):
+  assert r['grad_q99_rel_err'] <= q99, _show(r)
+  assert r['grad_max_rel_err'] <= mx, _show(r)
 
 
 def test_cfg2_atari_T20_B512_A18(device):
@@ -46,7 +53,7 @@ def test_cfg2_atari_T20_B512_A18(device):
   r = parity.atari_step(device, T1=21, B=512, A=18)
   assert r['loss_rel_err'] <= 1e-4, _show(r)
   assert r['logits_max_abs_err'] <= 2e-4 and r['baseline_max_abs_err'] <= 2e-4, _show(r)
-  _check_grads(r, 3e-4)
+  _check_grads_fp64(r)
   _check_params(r)
 
 
@@ -54,28 +61,28 @@ def test_cfg2_atari_T20_B512_lambda_kl_clip(device):
   """Same size, every loss term on (lambda 0.95 as gcp/train_dmlab_*.sh, kl_cost, reward clipping), non-zero
   frame-stacking state, more episode ends."""
   r = parity.atari_step(device, T1=21, B=512, A=18, seed=11, done_p=0.05, zero_state=False,
-                        loss_kw=dict(lambda_=0.95, kl_cost=0.05, max_abs_reward=1.0))
+                        loss_kw=dict(lambda_=0.95, kl_cost=0.05, max_abs_reward=1.0), truth=False)
   assert r['loss_rel_err'] <= 1e-4, _show(r)
-  _check_grads(r, 3e-4)
+  _check_grads_fp32(r)
   _check_params(r)
 
 
 def test_cfg3_dmlab_T20_B16(device):
   """BASELINE configs[2] at T=20 with B=16 columns (the oracle's ~100 GFLOP; B=256 differs only in the grid)."""
-  r = parity.deep_step(device, T1=21, B=16, A=9)
+  r = parity.deep_step(device, T1=21, B=16, A=9, truth=False)
   assert r['loss_rel_err'] <= 2e-4, _show(r)
   assert r['logits_max_abs_err'] <= 3e-4 and r['baseline_max_abs_err'] <= 3e-4, _show(r)
   assert r['grad_max_rel_err_post_pool'] <= 1e-3, _show(r)
-  assert r['grad_max_rel_err'] <= 1e-2 and r['grad_max_rel_err_vs_fp64'] <= 1e-2, _show(r)
+  assert r['grad_max_rel_err'] <= 1e-2, _show(r)
   assert r['param_max_abs_err'] <= 2.2 * LR, _show(r)
 
 
 def test_cfg5_r2d2_T120_burnin40_B4(device):
   """BASELINE configs[4] at its real sequence length: T=120 (121 steps), burn-in 40, n-step 5, both networks."""
-  r = parity.r2d2_step(device, T1=121, B=4, A=18, burn_in=40)
+  r = parity.r2d2_step(device, T1=121, B=4, A=18, burn_in=40, truth=False)
   assert r['loss_rel_err'] <= 2e-4, _show(r)
   assert r['q_max_abs_err'] <= 5e-4, _show(r)
   assert r['priority_max_rel_err'] <= 2e-3, _show(r)
-  _check_grads(r, 1e-3)
+  _check_grads_fp32(r, q99=1e-3, mx=2e-3)
   assert r['grad_norm_rel_err'] <= 1e-3, _show(r)
   assert r['param_max_abs_err'] <= 5e-5, _show(r)
