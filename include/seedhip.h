@@ -104,6 +104,11 @@ int seedhip_impala_loss_fwd_bwd_adaptive(
     float mean_denominator, float* d_policy_logits, float* d_baseline, float* vs, float* pg_advantages,
     float* scalars, void* workspace, size_t workspace_bytes, void* stream);
 
+/* CRC32C (Castagnoli) of a HOST buffer, continuing from `crc` (0 to start): the checksum TensorFlow's checkpoint
+ * bundles carry (tensorflow/core/lib/hash/crc32c.h); lets tf_checkpoint.py read / write tf.train.Checkpoint files of the
+ * reference (agents/vtrace/learner.py:286-296) at memory speed.  Host code; no stream. */
+unsigned int seedhip_crc32c(const void* data, size_t n, unsigned int crc);
+
 /* ---- optimizer --------------------------------------------------------------------
  * Replaces the Keras Adam apply_gradients of agents/vtrace/learner.py:272-275
  * (dmlab/vtrace_main.py:46-51) over ONE flat parameter buffer.  lr_t already
@@ -130,6 +135,9 @@ int seedhip_clip_by_global_norm(float* grads, long long n, float clip_norm, floa
  * frames_ext is uint8 [3+T, B, HW]: rows 3.. hold the unroll's frames (written by the
  * caller / the unroll store), rows 0..2 are filled by seedhip_stack_prepare from
  * the packed state; nvalid is uint8 [T,B] (number of valid stack channels). */
+/* football/observation.py:48-63 unpackbits: packed uint16 bit planes [n_words] -> uint8 [n_words * 16], 255 where the
+ * bit is set, channel order 2^7..2^0, 2^15..2^8 per word (what GFootball._torso feeds its first conv after / 255). */
+int seedhip_unpackbits_u16(const uint16_t* packed, long long n_words, uint8_t* out, void* stream);
 int seedhip_stack_prepare(const int* frame_stacking_state, const uint8_t* done, int T, int B, long long HW,
                           uint8_t* frames_ext, uint8_t* nvalid, void* stream);
 int seedhip_stack_frames_f32(const uint8_t* frames_ext, const uint8_t* nvalid, int T, int B, long long HW,

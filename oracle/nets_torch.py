@@ -91,6 +91,33 @@ def param_spec(kind, num_actions, obs_shape=None, core=None):
     dense('advantage/hidden', 512, 512)
     dense('advantage/head', 512, num_actions, bias=False)
     lstm('core', 512 + 1 + num_actions, 512)
+  elif kind == 'gfootball':           # football/networks.py:68-96 (lecun_normal kernels, four stacks, no LSTM)
+    h, w, c = obs_shape or (72, 96, 1)
+    cin = c * 16
+    def conv_ln(name, cin_, cout_):
+      spec.append((name + '/kernel', (3, 3, cin_, cout_), 'lecun_normal'))
+      spec.append((name + '/bias', (cout_,), 'zeros'))
+    for i, ch in enumerate([16, 32, 32, 32]):
+      conv_ln('stack%d/conv' % i, cin, ch)
+      for b in range(2):
+        conv_ln('stack%d/res_%d/conv2d_0' % (i, b), ch, ch)
+        conv_ln('stack%d/res_%d/conv2d_1' % (i, b), ch, ch)
+      cin = ch
+      h, w = (h + 1) // 2, (w + 1) // 2
+    for name, ci, co in (('conv_to_linear', h * w * cin, 256), ('policy_logits', 256, num_actions), ('baseline', 256, 1)):
+      spec.append((name + '/kernel', (ci, co), 'lecun_normal'))
+      spec.append((name + '/bias', (co,), 'zeros'))
+  elif kind == 'mlp_lstm':            # agents/vtrace/networks.py:25-52; core = (observation_size, mlp_sizes, lstm_sizes)
+    obs_size, mlp_sizes, lstm_sizes = core
+    cin = obs_size
+    for i, m in enumerate(mlp_sizes):
+      dense('mlp/dense_%d' % i, cin, m)
+      cin = m
+    for l, hh in enumerate(lstm_sizes):
+      lstm('core/cell_%d' % l, cin, hh)
+      cin = hh
+    dense('policy_logits', cin, num_actions)
+    dense('baseline', cin, 1)
   else:
     raise ValueError(kind)
   return spec
@@ -117,6 +144,17 @@ def init_params(spec, seed=0):
       h = shape[0] // 4
       v = np.zeros(shape)
       v[h:2 * h] = 1.0
+    elif init == 'lecun_normal':
+      # Keras lecun_normal = VarianceScaling(1, 'fan_in', 'truncated_normal'): stddev sqrt(1 / fan_in) / .87962566...,
+      # truncated at two standard deviations
+      rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+      std = math.sqrt(1.0 / (shape[-2] * rf)) / .87962566103423978
+      v = rng.standard_normal(size=shape)
+      bad = np.abs(v) > 2.0
+      while bad.any():
+        v[bad] = rng.standard_normal(size=int(bad.sum()))
+        bad = np.abs(v) > 2.0
+      v = v * std
     else:
       v = np.zeros(shape)
     out[name] = v.astype(np.float32)
@@ -221,10 +259,20 @@ def stack_frames_torch(frames_u8, frame_state, done, stack_size=4):
 # --------------------------------------------------------------------------- #
 # Agents.
 # --------------------------------------------------------------------------- #
-def impala_deep_torso(p, frames_u8):
-  """dmlab/networks.py:94-109 on [N,H,W,C] uint8."""
+def unpackbits(frame_u16):
+  """football/observation.py:48-63: every 16-bit word -> 16 channels of 0 / 255 in the order 2^7..2^0, 2^15..2^8."""
+  pats = torch.tensor([2 ** 7, 2 ** 6, 2 ** 5, 2 ** 4, 2 ** 3, 2 ** 2, 2 ** 1, 2 ** 0, 2 ** 15, 2 ** 14, 2 ** 13, 2 ** 12,
+                       2 ** 11, 2 ** 10, 2 ** 9, 2 ** 8], dtype=torch.int32)
+  f = frame_u16.to(torch.int32) & 0xFFFF
+  bits = (f[..., None] & pats) != 0
+  out = bits.to(torch.get_default_dtype()) * 255
+  return out.reshape(tuple(frame_u16.shape[:-1]) + (frame_u16.shape[-1] * 16,))
+
+
+def impala_deep_torso(p, frames_u8, num_stacks=3):
+  """dmlab/networks.py:94-109 on [N,H,W,C] uint8 (or already-float 0..255 planes: football/networks.py:98-116)."""
   x = frames_u8.to(torch.get_default_dtype()) / 255
-  for i in range(3):
+  for i in range(num_stacks):
     x = conv2d(x, p['stack%d/conv/kernel' % i], p['stack%d/conv/bias' % i], 1, 'same')
     x = max_pool_3x3_s2_same(x)
     for b in range(2):
@@ -255,6 +303,42 @@ def impala_deep_unroll(p, num_actions, prev_actions, reward, done, frames_u8,
   logits = (flat @ p['policy_logits/kernel'] + p['policy_logits/bias'])
   baseline = (flat @ p['baseline/kernel'] + p['baseline/bias'])[:, 0]
   return logits.reshape(T1, B, -1), baseline.reshape(T1, B), state
+
+
+def gfootball_unroll(p, num_actions, frames_packed):
+  """football/networks.py:98-150 with unroll=True: frames int16/uint16 [T1, B, H, W, planes] (packed bits)."""
+  T1, B = frames_packed.shape[:2]
+  x = unpackbits(frames_packed.reshape((T1 * B,) + tuple(frames_packed.shape[2:])))
+  feat = impala_deep_torso(p, x, num_stacks=4)
+  logits = feat @ p['policy_logits/kernel'] + p['policy_logits/bias']
+  baseline = (feat @ p['baseline/kernel'] + p['baseline/bias'])[:, 0]
+  return logits.reshape(T1, B, -1), baseline.reshape(T1, B)
+
+
+def mlp_lstm_unroll(p, num_mlp, num_lstm, observation, done, core_state):
+  """agents/vtrace/networks.py:99-121: Dense+relu stack, then StackedRNNCells stepped over time with the done-reset of
+  EVERY cell's state before each step; core_state = ((h, c), ...) per cell."""
+  T1, B = done.shape
+  x = observation.reshape(T1 * B, -1).to(torch.get_default_dtype())
+  for i in range(num_mlp):
+    x = F.relu(x @ p['mlp/dense_%d/kernel' % i] + p['mlp/dense_%d/bias' % i])
+  xs = x.reshape(T1, B, -1)
+  state = [tuple(s) for s in core_state]
+  outs = []
+  for t in range(T1):
+    keep = (~done[t]).to(torch.get_default_dtype())[:, None]
+    inp = xs[t]
+    for l in range(num_lstm):
+      h, c = state[l]
+      h, c = lstm_cell(inp, h * keep, c * keep, p['core/cell_%d/kernel' % l], p['core/cell_%d/recurrent_kernel' % l],
+                       p['core/cell_%d/bias' % l])
+      state[l] = (h, c)
+      inp = h
+    outs.append(inp)
+  flat = torch.stack(outs).reshape(T1 * B, -1)
+  logits = flat @ p['policy_logits/kernel'] + p['policy_logits/bias']
+  baseline = (flat @ p['baseline/kernel'] + p['baseline/bias'])[:, 0]
+  return logits.reshape(T1, B, -1), baseline.reshape(T1, B), tuple(state)
 
 
 def atari_body(p, x, prefix, convs):

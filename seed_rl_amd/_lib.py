@@ -42,6 +42,7 @@ class RowOp(ctypes.Structure):
 SIGNATURES = {
     'seedhip_last_error': (ctypes.c_char_p, []),
     'seedhip_abi_version': (c_int, []),
+    'seedhip_crc32c': (ctypes.c_uint, [P, c_size_t, ctypes.c_uint]),
     'seedhip_vtrace_from_importance_weights':
         (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, c_int, c_ll, P, P, P]),
     'seedhip_categorical_log_prob_entropy': (c_int, [P, P, c_int, c_ll, c_int, P, P, P]),
@@ -61,6 +62,7 @@ SIGNATURES = {
                                          c_ll, c_float, c_float, P]),
     'seedhip_global_norm_workspace_bytes': (c_size_t, []),
     'seedhip_clip_by_global_norm': (c_int, [P, c_ll, c_float, P, P, c_size_t, P]),
+    'seedhip_unpackbits_u16': (c_int, [P, c_ll, P, P]),
     'seedhip_stack_prepare': (c_int, [P, P, c_int, c_int, c_ll, P, P, P]),
     'seedhip_stack_frames_f32': (c_int, [P, P, c_int, c_int, c_ll, P, P]),
     'seedhip_stack_pack_state': (c_int, [P, P, c_int, c_int, c_ll, P, P]),

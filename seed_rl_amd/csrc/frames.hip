@@ -113,3 +113,42 @@ extern "C" int seedhip_stack_pack_state(const uint8_t* frames_ext, const uint8_t
                      frames_ext, nvalid, T, B, HW, new_state);
   return seedhip::check_launch("stack_pack_kernel");
 }
+
+// ---- football observations: packed bit planes -> uint8 0 / 255 (football/observation.py:48-63) ---- //
+// unpackbits: every uint16 word holds 16 binary channels in the order 2^7..2^0, 2^15..2^8 (the byte order np.packbits
+// leaves in a little-endian uint16); channel j of word w becomes out[16 w + j] = 255 if the bit is set.  The first conv
+// then reads the bytes with its /255 fused (dmlab-style uint8 input): the float tensor the reference materialises (and
+// its XLA-compiled cast) never exists.  HBM-bound byte work: 2 B read + 16 B written per word, one 16-byte store per lane.
+namespace {
+__global__ void __launch_bounds__(256)
+unpackbits_u16_kernel(const uint16_t* __restrict__ in, long long n_words, uint4* __restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
+    const unsigned v = in[w];
+    unsigned o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned word = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int j = 4 * q + b;                               // output channel
+        const int bit = j < 8 ? 7 - j : 23 - j;
+        word |= ((v >> bit) & 1u) ? (0xFFu << (8 * b)) : 0u;
+      }
+      o[q] = word;
+    }
+    out[w] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+}  // namespace
+
+extern "C" int seedhip_unpackbits_u16(const uint16_t* packed, long long n_words, uint8_t* out, void* stream) {
+  SEEDHIP_REQUIRE(n_words >= 0, "unpackbits: negative size");
+  if (n_words == 0) return SEEDHIP_OK;
+  SEEDHIP_REQUIRE(packed && out, "unpackbits: null pointer");
+  SEEDHIP_REQUIRE((((uintptr_t)out) & 15) == 0, "unpackbits: output must be 16-byte aligned");
+  long long blocks = (n_words + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(unpackbits_u16_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, packed, n_words,
+                     reinterpret_cast<uint4*>(out));
+  return seedhip::check_launch("unpackbits_u16_kernel");
+}

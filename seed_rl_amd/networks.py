@@ -54,6 +54,17 @@ def keras_init(spec, seed=0):
       h = shape[0] // 4
       v = np.zeros(shape)
       v[h:2 * h] = 1.0
+    elif init == 'lecun_normal':
+      # Keras VarianceScaling(scale=1, mode='fan_in', distribution='truncated_normal'): N(0, sqrt(1/fan_in)/.8796...)
+      # truncated at two standard deviations (football/networks.py:33-49,86-96)
+      rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+      std = math.sqrt(1.0 / (shape[-2] * rf)) / .87962566103423978
+      v = rng.standard_normal(size=shape)
+      bad = np.abs(v) > 2.0
+      while bad.any():                               # resample the tails (deterministic given the generator)
+        v[bad] = rng.standard_normal(size=int(bad.sum()))
+        bad = np.abs(v) > 2.0
+      v = v * std
     else:
       v = np.zeros(shape)
     out[name] = v.astype(np.float32)
@@ -69,6 +80,7 @@ class _Agent(object):
     if self.device.type != 'cuda':
       raise _lib.SeedHipError('agents run on a HIP device only (no CPU fallback)')
     self._ws = {}
+    self._lstm_ctx = {}
     self._ldh = _round4(num_actions + 1)     # head row: [logits(A) | baseline | zero pad]
 
   # -- parameters ------------------------------------------------------------- #
@@ -237,14 +249,14 @@ class _Agent(object):
     N = T1 * B
     fl = self.flat
     gx = ops.dense_geom(N, in_dim, 4 * H, ld_in=ldx)
-    Zx = self._buf('lstm_zx', (N, 4 * H))
+    Zx = self._buf(prefix + '/lstm_zx', (N, 4 * H))
     ops.conv2d_fwd(gx, X, fl.p(prefix + '/kernel'), fl.p(prefix + '/bias'), Zx)
-    Hin = self._buf('lstm_hin', (T1 + 1, B, H))
-    Cin = self._buf('lstm_cin', (T1 + 1, B, H))
+    Hin = self._buf(prefix + '/lstm_hin', (T1 + 1, B, H))
+    Cin = self._buf(prefix + '/lstm_cin', (T1 + 1, B, H))
     h0, c0 = state
     ops.lstm_mask_state(h0.contiguous(), c0.contiguous(), done_u8[0], B, H, Hin[0], Cin[0])
-    Z = self._buf('lstm_z', (T1, B, 4 * H))
-    Hout = self._buf('lstm_hout', (N, H))
+    Z = self._buf(prefix + '/lstm_z', (T1, B, 4 * H))
+    Hout = self._buf(prefix + '/lstm_hout', (N, H))
     gu = ops.dense_geom(B, H, 4 * H)
     U = fl.p(prefix + '/recurrent_kernel')
     Zx3, Hout3 = Zx.view(T1, B, 4 * H), Hout.view(T1, B, H)
@@ -258,7 +270,7 @@ class _Agent(object):
       capturing = torch.cuda.is_current_stream_capturing()
       if not capturing:
         self._lstm_seq_check()
-      ops.lstm_seq_fwd(Up, Zx3, done_u8, T1, B, H, Z, Hout, H, Hin, Cin, self._buf('lstm_seq_sync', (2,), torch.int32))
+      ops.lstm_seq_fwd(Up, Zx3, done_u8, T1, B, H, Z, Hout, H, Hin, Cin, self._seq_sync('fwd'))
       if not capturing:
         self.mirror_error_flags()
     for t in range(0 if not fused_seq else T1, T1):
@@ -270,7 +282,13 @@ class _Agent(object):
         ops.lstm_gates_fwd(Z[t], Cin[t], done_next, B, H, Hout3[t], H, Hin[t + 1], Cin[t + 1])
     self._last_lstm = dict(X=X, ldx=ldx, in_dim=in_dim, H=H, T1=T1, B=B, done=done_u8, gx=gx, gu=gu, Z=Z, Hin=Hin,
                            Cin=Cin, Hout=Hout, prefix=prefix, fused_seq=seq_ok)
+    self._lstm_ctx[prefix] = self._last_lstm       # stacked cores (MLPandLSTM): one context per layer
     return Hout, (Hin[T1].clone(), Cin[T1].clone())
+
+  def _seq_sync(self, which):
+    """int32[2] (arrival counter, abort flag) of the sequence kernels; one pair per direction for the whole agent (the
+    layers of a stacked core run one after the other on one stream)."""
+    return self._buf('lstm_seq_sync' if which == 'fwd' else 'lstm_seq_sync_bwd', (2,), torch.int32)
 
   def mirror_error_flags(self):
     """Asynchronous device -> pinned-host copy of the sequence kernels' abort flags (forward, backward) on the current
@@ -305,17 +323,17 @@ class _Agent(object):
       raise RuntimeError('seedhip_lstm_seq_fwd / _bwd: a wait timed out (workgroups were not co-resident); the LSTM '
                          'results of that step are invalid.  Set SEEDHIP_LSTM_SEQ=0 to use the per-step kernel.')
 
-  def _lstm_bwd(self, dHout, wsb):
+  def _lstm_bwd(self, dHout, wsb, prefix=None, relu_mask_x=True):
     """dHout [T1*B, H]: gradient wrt the core outputs.  Fills the core's weight gradients and returns
     dX [T1*B, ldx] (columns >= in_dim undefined), already masked by X > 0 (ReLU of the feature layer;
     reward / one-hot columns carry no gradient we use)."""
-    L = self._last_lstm
+    L = self._last_lstm if prefix is None else self._lstm_ctx[prefix]
     T1, B, H, N = L['T1'], L['B'], L['H'], L['T1'] * L['B']
     fl, prefix = self.flat, L['prefix']
     U = fl.p(prefix + '/recurrent_kernel')
-    dZ = self._buf('lstm_dz', (T1, B, 4 * H))
-    dcb = [self._buf('lstm_dc0', (B, H)), self._buf('lstm_dc1', (B, H))]
-    dhb = self._buf('lstm_dh', (B, H))
+    dZ = self._buf(prefix + '/lstm_dz', (T1, B, 4 * H))
+    dcb = [self._buf(prefix + '/lstm_dc0', (B, H)), self._buf(prefix + '/lstm_dc1', (B, H))]
+    dhb = self._buf(prefix + '/lstm_dh', (B, H))
     dH3 = dHout.view(T1, B, H)
     dh_rec = dc_rec = None
     fused_seq = L['fused_seq'] and os.environ.get('SEEDHIP_LSTM_SEQ_BWD', '1') != '0'
@@ -323,8 +341,8 @@ class _Agent(object):
       capturing = torch.cuda.is_current_stream_capturing()
       if not capturing:
         self._lstm_seq_check()
-      ring = self._buf('lstm_seq_ring', (ops.lstm_seq_bwd_workspace_bytes(B, H) // 4,))
-      sync = self._buf('lstm_seq_sync_bwd', (2,), torch.int32)
+      ring = self._buf(prefix + '/lstm_seq_ring', (ops.lstm_seq_bwd_workspace_bytes(B, H) // 4,))
+      sync = self._seq_sync('bwd')
       ops.lstm_seq_bwd(self._buf(prefix + '_u_perm', (H, 4 * H)), L['Z'], L['Cin'], dHout, H, L['done'], T1, B, H, dZ,
                        ring, sync)
       if not capturing:
@@ -340,12 +358,12 @@ class _Agent(object):
     gall = ops.dense_geom(N, H, 4 * H)
     ops.conv2d_bwd_weight(gall, L['Hin'][:T1].view(N, H), dZf, fl.g(prefix + '/recurrent_kernel'), None, wsb)
     ops.conv2d_bwd_weight(L['gx'], L['X'], dZf, fl.g(prefix + '/kernel'), fl.g(prefix + '/bias'), wsb)
-    dX = self._buf('lstm_dx', (N, L['ldx']))
-    ops.conv2d_bwd_data(L['gx'], dZf, fl.p(prefix + '/kernel'), dX, relu_mask=L['X'])
+    dX = self._buf(prefix + '/lstm_dx', (N, L['ldx']))
+    ops.conv2d_bwd_data(L['gx'], dZf, fl.p(prefix + '/kernel'), dX, relu_mask=L['X'] if relu_mask_x else None)
     return dX
 
-  def _lstm_ws_bytes(self):
-    L = self._last_lstm
+  def _lstm_ws_bytes(self, prefix=None):
+    L = self._last_lstm if prefix is None else self._lstm_ctx[prefix]
     N = L['T1'] * L['B']
     return max(ops.conv2d_bwd_weight_workspace_bytes(ops.dense_geom(N, L['H'], 4 * L['H'])),
                ops.conv2d_bwd_weight_workspace_bytes(L['gx']))
@@ -611,38 +629,50 @@ class ImpalaDeep(_Agent):
   reference's creation order (tests/agents_test.py:45)."""
 
   def __init__(self, num_actions, observation_shape=(72, 96, 3), device='cuda', seed=0, entropy_cost=None,
-               channels=(16, 32, 32), fc=256, lstm=256):
+               channels=(16, 32, 32), fc=256, lstm=256, kernel_init='glorot', packed_bits=False):
+    """lstm=0: feed-forward (no core, no reward / action inputs); kernel_init: initialiser of every kernel
+    ('glorot' Keras default | 'lecun_normal'); packed_bits: observations are uint16 / int16 bit planes [h, w, planes],
+    unpacked to 16 binary channels each (GFootball, football/networks.py:68-150)."""
     super(ImpalaDeep, self).__init__(num_actions, device)
     h, w, c = observation_shape
+    self._packed = bool(packed_bits)
+    self._obs_in = (h, w, c)
+    if packed_bits:
+      c = c * 16
     self._obs = (h, w, c)
     self._channels, self._fc, self._H = tuple(channels), fc, lstm
     self._entropy_cost = entropy_cost
     # csrc/convpool.hip is built for the reference's first stage: 3-channel uint8 frames -> 16 channels
     self._fused_first_stage = (c == 3 and self._channels[0] == 16 and w <= 114 and h >= 3 and w >= 3)
     spec, cin = [], c
+    ki = kernel_init
     self._stack_shapes = []                    # (ih, iw, cin, ch, oh, ow)
     for i, ch in enumerate(self._channels):
-      spec += [('stack%d/conv/kernel' % i, (3, 3, cin, ch), 'glorot'), ('stack%d/conv/bias' % i, (ch,), 'zeros')]
+      spec += [('stack%d/conv/kernel' % i, (3, 3, cin, ch), ki), ('stack%d/conv/bias' % i, (ch,), 'zeros')]
       for b in range(2):
         for j in range(2):
-          spec += [('stack%d/res_%d/conv2d_%d/kernel' % (i, b, j), (3, 3, ch, ch), 'glorot'),
+          spec += [('stack%d/res_%d/conv2d_%d/kernel' % (i, b, j), (3, 3, ch, ch), ki),
                    ('stack%d/res_%d/conv2d_%d/bias' % (i, b, j), (ch,), 'zeros')]
       oh, ow = (h + 1) // 2, (w + 1) // 2
       self._stack_shapes.append((h, w, cin, ch, oh, ow))
       h, w, cin = oh, ow, ch
     self._flat_dim = h * w * cin
-    self._in_dim = fc + 1 + num_actions
-    self._ldx = _round4(self._in_dim)
     H = lstm
-    spec += [('conv_to_linear/kernel', (self._flat_dim, fc), 'glorot'), ('conv_to_linear/bias', (fc,), 'zeros'),
-             ('core/kernel', (self._in_dim, 4 * H), 'glorot'), ('core/recurrent_kernel', (H, 4 * H), 'orthogonal'),
-             ('core/bias', (4 * H,), 'lstm_bias'),
-             ('policy_logits/kernel', (H, num_actions), 'glorot'), ('policy_logits/bias', (num_actions,), 'zeros'),
-             ('baseline/kernel', (H, 1), 'glorot'), ('baseline/bias', (1,), 'zeros')]
+    self._in_dim = fc + 1 + num_actions if H else fc
+    self._ldx = _round4(self._in_dim)
+    spec += [('conv_to_linear/kernel', (self._flat_dim, fc), ki), ('conv_to_linear/bias', (fc,), 'zeros')]
+    if H:
+      spec += [('core/kernel', (self._in_dim, 4 * H), 'glorot'), ('core/recurrent_kernel', (H, 4 * H), 'orthogonal'),
+               ('core/bias', (4 * H,), 'lstm_bias')]
+    feat = H or fc
+    spec += [('policy_logits/kernel', (feat, num_actions), ki), ('policy_logits/bias', (num_actions,), 'zeros'),
+             ('baseline/kernel', (feat, 1), ki), ('baseline/bias', (1,), 'zeros')]
     self._build_params(spec, seed)
     self._last = None
 
   def initial_state(self, batch_size):
+    if not self._H:
+      return ()
     z = torch.zeros((batch_size, self._H), dtype=torch.float32, device=self.device)
     return (z, z.clone())
 
@@ -654,11 +684,17 @@ class ImpalaDeep(_Agent):
       reward, done, obs, prev_actions = reward[None], done[None], obs[None], prev_actions[None]
     T1, B = done.shape[0], done.shape[1]
     N = T1 * B
-    if obs.dtype != torch.uint8:
-      raise ValueError('observations must be uint8 frames')
     fl = self.flat
     h0, w0, c0 = self._obs
-    x = obs.reshape(N, h0, w0, c0).contiguous()
+    if self._packed:
+      if obs.dtype not in (torch.int16, torch.uint16):
+        raise ValueError('packed observations must be 16-bit words (football/observation.py)')
+      x = self._buf('unpacked', (N, h0, w0, c0), torch.uint8)
+      ops.unpackbits_u16(obs.contiguous(), x)                                          # football/networks.py:101-104
+    else:
+      if obs.dtype != torch.uint8:
+        raise ValueError('observations must be uint8 frames')
+      x = obs.reshape(N, h0, w0, c0).contiguous()
     saved = []
     for i, (ih, iw, cin, ch, oh, ow) in enumerate(self._stack_shapes):
       g = ops.conv_geom(N, ih, iw, cin, 3, 3, 1, 'same', ch)
@@ -692,11 +728,15 @@ class ImpalaDeep(_Agent):
     gfc = ops.dense_geom(N, self._flat_dim, self._fc, ld_out=ldx)
     ops.conv2d_fwd(gfc, flat, fl.p('conv_to_linear/kernel'), fl.p('conv_to_linear/bias'), X, in_relu=True,
                    out_relu=True)                                                    # :105-109
-    ops.lstm_assemble_inputs(X, ldx, self._fc, self._num_actions, reward.to(torch.float32).contiguous(),
-                             prev_actions.contiguous(), True, N)                     # :112-114
-    done_u8 = ops.as_u8(done)
-    Hout, new_state = self._lstm_fwd(X, ldx, self._in_dim, self._H, T1, B, done_u8, core_state)
-    head = self._head_fwd(Hout, N, self._H)
+    if self._H:
+      ops.lstm_assemble_inputs(X, ldx, self._fc, self._num_actions, reward.to(torch.float32).contiguous(),
+                               prev_actions.contiguous(), True, N)                   # :112-114
+      done_u8 = ops.as_u8(done)
+      Hout, new_state = self._lstm_fwd(X, ldx, self._in_dim, self._H, T1, B, done_u8, core_state)
+      head = self._head_fwd(Hout, N, self._H)
+    else:                                                                            # football/networks.py:147-150
+      Hout, new_state = None, ()
+      head = self._head_fwd(X, N, self._fc)
     self._last = dict(T1=T1, B=B, N=N, saved=saved, flat=flat, gfc=gfc, X=X, Hout=Hout, head=head)
     out = self._agent_output(head, T1, B, sample=sample_actions and not is_training)
     if not unroll:
@@ -710,12 +750,18 @@ class ImpalaDeep(_Agent):
     d_head = self._buf('d_head', (N, self._ldh), zero=True)
     wsb = self._wgrad_ws()
     H = self._H
-    gh = ops.dense_geom(N, H, self._ldh)
-    ops.conv2d_bwd_weight(gh, L['Hout'], d_head, fl.g('heads/kernel'), fl.g('heads/bias'), wsb)
-    dHout = self._buf('d_hout', (N, H))
-    ops.conv2d_bwd_data(gh, d_head, fl.p('heads/kernel'), dHout)
-    dX = self._lstm_bwd(dHout, wsb)
-    # Dense 256 (its ReLU mask was applied to dX by the LSTM input-projection dgrad)
+    if H:
+      gh = ops.dense_geom(N, H, self._ldh)
+      ops.conv2d_bwd_weight(gh, L['Hout'], d_head, fl.g('heads/kernel'), fl.g('heads/bias'), wsb)
+      dHout = self._buf('d_hout', (N, H))
+      ops.conv2d_bwd_data(gh, d_head, fl.p('heads/kernel'), dHout)
+      dX = self._lstm_bwd(dHout, wsb)
+    else:
+      gh = ops.dense_geom(N, self._fc, self._ldh)
+      ops.conv2d_bwd_weight(gh, L['X'], d_head, fl.g('heads/kernel'), fl.g('heads/bias'), wsb)
+      dX = self._buf('d_fc', (N, self._ldx))
+      ops.conv2d_bwd_data(gh, d_head, fl.p('heads/kernel'), dX, relu_mask=L['X'])
+    # Dense 256 (its ReLU mask was applied to dX by the LSTM input-projection / head dgrad)
     ops.conv2d_bwd_weight(L['gfc'], L['flat'], dX, fl.g('conv_to_linear/kernel'), fl.g('conv_to_linear/bias'), wsb,
                           in_relu=True)
     self._grads_ready_from('conv_to_linear/kernel')        # Dense + LSTM + heads: exchanged under the conv backward
@@ -753,8 +799,117 @@ class ImpalaDeep(_Agent):
 
   def _wgrad_ws(self):
     L = self._last
-    need = ops.conv2d_bwd_weight_workspace_bytes(ops.dense_geom(L['N'], self._H, self._ldh))
-    need = max(need, ops.conv2d_bwd_weight_workspace_bytes(L['gfc']), self._lstm_ws_bytes())
+    need = ops.conv2d_bwd_weight_workspace_bytes(ops.dense_geom(L['N'], self._H or self._fc, self._ldh))
+    need = max(need, ops.conv2d_bwd_weight_workspace_bytes(L['gfc']))
+    if self._H:
+      need = max(need, self._lstm_ws_bytes())
     for S in L['saved']:
       need = max(need, ops.conv2d_bwd_weight_workspace_bytes(S['g']), ops.conv2d_bwd_weight_workspace_bytes(S['gres']))
     return self._buf('wgrad_ws', (need // 4 + 4,))
+
+
+class GFootball(ImpalaDeep):
+  """Google Research Football agent: mirror of /root/reference/football/networks.py:68-150 -- the ImpalaDeep torso with
+  FOUR stacks (16, 32, 32, 32 channels), lecun_normal kernels, no LSTM and no reward / action inputs; observations are
+  the packed SMM bit planes of football/observation.py (uint16 words, 16 binary channels each), unpacked on the
+  device (csrc/frames.hip: unpackbits) and read by the first conv as bytes with its / 255 fused."""
+
+  def __init__(self, num_actions, observation_shape=(72, 96, 1), device='cuda', seed=0, entropy_cost=None):
+    super(GFootball, self).__init__(num_actions, observation_shape=observation_shape, device=device, seed=seed,
+                                    entropy_cost=entropy_cost, channels=(16, 32, 32, 32), fc=256, lstm=0,
+                                    kernel_init='lecun_normal', packed_bits=True)
+
+
+class MLPandLSTM(_Agent):
+  """MLP + stacked-LSTM agent: mirror of /root/reference/agents/vtrace/networks.py:25-121 (the agent of the MuJoCo /
+  generic V-trace mains): Dense(size, relu) layers on the flat float observation, tf.keras StackedRNNCells of LSTMCells
+  with the done-reset before every step, policy / baseline heads.  The recurrences run layer by layer over the whole
+  unroll (a layer only needs its own previous state and the layer below at the same step), each on the whole-sequence
+  LSTM kernels; state = tuple of (h, c) per cell (StackedRNNCells.get_initial_state)."""
+
+  def __init__(self, num_actions, observation_size, mlp_sizes=(64, 64), lstm_sizes=(64,), device='cuda', seed=0,
+               entropy_cost=None):
+    super(MLPandLSTM, self).__init__(num_actions, device)
+    if not lstm_sizes:
+      raise ValueError('MLPandLSTM needs at least one LSTM layer')
+    if any(m % 4 for m in mlp_sizes) or any(h % 4 for h in lstm_sizes):
+      raise ValueError('layer sizes must be multiples of 4 (16-byte rows)')
+    self._obs_dim, self._mlp, self._lstm = observation_size, tuple(mlp_sizes), tuple(lstm_sizes)
+    self._entropy_cost = entropy_cost
+    spec, cin = [], observation_size
+    for i, m in enumerate(self._mlp):
+      spec += [('mlp/dense_%d/kernel' % i, (cin, m), 'glorot'), ('mlp/dense_%d/bias' % i, (m,), 'zeros')]
+      cin = m
+    for l, h in enumerate(self._lstm):
+      spec += [('core/cell_%d/kernel' % l, (cin, 4 * h), 'glorot'), ('core/cell_%d/recurrent_kernel' % l, (h, 4 * h), 'orthogonal'),
+               ('core/cell_%d/bias' % l, (4 * h,), 'lstm_bias')]
+      cin = h
+    spec += [('policy_logits/kernel', (cin, num_actions), 'glorot'), ('policy_logits/bias', (num_actions,), 'zeros'),
+             ('baseline/kernel', (cin, 1), 'glorot'), ('baseline/bias', (1,), 'zeros')]
+    self._build_params(spec, seed)
+    self._last = None
+
+  accepts_sample_actions = True
+
+  def initial_state(self, batch_size):
+    z = lambda h: torch.zeros((batch_size, h), dtype=torch.float32, device=self.device)
+    return tuple((z(h), z(h)) for h in self._lstm)
+
+  def __call__(self, prev_actions, env_outputs, core_state, unroll=False, is_training=False, sample_actions=True):
+    del prev_actions                                 # unused by this agent (networks.py:79)
+    done, obs = env_outputs.done, env_outputs.observation
+    if not unroll:
+      done, obs = done[None], obs[None]
+    T1, B = done.shape[0], done.shape[1]
+    N = T1 * B
+    fl = self.flat
+    x = obs.reshape(N, self._obs_dim).to(torch.float32)
+    ld = _round4(self._obs_dim)
+    if ld != self._obs_dim or not x.is_contiguous():
+      xp = self._buf('obs_pad', (N, ld), zero=True)
+      xp[:, :self._obs_dim].copy_(x)
+      x = xp
+    acts, geoms, cin = [x], [], self._obs_dim
+    for i, m in enumerate(self._mlp):                # networks.py:104 (Dense + relu)
+      g = ops.dense_geom(N, cin, m, ld_in=ld)
+      a = self._buf('mlp%d' % i, (N, m))
+      ops.conv2d_fwd(g, acts[-1], fl.p('mlp/dense_%d/kernel' % i), fl.p('mlp/dense_%d/bias' % i), a, out_relu=True)
+      acts.append(a); geoms.append(g); cin, ld = m, m
+    done_u8 = ops.as_u8(done)
+    h_in, new_state = acts[-1], []
+    for l, h in enumerate(self._lstm):               # networks.py:106-119, one layer at a time
+      h_in, st = self._lstm_fwd(h_in, ld, cin, h, T1, B, done_u8, core_state[l], prefix='core/cell_%d' % l)
+      new_state.append(st); cin, ld = h, h
+    head = self._head_fwd(h_in, N, cin)
+    self._last = dict(T1=T1, B=B, N=N, acts=acts, geoms=geoms, top=h_in, head=head)
+    out = self._agent_output(head, T1, B, sample=sample_actions and not is_training)
+    if not unroll:
+      out = AgentOutput(*[None if t is None else t[0] for t in out])
+    return out, tuple(new_state)
+
+  def backward(self):
+    L = self._last
+    N, fl = L['N'], self.flat
+    d_head = self._buf('d_head', (N, self._ldh), zero=True)
+    htop = self._lstm[-1]
+    gh = ops.dense_geom(N, htop, self._ldh)
+    need = ops.conv2d_bwd_weight_workspace_bytes(gh)
+    for l in range(len(self._lstm)):
+      need = max(need, self._lstm_ws_bytes('core/cell_%d' % l))
+    for g in L['geoms']:
+      need = max(need, ops.conv2d_bwd_weight_workspace_bytes(g))
+    wsb = self._buf('wgrad_ws', (need // 4 + 4,))
+    ops.conv2d_bwd_weight(gh, L['top'], d_head, fl.g('heads/kernel'), fl.g('heads/bias'), wsb)
+    dh = self._buf('d_top', (N, htop))
+    ops.conv2d_bwd_data(gh, d_head, fl.p('heads/kernel'), dh)
+    for l in range(len(self._lstm) - 1, -1, -1):
+      # the layer's input is the layer below (no activation) or, for layer 0, the last Dense + relu output
+      dh = self._lstm_bwd(dh, wsb, prefix='core/cell_%d' % l, relu_mask_x=(l == 0 and bool(self._mlp)))
+    acts, geoms = L['acts'], L['geoms']
+    for i in range(len(self._mlp) - 1, -1, -1):
+      ops.conv2d_bwd_weight(geoms[i], acts[i], dh, fl.g('mlp/dense_%d/kernel' % i), fl.g('mlp/dense_%d/bias' % i), wsb)
+      if i > 0:
+        d_in = self._buf('d_mlp%d' % (i - 1), tuple(acts[i].shape))
+        ops.conv2d_bwd_data(geoms[i], dh, fl.p('mlp/dense_%d/kernel' % i), d_in, relu_mask=acts[i])
+        dh = d_in
+    self._grads_ready_from(None)

@@ -171,6 +171,13 @@ def stack_prepare(state, done_u8, T, B, HW, frames_ext, nvalid):
           'seedhip_stack_prepare')
 
 
+def unpackbits_u16(packed, out):
+  """football/observation.py:48-63: uint16 / int16 words [...] -> uint8 [... * 16] of 0 / 255."""
+  with _dev(out):
+    _lib.check(_lib.lib().seedhip_unpackbits_u16(_lib.ptr(packed), packed.numel(), _lib.ptr(out), _lib.stream()),
+               'seedhip_unpackbits_u16')
+
+
 def stack_frames_f32(frames_ext, nvalid, T, B, HW, out):
   with _dev(out):
     _lib.check(_lib.lib().seedhip_stack_frames_f32(
