@@ -22,11 +22,25 @@ def _ref_views(agent, flat_tensor):
   return collections.OrderedDict((n, agent._ref_view(getter, n)) for n, _, _ in agent._ref_spec)   # pylint: disable=protected-access
 
 
-def save(path, agent, optimizer=None):
-  """Writes `path` (.npz): agent/<name>, and with an optimizer adam_m/<name>, adam_v/<name>, iterations."""
+def _npz(path):
+  """np.savez appends '.npz' to a path without it while np.load does not: use ONE spelling on both sides."""
+  path = str(path)
+  return path if path.endswith('.npz') else path + '.npz'
+
+
+def save(path, agent, optimizer=None, target_agent=None, learner=None):
+  """Writes `path` (.npz): agent/<name>, and with an optimizer adam_m/<name>, adam_v/<name>, iterations; for R2D2
+  also the target network (target_agent/<name>: the reference checkpoints it, agents/r2d2/learner.py:646-647) and the
+  learner's step counter (the phase of the target-update period)."""
+  path = _npz(path)
   out = collections.OrderedDict()
   for name, view in agent.trainable_variables:
     out['agent/' + name] = view.detach().cpu().numpy()
+  if target_agent is not None:
+    for name, view in target_agent.trainable_variables:
+      out['target_agent/' + name] = view.detach().cpu().numpy()
+  if learner is not None and hasattr(learner, 'iterations'):
+    out['learner_iterations'] = np.asarray(learner.iterations, np.int64)
   if optimizer is not None:
     sd = optimizer.state_dict()
     out['iterations'] = np.asarray(sd['iterations'], np.int64)
@@ -38,11 +52,16 @@ def save(path, agent, optimizer=None):
   return list(out)
 
 
-def restore(path, agent, optimizer=None, strict=True):
+def restore(path, agent, optimizer=None, strict=True, target_agent=None, learner=None):
   """Loads what `save` wrote.  strict=False: parameters only are required (e.g. arrays exported from a reference
-  checkpoint); the optimizer then starts fresh."""
-  data = np.load(path)
-  agent.load_reference_params(dict((n, data['agent/' + n]) for n, _, _ in agent._ref_spec))   # pylint: disable=protected-access
+  checkpoint); the optimizer then starts fresh.  (TensorFlow checkpoint files: seed_rl_amd/tf_checkpoint.py.)"""
+  data = np.load(_npz(path))
+  agent.load_reference_params(dict((n, data['agent/' + n]) for n, _, _ in agent._ref_spec   # pylint: disable=protected-access
+                                   if 'agent/' + n in data.files or n != 'entropy_cost_param'))
+  if target_agent is not None and any(k.startswith('target_agent/') for k in data.files):
+    target_agent.load_reference_params(dict((n, data['target_agent/' + n]) for n, _, _ in target_agent._ref_spec))   # pylint: disable=protected-access
+  if learner is not None and 'learner_iterations' in data.files:
+    learner.iterations = int(data['learner_iterations'])
   if optimizer is None:
     return
   have_opt = 'iterations' in data.files
