@@ -122,7 +122,7 @@ def test_checkpoint_roundtrip(device, tmp_path):
   agent, opt, lrn = make(0)
   unroll = smoke_step.make_unroll(agent, T + 1, B, A, device, seed=3)
   lrn.minimize(unroll); lrn.minimize(unroll)
-  path = str(tmp_path / 'ckpt.npz')
+  path = str(tmp_path / 'ckpt')          # no extension: save and restore agree on '.npz' 
   names = checkpoint.save(path, agent, opt)
   assert 'agent/policy_logits/kernel' in names and 'adam_v/baseline/bias' in names and 'iterations' in names
   agent2, opt2, lrn2 = make(123)                          # different init: everything must come from the file
