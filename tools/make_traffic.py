@@ -16,7 +16,9 @@ import sys
 REGIONS = [
     ('stack_conv_fwd', 'stackconv::stackconv_fwd'),
     ('stack_conv_wgrad', 'stackconv::stackconv_wgrad'),
-    ('conv_fwd[4x4/2 16->32 @20x20]', 'wsgemm::ws_fast_kernel<2, 8, 0>'),
+    ('conv_fwd[4x4/2 16->32 @20x20]', 'wsgemm::ws_tab_kernel<2, 8, 0'),
+    ('conv_dgrad[4x4/2 16->32 @20x20]', 'wsgemm::ws_tab_kernel<4, 4, 1'),
+    ('conv_fwd[4x4/2 16->32 @20x20]', 'wsgemm::ws_fast_kernel<2, 8, 0>'),     # SEEDHIP_WS_TAB=0
     ('conv_dgrad[4x4/2 16->32 @20x20]', 'wsgemm::ws_fast_kernel<4, 4, 1>'),
     ('conv_fwd[4x4/2 16->32 @20x20]', 'wsgemm::ws_kernel<1, 2,'),            # SEEDHIP_WS_FAST=0
     ('conv_dgrad[4x4/2 16->32 @20x20]', 'wsgemm::ws_kernel<1, 4,'),
