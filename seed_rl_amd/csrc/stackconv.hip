@@ -420,6 +420,10 @@ __device__ __forceinline__ void band_prologue16(const Params& p, unsigned char* 
   wave_lds_fence();
 }
 
+// EXP (tools/probes/stack_probe.hip only; the library instantiates EXP = 0): leave one ingredient out -- 1 no MFMAs,
+// 2 no global band prefetch after the prologue, 4 no output stores, 8 no LDS pixel reads (one fragment reused),
+// 16 no band conversion / LDS store.
+template <int EXP>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
 stackconv_fwd_bf16r_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -474,7 +478,8 @@ stackconv_fwd_bf16r_kernel(const Params p) {
     for (int t = t0; t < t1; ++t) {
       const bool more = t + 1 < t1;
       BandPrefetch pf;
-      if (more) pf = band_load(band_src(p, t + 4, b, wave), lane);
+      if (EXP & 2) { pf.v0 = make_uint4(lane, t, 3, 4); pf.v1 = pf.v0; }
+      else if (more) pf = band_load(band_src(p, t + 4, b, wave), lane);
       const int nv = p.nvalid[(long long)t * p.B + b];
       f32x4_t acc[kMT];
 #pragma unroll
@@ -483,16 +488,27 @@ stackconv_fwd_bf16r_kernel(const Params p) {
         const unsigned char* base = myring + ((t + 3 - (G >> 1)) % kSlots) * kBand16 + (G & 1) * 4 * kIW * 2;
         Frag8 wlo;
         wlo.u = wlo_lds[G * 64 + lane];
+        // the five pixel fragments first, then part-major MFMAs: consecutive instructions then write DIFFERENT
+        // accumulators (a dependent 16x16x32 bf16 MFMA issued straight behind its producer waits out the producer's
+        // passes: lo -> mid -> hi on one accumulator ran the matrix pipe at ~40 %, tools/probes/stack_probe.hip)
+        Frag8 xf[kMT];
 #pragma unroll
         for (int m = 0; m < kMT; ++m) {
-          const uint2* src = reinterpret_cast<const uint2*>(base + aoff[m]);
-          const uint2 x0 = src[0], x1 = src[1];
-          Frag8 xf;
-          xf.u = make_uint4(x0.x, x0.y, x1.x, x1.y);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo.v, xf.v, acc[m], 0, 0, 0);            // lo, mid, hi
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[G][1].v, xf.v, acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[G][0].v, xf.v, acc[m], 0, 0, 0);
+          const uint2* src = reinterpret_cast<const uint2*>(base + ((EXP & 8) ? aoff[0] : aoff[m]));
+          if ((EXP & 8) && (m > 0 || G > 0)) xf[m].u = make_uint4(t, G, m, lane);
+          else { const uint2 x0 = src[0], x1 = src[1]; xf[m].u = make_uint4(x0.x, x0.y, x1.x, x1.y); }
         }
+        if (EXP & 1) {
+#pragma unroll
+          for (int m = 0; m < kMT; ++m) asm volatile("" :: "v"(xf[m].u.x), "v"(xf[m].u.y), "v"(xf[m].u.z), "v"(xf[m].u.w), "v"(wlo.u.x), "v"(wlo.u.w));
+          return;
+        }
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo.v, xf[m].v, acc[m], 0, 0, 0);         // lo
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[G][1].v, xf[m].v, acc[m], 0, 0, 0);  // mid
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[G][0].v, xf[m].v, acc[m], 0, 0, 0);  // hi
       };
       if (nv == 4) {                                   // the common case: one straight-line block of 8 k-groups
 #pragma unroll
@@ -509,11 +525,13 @@ stackconv_fwd_bf16r_kernel(const Params p) {
           v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
         }
         float* o = p.out + (((long long)t * p.B + b) * 400 + pix) * p.ld_out + co0 + 4 * kq;
-        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        if (EXP & 4) asm volatile("" :: "v"(v));
+        else *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
       }
       if (more) {
         wave_lds_fence();                              // this wave's reads of frame t are done
-        band_store16(myring + ((t + 4) % kSlots) * kBand16, pf, lane);
+        if (EXP & 16) asm volatile("" :: "v"(pf.v0.x), "v"(pf.v0.y), "v"(pf.v0.z), "v"(pf.v0.w), "v"(pf.v1.x), "v"(pf.v1.y), "v"(pf.v1.z), "v"(pf.v1.w));
+        else band_store16(myring + ((t + 4) % kSlots) * kBand16, pf, lane);
         wave_lds_fence();
       }
     }
@@ -900,8 +918,8 @@ int launch_fwd(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, cons
     const size_t lds = (size_t)kGroups * 64 * 16 + (size_t)kWaves * kWaveRing16;
     int grid;
     decompose(p.T1, p.B, max_grid_for(2), &p.spc, &p.items, &grid);
-    (void)hipFuncSetAttribute((const void*)stackconv_fwd_bf16r_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(stackconv_fwd_bf16r_kernel, dim3(grid, 1, g->cout / 16), dim3(kThreads), lds, s, p);
+    (void)hipFuncSetAttribute((const void*)stackconv_fwd_bf16r_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(stackconv_fwd_bf16r_kernel<0>, dim3(grid, 1, g->cout / 16), dim3(kThreads), lds, s, p);
     return check_launch("stackconv_fwd_bf16r_kernel");
   }
   const size_t lds = kWFloats * sizeof(float) + (size_t)kWaves * kWaveRing;

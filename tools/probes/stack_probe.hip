@@ -1,0 +1,55 @@
+// Probe: the bf16x3 first-conv forward (csrc/stackconv.hip: stackconv_fwd_bf16r_kernel) at cfg2 (T1 = 21, B = 512),
+// one ingredient left out at a time.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iseed_rl_amd/csrc -Iinclude tools/probes/stack_probe.hip \
+//         seed_rl_amd/csrc/error.cpp -o tools/probes/stack_probe.bin
+#include "../../seed_rl_amd/csrc/stackconv.hip"
+#include <vector>
+using namespace seedhip::stackconv;
+
+template <int EXP>
+static float run(Params p, int grid, size_t lds, int reps) {
+  (void)hipFuncSetAttribute((const void*)stackconv_fwd_bf16r_kernel<EXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(stackconv_fwd_bf16r_kernel<EXP>, dim3(grid, 1, 1), dim3(kThreads), lds, 0, p);
+  (void)hipEventRecord(e0, 0);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(stackconv_fwd_bf16r_kernel<EXP>, dim3(grid, 1, 1), dim3(kThreads), lds, 0, p);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) printf("error: %s\n", hipGetErrorString(e));
+  return ms / reps * 1e3f;
+}
+
+int main(int argc, char** argv) {
+  const int T1 = 21, B = argc > 1 ? atoi(argv[1]) : 512;
+  const int wgs_per_cu = argc > 2 ? atoi(argv[2]) : 2;
+  seedhip_stack_conv_geom g;
+  memset(&g, 0, sizeof(g));
+  g.T = T1; g.B = B; g.ih = 84; g.iw = 84; g.oh = 20; g.ow = 20; g.kh = 8; g.kw = 8; g.stride = 4; g.cout = 16; g.ld_out = 16;
+  uint8_t *frames, *nvalid; float *w, *bias, *out;
+  const size_t nf = (size_t)(T1 + 3) * B * 7056, no = (size_t)T1 * B * 400 * 16;
+  (void)hipMalloc(&frames, nf); (void)hipMalloc(&nvalid, T1 * B); (void)hipMalloc(&w, 4096 * 4); (void)hipMalloc(&bias, 64); (void)hipMalloc(&out, no * 4);
+  std::vector<uint8_t> h(nf);
+  for (size_t i = 0; i < nf; ++i) h[i] = (uint8_t)((i * 2654435761u) >> 13);
+  (void)hipMemcpy(frames, h.data(), nf, hipMemcpyHostToDevice);
+  std::vector<uint8_t> nv(T1 * B, 4);
+  (void)hipMemcpy(nvalid, nv.data(), nv.size(), hipMemcpyHostToDevice);
+  std::vector<float> hw(4096);
+  for (int i = 0; i < 4096; ++i) hw[i] = (float)((i * 37) % 211) / 211.f - 0.5f;
+  (void)hipMemcpy(w, hw.data(), 4096 * 4, hipMemcpyHostToDevice); (void)hipMemcpy(bias, hw.data(), 64, hipMemcpyHostToDevice);
+  Params p = make_params(&g, frames, nvalid);
+  p.w = w; p.bias = bias; p.out = out; p.out_relu = 1;
+  int grid;
+  decompose(p.T1, p.B, max_grid_for(wgs_per_cu), &p.spc, &p.items, &grid);
+  const size_t lds = (size_t)kGroups * 64 * 16 + (size_t)kWaves * kWaveRing16;
+  const double flops = 2.0 * T1 * B * 400 * 16 * 256;
+  printf("stack conv fwd bf16x3: T1=%d B=%d grid=%d spc=%d items=%d lds=%zu\n", T1, B, grid, p.spc, p.items, lds);
+#define R(E, what) { float us = run<E>(p, grid, lds, 20); printf("  %-46s %7.1f us  %6.1f algorithmic TF/s\n", what, us, flops / us / 1e6); }
+  R(0, "full") R(1, "no MFMA") R(2, "no global band prefetch") R(4, "no stores") R(8, "no LDS pixel reads") R(16, "no band convert + LDS store")
+  R(2 | 4, "no global traffic") R(1 | 8, "no MFMA, no LDS pixel reads") R(2 | 4 | 16, "LDS reads + MFMA only") R(2 | 4 | 8 | 16, "MFMA only (+ w lo reads)")
+  R(1 | 8 | 16, "memory only") R(1 | 2 | 4 | 16, "LDS pixel reads only")
+  return 0;
+}
