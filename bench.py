@@ -430,11 +430,15 @@ def main():
   # HBM traffic of the dominant kernel from the committed PMC passes (same config only; latest profiling round)
   tfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_cfg2_traffic.json')))
   if headline and tfiles:
-    tb = json.load(open(tfiles[-1]))['traffic_bytes']
+    tj = json.load(open(tfiles[-1]))
+    tb = tj['traffic_bytes']
     if rec['dominant'] in tb:
       roofline['traffic'] = tb[rec['dominant']]
       roofline['traffic_source'] = ('profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'
                                     % os.path.basename(tfiles[-1]))
+    if rec['dominant'] in tj.get('mfma_pmc', {}):
+      # the matrix pipe's busy share from the SQ counters of the committed profiling round (same kernel, same shape)
+      roofline['mfma_pmc'] = tj['mfma_pmc'][rec['dominant']]
   if rank != 0:
     if distributed:
       torch.distributed.destroy_process_group()

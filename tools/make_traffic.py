@@ -44,11 +44,28 @@ def main():
     if best:
       kernel[region], fetch[region], write[region] = best[0][:100], best[1], best[2]
       traffic[region] = int((2 * best[1] + best[2]) * 1024)
+  # MFMA-pipe utilisation of the same kernels from the SQ counters (tools/pmc_mfma.sh / pmc_mfma.py), when condensed
+  mfma = {}
+  mpath = src.replace('_pmc.csv', '_mfma.csv')
+  import os
+  if os.path.exists(mpath):
+    mrows = list(csv.DictReader(open(mpath)))
+    for region, pat in REGIONS:
+      if region in mfma:
+        continue
+      for r in mrows:
+        if pat in r['Kernel']:
+          mfma[region] = dict(mfma_utilisation=float(r['mfma_utilisation']), effective_clock_GHz=float(r['effective_clock_GHz']),
+                              duration_us=float(r['avg_duration_us']))
+          break
   json.dump({
       'note': 'HBM bytes per launch from rocprofv3 PMC passes (%s): (2 x FETCH_SIZE + WRITE_SIZE) x 1024; FETCH_SIZE '
               'doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced read stream)' % src,
       'config': 'cfg2 Atari shallow T=20 B=512 A=18',
       'traffic_bytes': traffic, 'fetch_kb_raw': fetch, 'write_kb': write, 'kernel': kernel,
+      'mfma_pmc': mfma,
+      'mfma_note': 'mfma_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), separate --pmc pass; '
+                   'executed MFMA work incl. structural zeros (conv1 data gradient: border taps of the super-pixel GEMM, +23 %)',
   }, open(out, 'w'), indent=1)
   for k, v in traffic.items():
     print('%-40s %8.1f MB' % (k, v / 1e6))
