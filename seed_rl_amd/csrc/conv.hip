@@ -16,6 +16,7 @@
 #include "halo_fwd.h"
 #include "gemm.h"
 #include "wsgemm.h"
+#include "wsw.h"
 #include "../../include/seedhip.h"
 
 using namespace seedhip;
@@ -373,6 +374,13 @@ extern "C" size_t seedhip_conv2d_bwd_weight_workspace_bytes(const seedhip_conv_g
     const size_t mm = (size_t)gpl.slices * ((size_t)M * N + N) * sizeof(float);
     if (mm > need) need = mm;
   }
+  {
+    wsw::Params wp;
+    if (wsw::plan(wp, g)) {
+      const size_t mm = (size_t)wsw::grid_for(g->n_img) * ((size_t)M * N + N) * sizeof(float);
+      if (mm > need) need = mm;
+    }
+  }
   return need;
 }
 
@@ -384,6 +392,21 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
   SEEDHIP_REQUIRE(in_dtype == kInF32 || in_dtype == kInU8Div255, "conv2d_bwd_weight: bad in_dtype %d", in_dtype);
   SEEDHIP_REQUIRE(workspace_bytes >= seedhip_conv2d_bwd_weight_workspace_bytes(geom),
                   "conv2d_bwd_weight: workspace too small");
+  {
+    // streaming kernel (wsw.h): 64-float tap rows, 32 output channels -- the second Atari conv
+    static const int wsw_on = getenv("SEEDHIP_WSW") ? atoi(getenv("SEEDHIP_WSW")) : 1;
+    wsw::Params wp;
+    if (wsw_on && in_dtype == kInF32 && al16(in) && al16(dy) && al16(workspace) && wsw::plan(wp, geom)) {
+      const int M = geom->kh * geom->kw * geom->cin, N = geom->cout, slices = wsw::grid_for(geom->n_img);
+      hipStream_t s = (hipStream_t)stream;
+      float* pw = (float*)workspace;
+      float* pb = pw + (size_t)slices * M * N;
+      wp.X = (const float*)in; wp.dY = dy; wp.partial_w = pw; wp.partial_b = dbias ? pb : nullptr; wp.in_relu = in_relu;
+      rc = wsw::launch(wp, s); if (rc) return rc;
+      reduce_slices2(pw, (long long)M * N, dw, pb, N, dbias, slices, s);
+      return check_launch("conv2d_bwd_weight(wsw)");
+    }
+  }
   if (in_dtype == kInF32 && conv_wgrad_gemm_ok(geom) && al16(in) && al16(dy) && al16(workspace)) {
     gemm::Params gp;
     gemm::conv_wgrad_setup(gp, geom);
