@@ -544,13 +544,16 @@ class Server(object):
     async def call(request_iterator, context):
       del context
       loop = asyncio.get_running_loop()
-      async for request in request_iterator:
-        fut = loop.create_future()
+      try:
+        async for request in request_iterator:
+          fut = loop.create_future()
 
-        def done(resp, fut=fut):
-          loop.call_soon_threadsafe(lambda: fut.done() or fut.set_result(resp))
-        self._call(request, done)
-        yield await fut
+          def done(resp, fut=fut):
+            loop.call_soon_threadsafe(lambda: fut.done() or fut.set_result(resp))
+          self._call(request, done)
+          yield await fut
+      except asyncio.CancelledError:                 # stream cut by shutdown / a vanished client: nothing to report
+        return
 
     async def main():
       server = grpc.aio.server(options=[('grpc.max_receive_message_length', -1), ('grpc.max_send_message_length', -1)])

@@ -325,6 +325,32 @@ class FusedInferenceState(object):
       raise ValueError('inference bookkeeping error flags %d (1 id out of range, 2 duplicate ids, 4 store overflow, '
                        '8 training batch overflow)' % f)
 
+  def dequeue_into(self, dst, batch_size):
+    """unroll_queue.dequeue(batch_size) + make_time_major of the reference (learner.py:418-432) without either: copies
+    the first `batch_size` completed unrolls -- already time-major -- from the device batch into the learner's STATIC
+    training unroll `dst` (an Unroll of [T+1, batch_size, ...] tensors + first agent states [batch_size, ...]; the input
+    of a captured GraphedStep), moves the remaining completed unrolls to the front and adjusts the fill count.  Returns
+    False (nothing copied) when fewer than batch_size unrolls are complete.  One host read of the fill count; call it under
+    the same lock as `inference` when another thread serves actors."""
+    k = int(self.batch_count[0])
+    if k < batch_size:
+      return False
+    B = batch_size
+    for d, s_ in zip(utils.flatten(dst.agent_state), utils.flatten(self.batch.agent_state)):
+      d.copy_(s_[:B])
+      if k > B:
+        s_[:k - B].copy_(s_[B:k].clone())
+    rest_d = (dst.prev_actions, dst.env_outputs, dst.agent_outputs)
+    rest_s = (self.batch.prev_actions, self.batch.env_outputs, self.batch.agent_outputs)
+    for d, s_ in zip(utils.flatten(rest_d), utils.flatten(rest_s)):
+      if d is None:
+        continue
+      d.copy_(s_[:, :B].reshape(d.shape).to(d.dtype))
+      if k > B:
+        s_[:, :k - B].copy_(s_[:, B:k].clone())
+    self.batch_count.fill_(k - B)
+    return True
+
   def take_batch(self):
     """Host read of the fill count; returns (count, Unroll of views over the filled columns) and restarts filling."""
     k = int(self.batch_count[0])
