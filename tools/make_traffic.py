@@ -22,7 +22,8 @@ REGIONS = [
     ('conv_dgrad[4x4/2 16->32 @20x20]', 'wsgemm::ws_fast_kernel<4, 4, 1>'),
     ('conv_fwd[4x4/2 16->32 @20x20]', 'wsgemm::ws_kernel<1, 2,'),            # SEEDHIP_WS_FAST=0
     ('conv_dgrad[4x4/2 16->32 @20x20]', 'wsgemm::ws_kernel<1, 4,'),
-    ('conv_wgrad[4x4/2 16->32 @20x20]', 'false, false, true, false, false, 1>(seedhip::gemm::Params)'),
+    ('conv_wgrad[4x4/2 16->32 @20x20]', 'wsw::wsw_kernel'),
+    ('conv_wgrad[4x4/2 16->32 @20x20]', 'false, false, true, false, false, 1>(seedhip::gemm::Params)'),   # SEEDHIP_WSW=0
     ('conv_fwd[1x1/1 2592->256 @1x1]', 'true, false, false, false, false, 2>(seedhip::gemm::Params)'),
     ('conv_dgrad[1x1/1 2592->256 @1x1]', 'true, true, false, false, false, 2>(seedhip::gemm::Params)'),
     ('conv_wgrad[1x1/1 2592->256 @1x1]', 'false, false, false, false, false, 2>(seedhip::gemm::Params)'),
