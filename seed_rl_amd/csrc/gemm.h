@@ -279,6 +279,7 @@ __global__ void __launch_bounds__(256)
 gemm_kernel(const Params p) {
   constexpr int WM = 4 / WN;
   constexpr int BM = WM * MR * 16, BN = WN * NR * 16;
+  constexpr bool kSwap = AKC && BKC;
   typedef typename PickStager<BM, AKC, AG>::type SA;
   typedef typename PickStager<BN, BKC, BG>::type SB;
   __shared__ __attribute__((aligned(16))) float smem[SA::kLdsFloats + SB::kLdsFloats];
@@ -349,8 +350,16 @@ gemm_kernel(const Params p) {
         for (int i = 0; i < MR; ++i)
 #pragma unroll
           for (int j = 0; j < NR; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(AKC ? a_kc[i][kk] : a_oc[kk][i], BKC ? b_kc[j][kk] : b_oc[kk][j],
-                                                             acc[i][j], 0, 0, 0);
+          {
+            // both operands k-contiguous (Dense data gradient): the operands are SWAPPED -- B supplies the instruction's
+            // rows -- so that a lane ends up with four consecutive n of ONE row m: 16-byte epilogue accesses (mask load,
+            // store) instead of four 4-byte ones per accumulator
+            if constexpr (kSwap)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_kc[j][kk], a_kc[i][kk], acc[i][j], 0, 0, 0);
+            else
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(AKC ? a_kc[i][kk] : a_oc[kk][i], BKC ? b_kc[j][kk] : b_oc[kk][j],
+                                                               acc[i][j], 0, 0, 0);
+          }
     }
   }
 
@@ -374,6 +383,83 @@ gemm_kernel(const Params p) {
 
   // epilogue.  MFMA C layout: row 4*kq + r, column lx of each 16x16 tile; tile (i, j) of the wave covers
   //   m = wm*MR*16 + (AKC ? 16*i + row : MR*row + i),   n = wn*NR*16 + (BKC ? 16*j + col : NR*col + j)
+  if constexpr (kSwap) {
+    // swapped operands: accumulator (i, j) of lane (lx, kq) holds C[m = 16 i + lx][n = 16 j + 4 kq + r]
+    const bool vec = (p.ldc & 3) == 0 && (p.N & 3) == 0 &&
+        ((((uintptr_t)p.C) | ((uintptr_t)p.mask) | ((uintptr_t)p.add) | ((uintptr_t)p.residual) | ((uintptr_t)p.bias) |
+          ((uintptr_t)p.partial)) & 15) == 0;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      const int m = m0 + wm * MR * 16 + 16 * i + lx;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int n = n0 + wn * NR * 16 + 16 * j + 4 * kq;
+        if (n >= p.N) continue;
+        f32x4_t v = acc[i][j];
+        if constexpr (SCATTER) {
+          // conv data gradient: column n = (py, px, ci) with ci fastest -- four consecutive n are four consecutive
+          // channels of ONE dX pixel when cin % 4 == 0: one scatter address, one 16-byte mask load and store
+          const bool quad = vec && (p.gb.d2.d & 3u) == 0;
+          if (quad) {
+            long long at;
+            if (!scatter_addr(p.ga, p.gb, p.es, p.eih, p.eiw, p.ldc, m, n, at)) continue;
+            if (p.mask) {
+              const f32x4_t mv = *reinterpret_cast<const f32x4_t*>(p.mask + at);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = mv[r] > 0.f ? v[r] : 0.f;
+            }
+            if (p.add) v += *reinterpret_cast<const f32x4_t*>(p.add + at);
+            *reinterpret_cast<f32x4_t*>(p.C + at) = v;
+          } else {
+            for (int r = 0; r < 4; ++r) {
+              long long at;
+              if (n + r >= p.N || !scatter_addr(p.ga, p.gb, p.es, p.eih, p.eiw, p.ldc, m, n + r, at)) continue;
+              float o = v[r];
+              if (p.mask && !(p.mask[at] > 0.f)) o = 0.f;
+              if (p.add) o += p.add[at];
+              p.C[at] = o;
+            }
+          }
+          continue;
+        }
+        if (p.partial) {
+          float* dst = p.partial + ((long long)blockIdx.z * p.M + m) * p.N + n;
+          if (vec) *reinterpret_cast<f32x4_t*>(dst) = v;
+          else { for (int r = 0; r < 4; ++r) if (n + r < p.N) dst[r] = v[r]; }
+          continue;
+        }
+        const long long at = (long long)m * p.ldc + n;
+        if (vec) {
+          if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + n);
+          if (p.residual) v += *reinterpret_cast<const f32x4_t*>(p.residual + at);
+          if (p.out_relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          if (p.mask) {
+            const f32x4_t mv = *reinterpret_cast<const f32x4_t*>(p.mask + at);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = mv[r] > 0.f ? v[r] : 0.f;
+          }
+          if (p.add) v += *reinterpret_cast<const f32x4_t*>(p.add + at);
+          *reinterpret_cast<f32x4_t*>(p.C + at) = v;
+        } else {
+          for (int r = 0; r < 4; ++r) {
+            if (n + r >= p.N) break;
+            float o = v[r];
+            if (p.bias) o += p.bias[n + r];
+            if (p.residual) o += p.residual[at + r];
+            if (p.out_relu && o < 0.f) o = 0.f;
+            if (p.mask && !(p.mask[at + r] > 0.f)) o = 0.f;
+            if (p.add) o += p.add[at + r];
+            p.C[at + r] = o;
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MR; ++i) {
 #pragma unroll
