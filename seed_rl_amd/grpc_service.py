@@ -677,13 +677,14 @@ class Client(object):
 # --------------------------------------------------------------------------------------------------------------------- #
 # The inference function of the learner behind the service (learner.py:339-405).
 # --------------------------------------------------------------------------------------------------------------------- #
-def bind_inference(server, fused_states, inference_batch_size, observation_shape, action_dtype=np.int64):
+def bind_inference(server, fused_states, inference_batch_size, observation_shape, action_dtype=np.int64, lock=None):
   """Binds `inference(env_ids, run_ids, env_outputs, raw_rewards) -> actions` with the reference's input signature
   (learner.py:339-349: env_id int32, run_id int64, EnvOutput(reward f32, done bool, observation uint8 [...], abandoned
   bool, episode_step int32), raw_reward f32 -- every spec with the leading inference_batch_size dimension), one function
   per FusedInferenceState (the reference's one-per-inference-device list: round-robin, learner.py:406-414).  A filled
   batch is packed into one pinned host buffer (`inference.request_layout`) + the pinned frames and handed to the
-  state's captured HIP graph: two H2D copies, one graph launch, one D2H of the actions."""
+  state's captured HIP graph: two H2D copies, one graph launch, one D2H of the actions.  `lock`: a lock that also orders
+  the caller's own submissions to the device (a training thread dequeuing completed unrolls) against inference calls."""
   import torch
   from seed_rl_amd import inference as inf, utils
   n = inference_batch_size
@@ -698,10 +699,10 @@ def bind_inference(server, fused_states, inference_batch_size, observation_shape
     lay = inf.request_layout(n)
     req_pinned = torch.zeros(lay['bytes'], dtype=torch.uint8).pin_memory()
     obs_pinned = torch.zeros((n,) + tuple(observation_shape), dtype=torch.uint8).pin_memory()
-    lock = threading.Lock()
+    st_lock = lock if lock is not None else threading.Lock()      # `lock`: one shared with a training thread (LearnerServer)
 
     def inference(env_ids, run_ids, env_outputs, raw_rewards, graphed=graphed, req_pinned=req_pinned,
-                  obs_pinned=obs_pinned, lock=lock, st=st):
+                  obs_pinned=obs_pinned, lock=st_lock, st=st):
       with lock:                                     # one batch at a time per device state
         inf.pack_request(n, env_ids, run_ids, env_outputs.reward, raw_rewards, env_outputs.done, env_outputs.abandoned,
                          env_outputs.episode_step, out=req_pinned.numpy())

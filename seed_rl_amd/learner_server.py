@@ -40,8 +40,7 @@ class LearnerServer(object):
                                                device=dev)
     self.lock = threading.Lock()
     self.server = grpc_service.Server(list(server_addresses))
-    fns = grpc_service.bind_inference(self.server, self.state, inference_batch_size, observation_shape)
-    self._wrap_with_lock(fns)
+    grpc_service.bind_inference(self.server, self.state, inference_batch_size, observation_shape, lock=self.lock)
     # static training unroll (the input of the train step, and of its HIP graph when graphed)
     T1 = unroll_length + 1
     z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
@@ -60,20 +59,6 @@ class LearnerServer(object):
     if hasattr(self.agent, 'frames_buffer') and len(shape) == 3 and shape[2] == 1 and dtype == torch.uint8:
       return self.agent.frames_buffer(T1, B)[3:].view((T1, B) + tuple(shape))
     return torch.zeros((T1, B) + tuple(shape), dtype=dtype, device=self.device)
-
-  def _wrap_with_lock(self, fns):
-    lock = self.lock
-    for i, f in enumerate(fns):
-      def locked(*args, _f=f):
-        with lock:
-          return _f(*args)
-      locked.__name__ = f.__name__
-      locked.input_signature, locked.output_signature = f.input_signature, f.output_signature
-      # rebind: the server holds _DynamicFn objects that captured `f`; swap their callable
-      for bucket in self.server._fns.values():         # pylint: disable=protected-access
-        for dyn in bucket['fn']:
-          if dyn.fn is f:
-            dyn.fn = locked
 
   def start(self):
     self.server.start()
