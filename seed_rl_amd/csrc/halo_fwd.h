@@ -68,7 +68,8 @@ halo_fwd_kernel(const FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w_floats = p.total_slices * NT * 256;
   float* w_lds = smem;
-  float* x_lds = smem + w_floats;
+  int* koff_tab = reinterpret_cast<int*>(smem + w_floats);      // [total_slices][4]: LDS offset of (slice, lane group kq)
+  float* x_lds = smem + w_floats + p.total_slices * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kq = lane >> 4, j = lane & 15;
 
@@ -97,6 +98,21 @@ halo_fwd_kernel(const FwdParams p) {
     }
   }
 
+  // per-slice operand offsets, once per workgroup: the slice loop then costs one ds_read instead of ~15 integer
+  // instructions (SQ counters of cfg3, r02c: 7.8 VALU + 2.3 SALU per MFMA in this kernel, matrix pipe 39 % busy)
+  for (int idx = tid; idx < p.total_slices * 4; idx += 256) {
+    const int sl = idx >> 2, q = idx & 3;
+    int ci = 0;
+    while (ci + 1 < p.ncls && sl >= p.cls[ci + 1].w_off) ++ci;
+    const FwdClass& c = p.cls[ci];
+    const int G = (sl - c.w_off) * 4 + q;
+    int tap = G >> p.cgs_shift;
+    const int cg = G & (p.cgs - 1);
+    if (tap > c.kh * c.kw - 1) tap = c.kh * c.kw - 1;     // padded k-groups carry zero weights
+    const int ty = tap / c.kw, tx = tap - ty * c.kw;
+    koff_tab[idx] = (ty * p.twp + tx) * p.xs + (cg << 2);
+  }
+
   // ---- tile pipeline (as halo_wgrad.h) ----
   constexpr int kXV = 7;
   const bool vec = p.in_dtype == 0 && (p.cin & 3) == 0 && (p.ld_in & 3) == 0;
@@ -107,23 +123,34 @@ halo_fwd_kernel(const FwdParams p) {
     y0 = band * p.TH;
     th = (y0 + p.TH <= p.oh_max) ? p.TH : p.oh_max - y0;
   };
-  auto load_tile = [&](int tile) {
-    if (!vec) return;
-    int n, y0, th; band_of(tile, n, y0, th);
-    const int c4 = p.cin >> 2;
-    const int per_row = p.twp * c4;
-    const int nvec = (p.thp - (p.TH - th) * p.stride) * per_row;
+  // A thread's staging vectors have the SAME tile coordinates in every tile: decode them once (two integer divisions
+  // per vector) instead of in every load and every store (four divisions per vector and tile).
+  int st_row[kXV], st_goff[kXV], st_lds[kXV];            // tile row; offset in the image relative to the band's first
+  {                                                      // row, or -1 (column outside the map); LDS offset
+    const int c4 = p.cin >> 2, per_row = p.twp * (c4 > 0 ? c4 : 1), rowf = p.twp * p.xs;
 #pragma unroll
     for (int u = 0; u < kXV; ++u) {
       const int v = tid + u * 256;
+      const int r = v / per_row, rem = v - r * per_row;
+      const int xcol = rem / (c4 > 0 ? c4 : 1), cq = rem - xcol * c4;
+      const int ix = xcol - p.tile_pad_l;
+      st_row[u] = r;
+      st_goff[u] = (ix >= 0 && ix < p.iw) ? ((r - p.tile_pad_t) * p.iw + ix) * p.ld_in + 4 * cq : -1;
+      st_lds[u] = r * rowf + xcol * p.xs + 4 * cq;
+    }
+  }
+  auto load_tile = [&](int tile) {
+    if (!vec) return;
+    int n, y0, th; band_of(tile, n, y0, th);
+    const int nrows = p.thp - (p.TH - th) * p.stride;
+    const int iy0 = y0 * p.stride - p.tile_pad_t;
+    const float* src = (const float*)p.in + ((long long)n * p.ih + y0 * p.stride) * p.iw * p.ld_in;
+#pragma unroll
+    for (int u = 0; u < kXV; ++u) {
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (v < nvec) {
-        const int r = v / per_row, rem = v - r * per_row;
-        const int xcol = rem / c4, cq = rem - xcol * c4;
-        const int iy = y0 * p.stride - p.tile_pad_t + r, ix = xcol - p.tile_pad_l;
-        if (iy >= 0 && iy < p.ih && ix >= 0 && ix < p.iw)
-          val = *reinterpret_cast<const float4*>((const float*)p.in + (((long long)n * p.ih + iy) * p.iw + ix) * p.ld_in + 4 * cq);
-      }
+      const int iy = iy0 + st_row[u];
+      if (st_row[u] < nrows && st_goff[u] != -1 && iy >= 0 && iy < p.ih)
+        val = *reinterpret_cast<const float4*>(src + st_goff[u]);
       xr[u] = val;
     }
   };
@@ -132,17 +159,12 @@ halo_fwd_kernel(const FwdParams p) {
     const int rowf = p.twp * p.xs;
     const int nrows = p.thp - (p.TH - th) * p.stride;
     if (vec) {
-      const int c4 = p.cin >> 2;
-      const int per_row = p.twp * c4;
 #pragma unroll
       for (int u = 0; u < kXV; ++u) {
-        const int v = tid + u * 256;
-        if (v < nrows * per_row) {
-          const int r = v / per_row, rem = v - r * per_row;
-          const int xcol = rem / c4, cq = rem - xcol * c4;
+        if (st_row[u] < nrows) {
           float4 val = xr[u];
           if (p.in_relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
-          *reinterpret_cast<float4*>(x_lds + r * rowf + xcol * p.xs + 4 * cq) = val;
+          *reinterpret_cast<float4*>(x_lds + st_lds[u]) = val;
         }
       }
     } else {                                           // u8 / odd channel counts: channels padded to 4*cgs with zeros
@@ -175,18 +197,18 @@ halo_fwd_kernel(const FwdParams p) {
       const FwdClass& c = p.cls[ci];
       const int thc = (y0 + th <= c.oh) ? th : c.oh - y0;      // this class may have fewer rows than the band
       if (thc <= 0) continue;
-      const int ntaps = c.kh * c.kw;
       const int npix = thc * c.ow;
       const int ntile16 = (npix + 15) >> 4;
       const float* wl = w_lds + c.w_off * NT * 256;
       for (int t0 = wave * MT; t0 < ntile16; t0 += 4 * MT) {
-        int xbase[MT];
+        int xbase[MT], opy[MT], opx[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           int pix = (t0 + m) * 16 + j;
           if (pix > npix - 1) pix = npix - 1;
           uint32_t py, px;
           c.d_ow.divmod((uint32_t)pix, py, px);
+          opy[m] = (int)py; opx[m] = (int)px;
           xbase[m] = (((int)py * p.stride + c.r_off) * p.twp + (int)px * p.stride + c.c_off) * p.xs;
         }
         f32x4_t acc[MT][NT];
@@ -194,13 +216,9 @@ halo_fwd_kernel(const FwdParams p) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const int* kt = koff_tab + c.w_off * 4 + kq;
         for (int s = 0; s < c.nslices; ++s) {
-          const int G = s * 4 + kq;
-          int tap = G >> p.cgs_shift;
-          const int cg = G & (p.cgs - 1);
-          if (tap > ntaps - 1) tap = ntaps - 1;             // padded k-groups carry zero weights
-          const int ty = tap / c.kw, tx = tap - ty * c.kw;
-          const int koff = (ty * p.twp + tx) * p.xs + (cg << 2);
+          const int koff = kt[s * 4];
           f32x4_t a[NT], b[MT];
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) a[nt] = *reinterpret_cast<const f32x4_t*>(wl + ((s * NT + nt) * 64 + lane) * 4);
@@ -219,11 +237,9 @@ halo_fwd_kernel(const FwdParams p) {
         for (int m = 0; m < MT; ++m) {
           const int pix = (t0 + m) * 16 + j;
           if (t0 + m >= ntile16 || pix >= npix) continue;
-          uint32_t py, px;
-          c.d_ow.divmod((uint32_t)pix, py, px);
-          const int oy = (y0 + (int)py) * p.so + c.oy0, ox = (int)px * p.so + c.ox0;
+          const int oy = (y0 + opy[m]) * p.so + c.oy0, ox = opx[m] * p.so + c.ox0;
           if (oy < 0 || oy >= p.OH || ox < 0 || ox >= p.OW) continue;
-          const long long obase = (((long long)n * p.OH + oy) * p.OW + ox) * p.ld_out;
+          const long long obase = (long long)n * p.OH * p.OW * p.ld_out + (oy * p.OW + ox) * p.ld_out;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const int co = nt * 16 + 4 * kq;
@@ -299,7 +315,7 @@ inline FwdPlan plan_fwd(FwdParams& p, const ClassSpec* cs, int ncls, bool u8) {
     const int thp = (th - 1) * p.stride + ext_h;
     const size_t x_b = (size_t)thp * p.twp * p.xs * 4;
     const size_t x_src = (size_t)thp * p.twp * p.cin * 4;                       // bytes prefetched in registers
-    if (!(w_b + x_b <= 64 * 1024 && (u8 || p.cin % 4 != 0 || x_src <= 7 * 256 * 16))) continue;
+    if (!(w_b + (size_t)total * 16 + x_b <= 64 * 1024 && (u8 || p.cin % 4 != 0 || x_src <= 7 * 256 * 16))) continue;
     const int nb = (oh_max + th - 1) / th, last = oh_max - (nb - 1) * th;
     const int t_full = (th * ow_max + 15) / 16, t_last = (last * ow_max + 15) / 16;
     for (int mt = 2; mt <= 5; ++mt) {
@@ -313,7 +329,7 @@ inline FwdPlan plan_fwd(FwdParams& p, const ClassSpec* cs, int ncls, bool u8) {
   if (!best_th) return pl;
   {
     const int thp = (best_th - 1) * p.stride + ext_h;
-    pl.lds = w_b + (size_t)thp * p.twp * p.xs * 4;
+    pl.lds = w_b + (size_t)total * 16 + (size_t)thp * p.twp * p.xs * 4;
   }
   const int th = best_th;
   pl.TH = th; p.TH = th; p.thp = (th - 1) * p.stride + ext_h;

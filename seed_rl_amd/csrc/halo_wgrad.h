@@ -100,23 +100,42 @@ halo_wgrad_kernel(const WgradParams p) {
     y0 = band * p.TH;
     th = (y0 + p.TH <= p.oh) ? p.TH : p.oh - y0;
   };
+  // A thread's staging vectors have the same tile coordinates in every tile: decode them once (the integer divisions
+  // used to run in every load and every store -- cfg3's SQ counters, r02c: ~5 VALU per MFMA, matrix pipe 41 % busy).
+  int st_row[kXV], st_goff[kXV], st_lds[kXV];          // tile row; image offset relative to the band's first input row
+  int dy_goff[kDV];                                    // (-1: column outside the map); LDS offset; dY offset in the band
+  {
+    const int c4 = p.cin >> 2, per_row = p.twp * (c4 > 0 ? c4 : 1), rowf = p.twp * p.xs;
+#pragma unroll
+    for (int u = 0; u < kXV; ++u) {
+      const int v = tid + u * 256;
+      const int r = v / per_row, rem = v - r * per_row;
+      const int xcol = rem / (c4 > 0 ? c4 : 1), cq = rem - xcol * c4;
+      const int ix = xcol - p.pad_l;
+      st_row[u] = r;
+      st_goff[u] = (ix >= 0 && ix < p.iw) ? ((r - p.pad_t) * p.iw + ix) * p.ld_in + 4 * cq : -1;
+      st_lds[u] = r * rowf + xcol * p.xs + 4 * cq;
+    }
+    const int d4 = coutp >> 2;
+#pragma unroll
+    for (int u = 0; u < kDV; ++u) {
+      const int v = tid + u * 256;
+      const int pix = v / d4, cq = v - pix * d4;
+      dy_goff[u] = pix * p.ld_out + 4 * cq;
+    }
+  }
   auto load_tile = [&](int tile) {
     int n, y0, th; band_of(tile, n, y0, th);
     if (vec) {
-      const int c4 = p.cin >> 2;
-      const int per_row = p.twp * c4;
-      const int nvec = ((th - 1) * p.stride + p.kh) * per_row;
+      const int nrows = (th - 1) * p.stride + p.kh;
+      const int iy0 = y0 * p.stride - p.pad_t;
+      const float* xsrc = (const float*)p.in + ((long long)n * p.ih + y0 * p.stride) * p.iw * p.ld_in;
 #pragma unroll
       for (int u = 0; u < kXV; ++u) {
-        const int v = tid + u * 256;
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (v < nvec) {
-          const int r = v / per_row, rem = v - r * per_row;
-          const int xcol = rem / c4, cq = rem - xcol * c4;
-          const int iy = y0 * p.stride - p.pad_t + r, ix = xcol - p.pad_l;
-          if (iy >= 0 && iy < p.ih && ix >= 0 && ix < p.iw)
-            val = *reinterpret_cast<const float4*>((const float*)p.in + (((long long)n * p.ih + iy) * p.iw + ix) * p.ld_in + 4 * cq);
-        }
+        const int iy = iy0 + st_row[u];
+        if (st_row[u] < nrows && st_goff[u] != -1 && iy >= 0 && iy < p.ih)
+          val = *reinterpret_cast<const float4*>(xsrc + st_goff[u]);
         xr[u] = val;
       }
     }
@@ -127,10 +146,7 @@ halo_wgrad_kernel(const WgradParams p) {
     for (int u = 0; u < kDV; ++u) {
       const int v = tid + u * 256;
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (v < nd) {
-        const int pix = v / c4, cq = v - pix * c4;
-        val = *reinterpret_cast<const float4*>(src + (long long)pix * p.ld_out + 4 * cq);
-      }
+      if (v < nd) val = *reinterpret_cast<const float4*>(src + dy_goff[u]);
       dr[u] = val;
     }
   };
@@ -139,17 +155,12 @@ halo_wgrad_kernel(const WgradParams p) {
     const int rowf = p.twp * p.xs;                     // floats per LDS row
     const int nrows = (th - 1) * p.stride + p.kh;
     if (vec) {
-      const int c4 = p.cin >> 2;
-      const int per_row = p.twp * c4;
 #pragma unroll
       for (int u = 0; u < kXV; ++u) {
-        const int v = tid + u * 256;
-        if (v < nrows * per_row) {
-          const int r = v / per_row, rem = v - r * per_row;
-          const int xcol = rem / c4, cq = rem - xcol * c4;
+        if (st_row[u] < nrows) {
           float4 val = xr[u];
           if (p.in_relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
-          *reinterpret_cast<float4*>(xs_lds + r * rowf + xcol * p.xs + 4 * cq) = val;
+          *reinterpret_cast<float4*>(xs_lds + st_lds[u]) = val;
         }
       }
     } else {                                           // first layer (u8 / odd channel counts): direct, synchronous
