@@ -62,7 +62,9 @@ struct FwdParams {
   int total_slices;
 };
 
-template <int MT, int NT>
+// DG = data-gradient epilogue (relu mask, skip-path add) instead of the forward one (bias, residual, relu): the two
+// never mix (conv.hip), and a compile-time split keeps the epilogue straight-line.
+template <int MT, int NT, bool DG, int XV>
 __global__ void __launch_bounds__(256)
 halo_fwd_kernel(const FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -112,9 +114,12 @@ halo_fwd_kernel(const FwdParams p) {
     const int ty = tap / c.kw, tx = tap - ty * c.kw;
     koff_tab[idx] = (ty * p.twp + tx) * p.xs + (cg << 2);
   }
+  // the X tile starts as zeros: halo columns outside the map are never written again (vector path)
+  for (int idx = tid; idx < p.thp * p.twp * p.xs; idx += 256) x_lds[idx] = 0.f;
 
   // ---- tile pipeline (as halo_wgrad.h) ----
-  constexpr int kXV = 7;
+  constexpr int kXV = XV;                                // float4 registers per thread for the prefetched X tile
+  constexpr int kNoRow = 0x7fff;
   const bool vec = p.in_dtype == 0 && (p.cin & 3) == 0 && (p.ld_in & 3) == 0;
   float4 xr[kXV];
   auto band_of = [&](int tile, int& n, int& y0, int& th) {
@@ -125,8 +130,9 @@ halo_fwd_kernel(const FwdParams p) {
   };
   // A thread's staging vectors have the SAME tile coordinates in every tile: decode them once (two integer divisions
   // per vector) instead of in every load and every store (four divisions per vector and tile).
-  int st_row[kXV], st_goff[kXV], st_lds[kXV];            // tile row; offset in the image relative to the band's first
-  {                                                      // row, or -1 (column outside the map); LDS offset
+  uint32_t st_pack[kXV];                                 // tile row (kNoRow: column outside the map) << 16 | LDS byte offset
+  uint32_t st_goff[kXV];                                 // byte offset from the tile's first input row
+  {
     const int c4 = p.cin >> 2, per_row = p.twp * (c4 > 0 ? c4 : 1), rowf = p.twp * p.xs;
 #pragma unroll
     for (int u = 0; u < kXV; ++u) {
@@ -134,23 +140,24 @@ halo_fwd_kernel(const FwdParams p) {
       const int r = v / per_row, rem = v - r * per_row;
       const int xcol = rem / (c4 > 0 ? c4 : 1), cq = rem - xcol * c4;
       const int ix = xcol - p.tile_pad_l;
-      st_row[u] = r;
-      st_goff[u] = (ix >= 0 && ix < p.iw) ? ((r - p.tile_pad_t) * p.iw + ix) * p.ld_in + 4 * cq : -1;
-      st_lds[u] = r * rowf + xcol * p.xs + 4 * cq;
+      const bool col_ok = ix >= 0 && ix < p.iw && r < kNoRow;
+      st_goff[u] = col_ok ? (uint32_t)((r * p.iw + ix) * p.ld_in + 4 * cq) * 4u : 0u;
+      st_pack[u] = (uint32_t)(col_ok ? r : kNoRow) << 16 | ((uint32_t)(r * rowf + xcol * p.xs + 4 * cq) * 4u & 0xffffu);
     }
   }
   auto load_tile = [&](int tile) {
     if (!vec) return;
     int n, y0, th; band_of(tile, n, y0, th);
     const int nrows = p.thp - (p.TH - th) * p.stride;
-    const int iy0 = y0 * p.stride - p.tile_pad_t;
-    const float* src = (const float*)p.in + ((long long)n * p.ih + y0 * p.stride) * p.iw * p.ld_in;
+    const int iy0 = y0 * p.stride - p.tile_pad_t;                    // image row of tile row 0 (may be negative)
+    const int lo = iy0 < 0 ? -iy0 : 0;
+    int hi = p.ih - iy0 < nrows ? p.ih - iy0 : nrows;
+    const uint32_t cnt = hi > lo ? (uint32_t)(hi - lo) : 0u;        // tile rows [lo, lo + cnt) lie inside the image
+    const char* src = reinterpret_cast<const char*>((const float*)p.in + ((long long)n * p.ih + iy0) * p.iw * p.ld_in);
 #pragma unroll
     for (int u = 0; u < kXV; ++u) {
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int iy = iy0 + st_row[u];
-      if (st_row[u] < nrows && st_goff[u] != -1 && iy >= 0 && iy < p.ih)
-        val = *reinterpret_cast<const float4*>(src + st_goff[u]);
+      if ((st_pack[u] >> 16) - (uint32_t)lo < cnt) val = *reinterpret_cast<const float4*>(src + st_goff[u]);
       xr[u] = val;
     }
   };
@@ -161,10 +168,10 @@ halo_fwd_kernel(const FwdParams p) {
     if (vec) {
 #pragma unroll
       for (int u = 0; u < kXV; ++u) {
-        if (st_row[u] < nrows) {
+        if (st_pack[u] < ((uint32_t)nrows << 16)) {
           float4 val = xr[u];
           if (p.in_relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
-          *reinterpret_cast<float4*>(x_lds + st_lds[u]) = val;
+          *reinterpret_cast<float4*>(reinterpret_cast<char*>(x_lds) + (st_pack[u] & 0xffffu)) = val;
         }
       }
     } else {                                           // u8 / odd channel counts: channels padded to 4*cgs with zeros
@@ -185,6 +192,22 @@ halo_fwd_kernel(const FwdParams p) {
     }
   };
 
+  // ---- epilogue operands: eA = residual (forward) or relu mask (data gradient), eB = skip-path add ----
+  // Small tiles fetch them BEFORE the k loop, so that their latency hides under the MFMAs; the big ones (registers)
+  // fetch them all at once after it.  Offsets are 32-bit from a per-image base.
+  constexpr bool kPrefetch = MT * NT <= 6;
+  const float* pA = DG ? p.mask : p.residual;
+  const float* pB = DG ? p.add : nullptr;
+  const float floor_v = (!DG && p.out_relu) ? 0.f : -INFINITY;
+  float4 bias_f[NT];
+  bool ch_ok[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = nt * 16 + 4 * kq;
+    ch_ok[nt] = co < p.cout;
+    bias_f[nt] = (!DG && p.bias && ch_ok[nt]) ? *reinterpret_cast<const float4*>(p.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
   if ((int)blockIdx.x < p.ntiles) load_tile(blockIdx.x);
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     int n, y0, th; band_of(tile, n, y0, th);
@@ -192,6 +215,10 @@ halo_fwd_kernel(const FwdParams p) {
     store_tile(tile);
     __syncthreads();
     if (tile + (int)gridDim.x < p.ntiles) load_tile(tile + gridDim.x);
+    const long long img = (long long)n * p.OH * p.OW * p.ld_out;
+    char* out_n = reinterpret_cast<char*>(p.out + img);
+    const char* a_n = reinterpret_cast<const char*>(pA + img);
+    const char* b_n = reinterpret_cast<const char*>(pB + img);
 
     for (int ci = 0; ci < p.ncls; ++ci) {
       const FwdClass& c = p.cls[ci];
@@ -201,16 +228,38 @@ halo_fwd_kernel(const FwdParams p) {
       const int ntile16 = (npix + 15) >> 4;
       const float* wl = w_lds + c.w_off * NT * 256;
       for (int t0 = wave * MT; t0 < ntile16; t0 += 4 * MT) {
-        int xbase[MT], opy[MT], opx[MT];
+        int xbase[MT];
+        uint32_t ooff[MT];                                 // byte offset of the lane's 4 channels in the output image
+        bool ook[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          int pix = (t0 + m) * 16 + j;
-          if (pix > npix - 1) pix = npix - 1;
+          const int pix0 = (t0 + m) * 16 + j;
+          const int pix = pix0 > npix - 1 ? npix - 1 : pix0;
           uint32_t py, px;
           c.d_ow.divmod((uint32_t)pix, py, px);
-          opy[m] = (int)py; opx[m] = (int)px;
           xbase[m] = (((int)py * p.stride + c.r_off) * p.twp + (int)px * p.stride + c.c_off) * p.xs;
+          const int oy = (y0 + (int)py) * p.so + c.oy0, ox = (int)px * p.so + c.ox0;
+          ook[m] = pix0 < npix && (uint32_t)oy < (uint32_t)p.OH && (uint32_t)ox < (uint32_t)p.OW;
+          ooff[m] = ook[m] ? (uint32_t)((oy * p.OW + ox) * p.ld_out + 4 * kq) * 4u : 0u;   // 0: a safe address for masked lanes
         }
+        float4 eA[MT][NT], eB[MT][NT];
+        auto fetch_extras = [&]() {
+          if (pA) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                eA[m][nt] = *reinterpret_cast<const float4*>(a_n + (ch_ok[nt] ? ooff[m] + nt * 64u : 0u));
+          }
+          if (DG && pB) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                eB[m][nt] = *reinterpret_cast<const float4*>(b_n + (ch_ok[nt] ? ooff[m] + nt * 64u : 0u));
+          }
+        };
+        if constexpr (kPrefetch) fetch_extras();
         f32x4_t acc[MT][NT];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -233,27 +282,24 @@ halo_fwd_kernel(const FwdParams p) {
                 acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt][kk], b[m][kk], acc[m][nt], 0, 0, 0);
         }
         // ---- epilogue: lane holds channels nt*16 + 4*kq + {0..3} of pixel (t0+m)*16 + j ----
+        if constexpr (!kPrefetch) fetch_extras();
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          const int pix = (t0 + m) * 16 + j;
-          if (t0 + m >= ntile16 || pix >= npix) continue;
-          const int oy = (y0 + opy[m]) * p.so + c.oy0, ox = opx[m] * p.so + c.ox0;
-          if (oy < 0 || oy >= p.OH || ox < 0 || ox >= p.OW) continue;
-          const long long obase = (long long)n * p.OH * p.OW * p.ld_out + (oy * p.OW + ox) * p.ld_out;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            const int co = nt * 16 + 4 * kq;
-            if (co >= p.cout) continue;
-            f32x4_t v = acc[m][nt];
-            if (p.bias) { const float4 bv = *reinterpret_cast<const float4*>(p.bias + co); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
-            if (p.residual) { const float4 rv = *reinterpret_cast<const float4*>(p.residual + obase + co); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
-            if (p.out_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-            if (p.mask) {
-              const float4 mv = *reinterpret_cast<const float4*>(p.mask + obase + co);
-              if (!(mv.x > 0.f)) v[0] = 0.f; if (!(mv.y > 0.f)) v[1] = 0.f; if (!(mv.z > 0.f)) v[2] = 0.f; if (!(mv.w > 0.f)) v[3] = 0.f;
+            float4 v = make_float4(acc[m][nt][0], acc[m][nt][1], acc[m][nt][2], acc[m][nt][3]);
+            if constexpr (!DG) {
+              v.x += bias_f[nt].x; v.y += bias_f[nt].y; v.z += bias_f[nt].z; v.w += bias_f[nt].w;
+              if (pA) { v.x += eA[m][nt].x; v.y += eA[m][nt].y; v.z += eA[m][nt].z; v.w += eA[m][nt].w; }
+              v.x = fmaxf(v.x, floor_v); v.y = fmaxf(v.y, floor_v); v.z = fmaxf(v.z, floor_v); v.w = fmaxf(v.w, floor_v);
+            } else {
+              if (pA) {
+                if (!(eA[m][nt].x > 0.f)) v.x = 0.f; if (!(eA[m][nt].y > 0.f)) v.y = 0.f;
+                if (!(eA[m][nt].z > 0.f)) v.z = 0.f; if (!(eA[m][nt].w > 0.f)) v.w = 0.f;
+              }
+              if (pB) { v.x += eB[m][nt].x; v.y += eB[m][nt].y; v.z += eB[m][nt].z; v.w += eB[m][nt].w; }
             }
-            if (p.add) { const float4 av = *reinterpret_cast<const float4*>(p.add + obase + co); v[0] += av.x; v[1] += av.y; v[2] += av.z; v[3] += av.w; }
-            *reinterpret_cast<float4*>(p.out + obase + co) = make_float4(v[0], v[1], v[2], v[3]);
+            if (ook[m] && ch_ok[nt]) *reinterpret_cast<float4*>(out_n + ooff[m] + nt * 64u) = v;
           }
         }
       }
@@ -262,7 +308,7 @@ halo_fwd_kernel(const FwdParams p) {
 }
 
 // ---- host side ------------------------------------------------------------------------------ //
-struct FwdPlan { bool ok; int MT, NT, TH, grid; size_t lds; };
+struct FwdPlan { bool ok; int MT, NT, TH, XV, grid; size_t lds; };
 
 // Describes one class before tiling.
 struct ClassSpec { int kh, kw, pad_t, pad_l, oh, ow, oy0, ox0, w_py, w_px; };
@@ -335,7 +381,11 @@ inline FwdPlan plan_fwd(FwdParams& p, const ClassSpec* cs, int ncls, bool u8) {
   pl.TH = th; p.TH = th; p.thp = (th - 1) * p.stride + ext_h;
   p.bands = (oh_max + th - 1) / th; p.ntiles = p.n_img * p.bands;
   pl.MT = best_mt;
-  int per_cu = (int)((160 * 1024) / pl.lds); if (per_cu > 3) per_cu = 3; if (per_cu < 1) per_cu = 1;
+  {                                                          // prefetch registers the band needs: 5 or 7 float4
+    const size_t x_src = (size_t)p.thp * p.twp * p.cin * 4;
+    pl.XV = (!u8 && p.cin % 4 == 0 && x_src <= 5 * 256 * 16) ? 5 : 7;
+  }
+  int per_cu = (int)((160 * 1024) / pl.lds); if (per_cu > 4) per_cu = 4; if (per_cu < 1) per_cu = 1;
   const long long mg = 256LL * per_cu;
   pl.grid = (int)(p.ntiles < mg ? p.ntiles : mg);
   pl.ok = true;
@@ -343,16 +393,37 @@ inline FwdPlan plan_fwd(FwdParams& p, const ClassSpec* cs, int ncls, bool u8) {
 }
 
 inline int launch_fwd_kernel(const FwdParams& p, const FwdPlan& pl, hipStream_t s) {
+  const bool dg = p.wmode == 1;
+  if (dg ? (p.bias || p.residual || p.out_relu) : (p.mask || p.add))
+    return fail(SEEDHIP_ERR_UNSUPPORTED, "halo_fwd: forward and data-gradient epilogues do not mix");
+  if ((long long)p.OH * p.OW * p.ld_out * 4 >= (1LL << 31) || (long long)(p.thp + p.ih) * p.iw * p.ld_in * 4 >= (1LL << 31))
+    return fail(SEEDHIP_ERR_UNSUPPORTED, "halo_fwd: one image exceeds the 32-bit offsets of the kernel");
+#define SEEDHIP_HF3(MT_, NT_, DG_, XV_)                                                                          \
+  {                                                                                                              \
+    if (pl.lds > 64 * 1024)                                                                                      \
+      (void)hipFuncSetAttribute((const void*)halo_fwd_kernel<MT_, NT_, DG_, XV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds); \
+    static int occ_lds = -1, occ = 0;            /* resident workgroups per CU of this variant at this LDS size */ \
+    if (occ_lds != (int)pl.lds) {                                                                                \
+      int o = 0;                                                                                                 \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)halo_fwd_kernel<MT_, NT_, DG_, XV_>, 256, pl.lds) != hipSuccess || o < 1) o = 1; \
+      occ = o; occ_lds = (int)pl.lds;                                                                            \
+    }                                                                                                            \
+    const long long mg = 256LL * occ;                                                                            \
+    const int grid = (int)(p.ntiles < mg ? p.ntiles : mg);                                                       \
+    hipLaunchKernelGGL((halo_fwd_kernel<MT_, NT_, DG_, XV_>), dim3(grid), dim3(256), pl.lds, s, p);              \
+    return check_launch("halo_fwd_kernel");                                                                      \
+  }
+#define SEEDHIP_HF2(MT_, NT_, DG_)                                                                               \
+  { if (pl.XV == 5) SEEDHIP_HF3(MT_, NT_, DG_, 5) else SEEDHIP_HF3(MT_, NT_, DG_, 7) }
 #define SEEDHIP_HF(MT_, NT_)                                                                                     \
   if (pl.MT == MT_ && pl.NT == NT_) {                                                                            \
-    if (pl.lds > 64 * 1024)                                                                                      \
-      (void)hipFuncSetAttribute((const void*)halo_fwd_kernel<MT_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds); \
-    hipLaunchKernelGGL((halo_fwd_kernel<MT_, NT_>), dim3(pl.grid), dim3(256), pl.lds, s, p);                     \
-    return check_launch("halo_fwd_kernel");                                                                      \
+    if (dg) SEEDHIP_HF2(MT_, NT_, true) else SEEDHIP_HF2(MT_, NT_, false)                                        \
   }
   SEEDHIP_HF(4, 1) SEEDHIP_HF(4, 2) SEEDHIP_HF(2, 1) SEEDHIP_HF(2, 2) SEEDHIP_HF(3, 1) SEEDHIP_HF(3, 2)
   SEEDHIP_HF(5, 1) SEEDHIP_HF(5, 2)
 #undef SEEDHIP_HF
+#undef SEEDHIP_HF2
+#undef SEEDHIP_HF3
   return fail(SEEDHIP_ERR_UNSUPPORTED, "halo_fwd: no kernel for MT=%d NT=%d", pl.MT, pl.NT);
 }
 
