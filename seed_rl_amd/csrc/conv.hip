@@ -76,6 +76,14 @@ bool gemm_fwd_ok(const seedhip_conv_geom* g) {
   // read whole and meets zero-filled B rows
   return (gemm_mode() & 1) && g->ld_in % 4 == 0 && g->ld_in >= (g->cin + 3) / 4 * 4 && g->cout % 4 == 0;
 }
+// 32 -> 32 3x3 layers on maps of >= 400 pixels (ImpalaDeep's five @18x24): bit 0 = forward through the halo kernel,
+// bit 1 = data gradient through the halo kernel, instead of the gather-GEMM.  Measured in the cfg3 step (r02d, HIP
+// graph, ms per step): 0 -> 25.0, 1 -> 24.3, 2 -> 25.4, 3 -> 24.7; stand-alone the gather-GEMM forward is the faster
+// one (0.52 vs 0.56 ms) -- with the ReLU'd input and the residual add of the real layers it is not.
+int halo_all() {
+  static const int v = getenv("SEEDHIP_HALO_ALL") ? atoi(getenv("SEEDHIP_HALO_ALL")) : 1;
+  return v;
+}
 bool gemm_dgrad_ok(const seedhip_conv_geom* g) { return (gemm_mode() & 2) && g->cout % 4 == 0 && g->ld_out % 4 == 0; }
 bool gemm_wgrad_ok(const seedhip_conv_geom* g) {
   return (gemm_mode() & 4) && g->ld_in % 4 == 0 && g->ld_in >= (g->cin + 3) / 4 * 4 && g->cout % 4 == 0 && g->ld_out % 4 == 0;
@@ -162,10 +170,9 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
     }
   }
   if ((gemm_mode() & 32) && !is_dense(geom) && in_dtype == kInF32 && al16(in) && al16(w) && al16(out) &&
-      (geom->cout >= conv_min_n() || (geom->cout == 32 && geom->cin == 32 && geom->stride == 1 && geom->oh * geom->ow >= 400))) {
-    // convs with >= 64 output channels on the GEMM core with a gathered A operand (gemm.h), and 32 -> 32 layers on
-    // maps of >= 400 pixels through the 4x1-wave 32-column tiles (3.71 -> 3.52 ms for ImpalaDeep's five @18x24 convs,
-    // which the halo kernel does not take).  Measured: the other 16 / 32-channel layers are faster on the halo kernels
+      (geom->cout >= conv_min_n() || (!(halo_all() & 1) && geom->cout == 32 && geom->cin == 32 && geom->stride == 1 && geom->oh * geom->ow >= 400))) {
+    // convs with >= 64 output channels on the GEMM core with a gathered A operand (gemm.h); the 16 / 32-channel
+    // layers are faster on the halo kernels (see halo_all() for the 32 -> 32 layers on large maps)
     gemm::Params gp;
     if (gemm::conv_fwd_setup(gp, geom)) {
       gp.A = (const float*)in; gp.a_relu = in_relu; gp.B = w; gp.C = out; gp.bias = bias; gp.residual = residual;
@@ -178,9 +185,9 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
   }
   {
     // small-kernel layers: input band staged once in LDS (halo_fwd.h).  Measured on MI355X
-    // (tools/bench_kernels.py): the halo forward wins for stride-1 layers with few input channels / small maps;
-    // the implicit-GEMM core stays ahead for stride 2 and for 32 channels on >= 400 pixels.
-    const bool halo_wins = geom->stride == 1 && geom->kh * geom->kw > 1 && !(geom->cin >= 32 && geom->oh * geom->ow >= 400);
+    // (tools/bench_kernels.py, cfg3 step): the halo forward wins for stride-1 layers; the implicit-GEMM core stays
+    // ahead for stride 2.
+    const bool halo_wins = geom->stride == 1 && geom->kh * geom->kw > 1 && ((halo_all() & 1) || !(geom->cin >= 32 && geom->oh * geom->ow >= 400));
     auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
     if (halo_wins && al16(out) && al16(bias) && al16(residual) && (in_dtype == kInU8Div255 || al16(in))) {
       halo::FwdParams hp;
@@ -268,7 +275,7 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
   // layers stay on the halo kernels (equal / 2.7x slower there)
   const int dgrad_n = geom->stride * geom->stride * geom->cin;
   if ((gemm_mode() & 64) && !is_dense(geom) && al16(dy) && al16(w) &&
-      (dgrad_n >= conv_min_n() || (dgrad_n == 32 && geom->ih * geom->iw >= 400 && geom->stride == 1))) {
+      (dgrad_n >= conv_min_n() || (!(halo_all() & 2) && dgrad_n == 32 && geom->ih * geom->iw >= 400 && geom->stride == 1))) {
     gemm::Params gp;
     if (gemm::conv_dgrad_setup(gp, geom)) {
       gp.A = dy; gp.B = w; gp.C = dx; gp.mask = relu_mask; gp.add = add;
