@@ -9,39 +9,62 @@
 // windows covering it -- no atomics, deterministic.
 // HBM-bound: forward reads 4C B/pixel in, writes (4C+C)/4 B/pixel; one thread owns 4 channels.
 #include "common.h"
+#include "igemm.h"
 #include "../../include/seedhip.h"
 
 namespace {
 
-struct PoolGeom { int n, ih, iw, c, oh, ow, pt, pl; };
+struct PoolGeom {
+  int n, ih, iw, c, oh, ow, pt, pl;
+  seedhip::FastDiv d_c4, d_ow, d_oh, d_iw, d_ih;         // 32-bit mul-hi decodes (the item counts fit 31 bits: make_geom)
+};
 
+// One thread owns 4 channels of one pooled pixel.  Interior windows (all 9 taps inside the map: all but the last row /
+// column of an even map) take the straight-line path: nine independent 16-byte loads in flight, no border tests.
 __global__ void __launch_bounds__(256)
 maxpool_fwd_kernel(PoolGeom g, const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ arg) {
-  const int c4 = g.c >> 2;
-  const long long total = (long long)g.n * g.oh * g.ow * c4;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int cq = (int)(i % c4);
-    long long r = i / c4;
-    const int ox = (int)(r % g.ow); r /= g.ow;
-    const int oy = (int)(r % g.oh);
-    const int n = (int)(r / g.oh);
-    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  const uint32_t c4 = (uint32_t)g.c >> 2;
+  const uint32_t total = (uint32_t)g.n * g.oh * g.ow * c4;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    uint32_t r, r2, cq, ox, oy, n;
+    g.d_c4.divmod(i, r, cq);
+    g.d_ow.divmod(r, r2, ox);
+    g.d_oh.divmod(r2, n, oy);
+    const float* img = x + (long long)n * g.ih * g.iw * g.c + 4 * cq;
+    const int iy0 = 2 * (int)oy - g.pt, ix0 = 2 * (int)ox - g.pl;
+    float4 best;
     int bi[4] = {0, 0, 0, 0};
+    if (iy0 >= 0 && iy0 + 2 < g.ih && ix0 >= 0 && ix0 + 2 < g.iw) {
+      const float* p0 = img + (iy0 * g.iw + ix0) * g.c;
+      float4 v[9];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = 2 * oy - g.pt + ky;
-      if (iy < 0 || iy >= g.ih) continue;
+      for (int w = 0; w < 9; ++w) v[w] = *reinterpret_cast<const float4*>(p0 + ((w / 3) * g.iw + (w % 3)) * g.c);
+      best = v[0];
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = 2 * ox - g.pl + kx;
-        if (ix < 0 || ix >= g.iw) continue;
-        const float4 v = *reinterpret_cast<const float4*>(x + (((long long)n * g.ih + iy) * g.iw + ix) * g.c + 4 * cq);
-        const int w = ky * 3 + kx;
-        if (v.x > best.x) { best.x = v.x; bi[0] = w; }
-        if (v.y > best.y) { best.y = v.y; bi[1] = w; }
-        if (v.z > best.z) { best.z = v.z; bi[2] = w; }
-        if (v.w > best.w) { best.w = v.w; bi[3] = w; }
+      for (int w = 1; w < 9; ++w) {
+        if (v[w].x > best.x) { best.x = v[w].x; bi[0] = w; }
+        if (v[w].y > best.y) { best.y = v[w].y; bi[1] = w; }
+        if (v[w].z > best.z) { best.z = v[w].z; bi[2] = w; }
+        if (v[w].w > best.w) { best.w = v[w].w; bi[3] = w; }
+      }
+    } else {
+      best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = iy0 + ky;
+        if (iy < 0 || iy >= g.ih) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = ix0 + kx;
+          if (ix < 0 || ix >= g.iw) continue;
+          const float4 v = *reinterpret_cast<const float4*>(img + (iy * g.iw + ix) * g.c);
+          const int w = ky * 3 + kx;
+          if (v.x > best.x) { best.x = v.x; bi[0] = w; }
+          if (v.y > best.y) { best.y = v.y; bi[1] = w; }
+          if (v.z > best.z) { best.z = v.z; bi[2] = w; }
+          if (v.w > best.w) { best.w = v.w; bi[3] = w; }
+        }
       }
     }
     reinterpret_cast<float4*>(y)[i] = best;
@@ -49,37 +72,45 @@ maxpool_fwd_kernel(PoolGeom g, const float* __restrict__ x, float* __restrict__ 
   }
 }
 
+// One thread owns 4 channels of one INPUT pixel and looks at the <= 4 windows that cover it (1, 2 or 4 by the parity
+// of its coordinates): the candidates' argmax bytes and gradients are requested together, then compared.
 __global__ void __launch_bounds__(256)
 maxpool_bwd_kernel(PoolGeom g, const float* __restrict__ dy, const uint8_t* __restrict__ arg, float* __restrict__ dx) {
-  const int c4 = g.c >> 2;
-  const long long total = (long long)g.n * g.ih * g.iw * c4;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int cq = (int)(i % c4);
-    long long r = i / c4;
-    const int ix = (int)(r % g.iw); r /= g.iw;
-    const int iy = (int)(r % g.ih);
-    const int n = (int)(r / g.ih);
+  const uint32_t c4 = (uint32_t)g.c >> 2;
+  const uint32_t total = (uint32_t)g.n * g.ih * g.iw * c4;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    uint32_t r, r2, cq, ix, iy, n;
+    g.d_c4.divmod(i, r, cq);
+    g.d_iw.divmod(r, r2, ix);
+    g.d_ih.divmod(r2, n, iy);
+    // windows oy with 2*oy - pt <= iy <= 2*oy - pt + 2: oy in {(y0-1)>>1, y0>>1} (one window when y0 is odd)
+    const int y0 = (int)iy + g.pt, x0 = (int)ix + g.pl;
+    const int oya = (y0 - 1) >> 1, oyb = y0 >> 1, oxa = (x0 - 1) >> 1, oxb = x0 >> 1;
+    const int oys[2] = {oya, oyb}, oxs[2] = {oxa, oxb};
+    const bool yok[2] = {oya >= 0 && oya < g.oh, oyb != oya && oyb < g.oh};
+    const bool xok[2] = {oxa >= 0 && oxa < g.ow, oxb != oxa && oxb < g.ow};
+    const uint32_t obase = n * (uint32_t)(g.oh * g.ow) * c4 + cq;
+    uint32_t av[4];
+    float4 dv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int a = t >> 1, b = t & 1;
+      const bool ok = yok[a] && xok[b];
+      const uint32_t o = ok ? obase + (uint32_t)(oys[a] * g.ow + oxs[b]) * c4 : obase;    // masked: any mapped element
+      av[t] = reinterpret_cast<const uint32_t*>(arg)[o];
+      dv[t] = reinterpret_cast<const float4*>(dy)[o];
+      if (!ok) av[t] = 0xFFFFFFFFu;                        // code 255 matches no tap
+    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    // windows oy with 2*oy - pt <= iy <= 2*oy - pt + 2
-    const int y0 = iy + g.pt, x0 = ix + g.pl;
-    for (int oy = (y0 - 1) >> 1; oy <= (y0 >> 1); ++oy) {       // (y0-2+1)/2 rounded up == (y0-1)>>1 for y0>=1
-      if (oy < 0 || oy >= g.oh) continue;
-      const int ky = y0 - 2 * oy;
-      if (ky < 0 || ky > 2) continue;
-      for (int ox = (x0 - 1) >> 1; ox <= (x0 >> 1); ++ox) {
-        if (ox < 0 || ox >= g.ow) continue;
-        const int kx = x0 - 2 * ox;
-        if (kx < 0 || kx > 2) continue;
-        const long long o = (((long long)n * g.oh + oy) * g.ow + ox) * c4 + cq;
-        const uchar4 a = reinterpret_cast<const uchar4*>(arg)[o];
-        const float4 d = reinterpret_cast<const float4*>(dy)[o];
-        const int w = ky * 3 + kx;
-        if (a.x == w) acc.x += d.x;
-        if (a.y == w) acc.y += d.y;
-        if (a.z == w) acc.z += d.z;
-        if (a.w == w) acc.w += d.w;
-      }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int a = t >> 1, b = t & 1;
+      const uint32_t w = (uint32_t)((y0 - 2 * oys[a]) * 3 + (x0 - 2 * oxs[b]));
+      if ((av[t] & 255u) == w) acc.x += dv[t].x;
+      if (((av[t] >> 8) & 255u) == w) acc.y += dv[t].y;
+      if (((av[t] >> 16) & 255u) == w) acc.z += dv[t].z;
+      if ((av[t] >> 24) == w) acc.w += dv[t].w;
     }
     reinterpret_cast<float4*>(dx)[i] = acc;
   }
@@ -91,6 +122,8 @@ int make_geom(int n, int ih, int iw, int c, PoolGeom* g, const char* what) {
   g->oh = (ih + 1) / 2; g->ow = (iw + 1) / 2;
   const int ph = (g->oh - 1) * 2 + 3 - ih, pw = (g->ow - 1) * 2 + 3 - iw;
   g->pt = (ph > 0 ? ph : 0) / 2; g->pl = (pw > 0 ? pw : 0) / 2;
+  SEEDHIP_REQUIRE((long long)n * ih * iw * c < (1LL << 31), "%s: tensor of 2^31 elements or more", what);
+  g->d_c4.init(c / 4); g->d_ow.init(g->ow); g->d_oh.init(g->oh); g->d_iw.init(iw); g->d_ih.init(ih);
   return SEEDHIP_OK;
 }
 int grid_for(long long n) { long long b = (n + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
