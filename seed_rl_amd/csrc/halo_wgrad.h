@@ -70,13 +70,11 @@ halo_wgrad_kernel(const WgradParams p) {
   constexpr int NQ = MTW / 4;
   const bool ilv = p.ilv != 0;
   int lane_off[MTW];
-  bool row_ok[MTW];
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt) {
     const bool quad = ilv && mt < 4 * NQ;
     const int R = quad ? (ms * MTW + (mt & ~3)) * 16 + 4 * i + (mt & 3) : (ms * MTW + mt) * 16 + i;
-    row_ok[mt] = R < p.rows;
-    const int Rc = row_ok[mt] ? R : 0;
+    const int Rc = R < p.rows ? R : 0;
     const int tap = Rc / p.cin, c = Rc - tap * p.cin;
     lane_off[mt] = ((tap / p.kw) * p.twp + (tap % p.kw)) * p.xs + c;
   }
@@ -221,19 +219,20 @@ halo_wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bsum[nt] += b[nt];
       }
+      // rows beyond p.rows (partial last tile of the first layer) read row 0's operand: finite values into
+      // accumulators that are never written out -- no predicate, no exec juggling around the LDS reads
       float a[MTW];
       if (ilv) {
 #pragma unroll
         for (int Q = 0; Q < NQ; ++Q) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (row_ok[4 * Q]) v = *reinterpret_cast<const float4*>(xb + lane_off[4 * Q]);   // rows % 4 == 0: all 4 or none
+          const float4 v = *reinterpret_cast<const float4*>(xb + lane_off[4 * Q]);
           a[4 * Q] = v.x; a[4 * Q + 1] = v.y; a[4 * Q + 2] = v.z; a[4 * Q + 3] = v.w;
         }
 #pragma unroll
-        for (int mt = 4 * NQ; mt < MTW; ++mt) a[mt] = row_ok[mt] ? xb[lane_off[mt]] : 0.f;
+        for (int mt = 4 * NQ; mt < MTW; ++mt) a[mt] = xb[lane_off[mt]];
       } else {
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) a[mt] = row_ok[mt] ? xb[lane_off[mt]] : 0.f;
+        for (int mt = 0; mt < MTW; ++mt) a[mt] = xb[lane_off[mt]];
       }
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt)
