@@ -51,7 +51,7 @@ struct WgradParams {
   FastDiv d_ow;
 };
 
-template <int MTW, int NT, int MSPLIT>
+template <int MTW, int NT, int MSPLIT, bool ILV>         // ILV = p.ilv, compile-time: no branches inside the pixel loop
 __global__ void __launch_bounds__(256)
 halo_wgrad_kernel(const WgradParams p) {
   constexpr int PP = 4 / MSPLIT;                      // pixel partitions
@@ -68,7 +68,7 @@ halo_wgrad_kernel(const WgradParams p) {
   // 4*NQ row-tiles form quads, tile e of quad Q owns rows base + 64 Q + 4 i + e and lane i reads them as one float4;
   // lane_off[4Q] is that quad's offset.  The remaining tiles (and everything when !p.ilv) own rows base + 16 mt + i.
   constexpr int NQ = MTW / 4;
-  const bool ilv = p.ilv != 0;
+  constexpr bool ilv = ILV;
   int lane_off[MTW];
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt) {
@@ -192,16 +192,16 @@ halo_wgrad_kernel(const WgradParams p) {
     store_tile(tile);
     __syncthreads();
     if (tile + (int)gridDim.x < p.ntiles) load_tile(tile + gridDim.x);
-    // ---- MFMA over this wave's pixel groups ----
+    // ---- MFMA over this wave's pixel groups (a two-register-set prefetch of the next group's operands was measured
+    //      slower, r02d: 32->32 @18x24 0.46 -> 0.61 ms) ----
     const int npix = th * p.ow;
     const int G = (npix + 3) >> 2;
-    for (int g = pp; g < G; g += PP) {
+    auto load_ab = [&](int g, float (&a)[MTW], float (&b)[NT]) {
       const int pix = 4 * g + kq;
       const bool pv = pix < npix;                      // tail group of a band whose pixel count is not 4k
       uint32_t py, px;
       p.d_ow.divmod((uint32_t)(pv ? pix : 0), py, px);
       const float* xb = xs_lds + ((int)py * p.stride * p.twp + (int)px * p.stride) * p.xs;
-      float b[NT];
       if (ilv) {                                         // NT consecutive channels NT*i .. : one read
         if constexpr (NT == 1) {
           b[0] = pv ? dy_lds[pix * coutp + i] : 0.f;
@@ -215,13 +215,8 @@ halo_wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) b[nt] = pv ? dy_lds[pix * coutp + nt * 16 + i] : 0.f;
       }
-      if (ms == 0) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bsum[nt] += b[nt];
-      }
       // rows beyond p.rows (partial last tile of the first layer) read row 0's operand: finite values into
       // accumulators that are never written out -- no predicate, no exec juggling around the LDS reads
-      float a[MTW];
       if (ilv) {
 #pragma unroll
         for (int Q = 0; Q < NQ; ++Q) {
@@ -234,11 +229,22 @@ halo_wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) a[mt] = xb[lane_off[mt]];
       }
+    };
+    auto mma = [&](const float (&a)[MTW], const float (&b)[NT]) {
+      if (ms == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bsum[nt] += b[nt];
+      }
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    };
+    for (int g = pp; g < G; g += PP) {
+      float a[MTW], b[NT];
+      load_ab(g, a, b);
+      mma(a, b);
     }
   }
 
@@ -350,9 +356,11 @@ inline int launch_wgrad(const seedhip_conv_geom* g, const WgradPlan& pl, const v
 #define SEEDHIP_HALO_LAUNCH(MTW_, NT_, MS_)                                                                        \
   do {                                                                                                             \
     if (pl.lds > 64 * 1024)                                                                                        \
-      (void)hipFuncSetAttribute((const void*)halo_wgrad_kernel<MTW_, NT_, MS_>,                                    \
+      (void)hipFuncSetAttribute(p.ilv ? (const void*)halo_wgrad_kernel<MTW_, NT_, MS_, true>                       \
+                                      : (const void*)halo_wgrad_kernel<MTW_, NT_, MS_, false>,                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);                          \
-    hipLaunchKernelGGL((halo_wgrad_kernel<MTW_, NT_, MS_>), dim3(pl.grid), dim3(256), pl.lds, s, p);               \
+    if (p.ilv) hipLaunchKernelGGL((halo_wgrad_kernel<MTW_, NT_, MS_, true>), dim3(pl.grid), dim3(256), pl.lds, s, p);  \
+    else hipLaunchKernelGGL((halo_wgrad_kernel<MTW_, NT_, MS_, false>), dim3(pl.grid), dim3(256), pl.lds, s, p);   \
   } while (0)
 #define SEEDHIP_HALO_CASE(MTW_, NT_, MS_) if (pl.MTW == MTW_ && pl.NT == NT_ && pl.MSPLIT == MS_) { SEEDHIP_HALO_LAUNCH(MTW_, NT_, MS_); launched = true; }
   bool launched = false;
