@@ -9,8 +9,11 @@
 // (6.3 ms measured) around 32 GFLOP of arithmetic.  Fused, the step reads the uint8 frames (111 MB) and writes /
 // reads only the pooled tensor (0.6 GB) and the argmax bytes (0.15 GB).
 //
-// The conv has K = 27 and 16 output channels: too thin for the matrix cores to matter, so both kernels are plain
-// fp32 FMA on the vector ALU (v_pk_fma_f32: two channels per instruction; FMA chain in (ky, kx, c) order):
+// Two generations live here.  The kernels that run (convpool_fwd_mfma_kernel, convpool_bwd_mfma_kernel, further down) put
+// the conv on the matrix pipes -- exact bf16x3 forward, fp32 MFMA weight gradient fed by a deterministic scatter of the
+// pool gradient -- at 0.43 + 0.80 ms (T=20, B=256).  The round-1 kernels below them in history and above them in this
+// file (SEEDHIP_CONVPOOL_MFMA=0, kept for A/B runs: 1.09 + 1.69 ms) are plain fp32 FMA on the vector ALU
+// (v_pk_fma_f32: two channels per instruction; FMA chain in (ky, kx, c) order):
 //   * a workgroup walks (image, band of 4 pooled rows) tiles; the band's input rows + halo are staged in LDS as fp32
 //     (x/255, zero padding, channels padded to 4 so that a pixel's 3x3x3 window is nine 16-byte reads);
 //   * wave w owns output channels 4w..4w+3 and keeps their 27 x 4 weights (forward) or 27 x 4 gradient accumulators
