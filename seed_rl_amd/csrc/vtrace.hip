@@ -24,13 +24,24 @@ template <int V> __device__ __forceinline__ void ld(const float* p, float (&o)[V
   if constexpr (V == 4) { float4 v = *reinterpret_cast<const float4*>(p); o[0]=v.x; o[1]=v.y; o[2]=v.z; o[3]=v.w; }
   else o[0] = *p;
 }
-template <int V> __device__ __forceinline__ void st(float* p, const float (&o)[V]) {
-  if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
-  else *p = o[0];
+template <int V, bool NT = false> __device__ __forceinline__ void st(float* p, const float (&o)[V]) {
+  if constexpr (V == 4) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = {o[0], o[1], o[2], o[3]};
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p));      // written once, read by a later kernel
+    else *reinterpret_cast<f4*>(p) = v;
+  } else *p = o[0];
+}
+template <int V, bool NT> __device__ __forceinline__ void ldx(const float* p, float (&o)[V]) {
+  if constexpr (V == 4 && NT) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  } else ld<V>(p, o);
 }
 
 // U = timesteps whose loads are in flight together.
-template <int V, int U>
+template <int V, int U, int NT = 0>                     // NT bit 0: non-temporal stores, bit 1: non-temporal loads
 __global__ void __launch_bounds__(256)
 vtrace_scan_kernel(const float* __restrict__ tgt, const float* __restrict__ beh,
                    const float* __restrict__ disc, const float* __restrict__ rew,
@@ -54,8 +65,8 @@ vtrace_scan_kernel(const float* __restrict__ tgt, const float* __restrict__ beh,
     for (int u = 0; u < U; ++u) {
       if (u < n) {
         const long long off = (long long)(t - u) * B + col;
-        ld<V>(tgt + off, a_t[u]); ld<V>(beh + off, a_b[u]); ld<V>(disc + off, a_d[u]);
-        ld<V>(rew + off, a_r[u]); ld<V>(val + off, a_v[u]);
+        ldx<V, (NT & 2) != 0>(tgt + off, a_t[u]); ldx<V, (NT & 2) != 0>(beh + off, a_b[u]); ldx<V, (NT & 2) != 0>(disc + off, a_d[u]);
+        ldx<V, (NT & 2) != 0>(rew + off, a_r[u]); ldx<V, (NT & 2) != 0>(val + off, a_v[u]);
       }
     }
 #pragma unroll
@@ -77,7 +88,7 @@ vtrace_scan_kernel(const float* __restrict__ tgt, const float* __restrict__ beh,
           o_vs[i] = vs; vs_next[i] = vs; v_next[i] = v;
         }
         const long long off = (long long)(t - u) * B + col;
-        st<V>(vs_out + off, o_vs); st<V>(pg_out + off, o_pg);
+        st<V, (NT & 1) != 0>(vs_out + off, o_vs); st<V, (NT & 1) != 0>(pg_out + off, o_pg);
       }
     }
     t -= n;
@@ -104,10 +115,30 @@ extern "C" int seedhip_vtrace_from_importance_weights(
   if (vec4) {
     const long long nthr = B / 4;
     const int block = 256;
-    hipLaunchKernelGGL((vtrace_scan_kernel<4, 2>), dim3(seedhip::cdiv(nthr, block)), dim3(block), 0, s,
-                       target_action_log_probs, behaviour_action_log_probs, discounts, rewards, values,
-                       bootstrap_value, clip_rho_threshold, clip_pg_rho_threshold, lambda_, T, B, vs,
-                       pg_advantages);
+    // Cache policy by working set (measured on MI355X, tools/bench_vtrace.py, GB/s of the 28 B per element):
+    //   <= 0.3 GB (B <= 2^19; the 256 MB infinity cache still helps): plain loads / stores, one step in flight
+    //                                                     4.8 / 6.3 / 6.7 TB/s at 2^17 / 2^18 / 2^19 (non-temporal: 3.4 / 5.2 / 6.0)
+    //   0.6-1.2 GB (B = 2^20, 2^21): non-temporal loads AND stores, one step in flight     5.8-6.1 / 5.3 TB/s (plain: 5.1-5.2)
+    //   2.3 GB (B = 2^22): non-temporal, two steps in flight                               4.8-5.0 TB/s (plain: 4.6)
+    static const int forced = getenv("SEEDHIP_VTRACE_VARIANT") ? atoi(getenv("SEEDHIP_VTRACE_VARIANT")) : -1;
+    const long long bytes = 28LL * T * B;
+    const int variant = forced >= 0 ? forced : (bytes <= (400LL << 20) ? 6 : (bytes <= (1500LL << 20) ? 7 : 4));
+#define SEEDHIP_VT(U_, NT_)                                                                                        \
+    hipLaunchKernelGGL((vtrace_scan_kernel<4, U_, NT_>), dim3(seedhip::cdiv(nthr, block)), dim3(block), 0, s,      \
+                       target_action_log_probs, behaviour_action_log_probs, discounts, rewards, values,           \
+                       bootstrap_value, clip_rho_threshold, clip_pg_rho_threshold, lambda_, T, B, vs,             \
+                       pg_advantages)
+    switch (variant) {
+      case 1: SEEDHIP_VT(4, 0); break;
+      case 2: SEEDHIP_VT(2, 1); break;
+      case 3: SEEDHIP_VT(4, 1); break;
+      case 4: SEEDHIP_VT(2, 3); break;
+      case 5: SEEDHIP_VT(4, 3); break;
+      case 6: SEEDHIP_VT(1, 0); break;
+      case 7: SEEDHIP_VT(1, 3); break;
+      default: SEEDHIP_VT(2, 0); break;
+    }
+#undef SEEDHIP_VT
   } else {
     // Small B: spread the columns over as many CUs as possible (64-lane blocks).
     const int block = (B >= (1 << 15)) ? 256 : 64;

@@ -56,7 +56,10 @@ def test_vtrace_reference_golden(device):
   np.testing.assert_allclose(pg, gt.pg_advantages, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize('T,B', [(1, 1), (3, 7), (20, 512), (20, 4096), (5, 65536), (20, 262144), (100, 33)])
+# the float4 path picks its cache policy by working set (csrc/vtrace.hip): (20, 262144) = 147 MB plain loads / stores,
+# (100, 262144) = 0.73 GB non-temporal with one step in flight, (240, 262144) = 1.76 GB non-temporal with two
+@pytest.mark.parametrize('T,B', [(1, 1), (3, 7), (20, 512), (20, 4096), (5, 65536), (20, 262144), (100, 33),
+                                 (100, 262144), (240, 262144)])
 def test_vtrace_shapes(device, T, B):
   inp = synth.vtrace_inputs(3, T, B, 4) if B <= 4096 else None
   if inp is None:
