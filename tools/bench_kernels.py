@@ -89,6 +89,11 @@ def main():
                         ('r2d2 recurrent 512->2048', 256, 512, 2048), ('deep recurrent 256->1024', 256, 256, 1024),
                         ('inference fc 2592->256', 64, 2592, 256)]:
       bench_conv(nm, n, 1, 1, k, 1, 1, 'valid', c)
+  if a.what in ('r2d2',):                                   # the Dense-layer GEMMs of the cfg5 step (81 and 40 steps x B=256)
+    for nm, n, k, c in [('r2d2 fc 3136->512 M=20736', 20736, 3136, 512), ('r2d2 fc 3136->512 M=10240', 10240, 3136, 512),
+                        ('r2d2 lstm-x 532->2048 M=20736', 20736, 532, 2048), ('r2d2 lstm-x 532->2048 M=10240', 10240, 532, 2048),
+                        ('r2d2 heads 512->512 M=20736', 20736, 512, 512)]:
+      bench_conv(nm, n, 1, 1, k, 1, 1, 'valid', c)
   if a.what in ('deep',):
     n = 21 * 256
     bench_conv('deep s0 3x3 16->16 @36x48', n, 36, 48, 16, 3, 1, 'same', 16)
