@@ -357,19 +357,25 @@ inline FwdPlan plan_fwd(FwdParams& p, const ClassSpec* cs, int ncls, bool u8) {
   int best_th = 0, best_mt = 0;
   double best_u = -1.0;
   const int th_hi = (320 + ow_max - 1) / ow_max < oh_max ? (320 + ow_max - 1) / ow_max : oh_max;
-  for (int th = 1; th <= th_hi; ++th) {
-    const int thp = (th - 1) * p.stride + ext_h;
-    const size_t x_b = (size_t)thp * p.twp * p.xs * 4;
-    const size_t x_src = (size_t)thp * p.twp * p.cin * 4;                       // bytes prefetched in registers
-    if (!(w_b + (size_t)total * 16 + x_b <= 64 * 1024 && (u8 || p.cin % 4 != 0 || x_src <= 7 * 256 * 16))) continue;
-    const int nb = (oh_max + th - 1) / th, last = oh_max - (nb - 1) * th;
-    const int t_full = (th * ow_max + 15) / 16, t_last = (last * ow_max + 15) / 16;
-    for (int mt = 2; mt <= 5; ++mt) {
-      const int round = 4 * mt;
-      const double slots = (double)(nb - 1) * ((t_full + round - 1) / round) * round + (double)((t_last + round - 1) / round) * round;
-      double u = ((double)(nb - 1) * t_full + t_last) / slots;
-      u *= 1.0 - 0.02 * nb / (double)oh_max;                                     // fewer bands: fewer barriers / halo re-reads
-      if (u > best_u + 1e-9) { best_u = u; best_th = th; best_mt = mt; }
+  // two budgets: the standard one (64 KB of LDS: 2+ workgroups per CU whatever else; 7 prefetch vectors), and -- only
+  // when that leaves more than a fifth of the MFMA tile slots empty (32 input channels on 48-pixel rows: bands of 2
+  // rows, 6 of 8 slots, 2x halo re-reads) -- a larger one (80 KB, 10 vectors)
+  for (int tier = 0; tier < 2 && best_u < 0.8; ++tier) {
+    const size_t lds_cap = tier ? 80 * 1024 : 64 * 1024, src_cap = (size_t)(tier ? 10 : 7) * 256 * 16;
+    for (int th = 1; th <= th_hi; ++th) {
+      const int thp = (th - 1) * p.stride + ext_h;
+      const size_t x_b = (size_t)thp * p.twp * p.xs * 4;
+      const size_t x_src = (size_t)thp * p.twp * p.cin * 4;                     // bytes prefetched in registers
+      if (!(w_b + (size_t)total * 16 + x_b <= lds_cap && x_b < 65536 && (u8 || p.cin % 4 != 0 || x_src <= src_cap))) continue;
+      const int nb = (oh_max + th - 1) / th, last = oh_max - (nb - 1) * th;
+      const int t_full = (th * ow_max + 15) / 16, t_last = (last * ow_max + 15) / 16;
+      for (int mt = 2; mt <= 5; ++mt) {
+        const int round = 4 * mt;
+        const double slots = (double)(nb - 1) * ((t_full + round - 1) / round) * round + (double)((t_last + round - 1) / round) * round;
+        double u = ((double)(nb - 1) * t_full + t_last) / slots;
+        u *= 1.0 - 0.02 * nb / (double)oh_max;                                   // fewer bands: fewer barriers / halo re-reads
+        if (u > best_u + 1e-9) { best_u = u; best_th = th; best_mt = mt; }
+      }
     }
   }
   if (!best_th) return pl;
@@ -383,7 +389,7 @@ inline FwdPlan plan_fwd(FwdParams& p, const ClassSpec* cs, int ncls, bool u8) {
   pl.MT = best_mt;
   {                                                          // prefetch registers the band needs: 5 or 7 float4
     const size_t x_src = (size_t)p.thp * p.twp * p.cin * 4;
-    pl.XV = (!u8 && p.cin % 4 == 0 && x_src <= 5 * 256 * 16) ? 5 : 7;
+    pl.XV = (!u8 && p.cin % 4 == 0 && x_src <= 5 * 256 * 16) ? 5 : (x_src <= 7 * 256 * 16 || u8 || p.cin % 4 != 0 ? 7 : 10);
   }
   int per_cu = (int)((160 * 1024) / pl.lds); if (per_cu > 4) per_cu = 4; if (per_cu < 1) per_cu = 1;
   const long long mg = 256LL * per_cu;
@@ -414,7 +420,7 @@ inline int launch_fwd_kernel(const FwdParams& p, const FwdPlan& pl, hipStream_t 
     return check_launch("halo_fwd_kernel");                                                                      \
   }
 #define SEEDHIP_HF2(MT_, NT_, DG_)                                                                               \
-  { if (pl.XV == 5) SEEDHIP_HF3(MT_, NT_, DG_, 5) else SEEDHIP_HF3(MT_, NT_, DG_, 7) }
+  { if (pl.XV == 5) SEEDHIP_HF3(MT_, NT_, DG_, 5) else if (pl.XV == 7) SEEDHIP_HF3(MT_, NT_, DG_, 7) else SEEDHIP_HF3(MT_, NT_, DG_, 10) }
 #define SEEDHIP_HF(MT_, NT_)                                                                                     \
   if (pl.MT == MT_ && pl.NT == NT_) {                                                                            \
     if (dg) SEEDHIP_HF2(MT_, NT_, true) else SEEDHIP_HF2(MT_, NT_, false)                                        \
