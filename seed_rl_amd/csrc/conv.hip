@@ -77,11 +77,12 @@ bool gemm_fwd_ok(const seedhip_conv_geom* g) {
   return (gemm_mode() & 1) && g->ld_in % 4 == 0 && g->ld_in >= (g->cin + 3) / 4 * 4 && g->cout % 4 == 0;
 }
 // 32 -> 32 3x3 layers on maps of >= 400 pixels (ImpalaDeep's five @18x24): bit 0 = forward through the halo kernel,
-// bit 1 = data gradient through the halo kernel, instead of the gather-GEMM.  Measured in the cfg3 step (r02d, HIP
-// graph, ms per step): 0 -> 25.0, 1 -> 24.3, 2 -> 25.4, 3 -> 24.7; stand-alone the gather-GEMM forward is the faster
-// one (0.52 vs 0.56 ms) -- with the ReLU'd input and the residual add of the real layers it is not.
+// bit 1 = data gradient through the halo kernel, instead of the gather-GEMM.  Measured in the cfg3 step (HIP graph, ms
+// per step): r02d before the second tiling budget of halo_fwd.h: 0 -> 25.0, 1 -> 24.3, 2 -> 25.4, 3 -> 24.7; with it:
+// 1 -> 21.25, 3 -> 21.17.  Stand-alone the gather-GEMM forward used to be the faster one (0.52 vs 0.56 ms) -- with the
+// ReLU'd input and the residual add of the real layers it was not; the halo forward now takes 0.47 ms.
 int halo_all() {
-  static const int v = getenv("SEEDHIP_HALO_ALL") ? atoi(getenv("SEEDHIP_HALO_ALL")) : 1;
+  static const int v = getenv("SEEDHIP_HALO_ALL") ? atoi(getenv("SEEDHIP_HALO_ALL")) : 3;
   return v;
 }
 bool gemm_dgrad_ok(const seedhip_conv_geom* g) { return (gemm_mode() & 2) && g->cout % 4 == 0 && g->ld_out % 4 == 0; }
