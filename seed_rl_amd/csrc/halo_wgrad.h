@@ -89,7 +89,8 @@ halo_wgrad_kernel(const WgradParams p) {
 
   // Software pipeline over tiles: the global loads of tile i+1 (float4 per lane, kept in registers)
   // are in flight while tile i is reduced out of LDS.
-  constexpr int kXV = 7, kDV = 3;                      // float4 registers per thread for the X / dY tile
+  constexpr int kXV = 7, kDV = NT <= 2 ? 6 : 3;        // float4 registers per thread for the X / dY tile (2 workgroups per
+                                                       // CU: the budget is 256 registers, 144 of them accumulators at NT = 4)
   const bool vec = p.in_dtype == 0 && (p.cin & 3) == 0 && (p.ld_in & 3) == 0;
   float4 xr[kXV], dr[kDV];
   auto band_of = [&](int tile, int& n, int& y0, int& th) {
@@ -319,11 +320,28 @@ inline WgradPlan plan_wgrad(const seedhip_conv_geom* g) {
   const int twp = (g->ow - 1) * g->stride + g->kw;
   int th = 256 / g->ow; if (th < 1) th = 1; if (th > g->oh) th = g->oh;
   size_t red_b = (size_t)msplit * pl.MTW * 16 * g->cout * 4;
-  for (;; --th) {
-    const size_t x_b = (size_t)((th - 1) * g->stride + g->kh) * twp * g->cin * 4, dy_b = (size_t)th * g->ow * g->cout * 4;
+  auto need_of = [&](int t, bool& fits_regs) {
+    const size_t x_b = (size_t)((t - 1) * g->stride + g->kh) * twp * g->cin * 4, dy_b = (size_t)t * g->ow * g->cout * 4;
     size_t need = x_b + dy_b + 16; if (need < red_b) need = red_b;
-    const bool fits_regs = (g->cin % 4 != 0 || x_b <= 7 * 256 * 16) && dy_b <= 3 * 256 * 16;   // kXV / kDV
-    if ((need <= 64 * 1024 && fits_regs) || th == 1) { pl.lds = need; if (!fits_regs) return pl; break; }
+    fits_regs = (g->cin % 4 != 0 || x_b <= 7 * 256 * 16) && dy_b <= (size_t)(pl.NT <= 2 ? 6 : 3) * 256 * 16;   // kXV / kDV
+    return need;
+  };
+  for (;; --th) {
+    bool fits_regs;
+    const size_t need = need_of(th, fits_regs);
+    if ((need <= 64 * 1024 && fits_regs) || th == 1) { if (!fits_regs) return pl; break; }
+  }
+  // th is the tallest band that fits; among the heights down to 70 % of it take the one that wastes the fewest rows in
+  // the last band (36 rows: 9 x 4, not 7 x 5 + 1 -- measured 0.55 vs 0.60 ms; 9 rows: one band of 9, not 8 + 1)
+  {
+    int best = th, best_waste = ((g->oh + th - 1) / th) * th - g->oh;
+    for (int t = th - 1; t >= 1 && 10 * t >= 7 * th; --t) {
+      const int waste = ((g->oh + t - 1) / t) * t - g->oh;
+      if (waste < best_waste) { best = t; best_waste = waste; }
+    }
+    th = best;
+    bool fits_regs;
+    pl.lds = need_of(th, fits_regs);
   }
   if (pl.lds > 150 * 1024) return pl;
   pl.TH = th;
@@ -351,6 +369,15 @@ inline int launch_wgrad(const seedhip_conv_geom* g, const WgradPlan& pl, const v
   p.ilv = (ilv_on && in_dtype == 0 && g->cin % 4 == 0 && g->ld_in % 4 == 0) ? 1 : 0;
   p.twp = (g->ow - 1) * g->stride + g->kw; p.thp = (pl.TH - 1) * g->stride + g->kh;
   p.d_ow.init(g->ow);
+  if (getenv("SEEDHIP_HALO_DEBUG")) {
+    static long long last = -1;
+    const long long key = ((long long)g->ih << 40) ^ ((long long)g->iw << 28) ^ ((long long)g->cin << 16) ^ g->cout;
+    if (key != last) {
+      last = key;
+      fprintf(stderr, "[halo_wgrad] %dx%d cin %d cout %d k %d stride %d -> TH %d (bands %d) MTW %d NT %d MSPLIT %d grid %d lds %zu\n",
+              g->ih, g->iw, g->cin, g->cout, g->kh, g->stride, pl.TH, p.bands, pl.MTW, pl.NT, pl.MSPLIT, pl.grid, pl.lds);
+    }
+  }
   p.partial_w = (float*)workspace;
   p.partial_b = dbias ? (float*)workspace + (size_t)pl.grid * p.rows * g->cout : nullptr;
 #define SEEDHIP_HALO_LAUNCH(MTW_, NT_, MS_)                                                                        \
