@@ -326,6 +326,9 @@ CONV_CASES = [
     (2, 7, 5, 128, 1, 1, 1, 'valid', 64),     # 1x1 conv on a map (not Dense: ih, iw > 1)
     (1, 6, 6, 32, 2, 2, 2, 'valid', 256),     # 2x2/2 (non-overlapping), wide output
     (2, 8, 8, 64, 3, 3, 1, 'same', 192),      # cout = 3 column tiles of 64
+    (2, 17, 50, 32, 3, 3, 1, 'same', 32),     # halo kernels, second tiling budget (80 KB / 10 prefetch vectors), odd map
+    (3, 10, 48, 32, 3, 3, 1, 'same', 16),     # 32 -> 16 on 48-pixel rows: forward of the shape ImpalaDeep has as a data gradient
+    (5, 9, 12, 16, 3, 3, 1, 'same', 32),      # weight gradient: one band per 9x12 image (6 dY prefetch vectors)
 ]
 
 
