@@ -94,6 +94,9 @@ def main():
                         ('r2d2 lstm-x 532->2048 M=20736', 20736, 532, 2048), ('r2d2 lstm-x 532->2048 M=10240', 10240, 532, 2048),
                         ('r2d2 heads 512->512 M=20736', 20736, 512, 512)]:
       bench_conv(nm, n, 1, 1, k, 1, 1, 'valid', c)
+  if a.what in ('r2d2conv',):                               # the DQN convs of the cfg5 step at its 81 x 256 training frames
+    bench_conv('r2d2 conv2 4x4/2 32->64 @20x20', 20736, 20, 20, 32, 4, 2, 'valid', 64)
+    bench_conv('r2d2 conv3 3x3/1 64->64 @9x9', 20736, 9, 9, 64, 3, 1, 'valid', 64)
   if a.what in ('deep',):
     n = 21 * 256
     bench_conv('deep s0 3x3 16->16 @36x48', n, 36, 48, 16, 3, 1, 'same', 16)
