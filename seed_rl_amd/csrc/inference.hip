@@ -179,38 +179,62 @@ categorical_sample_kernel(const float* __restrict__ logits, int ld, long long ro
 }
 __global__ void rng_advance_kernel(unsigned long long* rng) { rng[1] += 1; }
 
-// Several independent row moves in ONE launch (blockIdx.y = operation): dst[dst_rows[i]] = src[src_rows[i]] with
-// per-operation row count, mask and pitches.  The ~8 data movements of an inference step (previous-state gather,
-// append, emit, carry, state tables) become 4 launches of mutually independent operations.
+// Several independent row moves in ONE launch: dst[dst_rows[i]] = src[src_rows[i]] with per-operation row count, mask
+// and pitches.  The ~8 data movements of an inference step (previous-state gather, append, emit, carry, state tables)
+// become 4 launches of mutually independent operations.
+// Every operation gets exactly the workgroups it needs (a 1-D grid with per-operation block ranges; r02c sized one grid
+// dimension by the LARGEST operation, so the scalar fields of a step dispatched hundreds of empty workgroups beside the
+// 28 KB frame-state rows), and no index is divided per element: long rows are cut into 1024-element pieces (one
+// uniform division per workgroup), short rows are packed several to a workgroup (one division per thread).
 constexpr int kMaxOps = 32;
+constexpr int kPiece = 1024;                              // elements of a long row per workgroup
 struct RowOp {
-  void* dst; const void* src; long long row_bytes; long long dst_pitch; long long src_pitch;
-  const long long* dst_rows; const long long* src_rows; long long n; const uint8_t* mask; int zero_where_masked; int pad;
+  void* dst; const void* src; long long dst_pitch; long long src_pitch;
+  const long long* dst_rows; const long long* src_rows; const uint8_t* mask;
+  unsigned n, row_elems, w;                               // rows; elements of w bytes per row (w = 16, 4 or 1)
+  unsigned pieces;                                        // long rows (row_elems > 256): workgroups per row; else 0
+  unsigned rows_per_wg;                                   // short rows: rows per workgroup
+  int zero_where_masked;
 };
-struct OpsArgs { RowOp op[kMaxOps]; };
+struct OpsArgs { RowOp op[kMaxOps]; int blk_start[kMaxOps + 1]; int nops; };
+
+__device__ __forceinline__ void move_elem(const RowOp& o, long long drow, long long srow, unsigned el, bool zero) {
+  char* d = (char*)o.dst + drow * o.dst_pitch + (long long)el * o.w;
+  const char* sp = (o.src && !zero) ? (const char*)o.src + srow * o.src_pitch + (long long)el * o.w : nullptr;
+  if (o.w == 16) *reinterpret_cast<uint4*>(d) = sp ? *reinterpret_cast<const uint4*>(sp) : make_uint4(0, 0, 0, 0);
+  else if (o.w == 4) *reinterpret_cast<uint32_t*>(d) = sp ? *reinterpret_cast<const uint32_t*>(sp) : 0u;
+  else *d = sp ? *sp : (char)0;
+}
 
 __global__ void __launch_bounds__(256)
 rows_move_ops_kernel(OpsArgs a) {
-  const RowOp& o = a.op[blockIdx.y];
-  const long long rb = o.row_bytes;
-  const uintptr_t al = (uintptr_t)o.dst | (uintptr_t)o.src | (uintptr_t)rb | (uintptr_t)o.dst_pitch | (uintptr_t)o.src_pitch;
-  const int w = (al & 15) == 0 ? 16 : ((al & 3) == 0 ? 4 : 1);       // uniform per operation
-  const long long row_elems = rb / w;
-  const long long total = o.n * row_elems;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const long long r = i / row_elems, el = i - r * row_elems;
-    bool zero = false;
-    if (o.mask) {
-      const bool m = o.mask[r] != 0;
-      if (o.zero_where_masked) zero = m; else if (!m) continue;
-    }
-    char* d = (char*)o.dst + (o.dst_rows ? o.dst_rows[r] : r) * o.dst_pitch + el * w;
-    const char* sp = (o.src && !zero) ? (const char*)o.src + (o.src_rows ? o.src_rows[r] : r) * o.src_pitch + el * w : nullptr;
-    if (w == 16) *reinterpret_cast<uint4*>(d) = sp ? *reinterpret_cast<const uint4*>(sp) : make_uint4(0, 0, 0, 0);
-    else if (w == 4) *reinterpret_cast<uint32_t*>(d) = sp ? *reinterpret_cast<const uint32_t*>(sp) : 0u;
-    else *d = sp ? *sp : (char)0;
+  int k = 0;
+  while (k + 1 < a.nops && (int)blockIdx.x >= a.blk_start[k + 1]) ++k;       // scalar: <= 32 entries
+  const RowOp& o = a.op[k];
+  const unsigned lb = blockIdx.x - (unsigned)a.blk_start[k];
+  unsigned r, el, el_end, step;
+  if (o.pieces) {                                           // one piece of one long row
+    r = lb / o.pieces;
+    const unsigned part = lb - r * o.pieces;
+    el = part * kPiece + threadIdx.x;
+    el_end = (part + 1) * kPiece < o.row_elems ? (part + 1) * kPiece : o.row_elems;
+    step = 256;
+  } else {                                                  // several short rows
+    const unsigned rl = threadIdx.x / o.row_elems;
+    el = threadIdx.x - rl * o.row_elems;
+    r = lb * o.rows_per_wg + rl;
+    el_end = rl < o.rows_per_wg ? o.row_elems : 0;
+    step = 0x40000000u;                                     // one element per thread
   }
+  if (r >= o.n) return;
+  bool zero = false;
+  if (o.mask) {
+    const bool m = o.mask[r] != 0;
+    if (o.zero_where_masked) zero = m; else if (!m) return;
+  }
+  const long long drow = o.dst_rows ? o.dst_rows[r] : (long long)r;
+  const long long srow = o.src_rows ? o.src_rows[r] : (long long)r;
+  for (; el < el_end; el += step) move_elem(o, drow, srow, el, zero);
 }
 
 template <typename V>
@@ -354,24 +378,33 @@ extern "C" int seedhip_rows_move_ops(int nops, const seedhip_row_op* ops, void* 
   if (nops == 0) return SEEDHIP_OK;
   SEEDHIP_REQUIRE(ops, "rows_move_ops: null ops");
   OpsArgs a;
-  long long max_elems = 0;
   int k = 0;
+  long long blocks = 0;
   for (int f = 0; f < nops; ++f) {
     const seedhip_row_op& o = ops[f];
     SEEDHIP_REQUIRE(o.n >= 0 && o.row_bytes >= 1, "rows_move_ops: bad op %d", f);
     if (o.n == 0) continue;
     SEEDHIP_REQUIRE(o.dst, "rows_move_ops: null dst in op %d", f);
-    RowOp& r = a.op[k++];
-    r.dst = o.dst; r.src = o.src; r.row_bytes = o.row_bytes;
+    SEEDHIP_REQUIRE(o.n < (1LL << 31) && o.row_bytes < (1LL << 31), "rows_move_ops: op %d too large", f);
+    RowOp& r = a.op[k];
+    r.dst = o.dst; r.src = o.src;
     r.dst_pitch = o.dst_pitch ? o.dst_pitch : o.row_bytes; r.src_pitch = o.src_pitch ? o.src_pitch : o.row_bytes;
-    r.dst_rows = o.dst_rows; r.src_rows = o.src_rows; r.n = o.n; r.mask = o.row_mask;
-    r.zero_where_masked = o.zero_where_masked; r.pad = 0;
-    const long long e = o.n * ((o.row_bytes + 15) / 16);
-    if (e > max_elems) max_elems = e;
+    r.dst_rows = o.dst_rows; r.src_rows = o.src_rows; r.n = (unsigned)o.n; r.mask = o.row_mask;
+    r.zero_where_masked = o.zero_where_masked;
+    const uintptr_t al = (uintptr_t)o.dst | (uintptr_t)o.src | (uintptr_t)o.row_bytes | (uintptr_t)r.dst_pitch | (uintptr_t)r.src_pitch;
+    r.w = (al & 15) == 0 ? 16u : ((al & 3) == 0 ? 4u : 1u);
+    r.row_elems = (unsigned)(o.row_bytes / r.w);
+    long long nb;
+    if (r.row_elems > 256) { r.pieces = (r.row_elems + kPiece - 1) / kPiece; r.rows_per_wg = 0; nb = (long long)r.n * r.pieces; }
+    else { r.pieces = 0; r.rows_per_wg = 256u / r.row_elems; nb = ((long long)r.n + r.rows_per_wg - 1) / r.rows_per_wg; }
+    a.blk_start[k] = (int)blocks;
+    blocks += nb;
+    SEEDHIP_REQUIRE(blocks < (1LL << 31), "rows_move_ops: too many workgroups");
+    ++k;
   }
   if (k == 0) return SEEDHIP_OK;
-  long long gx = (max_elems + 255) / 256; if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(rows_move_ops_kernel, dim3((int)gx, k), dim3(256), 0, (hipStream_t)stream, a);
+  a.blk_start[k] = (int)blocks; a.nops = k;
+  hipLaunchKernelGGL(rows_move_ops_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   return seedhip::check_launch("rows_move_ops_kernel");
 }
 
