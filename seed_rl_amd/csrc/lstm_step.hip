@@ -194,17 +194,22 @@ lstm_step_fwd_kernel(const StepParams p) {
 // bounded: a workgroup that waits too long (the grid was not co-resident) raises the abort flag and all leave.
 // Arms an exchange buffer with the sentinel and clears the 8-byte sync word, as ONE ordinary kernel (a captured
 // hipMemsetAsync node misbehaved under HIP-graph replay on ROCm 7.2: see DESIGN.md).
+// hs (may be null): the XCD handshake words of the sequence kernels, `nrow` groups of `ncol` words `hs_stride` apart.
 __global__ void __launch_bounds__(256)
-seq_arm_kernel(uint4* __restrict__ buf, long long n16, unsigned* __restrict__ sync_ws) {
+seq_arm_kernel(uint4* __restrict__ buf, long long n16, unsigned* __restrict__ sync_ws, unsigned* __restrict__ hs = nullptr,
+               int nrow = 0, int ncol = 0, long long hs_stride = 0) {
   const uint4 s = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) buf[i] = s;
   if (blockIdx.x == 0 && threadIdx.x < 2) sync_ws[threadIdx.x] = 0u;
+  if (hs && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < nrow * ncol; i += 256) hs[(long long)(i / ncol) * hs_stride + (i % ncol)] = 0xffffffffu;
 }
 
 struct SeqParams {
   const float* up; const float* zx; const uint8_t* done; int T1, B, H;
   float* z; float* h_out; int ld_h; float* hin; float* cin;          // hin / cin [T1 + 1, B, H]; slot 0 = initial state
   int* abort_flag; int fault;
+  int xcd_local;                                             // try the same-XCD exchange (plain producer stores)
 };
 
 constexpr unsigned kMaxSpins = 200000;                    // x (one agent-scope round trip): a few hundred ms
@@ -215,13 +220,10 @@ lstm_seq_fwd_kernel(const SeqParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];       // U slabs [H][64] | staging / partial sums (24 KB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lx = lane & 15, kq = lane >> 4;
   const int nrow = (p.B + kRows - 1) / kRows, ncol = p.H / kUnits;
-  int rt, ct;
-  if ((ncol & 7) == 0) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = ncol >> 3;
-    ct = xcd * per + j / nrow; rt = j - (j / nrow) * nrow;
-  } else {
-    ct = blockIdx.x / nrow; rt = blockIdx.x - ct * nrow;
-  }
+  // Row tile = blockIdx % nrow: workgroup i runs on XCD i % 8 (tools/probes/xcc_probe.hip), so with 8 row tiles
+  // (B = 256) the ncol workgroups that exchange h among themselves -- those of ONE row tile -- share an XCD and its
+  // L2.  (U lives in LDS for the whole sequence: which XCD reads it once does not matter.)
+  const int ct = blockIdx.x / nrow, rt = blockIdx.x - ct * nrow;
   const int m0 = rt * kRows, u0 = ct * kUnits;
   const int H = p.H, ld_u = 4 * H, kper = H / kWaves, k0 = wave * kper, nkt = kper / BK;    // nkt <= 4 (H <= 512)
   const long long BH = (long long)p.B * H;
@@ -258,6 +260,36 @@ lstm_seq_fwd_kernel(const SeqParams p) {
   const float* b_frag = Us + (4 * kq) * kCols + 4 * lx;
 
   bool dead = false;                                      // a wait timed out: stop polling, finish with garbage
+  // ---- same-XCD exchange?  Every workgroup publishes the XCD it runs on (agent-scope store into a word of z's LAST
+  //      step, which nobody touches before step T1 - 1; armed with the sentinel by seq_arm_kernel) and reads the words
+  //      of its row tile's ncol workgroups.  If they all agree, h can travel through the shared L2: PLAIN producer
+  //      stores keep the line there (an sc1 store would drop it: MI355X_MICROARCH.md), the consumers' sc1 loads bypass
+  //      only their L1.  Placement is verified, never assumed: any disagreement (or a timeout) keeps agent-scope stores.
+  bool xcd_local = false;
+  if (p.xcd_local) {
+    unsigned my_xcd;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcd));
+    my_xcd &= 15u;
+    unsigned* hs = reinterpret_cast<unsigned*>(p.z + ((long long)(p.T1 - 1) * p.B + m0) * 4 * H);
+    int* flag = reinterpret_cast<int*>(stage);
+    if (tid == 0) __hip_atomic_store(hs + ct, my_xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) {
+      unsigned v = my_xcd;
+      bool late = false;
+      if (lane < ncol) {
+        unsigned spins = 0;
+        while ((v = __hip_atomic_load(hs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kSentinel) {
+          if (++spins > kMaxSpins) { late = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      const bool same = __all(!late && v == my_xcd);
+      if (lane == 0) *flag = same ? 1 : 0;
+    }
+    __syncthreads();
+    xcd_local = *flag != 0;
+    __syncthreads();                                      // the flag word is the A stage of wave 0 again
+  }
   for (int t = 0; t < p.T1; ++t) {
     // epilogue operands first: their latency hides under the wait / the GEMM
     float zxv[2][4], keep[2];
@@ -378,8 +410,11 @@ lstm_seq_fwd_kernel(const SeqParams p) {
       p.h_out[row * p.ld_h + e_unit] = hh;
       float hn = hh * keep[rr];
       if (__float_as_uint(hn) == kSentinel) hn = __uint_as_float(0x7fc00000u);       // a NaN that happens to be the sentinel
-      if (!((p.fault & 1) && blockIdx.x == 0 && t == 1)) // test hook: a producer that never delivers
-        __hip_atomic_store(p.hin + (t + 1) * BH + (long long)e_b[rr] * H + e_unit, hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!((p.fault & 1) && blockIdx.x == 0 && t == 1)) { // test hook: a producer that never delivers
+        float* hp = p.hin + (t + 1) * BH + (long long)e_b[rr] * H + e_unit;
+        if (xcd_local) *hp = hn;                           // stays in the XCD's L2, where all its readers are
+        else __hip_atomic_store(hp, hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       cst[rr] = c * keep[rr];
       p.cin[(t + 1) * BH + (long long)e_b[rr] * H + e_unit] = cst[rr];
     }
@@ -634,6 +669,7 @@ extern "C" int seedhip_lstm_seq_fwd(const float* up, const float* zx, const uint
   p.up = up; p.zx = zx; p.done = done; p.T1 = T1; p.B = B; p.H = H; p.z = z; p.h_out = h_out; p.ld_h = ld_h;
   p.hin = hin; p.cin = cin; p.abort_flag = (int*)sync_ws + 1;
   { const char* e = getenv("SEEDHIP_LSTM_SEQ_FAULT"); p.fault = e ? atoi(e) : 0; }   // tests: exercise the bounded wait
+  { static const int x = getenv("SEEDHIP_LSTM_SEQ_XCD") ? atoi(getenv("SEEDHIP_LSTM_SEQ_XCD")) : 1; p.xcd_local = x; }
   const size_t lds = seq_lds_bytes(H);
   static bool attr_set = false;
   if (!attr_set) {
@@ -644,7 +680,9 @@ extern "C" int seedhip_lstm_seq_fwd(const float* up, const float* zx, const uint
     const long long n16 = (long long)T1 * B * H / 4;       // H % 128 == 0: whole 16-byte words
     long long blocks = (n16 + 255) / 256; if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(seq_arm_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<uint4*>(hin + (size_t)B * H), n16, (unsigned*)sync_ws);
+                       reinterpret_cast<uint4*>(hin + (size_t)B * H), n16, (unsigned*)sync_ws,
+                       reinterpret_cast<unsigned*>(z + (size_t)(T1 - 1) * B * 4 * H), (B + kRows - 1) / kRows, H / kUnits,
+                       (long long)kRows * 4 * H);
     if (int rc = seedhip::check_launch("seq_arm_kernel")) return rc;
   }
   hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(((B + kRows - 1) / kRows) * (H / kUnits)), dim3(64 * kWaves), lds,
