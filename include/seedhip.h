@@ -246,7 +246,8 @@ int seedhip_lstm_step_fwd(const float* hin, const float* up, const float* zx, co
  * h_out [T1 * B, ld_h].  sync_ws: 8 bytes of device memory, zeroed by the call; every wait is bounded, and after the
  * launch completes int32 sync_ws[1] != 0 means one timed out (the workgroups were not co-resident) and the outputs
  * are invalid.  seedhip_lstm_seq_supported: T1 >= 2, H % 128 == 0, H <= 512, and the grid of ceil(B / 32) * H / 16
- * workgroups fits the device's CUs (needs a current HIP device). */
+ * workgroups fits the device's CUs (needs a current HIP device).  (z's last step doubles as scratch for the kernel's
+ * start-up XCD handshake before step T1 - 1 overwrites it: do not read z concurrently with the call.) */
 int seedhip_lstm_seq_supported(int T1, int B, int H);
 int seedhip_lstm_seq_fwd(const float* up, const float* zx, const uint8_t* done, int T1, int B, int H, float* z,
                          float* h_out, int ld_h, float* hin, float* cin, void* sync_ws, void* stream);
