@@ -344,11 +344,11 @@ def inference_record(dev, sizes=(64, 256, 1024), unroll_len=20, calls=200):
 
 def ingest_record(dev, steps, T=20, B=512, A=18):
   """The cfg2 step fed from PINNED HOST memory: the whole unroll of step i+1 (frames = 98.7 % of its bytes) is copied
-  host->device on a copy stream while step i computes (double-buffered device unrolls, eager launches)."""
+  host->device on a copy stream while step i computes (double-buffered device unrolls, one HIP graph per buffer)."""
   from seed_rl_amd import learner, networks, optimizers, parametric_distribution as pd, smoke_step, utils
   T1 = T + 1
   agent = networks.AtariShallow(A, device=dev, seed=0)
-  opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, 10 ** 5), beta_1=0.0, epsilon=3.125e-7)
+  opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, 10 ** 5), beta_1=0.0, epsilon=3.125e-7, capturable=True)
   lrn = learner.Learner(agent, opt, pd.categorical_distribution(A))
   slots, hosts = [], []
   for s in range(2):
@@ -361,6 +361,10 @@ def ingest_record(dev, steps, T=20, B=512, A=18):
     slots.append((u, leaves))
     hosts.append([t.cpu().pin_memory() for t in leaves])
   nbytes = sum(t.numel() * t.element_size() for t in hosts[0])
+  graphed = []                                        # one captured step per device unroll (its frames buffer is static)
+  for s in range(2):
+    agent.frames_slot = s
+    graphed.append(learner.GraphedStep(lrn, slots[s][0]))
   copy_stream = torch.cuda.Stream()
   ready = [torch.cuda.Event(), torch.cuda.Event()]
   free = [torch.cuda.Event(), torch.cuda.Event()]
@@ -380,7 +384,7 @@ def ingest_record(dev, steps, T=20, B=512, A=18):
       agent.frames_slot = i & 1
       cur.wait_event(ready[i & 1])
       prefetch(i + 1)
-      lrn.minimize(slots[i & 1][0])
+      graphed[i & 1]()
       free[i & 1].record(cur)
     torch.cuda.synchronize()
 
@@ -396,7 +400,7 @@ def ingest_record(dev, steps, T=20, B=512, A=18):
   torch.cuda.synchronize()
   copy_ms = (time.perf_counter() - t1) / 4 * 1e3
   agent.frames_slot = 0
-  rec = dict(mode='pinned host unrolls, H2D of step i+1 on a copy stream under step i (eager launches)',
+  rec = dict(mode='pinned host unrolls, H2D of step i+1 on a copy stream under step i (HIP-graph replay per device buffer)',
              ms_per_step=round(dt / steps * 1e3, 4), env_frames_per_s=round(B * T / (dt / steps), 1),
              h2d_bytes_per_step=nbytes, h2d_ms_alone=round(copy_ms, 4), h2d_GBs=round(nbytes / copy_ms / 1e6, 1))
   del agent, lrn, slots, hosts
