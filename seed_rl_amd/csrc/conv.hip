@@ -282,6 +282,16 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
       gp.A = dy; gp.B = w; gp.C = dx; gp.mask = relu_mask; gp.add = add;
       gemm::Plan pl = gemm::plan(gp.M, gp.N, gp.K);
       pl.slices = 1; pl.k_per_slice = gp.K;
+      // 'valid' convs with several taps: rows in image-block x position order, so that a workgroup tile shares one
+      // super-pixel and skips the taps that fall outside dY (gemm_geom.h Gather::blk; A/B: SEEDHIP_DGRAD_POS=0)
+      static const int pos_major = getenv("SEEDHIP_DGRAD_POS") ? atoi(getenv("SEEDHIP_DGRAD_POS")) : 1;
+      const int bm = (4 / pl.wn) * pl.mr * 16, nkt = (gp.K + gemm::BK - 1) / gemm::BK;
+      const long long m_blk = (long long)((geom->n_img + bm - 1) / bm) * gp.ga.d1.d * bm;
+      if (pos_major && geom->pad_t == 0 && geom->pad_l == 0 && gp.ga.ntaps > 1 && nkt <= 32 && geom->cout % gemm::BK == 0 &&
+          m_blk < (1LL << 31)) {
+        gp.ga.blk = bm; gp.ga.n_img = geom->n_img; gp.ga.d_blk.init(bm);
+        gp.M = (int)m_blk;
+      }
       gemm::launch<true, true, true, true, true>(gp, pl, (hipStream_t)stream);
       return check_launch("conv2d_bwd_data(gather gemm)");
     }

@@ -146,8 +146,7 @@ struct GatherStager {                        // KC only; same interface as Stage
       int yy = 0, xx = 0;
       if (xbase + row < X) {
         long long off;
-        gather_row(gg, xbase + row, off, yy, xx);
-        b = p + off;
+        if (gather_row(gg, xbase + row, off, yy, xx)) b = p + off;
       }
       base[i] = b; y0[i] = yy; x0[i] = xx;
     }
@@ -315,8 +314,35 @@ gemm_kernel(const Params p) {
   const float* a_frag = AKC ? As + (wm * MR * 16 + lx) * LD_KC + 4 * kq : As + (4 * kq) * LDA_OC + wm * MR * 16 + MR * lx;
   const float* b_frag = BKC ? Bs + (wn * NR * 16 + lx) * LD_KC + 4 * kq : Bs + (4 * kq) * LDB_OC + wn * NR * 16 + NR * lx;
 
-  if (nkt > 0) { sa.load(k0, k1, p.a_relu != 0); sb.load(k0, k1, false); }
-  for (int kt = 0; kt < nkt; ++kt) {
+  // k-tiles to visit: all of them -- or, for a conv data gradient in image-block x position order (Gather::blk: this
+  // tile's rows share one super-pixel), only those whose tap lies inside dY: the others are exact zeros for every row
+  // (DQN conv3, 3x3 'valid' on 9x9: 40 % of the (position, tap) pairs)
+  uint32_t kmask = 0;
+  bool skipk = false;
+  if constexpr (AG && SCATTER) {
+    if (p.ga.blk && nkt <= 32) {
+      skipk = true;
+      uint32_t t = (uint32_t)m0 / (uint32_t)p.ga.blk, ib, pos, v, w;
+      p.ga.d1.divmod(t, ib, pos);
+      p.ga.d2.divmod(pos, v, w);
+      for (int kt = 0; kt < nkt; ++kt) {
+        int toff, dy, dx; bool tap_ok;
+        gather_tap(p.ga, k0 + kt * BK, toff, dy, dx, tap_ok);
+        if (tap_ok && gather_inside(p.ga, (int)v * p.ga.cy + p.ga.oy0 + dy, (int)w * p.ga.cx + p.ga.ox0 + dx)) kmask |= 1u << kt;
+      }
+      kmask = __builtin_amdgcn_readfirstlane(kmask);
+    }
+  }
+  const int nvisit = skipk ? __popc(kmask) : nkt;
+  int kt_seq = 0;
+  auto next_kt = [&]() -> int {
+    if (!skipk) return kt_seq++;
+    const int b = __ffs(kmask) - 1;
+    kmask &= kmask - 1;
+    return b;
+  };
+  if (nvisit > 0) { const int kt = next_kt(); sa.load(k0 + kt * BK, k1, p.a_relu != 0); sb.load(k0 + kt * BK, k1, false); }
+  for (int it = 0; it < nvisit; ++it) {
     __syncthreads();                                       // previous tile consumed
     sa.store(As); sb.store(Bs);
     if (do_colsum) {
@@ -324,7 +350,7 @@ gemm_kernel(const Params p) {
       for (int i = 0; i < SB::kVecs; ++i) { csum[i].x += sb.r[i].x; csum[i].y += sb.r[i].y; csum[i].z += sb.r[i].z; csum[i].w += sb.r[i].w; }
     }
     __syncthreads();
-    if (kt + 1 < nkt) { sa.load(k0 + (kt + 1) * BK, k1, p.a_relu != 0); sb.load(k0 + (kt + 1) * BK, k1, false); }
+    if (it + 1 < nvisit) { const int kt = next_kt(); sa.load(k0 + kt * BK, k1, p.a_relu != 0); sb.load(k0 + kt * BK, k1, false); }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                          // two 16-deep halves; lane (x, kq) holds k = 16h + 4kq + kk
       f32x4_t a_kc[MR], b_kc[NR];

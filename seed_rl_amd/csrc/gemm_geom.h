@@ -25,6 +25,12 @@ struct Gather {
   int tsy, tsx;
   int cy, oy0, ey, cx, ox0, ex, vh, vw, all_valid;
   long long extent;                         // floats in the gathered tensor (0 = unknown): bounds of the buffer view
+  // Row order "block of images x position" (data gradients of 'valid' convs, conv.hip): row x = (ib * G + pos) * blk + r
+  // is super-pixel `pos` of image ib * blk + r, G = d1.d positions per image.  A workgroup tile of blk rows then shares
+  // ONE position, so whether a tap (k-tile) falls outside dY is uniform and the tile skips it (gemm.h); consecutive
+  // tiles walk the positions of one image block, whose dY stays in L2.  blk = 0: rows are (image, position).
+  int blk, n_img;
+  FastDiv d_blk;
 };
 
 struct Params {
@@ -46,13 +52,28 @@ constexpr int BK = 32, LD_KC = BK + 8;
 
 // ---- index arithmetic of a gathered operand (see struct Gather) -------------------------------------------- //
 // Row part: float offset of the row base (relative to the operand pointer) and the border coordinates (y0, x0).
-SH_HD void gather_row(const Gather& g, int x, long long& base, int& y0, int& x0) {
-  uint32_t u, rem, v, w;
-  g.d1.divmod((uint32_t)x, u, rem);
+// row x -> (u, v, w) = (image, grid row, grid column); false: a padding row of the image-block order (no such image)
+SH_HD bool gather_locate(const Gather& g, uint32_t x, uint32_t& u, uint32_t& v, uint32_t& w) {
+  uint32_t rem;
+  if (g.blk) {
+    uint32_t t, r, ib;
+    g.d_blk.divmod(x, t, r);
+    g.d1.divmod(t, ib, rem);
+    g.d2.divmod(rem, v, w);
+    u = ib * (uint32_t)g.blk + r;
+    return u < (uint32_t)g.n_img;
+  }
+  g.d1.divmod(x, u, rem);
   g.d2.divmod(rem, v, w);
+  return true;
+}
+SH_HD bool gather_row(const Gather& g, int x, long long& base, int& y0, int& x0) {
+  uint32_t u, v, w;
+  const bool ok = gather_locate(g, (uint32_t)x, u, v, w);
   base = g.const0 + (long long)u * g.s0 + (long long)v * g.s1 + (long long)w * g.s2;
   y0 = (int)(g.coord_uv ? u : v) * g.cy + g.oy0;
   x0 = (int)(g.coord_uv ? v : w) * g.cx + g.ox0;
+  return ok;
 }
 // Tap part of reduction / row index k: float offset added to the row base, border shift, and whether the tap exists.
 SH_HD void gather_tap(const Gather& g, int k, int& toff, int& dy, int& dx, bool& tap_ok) {
@@ -88,9 +109,8 @@ SH_HD bool gather_inside(const Gather& g, int y, int x) {
 // (returns false when the pixel lies outside the input map: odd extents).
 SH_HD bool scatter_addr(const Gather& ga, const Gather& gb, int es, int eih, int eiw, long long ldc, int m, int n,
                         long long& at) {
-  uint32_t img, rem, sa, sb, py, rem2, px, ci;
-  ga.d1.divmod((uint32_t)m, img, rem);
-  ga.d2.divmod(rem, sa, sb);
+  uint32_t img, sa, sb, py, rem2, px, ci;
+  if (!gather_locate(ga, (uint32_t)m, img, sa, sb)) return false;
   gb.d1.divmod((uint32_t)n, py, rem2);
   gb.d2.divmod(rem2, px, ci);
   const int oy = (int)sa * es + (int)py, ox = (int)sb * es + (int)px;

@@ -329,6 +329,8 @@ CONV_CASES = [
     (2, 17, 50, 32, 3, 3, 1, 'same', 32),     # halo kernels, second tiling budget (80 KB / 10 prefetch vectors), odd map
     (3, 10, 48, 32, 3, 3, 1, 'same', 16),     # 32 -> 16 on 48-pixel rows: forward of the shape ImpalaDeep has as a data gradient
     (5, 9, 12, 16, 3, 3, 1, 'same', 32),      # weight gradient: one band per 9x12 image (6 dY prefetch vectors)
+    (130, 9, 9, 64, 3, 3, 1, 'valid', 64),    # data gradient in image-block x position order: two blocks + a padded third, taps skipped at the border
+    (70, 20, 20, 32, 4, 4, 2, 'valid', 64),   # the same for the stride-2 super-pixel GEMM (DQN conv2)
 ]
 
 
