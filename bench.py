@@ -62,14 +62,19 @@ def parse():
                        'r2d2 = configs[4] (DuelingLSTMDQNNet, replayed T=120 B=256 sequences, burn-in 40)')
   ap.add_argument('--torso', default='shallow', choices=['shallow', 'dqn'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--cpu-batch', type=int, default=64)
+  ap.add_argument('--cpu-batch', type=int, default=0,
+                  help='batch columns of the CPU-baseline sample (default: 256 atari, 16 dmlab, 8 r2d2: 10-30 s of host time)')
   ap.add_argument('--reduction', default='mean', choices=['mean', 'sum'])
   ap.add_argument('--graph', type=int, default=1,
-                  help='1 (default, single GPU): replay the step from a captured HIP graph (learner.GraphedStep; measured '
-                       '0-2%% over eager on MI355X); 0: eager launches.  Multi-GPU runs launch eagerly.')
+                  help='1 (default): replay the step from captured HIP graphs (learner.GraphedStep; N > 1: graph segments '
+                       'with the gradient exchange launched between them); 0: eager launches.')
   ap.add_argument('--ingest', default='resident', choices=['resident', 'pinned'],
                   help="resident (headline): the unroll is in HBM when the timed region starts; pinned: every step's "
                        'unroll comes from pinned host memory, the copy of step i+1 on its own stream under step i')
+  ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                  help="process group for --gpus > 1: nccl (= RCCL over xGMI, one rank per GPU) or gloo -- a DRY RUN of "
+                       'the N-rank code path on fewer devices (ranks share GPUs, the exchange goes through host memory); '
+                       'its throughput is not a scaling measurement and the line says so')
   ap.add_argument('--quick', action='store_true',
                   help='only the timed learner step: no parity / other_configs / inference / ingest / cpu_baseline records')
   return ap.parse_args()
@@ -216,14 +221,19 @@ def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, 
   # ---- timed region: exactly K steps, barrier + sync on both sides ----
   step_fn = lambda: lrn.minimize(unroll, *extra)
   mode = 'eager'
-  if graph and world == 1:
+  gs = None
+  if graph:
     try:
       gs = learner.GraphedStep(lrn, unroll, *extra, warmup=1)
       step_fn, mode = (lambda: gs()), 'hip-graph'
+      if gs.split:
+        mode = 'hip-graph x%d segments + eager RCCL exchange + update graph' % len(gs.segments)
       step_fn(); torch.cuda.synchronize()
     except Exception as e:                       # pylint: disable=broad-except
       sys.stderr.write('HIP-graph capture unavailable (%s); timing eager launches\n' % e)
-      step_fn, mode = (lambda: lrn.minimize(unroll, *extra)), 'eager'
+      if world > 1:
+        raise                                    # ranks must not diverge into different launch modes
+      gs, step_fn, mode = None, (lambda: lrn.minimize(unroll, *extra)), 'eager'
   prof = ops.Profiler(only=[dominant])
   if mode == 'eager':
     ops.set_profiler(prof)
@@ -242,10 +252,38 @@ def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, 
     for _ in range(min(steps, 5)):
       lrn.minimize(unroll, *extra)
     ops.set_profiler(None)
+  exchange = None
   if world > 1:
-    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-    torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tt[0])
+    # per-rank wall time of the timed region, then its maximum (the contract's clock)
+    mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    torch.distributed.all_gather(every, mine)
+    per_rank = [float(t[0]) for t in every]
+    dt = max(per_rank)
+    # what the exchange costs: the same K steps with the all-reduce left out (replicas diverge from here on -- this
+    # is the last thing the run does with them).  exposed = (step with exchange) - (step without).
+    bucket = agent.flat.grads.numel() * 4
+    exposed = None
+    if gs is not None:
+      gs.exchange = False
+      for _ in range(2):
+        step_fn()
+      barrier()
+      t1 = time.perf_counter()
+      for _ in range(steps):
+        step_fn()
+      barrier()
+      tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+      torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+      exposed = max(0.0, dt - float(tt[0])) / steps * 1e3
+      gs.exchange = True
+    exchange = dict(ranks=world, backend=torch.distributed.get_backend(), bucket_bytes=bucket,
+                    per_rank_ms_per_step=[round(t / steps * 1e3, 4) for t in per_rank],
+                    exposed_ms_per_step=None if exposed is None else round(exposed, 4),
+                    overlapped_ranges=[list(r) for _, r in gs.segments if r] if gs is not None and gs.split else [],
+                    note='exposed = ms_per_step minus the same steps replayed without the all-reduce; the range listed '
+                         'under overlapped_ranges (float offsets into the flat gradient bucket) is exchanged on the '
+                         'collective stream under the rest of the backward pass, the remainder after it')
   loss_val = float(loss)
   assert np.isfinite(loss_val)
   if hasattr(agent, 'check_errors'):
@@ -276,7 +314,7 @@ def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, 
   rec = dict(
       T=T, B=B, A=A, workload=workload, mode=mode, params=agent.flat.num_params(), loss=loss_val,
       ms_per_step=dt / steps * 1e3, frames_per_s=world * B * T / (dt / steps), roofline=roofline, dominant=dominant,
-      kernels_ms_per_step={k: round(v['total_ms'], 4) for k, v in kern.items()},
+      kernels_ms_per_step={k: round(v['total_ms'], 4) for k, v in kern.items()}, exchange=exchange,
       # the other MFMA kernels of the attribution pass (>= 50 us per launch), same (serialized) accounting as `roofline`
       mfma_kernels={
           k: dict(avg_ms=round(v['avg_ms'], 4), tflops=round(v['flops'] / (v['avg_ms'] * 1e-3) / 1e12, 1),
@@ -408,21 +446,67 @@ def ingest_record(dev, steps, T=20, B=512, A=18):
   return rec
 
 
+def _free_port():
+  import socket
+  so = socket.socket()
+  so.bind(('127.0.0.1', 0))
+  port = so.getsockname()[1]
+  so.close()
+  return port
+
+
+def self_launch(args):
+  """`python bench.py --gpus N` without a launcher: re-executes this script as N ranks under torch.distributed.run
+  (one process per GPU, rendezvous on 127.0.0.1) with the same arguments and hands back its exit code, so that the
+  printed line is the N-rank measurement -- or fails loudly when the box has fewer than N devices."""
+  import subprocess
+  ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+  if ndev < args.gpus and args.backend != 'gloo':
+    sys.stderr.write('bench.py: --gpus %d asked for but this box exposes %d GPU(s): RCCL needs one device per rank.  '
+                     '(--backend gloo runs the %d-rank code path as a dry run on the devices there are.)\n'
+                     % (args.gpus, ndev, args.gpus))
+    return 2
+  if ndev < 1:
+    sys.stderr.write('bench.py needs a GPU (no CPU fallback for the HIP path)\n')
+    return 2
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+         '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  env.setdefault('OMP_NUM_THREADS', '8')
+  return subprocess.call(cmd, env=env)
+
+
 def main():
   args = parse()
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(self_launch(args))
   rank = int(os.environ.get('RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the HIP path)'
-  torch.cuda.set_device(local_rank)
-  dev = torch.device('cuda', local_rank)
+  if world != args.gpus:
+    sys.stderr.write('bench.py: --gpus %d but the launcher started %d rank(s)\n' % (args.gpus, world))
+    sys.exit(2)
+  if not torch.cuda.is_available():
+    sys.stderr.write('bench.py needs a GPU (no CPU fallback for the HIP path)\n')
+    sys.exit(2)
+  ndev = torch.cuda.device_count()
+  if local_rank >= ndev and args.backend != 'gloo':
+    sys.stderr.write('bench.py: rank %d has no device (%d GPU(s) visible, %d ranks): RCCL needs one device per rank\n'
+                     % (rank, ndev, world))
+    sys.exit(2)
+  dev_index = local_rank % ndev
+  torch.cuda.set_device(dev_index)
+  dev = torch.device('cuda', dev_index)
   distributed = world > 1 or 'RANK' in os.environ       # launched by torch.distributed.run (also at N=1)
   if distributed:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
-    torch.distributed.init_process_group('nccl', device_id=dev)          # "nccl" is RCCL on ROCm
-  assert world == args.gpus or world == 1, 'launch with torchrun for --gpus > 1'
+    if args.backend == 'gloo':
+      torch.distributed.init_process_group('gloo')
+    else:
+      torch.distributed.init_process_group('nccl', device_id=dev)        # "nccl" is RCCL on ROCm
   deep, r2 = args.config == 'dmlab', args.config == 'r2d2'
 
   rec = run_learner(args.config, args.steps, args.warmup, dev, rank, world, distributed, args.torso, args.batch,
@@ -449,18 +533,24 @@ def main():
     return
   result = {
       'metric': 'learner env-frames/s (T=%d)' % T, 'value': round(rec['frames_per_s'], 1), 'unit': 'env-frames/s',
-      'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(rec['ms_per_step'], 4),
+      'n_gpus': min(world, ndev), 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(rec['ms_per_step'], 4),
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
       'config': {'workload': '%s, T=%d B=%d/GPU A=%d, synthetic uint8 frames in HBM, num_action_repeats=1'
                              % (rec['workload'], T, B, A),
                  'global_batch': B * world, 'unroll_length': T, 'parallelism': 'dp%d' % world,
                  'grad_reduction': args.reduction, 'params': rec['params'], 'launch': rec['mode'],
-                 'ingest': 'resident (unroll in HBM before the timed region)'},
+                 'ingest': 'resident (unroll in HBM before the timed region)',
+                 'process_group': (('rccl' if args.backend == 'nccl' else 'gloo') if distributed else None)},
       'roofline': roofline,
+      'exchange': rec['exchange'],
       'loss': round(rec['loss'], 6),
       'kernels_ms_per_step': rec['kernels_ms_per_step'],
       'mfma_kernels': rec['mfma_kernels'],
   }
+  if world > ndev:
+    result['dry_run'] = ('%d ranks share %d device(s) over gloo: exercises the N-rank code path (sharded columns, graph '
+                         'segments, overlapped exchange, update graph); the throughput is NOT a scaling measurement'
+                         % (world, ndev))
   if world == 1:
     err, err_ref, sweep = vtrace_checks(dev)
     result['vtrace_max_abs_err'] = err
@@ -472,9 +562,9 @@ def main():
     # tests/test_gpu_fullsize.py)
     # (fp32 oracle only: its fp64 evaluation -- tests/test_gpu_fullsize.py -- takes minutes of host time at this size)
     if r2:
-      p = parity.r2d2_step(dev, T1=T + 1, B=min(B, 4), A=A, truth=False)
+      p = parity.r2d2_step(dev, T1=T + 1, B=B, A=A, truth=False)
     elif deep:
-      p = parity.deep_step(dev, T1=T + 1, B=min(B, 16), A=A, truth=False)
+      p = parity.deep_step(dev, T1=T + 1, B=B, A=A, truth=False)
     else:
       p = parity.atari_step(dev, T1=T + 1, B=B, A=A, torso=args.torso, truth=False)
     result['parity'] = dict(parity.public(p), note=PARITY_NOTE)
@@ -490,8 +580,16 @@ def main():
               roofline={k: r['roofline'][k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
                                                       'frac_free_running', 'avg_kernel_ms')},
               loss=round(r['loss'], 6))
+          # one train step at THAT shape against the CPU oracle (tests/test_gpu_fullsize.py runs the same comparison)
+          pf = parity.deep_step if cfg == 'dmlab' else parity.r2d2_step
+          pr = parity.public(pf(dev, T1=r['T'] + 1, B=r['B'], A=r['A'], truth=False))
+          others[name]['parity'] = {k: pr[k] for k in (
+              'loss', 'loss_ref', 'loss_rel_err', 'logits_max_abs_err', 'baseline_max_abs_err', 'q_max_abs_err',
+              'priority_max_rel_err', 'grad_q99_rel_err', 'grad_max_rel_err', 'grad_worst', 'grad_norm_rel_err',
+              'param_max_abs_err', 'oracle_s', 'shape') if k in pr}
+          _release()
         except Exception as e:                   # pylint: disable=broad-except
-          others[name] = dict(error=repr(e))
+          others[name] = dict(others.get(name, {}), error=repr(e))
       result['other_configs'] = others
       try:
         result['inference'] = inference_record(dev)
@@ -506,21 +604,24 @@ def main():
   if world == 1 and not args.no_cpu_baseline and not args.quick:
     from oracle import cpu_learner
     T1 = T + 1
+    # BASELINE.md section 3 protocol: 3 warm-up steps, median of >= 10 timed steps, all host cores
+    CW, CS = 3, 10
     if r2:
-      cb = args.cpu_batch if args.cpu_batch != 64 else 8
-      fps, sec, thr = cpu_learner.time_cpu_r2d2_learner(A, T1, cb, steps=2, warmup=1)
+      cb = args.cpu_batch or 8
+      fps, sec, thr = cpu_learner.time_cpu_r2d2_learner(A, T1, cb, steps=CS, warmup=CW)
     elif deep:
-      cb = args.cpu_batch if args.cpu_batch != 64 else 16
-      fps, sec, thr = cpu_learner.time_cpu_deep_learner(A, T1, cb, steps=2, warmup=1)
+      cb = args.cpu_batch or 16
+      fps, sec, thr = cpu_learner.time_cpu_deep_learner(A, T1, cb, steps=CS, warmup=CW)
     else:
-      cb = args.cpu_batch
+      cb = args.cpu_batch or 256
       kind = 'atari_shallow' if args.torso == 'shallow' else 'atari_dqn_body'
-      fps, sec, thr = cpu_learner.time_cpu_learner(kind, A, T1, cb, steps=5, warmup=2)
+      fps, sec, thr = cpu_learner.time_cpu_learner(kind, A, T1, cb, steps=CS, warmup=CW)
     result['cpu_baseline'] = {
         'value': round(fps, 1), 'unit': 'env-frames/s', 'cores': thr, 'kind': 'port',
         'sample': 'same learner step as eager PyTorch-CPU fp32 restatement of the reference graph '
-                  '(oracle/cpu_learner.py; NOT the reference\'s TF graph), T=%d B=%d (per-frame cost is B-independent), '
-                  'median of timed steps, %.2f s/step; host cpu_count=%d' % (T, cb, sec, os.cpu_count())}
+                  '(oracle/cpu_learner.py; NOT the reference\'s TF graph), T=%d B=%d (a bounded sample of the workload: whole columns, same T), '
+                  '%d warm-up steps then the median of %d timed steps (BASELINE.md section 3), %.2f s/step; '
+                  'host cpu_count=%d, torch threads=%d' % (T, cb, CW, CS, sec, os.cpu_count(), thr)}
     result['speedup_vs_cpu_baseline'] = round(rec['frames_per_s'] / fps, 1)
   print(json.dumps(result))
   if distributed:

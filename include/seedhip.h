@@ -26,7 +26,12 @@
 extern "C" {
 #endif
 
-#define SEEDHIP_ABI_VERSION 1
+/* Bumped whenever an EXISTING entry point changes its signature or a *_workspace_bytes() contract changes (new entry
+ * points alone do not bump it: a missing symbol already fails at load).  History: 1 = round 1; 2 = round 2
+ * (seedhip_adam_flat*, seedhip_inference_pre/post signatures, impala-loss workspace size); 3 = round 3.
+ * Bindings must compare seedhip_abi_version() with the version they were written against before the first call
+ * (seed_rl_amd/_lib.py does): a stale library would otherwise be called with shifted arguments. */
+#define SEEDHIP_ABI_VERSION 3
 
 const char* seedhip_last_error(void);
 int seedhip_abi_version(void);

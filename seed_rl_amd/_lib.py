@@ -14,6 +14,7 @@ import torch  # noqa: F401  pylint: disable=unused-import
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libseedhip.so')
+ABI_VERSION = 3          # include/seedhip.h SEEDHIP_ABI_VERSION this binding was written against
 
 c_int, c_ll, c_float, c_size_t, c_void_p = (
     ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p)
@@ -135,6 +136,11 @@ def lib():
       fn = getattr(l, name)            # AttributeError if the symbol is missing
       fn.restype = res
       fn.argtypes = args
+    have = l.seedhip_abi_version()
+    if have != ABI_VERSION:
+      raise SeedHipError('%s reports ABI version %d but this binding was written against %d: the library is stale '
+                         '(run `python -m seed_rl_amd.build`); calling it would pass shifted arguments.'
+                         % (LIB_PATH, have, ABI_VERSION))
     _lib = l
   return _lib
 

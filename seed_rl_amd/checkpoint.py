@@ -56,7 +56,10 @@ def restore(path, agent, optimizer=None, strict=True, target_agent=None, learner
   """Loads what `save` wrote.  strict=False: parameters only are required (e.g. arrays exported from a reference
   checkpoint); the optimizer then starts fresh.  (TensorFlow checkpoint files: seed_rl_amd/tf_checkpoint.py.)"""
   data = np.load(_npz(path))
-  agent.load_reference_params(dict((n, data['agent/' + n]) for n, _, _ in agent._ref_spec   # pylint: disable=protected-access
+  names = [n for n, _, _ in agent._ref_spec]                          # pylint: disable=protected-access
+  if 'agent/entropy_cost_param' in data.files and 'entropy_cost_param' not in names:
+    names.append('entropy_cost_param')                                # agent not (yet) attached to a Learner
+  agent.load_reference_params(dict((n, data['agent/' + n]) for n in names
                                    if 'agent/' + n in data.files or n != 'entropy_cost_param'))
   if target_agent is not None and any(k.startswith('target_agent/') for k in data.files):
     target_agent.load_reference_params(dict((n, data['target_agent/' + n]) for n, _, _ in target_agent._ref_spec))   # pylint: disable=protected-access
@@ -74,6 +77,8 @@ def restore(path, agent, optimizer=None, strict=True, target_agent=None, learner
   if any(k.startswith('adam_m/') for k in data.files):
     for key, buf in (('adam_m/', m), ('adam_v/', v)):
       for name, view in _ref_views(agent, buf).items():
+        if name == 'entropy_cost_param' and key + name not in data.files:
+          continue                  # checkpoint written without the learnable entropy cost: its moments start at zero
         view.copy_(torch.as_tensor(data[key + name]).to(buf.device).reshape(view.shape))
     optimizer.load_state_dict(dict(iterations=int(data['iterations']), m=m, v=v))
   else:

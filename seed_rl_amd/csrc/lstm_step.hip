@@ -625,11 +625,11 @@ extern "C" int seedhip_lstm_step_fwd(const float* hin, const float* up, const fl
   p.hin = hin; p.up = up; p.zx = zx; p.cin = cin; p.done_next = done_next; p.B = B; p.H = H;
   p.z = z; p.h_out = h_out; p.ld_h = ld_h; p.hin_next = hin_next; p.cin_next = cin_next;
   const size_t lds = (size_t)kWaves * kWaveFloats * sizeof(float);                     // 104 KB: one workgroup per CU
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)lstm_step_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  // once per process, thread-safe (C++11 static initialisation): the ABI is called from the inference pool and the
+  // training thread concurrently
+  static const hipError_t attr_rc =
+      hipFuncSetAttribute((const void*)lstm_step_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)attr_rc;
   hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3(((B + kRows - 1) / kRows) * (H / kUnits)), dim3(64 * kWaves), lds,
                      (hipStream_t)stream, p);
   return seedhip::check_launch("lstm_step_fwd_kernel");
@@ -668,14 +668,12 @@ extern "C" int seedhip_lstm_seq_fwd(const float* up, const float* zx, const uint
   SeqParams p;
   p.up = up; p.zx = zx; p.done = done; p.T1 = T1; p.B = B; p.H = H; p.z = z; p.h_out = h_out; p.ld_h = ld_h;
   p.hin = hin; p.cin = cin; p.abort_flag = (int*)sync_ws + 1;
-  { const char* e = getenv("SEEDHIP_LSTM_SEQ_FAULT"); p.fault = e ? atoi(e) : 0; }   // tests: exercise the bounded wait
+  { const char* e = getenv("SEEDHIP_LSTM_SEQ_FAULT"); p.fault = e ? atoi(e) : 0; }   // tests: exercise the bounded wait (read per call on purpose: tests flip it)
   { static const int x = getenv("SEEDHIP_LSTM_SEQ_XCD") ? atoi(getenv("SEEDHIP_LSTM_SEQ_XCD")) : 1; p.xcd_local = x; }
   const size_t lds = seq_lds_bytes(H);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_lds_bytes(512));
-    attr_set = true;
-  }
+  static const hipError_t attr_rc = hipFuncSetAttribute(
+      (const void*)lstm_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_lds_bytes(512));
+  (void)attr_rc;
   {
     const long long n16 = (long long)T1 * B * H / 4;       // H % 128 == 0: whole 16-byte words
     long long blocks = (n16 + 255) / 256; if (blocks > 2048) blocks = 2048;
@@ -700,11 +698,9 @@ size_t seq_bwd_ring_bytes(int B, int H) {
 template <int NT>
 int launch_seq_bwd(const SeqBwdParams& p, int grid, hipStream_t stream) {
   const size_t lds = seq_bwd_lds_bytes(64 * NT);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static const hipError_t attr_rc =        // one static per NT instantiation
+      hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)attr_rc;
   hipLaunchKernelGGL(lstm_seq_bwd_kernel<NT>, dim3(grid), dim3(64 * kWaves), lds, stream, p);
   return seedhip::check_launch("lstm_seq_bwd_kernel");
 }

@@ -179,6 +179,9 @@ class Learner(object):
     if self.world <= 1 or hi <= lo:
       return
     if self.agent.flat.grads.is_cuda and torch.cuda.is_current_stream_capturing():
+      cut = getattr(self, '_capture_cut', None)          # GraphedStep (data parallel): end this graph segment here
+      if cut is not None:
+        cut(lo, hi)
       return
     work = torch.distributed.all_reduce(self.agent.flat.grads[lo:hi], op=torch.distributed.ReduceOp.SUM,
                                         group=self.pg, async_op=True)
@@ -221,13 +224,16 @@ class Learner(object):
 class GraphedStep(object):
   """Captures a train step ONCE into HIP graphs and replays it: the ~25 (Atari) to ~600 (R2D2) kernel launches
   of a step become one graph launch, removing the host-side launch gaps (HIP graphs in place of the reference's
-  tf.function / XLA step).  Single replica: one graph for the whole step.  Data parallel: graph 1 =
-  compute_gradients, then the RCCL all-reduce launched eagerly, then graph 2 = optimizer update.
+  tf.function / XLA step).  Single replica: one graph for the whole step.  Data parallel: compute_gradients is captured
+  as a CHAIN of graphs cut where the agent reports a range of the gradient bucket as final (`grad_ready_hook`, at most
+  `max_cuts` cuts): after replaying a segment its range's all-reduce is launched asynchronously on RCCL's stream and the
+  next segment (the rest of the backward pass) replays under it; whatever was not exchanged by then is exchanged after
+  the last segment, then the update graph replays -- the same overlap as the eager path, without its launch gaps.
   The unroll's tensors are the graph's static inputs: copy new trajectories into them (the unroll store can
   write completed unrolls straight into these buffers) and call the object.  Needs an optimizer created with
   capturable=True; everything else on the step is already free of host reads."""
 
-  def __init__(self, learner, unroll, *extra, warmup=2):
+  def __init__(self, learner, unroll, *extra, warmup=2, max_cuts=1):
     if not getattr(learner.optimizer, 'capturable', False):
       raise ValueError('GraphedStep needs optimizers.Adam(..., capturable=True)')
     self.learner, self.unroll, self.extra = learner, unroll, extra
@@ -258,11 +264,41 @@ class GraphedStep(object):
         self.outputs = learner.compute_gradients(unroll, *extra)
         learner.update()
     else:
-      with torch.cuda.graph(self.graph, capture_error_mode='relaxed'):
-        self.outputs = learner.compute_gradients(unroll, *extra)
-      self.graph2 = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(self.graph2, capture_error_mode='relaxed'):
-        learner.update()
+      # segments: [(graph, (lo, hi) | None)] -- the range to exchange asynchronously once that segment has replayed
+      self.segments = []
+      pool = torch.cuda.graph_pool_handle()
+      cap = torch.cuda.Stream()
+      state = dict(graph=self.graph, cuts=0)
+
+      def cut(lo, hi):
+        if state['cuts'] >= max_cuts or hi <= lo:
+          return
+        state['cuts'] += 1
+        state['graph'].capture_end()
+        self.segments.append((state['graph'], (lo, hi)))
+        state['graph'] = torch.cuda.CUDAGraph()
+        state['graph'].capture_begin(pool=pool, capture_error_mode='relaxed')
+      torch.cuda.synchronize()
+      cap.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(cap):
+        self.graph.capture_begin(pool=pool, capture_error_mode='relaxed')
+        learner._capture_cut = cut if hasattr(learner, '_on_grads_ready') else None
+        ok = False
+        try:
+          self.outputs = learner.compute_gradients(unroll, *extra)
+          ok = True
+        finally:
+          learner._capture_cut = None
+          if ok or torch.cuda.is_current_stream_capturing():
+            state['graph'].capture_end()
+        self.segments.append((state['graph'], None))
+        self.graph2 = torch.cuda.CUDAGraph()
+        self.graph2.capture_begin(pool=pool, capture_error_mode='relaxed')
+        try:
+          learner.update()
+        finally:
+          self.graph2.capture_end()
+      torch.cuda.current_stream().wait_stream(cap)
     # undo the warm-up (in place: the graphs hold these buffers' addresses); the capture itself ran only the Python
     # bookkeeping, not the kernels
     for a, p0 in zip(agents, saved_params):
@@ -278,14 +314,22 @@ class GraphedStep(object):
     for k, v in counters.items():
       setattr(learner, k, v)
     self._agents = agents
+    self.exchange = True          # bench.py clears it for a few steps to price the EXPOSED part of the exchange
     torch.cuda.synchronize()
 
   def __call__(self):
     opt = self.learner.optimizer
     opt.begin_step()
-    self.graph.replay()
-    if self.split:
-      self.learner.reduce_gradients()
+    if not self.split:
+      self.graph.replay()
+    else:
+      lrn = self.learner
+      for g, rng in self.segments:
+        g.replay()
+        if rng is not None and self.exchange:
+          lrn._on_grads_ready(*rng)               # asynchronous: flies under the next segment
+      if self.exchange:
+        lrn.reduce_gradients()                    # waits for those, exchanges the rest
       self.graph2.replay()
     opt.iterations += 1
     post = getattr(self.learner, 'after_graph_replay', None)

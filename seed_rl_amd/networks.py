@@ -117,12 +117,16 @@ class _Agent(object):
     [-20/speed, 20/speed]; entropy_cost() = exp(speed * param).  The parameter is one more element of the flat buffer
     (Adam and the gradient all-reduce see it like any other), its constraint is applied by the Adam kernel."""
     mul = np.float32(adjustment_speed)
-    if self._ec_speed is None:
-      self._ref_spec = list(self._ref_spec) + [('entropy_cost_param', (1,), 'zeros')]
+    self._ensure_entropy_cost_in_spec()
     self._ec_speed = float(mul)
-    with torch.no_grad():
-      self.flat.p('entropy_cost_param').fill_(float(np.log(np.float32(entropy_cost)) / mul))
+    if not getattr(self, '_ec_loaded', False):       # a value restored from a checkpoint BEFORE the learner existed stays
+      with torch.no_grad():
+        self.flat.p('entropy_cost_param').fill_(float(np.log(np.float32(entropy_cost)) / mul))
     self.flat.constraint = (self.flat.offsets['entropy_cost_param'], float(-20.0 / mul), float(20.0 / mul))
+
+  def _ensure_entropy_cost_in_spec(self):
+    if not any(n == 'entropy_cost_param' for n, _, _ in self._ref_spec):
+      self._ref_spec = list(self._ref_spec) + [('entropy_cost_param', (1,), 'zeros')]
 
   def entropy_cost_param(self):
     """(param, d_param, speed) device scalars of the attached learnable entropy cost, or None."""
@@ -141,6 +145,11 @@ class _Agent(object):
   def load_reference_params(self, values):
     """values: {reference variable name: numpy array} (Keras layouts)."""
     A = self._num_actions
+    if 'entropy_cost_param' in values and 'entropy_cost_param' in self.flat.offsets and not self.has_own_entropy_cost():
+      # a checkpoint of a learner with the learnable entropy cost, restored in ANY order relative to Learner():
+      # the value is kept by a later attach_entropy_cost_param() and its Adam slots are addressable from now on
+      self._ensure_entropy_cost_in_spec()
+      self._ec_loaded = True
     with torch.no_grad():
       for name, shape, _ in self._ref_spec:
         if name == 'entropy_cost_param' and name not in values:

@@ -1,8 +1,11 @@
 """Reader / writer of TensorFlow checkpoint files (the "tensor bundle" that tf.train.Checkpoint / CheckpointManager
 write) and the variable-name map of the reference agents -- SURVEY.md 8(f) rank 4: a reference checkpoint
 (/root/reference/agents/vtrace/learner.py:286-296: tf.train.Checkpoint(agent=agent, optimizer=optimizer);
-agents/r2d2/learner.py:646-647: + target_agent) can be loaded into the agents here, and agents here can be saved for
-the reference to restore.
+agents/r2d2/learner.py:646-647: + target_agent) can be loaded into the agents here.  The WRITER emits the same keys,
+dtypes and shapes for the VARIABLE_VALUE tensors but NOT the serialized TrackableObjectGraph that TensorFlow stores
+under `_CHECKPOINTABLE_OBJECT_GRAPH` and that tf.train.Checkpoint.restore() walks: files written here round-trip
+through this module (and are readable tensor by tensor with tf.train.load_checkpoint), they are not a drop-in for
+Checkpoint.restore().
 
 Format (TF 2.4.1; no TensorFlow in this image, so restated from its published sources and NOT checked against a
 TF-written file -- "format unpinned"; the writer and the reader here round-trip, tests/test_tf_checkpoint.py):
@@ -313,11 +316,11 @@ def restore_agent(prefix, agent, root='agent', optimizer=None, optimizer_root='o
   tensors = read_checkpoint(prefix)
   paths = reference_variable_paths(agent)
   values = {}
+  ec_key = '%s/entropy_cost_param%s' % (root, _SUFFIX)
+  if ec_key in tensors:                               # whether or not a Learner has attached the parameter yet
+    values['entropy_cost_param'] = np.asarray(tensors[ec_key]).reshape(1)
   for name, _, _ in agent._ref_spec:                  # pylint: disable=protected-access
     if name == 'entropy_cost_param':
-      key = '%s/entropy_cost_param%s' % (root, _SUFFIX)
-      if key in tensors:
-        values[name] = tensors[key].reshape(1)
       continue
     key = '%s/%s%s' % (root, paths[name], _SUFFIX)
     if key not in tensors:
@@ -346,7 +349,10 @@ def save_agent(prefix, agent, root='agent', optimizer=None, optimizer_root='opti
   paths = reference_variable_paths(agent)
   tensors = dict(extra or {})
   for name, view in agent.trainable_variables:
-    tensors['%s/%s%s' % (root, paths.get(name, name), _SUFFIX)] = view.detach().cpu().numpy()
+    a = view.detach().cpu().numpy()
+    if name == 'entropy_cost_param':
+      a = a.reshape(())                               # a scalar variable in the reference (learner.py:225-234)
+    tensors['%s/%s%s' % (root, paths.get(name, name), _SUFFIX)] = a
   if optimizer is not None:
     sd = optimizer.state_dict()
     tensors['%s/iter%s' % (optimizer_root, _SUFFIX)] = np.asarray(sd['iterations'], np.int64)
@@ -354,6 +360,7 @@ def save_agent(prefix, agent, root='agent', optimizer=None, optimizer_root='opti
       for slot, buf in (('m', sd['m']), ('v', sd['v'])):
         for name, view in ckpt._ref_views(agent, buf).items():   # pylint: disable=protected-access
           key = '%s/%s/.OPTIMIZER_SLOT/%s/%s%s' % (root, paths.get(name, name), optimizer_root, slot, _SUFFIX)
-          tensors[key] = view.detach().cpu().numpy()
+          a = view.detach().cpu().numpy()
+          tensors[key] = a.reshape(()) if name == 'entropy_cost_param' else a
   write_checkpoint(prefix, tensors)
   return sorted(tensors)

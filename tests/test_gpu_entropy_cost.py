@@ -111,3 +111,66 @@ def test_adam_clamp_index(device):
     assert abs(out[idx] + 0.25) < 1e-7
     rest = np.delete(out, idx)
     assert np.all(np.abs(rest + 31.6227) < 1e-2), rest[:4]       # lr_t * g / sqrt((1 - b2) g^2)
+
+
+@pytest.mark.parametrize('fmt', ['npz', 'tf'])
+def test_entropy_cost_restore_is_order_independent(device, tmp_path, fmt):
+  """restoring a checkpoint that holds the learnable entropy cost BEFORE a Learner has attached the
+  parameter must keep the value and its Adam moments (it used to be skipped silently and re-initialised to
+  log(cfg.entropy_cost)/speed); an attached agent restoring a checkpoint WITHOUT the parameter's Adam slots must not
+  raise (agents/vtrace/learner.py:225-234, 286-296)."""
+  from seed_rl_amd import checkpoint, learner, networks, optimizers, smoke_step, tf_checkpoint as tc
+  from seed_rl_amd import parametric_distribution as pd
+  A, speed = 6, 10.0
+  cfg = learner.LossConfig(entropy_cost=0.01, target_entropy=0.5, entropy_cost_adjustment_speed=speed)
+
+  def make(seed):
+    cls = networks.AtariShallow if fmt == 'npz' else networks.ImpalaDeep
+    kw = {} if fmt == 'npz' else dict(observation_shape=(24, 32, 3))
+    return cls(A, device=device, seed=seed, **kw)
+  agent = make(0)
+  opt = optimizers.Adam(1e-2, beta_1=0.9, epsilon=3.125e-7)
+  lrn = learner.Learner(agent, opt, pd.categorical_distribution(A), config=cfg)
+  mk = smoke_step.make_unroll if fmt == 'npz' else smoke_step.make_deep_unroll
+  unroll = mk(agent, 6, 8, A, device, seed=1)
+  for _ in range(2):
+    lrn.minimize(unroll)
+  want = float(agent.flat.p('entropy_cost_param')[0])
+  o = agent.flat.offsets['entropy_cost_param']
+  want_m = float(opt.state_dict()['m'][o])
+  assert want != float(np.log(np.float32(0.01)) / np.float32(speed)) and want_m != 0.0
+  path = str(tmp_path / 'ck')
+  if fmt == 'npz':
+    checkpoint.save(path, agent, opt)
+  else:
+    tc.save_agent(path, agent, optimizer=opt)
+    assert tc.read_checkpoint(path)['agent/entropy_cost_param/.ATTRIBUTES/VARIABLE_VALUE'].shape == ()   # a scalar
+
+  # (1) restore FIRST, attach afterwards
+  agent2 = make(7)
+  opt2 = optimizers.Adam(1e-2, beta_1=0.9, epsilon=3.125e-7)
+  if fmt == 'npz':
+    checkpoint.restore(path, agent2, opt2)
+  else:
+    tc.restore_agent(path, agent2, optimizer=opt2)
+  lrn2 = learner.Learner(agent2, opt2, pd.categorical_distribution(A), config=cfg)
+  assert float(agent2.flat.p('entropy_cost_param')[0]) == want
+  assert float(opt2.state_dict()['m'][o]) == want_m
+  assert agent2.entropy_cost_param() is not None and lrn2 is not None
+  torch.testing.assert_close(agent2.flat.params, agent.flat.params, rtol=0, atol=0)
+
+  # (2) attached agent, checkpoint without the parameter (and without its Adam slots)
+  if fmt == 'npz':
+    plain = make(3)
+    popt = optimizers.Adam(1e-2, beta_1=0.9, epsilon=3.125e-7)
+    plrn = learner.Learner(plain, popt, pd.categorical_distribution(A),
+                           config=learner.LossConfig(entropy_cost=0.01))
+    plain._ref_spec = [e for e in plain._ref_spec if e[0] != 'entropy_cost_param']     # written by a round-1 learner
+    plrn.minimize(unroll)
+    path2 = str(tmp_path / 'old')
+    checkpoint.save(path2, plain, popt)
+    agent3 = make(9)
+    opt3 = optimizers.Adam(1e-2, beta_1=0.9, epsilon=3.125e-7)
+    learner.Learner(agent3, opt3, pd.categorical_distribution(A), config=cfg)
+    checkpoint.restore(path2, agent3, opt3)                    # used to raise KeyError in the optimizer-slot loop
+    assert float(opt3.state_dict()['m'][o]) == 0.0

@@ -30,6 +30,18 @@ def _show(r):
   return {k: v for k, v in r.items() if k != 'grad_rel_err'}
 
 
+def _record(name, r):
+  """Prints the numbers (pytest -s / the captured log) and, when gpurun_out/ exists, keeps them as JSON."""
+  import json
+  import os
+  line = json.dumps({name: _show(r)})
+  print(line)
+  d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+  if os.path.isdir(d):
+    with open(os.path.join(d, 'fullsize_parity.jsonl'), 'a') as f:
+      f.write(line + '\n')
+
+
 def _check_params(r):
   assert r['param_frac_gt_5e5'] <= 1e-3, _show(r)
   assert r['param_max_abs_err'] <= 2.2 * LR, _show(r)
@@ -86,3 +98,30 @@ def test_cfg5_r2d2_T120_burnin40_B4(device):
   _check_grads_fp32(r, q99=1e-3, mx=2e-3)
   assert r['grad_norm_rel_err'] <= 1e-3, _show(r)
   assert r['param_max_abs_err'] <= 5e-5, _show(r)
+
+
+def test_cfg3_dmlab_T20_B256(device):
+  """BASELINE configs[2] exactly as bench.py runs it: T=20, B=256, A=9 (dmlab/networks.py:135-171).  This is the shape
+  at which the halo kernels' persistent grids, the gemm.h cost-model plans and the LSTM sequence kernels (8 row tiles x
+  32 workgroups) are benched; the fp32 oracle of the same graph takes about a minute of host time."""
+  r = parity.deep_step(device, T1=21, B=256, A=9, truth=False)
+  _record('cfg3_dmlab_T20_B256', r)
+  assert r['loss_rel_err'] <= 2e-4, _show(r)
+  assert r['logits_max_abs_err'] <= 3e-4 and r['baseline_max_abs_err'] <= 3e-4, _show(r)
+  assert r['grad_q99_rel_err'] <= 1.5e-3, _show(r)
+  assert r['grad_max_rel_err_post_pool'] <= 2e-3, _show(r)
+  assert r['grad_max_rel_err'] <= 1e-2, _show(r)
+  _check_params(r)
+
+
+def test_cfg5_r2d2_T120_burnin40_B256(device):
+  """BASELINE configs[4] exactly as bench.py runs it: T=120 (121 steps), burn-in 40, n-step 5, B=256, both networks
+  (agents/r2d2/learner.py:333-384,572-636)."""
+  r = parity.r2d2_step(device, T1=121, B=256, A=18, burn_in=40, truth=False)
+  _record('cfg5_r2d2_T120_B256', r)
+  assert r['loss_rel_err'] <= 2e-4, _show(r)
+  assert r['q_max_abs_err'] <= 5e-4, _show(r)
+  assert r['priority_max_rel_err'] <= 2e-3, _show(r)
+  _check_grads_fp32(r, q99=1e-3, mx=1e-2)
+  assert r['grad_norm_rel_err'] <= 1e-3, _show(r)
+  assert r['param_max_abs_err'] <= 1e-4, _show(r)

@@ -6,8 +6,9 @@ must equal a single-process run:
   reduction='mean': the single-replica step on the GLOBAL batch (<= 1e-6);
   reduction='sum' : the reference's cross-replica semantics (per-replica mean losses, gradients SUMMED,
                     /root/reference/tests/utils_test.py:609-650): one process that adds the two shards' gradients.
-`graphed=True` runs the same through learner.GraphedStep's SPLIT mode (graph 1 = compute_gradients, eager exchange,
-graph 2 = update).  What stays unmeasured: RCCL/xGMI itself with more than one rank (no multi-GPU box here)."""
+`graphed=True` runs the same through learner.GraphedStep's SPLIT mode (compute_gradients as a chain of graph segments
+cut where a gradient range becomes final, that range's exchange launched between them, the rest after the last segment,
+then the update graph).  What stays unmeasured: RCCL/xGMI itself with more than one rank (no multi-GPU box here)."""
 import os
 import socket
 import sys
@@ -61,6 +62,10 @@ def _worker(rank, world, port, reduction, graphed, out):
     if graphed:
       step = learner.GraphedStep(lrn, unroll, warmup=1)
       assert step.split and step.graph2 is not None
+      # compute_gradients is cut where the agent reports the Dense + heads range as final: that range's exchange is
+      # launched between the two segments and flies under the conv backward
+      fl = agent.flat
+      assert [r for _, r in step.segments] == [(fl.offsets['fc/kernel'], fl.size), None], step.segments
       for _ in range(STEPS):
         step()
     else:
