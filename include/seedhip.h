@@ -374,6 +374,20 @@ int seedhip_replay_sample(const float* priorities, long long limit, float priori
                           float importance_sampling_exponent, const float* uniforms, int num_samples,
                           long long* indices, float* weights, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- R2D2 actor-side exploration and replay <-> time-major batch -----------------------------------
+ * seedhip_epsilon_greedy replaces apply_epsilon_greedy of agents/r2d2/learner.py:147-177: actions[i] (int64, in
+ * place) becomes a uniform random action in [0, num_actions) with probability epsilons[env_ids[i]] (the caller's
+ * per-environment table = get_envs_epsilon, :129-145: 0.4^linspace(1, 8, num_training_envs) ++ eval_epsilon); ids out
+ * of [0, num_envs) keep their action.  Randoms: Philox4x32-10 keyed by rng_state[0] = seed, rng_state[1] = call
+ * counter (advanced by this call); replaced u8[n] (may be NULL) records which rows were replaced. */
+int seedhip_epsilon_greedy(long long* actions, const long long* env_ids, const float* epsilons, int n, int num_envs,
+                           int num_actions, unsigned long long* rng_state, uint8_t* replaced, void* stream);
+/* Row indices for moving unrolls between replay rows [slot][t] and a TIME-MAJOR batch [t][column] with ONE row move
+ * per field (utils.make_time_major of agents/r2d2/learner.py:453-457 folded into PrioritizedReplay's gather /
+ * scatter): for k = t * num_unrolls + b: replay_rows[k] = slots[b] * steps + t, batch_rows[k] = k. */
+int seedhip_replay_time_rows(const long long* slots, int num_unrolls, int steps, long long* replay_rows,
+                             long long* batch_rows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,3 +115,67 @@ extern "C" int seedhip_replay_sample(const float* priorities, long long limit, f
   hipLaunchKernelGGL(replay_normalize_kernel, dim3(1), dim3(256), 0, s, weights, num_samples);
   return seedhip::check_launch("replay_sample");
 }
+
+// ---- R2D2 actor-side exploration and the replay's time-major row indices ----------------------------------------- //
+namespace {
+// apply_epsilon_greedy (agents/r2d2/learner.py:147-177): with probability epsilons[env_id] the action is replaced by a
+// uniform random one.  Two Philox randoms per row, keyed like the categorical sampler (seed, call counter, row).
+__global__ void __launch_bounds__(256)
+epsilon_greedy_kernel(long long* __restrict__ actions, const long long* __restrict__ env_ids,
+                      const float* __restrict__ epsilons, int n, int num_envs, int num_actions,
+                      const unsigned long long* __restrict__ rng, uint8_t* __restrict__ replaced) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long seed = rng[0], call = rng[1];
+  const uint4 r = seedhip::philox4x32_10(make_uint4((uint32_t)call, (uint32_t)(call >> 32), (uint32_t)i, 0x45505347u),
+                                         make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+  const long long id = env_ids[i];
+  const float eps = (id >= 0 && id < num_envs) ? epsilons[id] : 0.0f;
+  const float prob = (float)(r.x >> 8) * (1.0f / 16777216.0f);                 // U[0,1): tf.random.uniform(shape)
+  // tf.random.uniform(maxval=num_actions, dtype=int32): uniform over [0, num_actions)
+  const int random_action = (int)(((unsigned long long)r.y * (unsigned long long)num_actions) >> 32);
+  const bool take = prob < eps;                                                  // tf.where(probs < epsilons, random, actions)
+  if (take) actions[i] = random_action;
+  if (replaced) replaced[i] = take ? 1 : 0;
+}
+__global__ void rng_advance1_kernel(unsigned long long* rng) { rng[1] += 1; }
+
+// Row indices that move unrolls between the replay's [slot][t] rows and a time-major [t][column] batch in ONE pass
+// (utils.make_time_major of agents/r2d2/learner.py:453-457 folded into the gather): k = t * B + b ->
+// replay_rows[k] = slots[b] * T1 + t, batch_rows[k] = k.
+__global__ void __launch_bounds__(256)
+replay_time_rows_kernel(const long long* __restrict__ slots, int B, int T1, long long* __restrict__ replay_rows,
+                        long long* __restrict__ batch_rows) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= B * T1) return;
+  const int t = k / B, b = k - t * B;
+  replay_rows[k] = slots[b] * T1 + t;
+  batch_rows[k] = k;
+}
+}  // namespace
+
+extern "C" int seedhip_epsilon_greedy(long long* actions, const long long* env_ids, const float* epsilons, int n,
+                                      int num_envs, int num_actions, unsigned long long* rng_state, uint8_t* replaced,
+                                      void* stream) {
+  SEEDHIP_REQUIRE(n >= 0 && num_envs >= 1 && num_actions >= 1, "epsilon_greedy: bad sizes");
+  SEEDHIP_REQUIRE(rng_state, "epsilon_greedy: null rng_state");
+  hipStream_t s = (hipStream_t)stream;
+  if (n > 0) {
+    SEEDHIP_REQUIRE(actions && env_ids && epsilons, "epsilon_greedy: null pointer");
+    hipLaunchKernelGGL(epsilon_greedy_kernel, dim3(seedhip::cdiv(n, 256)), dim3(256), 0, s, actions, env_ids, epsilons,
+                       n, num_envs, num_actions, rng_state, replaced);
+  }
+  hipLaunchKernelGGL(rng_advance1_kernel, dim3(1), dim3(1), 0, s, rng_state);
+  return seedhip::check_launch("epsilon_greedy_kernel");
+}
+
+extern "C" int seedhip_replay_time_rows(const long long* slots, int num_unrolls, int steps, long long* replay_rows,
+                                        long long* batch_rows, void* stream) {
+  SEEDHIP_REQUIRE(num_unrolls >= 0 && steps >= 1, "replay_time_rows: bad sizes");
+  if (num_unrolls == 0) return SEEDHIP_OK;
+  SEEDHIP_REQUIRE(slots && replay_rows && batch_rows, "replay_time_rows: null pointer");
+  SEEDHIP_REQUIRE((long long)num_unrolls * steps < (1LL << 31), "replay_time_rows: too many rows");
+  hipLaunchKernelGGL(replay_time_rows_kernel, dim3(seedhip::cdiv((long long)num_unrolls * steps, 256)), dim3(256), 0,
+                     (hipStream_t)stream, slots, num_unrolls, steps, replay_rows, batch_rows);
+  return seedhip::check_launch("replay_time_rows_kernel");
+}

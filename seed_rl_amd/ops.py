@@ -542,3 +542,18 @@ def replay_sample(priorities, limit, priority_exp, is_exp, uniforms, indices, we
 
 def replay_sample_workspace_bytes(limit):
   return int(_lib.lib().seedhip_replay_sample_workspace_bytes(limit))
+
+
+def epsilon_greedy(actions, env_ids, epsilons, num_actions, rng_state, replaced=None):
+  """apply_epsilon_greedy (agents/r2d2/learner.py:147-177) in place on int64 actions; advances rng_state[1]."""
+  with _dev(actions):
+    _lib.check(_lib.lib().seedhip_epsilon_greedy(
+        _lib.ptr(actions), _lib.ptr(env_ids), _lib.ptr(epsilons), actions.numel(), epsilons.numel(), int(num_actions),
+        _lib.ptr(rng_state), _lib.ptr(replaced), _lib.stream()), 'seedhip_epsilon_greedy')
+
+
+def replay_time_rows(slots, steps, replay_rows, batch_rows):
+  """Row indices moving `slots.numel()` unrolls of `steps` steps between replay rows and a time-major batch."""
+  with _dev(slots):
+    _lib.check(_lib.lib().seedhip_replay_time_rows(_lib.ptr(slots), slots.numel(), int(steps), _lib.ptr(replay_rows),
+                                                   _lib.ptr(batch_rows), _lib.stream()), 'seedhip_replay_time_rows')
