@@ -260,13 +260,17 @@ def inference_signature(n, observation_shape, observation_dtype=np.uint8):
 
 
 def bind_inference(server, fused_states, inference_batch_size, observation_shape, action_dtype=np.int64, num_slots=4,
-                   observation_dtype=np.uint8, stream=None, on_batch=None):
+                   observation_dtype=np.uint8, stream=None, gate=None, lock=None):
   """Binds `inference(env_ids, run_ids, env_outputs, raw_rewards) -> actions`, one instance per FusedInferenceState
   (the reference's one-per-inference-device list, round-robin: learner.py:406-414).  Each slot is ONE pinned byte
   buffer in `inference.request_layout` (the C++ side writes every argument at its offset, env ids widened to int64)
   plus the pinned observations: a filled batch costs two H2D copies, one HIP-graph replay and one D2H of the actions,
   all on `stream` (default: a high-priority stream per state, so that inference runs beside the train step instead of
-  queueing behind it).  `on_batch(state)`: called after every batch (the learner's hand-over bookkeeping)."""
+  queueing behind it).  `gate` (learner_server.BatchGate): back-pressure -- `admit()` blocks while the device batch
+  could overflow (the reference blocks in unroll_queue.enqueue_many), `submitted()` / `completed(token)` keep its fill
+  estimate exact.  `lock`: held
+  while a batch is SUBMITTED to the stream (not while it runs): a training thread that dequeues completed unrolls on
+  the same stream takes it too, so that its count read and column moves are not interleaved with a batch."""
   import torch
   from seed_rl_amd import inference as inf
   n = inference_batch_size
@@ -294,13 +298,22 @@ def bind_inference(server, fused_states, inference_batch_size, observation_shape
                for k in range(num_slots)]
     out_ptrs = [[(act[k].data_ptr() if np.dtype(action_dtype) == np.int64 else out[k].ctypes.data)] for k in range(num_slots)]
 
-    def compute(slot, graphed=graphed, req=req, obs=obs, act=act, out=out, st=st, s_inf=s_inf):
-      with torch.cuda.device(st.device), torch.cuda.stream(s_inf):
-        actions = graphed.replay_packed(req[slot], obs[slot])
-        act[slot].copy_(actions, non_blocking=True)
-        if on_batch is not None:
-          on_batch(st)
-      s_inf.synchronize()                            # the actions are on the host: the callers can be answered
+    st_lock = lock if lock is not None else threading.Lock()
+    done = [torch.cuda.Event() for _ in range(num_slots)]
+
+    def compute(slot, graphed=graphed, req=req, obs=obs, act=act, out=out, st=st, s_inf=s_inf, st_lock=st_lock,
+                done=done):
+      if gate is not None:
+        gate.admit()
+      with st_lock:
+        with torch.cuda.device(st.device), torch.cuda.stream(s_inf):
+          actions = graphed.replay_packed(req[slot], obs[slot])
+          act[slot].copy_(actions, non_blocking=True)
+          token = gate.submitted() if gate is not None else None
+          done[slot].record(s_inf)
+      done[slot].synchronize()                       # the actions are on the host: the callers can be answered
+      if gate is not None:
+        gate.completed(token)
       if np.dtype(action_dtype) != np.int64:
         out[slot][...] = act[slot].numpy()
     fids.append(server.bind_buffers('inference', in_specs, out_specs, num_slots, in_ptrs, out_ptrs, compute,

@@ -677,7 +677,8 @@ class Client(object):
 # --------------------------------------------------------------------------------------------------------------------- #
 # The inference function of the learner behind the service (learner.py:339-405).
 # --------------------------------------------------------------------------------------------------------------------- #
-def bind_inference(server, fused_states, inference_batch_size, observation_shape, action_dtype=np.int64, lock=None):
+def bind_inference(server, fused_states, inference_batch_size, observation_shape, action_dtype=np.int64, lock=None,
+                   observation_dtype=np.uint8, stream=None, gate=None):
   """Binds `inference(env_ids, run_ids, env_outputs, raw_rewards) -> actions` with the reference's input signature
   (learner.py:339-349: env_id int32, run_id int64, EnvOutput(reward f32, done bool, observation uint8 [...], abandoned
   bool, episode_step int32), raw_reward f32 -- every spec with the leading inference_batch_size dimension), one function
@@ -690,7 +691,7 @@ def bind_inference(server, fused_states, inference_batch_size, observation_shape
   n = inference_batch_size
   sig = (TensorSpec((n,), np.int32, 'env_id'), TensorSpec((n,), np.int64, 'run_id'),
          utils.EnvOutput(TensorSpec((n,), np.float32, 'reward'), TensorSpec((n,), np.bool_, 'done'),
-                         TensorSpec((n,) + tuple(observation_shape), np.uint8, 'observation'),
+                         TensorSpec((n,) + tuple(observation_shape), observation_dtype, 'observation'),
                          TensorSpec((n,), np.bool_, 'abandoned'), TensorSpec((n,), np.int32, 'episode_step')),
          TensorSpec((n,), np.float32, 'raw_reward'))
   fns = []
@@ -698,18 +699,27 @@ def bind_inference(server, fused_states, inference_batch_size, observation_shape
     graphed = st.graphed(n, observation_shape)
     lay = inf.request_layout(n)
     req_pinned = torch.zeros(lay['bytes'], dtype=torch.uint8).pin_memory()
-    obs_pinned = torch.zeros((n,) + tuple(observation_shape), dtype=torch.uint8).pin_memory()
+    t_obs = {np.dtype(np.uint8): torch.uint8, np.dtype(np.uint16): torch.int16, np.dtype(np.int16): torch.int16,
+             np.dtype(np.float32): torch.float32}[np.dtype(observation_dtype)]       # env_output_specs' dtype
+    obs_pinned = torch.zeros((n,) + tuple(observation_shape), dtype=t_obs).pin_memory()
     st_lock = lock if lock is not None else threading.Lock()      # `lock`: one shared with a training thread (LearnerServer)
+    s_inf = stream if stream is not None else torch.cuda.current_stream(st.device)
 
     def inference(env_ids, run_ids, env_outputs, raw_rewards, graphed=graphed, req_pinned=req_pinned,
-                  obs_pinned=obs_pinned, lock=st_lock, st=st):
+                  obs_pinned=obs_pinned, lock=st_lock, st=st, s_inf=s_inf):
+      if gate is not None:
+        gate.admit()                                 # back-pressure: the device batch must have room for this call
       with lock:                                     # one batch at a time per device state
         inf.pack_request(n, env_ids, run_ids, env_outputs.reward, raw_rewards, env_outputs.done, env_outputs.abandoned,
                          env_outputs.episode_step, out=req_pinned.numpy())
-        obs_pinned.numpy()[...] = env_outputs.observation
-        with torch.cuda.device(st.device):
+        obs_pinned.numpy()[...] = np.asarray(env_outputs.observation).view(obs_pinned.numpy().dtype)
+        with torch.cuda.device(st.device), torch.cuda.stream(s_inf):
           actions = graphed.replay_packed(req_pinned, obs_pinned)
-          return actions.cpu().numpy().astype(action_dtype, copy=False)     # the D2H orders after both H2D copies
+          token = gate.submitted() if gate is not None else None
+          out = actions.cpu().numpy().astype(action_dtype, copy=False)      # the D2H orders after both H2D copies
+      if gate is not None:
+        gate.completed(token)
+      return out
     inference.__name__ = 'inference'
     fns.append(function(sig, TensorSpec((n,), action_dtype, 'action'))(inference))
   server.bind(fns)

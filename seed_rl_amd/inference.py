@@ -142,6 +142,7 @@ class FusedInferenceState(object):
     self.info_return = torch.zeros(num_envs, dtype=torch.float32, device=dev)
     self.info_raw = torch.zeros(num_envs, dtype=torch.float32, device=dev)
     field_specs = (Spec((), torch.int64), env_output_specs, agent_output_specs)
+    self._obs_dtype = env_output_specs.observation.dtype      # uint8 frames, uint16 bit planes (GFootball), float32 vectors
     mk = lambda lead: unroll_store._map_specs(
         lambda s: torch.zeros(lead + tuple(s.shape), dtype=s.dtype, device=dev), field_specs)
     self.store = mk((self.L, num_envs))                       # time-major [T+1, num_envs, ...]
@@ -269,10 +270,11 @@ class FusedInferenceState(object):
     req = torch.zeros(lay['bytes'], dtype=torch.uint8, device=dev)
     view = lambda k, dt: req[lay[k][0]:lay[k][0] + lay[k][1]].view(dt)
     si = dict(ids=view('ids', torch.int64), runs=view('runs', torch.int64), raw=view('raw', torch.float32))
-    if hasattr(self.agent, 'frames_buffer') and len(observation_shape) == 3 and observation_shape[2] == 1:
+    if hasattr(self.agent, 'frames_buffer') and len(observation_shape) == 3 and observation_shape[2] == 1 and \
+        self._obs_dtype == torch.uint8:
       obs = self.agent.frames_buffer(1, n)[3:].view((n,) + tuple(observation_shape))   # what the first conv reads
     else:
-      obs = torch.zeros((n,) + tuple(observation_shape), dtype=torch.uint8, device=dev)
+      obs = torch.zeros((n,) + tuple(observation_shape), dtype=self._obs_dtype, device=dev)
     senv = utils.EnvOutput(view('reward', torch.float32), view('done', torch.bool), obs,
                            view('abandoned', torch.bool), view('episode_step', torch.int32))
     saved = [t.clone() for t in self._state_tensors()]
@@ -285,7 +287,11 @@ class FusedInferenceState(object):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, capture_error_mode='relaxed'):
+    # a capture stream of its own: per-stream scratch (ops._splitk_ws) is then not shared with graphs captured on
+    # torch's default capture stream (the train step), so the two can replay concurrently
+    if getattr(self, '_capture_stream', None) is None:
+      self._capture_stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode='relaxed'):
       actions = self.inference(si['ids'], si['runs'], senv, si['raw'])
     for t, s in zip(self._state_tensors(), saved):          # warm-up calls must not leave traces in the tables
       t.copy_(s)
@@ -330,12 +336,15 @@ class FusedInferenceState(object):
     the first `batch_size` completed unrolls -- already time-major -- from the device batch into the learner's STATIC
     training unroll `dst` (an Unroll of [T+1, batch_size, ...] tensors + first agent states [batch_size, ...]; the input
     of a captured GraphedStep), moves the remaining completed unrolls to the front and adjusts the fill count.  Returns
-    False (nothing copied) when fewer than batch_size unrolls are complete.  One host read of the fill count; call it under
-    the same lock as `inference` when another thread serves actors."""
+    False (nothing copied) when fewer than batch_size unrolls are complete.  One host read of the fill count.
+    Call it on the stream the inference calls are submitted to (`with torch.cuda.stream(s)`: the read then orders after
+    every inference call in flight) and under the lock that serialises those submissions."""
     k = int(self.batch_count[0])
+    self.last_fill = k                               # exact fill after this call (learner_server.BatchGate)
     if k < batch_size:
       return False
     B = batch_size
+    self.last_fill = k - B
     for d, s_ in zip(utils.flatten(dst.agent_state), utils.flatten(self.batch.agent_state)):
       d.copy_(s_[:B])
       if k > B:

@@ -209,6 +209,20 @@ class _Agent(object):
   def get_action(self, *args, **kwargs):
     return self.__call__(*args, **kwargs)
 
+  def inference_twin(self):
+    """A second handle on the SAME parameters (one flat buffer: every optimizer step is visible at once, no weight
+    copy) with its OWN workspaces, activations and sampler state, for central inference on another stream beside the
+    train step -- the reference runs inference on its own devices against the shared variables
+    (agents/vtrace/learner.py:350-411).  A forward that overlaps an Adam launch may read some tensors before and some
+    after the update; the behaviour logits it returns are the ones it acted with, which is what V-trace corrects for."""
+    import copy
+    t = copy.copy(self)
+    t._ws, t._lstm_ctx, t._last = {}, {}, None
+    t._last_lstm, t._seq_flag, t._seq_event, t._rng = None, None, None, None
+    t.grad_ready_hook = None
+    t.frames_slot = 0
+    return t
+
   # -- head -------------------------------------------------------------------- #
   def _head_fwd(self, feat, rows, feat_dim, ld_feat=None):
     ldh = self._ldh

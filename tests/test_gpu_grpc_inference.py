@@ -14,8 +14,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_actors_through_grpc_into_fused_inference(device):
-  from seed_rl_amd import grpc_service as gs, inference, networks, utils
+@pytest.mark.parametrize('transport', ['python', 'native'])
+def test_actors_through_grpc_into_fused_inference(device, transport):
+  from seed_rl_amd import grpc_native as gn, grpc_service as gs, inference, networks, utils
   from seed_rl_amd.unroll_store import Spec
   T, E, A, n = 3, 8, 6, 4
   obs_shape = (84, 84, 1)
@@ -26,8 +27,12 @@ def test_actors_through_grpc_into_fused_inference(device):
   fused = inference.FusedInferenceState(agent, E, T, env_specs, ao_specs, batch_capacity=4 * E, device=device)
   path = os.path.join(tempfile.gettempdir(), 'seedrl_' + uuid.uuid4().hex[:12])
   address = 'unix:' + path
-  server = gs.Server([address])
-  gs.bind_inference(server, fused, n, obs_shape)
+  if transport == 'native':                            # libseedserve.so: pinned request_layout slots filled by the C++ side
+    server = gn.NativeServer([address], num_io_threads=2)
+    gn.bind_inference(server, fused, n, obs_shape)
+  else:
+    server = gs.Server([address])
+    gs.bind_inference(server, fused, n, obs_shape)
   server.start()
   steps = 2 * T + 1
 

@@ -1,89 +1,229 @@
 #!/usr/bin/env python
-"""End-to-end serving throughput: synthetic actor processes -> gRPC (reference wire format) -> dynamic batching ->
-central inference on the GPU -> completed unrolls -> train steps (seed_rl_amd/learner_server.py).
+"""Central inference and the train step TOGETHER on one GPU: env-steps/s served while the learner
+trains on exactly those steps (closed loop: every served step ends up in a training unroll, so in steady state the
+learner's env-frames/s equals the inference side's env-steps/s -- that common rate is the number reported).
 
-  python tools/bench_serving.py [--procs 8] [--envs-per-proc 16] [--n 64] [--batch 64] [--seconds 10]
-Each actor process steps `envs-per-proc` synthetic Atari environments and sends them as ONE client-side batch per call
-(the reference's env_batch_size: common/actor.py), so a server-side inference batch of n is filled by n / envs-per-proc
-calls.  Prints env-steps/s served and train steps taken.  The transport is host Python (asyncio + protobuf): this
-measures IT, not the GPU path (bench.py `inference`: 2.2 M env-steps/s at n = 256).
+  python tools/bench_serving.py [--mode inprocess|transport|both] [--n 1024] [--batch 512] [--envs 4096]
+                                [--procs 16] [--envs-per-proc 64] [--seconds 6]
+
+inprocess  a host thread replays the captured inference graph on pre-staged pinned request batches as fast as the
+           back-pressure gate admits them (what a transport that is never the bottleneck would deliver); the main
+           thread runs LearnerServer.train_step().  Measures the GPU side: two streams, one device.
+transport  the same learner behind the NATIVE gRPC front-end (libseedserve.so): actor PROCESSES, one stream each,
+           `envs-per-proc` environments per call (the reference's env_batch_size), requests serialized once per actor
+           (the load generator is Python: it must not be the bottleneck) -- reference wire format end to end.
+Reference semantics: agents/vtrace/learner.py:350-470 (inference on its own devices beside the training loop).
 """
 import argparse
 import multiprocessing as mp
 import os
 import sys
 import tempfile
+import threading
 import time
 import uuid
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
 import numpy as np
 
+OBS = (84, 84, 1)
 
-def actor_proc(address, first_env, k, seconds, out):
-  import collections
-  from seed_rl_amd import grpc_service as gs                 # (no torch in the actor processes)
-  EnvOutput = collections.namedtuple('EnvOutput', 'reward done observation abandoned episode_step')
+
+def _make_server(dev, T, B, n, envs, address, transport='native', A=18, io_threads=None, slots=4):
+  import torch
+  from seed_rl_amd import learner, learner_server, networks, optimizers, parametric_distribution as pd
+  agent = networks.AtariShallow(A, device=dev, seed=0)
+  opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, 10 ** 7), beta_1=0.0, epsilon=3.125e-7, capturable=True)
+  lrn = learner.Learner(agent, opt, pd.categorical_distribution(A))
+  srv = learner_server.LearnerServer(agent, lrn, T, B, n, envs, OBS, [address], device=dev, transport=transport,
+                                     graphed=True, num_io_threads=io_threads, inference_slots=slots)
+  return srv
+
+
+def run_inprocess(dev, seconds=5.0, T=20, B=512, n=1024, envs=4096, warm_steps=3):
+  """Returns a dict: env_steps_per_s served == learner env-frames/s consumed, measured over the same wall interval."""
+  import torch
+  from seed_rl_amd import inference
+  path = os.path.join(tempfile.gettempdir(), 'seedrl_s_' + uuid.uuid4().hex[:12])
+  srv = _make_server(dev, T, B, n, envs, 'unix:' + path)
+  st, gate, lock, s_inf = srv.state, srv.gate, srv.lock, srv.infer_stream
+  with torch.cuda.device(dev), torch.cuda.stream(s_inf):
+    fn = st.graphed(n, OBS)
+  s_inf.synchronize()
+  groups = envs // n
+  g = torch.Generator(device='cpu').manual_seed(0)
+  reqs, obs = [], []
+  for k in range(groups):
+    ids = np.arange(k * n, (k + 1) * n, dtype=np.int64)
+    r = torch.randn(n, generator=g).numpy()
+    reqs.append(torch.from_numpy(inference.pack_request(n, ids, np.full(n, 7, np.int64), r, r,
+                                                        (torch.rand(n, generator=g) < 0.01).numpy())).pin_memory())
+    obs.append(torch.randint(0, 256, (n,) + OBS, dtype=torch.uint8, generator=g).pin_memory())
+  stop = threading.Event()
+  served = [0]
+  act = torch.zeros(n, dtype=torch.int64).pin_memory()
+  done = torch.cuda.Event()
+
+  def feeder():
+    i = 0
+    with torch.cuda.device(dev):
+      while not stop.is_set():
+        gate.admit()
+        with lock:
+          with torch.cuda.stream(s_inf):
+            a = fn.replay_packed(reqs[i % groups], obs[i % groups])
+            act.copy_(a, non_blocking=True)                     # what the transport sends back to the actors
+            token = gate.submitted()
+            done.record(s_inf)
+        done.synchronize()
+        gate.completed(token)
+        served[0] += n
+        i += 1
+  th = threading.Thread(target=feeder, daemon=True)
+  th.start()
+  try:
+    for _ in range(warm_steps):                                 # includes the HIP-graph capture of both unroll slots
+      assert srv.train_step(timeout=120) is not None
+    srv.synchronize()
+    s0, t0, steps = served[0], time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+      assert srv.train_step(timeout=60) is not None
+      steps += 1
+    srv.train_stream.synchronize()
+    dt = time.perf_counter() - t0
+    s1 = served[0]
+  finally:
+    stop.set()
+    gate.n = -10 ** 9                                           # release a feeder blocked in admit()
+    th.join(timeout=10)
+  srv.state.check_errors()
+  srv.shutdown()
+  return dict(mode='in-process feeder (no transport): inference graph replays on the high-priority stream, train step '
+                   'graph on its own stream, same device',
+              seconds=round(dt, 2), inference_batch=n, train_batch=B, unroll_length=T, envs=envs,
+              env_steps_per_s_served=round((s1 - s0) / dt, 0), learner_env_frames_per_s=round(steps * B * T / dt, 0),
+              train_steps=steps, ms_per_train_step_wall=round(dt / max(steps, 1) * 1e3, 3),
+              inference_calls_per_s=round((s1 - s0) / n / dt, 0), gate_waits=gate.waits)
+
+
+def actor_proc(address, first_env, k, out, start, stop_at):
+  import queue
+  import grpc
+  from seed_rl_amd import grpc_service as gs
   rng = np.random.default_rng(first_env)
-  client = gs.Client(address)
-  ids = np.arange(first_env, first_env + k, dtype=np.int32)
-  runs = np.full(k, 7, np.int64)
-  frames = rng.integers(0, 256, (k, 84, 84, 1)).astype(np.uint8)
-  zeros_b, step = np.zeros(k, np.bool_), 0
-  t_end = time.time() + seconds
+  req = gs.CallRequest()
+  req.function = 'inference'
+  for a in (np.arange(first_env, first_env + k, dtype=np.int32), np.full(k, 7, np.int64),
+            rng.normal(size=k).astype(np.float32), rng.uniform(size=k) < 0.01,
+            rng.integers(0, 256, (k,) + OBS).astype(np.uint8), np.zeros(k, np.bool_), np.zeros(k, np.int32),
+            rng.normal(size=k).astype(np.float32)):
+    req.tensor.append(gs.encode_tensor(a))
+  blob = req.SerializeToString()
+  channel = grpc.insecure_channel(address, options=[('grpc.max_receive_message_length', -1),
+                                                    ('grpc.max_send_message_length', -1),
+                                                    ('grpc.use_local_subchannel_pool', 1)])
+  ident = lambda b: b
+  channel.unary_unary('/%s/Init' % gs.SERVICE, request_serializer=ident, response_deserializer=ident)(
+      b'', wait_for_ready=True, timeout=120)
+  q = queue.SimpleQueue()
+
+  def gen():
+    while True:
+      item = q.get()
+      if item is None:
+        return
+      yield item
+  responses = channel.stream_stream('/%s/Call' % gs.SERVICE, request_serializer=ident, response_deserializer=ident)(gen())
+  start.wait()
   calls = 0
   try:
-    while time.time() < t_end:
-      env = EnvOutput(rng.normal(size=k).astype(np.float32), rng.uniform(size=k) < 0.01, frames, zeros_b,
-                            np.full(k, step, np.int32))
-      client.inference(ids, runs, env, env.reward)
-      step += 1; calls += 1
-  except gs.OpError:
+    while time.time() < stop_at.value:
+      q.put(blob)
+      resp = gs.CallResponse.FromString(next(responses))
+      if resp.status_code != 0:
+        raise RuntimeError(resp.status_error_message)
+      calls += 1
+  except (grpc.RpcError, StopIteration):
     pass
+  q.put(None)
   out.put(calls * k)
+
+
+def run_transport(dev, seconds=5.0, T=20, B=512, n=256, procs=16, envs_per_proc=64, io_threads=None):
+  import torch
+  envs = procs * envs_per_proc
+  assert n % envs_per_proc == 0 and envs % n == 0, 'actors must fill whole inference batches'
+  path = os.path.join(tempfile.gettempdir(), 'seedrl_s_' + uuid.uuid4().hex[:12])
+  srv = _make_server(dev, T, B, n, envs, 'unix:' + path, io_threads=io_threads)
+  srv.start()
+  ctx = mp.get_context('spawn')
+  q, start, stop_at = ctx.Queue(), ctx.Event(), ctx.Value('d', time.time() + 3600.0)
+  ps = [ctx.Process(target=actor_proc, args=('unix:' + path, i * envs_per_proc, envs_per_proc, q, start, stop_at))
+        for i in range(procs)]
+  for p in ps:
+    p.start()
+  time.sleep(4.0)                                               # imports + connects
+  start.set()
+  try:
+    for _ in range(3):                                          # warm-up incl. graph capture
+      assert srv.train_step(timeout=120) is not None
+    srv.synchronize()
+    st0 = srv.server.stats()
+    t0, steps = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+      assert srv.train_step(timeout=60) is not None
+      steps += 1
+    srv.train_stream.synchronize()
+    dt = time.perf_counter() - t0
+    st1 = srv.server.stats()
+  finally:
+    stop_at.value = 0.0
+    time.sleep(0.2)
+    srv.shutdown()                                              # unblocks actors whose last batch can never fill
+  total = 0
+  for _ in ps:
+    try:
+      total += q.get(timeout=60)
+    except Exception:                                           # pylint: disable=broad-except
+      pass
+  for p in ps:
+    p.join(timeout=30)
+  if os.path.exists(path):
+    os.remove(path)
+  served = (st1['batches'] - st0['batches']) * n
+  return dict(mode='actor processes -> native gRPC front-end (libseedserve.so, unix socket, reference wire format) -> '
+                   'central inference -> train step, same device',
+              seconds=round(dt, 2), actor_processes=procs, envs_per_call=envs_per_proc, inference_batch=n, train_batch=B,
+              unroll_length=T, env_steps_per_s_served=round(served / dt, 0),
+              learner_env_frames_per_s=round(steps * B * T / dt, 0), train_steps=steps,
+              observation_MB_per_s=round((st1['bytes_in'] - st0['bytes_in']) / dt / 1e6, 0),
+              calls_per_s=round((st1['calls'] - st0['calls']) / dt, 0), gate_waits=srv.gate.waits,
+              host_cpus=os.cpu_count())
 
 
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument('--procs', type=int, default=8)
-  ap.add_argument('--envs-per-proc', type=int, default=16)
-  ap.add_argument('--n', type=int, default=64, help='server-side inference batch')
-  ap.add_argument('--batch', type=int, default=64, help='train batch (unrolls)')
+  ap.add_argument('--mode', default='both', choices=['inprocess', 'transport', 'both'])
+  ap.add_argument('--n', type=int, default=1024)
+  ap.add_argument('--tn', type=int, default=256, help='inference batch of the transport run')
+  ap.add_argument('--batch', type=int, default=512)
   ap.add_argument('--unroll', type=int, default=20)
-  ap.add_argument('--seconds', type=float, default=10.0)
+  ap.add_argument('--envs', type=int, default=4096)
+  ap.add_argument('--procs', type=int, default=16)
+  ap.add_argument('--envs-per-proc', type=int, default=64)
+  ap.add_argument('--io-threads', type=int, default=0)
+  ap.add_argument('--seconds', type=float, default=5.0)
   a = ap.parse_args()
+  import json
   import torch
-  from seed_rl_amd import learner, learner_server, networks, optimizers, parametric_distribution as pd
   dev = torch.device('cuda:0')
-  A, E = 18, a.procs * a.envs_per_proc
-  agent = networks.AtariShallow(A, device=dev, seed=0)
-  opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, 10 ** 6), beta_1=0.0, epsilon=3.125e-7)
-  lrn = learner.Learner(agent, opt, pd.categorical_distribution(A))
-  path = os.path.join(tempfile.gettempdir(), 'seedrl_' + uuid.uuid4().hex[:12])
-  srv = learner_server.LearnerServer(agent, lrn, a.unroll, a.batch, a.n, E, (84, 84, 1), ['unix:' + path], device=dev)
-  srv.start()
-  ctx = mp.get_context('spawn')
-  q = ctx.Queue()
-  procs = [ctx.Process(target=actor_proc, args=('unix:' + path, i * a.envs_per_proc, a.envs_per_proc, a.seconds, q))
-           for i in range(a.procs)]
-  t0 = time.time()
-  for p in procs:
-    p.start()
-  steps = 0
-  while time.time() - t0 < a.seconds + 1:
-    if srv.train_step(timeout=0.5) is not None:
-      steps += 1
-  dt = time.time() - t0
-  srv.shutdown()                                      # unblocks the actors whose last batch can never fill
-  total = sum(q.get(timeout=60) for _ in procs)
-  for p in procs:
-    p.join(timeout=30)
-  if os.path.exists(path):
-    os.remove(path)
-  print('served %d env steps in %.1f s = %.0f env-steps/s through the Python transport (%d actor processes x %d envs, '
-        'inference batch %d); %d train steps of %d unrolls x %d' % (total, dt, total / dt, a.procs, a.envs_per_proc, a.n,
-                                                                   steps, a.batch, a.unroll))
+  if a.mode in ('inprocess', 'both'):
+    print(json.dumps(run_inprocess(dev, a.seconds, a.unroll, a.batch, a.n, a.envs)))
+  if a.mode in ('transport', 'both'):
+    print(json.dumps(run_transport(dev, a.seconds, a.unroll, a.batch, a.tn, a.procs, a.envs_per_proc,
+                                   a.io_threads or None)))
 
 
 if __name__ == '__main__':
