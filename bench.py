@@ -16,6 +16,7 @@ The default single-GPU run also reports, outside the timed region and in the sam
   parity         one train step at the bench shape against the CPU oracle (tests/parity.py)
   other_configs  BASELINE configs[2] (DMLab ImpalaDeep+LSTM) and configs[4] (R2D2), a few steps each
   inference      central-inference step (learner.py:350-405) at n = 64 / 256 / 1024
+  serving        inference and training together on the one GPU, without and with the native gRPC transport
   ingest         the same step with the NEXT unroll's host->device copy in flight on its own stream
   cpu_baseline   the oracle's eager PyTorch-CPU learner step on the host cores
 (--quick skips them.)
@@ -599,6 +600,27 @@ def main():
         result['ingest'] = ingest_record(dev, args.steps)
       except Exception as e:                     # pylint: disable=broad-except
         result['ingest'] = dict(error=repr(e))
+      # inference and training TOGETHER on this GPU (tools/bench_serving.py): the learner trains on exactly the steps
+      # central inference serves, so both rates are one number; once without a transport, once through the native gRPC
+      # front-end with actor processes on the host cores
+      try:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import bench_serving
+        serving = dict(inprocess=bench_serving.run_inprocess(dev, seconds=3.0))
+        _release()
+        try:
+          procs = 32 if (os.cpu_count() or 8) >= 64 else 8
+          serving['transport'] = bench_serving.run_transport(dev, seconds=3.0, n=1024 if procs == 32 else 256,
+                                                             procs=procs, envs_per_proc=128 if procs == 32 else 64)
+        except Exception as e:                   # pylint: disable=broad-except
+          serving['transport'] = dict(error=repr(e))
+        serving['note'] = ('closed loop on ONE GPU: inference batches on a high-priority stream (inference twin of the '
+                           'agent, same parameters), train step graph on its own stream, dequeue as the only ordered '
+                           'hand-over; learner alone = `value`, inference alone = `inference`')
+        result['serving'] = serving
+        _release()
+      except Exception as e:                     # pylint: disable=broad-except
+        result['serving'] = dict(error=repr(e))
   elif world == 1 and args.ingest == 'pinned' and headline:
     result['ingest'] = ingest_record(dev, args.steps)
   if world == 1 and not args.no_cpu_baseline and not args.quick:

@@ -17,6 +17,7 @@ a filled batch goes to the device with two asynchronous copies and one HIP-graph
 """
 import ctypes
 import os
+import queue
 import threading
 
 import numpy as np
@@ -91,7 +92,7 @@ def _spec(shape, dtype_enum, widen=False):
 
 
 class _Bound(object):
-  __slots__ = ('fn_id', 'name', 'compute', 'thread', 'keep')
+  __slots__ = ('fn_id', 'name', 'compute', 'thread', 'keep', 'inflight', 'finisher')
 
 
 class NativeServer(object):
@@ -132,6 +133,7 @@ class NativeServer(object):
       raise gs.InvalidArgumentError(_err())
     b = _Bound()
     b.fn_id, b.name, b.compute, b.thread, b.keep = fid, name, compute, None, keep
+    b.inflight, b.finisher = queue.Queue(), None
     self._bound.append(b)
     if name not in self._names:
       self._names.add(name)
@@ -192,14 +194,33 @@ class NativeServer(object):
         return
       if slot < 0:
         continue
-      code, msg = gs.OK, b''
+      code, msg, finish = gs.OK, b'', None
       try:
-        b.compute(slot)
+        finish = b.compute(slot)                     # None: done; a callable: finishes the batch later (pipelined)
       except gs.OpError as e:
         code, msg = e.code, str(e.message).encode()
       except Exception as e:                         # pylint: disable=broad-except
         code = gs.INVALID_ARGUMENT if isinstance(e, (ValueError, AssertionError)) else gs.INTERNAL
         msg = ('%s: %s' % (type(e).__name__, e)).encode()
+      if finish is None:
+        l.seedserve_complete(h, b.fn_id, slot, code, msg)
+      else:
+        b.inflight.put((slot, finish))
+
+  def _finish_loop(self, b):
+    """Completes pipelined batches in submission order: the compute thread keeps SUBMITTING the next batches to the
+    device while this thread waits for the oldest one's actions and answers its callers."""
+    l, h = lib(), self._h
+    while True:
+      item = b.inflight.get()
+      if item is None:
+        return
+      slot, finish = item
+      code, msg = gs.OK, b''
+      try:
+        finish()
+      except Exception as e:                         # pylint: disable=broad-except
+        code, msg = gs.INTERNAL, ('%s: %s' % (type(e).__name__, e)).encode()
       l.seedserve_complete(h, b.fn_id, slot, code, msg)
 
   def start(self):
@@ -219,7 +240,9 @@ class NativeServer(object):
     self._started = True
     for b in self._bound:
       b.thread = threading.Thread(target=self._compute_loop, args=(b,), name='seedserve_compute_%s' % b.name, daemon=True)
+      b.finisher = threading.Thread(target=self._finish_loop, args=(b,), name='seedserve_finish_%s' % b.name, daemon=True)
       b.thread.start()
+      b.finisher.start()
 
   def stats(self):
     s = Stats()
@@ -234,6 +257,8 @@ class NativeServer(object):
     for b in self._bound:
       if b.thread is not None:
         b.thread.join(timeout=10)
+        b.inflight.put(None)
+        b.finisher.join(timeout=10)
 
   def __del__(self):
     try:
@@ -260,7 +285,7 @@ def inference_signature(n, observation_shape, observation_dtype=np.uint8):
 
 
 def bind_inference(server, fused_states, inference_batch_size, observation_shape, action_dtype=np.int64, num_slots=4,
-                   observation_dtype=np.uint8, stream=None, gate=None, lock=None):
+                   observation_dtype=np.uint8, stream=None, gate=None, lock=None, pipeline=1):
   """Binds `inference(env_ids, run_ids, env_outputs, raw_rewards) -> actions`, one instance per FusedInferenceState
   (the reference's one-per-inference-device list, round-robin: learner.py:406-414).  Each slot is ONE pinned byte
   buffer in `inference.request_layout` (the C++ side writes every argument at its offset, env ids widened to int64)
@@ -270,7 +295,10 @@ def bind_inference(server, fused_states, inference_batch_size, observation_shape
   could overflow (the reference blocks in unroll_queue.enqueue_many), `submitted()` / `completed(token)` keep its fill
   estimate exact.  `lock`: held
   while a batch is SUBMITTED to the stream (not while it runs): a training thread that dequeues completed unrolls on
-  the same stream takes it too, so that its count read and column moves are not interleaved with a batch."""
+  the same stream takes it too, so that its count read and column moves are not interleaved with a batch.
+  `pipeline`: graph instances with their own static inputs; 1 (default): copies, replay and read-back on the one
+  inference stream; 2: the copies of batch i+1 go to a copy stream beside the replay of batch i (measured SLOWER on
+  MI355X / ROCm 7: 1.30 vs 1.77 M env-steps/s with the learner training alongside, tools/bench_serving.py)."""
   import torch
   from seed_rl_amd import inference as inf
   n = inference_batch_size
@@ -287,8 +315,9 @@ def bind_inference(server, fused_states, inference_batch_size, observation_shape
     dev = st.device
     with torch.cuda.device(dev):
       s_inf = stream or torch.cuda.Stream(device=dev, priority=-1)
+      s_copy = torch.cuda.Stream(device=dev, priority=-1) if pipeline > 1 else s_inf
       with torch.cuda.stream(s_inf):
-        graphed = st.graphed(n, observation_shape)
+        graphs = [st.graphed(n, observation_shape, input_slot=k) for k in range(pipeline)]
       s_inf.synchronize()
     req = [torch.zeros(lay['bytes'], dtype=torch.uint8).pin_memory() for _ in range(num_slots)]
     obs = [torch.zeros((n,) + tuple(observation_shape), dtype=t_obs).pin_memory() for _ in range(num_slots)]
@@ -297,26 +326,52 @@ def bind_inference(server, fused_states, inference_batch_size, observation_shape
     in_ptrs = [[(obs[k].data_ptr() if name is None else req[k].data_ptr() + lay[name][0]) for name in order]
                for k in range(num_slots)]
     out_ptrs = [[(act[k].data_ptr() if np.dtype(action_dtype) == np.int64 else out[k].ctypes.data)] for k in range(num_slots)]
-
     st_lock = lock if lock is not None else threading.Lock()
     done = [torch.cuda.Event() for _ in range(num_slots)]
+    staged = [torch.cuda.Event() for _ in range(pipeline)]
+    ran = [None] * pipeline                          # event after the last replay of graph k (its inputs are free again)
+    counter = [0]
 
-    def compute(slot, graphed=graphed, req=req, obs=obs, act=act, out=out, st=st, s_inf=s_inf, st_lock=st_lock,
-                done=done):
+    def compute(slot, graphs=graphs, req=req, obs=obs, act=act, out=out, st=st, s_inf=s_inf, s_copy=s_copy,
+                st_lock=st_lock, done=done, staged=staged, ran=ran, counter=counter):
+      """Submits one batch and returns: the host->device copies go to the copy stream (they wait only for the previous
+      replay of the SAME graph instance), the replay + action read-back to the inference stream; `finish` -- run by the
+      server's completion thread -- waits for the actions.  Batch i+1 is staged while batch i computes."""
       if gate is not None:
         gate.admit()
-      with st_lock:
-        with torch.cuda.device(st.device), torch.cuda.stream(s_inf):
-          actions = graphed.replay_packed(req[slot], obs[slot])
-          act[slot].copy_(actions, non_blocking=True)
-          token = gate.submitted() if gate is not None else None
-          done[slot].record(s_inf)
-      done[slot].synchronize()                       # the actions are on the host: the callers can be answered
-      if gate is not None:
-        gate.completed(token)
-      if np.dtype(action_dtype) != np.int64:
-        out[slot][...] = act[slot].numpy()
+      k = counter[0] % len(graphs)
+      counter[0] += 1
+      g = graphs[k]
+      with torch.cuda.device(st.device):
+        if s_copy is not s_inf:
+          with torch.cuda.stream(s_copy):
+            if ran[k] is not None:
+              s_copy.wait_event(ran[k])
+            g.stage(req[slot], obs[slot])
+            staged[k].record(s_copy)
+        with st_lock:
+          with torch.cuda.stream(s_inf):
+            if s_copy is not s_inf:
+              s_inf.wait_event(staged[k])
+            else:
+              g.stage(req[slot], obs[slot])          # one stream: copies, replay and read-back in order
+            actions = g.launch()
+            if s_copy is not s_inf:
+              ev = torch.cuda.Event()
+              ev.record(s_inf)
+              ran[k] = ev
+            act[slot].copy_(actions, non_blocking=True)
+            token = gate.submitted() if gate is not None else None
+            done[slot].record(s_inf)
+
+      def finish():
+        done[slot].synchronize()                     # the actions are on the host: the callers can be answered
+        if gate is not None:
+          gate.completed(token)
+        if np.dtype(action_dtype) != np.int64:
+          out[slot][...] = act[slot].numpy()
+      return finish
     fids.append(server.bind_buffers('inference', in_specs, out_specs, num_slots, in_ptrs, out_ptrs, compute,
                                     output_nest=gs.TensorSpec((n,), action_dtype, 'action'),
-                                    keep=(req, obs, act, out, graphed, s_inf)))
+                                    keep=(req, obs, act, out, graphs, s_inf, s_copy)))
   return fids

@@ -256,7 +256,7 @@ class FusedInferenceState(object):
         [op(f, p, rb, n, dst_rows=sid, mask=b['carry']) for f, p, rb in zip(firsts, prevs, srb)])   # :398-399
     return b['actions']
 
-  def graphed(self, n, observation_shape, warmup=3):
+  def graphed(self, n, observation_shape, warmup=3, input_slot=0):
     """Captures one inference call for batch size n in a HIP graph.  Returns fn(env_ids, run_ids, env_outputs,
     raw_rewards) -> actions that copies its arguments into the graph's static inputs and replays it.
 
@@ -264,8 +264,16 @@ class FusedInferenceState(object):
     (`fn.request`, layout `request_layout(n)`: ids i64 | run ids i64 | reward f32 | raw reward f32 | episode_step i32 |
     done u8 | abandoned u8), so a front-end that batches requests in pinned host memory hands a batch over with two
     copies -- the packed scalars and the frames -- through `fn.replay_packed(request, observation)`; for the Atari
-    agents the frames land directly in the agent's frame buffer (no device-side copy before the first conv)."""
+    agents the frames land directly in the agent's frame buffer (no device-side copy before the first conv).
+
+    input_slot: graphs captured with different slots have DIFFERENT static inputs (their own request bytes and, for
+    the Atari agents, their own frame buffer), so the host->device copies of batch i+1 can run on a copy stream while
+    the graph of batch i executes: `fn.stage(request, observation)` does the two copies on the current stream,
+    `fn.launch()` replays (replay_packed = both, on one stream)."""
     dev = self.device
+    prev_slot = getattr(self.agent, 'frames_slot', 0)
+    if hasattr(self.agent, 'frames_buffer'):
+      self.agent.frames_slot = input_slot            # read by the agent's forward while it is warmed up / captured
     lay = request_layout(n)
     req = torch.zeros(lay['bytes'], dtype=torch.uint8, device=dev)
     view = lambda k, dt: req[lay[k][0]:lay[k][0] + lay[k][1]].view(dt)
@@ -295,6 +303,8 @@ class FusedInferenceState(object):
       actions = self.inference(si['ids'], si['runs'], senv, si['raw'])
     for t, s in zip(self._state_tensors(), saved):          # warm-up calls must not leave traces in the tables
       t.copy_(s)
+    if hasattr(self.agent, 'frames_buffer'):
+      self.agent.frames_slot = prev_slot
 
     def fn(env_ids, run_ids, env_outputs, raw_rewards):
       si['ids'].copy_(torch.as_tensor(env_ids, device=dev)); si['runs'].copy_(torch.as_tensor(run_ids, device=dev))
@@ -308,13 +318,21 @@ class FusedInferenceState(object):
       graph.replay()
       return actions
 
-    def replay_packed(request, observation):
-      """request: uint8[request_layout(n)['bytes']] (host pinned or device), observation uint8 [n, ...]."""
+    def stage(request, observation):
+      """request: uint8[request_layout(n)['bytes']] (host pinned or device), observation [n, ...]: the two copies into
+      this graph's static inputs, on the current stream."""
       req.copy_(request, non_blocking=True)
       senv.observation.copy_(observation, non_blocking=True)
+
+    def launch():
       graph.replay()
       return actions
+
+    def replay_packed(request, observation):
+      stage(request, observation)
+      return launch()
     fn.graph, fn.static_inputs, fn.static_env, fn.request, fn.replay_packed = graph, si, senv, req, replay_packed
+    fn.stage, fn.launch, fn.actions = stage, launch, actions
     return fn
 
   def _state_tensors(self):

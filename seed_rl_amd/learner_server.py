@@ -40,28 +40,32 @@ class BatchGate(object):
 
   def __init__(self, state, n, lock):
     self.state, self.n, self.lock = state, n, lock
-    self.fill, self.gen = 0, 0
+    self.fill, self.gen, self.inflight = 0, 0, 0
     self.mirror = torch.zeros(1, dtype=torch.int32).pin_memory()
     self.waits = 0
+    self.open = True
 
   def admit(self, poll_s=0.0001):
-    while self.fill + self.n > self.state.cap:
+    """Blocks while this batch, on top of the ones still in flight, could overflow the device batch."""
+    while self.open and self.fill + self.n * (self.inflight + 1) > self.state.cap:
       self.waits += 1
       time.sleep(poll_s)
 
   def submitted(self):
     """Under the submission lock, on the inference stream, right after the batch was enqueued."""
     self.mirror.copy_(self.state.batch_count, non_blocking=True)
+    self.inflight += 1
     return self.gen
 
   def completed(self, token):
-    """After the batch's event completed (the mirror has landed)."""
+    """After the batch's event completed (its mirror copy -- or a later batch's -- has landed)."""
     with self.lock:
+      self.inflight -= 1
       if self.gen == token:
         self.fill = int(self.mirror[0])
 
   def dequeued(self, fill_now):
-    """Under the lock, by the dequeue: the exact fill after it."""
+    """Under the lock, by the dequeue: the exact fill after it (every batch submitted before is accounted for)."""
     self.fill = fill_now
     self.gen += 1
 
@@ -70,7 +74,7 @@ class LearnerServer(object):
 
   def __init__(self, agent, learner, unroll_length, batch_size, inference_batch_size, num_envs, observation_shape,
                server_addresses, observation_dtype=torch.uint8, device='cuda', graphed=True, batch_capacity=None,
-               transport='native', num_unroll_slots=2, num_io_threads=None, inference_slots=4):
+               transport='native', num_unroll_slots=2, num_io_threads=None, inference_slots=4, inference_pipeline=1):
     self.agent, self.learner = agent, learner
     self.T, self.B, self.n = unroll_length, batch_size, inference_batch_size
     self.device = dev = torch.device(device)
@@ -79,7 +83,9 @@ class LearnerServer(object):
     env_specs = utils.EnvOutput(Spec((), torch.float32), Spec((), torch.bool), Spec(self.obs_shape, observation_dtype),
                                 Spec((), torch.bool), Spec((), torch.int32))
     ao_specs = networks.AgentOutput(Spec((), torch.int64), Spec((A,), torch.float32), Spec((), torch.float32))
-    cap = batch_capacity or max(2 * batch_size, batch_size + num_envs)
+    # room for every env completing an unroll at once (lock-stepped actors do) on top of a batch being assembled and
+    # the inference batches in flight: back-pressure (BatchGate) then only engages when the learner really lags
+    cap = batch_capacity or (2 * batch_size + num_envs + inference_batch_size * (inference_slots + 1))
     with torch.cuda.device(dev):
       self.infer_stream = torch.cuda.Stream(device=dev, priority=-1)
       self.train_stream = torch.cuda.Stream(device=dev)
@@ -95,7 +101,7 @@ class LearnerServer(object):
       self.server = grpc_native.NativeServer(list(server_addresses), num_io_threads=num_io_threads)
       grpc_native.bind_inference(self.server, self.state, inference_batch_size, self.obs_shape,
                                  num_slots=inference_slots, observation_dtype=np_obs, stream=self.infer_stream,
-                                 lock=self.lock, gate=self.gate)
+                                 lock=self.lock, gate=self.gate, pipeline=inference_pipeline)
     else:
       self.server = grpc_service.Server(list(server_addresses))
       grpc_service.bind_inference(self.server, self.state, inference_batch_size, self.obs_shape, lock=self.lock,
@@ -134,6 +140,7 @@ class LearnerServer(object):
     self.server.start()
 
   def shutdown(self):
+    self.gate.open = False                            # releases an inference batch waiting for room
     self.server.shutdown()
 
   def _step(self, slot):
@@ -153,6 +160,12 @@ class LearnerServer(object):
     if self._done[slot] is not None:
       self._done[slot].synchronize()                  # the step that last read this unroll (two steps ago) is through
     while True:
+      # wait on the HOST copy of the fill count (exact as of the last completed inference batch): no lock, no device
+      # read while the batch is still filling -- the dequeue below is the only thing that orders against inference
+      while self.gate.fill < self.B:
+        if timeout is not None and time.time() - t0 > timeout:
+          return None
+        time.sleep(poll_s)
       with self.lock:
         with torch.cuda.device(self.device), torch.cuda.stream(self.infer_stream):
           ready = self.state.dequeue_into(self.unrolls[slot], self.B)
@@ -161,9 +174,6 @@ class LearnerServer(object):
             self._ready.record(self.infer_stream)
       if ready:
         break
-      if timeout is not None and time.time() - t0 > timeout:
-        return None
-      time.sleep(poll_s)
     with torch.cuda.device(self.device), torch.cuda.stream(self.train_stream):
       self.train_stream.wait_event(self._ready)
       out = self._step(slot)

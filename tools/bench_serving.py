@@ -31,58 +31,85 @@ import numpy as np
 OBS = (84, 84, 1)
 
 
-def _make_server(dev, T, B, n, envs, address, transport='native', A=18, io_threads=None, slots=4):
+def _make_server(dev, T, B, n, envs, address, transport='native', A=18, io_threads=None, slots=4, pipeline=None):
   import torch
   from seed_rl_amd import learner, learner_server, networks, optimizers, parametric_distribution as pd
   agent = networks.AtariShallow(A, device=dev, seed=0)
   opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, 10 ** 7), beta_1=0.0, epsilon=3.125e-7, capturable=True)
   lrn = learner.Learner(agent, opt, pd.categorical_distribution(A))
+  kw = {} if pipeline is None else dict(inference_pipeline=pipeline)
   srv = learner_server.LearnerServer(agent, lrn, T, B, n, envs, OBS, [address], device=dev, transport=transport,
-                                     graphed=True, num_io_threads=io_threads, inference_slots=slots)
+                                     graphed=True, num_io_threads=io_threads, inference_slots=slots, **kw)
   return srv
 
 
-def run_inprocess(dev, seconds=5.0, T=20, B=512, n=1024, envs=4096, warm_steps=3):
+def _stagger(srv, T):
+  """Real actors are never in lock step.  Synthetic ones started together would all complete their unrolls in the same
+  inference call (a burst of num_envs / batch_size train steps, then nothing for T calls): give every env a random
+  phase by starting its store row index somewhere inside the unroll (its first unroll then begins with zero steps)."""
+  import torch
+  st = srv.state
+  g = torch.Generator(device='cpu').manual_seed(1)
+  st.store_index.copy_(torch.randint(0, T + 1, (st.E,), generator=g).to(st.store_index.device))
+
+
+def run_inprocess(dev, seconds=5.0, T=20, B=512, n=1024, envs=4096, warm_steps=3, pipeline=None, depth=None):
   """Returns a dict: env_steps_per_s served == learner env-frames/s consumed, measured over the same wall interval."""
   import torch
   from seed_rl_amd import inference
   path = os.path.join(tempfile.gettempdir(), 'seedrl_s_' + uuid.uuid4().hex[:12])
-  srv = _make_server(dev, T, B, n, envs, 'unix:' + path)
-  st, gate, lock, s_inf = srv.state, srv.gate, srv.lock, srv.infer_stream
-  with torch.cuda.device(dev), torch.cuda.stream(s_inf):
-    fn = st.graphed(n, OBS)
-  s_inf.synchronize()
   groups = envs // n
+  srv = _make_server(dev, T, B, n, envs, 'unix:' + path, slots=groups, pipeline=pipeline)
+  gate = srv.gate
+  # the bound inference function's pinned slot buffers, filled the way the C++ front-end fills them: slot k always
+  # carries env group k; `compute(slot)` submits a batch (copy stream + inference stream), `finish()` waits for it
+  bound = srv.server._bound[0]                                  # pylint: disable=protected-access
+  req, obs = bound.keep[0], bound.keep[1]
   g = torch.Generator(device='cpu').manual_seed(0)
-  reqs, obs = [], []
   for k in range(groups):
     ids = np.arange(k * n, (k + 1) * n, dtype=np.int64)
     r = torch.randn(n, generator=g).numpy()
-    reqs.append(torch.from_numpy(inference.pack_request(n, ids, np.full(n, 7, np.int64), r, r,
-                                                        (torch.rand(n, generator=g) < 0.01).numpy())).pin_memory())
-    obs.append(torch.randint(0, 256, (n,) + OBS, dtype=torch.uint8, generator=g).pin_memory())
+    req[k].copy_(torch.from_numpy(inference.pack_request(n, ids, np.full(n, 7, np.int64), r, r,
+                                                         (torch.rand(n, generator=g) < 0.01).numpy())))
+    obs[k].copy_(torch.randint(0, 256, (n,) + OBS, dtype=torch.uint8, generator=g))
+  _stagger(srv, T)
   stop = threading.Event()
   served = [0]
-  act = torch.zeros(n, dtype=torch.int64).pin_memory()
-  done = torch.cuda.Event()
+  import queue
+  inflight = queue.Queue(maxsize=depth or max(1, groups - 1))
 
-  def feeder():
+  prof = dict(compute=0.0, put=0.0, finish=0.0, get=0.0, calls=0)
+
+  def submitter():
     i = 0
-    with torch.cuda.device(dev):
-      while not stop.is_set():
-        gate.admit()
-        with lock:
-          with torch.cuda.stream(s_inf):
-            a = fn.replay_packed(reqs[i % groups], obs[i % groups])
-            act.copy_(a, non_blocking=True)                     # what the transport sends back to the actors
-            token = gate.submitted()
-            done.record(s_inf)
-        done.synchronize()
-        gate.completed(token)
-        served[0] += n
-        i += 1
-  th = threading.Thread(target=feeder, daemon=True)
-  th.start()
+    while not stop.is_set():
+      t = time.perf_counter()
+      f = bound.compute(i % groups)
+      t1 = time.perf_counter()
+      inflight.put(f)                                           # blocks while groups - 1 batches are in flight
+      t2 = time.perf_counter()
+      prof['compute'] += t1 - t; prof['put'] += t2 - t1; prof['calls'] += 1
+      i += 1
+    inflight.put(None)
+
+  def finisher():
+    while True:
+      t = time.perf_counter()
+      f = inflight.get()
+      t1 = time.perf_counter()
+      if f is None:
+        return
+      f()
+      prof['get'] += t1 - t; prof['finish'] += time.perf_counter() - t1
+      served[0] += n
+  # three busy Python threads in one process (submitter, finisher, trainer): hand the GIL over every 0.1 ms instead of
+  # every 5 ms, or the trainer sees its turn a few times per step (the transport mode has no such problem: its
+  # per-message work is in C++ threads)
+  switch = sys.getswitchinterval()
+  sys.setswitchinterval(1e-4)
+  ths = [threading.Thread(target=submitter, daemon=True), threading.Thread(target=finisher, daemon=True)]
+  for th in ths:
+    th.start()
   try:
     for _ in range(warm_steps):                                 # includes the HIP-graph capture of both unroll slots
       assert srv.train_step(timeout=120) is not None
@@ -96,16 +123,19 @@ def run_inprocess(dev, seconds=5.0, T=20, B=512, n=1024, envs=4096, warm_steps=3
     s1 = served[0]
   finally:
     stop.set()
-    gate.n = -10 ** 9                                           # release a feeder blocked in admit()
-    th.join(timeout=10)
+    gate.open = False                                           # release a submitter blocked in admit()
+    for th in ths:
+      th.join(timeout=10)
+    sys.setswitchinterval(switch)
   srv.state.check_errors()
   srv.shutdown()
-  return dict(mode='in-process feeder (no transport): inference graph replays on the high-priority stream, train step '
-                   'graph on its own stream, same device',
+  return dict(mode='in-process feeder (no transport): request copies on a copy stream, inference graph replays on the '
+                   'high-priority stream, train step graph on its own stream, same device',
               seconds=round(dt, 2), inference_batch=n, train_batch=B, unroll_length=T, envs=envs,
               env_steps_per_s_served=round((s1 - s0) / dt, 0), learner_env_frames_per_s=round(steps * B * T / dt, 0),
               train_steps=steps, ms_per_train_step_wall=round(dt / max(steps, 1) * 1e3, 3),
-              inference_calls_per_s=round((s1 - s0) / n / dt, 0), gate_waits=gate.waits)
+              inference_calls_per_s=round((s1 - s0) / n / dt, 0), gate_waits=gate.waits,
+              feeder_us_per_call={k: round(v / max(prof['calls'], 1) * 1e6, 1) for k, v in prof.items() if k != 'calls'})
 
 
 def actor_proc(address, first_env, k, out, start, stop_at):
@@ -151,12 +181,13 @@ def actor_proc(address, first_env, k, out, start, stop_at):
   out.put(calls * k)
 
 
-def run_transport(dev, seconds=5.0, T=20, B=512, n=256, procs=16, envs_per_proc=64, io_threads=None):
+def run_transport(dev, seconds=5.0, T=20, B=512, n=256, procs=16, envs_per_proc=64, io_threads=None, pipeline=None):
   import torch
   envs = procs * envs_per_proc
   assert n % envs_per_proc == 0 and envs % n == 0, 'actors must fill whole inference batches'
   path = os.path.join(tempfile.gettempdir(), 'seedrl_s_' + uuid.uuid4().hex[:12])
-  srv = _make_server(dev, T, B, n, envs, 'unix:' + path, io_threads=io_threads)
+  srv = _make_server(dev, T, B, n, envs, 'unix:' + path, io_threads=io_threads, pipeline=pipeline)
+  _stagger(srv, T)
   srv.start()
   ctx = mp.get_context('spawn')
   q, start, stop_at = ctx.Queue(), ctx.Event(), ctx.Value('d', time.time() + 3600.0)
@@ -215,15 +246,18 @@ def main():
   ap.add_argument('--envs-per-proc', type=int, default=64)
   ap.add_argument('--io-threads', type=int, default=0)
   ap.add_argument('--seconds', type=float, default=5.0)
+  ap.add_argument('--pipeline', type=int, default=0)
+  ap.add_argument('--depth', type=int, default=0)
   a = ap.parse_args()
   import json
   import torch
   dev = torch.device('cuda:0')
   if a.mode in ('inprocess', 'both'):
-    print(json.dumps(run_inprocess(dev, a.seconds, a.unroll, a.batch, a.n, a.envs)))
+    print(json.dumps(run_inprocess(dev, a.seconds, a.unroll, a.batch, a.n, a.envs, pipeline=a.pipeline or None,
+                                   depth=a.depth or None)))
   if a.mode in ('transport', 'both'):
     print(json.dumps(run_transport(dev, a.seconds, a.unroll, a.batch, a.tn, a.procs, a.envs_per_proc,
-                                   a.io_threads or None)))
+                                   a.io_threads or None, pipeline=a.pipeline or None)))
 
 
 if __name__ == '__main__':
