@@ -285,7 +285,7 @@ def inference_signature(n, observation_shape, observation_dtype=np.uint8):
 
 
 def bind_inference(server, fused_states, inference_batch_size, observation_shape, action_dtype=np.int64, num_slots=4,
-                   observation_dtype=np.uint8, stream=None, gate=None, lock=None, pipeline=1):
+                   observation_dtype=np.uint8, stream=None, gate=None, lock=None, pipeline=2):
   """Binds `inference(env_ids, run_ids, env_outputs, raw_rewards) -> actions`, one instance per FusedInferenceState
   (the reference's one-per-inference-device list, round-robin: learner.py:406-414).  Each slot is ONE pinned byte
   buffer in `inference.request_layout` (the C++ side writes every argument at its offset, env ids widened to int64)
@@ -296,9 +296,11 @@ def bind_inference(server, fused_states, inference_batch_size, observation_shape
   estimate exact.  `lock`: held
   while a batch is SUBMITTED to the stream (not while it runs): a training thread that dequeues completed unrolls on
   the same stream takes it too, so that its count read and column moves are not interleaved with a batch.
-  `pipeline`: graph instances with their own static inputs; 1 (default): copies, replay and read-back on the one
-  inference stream; 2: the copies of batch i+1 go to a copy stream beside the replay of batch i (measured SLOWER on
-  MI355X / ROCm 7: 1.30 vs 1.77 M env-steps/s with the learner training alongside, tools/bench_serving.py)."""
+  `pipeline`: graph instances with their own static inputs.  1: copies, replay and read-back on the one inference
+  stream.  2 (default): the copies of batch i+1 go to a copy stream while the graph of batch i runs, the two streams
+  ordered by HOST waits of the submitting thread -- device-side cross-stream waits in front of the graph launches stalled
+  that thread for the whole copy (1.30 M env-steps/s against 2.0 M on one stream and 2.2-2.26 M host-ordered, learner
+  training alongside on MI355X / ROCm 7: tools/bench_serving.py)."""
   import torch
   from seed_rl_amd import inference as inf
   n = inference_batch_size
@@ -344,16 +346,17 @@ def bind_inference(server, fused_states, inference_batch_size, observation_shape
       g = graphs[k]
       with torch.cuda.device(st.device):
         if s_copy is not s_inf:
+          # two streams ordered by the HOST (this thread exists to wait): device-side cross-stream waits in front of
+          # graph launches were measured to stall the submitting thread for the whole copy
+          if ran[k] is not None:
+            ran[k].synchronize()                     # the previous replay of this instance has read its inputs
           with torch.cuda.stream(s_copy):
-            if ran[k] is not None:
-              s_copy.wait_event(ran[k])
             g.stage(req[slot], obs[slot])
             staged[k].record(s_copy)
+          staged[k].synchronize()                    # meanwhile the previous batch's graph runs on the inference stream
         with st_lock:
           with torch.cuda.stream(s_inf):
-            if s_copy is not s_inf:
-              s_inf.wait_event(staged[k])
-            else:
+            if s_copy is s_inf:
               g.stage(req[slot], obs[slot])          # one stream: copies, replay and read-back in order
             actions = g.launch()
             if s_copy is not s_inf:
