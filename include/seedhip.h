@@ -149,6 +149,15 @@ int seedhip_stack_frames_f32(const uint8_t* frames_ext, const uint8_t* nvalid, i
                              float* stacked /* [T,B,HW,4] newest->oldest, range 0..255 */, void* stream);
 int seedhip_stack_pack_state(const uint8_t* frames_ext, const uint8_t* nvalid, int T, int B, long long HW,
                              int* new_state /* [B,HW] */, void* stream);
+/* The same two steps against a per-environment state TABLE int32[num_envs, HW] (central inference keeps one packed
+ * state per env, learner.py:381-403): column b's state is state_table[rows[b]] (rows NULL: row b), read in place --
+ * zero_mask[b] != 0 (may be NULL): the actor restarted, its state counts as zeros (:363-365) -- and written back in
+ * place (valid_mask[b] == 0: row skipped).  Replaces a gather of n rows into a scratch and a scatter back. HW % 4 == 0. */
+int seedhip_stack_prepare_indexed(const int* state_table, const long long* rows, const uint8_t* zero_mask,
+                                  const uint8_t* done, int T, int B, long long HW, uint8_t* frames_ext, uint8_t* nvalid,
+                                  void* stream);
+int seedhip_stack_pack_state_indexed(const uint8_t* frames_ext, const uint8_t* nvalid, int T, int B, long long HW,
+                                     int* state_table, const long long* rows, const uint8_t* valid_mask, void* stream);
 
 /* ---- Conv2D / Dense on fp32 MFMA -------------------------------------------------------
  * Replace the Keras Conv2D / Dense forward of dmlab/networks.py:31-60,84-89,116-118 and
@@ -328,14 +337,18 @@ int seedhip_rows_move_multi(int nfields, void* const* dst, const void* const* sr
 /* inference_pre also validates the ids: out-of-range (flag 1) and duplicate (flag 2, found in O(1) through
  * stamp_table[num_envs] / *call_counter, both zero-initialised by the caller and owned by these kernels) rows get
  * valid[i] = 0 and are skipped by every table access of the step; ids_safe[i] is the id clamped into range for the
- * gathers that run unmasked.  (The reference raises on both: common/utils.py:173-176.) */
+ * gathers that run unmasked.  (The reference raises on both: common/utils.py:173-176.)
+ * will_complete u8[n] (optional; ABI 3): 1 where the env's unroll completes with this step (store index, after a
+ * possible reset, + 1 == full_length) -- known before the agent runs, so the caller can set aside the previous agent
+ * state of exactly those envs (first_agent_states.replace(completed, agent_states.read(completed)), learner.py:398-399)
+ * and let the agent update its state tables in place. */
 int seedhip_inference_pre(const long long* env_ids, const long long* run_ids, const float* reward,
                           const float* raw_reward, const uint8_t* done, int n, int num_envs, int num_action_repeats,
                           long long* run_ids_table, long long* info_frames, float* info_return,
                           float* info_raw_return, long long* actions_table, long long* store_index,
                           uint8_t* reset_mask, long long* prev_actions, float* episode_stats, int stats_capacity,
                           int* stats_count, int* error_flag, long long* ids_safe, uint8_t* valid, int* stamp_table,
-                          int* call_counter, void* stream);
+                          int* call_counter, uint8_t* will_complete /* may be NULL */, int full_length, void* stream);
 /* inference_post: env_ids = ids_safe, valid = the mask of inference_pre (NULL: every in-range row).  With
  * policy_logits != NULL the actions are SAMPLED here from the head rows policy_logits[i*logits_ld + a] (Gumbel-max
  * over Philox4x32-10 randoms keyed by rng_state[0] = seed, rng_state[1] = call counter, advanced by this launch:

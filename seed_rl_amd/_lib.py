@@ -67,6 +67,8 @@ SIGNATURES = {
     'seedhip_stack_prepare': (c_int, [P, P, c_int, c_int, c_ll, P, P, P]),
     'seedhip_stack_frames_f32': (c_int, [P, P, c_int, c_int, c_ll, P, P]),
     'seedhip_stack_pack_state': (c_int, [P, P, c_int, c_int, c_ll, P, P]),
+    'seedhip_stack_prepare_indexed': (c_int, [P, P, P, P, c_int, c_int, c_ll, P, P, P]),
+    'seedhip_stack_pack_state_indexed': (c_int, [P, P, c_int, c_int, c_ll, P, P, P, P]),
     'seedhip_conv2d_fwd': (c_int, [ctypes.POINTER(ConvGeom), P, c_int, c_int, P, P, P, c_int, P, P]),
     'seedhip_conv2d_bwd_data': (c_int, [ctypes.POINTER(ConvGeom), P, P, P, P, P, P]),
     'seedhip_conv2d_fwd_workspace_bytes': (c_size_t, [ctypes.POINTER(ConvGeom)]),
@@ -100,7 +102,7 @@ SIGNATURES = {
     'seedhip_rows_move_masked': (c_int, [P, P, P, P, c_ll, c_ll, P, c_int, P]),
     'seedhip_rows_move_multi': (c_int, [c_int, P, P, P, P, P, c_ll, P, c_int, P]),
     'seedhip_inference_pre': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P,
-                                      P, P, P, P, P]),
+                                      P, P, P, P, P, c_int, P]),
     'seedhip_inference_post': (c_int, [P, P, P, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P,
                                        P, P, P, P, P]),
     'seedhip_categorical_sample': (c_int, [P, c_int, c_ll, c_int, P, P, P]),

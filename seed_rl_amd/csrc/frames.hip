@@ -82,8 +82,94 @@ stack_pack_kernel(const uint8_t* __restrict__ frames_ext, const uint8_t* __restr
   }
 }
 
+// ---- the same two steps against a per-environment state TABLE (central inference, learner.py:381-403) ------------- //
+// `state_table[rows[b]]` is column b's packed state: stack_prepare reads it in place (zero_mask[b] != 0: the actor
+// restarted, its state counts as zeros) and stack_pack writes the new state back in place (valid_mask[b] == 0: skip
+// the row) -- the gather of n x 28 KB into a scratch and the scatter back (2 x 58 MB of traffic per inference batch of
+// 1024 Atari envs) disappear.  Four pixels per thread: one 16-byte state access, three / one 4-byte frame accesses.
+__global__ void __launch_bounds__(256)
+stack_prepare_rows_kernel(const int* __restrict__ table, const long long* __restrict__ rows,
+                          const uint8_t* __restrict__ zero_mask, const uint8_t* __restrict__ done, int T, int B,
+                          long long HW, uint8_t* __restrict__ frames_ext, uint8_t* __restrict__ nvalid) {
+  const long long q = HW >> 2, n4 = (long long)B * q, n = (long long)B * HW;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const long long b = i / q, e = i - b * q;
+    uint4 s = make_uint4(0, 0, 0, 0);
+    if (!(zero_mask && zero_mask[b]))
+      s = reinterpret_cast<const uint4*>(table + (rows ? rows[b] : b) * HW)[e];
+    const unsigned v[4] = {s.x, s.y, s.z, s.w};
+    unsigned f[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[0] |= (v[k] & 0xFFu) << (8 * k);                      // oldest   (time -3)
+      f[1] |= ((v[k] >> 8) & 0xFFu) << (8 * k);               //          (time -2)
+      f[2] |= ((v[k] >> 16) & 0xFFu) << (8 * k);              // newest   (time -1)
+    }
+    const long long at = b * HW + 4 * e;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) *reinterpret_cast<unsigned*>(frames_ext + r * n + at) = f[r];
+  }
+  const long long tb = (long long)T * B;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tb; i += stride) {
+    const long long t = i / B;
+    int nv = 4;
+    if (done[i]) nv = 1;
+    else if (t >= 1 && done[i - B]) nv = 2;
+    else if (t >= 2 && done[i - 2 * (long long)B]) nv = 3;
+    nvalid[i] = (uint8_t)nv;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+stack_pack_rows_kernel(const uint8_t* __restrict__ frames_ext, const uint8_t* __restrict__ nvalid, int T, int B,
+                       long long HW, int* __restrict__ table, const long long* __restrict__ rows,
+                       const uint8_t* __restrict__ valid_mask) {
+  const long long q = HW >> 2, n4 = (long long)B * q, n = (long long)B * HW;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const long long b = i / q, e = i - b * q;
+    if (valid_mask && !valid_mask[b]) continue;
+    const int nv = nvalid[(long long)(T - 1) * B + b];
+    const uint8_t* p = frames_ext + (long long)(T - 1 + 3) * n + b * HW + 4 * e;      // newest frame, 4 pixels
+    const unsigned f0 = *reinterpret_cast<const unsigned*>(p);
+    const unsigned f1 = nv > 1 ? *reinterpret_cast<const unsigned*>(p - n) : 0u;
+    const unsigned f2 = nv > 2 ? *reinterpret_cast<const unsigned*>(p - 2 * n) : 0u;
+    unsigned o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)                               // networks.py:164-169 (MSB = newest)
+      o[k] = (((f0 >> (8 * k)) & 0xFFu) << 16) | (((f1 >> (8 * k)) & 0xFFu) << 8) | ((f2 >> (8 * k)) & 0xFFu);
+    reinterpret_cast<uint4*>(table + (rows ? rows[b] : b) * HW)[e] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 int grid_for(long long n) { int g = seedhip::cdiv(n, 256); return g > 4096 ? 4096 : (g < 1 ? 1 : g); }
 }  // namespace
+
+extern "C" int seedhip_stack_prepare_indexed(const int* state_table, const long long* rows, const uint8_t* zero_mask,
+                                             const uint8_t* done, int T, int B, long long HW, uint8_t* frames_ext,
+                                             uint8_t* nvalid, void* stream) {
+  SEEDHIP_REQUIRE(T >= 1 && B >= 1 && HW >= 4 && HW % 4 == 0, "stack_prepare_indexed: need T, B >= 1 and HW %% 4 == 0");
+  SEEDHIP_REQUIRE(state_table && done && frames_ext && nvalid, "stack_prepare_indexed: null pointer");
+  SEEDHIP_REQUIRE(((((uintptr_t)state_table) & 15) | (((uintptr_t)frames_ext) & 3)) == 0,
+                  "stack_prepare_indexed: state table must be 16-byte aligned, frames 4-byte aligned");
+  const long long n = (long long)B * (HW / 4) > (long long)T * B ? (long long)B * (HW / 4) : (long long)T * B;
+  hipLaunchKernelGGL(stack_prepare_rows_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, state_table, rows,
+                     zero_mask, done, T, B, HW, frames_ext, nvalid);
+  return seedhip::check_launch("stack_prepare_rows_kernel");
+}
+
+extern "C" int seedhip_stack_pack_state_indexed(const uint8_t* frames_ext, const uint8_t* nvalid, int T, int B,
+                                                long long HW, int* state_table, const long long* rows,
+                                                const uint8_t* valid_mask, void* stream) {
+  SEEDHIP_REQUIRE(T >= 1 && B >= 1 && HW >= 4 && HW % 4 == 0, "stack_pack_indexed: need T, B >= 1 and HW %% 4 == 0");
+  SEEDHIP_REQUIRE(frames_ext && nvalid && state_table, "stack_pack_indexed: null pointer");
+  SEEDHIP_REQUIRE(((((uintptr_t)state_table) & 15) | (((uintptr_t)frames_ext) & 3)) == 0,
+                  "stack_pack_indexed: state table must be 16-byte aligned, frames 4-byte aligned");
+  hipLaunchKernelGGL(stack_pack_rows_kernel, dim3(grid_for((long long)B * (HW / 4))), dim3(256), 0, (hipStream_t)stream,
+                     frames_ext, nvalid, T, B, HW, state_table, rows, valid_mask);
+  return seedhip::check_launch("stack_pack_rows_kernel");
+}
 
 extern "C" int seedhip_stack_prepare(const int* frame_stacking_state, const uint8_t* done, int T, int B,
                                      long long HW, uint8_t* frames_ext, uint8_t* nvalid, void* stream) {

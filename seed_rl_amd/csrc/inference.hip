@@ -28,6 +28,7 @@ struct PreArgs {
   uint8_t* reset_mask; long long* prev_actions;
   float* episode_stats; int stats_capacity; int* stats_count; int* error_flag;
   long long* ids_safe; uint8_t* valid; int* stamp_tab; int* call_counter;
+  uint8_t* will_complete; int full_length;                 // optional: rows whose unroll completes with this step
 };
 
 __global__ void __launch_bounds__(1024)
@@ -44,6 +45,7 @@ inference_pre_kernel(PreArgs a) {
     // the step (valid = 0, ids_safe = 0 keeps reads in range) and the error is flagged
     atomicOr(a.error_flag, 1);
     a.reset_mask[i] = 0; a.prev_actions[i] = 0; a.ids_safe[i] = 0; a.valid[i] = 0;
+    if (a.will_complete) a.will_complete[i] = 0;
     return;
   }
   // duplicate ids in one batch are an error in the reference (utils.py:173-176): the first occurrence stamps the
@@ -52,6 +54,7 @@ inference_pre_kernel(PreArgs a) {
   if (atomicExch(a.stamp_tab + e, stamp) == stamp) {
     atomicOr(a.error_flag, 2);
     a.reset_mask[i] = 0; a.prev_actions[i] = 0; a.ids_safe[i] = e; a.valid[i] = 0;
+    if (a.will_complete) a.will_complete[i] = 0;
     return;
   }
   a.ids_safe[i] = e; a.valid[i] = 1;
@@ -81,6 +84,9 @@ inference_pre_kernel(PreArgs a) {
   a.info_frames[e] = frames; a.info_return[e] = ret; a.info_raw_return[e] = raw;
   a.reset_mask[i] = reset ? 1 : 0;
   a.prev_actions[i] = act;                                             // :381
+  // the unroll of env e completes with this step iff its (possibly just reset) write index is the last row: known
+  // BEFORE the agent runs, so the previous agent state of exactly those envs can be set aside (learner.py:398-399)
+  if (a.will_complete) a.will_complete[i] = (a.store_index[e] + 1 == a.full_length) ? 1 : 0;
 }
 
 struct PostArgs {
@@ -162,11 +168,27 @@ inference_post_kernel(PostArgs a) {
     a.complete[i] = ok ? 1 : 0;
     a.carry[i] = done ? 1 : 0;
     a.batch_cols[i] = ok ? col : 0;
-    for (int t = 0; t < L; ++t) {
-      a.gather_src[(long long)t * a.n + i] = (long long)t * E + e;
-      a.gather_dst[(long long)t * a.n + i] = ok ? (long long)t * a.batch_capacity + col : 0;
-      a.gather_mask[(long long)t * a.n + i] = ok ? 1 : 0;
-    }
+  }
+}
+
+// Row lists of the completed-unroll emission, one workgroup per time step (the single bookkeeping workgroup used to
+// write all full_length * n entries itself: 17 us of a 1024-row step): row (t, i) moves store row t * E + e_i to batch
+// row t * capacity + col_i when env i completed an unroll that got a column.
+__global__ void __launch_bounds__(256)
+emit_rows_fill_kernel(const long long* __restrict__ env_ids, const uint8_t* __restrict__ valid,
+                      const uint8_t* __restrict__ complete, const long long* __restrict__ batch_cols, int n, int E,
+                      int capacity, long long* __restrict__ gather_src, long long* __restrict__ gather_dst,
+                      uint8_t* __restrict__ gather_mask) {
+  const int t = blockIdx.x;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    long long e = env_ids[i];
+    const bool ok_row = valid ? valid[i] != 0 : (e >= 0 && e < E);
+    if (!ok_row) e = 0;
+    const bool ok = complete[i] != 0;
+    const long long k = (long long)t * n + i;
+    gather_src[k] = (long long)t * E + e;
+    gather_dst[k] = ok ? (long long)t * capacity + batch_cols[i] : 0;
+    gather_mask[k] = ok ? 1 : 0;
   }
 }
 
@@ -324,7 +346,7 @@ extern "C" int seedhip_inference_pre(const long long* env_ids, const long long* 
                                      long long* store_index, uint8_t* reset_mask, long long* prev_actions,
                                      float* episode_stats, int stats_capacity, int* stats_count, int* error_flag,
                                      long long* ids_safe, uint8_t* valid, int* stamp_table, int* call_counter,
-                                     void* stream) {
+                                     uint8_t* will_complete, int full_length, void* stream) {
   SEEDHIP_REQUIRE(n >= 1 && n <= 1024 && num_envs >= 1, "inference_pre: need 1 <= n <= 1024");
   SEEDHIP_REQUIRE(env_ids && run_ids && reward && raw_reward && done && run_ids_table && info_frames && info_return &&
                   info_raw_return && actions_table && store_index && reset_mask && prev_actions && episode_stats &&
@@ -332,7 +354,8 @@ extern "C" int seedhip_inference_pre(const long long* env_ids, const long long* 
                   "inference_pre: null pointer");
   PreArgs a{env_ids, run_ids, reward, raw_reward, done, n, num_envs, num_action_repeats, run_ids_table, info_frames,
             info_return, info_raw_return, actions_table, store_index, reset_mask, prev_actions, episode_stats,
-            stats_capacity, stats_count, error_flag, ids_safe, valid, stamp_table, call_counter};
+            stats_capacity, stats_count, error_flag, ids_safe, valid, stamp_table, call_counter, will_complete,
+            full_length};
   hipLaunchKernelGGL(inference_pre_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
   return seedhip::check_launch("inference_pre_kernel");
 }
@@ -356,6 +379,9 @@ extern "C" int seedhip_inference_post(const long long* env_ids, const uint8_t* v
              batch_capacity, store_index, actions_table, batch_count, append_rows, complete, carry, batch_cols,
              gather_src, gather_dst, gather_mask, last_rows, error_flag};
   hipLaunchKernelGGL(inference_post_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(emit_rows_fill_kernel, dim3(full_length), dim3(256), 0, (hipStream_t)stream, env_ids, valid,
+                     (const uint8_t*)complete, (const long long*)batch_cols, n, num_envs, batch_capacity, gather_src,
+                     gather_dst, gather_mask);
   return seedhip::check_launch("inference_post_kernel");
 }
 

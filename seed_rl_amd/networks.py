@@ -27,6 +27,10 @@ from seed_rl_amd import _lib, ops
 from seed_rl_amd.flat import FlatParams
 
 AgentOutput = collections.namedtuple('AgentOutput', 'action policy_logits baseline')
+# A frame-stacking state that is NOT a [B, HW] tensor but rows of a per-environment table, read and updated in place
+# by the torso (csrc/frames.hip: *_indexed): column b's state is table[rows[b]]; zero_mask[b] != 0: counts as zeros
+# (restarted actor); valid_mask[b] == 0: the row is not written back.  Passed by inference.FusedInferenceState.
+IndexedFrameState = collections.namedtuple('IndexedFrameState', 'table rows zero_mask valid_mask')
 AgentState = collections.namedtuple('AgentState', 'core_state frame_stacking_state')
 
 
@@ -435,7 +439,12 @@ class _AtariTorso(object):
     if fr.data_ptr() != ext[3:].data_ptr():
       ext[3:].copy_(fr)
     nvalid = self._buf('nvalid', (T1, B), torch.uint8)
-    ops.stack_prepare(frame_state.contiguous(), done_u8, T1, B, HW, ext, nvalid)
+    indexed = isinstance(frame_state, IndexedFrameState)
+    if indexed:                                   # central inference: the state lives in a per-env table, used in place
+      ops.stack_prepare_indexed(frame_state.table, frame_state.rows, frame_state.zero_mask, done_u8, T1, B, HW, ext,
+                                nvalid)
+    else:
+      ops.stack_prepare(frame_state.contiguous(), done_u8, T1, B, HW, ext, nvalid)
     acts, geoms = [], []
     ih, iw, cin, k, s, ch, oh, ow = self._shapes[0]
     g0 = ops.StackConvGeom(T1, B, ih, iw, oh, ow, k, k, s, ch, ch)
@@ -451,7 +460,10 @@ class _AtariTorso(object):
     gfc = ops.dense_geom(N, self._flat_dim, self._fc, ld_out=ld_out)
     ops.conv2d_fwd(gfc, a, fl.p(tp + 'fc/kernel'), fl.p(tp + 'fc/bias'), out, out_relu=True)
     new_fs = None
-    if need_state:                                # the learner discards it (agents/vtrace/learner.py:75-79 `learner_outputs, _ =`)
+    if need_state and indexed:
+      ops.stack_pack_state_indexed(ext, nvalid, T1, B, HW, frame_state.table, frame_state.rows, frame_state.valid_mask)
+      new_fs = frame_state                        # updated in place
+    elif need_state:                              # the learner discards it (agents/vtrace/learner.py:75-79 `learner_outputs, _ =`)
       new_fs = torch.empty_like(frame_state)
       ops.stack_pack_state(ext, nvalid, T1, B, HW, new_fs)
     return new_fs, dict(ext=ext, nvalid=nvalid, acts=acts, geoms=geoms, gfc=gfc)
@@ -508,6 +520,7 @@ class AtariShallow(_Agent, _AtariTorso):
 
   accepts_need_state = True      # need_state=False: skip re-packing the frame-stacking state the caller will not use
   accepts_sample_actions = True
+  accepts_indexed_frame_state = True    # agent_state.frame_stacking_state may be an IndexedFrameState (table rows, in place)
 
   def __call__(self, prev_actions, env_outputs, agent_state, unroll=False, is_training=False, need_state=True,
                sample_actions=True):

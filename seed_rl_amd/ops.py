@@ -175,6 +175,24 @@ def stack_prepare(state, done_u8, T, B, HW, frames_ext, nvalid):
           'seedhip_stack_prepare')
 
 
+def stack_prepare_indexed(table, rows, zero_mask, done_u8, T, B, HW, frames_ext, nvalid):
+  """stack_prepare reading column b's state from table[rows[b]] in place (zero where zero_mask[b])."""
+  with _region('stack_prepare', 0, B * HW * 7):
+    with _dev(frames_ext):
+      _lib.check(_lib.lib().seedhip_stack_prepare_indexed(
+          _lib.ptr(table), _lib.ptr(rows), _lib.ptr(zero_mask), _lib.ptr(done_u8), T, B, HW, _lib.ptr(frames_ext),
+          _lib.ptr(nvalid), _lib.stream()), 'seedhip_stack_prepare_indexed')
+
+
+def stack_pack_state_indexed(frames_ext, nvalid, T, B, HW, table, rows, valid_mask):
+  """stack_pack_state writing column b's new state to table[rows[b]] in place (rows with valid_mask == 0 skipped)."""
+  with _region('stack_pack_state', 0, B * HW * 7):
+    with _dev(table):
+      _lib.check(_lib.lib().seedhip_stack_pack_state_indexed(
+          _lib.ptr(frames_ext), _lib.ptr(nvalid), T, B, HW, _lib.ptr(table), _lib.ptr(rows), _lib.ptr(valid_mask),
+          _lib.stream()), 'seedhip_stack_pack_state_indexed')
+
+
 def unpackbits_u16(packed, out):
   """football/observation.py:48-63: uint16 / int16 words [...] -> uint8 [... * 16] of 0 / 255."""
   with _dev(out):
@@ -457,15 +475,16 @@ def rows_move_masked(dst, dst_rows, src, src_rows, n, row_bytes, mask_u8, zero_w
 
 def inference_pre(env_ids, run_ids, reward, raw_reward, done_u8, n, num_envs, num_action_repeats, run_ids_tab,
                   info_frames, info_return, info_raw, actions_tab, store_index, reset_mask, prev_actions,
-                  episode_stats, stats_count, error_flag, ids_safe, valid, stamp_tab, call_counter):
+                  episode_stats, stats_count, error_flag, ids_safe, valid, stamp_tab, call_counter, will_complete=None,
+                  full_length=0):
   with _dev(reset_mask):
     _lib.check(_lib.lib().seedhip_inference_pre(
         _lib.ptr(env_ids), _lib.ptr(run_ids), _lib.ptr(reward), _lib.ptr(raw_reward), _lib.ptr(done_u8), n, num_envs,
         num_action_repeats, _lib.ptr(run_ids_tab), _lib.ptr(info_frames), _lib.ptr(info_return), _lib.ptr(info_raw),
         _lib.ptr(actions_tab), _lib.ptr(store_index), _lib.ptr(reset_mask), _lib.ptr(prev_actions),
         _lib.ptr(episode_stats), episode_stats.shape[0], _lib.ptr(stats_count), _lib.ptr(error_flag),
-        _lib.ptr(ids_safe), _lib.ptr(valid), _lib.ptr(stamp_tab), _lib.ptr(call_counter), _lib.stream()),
-        'seedhip_inference_pre')
+        _lib.ptr(ids_safe), _lib.ptr(valid), _lib.ptr(stamp_tab), _lib.ptr(call_counter), _lib.ptr(will_complete),
+        int(full_length), _lib.stream()), 'seedhip_inference_pre')
 
 
 def inference_post(env_ids, valid, actions, logits, logits_ld, num_actions, rng_state, n, num_envs, full_length,

@@ -331,3 +331,42 @@ def test_graphed_inference_packed_request(device):
   from seed_rl_amd import utils
   for x, y in zip(utils.flatten(a.batch) + [a.info_return, a.info_raw], utils.flatten(b.batch) + [b.info_return, b.info_raw]):
     assert torch.equal(x, y)
+
+
+def test_stack_state_indexed_matches_gather_scatter(device):
+  """csrc/frames.hip *_indexed (the frame-stacking state used in place in its per-env table, atari/networks.py:102-108,
+  164-169 through learner.py:381-403) equals gather -> stack_prepare / stack_pack_state -> scatter, bit for bit,
+  including restarted actors (state counts as zeros) and rows that must not be written back."""
+  from seed_rl_amd import ops
+  E, n, HW, T1 = 11, 6, 7056, 1
+  rng = np.random.default_rng(0)
+  table = torch.as_tensor(rng.integers(0, 2 ** 24, (E, HW)).astype(np.int32)).to(device)
+  rows = torch.as_tensor(np.array([7, 2, 9, 0, 4, 10], np.int64)).to(device)
+  zero = torch.as_tensor(np.array([0, 1, 0, 0, 1, 0], np.uint8)).to(device)
+  valid = torch.as_tensor(np.array([1, 1, 0, 1, 1, 1], np.uint8)).to(device)
+  done = torch.as_tensor(np.array([[0, 0, 1, 0, 0, 1]], np.uint8)).to(device)
+  frames = torch.as_tensor(rng.integers(0, 256, (n, HW)).astype(np.uint8)).to(device)
+  # dense path
+  st = table[rows].clone()
+  st[zero.bool()] = 0
+  ext_a = torch.zeros((T1 + 3, n, HW), dtype=torch.uint8, device=device); ext_a[3] = frames
+  nv_a = torch.zeros((T1, n), dtype=torch.uint8, device=device)
+  ops.stack_prepare(st.contiguous(), done, T1, n, HW, ext_a, nv_a)
+  new_a = torch.empty_like(st)
+  ops.stack_pack_state(ext_a, nv_a, T1, n, HW, new_a)
+  want = table.clone()
+  keep = valid.bool()
+  want[rows[keep]] = new_a[keep]
+  # in place
+  tab_b = table.clone()
+  ext_b = torch.zeros_like(ext_a); ext_b[3] = frames
+  nv_b = torch.zeros_like(nv_a)
+  ops.stack_prepare_indexed(tab_b, rows, zero, done, T1, n, HW, ext_b, nv_b)
+  assert torch.equal(ext_b, ext_a) and torch.equal(nv_b, nv_a)
+  ops.stack_pack_state_indexed(ext_b, nv_b, T1, n, HW, tab_b, rows, valid)
+  assert torch.equal(tab_b, want)
+  # rows = None: row b, no masks
+  tab_c = table[:n].clone().contiguous()
+  ops.stack_prepare_indexed(tab_c, None, None, done, T1, n, HW, ext_b, nv_b)
+  ops.stack_prepare(table[:n].contiguous(), done, T1, n, HW, ext_a, nv_a)
+  assert torch.equal(ext_b, ext_a)
