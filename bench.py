@@ -290,8 +290,12 @@ def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, 
   if hasattr(agent, 'check_errors'):
     agent.check_errors()
 
-  free = prof.summary()[dominant]
+  free = prof.summary().get(dominant) or dict(avg_ms=0.0)
   d = kern[dominant]
+  if not free.get('avg_ms', 0.0) > 0.0:          # tiny shapes: an event pair around a few-microsecond kernel can read 0
+    free = dict(free, avg_ms=d['avg_ms'])
+  if not d['avg_ms'] > 0.0:
+    d = dict(d, avg_ms=1e-6); free = dict(free, avg_ms=1e-6)
   flops, nbytes = d['flops'], d['bytes']
   if flops > 0:
     peak, bf16x3 = _peak(dominant)
@@ -379,6 +383,52 @@ def inference_record(dev, sizes=(64, 256, 1024), unroll_len=20, calls=200):
                  'frames) into the static inputs + one HIP-graph replay (bookkeeping, agent forward, in-kernel action '
                  'sampling, store append, completed unrolls -> training batch); Atari shallow agent, A=18, unroll 20')
   return out
+
+
+def r2d2_replay_record(dev, steps=5, T=120, B=256, A=18, burn_in=40, replay_size=2048):
+  """cfg5 END TO END (agents/r2d2/learner.py:387-468, 856-885): every iteration inserts freshly completed unrolls
+  (B / replay_ratio of them, replay_ratio 1.5: learner.py:62-66) with initial priorities, samples a prioritized batch
+  time-major out of the device replay, trains and writes the new priorities back (r2d2_loop.ReplayTrainer)."""
+  from seed_rl_amd import networks, optimizers, r2d2_learner, r2d2_loop
+  T1 = T + 1
+  agent = networks.DuelingLSTMDQNNet(A, device=dev, seed=0)
+  target = networks.DuelingLSTMDQNNet(A, device=dev, seed=0)
+  cfg = r2d2_learner.R2D2Config(burn_in=burn_in)
+  lrn = r2d2_learner.R2D2Learner(agent, target, optimizers.Adam(4.8e-4, epsilon=1e-3), cfg)
+  specs = r2d2_loop.unroll_specs(agent, T - burn_in, burn_in, (84, 84, 1), A)
+  tr = r2d2_loop.ReplayTrainer(lrn, specs, replay_buffer_size=replay_size, replay_buffer_min_size=2 * B,
+                               batch_size=B, device=dev)
+  g = torch.Generator(device='cpu').manual_seed(0)
+
+  def fresh(n):
+    from seed_rl_amd import utils
+    env = utils.EnvOutput(torch.randn((T1, n), generator=g).to(dev), (torch.rand((T1, n), generator=g) < 0.01).to(dev),
+                          torch.randint(0, 256, (T1, n, 84, 84, 1), dtype=torch.uint8, generator=g).to(dev),
+                          torch.zeros((T1, n), dtype=torch.bool, device=dev),
+                          torch.zeros((T1, n), dtype=torch.int32, device=dev))
+    ao = networks.R2D2AgentOutput(torch.randint(0, A, (T1, n), generator=g).to(dev),
+                                  torch.rand((T1, n, A), generator=g).to(dev))
+    u = r2d2_learner.Unroll(agent.initial_state(n), None, torch.randint(0, A, (T1, n), generator=g).to(dev), env, ao)
+    return u._replace(priority=r2d2_loop.initial_priorities(agent, u, burn_in, cfg))
+  n_ins = int(round(B / 1.5))
+  tr.insert(fresh(2 * B))
+  new = fresh(n_ins)
+  for _ in range(2):
+    tr.insert(new); tr.train_step()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    tr.insert(new)
+    loss, _, _, _ = tr.train_step()
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / steps
+  rec = dict(ms_per_iteration=round(dt * 1e3, 3), env_frames_per_s=round(B * T / dt, 1), loss=round(float(loss), 6),
+             inserted_per_iteration=n_ins, replay_unrolls=replay_size, launch='eager',
+             note='insert (initial priorities) + prioritized sample, time-major out of the HBM replay + train step + '
+                  'update_priorities per iteration; the plain train step on a resident batch is ms_per_step above')
+  del agent, target, lrn, tr
+  _release()
+  return rec
 
 
 def ingest_record(dev, steps, T=20, B=512, A=18):
@@ -584,6 +634,11 @@ def main():
           # one train step at THAT shape against the CPU oracle (tests/test_gpu_fullsize.py runs the same comparison)
           pf = parity.deep_step if cfg == 'dmlab' else parity.r2d2_step
           pr = parity.public(pf(dev, T1=r['T'] + 1, B=r['B'], A=r['A'], truth=False))
+          if cfg == 'r2d2':
+            try:
+              others[name]['replay_loop'] = r2d2_replay_record(dev)
+            except Exception as e:               # pylint: disable=broad-except
+              others[name]['replay_loop'] = dict(error=repr(e))
           others[name]['parity'] = {k: pr[k] for k in (
               'loss', 'loss_ref', 'loss_rel_err', 'logits_max_abs_err', 'baseline_max_abs_err', 'q_max_abs_err',
               'priority_max_rel_err', 'grad_q99_rel_err', 'grad_max_rel_err', 'grad_worst', 'grad_norm_rel_err',

@@ -104,13 +104,22 @@ def test_cfg3_dmlab_T20_B256(device):
   """BASELINE configs[2] exactly as bench.py runs it: T=20, B=256, A=9 (dmlab/networks.py:135-171).  This is the shape
   at which the halo kernels' persistent grids, the gemm.h cost-model plans and the LSTM sequence kernels (8 row tiles x
   32 workgroups) are benched; the fp32 oracle of the same graph takes about a minute of host time."""
-  r = parity.deep_step(device, T1=21, B=256, A=9, truth=False)
+  import os
+  # the fp64 evaluation of the same graph (oneDNN has no fp64 convolution: ~3 minutes of host time) says how far the
+  # fp32 ORACLE itself is from the truth on these 3.7e7-term sums; SEEDHIP_SKIP_FP64=1 skips it (builder's quick runs)
+  truth = os.environ.get('SEEDHIP_SKIP_FP64', '0') != '1'
+  r = parity.deep_step(device, T1=21, B=256, A=9, truth=truth)
   _record('cfg3_dmlab_T20_B256', r)
   assert r['loss_rel_err'] <= 2e-4, _show(r)
   assert r['logits_max_abs_err'] <= 3e-4 and r['baseline_max_abs_err'] <= 3e-4, _show(r)
   assert r['grad_q99_rel_err'] <= 1.5e-3, _show(r)
   assert r['grad_max_rel_err_post_pool'] <= 2e-3, _show(r)
   assert r['grad_max_rel_err'] <= 1e-2, _show(r)
+  if truth:
+    # the gate: against fp64 the HIP gradients may be no further away than 3x the fp32 oracle's own distance (+1e-4)
+    assert r['grad_q99_rel_err_vs_fp64'] <= 1.5e-3, _show(r)
+    assert r['grad_q99_rel_err_vs_fp64'] <= 3 * r['oracle_grad_q99_rel_err_vs_fp64'] + 1e-4, _show(r)
+    assert r['grad_max_rel_err_vs_fp64'] <= 1e-2, _show(r)
   _check_params(r)
 
 

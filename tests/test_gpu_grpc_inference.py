@@ -35,12 +35,17 @@ def test_actors_through_grpc_into_fused_inference(device, transport):
     gs.bind_inference(server, fused, n, obs_shape)
   server.start()
   steps = 2 * T + 1
+  # closed-loop actors must stay in step: were some of them allowed to run ahead, the last calls of the slow ones
+  # (fewer than n of them, each waiting for its answer) could never fill a batch -- the reference blocks the same way
+  import threading
+  in_step = threading.Barrier(E)
 
   def actor(env_id):
     rng = np.random.default_rng(env_id)
     client = gs.Client(address)
     acts = []
     for step in range(steps):
+      in_step.wait(timeout=120)
       env = utils.EnvOutput(np.float32(rng.normal()), np.bool_(step > 0 and rng.uniform() < 0.2),
                             rng.integers(0, 256, obs_shape).astype(np.uint8), np.bool_(False), np.int32(step))
       a = client.inference(np.int32(env_id), np.int64(1000 + env_id), env, np.float32(rng.normal()))

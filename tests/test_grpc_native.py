@@ -297,3 +297,56 @@ def test_stress(address):                                            # ops_test.
   # grpcio pools the channels of one process onto one connection: the ten clients are ten pairs of HTTP/2 streams
   assert st['connections'] >= 1 and st['streams'] == 2 * num_clients
   server.shutdown()
+
+
+def test_many_connections_large_messages(address):
+  """Twelve CONNECTIONS (one channel each: grpc.use_local_subchannel_pool) spread over three I/O threads, 150 calls of
+  3 rows x 64 KB each per connection: exercises the cross-thread response path (12 pending answers per batch, posted from
+  the compute thread to three I/O threads) and flow control of large DATA frames.  Every caller must get ITS rows back."""
+  import queue
+  import grpc
+  N, k, C, calls = 36, 3, 12, 150              # every batch = one call of every connection (closed loop, lock step)
+  @gs.function([TensorSpec((N,), np.int32), TensorSpec((N, 65536), np.uint8)], TensorSpec((N,), np.int64))
+  def foo(x, payload):
+    return x.astype(np.int64) * 1000 + payload[:, -1]
+  server = gn.NativeServer([address], num_io_threads=3)
+  server.bind(foo, num_slots=2)
+  server.start()
+  errors = []
+
+  def conn(cid):
+    try:
+      ch = grpc.insecure_channel(address, options=[('grpc.max_receive_message_length', -1),
+                                                   ('grpc.max_send_message_length', -1),
+                                                   ('grpc.use_local_subchannel_pool', 1)])
+      ident = lambda b: b
+      ch.unary_unary('/%s/Init' % gs.SERVICE, request_serializer=ident, response_deserializer=ident)(
+          b'', wait_for_ready=True, timeout=60)
+      q = queue.SimpleQueue()
+
+      def gen():
+        while True:
+          item = q.get()
+          if item is None:
+            return
+          yield item
+      responses = ch.stream_stream('/%s/Call' % gs.SERVICE, request_serializer=ident, response_deserializer=ident)(gen())
+      payload = np.zeros((k, 65536), np.uint8)
+      for i in range(calls):
+        x = np.array([cid * 10 + j for j in range(k)], np.int32)
+        payload[:, -1] = (i + cid) % 251
+        q.put(_req('foo', x, payload).SerializeToString())
+        resp = gs.CallResponse.FromString(next(responses))
+        assert resp.status_code == 0, resp.status_error_message
+        out = gs.decode_tensor(resp.tensor[0])[0]
+        assert out.tolist() == [int(v) * 1000 + (i + cid) % 251 for v in x], (cid, i, out.tolist())
+      q.put(None)
+      ch.close()
+    except Exception as e:                            # pylint: disable=broad-except
+      errors.append((cid, repr(e)))
+  with futures.ThreadPoolExecutor(max_workers=C) as ex:
+    list(ex.map(conn, range(C)))
+  st = server.stats()
+  server.shutdown()
+  assert not errors, errors[:3]
+  assert st['connections'] == C and st['calls'] == C * calls and st['batches'] == C * calls * k // N and st['errors'] == 0
