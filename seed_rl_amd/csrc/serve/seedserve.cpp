@@ -30,6 +30,7 @@
 #include <sys/un.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -719,7 +720,7 @@ void IoThread::run() {
   epoll_event evs[128];
   while (!srv->shutdown.load()) {
     const int n = epoll_wait(ep, evs, 128, 200);
-    std::vector<Conn*> touched;
+    std::vector<uint64_t> touched;                           // ids, not pointers: a connection may close below
     for (int i = 0; i < n; ++i) {
       const uint64_t key = evs[i].data.u64;
       if (key == 0) {                                        // wake-up: adopted connections + responses
@@ -741,7 +742,7 @@ void IoThread::run() {
       Conn* c = it->second;
       if (evs[i].events & (EPOLLHUP | EPOLLERR)) c->dead = true;
       if (!c->dead && (evs[i].events & EPOLLIN)) on_readable(c);
-      touched.push_back(c);
+      touched.push_back(c->id);
     }
     std::vector<OutItem> items; std::vector<int> fds;
     { std::lock_guard<std::mutex> l(mu); items.swap(outbox); fds.swap(new_fds); }
@@ -756,10 +757,17 @@ void IoThread::run() {
       s.out += it.data;
       if (s.inflight > 0) s.inflight--;
       if (s.deferred) { s.deferred = false; ng()->nghttp2_session_resume_data(c->session, it.stream); }
-      touched.push_back(c);
+      touched.push_back(c->id);
     }
-    for (Conn* c : touched) if (conns.count(c->id) && !c->dead) flush(c);
-    for (Conn* c : touched) if (conns.count(c->id) && c->dead) close_conn(c);
+    std::sort(touched.begin(), touched.end());
+    touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+    for (uint64_t id : touched) {
+      auto ci = conns.find(id);
+      if (ci == conns.end()) continue;
+      Conn* c = ci->second;
+      if (!c->dead) flush(c);
+      if (c->dead) close_conn(c);                            // erases it from `conns`; no other reference is kept
+    }
   }
   // shutdown: nothing more is written (grpc.cc:336-343); connections close, clients see UNAVAILABLE
   std::vector<Conn*> all;
