@@ -123,3 +123,79 @@ def test_two_rank_learner_matches_single_process(device, tmp_path, reduction, gr
   # (different summation order: shard sums vs one batch) but not a systematic difference
   frac = float(((got[0]['params'] - want).abs() > tol).float().mean())
   assert err <= 2.2 * 4.8e-4 and frac <= 1e-3, (err, frac)
+
+
+def _serving_worker(rank, world, port, graphed, out, sock_prefix):
+  """One data-parallel learner replica WITH its own LearnerServer: actors of this rank's env shard connect to this
+  rank's address (the reference assigns actors to inference devices, learner.py:406-414), the gradient exchange
+  happens inside Learner.minimize, nothing else crosses ranks."""
+  import concurrent.futures as futures
+  import threading
+  sys.path.insert(0, ROOT)
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from seed_rl_amd import grpc_service as gs, learner, learner_server, networks, optimizers, utils
+    from seed_rl_amd import parametric_distribution as pd
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    T, B, n, E = 3, 4, 4, 8
+    agent = networks.AtariShallow(A, device=dev, seed=5)              # identical initial weights on every rank
+    opt = optimizers.Adam(optimizers.PolynomialDecay(1e-3, 100), beta_1=0.0, epsilon=3.125e-7, capturable=graphed)
+    lrn = learner.Learner(agent, opt, pd.categorical_distribution(A), reduction='mean')
+    assert lrn.world == world
+    address = 'unix:%s%d' % (sock_prefix, rank)
+    srv = learner_server.LearnerServer(agent, lrn, T, B, n, E, (84, 84, 1), [address], device=dev, graphed=graphed)
+    srv.start()
+    stop = threading.Event()
+
+    def actor(env_id):
+      rng = np.random.default_rng(100 * rank + env_id)             # every rank's actors see different data
+      step = 0
+      try:
+        client = gs.Client(address, timeout=120)
+        while not stop.is_set():
+          env = utils.EnvOutput(np.float32(rng.normal()), np.bool_(False),
+                                rng.integers(0, 256, (84, 84, 1)).astype(np.uint8), np.bool_(False), np.int32(step))
+          client.inference(np.int32(env_id), np.int64(9), env, np.float32(0.0))
+          step += 1
+      except gs.OpError:
+        pass
+    losses = []
+    with futures.ThreadPoolExecutor(max_workers=E) as ex:
+      fs = [ex.submit(actor, e) for e in range(E)]
+      try:
+        for _ in range(STEPS):
+          o = srv.train_step(timeout=120)
+          assert o is not None
+          losses.append(float(o[0]))
+      finally:
+        stop.set()
+        srv.synchronize()
+        srv.shutdown()
+      for f in fs:
+        f.result(timeout=60)
+    torch.save(dict(params=agent.flat.params.cpu(), losses=losses), out + str(rank))
+  finally:
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('graphed', [False, True])
+def test_two_rank_learner_servers(device, tmp_path, graphed):
+  """Serving under data parallelism: two replicas, each behind its own native gRPC front-end with its own actors,
+  different trajectories per rank, ONE gradient all-reduce per step -- after every step both hold the same weights
+  (so no weight broadcast to the inference side is ever needed), and they moved away from the initial ones."""
+  import tempfile
+  import uuid
+  world, port = 2, _free_port()
+  out = str(tmp_path / 'srv')
+  prefix = os.path.join(tempfile.gettempdir(), 'seedrl_dp_' + uuid.uuid4().hex[:8] + '_')
+  mp.spawn(_serving_worker, args=(world, port, graphed, out, prefix), nprocs=world, join=True)
+  got = [torch.load(out + str(r)) for r in range(world)]
+  assert torch.equal(got[0]['params'], got[1]['params'])
+  from seed_rl_amd import networks
+  init = networks.AtariShallow(A, device=device, seed=5).flat.params.cpu()
+  assert not torch.equal(got[0]['params'], init)
+  assert all(np.isfinite(l) for g in got for l in g['losses'])
+  assert got[0]['losses'] != got[1]['losses']                         # different data on the two ranks
