@@ -387,6 +387,16 @@ int seedhip_replay_sample(const float* priorities, long long limit, float priori
                           float importance_sampling_exponent, const float* uniforms, int num_samples,
                           long long* indices, float* weights, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- policy + baseline heads forward as one skinny GEMM ---------------------------------------------------
+ * The two Dense heads of dmlab/networks.py:116-124 (policy_logits [feat, A], baseline [feat, 1]) packed as ONE matrix
+ * w [feat, ldh] = [logits | baseline | zero pad], ldh = round4(A + 1):
+ *   y [rows, ldh] = x [rows, feat] (row stride ldx) w + bias.
+ * Supported (seedhip_heads_supported): feat % 64 == 0, feat <= 512, ldh % 4 == 0, ldh <= 32; anything else (and the
+ * backward of the heads) goes through seedhip_conv2d_* with a dense geometry. */
+int seedhip_heads_supported(int feat, int ldh);
+int seedhip_heads_fwd(const float* x, int ldx, const float* w, const float* bias, long long rows, int feat, int ldh,
+                      float* y, void* stream);
+
 /* ---- R2D2 actor-side exploration and replay <-> time-major batch -----------------------------------
  * seedhip_epsilon_greedy replaces apply_epsilon_greedy of agents/r2d2/learner.py:147-177: actions[i] (int64, in
  * place) becomes a uniform random action in [0, num_actions) with probability epsilons[env_ids[i]] (the caller's

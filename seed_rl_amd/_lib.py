@@ -109,6 +109,8 @@ SIGNATURES = {
     'seedhip_rows_move_ops': (c_int, [c_int, P, P]),
     'seedhip_replay_sample_workspace_bytes': (c_size_t, [c_ll]),
     'seedhip_replay_sample': (c_int, [P, c_ll, c_float, c_float, P, c_int, P, P, P, c_size_t, P]),
+    'seedhip_heads_supported': (c_int, [c_int, c_int]),
+    'seedhip_heads_fwd': (c_int, [P, c_int, P, P, c_ll, c_int, c_int, P, P]),
     'seedhip_epsilon_greedy': (c_int, [P, P, P, c_int, c_int, c_int, P, P, P]),
     'seedhip_replay_time_rows': (c_int, [P, c_int, c_int, P, P, P]),
     'seedhip_dueling_fwd': (c_int, [P, c_int, c_ll, c_int, P, P, P]),

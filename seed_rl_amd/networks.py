@@ -231,9 +231,24 @@ class _Agent(object):
   def _head_fwd(self, feat, rows, feat_dim, ld_feat=None):
     ldh = self._ldh
     head = self._buf('head', (rows, ldh))
+    if self._skinny_heads(feat_dim):              # N <= 32: one skinny GEMM (csrc/heads.hip) instead of the general core
+      ops.heads_fwd(feat, ld_feat or feat_dim, self.flat.p('heads/kernel'), self.flat.p('heads/bias'), rows, feat_dim,
+                    ldh, head)
+      return head
     g = ops.dense_geom(rows, feat_dim, ldh, ld_in=ld_feat or feat_dim)
     ops.conv2d_fwd(g, feat, self.flat.p('heads/kernel'), self.flat.p('heads/bias'), head)
     return head
+
+  def _skinny_heads(self, feat_dim):
+    return os.environ.get('SEEDHIP_HEADS', '1') != '0' and ops.heads_supported(feat_dim, self._ldh)
+
+  def _head_bwd(self, feat, feat_dim, d_head, rows, dx, relu_mask, wsb):
+    """Gradients of the packed heads: heads/kernel, heads/bias into the flat gradient buffer and dx [rows, feat_dim] =
+    d_head W^T (zeroed where feat <= 0 when relu_mask: feat is then the ReLU output the heads read)."""
+    fl = self.flat
+    gh = ops.dense_geom(rows, feat_dim, self._ldh)
+    ops.conv2d_bwd_weight(gh, feat, d_head, fl.g('heads/kernel'), fl.g('heads/bias'), wsb)
+    ops.conv2d_bwd_data(gh, d_head, fl.p('heads/kernel'), dx, relu_mask=feat if relu_mask else None)
 
   def rng_state(self):
     """Device uint64[2] = (seed, call counter) of the action sampler; the kernels advance the counter themselves, so
@@ -551,9 +566,8 @@ class AtariShallow(_Agent, _AtariTorso):
     gh = ops.dense_geom(N, self._fc, self._ldh)
     need = max(ops.conv2d_bwd_weight_workspace_bytes(gh), self._torso_ws_bytes(L['ctx']))
     wsb = self._buf('wgrad_ws', (need // 4 + 4,))
-    ops.conv2d_bwd_weight(gh, L['hfc'], d_head, fl.g('heads/kernel'), fl.g('heads/bias'), wsb)
     dz = self._buf('d_fc', (N, self._fc))
-    ops.conv2d_bwd_data(gh, d_head, fl.p('heads/kernel'), dz, relu_mask=L['hfc'])
+    self._head_bwd(L['hfc'], self._fc, d_head, N, dz, True, wsb)
     self._torso_bwd(L['ctx'], dz, wsb)
 
 
@@ -788,9 +802,8 @@ class ImpalaDeep(_Agent):
     H = self._H
     if H:
       gh = ops.dense_geom(N, H, self._ldh)
-      ops.conv2d_bwd_weight(gh, L['Hout'], d_head, fl.g('heads/kernel'), fl.g('heads/bias'), wsb)
       dHout = self._buf('d_hout', (N, H))
-      ops.conv2d_bwd_data(gh, d_head, fl.p('heads/kernel'), dHout)
+      self._head_bwd(L['Hout'], H, d_head, N, dHout, False, wsb)
       dX = self._lstm_bwd(dHout, wsb)
     else:
       gh = ops.dense_geom(N, self._fc, self._ldh)
@@ -935,9 +948,8 @@ class MLPandLSTM(_Agent):
     for g in L['geoms']:
       need = max(need, ops.conv2d_bwd_weight_workspace_bytes(g))
     wsb = self._buf('wgrad_ws', (need // 4 + 4,))
-    ops.conv2d_bwd_weight(gh, L['top'], d_head, fl.g('heads/kernel'), fl.g('heads/bias'), wsb)
     dh = self._buf('d_top', (N, htop))
-    ops.conv2d_bwd_data(gh, d_head, fl.p('heads/kernel'), dh)
+    self._head_bwd(L['top'], htop, d_head, N, dh, False, wsb)
     for l in range(len(self._lstm) - 1, -1, -1):
       # the layer's input is the layer below (no activation) or, for layer 0, the last Dense + relu output
       dh = self._lstm_bwd(dh, wsb, prefix='core/cell_%d' % l, relu_mask_x=(l == 0 and bool(self._mlp)))

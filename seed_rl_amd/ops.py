@@ -576,3 +576,15 @@ def replay_time_rows(slots, steps, replay_rows, batch_rows):
   with _dev(slots):
     _lib.check(_lib.lib().seedhip_replay_time_rows(_lib.ptr(slots), slots.numel(), int(steps), _lib.ptr(replay_rows),
                                                    _lib.ptr(batch_rows), _lib.stream()), 'seedhip_replay_time_rows')
+
+
+def heads_supported(feat, ldh):
+  return bool(_lib.lib().seedhip_heads_supported(int(feat), int(ldh)))
+
+
+def heads_fwd(x, ldx, w, bias, rows, feat, ldh, y):
+  """y [rows, ldh] = x [rows, feat] w [feat, ldh] + bias (the packed policy / baseline heads, dmlab/networks.py:116-124)."""
+  with _region('heads_fwd', 2.0 * rows * feat * ldh, rows * (feat + ldh) * 4):
+    with _dev(y):
+      _lib.check(_lib.lib().seedhip_heads_fwd(_lib.ptr(x), int(ldx), _lib.ptr(w), _lib.ptr(bias), int(rows), int(feat),
+                                              int(ldh), _lib.ptr(y), _lib.stream()), 'seedhip_heads_fwd')

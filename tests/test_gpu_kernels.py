@@ -701,3 +701,23 @@ def test_lstm_seq_bwd_matches_steps(device, T1, B, H):
     assert torch.equal(outs[0], o)
   scale = float(dZ_ref.abs().max())
   assert float((outs[0] - dZ_ref).abs().max()) <= 2e-5 * max(1.0, scale)
+
+
+@pytest.mark.parametrize('rows,feat,A', [(1000, 256, 18), (37, 512, 6), (16, 64, 31), (5, 256, 9), (10752, 256, 18),
+                                         (1, 128, 3)])
+def test_heads_fwd(device, rows, feat, A):
+  """csrc/heads.hip: the packed policy / baseline heads (dmlab/networks.py:116-124) as one skinny GEMM, against float64
+  NumPy: y = x W + b.  Tolerance: fp32 accumulation over `feat` (1e-5 of the output scale)."""
+  from seed_rl_amd import ops
+  ldh = (A + 1 + 3) // 4 * 4
+  assert ops.heads_supported(feat, ldh)
+  rng = np.random.default_rng(rows + feat)
+  x = np.maximum(rng.normal(size=(rows, feat)), 0).astype(np.float32)           # a ReLU output (about half zeros)
+  w = np.zeros((feat, ldh), np.float32); w[:, :A + 1] = rng.normal(size=(feat, A + 1)) / np.sqrt(feat)
+  b = np.zeros(ldh, np.float32); b[:A + 1] = rng.normal(size=A + 1)
+  t = lambda a: torch.as_tensor(a).to(device)
+  y = torch.empty((rows, ldh), device=device)
+  ops.heads_fwd(t(x), feat, t(w), t(b), rows, feat, ldh, y)
+  want = x.astype(np.float64) @ w.astype(np.float64) + b
+  np.testing.assert_allclose(y.cpu().numpy(), want, rtol=0, atol=1e-5 * max(1.0, np.abs(want).max()))
+  assert not ops.heads_supported(100, 20) and not ops.heads_supported(256, 36) and not ops.heads_supported(1024, 20)
