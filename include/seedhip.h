@@ -355,13 +355,22 @@ int seedhip_inference_pre(const long long* env_ids, const long long* run_ids, co
  * the categorical sample of dmlab/networks.py:122 without an eager op) and written to actions[n]; otherwise actions[n]
  * is an input.  carry u8[n] marks every completed unroll (its last step is carried to slot 0, utils.py:237-252), complete
  * u8[n] those that also got a training-batch column (flag 8 when the batch is full: the unroll is dropped, the env's
- * store stays consistent). */
+ * store stays consistent); emit_env / emit_col [n] + *emit_count: the same completions as a compact list in batch-column
+ * order, for seedhip_emit_unrolls. */
 int seedhip_inference_post(const long long* env_ids, const uint8_t* valid, long long* actions,
                            const float* policy_logits, int logits_ld, int num_actions, unsigned long long* rng_state,
                            int n, int num_envs, int full_length, int batch_capacity, long long* store_index,
                            long long* actions_table, int* batch_count, long long* append_rows, uint8_t* complete,
-                           uint8_t* carry, long long* batch_cols, long long* gather_src, long long* gather_dst,
-                           uint8_t* gather_mask, long long* last_rows, int* error_flag, void* stream);
+                           uint8_t* carry, long long* batch_cols, long long* emit_env, long long* emit_col,
+                           int* emit_count, long long* last_rows, int* error_flag, void* stream);
+/* Completed unrolls -> training batch (unroll_queue.enqueue_many + dequeue + make_time_major of learner.py:396-397,
+ * 418-432) from the COMPACT list inference_post leaves on the device (ABI 3): emit_env[r] / emit_col[r], r < *emit_count,
+ * are the env and the batch column of the r-th completed unroll; for every field f and step t < full_length, store row
+ * t * num_envs + env_r (row_bytes[f] bytes) moves to batch row t * batch_capacity + col_r.  Up to 16 fields (host arrays
+ * of device pointers); max_unrolls (= the inference batch size) only bounds the grid -- the kernel reads the count. */
+int seedhip_emit_unrolls(int nfields, void* const* dst, const void* const* src, const long long* row_bytes,
+                         const long long* emit_env, const long long* emit_col, const int* emit_count, int max_unrolls,
+                         int full_length, int num_envs, int batch_capacity, void* stream);
 /* The agents' action sampling (tfd.Categorical(logits).sample(), common/parametric_distribution.py:94-95 as used by
  * dmlab/networks.py:122): actions[r] ~ Categorical(logits[r*ld .. r*ld + num_actions)), int64.  Same generator and
  * per-row function as inference_post: equal (seed, counter) give equal actions. */

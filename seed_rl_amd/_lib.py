@@ -105,6 +105,7 @@ SIGNATURES = {
                                       P, P, P, P, P, c_int, P]),
     'seedhip_inference_post': (c_int, [P, P, P, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P,
                                        P, P, P, P, P]),
+    'seedhip_emit_unrolls': (c_int, [c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'seedhip_categorical_sample': (c_int, [P, c_int, c_ll, c_int, P, P, P]),
     'seedhip_rows_move_ops': (c_int, [c_int, P, P]),
     'seedhip_replay_sample_workspace_bytes': (c_size_t, [c_ll]),

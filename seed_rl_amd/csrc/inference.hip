@@ -101,9 +101,9 @@ struct PostArgs {
   uint8_t* complete;           // [n]          1 where the step completed an unroll that got a batch column
   uint8_t* carry;              // [n]          1 where the step completed an unroll (carried over to slot 0 regardless)
   long long* batch_cols;       // [n]          destination column in the training batch (valid where complete)
-  long long* gather_src;       // [L*n]        t*E + e
-  long long* gather_dst;       // [L*n]        t*capacity + column
-  uint8_t* gather_mask;        // [L*n]
+  long long* emit_env;         // [n]          compact list: env of the r-th completed unroll that got a column ...
+  long long* emit_col;         // [n]          ... and that column; r < *emit_count
+  int* emit_count;             // [1]          number of entries of the compact list
   long long* last_rows;        // [n]          (L-1)*E + e: the step carried over to slot 0 (utils.py:237-252)
   int* error_flag;
 };
@@ -168,27 +168,47 @@ inference_post_kernel(PostArgs a) {
     a.complete[i] = ok ? 1 : 0;
     a.carry[i] = done ? 1 : 0;
     a.batch_cols[i] = ok ? col : 0;
+    if (ok) {                                                          // rank among the accepted completions
+      const int r = col - s_base;
+      a.emit_env[r] = e;
+      a.emit_col[r] = col;
+    }
+  }
+  if (i == 0) {
+    const int total = s_scan[1023];
+    const int room = a.batch_capacity - s_base;
+    *a.emit_count = total < room ? total : (room > 0 ? room : 0);
   }
 }
 
-// Row lists of the completed-unroll emission, one workgroup per time step (the single bookkeeping workgroup used to
-// write all full_length * n entries itself: 17 us of a 1024-row step): row (t, i) moves store row t * E + e_i to batch
-// row t * capacity + col_i when env i completed an unroll that got a column.
+// Completed unrolls -> training batch (what unroll_queue.enqueue_many + dequeue + make_time_major do in the reference,
+// learner.py:396-397, 418-432), driven by the COMPACT list inference_post leaves on the device: work item (r, t) moves
+// store row t * E + env_r of every field to batch row t * capacity + col_r.  Only the ~n / T unrolls that really
+// completed are touched: the masked generic mover dispatched full_length * n row groups per field (24 k workgroups at
+// n = 1024, 95 % of them exiting on the mask: 20 us), and the row lists it needed took another kernel to fill.
+constexpr int kEmitFields = 16;
+struct EmitArgs {
+  void* dst[kEmitFields]; const void* src[kEmitFields]; long long row_bytes[kEmitFields]; int w[kEmitFields];
+  int nfields; const long long* env; const long long* col; const int* count; int L, E, cap;
+};
 __global__ void __launch_bounds__(256)
-emit_rows_fill_kernel(const long long* __restrict__ env_ids, const uint8_t* __restrict__ valid,
-                      const uint8_t* __restrict__ complete, const long long* __restrict__ batch_cols, int n, int E,
-                      int capacity, long long* __restrict__ gather_src, long long* __restrict__ gather_dst,
-                      uint8_t* __restrict__ gather_mask) {
-  const int t = blockIdx.x;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    long long e = env_ids[i];
-    const bool ok_row = valid ? valid[i] != 0 : (e >= 0 && e < E);
-    if (!ok_row) e = 0;
-    const bool ok = complete[i] != 0;
-    const long long k = (long long)t * n + i;
-    gather_src[k] = (long long)t * E + e;
-    gather_dst[k] = ok ? (long long)t * capacity + batch_cols[i] : 0;
-    gather_mask[k] = ok ? 1 : 0;
+emit_unrolls_kernel(EmitArgs a) {
+  const int items = *a.count * a.L;
+  for (int it = blockIdx.x; it < items; it += gridDim.x) {
+    const int r = it / a.L, t = it - r * a.L;
+    const long long srow = (long long)t * a.E + a.env[r], drow = (long long)t * a.cap + a.col[r];
+    for (int f = 0; f < a.nfields; ++f) {
+      const long long rb = a.row_bytes[f];
+      const char* sp = (const char*)a.src[f] + srow * rb;
+      char* dp = (char*)a.dst[f] + drow * rb;
+      if (a.w[f] == 16) {
+        for (long long e = threadIdx.x; e < rb / 16; e += 256) reinterpret_cast<uint4*>(dp)[e] = reinterpret_cast<const uint4*>(sp)[e];
+      } else if (a.w[f] == 4) {
+        for (long long e = threadIdx.x; e < rb / 4; e += 256) reinterpret_cast<uint32_t*>(dp)[e] = reinterpret_cast<const uint32_t*>(sp)[e];
+      } else {
+        for (long long e = threadIdx.x; e < rb; e += 256) dp[e] = sp[e];
+      }
+    }
   }
 }
 
@@ -365,24 +385,42 @@ extern "C" int seedhip_inference_post(const long long* env_ids, const uint8_t* v
                                       unsigned long long* rng_state, int n, int num_envs,
                                       int full_length, int batch_capacity, long long* store_index,
                                       long long* actions_table, int* batch_count, long long* append_rows,
-                                      uint8_t* complete, uint8_t* carry, long long* batch_cols, long long* gather_src,
-                                      long long* gather_dst, uint8_t* gather_mask, long long* last_rows,
+                                      uint8_t* complete, uint8_t* carry, long long* batch_cols, long long* emit_env,
+                                      long long* emit_col, int* emit_count, long long* last_rows,
                                       int* error_flag, void* stream) {
   SEEDHIP_REQUIRE(n >= 1 && n <= 1024 && num_envs >= 1 && full_length >= 2 && batch_capacity >= 1,
                   "inference_post: bad sizes");
   SEEDHIP_REQUIRE(env_ids && actions && store_index && actions_table && batch_count && append_rows && complete &&
-                  carry && batch_cols && gather_src && gather_dst && gather_mask && last_rows && error_flag,
+                  carry && batch_cols && emit_env && emit_col && emit_count && last_rows && error_flag,
                   "inference_post: null pointer");
   SEEDHIP_REQUIRE(!policy_logits || (rng_state && num_actions >= 1 && logits_ld >= num_actions),
                   "inference_post: sampling needs rng_state and 1 <= num_actions <= logits_ld");
   PostArgs a{env_ids, valid, actions, policy_logits, logits_ld, num_actions, rng_state, n, num_envs, full_length,
              batch_capacity, store_index, actions_table, batch_count, append_rows, complete, carry, batch_cols,
-             gather_src, gather_dst, gather_mask, last_rows, error_flag};
+             emit_env, emit_col, emit_count, last_rows, error_flag};
   hipLaunchKernelGGL(inference_post_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(emit_rows_fill_kernel, dim3(full_length), dim3(256), 0, (hipStream_t)stream, env_ids, valid,
-                     (const uint8_t*)complete, (const long long*)batch_cols, n, num_envs, batch_capacity, gather_src,
-                     gather_dst, gather_mask);
   return seedhip::check_launch("inference_post_kernel");
+}
+
+extern "C" int seedhip_emit_unrolls(int nfields, void* const* dst, const void* const* src, const long long* row_bytes,
+                                    const long long* emit_env, const long long* emit_col, const int* emit_count,
+                                    int max_unrolls, int full_length, int num_envs, int batch_capacity, void* stream) {
+  SEEDHIP_REQUIRE(nfields >= 1 && nfields <= kEmitFields, "emit_unrolls: need 1 <= nfields <= %d", kEmitFields);
+  SEEDHIP_REQUIRE(dst && src && row_bytes && emit_env && emit_col && emit_count, "emit_unrolls: null pointer");
+  SEEDHIP_REQUIRE(max_unrolls >= 1 && full_length >= 1 && num_envs >= 1 && batch_capacity >= 1, "emit_unrolls: bad sizes");
+  EmitArgs a;
+  for (int f = 0; f < nfields; ++f) {
+    SEEDHIP_REQUIRE(dst[f] && src[f] && row_bytes[f] >= 1, "emit_unrolls: bad field %d", f);
+    a.dst[f] = dst[f]; a.src[f] = src[f]; a.row_bytes[f] = row_bytes[f];
+    const uintptr_t al = (uintptr_t)dst[f] | (uintptr_t)src[f] | (uintptr_t)row_bytes[f];
+    a.w[f] = (al & 15) == 0 ? 16 : ((al & 3) == 0 ? 4 : 1);
+  }
+  a.nfields = nfields; a.env = emit_env; a.col = emit_col; a.count = emit_count;
+  a.L = full_length; a.E = num_envs; a.cap = batch_capacity;
+  long long grid = (long long)max_unrolls * full_length;      // upper bound of the work items; the kernel reads the count
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(emit_unrolls_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a);
+  return seedhip::check_launch("emit_unrolls_kernel");
 }
 
 extern "C" int seedhip_categorical_sample(const float* logits, int ld, long long rows, int num_actions,

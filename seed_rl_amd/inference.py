@@ -176,7 +176,8 @@ class FusedInferenceState(object):
       i64 = lambda k: torch.zeros(k, dtype=torch.int64, device=dev)
       u8 = lambda k: torch.zeros(k, dtype=torch.uint8, device=dev)
       b = dict(reset=u8(n), prev_actions=i64(n), append_rows=i64(n), complete=u8(n), carry=u8(n), cols=i64(n),
-               gsrc=i64(L * n), gdst=i64(L * n), gmask=u8(L * n), last=i64(n), ids_safe=i64(n), valid=u8(n),
+               emit_env=i64(n), emit_col=i64(n), emit_count=torch.zeros(1, dtype=torch.int32, device=dev),
+               last=i64(n), ids_safe=i64(n), valid=u8(n),
                will_complete=u8(n),
                actions=i64(n), zeros_bool=torch.zeros(n, dtype=torch.bool, device=dev),
                zeros_i32=torch.zeros(n, dtype=torch.int32, device=dev))
@@ -194,8 +195,8 @@ class FusedInferenceState(object):
     on the device (check_errors) -- the reference raises.
 
     Launches: inference_pre, ONE row-mover launch (previous states), the agent's single-step forward (5-6 kernels),
-    inference_post (samples the actions from the head rows), THREE row-mover launches (append + state tables; completed
-    unrolls -> training batch; carry-over) -- no eager tensor op in between."""
+    inference_post (samples the actions from the head rows), two row-mover launches (append + state tables; carry-over)
+    and the emission of the completed unrolls from inference_post's compact list -- no eager tensor op in between."""
     dev = self.device
     ids = torch.as_tensor(env_ids, device=dev).to(torch.int64).contiguous()
     runs = torch.as_tensor(run_ids, device=dev).to(torch.int64).contiguous()
@@ -243,7 +244,7 @@ class FusedInferenceState(object):
       b['actions'].copy_(agent_outputs.action)
     ops.inference_post(sid, b['valid'], b['actions'], logits_src, ldh, A, rng, n, self.E, self.L, self.cap,
                        self.store_index, self.actions_tab, self.batch_count, b['append_rows'], b['complete'], b['carry'],
-                       b['cols'], b['gsrc'], b['gdst'], b['gmask'], b['last'], self.error_flag)
+                       b['cols'], b['emit_env'], b['emit_col'], b['emit_count'], b['last'], self.error_flag)
     store_env = env_outputs._replace(
         abandoned=env_outputs.abandoned if env_outputs.abandoned is not None else b['zeros_bool'],
         episode_step=env_outputs.episode_step if env_outputs.episode_step is not None else b['zeros_i32'])
@@ -275,8 +276,8 @@ class FusedInferenceState(object):
          for o, f, rb in zip(utils.flatten(self.batch.agent_state), firsts, srb)] +
         [op(t, c, rb, n, dst_rows=sid, mask=b['valid'])
          for k, (t, c, rb) in enumerate(zip(tabs, currs, srb)) if k != fi])                         # :401 (fi: done in place)
-    ops.rows_move_ops([op(o, s_, rb, self.L * n, dst_rows=b['gdst'], src_rows=b['gsrc'], mask=b['gmask'])
-                       for o, s_, rb in zip(outs, stores, rbs)])                                   # completed unrolls -> batch
+    ops.emit_unrolls(outs, stores, rbs, b['emit_env'], b['emit_col'], b['emit_count'], n, self.L, self.E,
+                     self.cap)                                                                     # completed unrolls -> batch
     ops.rows_move_ops(
         [op(s_, s_, rb, n, dst_rows=sid, src_rows=b['last'], mask=b['carry']) for s_, rb in zip(stores, rbs)] +   # carry
         [op(f, p, rb, n, dst_rows=sid, mask=b['carry']) for f, p, rb in zip(firsts, prevs, srb)])   # :398-399

@@ -489,7 +489,7 @@ def inference_pre(env_ids, run_ids, reward, raw_reward, done_u8, n, num_envs, nu
 
 def inference_post(env_ids, valid, actions, logits, logits_ld, num_actions, rng_state, n, num_envs, full_length,
                    batch_capacity, store_index, actions_tab, batch_count, append_rows, complete, carry, batch_cols,
-                   gather_src, gather_dst, gather_mask, last_rows, error_flag):
+                   emit_env, emit_col, emit_count, last_rows, error_flag):
   """logits given (a view whose first element is row 0's first logit): the actions are sampled in the kernel and
   written to `actions`; logits None: `actions` is an input."""
   with _dev(complete):
@@ -497,8 +497,24 @@ def inference_post(env_ids, valid, actions, logits, logits_ld, num_actions, rng_
         _lib.ptr(env_ids), _lib.ptr(valid), _lib.ptr(actions), _lib.ptr(logits), logits_ld, num_actions,
         _lib.ptr(rng_state), n, num_envs, full_length, batch_capacity, _lib.ptr(store_index),
         _lib.ptr(actions_tab), _lib.ptr(batch_count), _lib.ptr(append_rows), _lib.ptr(complete), _lib.ptr(carry),
-        _lib.ptr(batch_cols), _lib.ptr(gather_src), _lib.ptr(gather_dst), _lib.ptr(gather_mask), _lib.ptr(last_rows),
+        _lib.ptr(batch_cols), _lib.ptr(emit_env), _lib.ptr(emit_col), _lib.ptr(emit_count), _lib.ptr(last_rows),
         _lib.ptr(error_flag), _lib.stream()), 'seedhip_inference_post')
+
+
+def emit_unrolls(dsts, srcs, row_bytes, emit_env, emit_col, emit_count, max_unrolls, full_length, num_envs,
+                 batch_capacity):
+  """Completed unrolls (compact list of inference_post) -> training batch, every field in one launch (groups of 16)."""
+  for lo in range(0, len(dsts), 16):
+    d, s_, rb = dsts[lo:lo + 16], srcs[lo:lo + 16], row_bytes[lo:lo + 16]
+    k = len(d)
+    PA = ctypes.c_void_p * k
+    da, sa = PA(*[t.data_ptr() for t in d]), PA(*[t.data_ptr() for t in s_])
+    ra = (ctypes.c_longlong * k)(*rb)
+    with _dev(d[0]):
+      _lib.check(_lib.lib().seedhip_emit_unrolls(
+          k, ctypes.cast(da, ctypes.c_void_p), ctypes.cast(sa, ctypes.c_void_p), ctypes.cast(ra, ctypes.c_void_p),
+          _lib.ptr(emit_env), _lib.ptr(emit_col), _lib.ptr(emit_count), int(max_unrolls), int(full_length),
+          int(num_envs), int(batch_capacity), _lib.stream()), 'seedhip_emit_unrolls')
 
 
 def categorical_sample(logits, ld, rows, num_actions, rng_state, actions):
