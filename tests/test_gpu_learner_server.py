@@ -132,3 +132,54 @@ def test_learner_loop_entry_point(device):
   assert created['final_iteration'] == int(np.ceil(10 ** 6 / (4 * T)))                  # learner.py:236-239
   assert res.iterations == 3 and res.num_env_frames == 3 * 4 * T and [it for it, _ in seen] == [1, 2, 3]
   assert all(np.isfinite(l) for _, l in seen) and 'losses/total' in res.last_session
+
+
+def test_deep_lstm_agent_behind_the_native_server(device):
+  """ImpalaDeep + LSTM (dmlab/networks.py:63-171) served and trained through LearnerServer: RGB observations through the
+  native front-end, recurrent agent state in the per-env tables, the inference twin sharing the parameters, two train
+  steps from HIP-graph replays while the actors keep stepping."""
+  from seed_rl_amd import grpc_service as gs, learner, learner_server, networks, optimizers, utils
+  from seed_rl_amd import parametric_distribution as pd
+  T, B, A, n, E = 3, 4, 5, 4, 8
+  obs_shape = (24, 32, 3)
+  agent = networks.ImpalaDeep(A, observation_shape=obs_shape, device=device, seed=0)
+  opt = optimizers.Adam(optimizers.PolynomialDecay(1e-3, 1000), beta_1=0.0, epsilon=3.125e-7, capturable=True)
+  lrn = learner.Learner(agent, opt, pd.categorical_distribution(A))
+  path = os.path.join(tempfile.gettempdir(), 'seedrl_' + uuid.uuid4().hex[:12])
+  srv = learner_server.LearnerServer(agent, lrn, T, B, n, E, obs_shape, ['unix:' + path], device=device, graphed=True)
+  srv.start()
+  stop = threading.Event()
+
+  def actor(env_id):
+    rng = np.random.default_rng(env_id)
+    step = 0
+    try:
+      client = gs.Client('unix:' + path, timeout=120)
+      while not stop.is_set():
+        env = utils.EnvOutput(np.float32(rng.normal()), np.bool_(step > 0 and rng.uniform() < 0.2),
+                              rng.integers(0, 256, obs_shape).astype(np.uint8), np.bool_(False), np.int32(step))
+        a = client.inference(np.int32(env_id), np.int64(3), env, np.float32(0.0))
+        assert 0 <= int(a) < A
+        step += 1
+    except gs.OpError:
+      pass
+  p0 = agent.flat.params.clone()
+  losses = []
+  with futures.ThreadPoolExecutor(max_workers=E) as ex:
+    fs = [ex.submit(actor, e) for e in range(E)]
+    try:
+      for _ in range(2):
+        out = srv.train_step(timeout=120)
+        assert out is not None
+        losses.append(float(out[0]))
+    finally:
+      stop.set()
+      srv.synchronize()
+      srv.shutdown()
+    for f in fs:
+      f.result(timeout=60)
+  srv.state.check_errors()
+  agent.check_errors()
+  assert all(np.isfinite(l) for l in losses) and not torch.equal(p0, agent.flat.params)
+  u = srv.unroll
+  assert tuple(u.env_outputs.observation.shape) == (T + 1, B) + obs_shape and len(u.agent_state) == 2

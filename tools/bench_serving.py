@@ -84,7 +84,10 @@ def run_inprocess(dev, seconds=5.0, T=20, B=512, n=1024, envs=4096, warm_steps=3
     i = 0
     while not stop.is_set():
       t = time.perf_counter()
-      f = bound.compute(i % groups)
+      try:
+        f = bound.compute(i % groups)
+      except Exception:                                         # the gate was closed under us: the run is over
+        break
       t1 = time.perf_counter()
       inflight.put(f)                                           # blocks while groups - 1 batches are in flight
       t2 = time.perf_counter()
