@@ -24,7 +24,6 @@ OBS = (84, 84, 1)
 
 
 def actor_proc(address, first_env, k, seconds, out, start):
-  import collections
   import grpc
   from seed_rl_amd import grpc_service as gs
   rng = np.random.default_rng(first_env)
