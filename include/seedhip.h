@@ -356,13 +356,16 @@ int seedhip_inference_pre(const long long* env_ids, const long long* run_ids, co
  * is an input.  carry u8[n] marks every completed unroll (its last step is carried to slot 0, utils.py:237-252), complete
  * u8[n] those that also got a training-batch column (flag 8 when the batch is full: the unroll is dropped, the env's
  * store stays consistent); emit_env / emit_col [n] + *emit_count: the same completions as a compact list in batch-column
- * order, for seedhip_emit_unrolls. */
+ * order, for seedhip_emit_unrolls.  The training batch is a RING of batch_capacity columns: *batch_start (device
+ * scalar, NULL = 0) is its head, *batch_count its fill; the r-th accepted completion gets column (start + fill + r) %
+ * capacity, so the consumer takes columns from the head and advances it -- nothing is ever compacted. */
 int seedhip_inference_post(const long long* env_ids, const uint8_t* valid, long long* actions,
                            const float* policy_logits, int logits_ld, int num_actions, unsigned long long* rng_state,
                            int n, int num_envs, int full_length, int batch_capacity, long long* store_index,
                            long long* actions_table, int* batch_count, long long* append_rows, uint8_t* complete,
                            uint8_t* carry, long long* batch_cols, long long* emit_env, long long* emit_col,
-                           int* emit_count, long long* last_rows, int* error_flag, void* stream);
+                           int* emit_count, long long* last_rows, int* error_flag,
+                           const int* batch_start /* may be NULL = 0 */, void* stream);
 /* Completed unrolls -> training batch (unroll_queue.enqueue_many + dequeue + make_time_major of learner.py:396-397,
  * 418-432) from the COMPACT list inference_post leaves on the device (ABI 3): emit_env[r] / emit_col[r], r < *emit_count,
  * are the env and the batch column of the r-th completed unroll; for every field f and step t < full_length, store row

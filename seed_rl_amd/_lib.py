@@ -104,7 +104,7 @@ SIGNATURES = {
     'seedhip_inference_pre': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P,
                                       P, P, P, P, P, c_int, P]),
     'seedhip_inference_post': (c_int, [P, P, P, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P,
-                                       P, P, P, P, P]),
+                                       P, P, P, P, P, P]),
     'seedhip_emit_unrolls': (c_int, [c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'seedhip_categorical_sample': (c_int, [P, c_int, c_ll, c_int, P, P, P]),
     'seedhip_rows_move_ops': (c_int, [c_int, P, P]),

@@ -104,6 +104,7 @@ struct PostArgs {
   long long* emit_env;         // [n]          compact list: env of the r-th completed unroll that got a column ...
   long long* emit_col;         // [n]          ... and that column; r < *emit_count
   int* emit_count;             // [1]          number of entries of the compact list
+  const int* batch_start;      // [1] or NULL  ring head of the training batch: column = (start + fill + rank) % capacity
   long long* last_rows;        // [n]          (L-1)*E + e: the step carried over to slot 0 (utils.py:237-252)
   int* error_flag;
 };
@@ -111,7 +112,7 @@ struct PostArgs {
 __global__ void __launch_bounds__(1024)
 inference_post_kernel(PostArgs a) {
   __shared__ int s_scan[1024];
-  __shared__ int s_base;
+  __shared__ int s_base, s_start;
   const int i = threadIdx.x;
   const int L = a.full_length, E = a.num_envs;
   long long e = 0;
@@ -156,20 +157,23 @@ inference_post_kernel(PostArgs a) {
     const int total = s_scan[1023];
     const int base = *a.batch_count;
     s_base = base;
+    s_start = a.batch_start ? *a.batch_start : 0;
     *a.batch_count = base + total > a.batch_capacity ? a.batch_capacity : base + total;
     if (base + total > a.batch_capacity) atomicOr(a.error_flag, 8);
   }
   __syncthreads();
   if (i < a.n) {
-    const int col = s_base + s_scan[i] - done;
+    const int pos = s_base + s_scan[i] - done;                         // position in the batch, counted from its head
     // a completed unroll that finds the training batch full is dropped (flag 8) but its last step is STILL carried
     // to slot 0, so the env's next unroll starts from a consistent state
-    const bool ok = done && col < a.batch_capacity;
+    const bool ok = done && pos < a.batch_capacity;
+    int col = s_start + pos;                                           // the batch is a ring of columns
+    if (col >= a.batch_capacity) col -= a.batch_capacity;
     a.complete[i] = ok ? 1 : 0;
     a.carry[i] = done ? 1 : 0;
     a.batch_cols[i] = ok ? col : 0;
     if (ok) {                                                          // rank among the accepted completions
-      const int r = col - s_base;
+      const int r = pos - s_base;
       a.emit_env[r] = e;
       a.emit_col[r] = col;
     }
@@ -387,7 +391,7 @@ extern "C" int seedhip_inference_post(const long long* env_ids, const uint8_t* v
                                       long long* actions_table, int* batch_count, long long* append_rows,
                                       uint8_t* complete, uint8_t* carry, long long* batch_cols, long long* emit_env,
                                       long long* emit_col, int* emit_count, long long* last_rows,
-                                      int* error_flag, void* stream) {
+                                      int* error_flag, const int* batch_start, void* stream) {
   SEEDHIP_REQUIRE(n >= 1 && n <= 1024 && num_envs >= 1 && full_length >= 2 && batch_capacity >= 1,
                   "inference_post: bad sizes");
   SEEDHIP_REQUIRE(env_ids && actions && store_index && actions_table && batch_count && append_rows && complete &&
@@ -397,7 +401,7 @@ extern "C" int seedhip_inference_post(const long long* env_ids, const uint8_t* v
                   "inference_post: sampling needs rng_state and 1 <= num_actions <= logits_ld");
   PostArgs a{env_ids, valid, actions, policy_logits, logits_ld, num_actions, rng_state, n, num_envs, full_length,
              batch_capacity, store_index, actions_table, batch_count, append_rows, complete, carry, batch_cols,
-             emit_env, emit_col, emit_count, last_rows, error_flag};
+             emit_env, emit_col, emit_count, batch_start, last_rows, error_flag};
   hipLaunchKernelGGL(inference_post_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
   return seedhip::check_launch("inference_post_kernel");
 }

@@ -153,6 +153,11 @@ class FusedInferenceState(object):
     self.first_agent_states, self.agent_states = mks(num_envs), mks(num_envs)
     self.batch = learner_lib.Unroll(mks(batch_capacity), *fields)
     self.batch_count = torch.zeros(1, dtype=torch.int32, device=dev)
+    # the batch is a RING of columns: head on the device (read by inference_post) and mirrored on the host (it only
+    # moves when the host dequeues), fill = batch_count
+    self.batch_start = torch.zeros(1, dtype=torch.int32, device=dev)
+    self._start_host = 0
+    self._deq_rows = {}
     self.episode_stats = torch.zeros((stats_capacity, 3), dtype=torch.float32, device=dev)
     self.stats_count = torch.zeros(1, dtype=torch.int32, device=dev)
     self.error_flag = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -244,7 +249,8 @@ class FusedInferenceState(object):
       b['actions'].copy_(agent_outputs.action)
     ops.inference_post(sid, b['valid'], b['actions'], logits_src, ldh, A, rng, n, self.E, self.L, self.cap,
                        self.store_index, self.actions_tab, self.batch_count, b['append_rows'], b['complete'], b['carry'],
-                       b['cols'], b['emit_env'], b['emit_col'], b['emit_count'], b['last'], self.error_flag)
+                       b['cols'], b['emit_env'], b['emit_col'], b['emit_count'], b['last'], self.error_flag,
+                       batch_start=self.batch_start)
     store_env = env_outputs._replace(
         abandoned=env_outputs.abandoned if env_outputs.abandoned is not None else b['zeros_bool'],
         episode_step=env_outputs.episode_step if env_outputs.episode_step is not None else b['zeros_i32'])
@@ -365,7 +371,7 @@ class FusedInferenceState(object):
   def _state_tensors(self):
     rng = [self.agent.rng_state()] if hasattr(self.agent, 'rng_state') else []
     return ([self.run_ids_tab, self.info_frames, self.actions_tab, self.store_index, self.info_return, self.info_raw,
-             self.batch_count, self.stats_count, self.error_flag, self.episode_stats, self.stamp_tab,
+             self.batch_count, self.batch_start, self.stats_count, self.error_flag, self.episode_stats, self.stamp_tab,
              self.call_counter] + rng +
             utils.flatten(self.store) + utils.flatten(self.first_agent_states) + utils.flatten(self.agent_states) +
             utils.flatten(self.batch))
@@ -380,7 +386,7 @@ class FusedInferenceState(object):
     """unroll_queue.dequeue(batch_size) + make_time_major of the reference (learner.py:418-432) without either: copies
     the first `batch_size` completed unrolls -- already time-major -- from the device batch into the learner's STATIC
     training unroll `dst` (an Unroll of [T+1, batch_size, ...] tensors + first agent states [batch_size, ...]; the input
-    of a captured GraphedStep), moves the remaining completed unrolls to the front and adjusts the fill count.  Returns
+    of a captured GraphedStep) and advances the ring head: the batch is a ring of columns, nothing is compacted.  Returns
     False (nothing copied) when fewer than batch_size unrolls are complete.  One host read of the fill count.
     Call it on the stream the inference calls are submitted to (`with torch.cuda.stream(s)`: the read then orders after
     every inference call in flight) and under the lock that serialises those submissions."""
@@ -388,28 +394,54 @@ class FusedInferenceState(object):
     self.last_fill = k                               # exact fill after this call (learner_server.BatchGate)
     if k < batch_size:
       return False
-    B = batch_size
+    B, cap, L = batch_size, self.cap, self.L
     self.last_fill = k - B
-    for d, s_ in zip(utils.flatten(dst.agent_state), utils.flatten(self.batch.agent_state)):
-      d.copy_(s_[:B])
-      if k > B:
-        s_[:k - B].copy_(s_[B:k].clone())
+    start = self._start_host
+    # columns [start, start + B) of the ring, time-major: one row move per field (the strided torch copies it replaces
+    # ran at a quarter of the HBM rate, and the tail of the batch had to be cloned and shifted to the front)
+    key = (B, start)
+    idx = self._deq_rows.get(key)
+    if idx is None:
+      cols = (torch.arange(B, dtype=torch.int64, device=self.device) + start) % cap
+      rows = (torch.arange(L, dtype=torch.int64, device=self.device)[:, None] * cap + cols[None, :]).reshape(-1).contiguous()
+      idx = (cols.contiguous(), rows)
+      if len(self._deq_rows) < 64:
+        self._deq_rows[key] = idx
+    cols, rows = idx
+    ds, ss = utils.flatten(dst.agent_state), utils.flatten(self.batch.agent_state)
+    if ds:
+      ops.rows_move_multi(ds, ss, [self._rb(t, 1) for t in ss], None, cols, B)
     rest_d = (dst.prev_actions, dst.env_outputs, dst.agent_outputs)
     rest_s = (self.batch.prev_actions, self.batch.env_outputs, self.batch.agent_outputs)
+    fd, fs = [], []
     for d, s_ in zip(utils.flatten(rest_d), utils.flatten(rest_s)):
       if d is None:
         continue
-      d.copy_(s_[:, :B].reshape(d.shape).to(d.dtype))
-      if k > B:
-        s_[:, :k - B].copy_(s_[:, B:k].clone())
+      if d.dtype != s_.dtype or not d.is_contiguous():
+        d.copy_(s_.reshape((L * cap,) + tuple(s_.shape[2:]))[rows].reshape(d.shape).to(d.dtype))
+        continue
+      fd.append(d); fs.append(s_)
+    ops.rows_move_multi(fd, fs, [self._rb(t, 2) for t in fs], None, rows, L * B)
+    self._start_host = (start + B) % cap
+    self.batch_start.fill_(self._start_host)
     self.batch_count.fill_(k - B)
     return True
 
   def take_batch(self):
-    """Host read of the fill count; returns (count, Unroll of views over the filled columns) and restarts filling."""
+    """Host read of the fill count; returns (count, Unroll over the filled columns, oldest first) and restarts filling
+    at column 0.  Views when the ring head is at 0 (nothing was dequeued since the last restart), a gather otherwise."""
     k = int(self.batch_count[0])
-    first = utils.map_structure(lambda t: t[:k], self.batch.agent_state)
-    rest = utils.map_structure(lambda t: t[:, :k], (self.batch.prev_actions, self.batch.env_outputs,
-                                                    self.batch.agent_outputs))
+    start, cap = self._start_host, self.cap
+    if start == 0:
+      first = utils.map_structure(lambda t: t[:k], self.batch.agent_state)
+      rest = utils.map_structure(lambda t: t[:, :k], (self.batch.prev_actions, self.batch.env_outputs,
+                                                      self.batch.agent_outputs))
+    else:
+      cols = (torch.arange(k, dtype=torch.int64, device=self.device) + start) % cap
+      first = utils.map_structure(lambda t: t[cols], self.batch.agent_state)
+      rest = utils.map_structure(lambda t: t[:, cols], (self.batch.prev_actions, self.batch.env_outputs,
+                                                        self.batch.agent_outputs))
     self.batch_count.zero_()
+    self.batch_start.zero_()
+    self._start_host = 0
     return k, learner_lib.Unroll(first, *rest)

@@ -489,7 +489,7 @@ def inference_pre(env_ids, run_ids, reward, raw_reward, done_u8, n, num_envs, nu
 
 def inference_post(env_ids, valid, actions, logits, logits_ld, num_actions, rng_state, n, num_envs, full_length,
                    batch_capacity, store_index, actions_tab, batch_count, append_rows, complete, carry, batch_cols,
-                   emit_env, emit_col, emit_count, last_rows, error_flag):
+                   emit_env, emit_col, emit_count, last_rows, error_flag, batch_start=None):
   """logits given (a view whose first element is row 0's first logit): the actions are sampled in the kernel and
   written to `actions`; logits None: `actions` is an input."""
   with _dev(complete):
@@ -498,7 +498,7 @@ def inference_post(env_ids, valid, actions, logits, logits_ld, num_actions, rng_
         _lib.ptr(rng_state), n, num_envs, full_length, batch_capacity, _lib.ptr(store_index),
         _lib.ptr(actions_tab), _lib.ptr(batch_count), _lib.ptr(append_rows), _lib.ptr(complete), _lib.ptr(carry),
         _lib.ptr(batch_cols), _lib.ptr(emit_env), _lib.ptr(emit_col), _lib.ptr(emit_count), _lib.ptr(last_rows),
-        _lib.ptr(error_flag), _lib.stream()), 'seedhip_inference_post')
+        _lib.ptr(error_flag), _lib.ptr(batch_start), _lib.stream()), 'seedhip_inference_post')
 
 
 def emit_unrolls(dsts, srcs, row_bytes, emit_env, emit_col, emit_count, max_unrolls, full_length, num_envs,

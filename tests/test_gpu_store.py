@@ -370,3 +370,59 @@ def test_stack_state_indexed_matches_gather_scatter(device):
   ops.stack_prepare_indexed(tab_c, None, None, done, T1, n, HW, ext_b, nv_b)
   ops.stack_prepare(table[:n].contiguous(), done, T1, n, HW, ext_a, nv_a)
   assert torch.equal(ext_b, ext_a)
+
+
+def test_dequeue_ring_wraps_and_keeps_order(device):
+  """The training batch is a ring of columns (learner.py:418-432: dequeue(batch_size) takes the OLDEST unrolls): a small
+  capacity that is no multiple of the batch size forces the head to wrap while inference keeps appending; the unrolls
+  handed to the learner must be exactly the ones a never-dequeued, large batch collects, in the same order."""
+  from seed_rl_amd import inference, learner, networks, utils
+  from seed_rl_amd.unroll_store import Spec
+  E, T, A, n, B = 6, 2, 5, 3, 4
+  obs = (84, 84, 1)
+  env_specs = utils.EnvOutput(Spec((), torch.float32), Spec((), torch.bool), Spec(obs, torch.uint8), Spec((), torch.bool),
+                              Spec((), torch.int32))
+  ao_specs = networks.AgentOutput(Spec((), torch.int64), Spec((A,), torch.float32), Spec((), torch.float32))
+
+  def run(cap, dequeue):
+    agent = networks.AtariShallow(A, device=device, seed=0)
+    agent.seed_sampler(7)
+    st = inference.FusedInferenceState(agent, E, T, env_specs, ao_specs, batch_capacity=cap, device=device)
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
+    dst = learner.Unroll(agent.initial_state(B), z((T + 1, B), torch.int64),
+                         utils.EnvOutput(z((T + 1, B), torch.float32), z((T + 1, B), torch.bool),
+                                         z((T + 1, B) + obs, torch.uint8), z((T + 1, B), torch.bool),
+                                         z((T + 1, B), torch.int32)),
+                         networks.AgentOutput(z((T + 1, B), torch.int64), z((T + 1, B, A), torch.float32),
+                                              z((T + 1, B), torch.float32)))
+    got = []
+    rng = np.random.default_rng(0)
+    for step in range(14):
+      for lo in (0, n):                                      # two calls of n = 3 envs per round
+        ids = torch.arange(lo, lo + n, device=device)
+        env = utils.EnvOutput(
+            torch.as_tensor((100 * np.arange(lo, lo + n) + step).astype(np.float32)).to(device),   # identifies (env, step)
+            torch.as_tensor(rng.uniform(size=n) < 0.1).to(device),
+            torch.as_tensor(rng.integers(0, 256, (n,) + obs).astype(np.uint8)).to(device),
+            torch.zeros(n, dtype=torch.bool, device=device), torch.full((n,), step, dtype=torch.int32, device=device))
+        st.inference(ids, torch.full((n,), 5, dtype=torch.int64, device=device), env, env.reward)
+        if dequeue:
+          while st.dequeue_into(dst, B):
+            got.append((dst.env_outputs.reward.cpu().numpy().copy(), dst.agent_outputs.action.cpu().numpy().copy(),
+                        dst.env_outputs.observation.cpu().numpy()[:, :, 0, 0, 0].copy(),
+                        dst.agent_state.frame_stacking_state.cpu().numpy()[:, :3].copy()))
+    st.check_errors()
+    k, rest = st.take_batch()
+    return got, k, rest
+  got, k_left, rest = run(cap=7, dequeue=True)               # 7 columns, batches of 4: the head wraps every other dequeue
+  _, k_all, full = run(cap=64, dequeue=False)
+  assert len(got) >= 4 and k_all == 4 * len(got) + k_left
+  rew = full.env_outputs.reward.cpu().numpy(); act = full.agent_outputs.action.cpu().numpy()
+  ob = full.env_outputs.observation.cpu().numpy()[:, :, 0, 0, 0]
+  fs = full.agent_state.frame_stacking_state.cpu().numpy()[:, :3]
+  for j, (r, a, o, f) in enumerate(got):
+    sl = slice(4 * j, 4 * j + 4)
+    np.testing.assert_array_equal(r, rew[:, sl]); np.testing.assert_array_equal(a, act[:, sl])
+    np.testing.assert_array_equal(o, ob[:, sl]); np.testing.assert_array_equal(f, fs[sl])
+  # what is left in the wrapped ring comes out of take_batch in order too
+  np.testing.assert_array_equal(rest.env_outputs.reward.cpu().numpy(), rew[:, 4 * len(got):])
