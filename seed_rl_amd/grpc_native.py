@@ -186,24 +186,52 @@ class NativeServer(object):
                         [[a.ctypes.data for a in slot] for slot in obufs], compute, output_nest=out, keep=(ibufs, obufs))
 
   # ---- life cycle --------------------------------------------------------------------------------------------------- #
+  def _guarded(self, b, slot, fn, *a):
+    """Runs one submission step of a batch; a failure answers the batch's callers and returns None."""
+    try:
+      return fn(*a), True
+    except gs.OpError as e:
+      code, msg = e.code, str(e.message).encode()
+    except Exception as e:                           # pylint: disable=broad-except
+      code = gs.INVALID_ARGUMENT if isinstance(e, (ValueError, AssertionError)) else gs.INTERNAL
+      msg = ('%s: %s' % (type(e).__name__, e)).encode()
+    lib().seedserve_complete(self._h, b.fn_id, slot, code, msg)
+    return None, False
+
   def _compute_loop(self, b):
+    """One thread per bound function: takes filled slots and submits them.  A `compute` with .stage / .launch halves
+    (bind_inference) is run one batch ahead: when the next full batch is already queued, its host->device copies are
+    issued before the current batch's launch; when nothing is queued the current batch is launched at once."""
     l, h = lib(), self._h
+    stage, launch = getattr(b.compute, 'stage', None), getattr(b.compute, 'launch', None)
+    pending = None                                   # (slot, token): staged, not launched
+
+    def launch_pending():
+      slot, token = pending
+      finish, ok = self._guarded(b, slot, launch, token)
+      if ok:
+        b.inflight.put((slot, finish))
+
     while True:
-      slot = l.seedserve_next_batch(h, b.fn_id, 200)
+      slot = l.seedserve_next_batch(h, b.fn_id, 0 if pending is not None else 200)
       if slot == -2:
         return
       if slot < 0:
+        if pending is not None:
+          launch_pending()
+          pending = None
         continue
-      code, msg, finish = gs.OK, b'', None
-      try:
-        finish = b.compute(slot)                     # None: done; a callable: finishes the batch later (pipelined)
-      except gs.OpError as e:
-        code, msg = e.code, str(e.message).encode()
-      except Exception as e:                         # pylint: disable=broad-except
-        code = gs.INVALID_ARGUMENT if isinstance(e, (ValueError, AssertionError)) else gs.INTERNAL
-        msg = ('%s: %s' % (type(e).__name__, e)).encode()
+      if stage is not None:
+        token, ok = self._guarded(b, slot, stage, slot, 0 if pending is None else 1)
+        if pending is not None:
+          launch_pending()
+        pending = (slot, token) if ok else None
+        continue
+      finish, ok = self._guarded(b, slot, b.compute, slot)   # None: done; a callable: finishes the batch later
+      if not ok:
+        continue
       if finish is None:
-        l.seedserve_complete(h, b.fn_id, slot, code, msg)
+        l.seedserve_complete(h, b.fn_id, slot, gs.OK, b'')
       else:
         b.inflight.put((slot, finish))
 
@@ -300,7 +328,10 @@ def bind_inference(server, fused_states, inference_batch_size, observation_shape
   stream.  2 (default): the copies of batch i+1 go to a copy stream while the graph of batch i runs, the two streams
   ordered by HOST waits of the submitting thread -- device-side cross-stream waits in front of the graph launches stalled
   that thread for the whole copy (1.30 M env-steps/s against 2.0 M on one stream and 2.2-2.26 M host-ordered, learner
-  training alongside on MI355X / ROCm 7: tools/bench_serving.py)."""
+  training alongside on MI355X / ROCm 7: tools/bench_serving.py).  >= 3: the compute thread additionally stages batch
+  i+1 BEFORE it launches batch i whenever batch i+1 is already queued (NativeServer._compute_loop), taking the PCIe
+  copy off the submitting thread's critical path; measured equal to 2 (2.73-2.78 M vs 2.76-2.80 M at 4 / 8 / 16
+  groups of 1024 envs) because with the train step alongside the DEVICE is the bound (94 % busy), not that thread."""
   import torch
   from seed_rl_amd import inference as inf
   n = inference_batch_size
@@ -334,35 +365,36 @@ def bind_inference(server, fused_states, inference_batch_size, observation_shape
     ran = [None] * pipeline                          # event after the last replay of graph k (its inputs are free again)
     counter = [0]
 
-    def compute(slot, graphs=graphs, req=req, obs=obs, act=act, out=out, st=st, s_inf=s_inf, s_copy=s_copy,
-                st_lock=st_lock, done=done, staged=staged, ran=ran, counter=counter):
-      """Submits one batch and returns: the host->device copies go to the copy stream (they wait only for the previous
-      replay of the SAME graph instance), the replay + action read-back to the inference stream; `finish` -- run by the
-      server's completion thread -- waits for the actions.  Batch i+1 is staged while batch i computes."""
+    def stage(slot, ahead=0, graphs=graphs, req=req, obs=obs, st=st, s_copy=s_copy, staged=staged, ran=ran,
+              counter=counter):
+      """First half of a batch: its host->device copies, on the copy stream.  They wait only for the previous replay of
+      the SAME graph instance (by the host: device-side cross-stream waits in front of graph launches were measured to
+      stall the submitting thread for the whole copy).  `ahead`: batches staged before this one and not launched yet."""
       if gate is not None:
-        gate.admit()
+        gate.admit(ahead)
       k = counter[0] % len(graphs)
       counter[0] += 1
-      g = graphs[k]
       with torch.cuda.device(st.device):
-        if s_copy is not s_inf:
-          # two streams ordered by the HOST (this thread exists to wait): device-side cross-stream waits in front of
-          # graph launches were measured to stall the submitting thread for the whole copy
-          if ran[k] is not None:
-            ran[k].synchronize()                     # the previous replay of this instance has read its inputs
-          with torch.cuda.stream(s_copy):
-            g.stage(req[slot], obs[slot])
-            staged[k].record(s_copy)
-          staged[k].synchronize()                    # meanwhile the previous batch's graph runs on the inference stream
+        if ran[k] is not None:
+          ran[k].synchronize()                       # the previous replay of this instance has read its inputs
+        with torch.cuda.stream(s_copy):
+          graphs[k].stage(req[slot], obs[slot])
+          staged[k].record(s_copy)
+      return slot, k
+
+    def launch(token, graphs=graphs, act=act, out=out, st=st, s_inf=s_inf, st_lock=st_lock, done=done, staged=staged,
+               ran=ran):
+      """Second half: replay + action read-back on the inference stream; returns `finish`, which the server's
+      completion thread runs to wait for the actions."""
+      slot, k = token
+      with torch.cuda.device(st.device):
+        staged[k].synchronize()                      # meanwhile the previous batch's graph runs on the inference stream
         with st_lock:
           with torch.cuda.stream(s_inf):
-            if s_copy is s_inf:
-              g.stage(req[slot], obs[slot])          # one stream: copies, replay and read-back in order
-            actions = g.launch()
-            if s_copy is not s_inf:
-              ev = torch.cuda.Event()
-              ev.record(s_inf)
-              ran[k] = ev
+            actions = graphs[k].launch()
+            ev = torch.cuda.Event()
+            ev.record(s_inf)
+            ran[k] = ev
             act[slot].copy_(actions, non_blocking=True)
             token = gate.submitted() if gate is not None else None
             done[slot].record(s_inf)
@@ -374,6 +406,38 @@ def bind_inference(server, fused_states, inference_batch_size, observation_shape
         if np.dtype(action_dtype) != np.int64:
           out[slot][...] = act[slot].numpy()
       return finish
+
+    def one_stream(slot, graphs=graphs, req=req, obs=obs, act=act, out=out, st=st, s_inf=s_inf, st_lock=st_lock,
+                   done=done, counter=counter):
+      """pipeline == 1: copies, replay and read-back in order on one stream."""
+      if gate is not None:
+        gate.admit()
+      g = graphs[counter[0] % len(graphs)]
+      counter[0] += 1
+      with torch.cuda.device(st.device), st_lock, torch.cuda.stream(s_inf):
+        g.stage(req[slot], obs[slot])
+        actions = g.launch()
+        act[slot].copy_(actions, non_blocking=True)
+        token = gate.submitted() if gate is not None else None
+        done[slot].record(s_inf)
+
+      def finish():
+        done[slot].synchronize()
+        if gate is not None:
+          gate.completed(token)
+        if np.dtype(action_dtype) != np.int64:
+          out[slot][...] = act[slot].numpy()
+      return finish
+
+    if s_copy is s_inf:
+      compute = one_stream
+    else:
+      def compute(slot, stage=stage, launch=launch):
+        return launch(stage(slot))
+      # two-phase submission: the server's compute thread stages batch i+1 BEFORE it launches batch i whenever batch
+      # i+1 is already waiting, so the PCIe copy runs under the host's graph-launch time (a lone batch is never held)
+      if len(graphs) >= 3:                           # with two instances staging batch i+2 would wait for batch i's replay
+        compute.stage, compute.launch = stage, launch
     fids.append(server.bind_buffers('inference', in_specs, out_specs, num_slots, in_ptrs, out_ptrs, compute,
                                     output_nest=gs.TensorSpec((n,), action_dtype, 'action'),
                                     keep=(req, obs, act, out, graphs, s_inf, s_copy)))

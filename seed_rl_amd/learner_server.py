@@ -45,12 +45,12 @@ class BatchGate(object):
     self.waits = 0
     self.open = True
 
-  def admit(self, poll_s=0.0001):
+  def admit(self, ahead=0, poll_s=0.0001):
     """Blocks while this batch, on top of the ones still in flight, could overflow the device batch.  Once the gate is
     closed (shutdown) nothing is admitted any more: the batch's callers get CANCELLED, as the reference's pending calls
     do when its server shuts down -- letting batches through ungated then would overflow the device batch nobody
     consumes any longer."""
-    while self.open and self.fill + self.n * (self.inflight + 1) > self.state.cap:
+    while self.open and self.fill + self.n * (self.inflight + ahead + 1) > self.state.cap:
       self.waits += 1
       time.sleep(poll_s)
     if not self.open:

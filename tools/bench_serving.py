@@ -76,35 +76,51 @@ def run_inprocess(dev, seconds=5.0, T=20, B=512, n=1024, envs=4096, warm_steps=3
   stop = threading.Event()
   served = [0]
   import queue
-  inflight = queue.Queue(maxsize=depth or max(1, groups - 1))
+  inflight = queue.Queue()
+  free = queue.Queue()                                          # env groups whose previous batch was answered
+  for k in range(groups if depth is None else min(groups, depth)):
+    free.put(k)
 
   prof = dict(compute=0.0, put=0.0, finish=0.0, get=0.0, calls=0)
+  stage, launch = getattr(bound.compute, 'stage', None), getattr(bound.compute, 'launch', None)
 
   def submitter():
-    i = 0
-    while not stop.is_set():
-      t = time.perf_counter()
-      try:
-        f = bound.compute(i % groups)
-      except Exception:                                         # the gate was closed under us: the run is over
-        break
-      t1 = time.perf_counter()
-      inflight.put(f)                                           # blocks while groups - 1 batches are in flight
-      t2 = time.perf_counter()
-      prof['compute'] += t1 - t; prof['put'] += t2 - t1; prof['calls'] += 1
-      i += 1
+    """The native server's compute loop (grpc_native.NativeServer._compute_loop) with the free list standing in for
+    seedserve_next_batch: a group's next batch is 'filled' as soon as its previous one was answered."""
+    pending = None
+    try:
+      while not stop.is_set():
+        try:
+          slot = free.get(block=pending is None, timeout=0.2)
+        except queue.Empty:
+          if pending is not None:
+            inflight.put((pending[0], launch(pending)))
+            pending = None
+          continue
+        t = time.perf_counter()
+        if stage is None:
+          inflight.put((slot, bound.compute(slot)))
+        else:
+          token = stage(slot, 0 if pending is None else 1)
+          if pending is not None:
+            inflight.put((pending[0], launch(pending)))
+          pending = token
+        prof['compute'] += time.perf_counter() - t; prof['calls'] += 1
+    except Exception:                                           # the gate was closed under us: the run is over
+      pass
     inflight.put(None)
 
   def finisher():
     while True:
       t = time.perf_counter()
-      f = inflight.get()
+      item = inflight.get()
       t1 = time.perf_counter()
-      if f is None:
+      if item is None:
         return
-      f()
+      item[1]()
       prof['get'] += t1 - t; prof['finish'] += time.perf_counter() - t1
       served[0] += n
+      free.put(item[0])
   # three busy Python threads in one process (submitter, finisher, trainer): hand the GIL over every 0.1 ms instead of
   # every 5 ms, or the trainer sees its turn a few times per step (the transport mode has no such problem: its
   # per-message work is in C++ threads)
