@@ -198,6 +198,20 @@ typedef struct { int T, B, ih, iw, oh, ow, kh, kw, stride, cout, ld_out; } seedh
 int seedhip_conv2d_stack_fwd(const seedhip_stack_conv_geom* geom, const uint8_t* frames_ext,
                              const uint8_t* nvalid, const float* w, const float* bias, float* out,
                              int out_relu, void* stream);
+/* The ReLU mask as BYTES (r3): seedhip_conv2d_stack_fwd_bits is seedhip_conv2d_stack_fwd with out_relu = 1 that
+ * also writes relu_bits [T * B * oh * ow, ld_out / 4] -- bit r of byte [pixel][q] = out[pixel][4 q + r] > 0 --, and
+ * seedhip_conv2d_bwd_data_bits is seedhip_conv2d_bwd_data (no `add`) that reads those bytes (indexed like dx / 4 floats)
+ * instead of the fp32 activation: 1/16 of the mask traffic of the next layer's data gradient
+ * (atari torso: Conv 8x8/4 x16 -> ReLU -> Conv 4x4/2; TF autodiff's ReluGrad).  Each is served by ONE specialised kernel:
+ * ask the *_supported query (1 / 0, geometry only; operands must be 16-byte aligned) and use the fp32-mask entry points
+ * otherwise -- the *_bits calls return SEEDHIP_ERR_UNSUPPORTED rather than fall back. */
+int seedhip_conv2d_stack_fwd_bits_supported(const seedhip_stack_conv_geom* geom);
+int seedhip_conv2d_stack_fwd_bits(const seedhip_stack_conv_geom* geom, const uint8_t* frames_ext,
+                                  const uint8_t* nvalid, const float* w, const float* bias, float* out,
+                                  uint8_t* relu_bits, void* stream);
+int seedhip_conv2d_bwd_data_bits_supported(const seedhip_conv_geom* geom);
+int seedhip_conv2d_bwd_data_bits(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
+                                 const uint8_t* relu_bits, void* stream);
 size_t seedhip_conv2d_stack_bwd_weight_workspace_bytes(const seedhip_stack_conv_geom* geom);
 int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* geom, const uint8_t* frames_ext,
                                     const uint8_t* nvalid, const float* dy, float* dw, float* dbias,

@@ -257,6 +257,28 @@ extern "C" int seedhip_conv2d_bwd_data(const seedhip_conv_geom* geom, const floa
   return seedhip_conv2d_bwd_data_ws(geom, dy, w, dx, relu_mask, add, nullptr, 0, stream);
 }
 
+// Data gradient with the ReLU mask as bytes (one per four input channels, written by seedhip_conv2d_stack_fwd_bits).
+extern "C" int seedhip_conv2d_bwd_data_bits_supported(const seedhip_conv_geom* geom) {
+  if (!geom || check_geom(geom, "conv2d_bwd_data_bits_supported") || !(gemm_mode() & 16)) return 0;
+  wsgemm::Params wp;
+  wsgemm::Plan pl = wsgemm::plan_dgrad(wp, geom);
+  if (!pl.ok) return 0;
+  wp.mask_bits = reinterpret_cast<const unsigned char*>(16);          // any non-null value: nothing is launched
+  return wsgemm::launch(wp, pl, nullptr, true) == SEEDHIP_OK;
+}
+
+extern "C" int seedhip_conv2d_bwd_data_bits(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
+                                            const uint8_t* relu_bits, void* stream) {
+  int rc = check_geom(geom, "conv2d_bwd_data_bits"); if (rc) return rc;
+  SEEDHIP_REQUIRE(dy && w && dx && relu_bits, "conv2d_bwd_data_bits: null pointer");
+  SEEDHIP_REQUIRE((gemm_mode() & 16) && al16(dy) && al16(w) && al16(dx), "conv2d_bwd_data_bits: not served (ask seedhip_conv2d_bwd_data_bits_supported; 16-byte aligned operands)");
+  wsgemm::Params wp;
+  wsgemm::Plan pl = wsgemm::plan_dgrad(wp, geom);
+  if (!pl.ok) return fail(SEEDHIP_ERR_UNSUPPORTED, "conv2d_bwd_data_bits: geometry not served (ask seedhip_conv2d_bwd_data_bits_supported)");
+  wp.A = dy; wp.W = w; wp.C = dx; wp.mask_bits = relu_bits;
+  return wsgemm::launch(wp, pl, (hipStream_t)stream);
+}
+
 extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
                                           const float* relu_mask, const float* add, void* workspace,
                                           size_t workspace_bytes, void* stream) {

@@ -60,6 +60,7 @@ struct Params {
   int T1, B, ih, iw, oh, ow, cout, ld_out, out_relu;
   int fsz;                     // ih*iw bytes, multiple of 16, <= 2*kThreads*16
   int spc, items;              // steps per chunk; items = B * nchunks
+  unsigned char* relu_bits;    // fwd (bf16x3 kernel), optional: [T1*B*oh*ow, ld_out / 4] bytes, bit r of byte q = out[.., 4q + r] > 0
 };
 
 __device__ __forceinline__ float ubyte(uint32_t w, int q) { return (float)((w >> (8 * q)) & 0xFFu); }
@@ -423,7 +424,7 @@ __device__ __forceinline__ void band_prologue16(const Params& p, unsigned char* 
 // EXP (tools/probes/stack_probe.hip only; the library instantiates EXP = 0): leave one ingredient out -- 1 no MFMAs,
 // 2 no global band prefetch after the prologue, 4 no output stores, 8 no LDS pixel reads (one fragment reused),
 // 16 no band conversion / LDS store.
-template <int EXP>
+template <int EXP, bool BITS = false>                  // BITS: also write the ReLU byte mask (Params::relu_bits)
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
 stackconv_fwd_bf16r_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -527,6 +528,10 @@ stackconv_fwd_bf16r_kernel(const Params p) {
         float* o = p.out + (((long long)t * p.B + b) * 400 + pix) * p.ld_out + co0 + 4 * kq;
         if (EXP & 4) asm volatile("" :: "v"(v));
         else *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        // the ReLU mask the next layer's data gradient needs, as one byte per lane (its four channels): that kernel then
+        // reads 1 byte where it read the 16 of the activation (wsgemm.h, ws_tab_kernel<.., BITS>)
+        if (BITS)
+          p.relu_bits[(o - p.out) >> 2] = (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
       }
       if (more) {
         wave_lds_fence();                              // this wave's reads of frame t are done
@@ -909,15 +914,26 @@ Params make_params(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, 
   return p;
 }
 
-int launch_fwd(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, const uint8_t* nvalid, const float* w,
-               const float* bias, float* out, int out_relu, hipStream_t s) {
-  Params p = make_params(g, frames_ext, nvalid);
-  p.w = w; p.bias = bias; p.out = out; p.out_relu = out_relu;
+bool bf16x3_enabled() {
   static const int bf16x3 = getenv("SEEDHIP_STACK_BF16") ? atoi(getenv("SEEDHIP_STACK_BF16")) : 1;
+  return bf16x3 != 0;
+}
+
+int launch_fwd(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, const uint8_t* nvalid, const float* w,
+               const float* bias, float* out, int out_relu, hipStream_t s, unsigned char* relu_bits = nullptr) {
+  Params p = make_params(g, frames_ext, nvalid);
+  p.w = w; p.bias = bias; p.out = out; p.out_relu = out_relu; p.relu_bits = relu_bits;
+  const bool bf16x3 = bf16x3_enabled();
+  if (relu_bits && !bf16x3) return fail(SEEDHIP_ERR_UNSUPPORTED, "conv2d_stack_fwd_bits: only the bf16x3 kernel writes the byte mask");
   if (bf16x3) {
     const size_t lds = (size_t)kGroups * 64 * 16 + (size_t)kWaves * kWaveRing16;
     int grid;
     decompose(p.T1, p.B, max_grid_for(2), &p.spc, &p.items, &grid);
+    if (relu_bits) {
+      (void)hipFuncSetAttribute((const void*)stackconv_fwd_bf16r_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((stackconv_fwd_bf16r_kernel<0, true>), dim3(grid, 1, g->cout / 16), dim3(kThreads), lds, s, p);
+      return check_launch("stackconv_fwd_bf16r_kernel(byte mask)");
+    }
     (void)hipFuncSetAttribute((const void*)stackconv_fwd_bf16r_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(stackconv_fwd_bf16r_kernel<0>, dim3(grid, 1, g->cout / 16), dim3(kThreads), lds, s, p);
     return check_launch("stackconv_fwd_bf16r_kernel");
@@ -998,6 +1014,24 @@ extern "C" int seedhip_conv2d_stack_fwd(const seedhip_stack_conv_geom* geom, con
   p.init(to_stack(geom));
   launch_igemm_auto(p, 1, (hipStream_t)stream);
   return check_launch("conv2d_stack_fwd");
+}
+
+// The same forward, also writing the ReLU mask of its output as one byte per four channels (seedhip.h).
+extern "C" int seedhip_conv2d_stack_fwd_bits_supported(const seedhip_stack_conv_geom* g) {
+  return g && g->kh == 8 && g->kw == 8 && g->stride == 4 && g->ih == stackconv::kIH && g->iw == stackconv::kIW &&
+         g->oh == 20 && g->ow == 20 && g->cout % 16 == 0 && g->ld_out % 4 == 0 && stackconv::bf16x3_enabled() &&
+         (long long)g->T * g->B * g->oh * g->ow * g->ld_out < (1LL << 30);
+}
+
+extern "C" int seedhip_conv2d_stack_fwd_bits(const seedhip_stack_conv_geom* geom, const uint8_t* frames_ext,
+                                             const uint8_t* nvalid, const float* w, const float* bias, float* out,
+                                             uint8_t* relu_bits, void* stream) {
+  int rc = check_stack(geom, "conv2d_stack_fwd_bits"); if (rc) return rc;
+  SEEDHIP_REQUIRE(frames_ext && nvalid && w && out && relu_bits, "conv2d_stack_fwd_bits: null pointer");
+  if (!(seedhip_conv2d_stack_fwd_bits_supported(geom) && stackconv::eligible(geom, frames_ext, out) &&
+        (!bias || (((uintptr_t)bias) & 15) == 0)))
+    return fail(SEEDHIP_ERR_UNSUPPORTED, "conv2d_stack_fwd_bits: geometry / alignment not served (ask seedhip_conv2d_stack_fwd_bits_supported)");
+  return stackconv::launch_fwd(geom, frames_ext, nvalid, w, bias, out, 1, (hipStream_t)stream, relu_bits);
 }
 
 extern "C" size_t seedhip_conv2d_stack_bwd_weight_workspace_bytes(const seedhip_stack_conv_geom* g) {

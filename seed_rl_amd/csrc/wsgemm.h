@@ -443,9 +443,10 @@ ws_fast_kernel(const Params p) {
 // EXP (tools/probes/ws_probe.hip only; the library instantiates EXP = 0): leave one ingredient out to see what the
 // others cost -- 1 no MFMAs, 2 no global A loads after the first tile, 4 no stores, 8 no mask loads, 16 no LDS fragment
 // reads, 32 no LDS staging writes.
-template <int NT, int NKT, int MODE, int EXP = 0>
+template <int NT, int NKT, int MODE, int EXP = 0, bool BITS = false>
 __global__ void __launch_bounds__(512)
 ws_tab_kernel(const Params p) {
+  static_assert(!BITS || MODE == 1, "the byte mask belongs to the data gradient");
   constexpr int WAVES = 8, N = 16 * NT, K = NKT * BK, LDW = K + 8, kThreads = 64 * WAVES;
   constexpr int NV = MODE == 0 ? 1 : NKT;                     // load offsets per row
   constexpr unsigned kOut = 0x80000000u;                      // "outside": + any row base (< 2^31) stays beyond num_records
@@ -491,7 +492,8 @@ ws_tab_kernel(const Params p) {
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(sq), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t rsrc = view(p.A + minoff, p.a_bytes - (long long)minoff * 4),
-                               c_rsrc = view(p.C, p.c_bytes), m_rsrc = view(p.mask, p.c_bytes);
+                               c_rsrc = view(p.C, p.c_bytes),
+                               m_rsrc = BITS ? view(p.mask_bits, p.c_bytes >> 4) : view(p.mask, p.c_bytes);
   const unsigned a_img_bytes = p.a_img_stride * 4u;
   const unsigned c_img_bytes = MODE == 0 ? (unsigned)G * (unsigned)p.ldc * 4u : (unsigned)(p.ih * p.iw * p.ld_in) * 4u;
   // uniform store offsets of the NT accumulators: forward n = 16 t + 4 kq + r; data gradient n = (class, ci), cin % 16 == 0
@@ -505,6 +507,9 @@ ws_tab_kernel(const Params p) {
     }
     coff[t] = __builtin_amdgcn_readfirstlane(coff[t]);
   }
+  unsigned cbit[NT];                                          // the same offsets into the byte mask (one byte per 16 of C)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) cbit[t] = __builtin_amdgcn_readfirstlane(coff[t] >> 4);
 
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   unsigned voff[2][NV];
@@ -543,7 +548,7 @@ ws_tab_kernel(const Params p) {
     if (MODE == 0 && p.bias) bias_v[t] = *reinterpret_cast<const f32x4_t*>(p.bias + 16 * t + 4 * kq);
   }
   const int wstride = gridDim.x * WAVES;
-  const bool relu = p.out_relu != 0, has_mask = p.mask != nullptr;
+  const bool relu = p.out_relu != 0, has_mask = BITS || p.mask != nullptr;
 
   int tile = blockIdx.x * WAVES + wave;
   setup(tile);
@@ -566,7 +571,11 @@ ws_tab_kernel(const Params p) {
       at = img * c_img_bytes + tab_out[rem] + (unsigned)(kq * 16);
     }
     u32x4_t mpre[NT];
-    if (MODE == 1 && has_mask) {
+    int mbit[NT];
+    if (BITS) {                                               // one byte per accumulator: this lane's four channels
+#pragma unroll
+      for (int t = 0; t < NT; ++t) mbit[t] = (int)__builtin_amdgcn_raw_buffer_load_b8(m_rsrc, at >> 4, cbit[t], 0);
+    } else if (MODE == 1 && has_mask) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if (EXP & 8) mpre[t] = u32x4_t{0x3f800000u, 0x3f800000u, 0u, 0x3f800000u};
@@ -623,6 +632,10 @@ ws_tab_kernel(const Params p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
+      } else if (BITS) {                                       // bit r sign-extended to a 0 / ~0 word, ANDed in
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          v[r] = __uint_as_float(__float_as_uint(v[r]) & (unsigned)((mbit[t] << (31 - r)) >> 31));
       } else if (has_mask) {
         const f32x4_t mv = __builtin_bit_cast(f32x4_t, mpre[t]);
 #pragma unroll
@@ -634,7 +647,8 @@ ws_tab_kernel(const Params p) {
   }
 }
 
-inline int launch(Params& p, Plan& pl, hipStream_t s) {
+// `dry`: no launch -- SEEDHIP_OK iff the call would be served (the byte-mask query of conv.hip).
+inline int launch(Params& p, Plan& pl, hipStream_t s, bool dry = false) {
   static const int force_mr = getenv("SEEDHIP_WS_MR") ? atoi(getenv("SEEDHIP_WS_MR")) : 0;
   static const int force_w = getenv("SEEDHIP_WS_WAVES") ? atoi(getenv("SEEDHIP_WS_WAVES")) : 0;
   pl.mr = force_mr ? force_mr : 1;                           // measured (cfg2 step): 16-row wave tiles, 8 waves per workgroup
@@ -660,6 +674,16 @@ inline int launch(Params& p, Plan& pl, hipStream_t s) {
                      : (p.cin % 16 == 0 && p.gh * p.s == p.ih && p.gw * p.s == p.iw && p.c_bytes < (1LL << 31) - (1 << 20)));
     if (tab_ok) {
       const size_t lds = ((size_t)p.N * (p.K + 8) + 8 * 16 * LDA + (size_t)p.gh * p.gw * ((p.mode == 0 ? 1 : p.nkt) + 1)) * sizeof(float);
+      if (p.mask_bits) {                                     // byte ReLU mask: the 16-channel, four-tap data gradient only
+        if (!(pl.nr == 4 && p.nkt == 4 && p.mode == 1 && p.cin == 16 && p.ld_in == 16 && lds <= 72 * 1024))
+          return dry ? SEEDHIP_ERR_UNSUPPORTED : fail(SEEDHIP_ERR_UNSUPPORTED, "wsgemm: no byte-mask kernel for this data gradient");
+        if (dry) return SEEDHIP_OK;
+        if (lds > 64 * 1024)
+          (void)hipFuncSetAttribute((const void*)ws_tab_kernel<4, 4, 1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ws_tab_kernel<4, 4, 1, 0, true>), dim3(pl.grid), dim3(512), lds, s, p);
+        return check_launch("ws_tab_kernel(byte mask)");
+      }
+      if (dry) return SEEDHIP_OK;
 #define SEEDHIP_WST(NT_, NKT_, MODE_)                                                                             \
       if (pl.nr == NT_ && p.nkt == NKT_ && p.mode == MODE_ && lds <= 72 * 1024) {                                 \
         if (lds > 64 * 1024)                                                                                      \
@@ -670,6 +694,10 @@ inline int launch(Params& p, Plan& pl, hipStream_t s) {
       SEEDHIP_WST(2, 8, 0) SEEDHIP_WST(4, 8, 0) SEEDHIP_WST(4, 4, 1) SEEDHIP_WST(2, 4, 1) SEEDHIP_WST(4, 8, 1) SEEDHIP_WST(2, 8, 1)
 #undef SEEDHIP_WST
     }
+    // (the byte mask and the dry run end here: the kernels below take the fp32 mask only)
+    if (p.mask_bits || dry)
+      return dry ? (p.mask_bits ? SEEDHIP_ERR_UNSUPPORTED : SEEDHIP_OK)
+                 : fail(SEEDHIP_ERR_UNSUPPORTED, "wsgemm: the byte ReLU mask needs ws_tab_kernel");
 #define SEEDHIP_WSF(NR_, NKT_, MODE_)                                                                             \
     if (pl.nr == NR_ && p.nkt == NKT_ && p.mode == MODE_) {                                                       \
       if (pl.lds > 64 * 1024)                                                                                     \
@@ -680,6 +708,9 @@ inline int launch(Params& p, Plan& pl, hipStream_t s) {
     SEEDHIP_WSF(2, 8, 0) SEEDHIP_WSF(4, 8, 0) SEEDHIP_WSF(4, 4, 1) SEEDHIP_WSF(2, 4, 1) SEEDHIP_WSF(4, 8, 1) SEEDHIP_WSF(2, 8, 1)
 #undef SEEDHIP_WSF
   }
+  if (p.mask_bits || dry)
+    return dry ? (p.mask_bits ? SEEDHIP_ERR_UNSUPPORTED : SEEDHIP_OK)
+               : fail(SEEDHIP_ERR_UNSUPPORTED, "wsgemm: the byte ReLU mask needs ws_tab_kernel");
 #define SEEDHIP_WS(MR_, NR_, W_)                                                                                  \
   if (pl.mr == MR_ && pl.nr == NR_ && waves == W_) {                                                              \
     if (pl.lds > 64 * 1024)                                                                                       \

@@ -32,6 +32,10 @@ struct Params {
   long long a_bytes;                          // extent of A in bytes (buffer-resource range of the specialised kernel)
   long long c_bytes;                          // extent of C (and of mask / add / residual, which are indexed like C) in bytes
   int pow2, l_cout, l_cin, l_s, l_jw;         // data gradient: cout, cin, s, kw / s all powers of two -> W' index math by shifts
+  // data gradient, ws_tab_kernel<.., BITS = true> only: the ReLU mask as one BYTE per four channels, indexed like C / 16
+  // (bit r of byte [pixel][q] = activation[pixel][4 q + r] > 0; written by the producing forward kernel) instead of the
+  // fp32 activation itself: 1/16 of the mask traffic
+  const unsigned char* mask_bits;
 };
 
 

@@ -31,6 +31,7 @@ AgentOutput = collections.namedtuple('AgentOutput', 'action policy_logits baseli
 # by the torso (csrc/frames.hip: *_indexed): column b's state is table[rows[b]]; zero_mask[b] != 0: counts as zeros
 # (restarted actor); valid_mask[b] == 0: the row is not written back.  Passed by inference.FusedInferenceState.
 IndexedFrameState = collections.namedtuple('IndexedFrameState', 'table rows zero_mask valid_mask')
+_RELU_BITS = os.environ.get('SEEDHIP_RELU_BITS', '0') == '1'      # A/B knob, see _AtariTorso._torso_fwd
 AgentState = collections.namedtuple('AgentState', 'core_state frame_stacking_state')
 
 
@@ -440,9 +441,10 @@ class _AtariTorso(object):
     return self._buf('frames_ext' if not slot else 'frames_ext%d' % slot, (T1 + 3, B, self._obs[0] * self._obs[1]),
                      torch.uint8, zero=True)
 
-  def _torso_fwd(self, obs, done_u8, frame_state, out, ld_out, need_state=True):
+  def _torso_fwd(self, obs, done_u8, frame_state, out, ld_out, need_state=True, for_backward=True):
     """obs uint8 [T1,B,H,W,1]; writes relu(fc) into out[:, :fc] (row stride ld_out).  Returns the new
-    frame-stacking state and the context the backward needs."""
+    frame-stacking state and the context the backward needs (for_backward=False: a forward nobody differentiates --
+    central inference -- skips what only the backward reads)."""
     T1, B = done_u8.shape[0], done_u8.shape[1]
     H, W = self._obs
     HW, N = H * W, T1 * B
@@ -464,7 +466,18 @@ class _AtariTorso(object):
     ih, iw, cin, k, s, ch, oh, ow = self._shapes[0]
     g0 = ops.StackConvGeom(T1, B, ih, iw, oh, ow, k, k, s, ch, ch)
     a = self._buf('act0', (N, oh, ow, ch))
-    ops.conv2d_stack_fwd(g0, ext, nvalid, fl.p(tp + 'conv0/kernel'), fl.p(tp + 'conv0/bias'), a, out_relu=True)
+    # SEEDHIP_RELU_BITS=1: the ReLU mask of the first conv as bytes, where both it and the second conv's data gradient
+    # have the kernel for it (the shallow torso) -- that gradient then reads 1 byte where it read 16 of act0.  OFF by
+    # default: bit-identical, but measured a net loss on MI355X (cfg2: data gradient 172 -> 161 us, first conv forward
+    # 179 -> 198 us: the 10 VALU instructions per tile that form the nibble cost the producer more than the consumer's
+    # memory side gains)
+    bits0 = None
+    if _RELU_BITS and for_backward and len(self._shapes) > 1 and ops.conv2d_stack_fwd_bits_supported(g0):
+      ih1, iw1, cin1, k1, s1, ch1, _, _ = self._shapes[1]
+      if ops.conv2d_bwd_data_bits_supported(ops.conv_geom(N, ih1, iw1, cin1, k1, k1, s1, 'valid', ch1)):
+        bits0 = self._buf('act0_bits', (N, oh, ow, ch // 4), torch.uint8)
+    ops.conv2d_stack_fwd(g0, ext, nvalid, fl.p(tp + 'conv0/kernel'), fl.p(tp + 'conv0/bias'), a, out_relu=True,
+                         relu_bits=bits0)
     acts.append(a); geoms.append(g0)
     for i in range(1, len(self._shapes)):
       ih, iw, cin, k, s, ch, oh, ow = self._shapes[i]
@@ -481,7 +494,7 @@ class _AtariTorso(object):
     elif need_state:                              # the learner discards it (agents/vtrace/learner.py:75-79 `learner_outputs, _ =`)
       new_fs = torch.empty_like(frame_state)
       ops.stack_pack_state(ext, nvalid, T1, B, HW, new_fs)
-    return new_fs, dict(ext=ext, nvalid=nvalid, acts=acts, geoms=geoms, gfc=gfc)
+    return new_fs, dict(ext=ext, nvalid=nvalid, acts=acts, geoms=geoms, gfc=gfc, bits0=bits0)
 
   def _torso_bwd(self, ctx, dz, wsb):
     """dz: gradient wrt the Dense pre-activation (already masked by its ReLU), row stride = gfc.ld_out."""
@@ -498,7 +511,10 @@ class _AtariTorso(object):
       g, a_in = geoms[i], acts[i - 1]
       ops.conv2d_bwd_weight(g, a_in, da, fl.g('%sconv%d/kernel' % (tp, i)), fl.g('%sconv%d/bias' % (tp, i)), wsb)
       d_in = self._buf('d_act%d' % (i - 1), tuple(a_in.shape))
-      ops.conv2d_bwd_data(g, da, fl.p('%sconv%d/kernel' % (tp, i)), d_in, relu_mask=a_in)
+      if i == 1 and ctx.get('bits0') is not None:
+        ops.conv2d_bwd_data(g, da, fl.p('%sconv%d/kernel' % (tp, i)), d_in, relu_bits=ctx['bits0'])
+      else:
+        ops.conv2d_bwd_data(g, da, fl.p('%sconv%d/kernel' % (tp, i)), d_in, relu_mask=a_in)
       da = d_in
     # first conv: weight gradient straight from the uint8 frames
     ws0 = self._buf('stack_ws', (ops.conv2d_stack_bwd_weight_workspace_bytes(geoms[0]) // 4 + 4,))
@@ -549,7 +565,8 @@ class AtariShallow(_Agent, _AtariTorso):
     N = T1 * B
     done_u8 = ops.as_u8(done)
     hfc = self._buf('fc_out', (N, self._fc))
-    new_fs, ctx = self._torso_fwd(obs, done_u8, agent_state.frame_stacking_state, hfc, self._fc, need_state)
+    new_fs, ctx = self._torso_fwd(obs, done_u8, agent_state.frame_stacking_state, hfc, self._fc, need_state,
+                                  for_backward=unroll)
     head = self._head_fwd(hfc, N, self._fc)
     self._last = dict(T1=T1, B=B, N=N, ctx=ctx, hfc=hfc, head=head)
     out = self._agent_output(head, T1, B, sample=sample_actions and not is_training)

@@ -142,9 +142,24 @@ def conv2d_fwd(g, x, w, bias, out, in_dtype=IN_F32, in_relu=False, out_relu=Fals
     return out
 
 
-def conv2d_bwd_data(g, dy, w, dx, relu_mask=None, add=None):
+def conv2d_bwd_data_bits_supported(g):
+  """The data gradient of this geometry can take its ReLU mask as bytes (conv2d_stack_fwd(..., relu_bits=))."""
+  return bool(_lib.lib().seedhip_conv2d_bwd_data_bits_supported(ctypes.byref(g)))
+
+
+def conv2d_bwd_data(g, dy, w, dx, relu_mask=None, add=None, relu_bits=None):
+  """relu_bits (uint8, one byte per four input channels) replaces relu_mask where conv2d_bwd_data_bits_supported."""
   flops, nbytes = _conv_cost(g)
   nbytes += 4 * g.n_img * g.ih * g.iw * g.cin * ((relu_mask is not None) + (add is not None))   # mask / accumulate reads
+  if relu_bits is not None:
+    if relu_mask is not None or add is not None:
+      raise ValueError('conv2d_bwd_data: relu_bits excludes relu_mask / add')
+    with _region(_conv_name('conv_dgrad', g), flops, nbytes + g.n_img * g.ih * g.iw * g.cin // 4):
+      with _dev(dx):
+        _lib.check(_lib.lib().seedhip_conv2d_bwd_data_bits(
+            ctypes.byref(g), _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(relu_bits), _lib.stream()),
+            'seedhip_conv2d_bwd_data_bits')
+      return dx
   with _region(_conv_name('conv_dgrad', g), flops, nbytes):
     with _dev(dx):
       ws, wsb = _splitk_ws(int(_lib.lib().seedhip_conv2d_bwd_data_workspace_bytes(ctypes.byref(g))), dx)
@@ -215,9 +230,22 @@ def stack_pack_state(frames_ext, nvalid, T, B, HW, new_state):
           'seedhip_stack_pack_state')
 
 
-def conv2d_stack_fwd(g, frames_ext, nvalid, w, bias, out, out_relu=True):
+def conv2d_stack_fwd_bits_supported(g):
+  return bool(_lib.lib().seedhip_conv2d_stack_fwd_bits_supported(ctypes.byref(g)))
+
+
+def conv2d_stack_fwd(g, frames_ext, nvalid, w, bias, out, out_relu=True, relu_bits=None):
+  """relu_bits (uint8 [T * B * oh * ow, ld_out / 4], where conv2d_stack_fwd_bits_supported): also receives the ReLU mask
+  of `out` as bytes, for conv2d_bwd_data(..., relu_bits=) of the next layer."""
   with _region('stack_conv_fwd', 2.0 * g.T * g.B * g.oh * g.ow * g.cout * g.kh * g.kw * 4, g.T * g.B * g.ih * g.iw + g.T * g.B * g.oh * g.ow * g.cout * 4):
     with _dev(out):
+      if relu_bits is not None:
+        if not out_relu:
+          raise ValueError('conv2d_stack_fwd: relu_bits needs out_relu')
+        _lib.check(_lib.lib().seedhip_conv2d_stack_fwd_bits(
+            ctypes.byref(g), _lib.ptr(frames_ext), _lib.ptr(nvalid), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out),
+            _lib.ptr(relu_bits), _lib.stream()), 'seedhip_conv2d_stack_fwd_bits')
+        return
       _lib.check(_lib.lib().seedhip_conv2d_stack_fwd(
           ctypes.byref(g), _lib.ptr(frames_ext), _lib.ptr(nvalid), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out),
           int(out_relu), _lib.stream()), 'seedhip_conv2d_stack_fwd')

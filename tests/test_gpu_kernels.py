@@ -515,6 +515,54 @@ def test_stack_conv_fwd_fp32_accuracy(device):
   assert e_hip <= max(2.0 * e_f32, 2e-6 * np.abs(g64).max()), (e_hip, e_f32, np.abs(g64).max())
 
 
+@pytest.mark.parametrize('T1,B', [(3, 5), (6, 37)])
+def test_relu_byte_mask_pair(device, T1, B):
+  """The shallow Atari torso's ReLU mask as bytes (seedhip_conv2d_stack_fwd_bits -> seedhip_conv2d_bwd_data_bits): the
+  forward's activation is bit-identical to the plain call, byte [pixel][q] bit r = act[pixel][4 q + r] > 0, and the
+  second conv's data gradient through the bytes is bit-identical to the one through the fp32 activation (TF autodiff's
+  ReluGrad of atari torso layers 1 -> 2; ragged last tiles: 37 * 6 * 100 super-pixels is not a multiple of 16 * 8)."""
+  from seed_rl_amd import ops
+  cout, N = 16, T1 * B
+  u = synth.atari_unroll(5, T1, B, done_p=0.2, zero_state=False)
+  rng = np.random.default_rng(2)
+  w = (rng.normal(size=(8, 8, 4, cout)) / 16).astype(np.float32)
+  b = (rng.normal(size=cout) * 0.5).astype(np.float32)
+  HW = 84 * 84
+  ext = torch.zeros((T1 + 3, B, HW), dtype=torch.uint8, device=device)
+  ext[3:] = dev(u['frames'].reshape(T1, B, HW), device)
+  nv = torch.zeros((T1, B), dtype=torch.uint8, device=device)
+  ops.stack_prepare(dev(u['frame_state'], device), dev(u['done'].astype(np.uint8), device), T1, B, HW, ext, nv)
+  g0 = ops.StackConvGeom(T1, B, 84, 84, 20, 20, 8, 8, 4, cout, cout)
+  g1 = ops.conv_geom(N, 20, 20, 16, 4, 4, 2, 'valid', 32)
+  assert ops.conv2d_stack_fwd_bits_supported(g0) and ops.conv2d_bwd_data_bits_supported(g1)
+  # geometries the byte-mask kernels do not serve say so (the callers then keep the fp32 mask)
+  assert not ops.conv2d_bwd_data_bits_supported(ops.conv_geom(N, 20, 20, 32, 4, 4, 2, 'valid', 64))
+  assert not ops.conv2d_bwd_data_bits_supported(ops.conv_geom(N, 9, 9, 64, 3, 3, 1, 'valid', 64))
+  assert not ops.conv2d_stack_fwd_bits_supported(ops.StackConvGeom(T1, B, 64, 64, 15, 15, 8, 8, 4, cout, cout))
+  wd, bd = dev(w, device), dev(b, device)
+  ref = torch.empty((N, 20, 20, cout), device=device)
+  ops.conv2d_stack_fwd(g0, ext, nv, wd, bd, ref, out_relu=True)
+  out = torch.empty_like(ref)
+  bits = torch.full((N, 20, 20, cout // 4), 0xAA, dtype=torch.uint8, device=device)
+  ops.conv2d_stack_fwd(g0, ext, nv, wd, bd, out, out_relu=True, relu_bits=bits)
+  assert torch.equal(out, ref)
+  pos = (ref > 0).reshape(N, 20, 20, cout // 4, 4).to(torch.uint8)
+  want = pos[..., 0] | (pos[..., 1] << 1) | (pos[..., 2] << 2) | (pos[..., 3] << 3)
+  assert torch.equal(bits, want)
+  frac = float(pos.float().mean())
+  assert 0.2 < frac < 0.8, frac                       # the mask is not trivially all-ones / all-zeros
+  dy = dev(rng.normal(size=(N, 9, 9, 32)).astype(np.float32), device)
+  w1 = dev((rng.normal(size=(4, 4, 16, 32)) / 16).astype(np.float32), device)
+  dx_ref = torch.full((N, 20, 20, 16), float('nan'), device=device)
+  ops.conv2d_bwd_data(g1, dy, w1, dx_ref, relu_mask=ref)
+  dx = torch.full((N, 20, 20, 16), float('nan'), device=device)
+  ops.conv2d_bwd_data(g1, dy, w1, dx, relu_bits=bits)
+  assert torch.equal(dx, dx_ref)
+  assert bool((dx[~(ref > 0)] == 0).all())
+  with pytest.raises(Exception):                      # no silent fallback for a geometry without the kernel
+    ops.conv2d_bwd_data(ops.conv_geom(N, 20, 20, 32, 4, 4, 2, 'valid', 64), dy, w1, dx, relu_bits=bits)
+
+
 @pytest.mark.parametrize('n,ih,iw', [(3, 72, 96), (2, 11, 9), (5, 8, 12), (1, 3, 3)])
 def test_convpool_fused_parity(device, n, ih, iw):
   """Fused Conv2D(16, 3, 'same')(x/255) + MaxPool2D(3, 2, 'same') of ImpalaDeep's first stage
