@@ -661,12 +661,12 @@ def main():
       try:
         sys.path.insert(0, os.path.join(ROOT, 'tools'))
         import bench_serving
-        serving = dict(inprocess=bench_serving.run_inprocess(dev, seconds=3.0))
+        serving = dict(inprocess=bench_serving.run_inprocess(dev, seconds=3.0, n=2048, envs=8192))
         _release()
         try:
           procs = 32 if (os.cpu_count() or 8) >= 64 else 8
-          serving['transport'] = bench_serving.run_transport(dev, seconds=3.0, n=1024 if procs == 32 else 256,
-                                                             procs=procs, envs_per_proc=128 if procs == 32 else 64)
+          serving['transport'] = bench_serving.run_transport(dev, seconds=3.0, n=2048 if procs == 32 else 256,
+                                                             procs=procs, envs_per_proc=256 if procs == 32 else 64)
         except Exception as e:                   # pylint: disable=broad-except
           serving['transport'] = dict(error=repr(e))
         serving['note'] = ('closed loop on ONE GPU: inference batches on a high-priority stream (inference twin of the '

@@ -328,7 +328,7 @@ int seedhip_rows_move(void* dst, const long long* dst_rows, const void* src, con
 
 /* ---- batched inference bookkeeping (no host synchronisation, HIP-graph capturable) -----------------------
  * The small-tensor part of the `inference` function of agents/vtrace/learner.py:350-405 on the device store.
- * n = inference batch size (<= 1024), ids int64, unique within a call.
+ * n = inference batch size (<= 65536: one workgroup walks it in 1024-row chunks), ids int64, unique within a call.
  *  inference_pre : run-id compare / resets (:353-366), episode statistics (:373-378; finished episodes are
  *                  appended to episode_stats[stats_capacity][3] = (frames, return, raw_return) through *stats_count),
  *                  previous actions (:381).  Outputs reset_mask u8[n], prev_actions i64[n].

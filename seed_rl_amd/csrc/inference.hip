@@ -14,11 +14,13 @@
 //                    policy-head rows (Gumbel-max over Philox randoms, dmlab/networks.py:122) so that no eager op
 //                    sits between the head GEMM and the bookkeeping.
 //   rows_move_ops  : all data movement of the step as 4 launches of mutually independent row moves.
-// One workgroup; n = inference batch size <= 1024.  All integer work: exact.
+// One workgroup looping over 1024-row chunks; n = inference batch size <= 65536.  All integer work: exact.
 #include "common.h"
 #include "../../include/seedhip.h"
 
 namespace {
+
+constexpr int kMaxInferenceRows = 65536;
 
 struct PreArgs {
   const long long* env_ids; const long long* run_ids; const float* reward; const float* raw_reward;
@@ -33,60 +35,60 @@ struct PreArgs {
 
 __global__ void __launch_bounds__(1024)
 inference_pre_kernel(PreArgs a) {
-  const int i = threadIdx.x;
   // this call's stamp: every thread reads the counter, thread 0 advances it once all have (one workgroup)
   const int stamp = *a.call_counter + 1;
   __syncthreads();
-  if (i == 0) *a.call_counter = stamp;
-  if (i >= a.n) return;
-  const long long e = a.env_ids[i];
-  if (e < 0 || e >= a.num_envs) {
-    // the reference raises (tf scatter / gather out of range); here the row is masked out of EVERY table access of
-    // the step (valid = 0, ids_safe = 0 keeps reads in range) and the error is flagged
-    atomicOr(a.error_flag, 1);
-    a.reset_mask[i] = 0; a.prev_actions[i] = 0; a.ids_safe[i] = 0; a.valid[i] = 0;
-    if (a.will_complete) a.will_complete[i] = 0;
-    return;
-  }
-  // duplicate ids in one batch are an error in the reference (utils.py:173-176): the first occurrence stamps the
-  // env's slot, a later one finds this call's stamp there -- O(1) per row instead of an O(n) scan; a duplicate row is
-  // masked out like an invalid one (two rows updating one env's tables would race)
-  if (atomicExch(a.stamp_tab + e, stamp) == stamp) {
-    atomicOr(a.error_flag, 2);
-    a.reset_mask[i] = 0; a.prev_actions[i] = 0; a.ids_safe[i] = e; a.valid[i] = 0;
-    if (a.will_complete) a.will_complete[i] = 0;
-    return;
-  }
-  a.ids_safe[i] = e; a.valid[i] = 1;
-  const long long prev_run = a.run_ids_tab[e];
-  const long long run = a.run_ids[i];
-  a.run_ids_tab[e] = run;                                              // learner.py:354
-  const bool reset = prev_run != run;                                  // :355-357
-  long long frames = a.info_frames[e];
-  float ret = a.info_return[e], raw = a.info_raw_return[e];
-  long long act = a.actions_tab[e];
-  if (reset) {                                                         // :360-366
-    frames = 0; ret = 0.f; raw = 0.f; act = 0;
-    a.store_index[e] = 0;                                              // UnrollStore.reset, overlap 0 (utils.py:207)
-    a.actions_tab[e] = 0;
-  }
-  ret += a.reward[i]; raw += a.raw_reward[i];                          // :373
-  if (a.done[i]) {                                                     // :374-377: report + reset the episode stats
-    const int slot = atomicAdd(a.stats_count, 1);
-    if (slot < a.stats_capacity) {
-      a.episode_stats[3 * slot + 0] = (float)frames;
-      a.episode_stats[3 * slot + 1] = ret;
-      a.episode_stats[3 * slot + 2] = raw;
+  if (threadIdx.x == 0) *a.call_counter = stamp;
+  for (int i = threadIdx.x; i < a.n; i += 1024) {            // rows are independent: batches above 1024 rows just loop
+    const long long e = a.env_ids[i];
+    if (e < 0 || e >= a.num_envs) {
+      // the reference raises (tf scatter / gather out of range); here the row is masked out of EVERY table access of
+      // the step (valid = 0, ids_safe = 0 keeps reads in range) and the error is flagged
+      atomicOr(a.error_flag, 1);
+      a.reset_mask[i] = 0; a.prev_actions[i] = 0; a.ids_safe[i] = 0; a.valid[i] = 0;
+      if (a.will_complete) a.will_complete[i] = 0;
+      continue;
     }
-    frames = 0; ret = 0.f; raw = 0.f;
+    // duplicate ids in one batch are an error in the reference (utils.py:173-176): the first occurrence stamps the
+    // env's slot, a later one finds this call's stamp there -- O(1) per row instead of an O(n) scan; a duplicate row is
+    // masked out like an invalid one (two rows updating one env's tables would race)
+    if (atomicExch(a.stamp_tab + e, stamp) == stamp) {
+      atomicOr(a.error_flag, 2);
+      a.reset_mask[i] = 0; a.prev_actions[i] = 0; a.ids_safe[i] = e; a.valid[i] = 0;
+      if (a.will_complete) a.will_complete[i] = 0;
+      continue;
+    }
+    a.ids_safe[i] = e; a.valid[i] = 1;
+    const long long prev_run = a.run_ids_tab[e];
+    const long long run = a.run_ids[i];
+    a.run_ids_tab[e] = run;                                              // learner.py:354
+    const bool reset = prev_run != run;                                  // :355-357
+    long long frames = a.info_frames[e];
+    float ret = a.info_return[e], raw = a.info_raw_return[e];
+    long long act = a.actions_tab[e];
+    if (reset) {                                                         // :360-366
+      frames = 0; ret = 0.f; raw = 0.f; act = 0;
+      a.store_index[e] = 0;                                              // UnrollStore.reset, overlap 0 (utils.py:207)
+      a.actions_tab[e] = 0;
+    }
+    ret += a.reward[i]; raw += a.raw_reward[i];                          // :373
+    if (a.done[i]) {                                                     // :374-377: report + reset the episode stats
+      const int slot = atomicAdd(a.stats_count, 1);
+      if (slot < a.stats_capacity) {
+        a.episode_stats[3 * slot + 0] = (float)frames;
+        a.episode_stats[3 * slot + 1] = ret;
+        a.episode_stats[3 * slot + 2] = raw;
+      }
+      frames = 0; ret = 0.f; raw = 0.f;
+    }
+    frames += a.num_action_repeats;                                      // :378
+    a.info_frames[e] = frames; a.info_return[e] = ret; a.info_raw_return[e] = raw;
+    a.reset_mask[i] = reset ? 1 : 0;
+    a.prev_actions[i] = act;                                             // :381
+    // the unroll of env e completes with this step iff its (possibly just reset) write index is the last row: known
+    // BEFORE the agent runs, so the previous agent state of exactly those envs can be set aside (learner.py:398-399)
+    if (a.will_complete) a.will_complete[i] = (a.store_index[e] + 1 == a.full_length) ? 1 : 0;
   }
-  frames += a.num_action_repeats;                                      // :378
-  a.info_frames[e] = frames; a.info_return[e] = ret; a.info_raw_return[e] = raw;
-  a.reset_mask[i] = reset ? 1 : 0;
-  a.prev_actions[i] = act;                                             // :381
-  // the unroll of env e completes with this step iff its (possibly just reset) write index is the last row: known
-  // BEFORE the agent runs, so the previous agent state of exactly those envs can be set aside (learner.py:398-399)
-  if (a.will_complete) a.will_complete[i] = (a.store_index[e] + 1 == a.full_length) ? 1 : 0;
 }
 
 struct PostArgs {
@@ -111,76 +113,78 @@ struct PostArgs {
 
 __global__ void __launch_bounds__(1024)
 inference_post_kernel(PostArgs a) {
-  __shared__ int s_scan[1024];
+  __shared__ int s_wave[16];                                           // per-wave totals of the chunk being scanned
   __shared__ int s_base, s_start;
-  const int i = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L = a.full_length, E = a.num_envs;
-  long long e = 0;
-  int done = 0;
-  bool ok_row = false;
   unsigned long long seed = 0, call = 0;
   if (a.logits) { seed = a.rng[0]; call = a.rng[1]; }
-  if (i < a.n) {
-    e = a.env_ids[i];
-    ok_row = a.valid ? a.valid[i] != 0 : (e >= 0 && e < E);
-    if (!ok_row) e = 0;
-    long long act;
-    if (a.logits) {                                                    // dmlab/networks.py:122 (sample in the head)
-      act = seedhip::sample_categorical_row(a.logits + (long long)i * a.logits_ld, a.num_actions, seed, call, (unsigned)i);
-      a.actions[i] = act;
-    } else {
-      act = a.actions[i];
-    }
-    if (ok_row) {
-      const long long idx = a.store_index[e];
-      a.append_rows[i] = idx * E + e;
-      done = (idx + 1 == L) ? 1 : 0;
-      if (idx + 1 > L) atomicOr(a.error_flag, 4);
-      a.store_index[e] = done ? 1 : idx + 1;                           // utils.py:194, 254-255 (overlap 0)
-      a.actions_tab[e] = act;                                          // learner.py:403
-    } else {
-      a.append_rows[i] = 0;
-    }
-    a.last_rows[i] = (long long)(L - 1) * E + e;
-  }
-  // inclusive scan of `done` over the batch (order of env_ids, like tf.gather(env_ids, tf.where(...)))
-  s_scan[i] = done;
+  if (tid == 0) { s_base = *a.batch_count; s_start = a.batch_start ? *a.batch_start : 0; }
   __syncthreads();
-  if (a.logits && i == 0) a.rng[1] = call + 1;                         // every thread has read the counter
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int v = (i >= off) ? s_scan[i - off] : 0;
+  if (a.logits && tid == 0) a.rng[1] = call + 1;                       // every thread has read the counter
+  const int base = s_base, start = s_start;
+  int running = 0;                                                     // completions in the chunks before this one (uniform)
+  // 1024 rows per pass; the position of a completed unroll in the batch is its rank in env_ids order (like
+  // tf.gather(env_ids, tf.where(...))): wave-level inclusive scan + the totals of the waves / chunks before
+  for (int c0 = 0; c0 < a.n; c0 += 1024) {
+    const int i = c0 + tid;
+    long long e = 0;
+    int done = 0;
+    bool ok_row = false;
+    if (i < a.n) {
+      e = a.env_ids[i];
+      ok_row = a.valid ? a.valid[i] != 0 : (e >= 0 && e < E);
+      if (!ok_row) e = 0;
+      long long act;
+      if (a.logits) {                                                  // dmlab/networks.py:122 (sample in the head)
+        act = seedhip::sample_categorical_row(a.logits + (long long)i * a.logits_ld, a.num_actions, seed, call, (unsigned)i);
+        a.actions[i] = act;
+      } else {
+        act = a.actions[i];
+      }
+      if (ok_row) {
+        const long long idx = a.store_index[e];
+        a.append_rows[i] = idx * E + e;
+        done = (idx + 1 == L) ? 1 : 0;
+        if (idx + 1 > L) atomicOr(a.error_flag, 4);
+        a.store_index[e] = done ? 1 : idx + 1;                         // utils.py:194, 254-255 (overlap 0)
+        a.actions_tab[e] = act;                                        // learner.py:403
+      } else {
+        a.append_rows[i] = 0;
+      }
+      a.last_rows[i] = (long long)(L - 1) * E + e;
+    }
+    const unsigned long long votes = __ballot(done);
+    const int in_wave = __popcll(votes & ((2ull << lane) - 1ull));     // inclusive rank inside the wave
+    if (lane == 0) s_wave[wave] = __popcll(votes);
     __syncthreads();
-    s_scan[i] += v;
-    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int v = s_wave[w]; total += v; if (w < wave) before += v; }
+    __syncthreads();                                                   // s_wave is rewritten by the next chunk
+    if (i < a.n) {
+      const int rank = running + before + in_wave - done;              // among the completions of the whole batch
+      const int pos = base + rank;                                     // position in the batch, counted from its head
+      // a completed unroll that finds the training batch full is dropped (flag 8) but its last step is STILL carried
+      // to slot 0, so the env's next unroll starts from a consistent state
+      const bool ok = done && pos < a.batch_capacity;
+      int col = start + pos;                                           // the batch is a ring of columns
+      if (col >= a.batch_capacity) col -= a.batch_capacity;
+      a.complete[i] = ok ? 1 : 0;
+      a.carry[i] = done ? 1 : 0;
+      a.batch_cols[i] = ok ? col : 0;
+      if (ok) {                                                        // rank among the accepted completions
+        a.emit_env[rank] = e;
+        a.emit_col[rank] = col;
+      }
+    }
+    running += total;
   }
-  if (i == 0) {
-    const int total = s_scan[1023];
-    const int base = *a.batch_count;
-    s_base = base;
-    s_start = a.batch_start ? *a.batch_start : 0;
+  if (tid == 0) {
+    const int total = running;
     *a.batch_count = base + total > a.batch_capacity ? a.batch_capacity : base + total;
     if (base + total > a.batch_capacity) atomicOr(a.error_flag, 8);
-  }
-  __syncthreads();
-  if (i < a.n) {
-    const int pos = s_base + s_scan[i] - done;                         // position in the batch, counted from its head
-    // a completed unroll that finds the training batch full is dropped (flag 8) but its last step is STILL carried
-    // to slot 0, so the env's next unroll starts from a consistent state
-    const bool ok = done && pos < a.batch_capacity;
-    int col = s_start + pos;                                           // the batch is a ring of columns
-    if (col >= a.batch_capacity) col -= a.batch_capacity;
-    a.complete[i] = ok ? 1 : 0;
-    a.carry[i] = done ? 1 : 0;
-    a.batch_cols[i] = ok ? col : 0;
-    if (ok) {                                                          // rank among the accepted completions
-      const int r = pos - s_base;
-      a.emit_env[r] = e;
-      a.emit_col[r] = col;
-    }
-  }
-  if (i == 0) {
-    const int total = s_scan[1023];
-    const int room = a.batch_capacity - s_base;
+    const int room = a.batch_capacity - base;
     *a.emit_count = total < room ? total : (room > 0 ? room : 0);
   }
 }
@@ -371,7 +375,7 @@ extern "C" int seedhip_inference_pre(const long long* env_ids, const long long* 
                                      float* episode_stats, int stats_capacity, int* stats_count, int* error_flag,
                                      long long* ids_safe, uint8_t* valid, int* stamp_table, int* call_counter,
                                      uint8_t* will_complete, int full_length, void* stream) {
-  SEEDHIP_REQUIRE(n >= 1 && n <= 1024 && num_envs >= 1, "inference_pre: need 1 <= n <= 1024");
+  SEEDHIP_REQUIRE(n >= 1 && n <= kMaxInferenceRows && num_envs >= 1, "inference_pre: need 1 <= n <= %d", kMaxInferenceRows);
   SEEDHIP_REQUIRE(env_ids && run_ids && reward && raw_reward && done && run_ids_table && info_frames && info_return &&
                   info_raw_return && actions_table && store_index && reset_mask && prev_actions && episode_stats &&
                   stats_count && error_flag && ids_safe && valid && stamp_table && call_counter,
@@ -392,7 +396,7 @@ extern "C" int seedhip_inference_post(const long long* env_ids, const uint8_t* v
                                       uint8_t* complete, uint8_t* carry, long long* batch_cols, long long* emit_env,
                                       long long* emit_col, int* emit_count, long long* last_rows,
                                       int* error_flag, const int* batch_start, void* stream) {
-  SEEDHIP_REQUIRE(n >= 1 && n <= 1024 && num_envs >= 1 && full_length >= 2 && batch_capacity >= 1,
+  SEEDHIP_REQUIRE(n >= 1 && n <= kMaxInferenceRows && num_envs >= 1 && full_length >= 2 && batch_capacity >= 1,
                   "inference_post: bad sizes");
   SEEDHIP_REQUIRE(env_ids && actions && store_index && actions_table && batch_count && append_rows && complete &&
                   carry && batch_cols && emit_env && emit_col && emit_count && last_rows && error_flag,

@@ -208,6 +208,73 @@ def test_fused_inference_matches_reference_structured_inference(device, kind, gr
   assert got == ref_stats and ns > 0
 
 
+def test_fused_inference_batches_above_1024_rows(device):
+  """Inference batches of 1300 rows (inference_pre / inference_post walk them in 1024-row chunks; the rank of a
+  completed unroll in the training batch is its rank in env_ids order ACROSS chunks): same actions, same completed
+  unrolls in the same order, same episode statistics as the op-by-op mirror, with restarts that put the envs' unroll
+  phases out of step so that completions fall in both chunks of every batch."""
+  from seed_rl_amd import inference, networks, utils
+  from seed_rl_amd.unroll_store import Spec
+  T, n, A = 2, 1300, 6
+  E = 2 * n
+  obs_shape = (84, 84, 1)
+  mk = lambda: networks.AtariShallow(A, device=device, seed=0)
+  env_specs = utils.EnvOutput(Spec((), torch.float32), Spec((), torch.bool), Spec(obs_shape, torch.uint8),
+                              Spec((), torch.bool), Spec((), torch.int32))
+  ao_specs = networks.AgentOutput(Spec((), torch.int64), Spec((A,), torch.float32), Spec((), torch.float32))
+
+  def drive(call):
+    rng = np.random.default_rng(7)
+    torch.manual_seed(5)
+    run_ids = np.full(E, 1000, np.int64)
+    acts = []
+    for step in range(7):
+      if step in (2, 3):                                         # a third of the actors restart: their unrolls re-phase
+        who = rng.uniform(size=E) < 0.33
+        run_ids[who] += step
+      perm = rng.permutation(E)
+      for ids in (perm[:n], perm[n:]):
+        done = rng.uniform(size=n) < (0.0 if step == 0 else 0.2)
+        env = utils.EnvOutput(
+            reward=torch.tensor(rng.normal(size=n).astype(np.float32), device=device),
+            done=torch.tensor(done, device=device),
+            observation=torch.tensor(rng.integers(0, 256, (n,) + obs_shape).astype(np.uint8), device=device),
+            abandoned=torch.zeros(n, dtype=torch.bool, device=device),
+            episode_step=torch.full((n,), step, dtype=torch.int32, device=device))
+        raw = torch.tensor(rng.normal(size=n).astype(np.float32), device=device)
+        acts.append(call(torch.tensor(ids, dtype=torch.int32), torch.tensor(run_ids[ids]), env, raw).clone())
+    return acts
+
+  unrolls, infos = [], []
+  ref = inference.InferenceState(mk(), E, T, env_specs, ao_specs, Spec((), torch.int64), device=device,
+                                 unroll_sink=unrolls.append, info_sink=infos.append)
+  acts_ref = drive(ref.inference)
+  fused = inference.FusedInferenceState(mk(), E, T, env_specs, ao_specs, batch_capacity=4 * E, device=device)
+  acts = drive(fused.graphed(n, obs_shape))
+  fused.check_errors()
+  for a, b in zip(acts, acts_ref):
+    assert torch.equal(a, b)
+  k, batch = fused.take_batch()
+  per_call = [int(u.env_outputs.done.shape[1]) for u in unrolls]
+  assert k == sum(per_call) and k > E and max(per_call) > 300       # completions well inside the second chunk too
+  cat = lambda xs, dim: torch.cat(xs, dim)
+  for name in ('prev_actions', 'env_outputs', 'agent_outputs'):
+    ref_f = utils.map_structure(lambda *xs: cat(list(xs), 1), *[getattr(u, name) for u in unrolls])
+    for a, b in zip(utils.flatten(ref_f), utils.flatten(getattr(batch, name))):
+      if a.dtype.is_floating_point and name == 'agent_outputs':      # two agent instances: same weights, same kernels
+        assert torch.equal(a, b), name
+      else:
+        assert torch.equal(a.to(b.dtype), b), name
+  ref_first = utils.map_structure(lambda *xs: cat(list(xs), 0), *[u.agent_state for u in unrolls])
+  for a, b in zip(utils.flatten(ref_first), utils.flatten(batch.agent_state)):
+    assert torch.equal(a, b)
+  ref_stats = sorted((int(f), round(float(r), 5), round(float(w), 5)) for i in infos
+                     for f, r, w in zip(i.episode_num_frames.tolist(), i.episode_returns.tolist(), i.episode_raw_returns.tolist()))
+  ns = int(fused.stats_count[0])
+  got = sorted((int(f), round(float(r), 5), round(float(w), 5)) for f, r, w in fused.episode_stats[:ns].tolist())
+  assert got == ref_stats and ns > 100
+
+
 def test_categorical_sample_kernel(device):
   """seedhip_categorical_sample: frequencies follow softmax(logits) (chi-square over 2e5 draws, A = 18), the sample is
   a pure function of (seed, counter, row), and strided head rows are read in place."""
