@@ -424,7 +424,10 @@ __device__ __forceinline__ void band_prologue16(const Params& p, unsigned char* 
 // EXP (tools/probes/stack_probe.hip only; the library instantiates EXP = 0): leave one ingredient out -- 1 no MFMAs,
 // 2 no global band prefetch after the prologue, 4 no output stores, 8 no LDS pixel reads (one fragment reused),
 // 16 no band conversion / LDS store.
-template <int EXP, bool BITS = false>                  // BITS: also write the ReLU byte mask (Params::relu_bits)
+// BITS: also write the ReLU byte mask (Params::relu_bits).  RELU: the output activation as a template parameter -- a
+// run-time `if (p.out_relu)` is a branch per output tile, and every branch in the epilogue is a basic-block boundary the
+// scheduler cannot move the stores / the next frame's work across (an untaken one around the byte store cost 20 us).
+template <int EXP, bool BITS = false, bool RELU = true>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
 stackconv_fwd_bf16r_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -495,9 +498,15 @@ stackconv_fwd_bf16r_kernel(const Params p) {
         Frag8 xf[kMT];
 #pragma unroll
         for (int m = 0; m < kMT; ++m) {
-          const uint2* src = reinterpret_cast<const uint2*>(base + ((EXP & 8) ? aoff[0] : aoff[m]));
+          // two 8-byte reads with their own 16-bit immediate offsets: merged into one ds_read2_b64 (8-bit offsets in
+          // units of 8 bytes) every fragment costs a v_add for its base -- 60 VALU instructions per 120 MFMAs
+          typedef __attribute__((address_space(3))) const volatile unsigned long long lds_cv64_t;
+          lds_cv64_t* src = (lds_cv64_t*)(base + ((EXP & 8) ? aoff[0] : aoff[m]));
           if ((EXP & 8) && (m > 0 || G > 0)) xf[m].u = make_uint4(t, G, m, lane);
-          else { const uint2 x0 = src[0], x1 = src[1]; xf[m].u = make_uint4(x0.x, x0.y, x1.x, x1.y); }
+          else {
+            const unsigned long long x0 = src[0], x1 = src[1];
+            xf[m].u = make_uint4((unsigned)x0, (unsigned)(x0 >> 32), (unsigned)x1, (unsigned)(x1 >> 32));
+          }
         }
         if (EXP & 1) {
 #pragma unroll
@@ -522,8 +531,9 @@ stackconv_fwd_bf16r_kernel(const Params p) {
       for (int m = 0; m < kMT; ++m) {
         const int pix = wave * 80 + m * 16 + j;
         f32x4_t v = acc[m] + bias4;
-        if (p.out_relu) {
-          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        if (RELU) {                                    // one v_med3 each (fmaxf is two: it first quiets its operand)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], 0.f, __builtin_inff());
         }
         float* o = p.out + (((long long)t * p.B + b) * 400 + pix) * p.ld_out + co0 + 4 * kq;
         if (EXP & 4) asm volatile("" :: "v"(v));
@@ -929,14 +939,16 @@ int launch_fwd(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, cons
     const size_t lds = (size_t)kGroups * 64 * 16 + (size_t)kWaves * kWaveRing16;
     int grid;
     decompose(p.T1, p.B, max_grid_for(2), &p.spc, &p.items, &grid);
-    if (relu_bits) {
-      (void)hipFuncSetAttribute((const void*)stackconv_fwd_bf16r_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((stackconv_fwd_bf16r_kernel<0, true>), dim3(grid, 1, g->cout / 16), dim3(kThreads), lds, s, p);
-      return check_launch("stackconv_fwd_bf16r_kernel(byte mask)");
+#define SEEDHIP_SCF(BITS_, RELU_)                                                                                 \
+    {                                                                                                             \
+      (void)hipFuncSetAttribute((const void*)stackconv_fwd_bf16r_kernel<0, BITS_, RELU_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((stackconv_fwd_bf16r_kernel<0, BITS_, RELU_>), dim3(grid, 1, g->cout / 16), dim3(kThreads), lds, s, p); \
+      return check_launch("stackconv_fwd_bf16r_kernel");                                                          \
     }
-    (void)hipFuncSetAttribute((const void*)stackconv_fwd_bf16r_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(stackconv_fwd_bf16r_kernel<0>, dim3(grid, 1, g->cout / 16), dim3(kThreads), lds, s, p);
-    return check_launch("stackconv_fwd_bf16r_kernel");
+    if (relu_bits) SEEDHIP_SCF(true, true)
+    if (out_relu) SEEDHIP_SCF(false, true)
+    SEEDHIP_SCF(false, false)
+#undef SEEDHIP_SCF
   }
   const size_t lds = kWFloats * sizeof(float) + (size_t)kWaves * kWaveRing;
   const int per_cu = (int)((160 * 1024) / lds) < 3 ? (int)((160 * 1024) / lds) : 3;

@@ -328,10 +328,10 @@ def bind_inference(server, fused_states, inference_batch_size, observation_shape
   stream.  2 (default): the copies of batch i+1 go to a copy stream while the graph of batch i runs, the two streams
   ordered by HOST waits of the submitting thread -- device-side cross-stream waits in front of the graph launches stalled
   that thread for the whole copy (1.30 M env-steps/s against 2.0 M on one stream and 2.2-2.26 M host-ordered, learner
-  training alongside on MI355X / ROCm 7: tools/bench_serving.py).  >= 3: the compute thread additionally stages batch
-  i+1 BEFORE it launches batch i whenever batch i+1 is already queued (NativeServer._compute_loop), taking the PCIe
-  copy off the submitting thread's critical path; measured equal to 2 (2.73-2.78 M vs 2.76-2.80 M at 4 / 8 / 16
-  groups of 1024 envs) because with the train step alongside the DEVICE is the bound (94 % busy), not that thread."""
+  training alongside on MI355X / ROCm 7: tools/bench_serving.py).  >= 3 (LearnerServer's default): the compute thread
+  additionally stages batch i+1 BEFORE it launches batch i whenever batch i+1 is already queued
+  (NativeServer._compute_loop), taking the PCIe copy off the submitting thread's critical path: equal to 2 up to
+  2 048-row batches (the device is the bound there), 2.9 -> 3.6 M env-steps/s at 4 096 rows (28.9 MB per copy)."""
   import torch
   from seed_rl_amd import inference as inf
   n = inference_batch_size

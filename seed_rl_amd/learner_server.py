@@ -79,7 +79,7 @@ class LearnerServer(object):
 
   def __init__(self, agent, learner, unroll_length, batch_size, inference_batch_size, num_envs, observation_shape,
                server_addresses, observation_dtype=torch.uint8, device='cuda', graphed=True, batch_capacity=None,
-               transport='native', num_unroll_slots=2, num_io_threads=None, inference_slots=4, inference_pipeline=2):
+               transport='native', num_unroll_slots=2, num_io_threads=None, inference_slots=4, inference_pipeline=3):
     self.agent, self.learner = agent, learner
     self.T, self.B, self.n = unroll_length, batch_size, inference_batch_size
     self.device = dev = torch.device(device)
