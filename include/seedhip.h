@@ -212,6 +212,18 @@ int seedhip_conv2d_stack_fwd_bits(const seedhip_stack_conv_geom* geom, const uin
 int seedhip_conv2d_bwd_data_bits_supported(const seedhip_conv_geom* geom);
 int seedhip_conv2d_bwd_data_bits(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
                                  const uint8_t* relu_bits, void* stream);
+/* First conv's weight gradient FUSED with the second conv's data gradient (r3; shallow Atari torso Conv 8x8/4 x16 ->
+ * ReLU -> Conv 4x4/2 x32): dw0 / dbias0 = seedhip_conv2d_stack_bwd_weight(g0, .., dy = relu_mask(act0) *
+ * seedhip_conv2d_bwd_data(g1, dy1, w1)) without ever writing that dy -- a workgroup computes each frame's data gradient
+ * from conv1's dy1 [T * B, 9, 9, 32] in LDS, masks it with act0 [T * B, 400, 16] > 0, splits it and feeds the weight
+ * gradient.  Equal to the two-call path up to fp32 summation order.  Served for exactly that pair of geometries
+ * (*_supported: 1 / 0); workspace from *_workspace_bytes; 16-byte aligned operands. */
+int seedhip_conv2d_stack_bwd_weight_fused_supported(const seedhip_stack_conv_geom* g0, const seedhip_conv_geom* g1);
+size_t seedhip_conv2d_stack_bwd_weight_fused_workspace_bytes(const seedhip_stack_conv_geom* g0);
+int seedhip_conv2d_stack_bwd_weight_fused(const seedhip_stack_conv_geom* g0, const seedhip_conv_geom* g1,
+                                          const uint8_t* frames_ext, const uint8_t* nvalid, const float* act0,
+                                          const float* dy1, const float* w1, float* dw0, float* dbias0,
+                                          void* workspace, size_t workspace_bytes, void* stream);
 size_t seedhip_conv2d_stack_bwd_weight_workspace_bytes(const seedhip_stack_conv_geom* geom);
 int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* geom, const uint8_t* frames_ext,
                                     const uint8_t* nvalid, const float* dy, float* dw, float* dbias,

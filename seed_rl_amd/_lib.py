@@ -79,6 +79,10 @@ SIGNATURES = {
     'seedhip_conv2d_bwd_weight':
         (c_int, [ctypes.POINTER(ConvGeom), P, c_int, c_int, P, P, P, P, c_size_t, P]),
     'seedhip_conv2d_stack_fwd': (c_int, [ctypes.POINTER(StackConvGeom), P, P, P, P, P, c_int, P]),
+    'seedhip_conv2d_stack_bwd_weight_fused_supported': (c_int, [ctypes.POINTER(StackConvGeom), ctypes.POINTER(ConvGeom)]),
+    'seedhip_conv2d_stack_bwd_weight_fused_workspace_bytes': (c_size_t, [ctypes.POINTER(StackConvGeom)]),
+    'seedhip_conv2d_stack_bwd_weight_fused': (c_int, [ctypes.POINTER(StackConvGeom), ctypes.POINTER(ConvGeom), P, P, P, P, P, P, P,
+                                              P, c_size_t, P]),
     'seedhip_conv2d_stack_fwd_bits_supported': (c_int, [ctypes.POINTER(StackConvGeom)]),
     'seedhip_conv2d_stack_fwd_bits': (c_int, [ctypes.POINTER(StackConvGeom), P, P, P, P, P, P, P]),
     'seedhip_conv2d_bwd_data_bits_supported': (c_int, [ctypes.POINTER(ConvGeom)]),

@@ -32,6 +32,7 @@ AgentOutput = collections.namedtuple('AgentOutput', 'action policy_logits baseli
 # (restarted actor); valid_mask[b] == 0: the row is not written back.  Passed by inference.FusedInferenceState.
 IndexedFrameState = collections.namedtuple('IndexedFrameState', 'table rows zero_mask valid_mask')
 _RELU_BITS = os.environ.get('SEEDHIP_RELU_BITS', '0') == '1'      # A/B knob, see _AtariTorso._torso_fwd
+_FUSE01 = os.environ.get('SEEDHIP_FUSE01', '0') == '1'            # A/B knob, see _AtariTorso._torso_bwd
 AgentState = collections.namedtuple('AgentState', 'core_state frame_stacking_state')
 
 
@@ -510,6 +511,14 @@ class _AtariTorso(object):
     for i in range(len(acts) - 1, 0, -1):
       g, a_in = geoms[i], acts[i - 1]
       ops.conv2d_bwd_weight(g, a_in, da, fl.g('%sconv%d/kernel' % (tp, i)), fl.g('%sconv%d/bias' % (tp, i)), wsb)
+      if i == 1 and _FUSE01 and ops.conv2d_stack_bwd_weight_fused_supported(geoms[0], g):
+        # shallow torso: the second conv's data gradient exists only to feed the first conv's weight gradient -- one
+        # kernel computes it per frame in LDS and consumes it there (d_act0 is never written)
+        ws0 = self._buf('stack_ws', (ops.conv2d_stack_bwd_weight_fused_workspace_bytes(geoms[0]) // 4 + 4,))
+        ops.conv2d_stack_bwd_weight_fused(geoms[0], g, ctx['ext'], ctx['nvalid'], a_in, da, fl.p('%sconv%d/kernel' % (tp, i)),
+                                          fl.g(tp + 'conv0/kernel'), fl.g(tp + 'conv0/bias'), ws0)
+        self._grads_ready_from(None, upto=tp + 'fc/kernel')
+        return
       d_in = self._buf('d_act%d' % (i - 1), tuple(a_in.shape))
       if i == 1 and ctx.get('bits0') is not None:
         ops.conv2d_bwd_data(g, da, fl.p('%sconv%d/kernel' % (tp, i)), d_in, relu_bits=ctx['bits0'])

@@ -264,6 +264,28 @@ def conv2d_stack_bwd_weight(g, frames_ext, nvalid, dy, dw, dbias, workspace):
           'seedhip_conv2d_stack_bwd_weight')
 
 
+def conv2d_stack_bwd_weight_fused_supported(g0, g1):
+  """The first conv's weight gradient can be fused with the second conv's data gradient for this pair of geometries."""
+  return bool(_lib.lib().seedhip_conv2d_stack_bwd_weight_fused_supported(ctypes.byref(g0), ctypes.byref(g1)))
+
+
+def conv2d_stack_bwd_weight_fused_workspace_bytes(g0):
+  return int(_lib.lib().seedhip_conv2d_stack_bwd_weight_fused_workspace_bytes(ctypes.byref(g0)))
+
+
+def conv2d_stack_bwd_weight_fused(g0, g1, frames_ext, nvalid, act0, dy1, w1, dw0, dbias0, workspace):
+  """dw0 / dbias0 of the first conv from the SECOND conv's output gradient dy1: its data gradient, the ReLU mask (act0 > 0)
+  and the weight gradient in one kernel (seedhip.h); flops / bytes of both folded kernels."""
+  flops = 2.0 * g0.T * g0.B * g0.oh * g0.ow * g0.cout * g0.kh * g0.kw * 4 + _conv_cost(g1)[0]
+  nbytes = g0.T * g0.B * (g0.ih * g0.iw + g0.oh * g0.ow * g0.cout * 4 + g1.oh * g1.ow * g1.cout * 4)
+  with _region('stack_conv_wgrad_fused', flops, nbytes):
+    with _dev(dw0):
+      _lib.check(_lib.lib().seedhip_conv2d_stack_bwd_weight_fused(
+          ctypes.byref(g0), ctypes.byref(g1), _lib.ptr(frames_ext), _lib.ptr(nvalid), _lib.ptr(act0), _lib.ptr(dy1),
+          _lib.ptr(w1), _lib.ptr(dw0), _lib.ptr(dbias0), _lib.ptr(workspace),
+          workspace.numel() * workspace.element_size(), _lib.stream()), 'seedhip_conv2d_stack_bwd_weight_fused')
+
+
 def impala_loss_workspace_bytes(T, B):
   return int(_lib.lib().seedhip_impala_loss_workspace_bytes(T, B))
 
