@@ -65,6 +65,16 @@ struct Params {
 
 __device__ __forceinline__ float ubyte(uint32_t w, int q) { return (float)((w >> (8 * q)) & 0xFFu); }
 
+// nvalid[idx] through the SCALAR data cache (constant address space, uniform address -> s_load_dword): a vector load
+// here is waited for with s_waitcnt vmcnt(0) at the head of the time loop, and that counter also holds the previous
+// step's output stores and the band prefetch -- every wave would sit out their latency before its first MFMA.
+__device__ __forceinline__ int nvalid_at(const uint8_t* nvalid, long long idx) {
+  typedef __attribute__((address_space(4))) const uint32_t cu32_t;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(nvalid) + (uintptr_t)idx;
+  const uint32_t w = *reinterpret_cast<cu32_t*>(a & ~(uintptr_t)3);      // the aligned word around the byte
+  return (int)((w >> (8 * (unsigned)(a & 3))) & 0xFFu);
+}
+
 // Geometry of the specialised path: 84x84 frames, 8x8 stride-4 VALID -> 20x20 outputs.  Wave w of a workgroup owns
 // output rows 4w..4w+3 (80 pixels = 5 MFMA tiles / 20 four-pixel groups), which depend on input rows 16w..16w+19
 // only.  Each wave keeps ITS band of the last 4 frames in its own LDS ring and walks time on its own: the t loop has
@@ -479,18 +489,12 @@ stackconv_fwd_bf16r_kernel(const Params p) {
     const int t0 = chunk * p.spc;
     const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
     band_prologue16(p, myring, b, t0, wave, lane);
-    // nvalid of step t is requested during step t - 1: read behind the band prefetch it would make this wave wait for
-    // that prefetch (memory operations retire in order) before its first MFMA of every step
-    int nv_next = p.nvalid[(long long)t0 * p.B + b];
     for (int t = t0; t < t1; ++t) {
       const bool more = t + 1 < t1;
-      int nv_v = nv_next;                               // stays in a VGPR until here: the wait for it belongs HERE, not
-      asm volatile("" : "+v"(nv_v));                    // behind the load (where the compiler would move it to an SGPR)
-      const int nv = __builtin_amdgcn_readfirstlane(nv_v);
+      const int nv = nvalid_at(p.nvalid, (long long)t * p.B + b);
       BandPrefetch pf;
       if (EXP & 2) { pf.v0 = make_uint4(lane, t, 3, 4); pf.v1 = pf.v0; }
       else if (more) pf = band_load(band_src(p, t + 4, b, wave), lane);
-      if (more) nv_next = p.nvalid[(long long)(t + 1) * p.B + b];
       f32x4_t acc[kMT];
 #pragma unroll
       for (int m = 0; m < kMT; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -754,16 +758,12 @@ stackconv_wgrad_cp_kernel(const Params p) {
       for (int idx = tid; idx < kVec; idx += 64 * kCW) frame_store16(smem + ((t0 + e) % kFrameSlots) * kFrame16, src[idx], idx);
     }
     __syncthreads();
-    int nv_next = p.nvalid[(long long)t0 * p.B + b];      // requested a step ahead (see stackconv_fwd_bf16r_kernel)
     for (int t = t0; t < t1; ++t) {
       const bool more = t + 1 < t1;
-      int nv_v = nv_next;                               // stays in a VGPR until here: the wait for it belongs HERE, not
-      asm volatile("" : "+v"(nv_v));                    // behind the load (where the compiler would move it to an SGPR)
-      const int nv = __builtin_amdgcn_readfirstlane(nv_v);
+      const int nv = nvalid_at(p.nvalid, (long long)t * p.B + b);
       uint4 pf = make_uint4(0, 0, 0, 0);                  // 441 vectors over 512 threads: one each
       if (more && tid < kVec)
         pf = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t + 4) * p.B + b) * p.fsz)[tid];
-      if (more) nv_next = p.nvalid[(long long)(t + 1) * p.B + b];
       if (2 * cp < nv) {
         const bool two = 2 * cp + 1 < nv;                   // the pair's second channel is inside the episode too
         const unsigned char* frame0 = smem + ((t + 3 - 2 * cp) % kFrameSlots) * kFrame16;
@@ -1039,19 +1039,15 @@ stackconv_wgrad_fused_kernel(const FusedParams p) {
         *reinterpret_cast<uint4*>(ybytes + (idx >> 3) * (kYStride * 4) + (idx & 7) * 16) = ysrc[idx];
     }
     __syncthreads();
-    int nv_next = p.nvalid[(long long)t0 * p.B + b];      // requested a step ahead (see stackconv_fwd_bf16r_kernel)
     for (int t = t0; t < t1; ++t) {
       const bool more = t + 1 < t1;
-      int nv_v = nv_next;                               // stays in a VGPR until here: the wait for it belongs HERE, not
-      asm volatile("" : "+v"(nv_v));                    // behind the load (where the compiler would move it to an SGPR)
-      const int nv = __builtin_amdgcn_readfirstlane(nv_v);
+      const int nv = nvalid_at(p.nvalid, (long long)t * p.B + b);
       uint4 pf = make_uint4(0, 0, 0, 0), py0 = pf, py1 = pf;
       if (more) {                                         // next step's frame and dY: in flight under this step's work
         if (tid < kVec) pf = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t + 4) * p.B + b) * p.fsz)[tid];
         const uint4* ysrc = reinterpret_cast<const uint4*>(p.dy1 + ((long long)(t + 1) * p.B + b) * (81 * 32));
         py0 = ysrc[tid];
         if (tid + 64 * kCW < kYVec) py1 = ysrc[tid + 64 * kCW];
-        nv_next = p.nvalid[(long long)(t + 1) * p.B + b];
       }
       if (nv > 0 && !(EXP & 8)) {
         const float* mask_f = p.act0 + ((long long)t * p.B + b) * (400 * 16);
