@@ -537,6 +537,17 @@ stackconv_fwd_bf16r_kernel(const Params p) {
 #pragma unroll
         for (int G = 0; G < kGroups; ++G) if (G < 2 * nv) group(G);
       }
+      // The next band goes to LDS BEFORE this step's output stores are issued: waiting for the prefetch with stores in
+      // flight is s_waitcnt vmcnt(0) (loads and stores share the counter and do not retire in order with each other), i.e.
+      // the wave would sit out the write latency of stores it has just issued, every step.  Issued after it, the stores
+      // have the whole next step to complete.  (Same-box A/B: 129.8 -> 126.7 us alone, nothing on the step: the other
+      // waves of the SIMD cover most of that wait.)
+      if (more) {
+        wave_lds_fence();                              // this wave's reads of frame t are done (the MFMA operands above)
+        if (EXP & 16) asm volatile("" :: "v"(pf.v0.x), "v"(pf.v0.y), "v"(pf.v0.z), "v"(pf.v0.w), "v"(pf.v1.x), "v"(pf.v1.y), "v"(pf.v1.z), "v"(pf.v1.w));
+        else band_store16(myring + ((t + 4) % kSlots) * kBand16, pf, lane);
+        wave_lds_fence();
+      }
 #pragma unroll
       for (int m = 0; m < kMT; ++m) {
         const int pix = wave * 80 + m * 16 + j;
@@ -552,12 +563,6 @@ stackconv_fwd_bf16r_kernel(const Params p) {
         // reads 1 byte where it read the 16 of the activation (wsgemm.h, ws_tab_kernel<.., BITS>)
         if (BITS)
           p.relu_bits[(o - p.out) >> 2] = (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
-      }
-      if (more) {
-        wave_lds_fence();                              // this wave's reads of frame t are done
-        if (EXP & 16) asm volatile("" :: "v"(pf.v0.x), "v"(pf.v0.y), "v"(pf.v0.z), "v"(pf.v0.w), "v"(pf.v1.x), "v"(pf.v1.y), "v"(pf.v1.z), "v"(pf.v1.w));
-        else band_store16(myring + ((t + 4) % kSlots) * kBand16, pf, lane);
-        wave_lds_fence();
       }
     }
   }
