@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  pylint: disable=unused-import
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libseedhip.so')
+# SEEDHIP_LIB: another build of the same library (same-box A/B runs of two builds; nothing else changes: no fallback)
+LIB_PATH = os.environ.get('SEEDHIP_LIB') or os.path.join(_HERE, 'lib', 'libseedhip.so')
 ABI_VERSION = 3          # include/seedhip.h SEEDHIP_ABI_VERSION this binding was written against
 
 c_int, c_ll, c_float, c_size_t, c_void_p = (

@@ -243,23 +243,29 @@ halo_fwd_kernel(const FwdParams p) {
           ooff[m] = ook[m] ? (uint32_t)((oy * p.OW + ox) * p.ld_out + 4 * kq) * 4u : 0u;   // 0: a safe address for masked lanes
         }
         float4 eA[MT][NT], eB[MT][NT];
+        auto ld_pinned = [](const char* q) { return *reinterpret_cast<const float4*>(q); };
         auto fetch_extras = [&]() {
           if (pA) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt)
-                eA[m][nt] = *reinterpret_cast<const float4*>(a_n + (ch_ok[nt] ? ooff[m] + nt * 64u : 0u));
+                eA[m][nt] = ld_pinned(a_n + (ch_ok[nt] ? ooff[m] + nt * 64u : 0u));
           }
           if (DG && pB) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt)
-                eB[m][nt] = *reinterpret_cast<const float4*>(b_n + (ch_ok[nt] ? ooff[m] + nt * 64u : 0u));
+                eB[m][nt] = ld_pinned(b_n + (ch_ok[nt] ? ooff[m] + nt * 64u : 0u));
           }
         };
-        if constexpr (kPrefetch) fetch_extras();
+        if constexpr (kPrefetch) {
+          fetch_extras();
+          // compiler barrier for memory operations: without it the loads just requested are SUNK to their first use
+          // behind the k loop, and the epilogue waits out a full memory round trip per tile
+          asm volatile("" ::: "memory");
+        }
         f32x4_t acc[MT][NT];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -283,6 +289,11 @@ halo_fwd_kernel(const FwdParams p) {
         }
         // ---- epilogue: lane holds channels nt*16 + 4*kq + {0..3} of pixel (t0+m)*16 + j ----
         if constexpr (!kPrefetch) fetch_extras();
+        // every output is FINISHED (all epilogue operands consumed) before the first store is issued: the stores sit in
+        // predicated blocks, and a block that still needs a prefetched operand while an earlier block's store is in
+        // flight waits with s_waitcnt vmcnt(0) -- loads and stores share the counter and do not retire in order with
+        // each other --, i.e. for that store's write latency: MT * NT - 1 serialised round trips per tile
+        float4 outv[MT][NT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -299,8 +310,16 @@ halo_fwd_kernel(const FwdParams p) {
               }
               if (pB) { v.x += eB[m][nt].x; v.y += eB[m][nt].y; v.z += eB[m][nt].z; v.w += eB[m][nt].w; }
             }
-            if (ook[m] && ch_ok[nt]) *reinterpret_cast<float4*>(out_n + ooff[m] + nt * 64u) = v;
+            // (pinned here: the compiler would otherwise sink the arithmetic back into the predicated store blocks)
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+            outv[m][nt] = v;
           }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            if (ook[m] && ch_ok[nt]) *reinterpret_cast<float4*>(out_n + ooff[m] + nt * 64u) = outv[m][nt];
         }
       }
     }
