@@ -123,8 +123,44 @@ halo_wgrad_kernel(const WgradParams p) {
       dy_goff[u] = pix * p.ld_out + 4 * cq;
     }
   }
+  // The tile prefetch goes through BUFFER loads whose offset is 0x80000000 for cells outside the image / band (the
+  // hardware returns zeros, the tensors are < 2 GB: `bufok`): one unconditional load per register.  The conditional
+  // global loads they replace (`val = 0; if (inside) val = load;`) came out of the compiler as predicated blocks with
+  // register copies behind the load -- and an s_waitcnt vmcnt(0) in front of the copies: the whole prefetch was waited
+  // for where it was issued, in front of the MFMA loop it was meant to hide under.
+  const long long x_bytes = (long long)p.n_img * p.ih * p.iw * p.ld_in * 4, d_bytes = (long long)p.n_img * p.oh * p.ow * p.ld_out * 4;
+  const bool bufok = vec && x_bytes < (1LL << 31) && d_bytes < (1LL << 31);
+  auto mk_view = [](const void* q, long long bytes) {
+    const uint64_t ab = reinterpret_cast<uint64_t>(q);
+    const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(ab >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)ab);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(sb), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t x_view = mk_view(p.in, bufok ? x_bytes : 0), d_view = mk_view(p.dy, bufok ? d_bytes : 0);
+  auto view_ld = [](const __amdgpu_buffer_rsrc_t& r, unsigned byte_off) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
+  };
   auto load_tile = [&](int tile) {
     int n, y0, th; band_of(tile, n, y0, th);
+    if (bufok) {
+      const int nrows = (th - 1) * p.stride + p.kh;
+      const int iy0 = y0 * p.stride - p.pad_t;
+      const unsigned xb = (unsigned)((((long long)n * p.ih + y0 * p.stride) * p.iw * p.ld_in) * 4);
+#pragma unroll
+      for (int u = 0; u < kXV; ++u) {
+        const int iy = iy0 + st_row[u];
+        const bool ok = st_row[u] < nrows && st_goff[u] != -1 && iy >= 0 && iy < p.ih;
+        xr[u] = view_ld(x_view, ok ? xb + (unsigned)(st_goff[u] * 4) : 0x80000000u);
+      }
+      const int nd = th * p.ow * (coutp >> 2);
+      const unsigned db = (unsigned)((((long long)n * p.oh + y0) * p.ow * p.ld_out) * 4);
+#pragma unroll
+      for (int u = 0; u < kDV; ++u)
+        dr[u] = view_ld(d_view, tid + u * 256 < nd ? db + (unsigned)(dy_goff[u] * 4) : 0x80000000u);
+      return;
+    }
     if (vec) {
       const int nrows = (th - 1) * p.stride + p.kh;
       const int iy0 = y0 * p.stride - p.pad_t;
