@@ -443,7 +443,11 @@ ws_fast_kernel(const Params p) {
 // EXP (tools/probes/ws_probe.hip only; the library instantiates EXP = 0): leave one ingredient out to see what the
 // others cost -- 1 no MFMAs, 2 no global A loads after the first tile, 4 no stores, 8 no mask loads, 16 no LDS fragment
 // reads, 32 no LDS staging writes.
-template <int NT, int NKT, int MODE, int EXP = 0, bool BITS = false>
+// MPF (data gradient with the fp32 mask): a tile's ReLU-mask vectors are requested one tile AHEAD.  Requested at the head
+// of their own tile they are the youngest vector-memory operations in flight when the tile's first operand wait comes
+// (vmcnt retires in order; with stores pending that wait is vmcnt(0) anyway): every tile began with a full memory
+// round trip that no other work of the wave could cover.
+template <int NT, int NKT, int MODE, int EXP = 0, bool BITS = false, bool MPF = false>
 __global__ void __launch_bounds__(512)
 ws_tab_kernel(const Params p) {
   static_assert(!BITS || MODE == 1, "the byte mask belongs to the data gradient");
@@ -558,21 +562,30 @@ ws_tab_kernel(const Params p) {
   f32x4_t av_keep = f32x4_t{1.f, 2.f, 3.f, 4.f}, wv_keep[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) wv_keep[t] = f32x4_t{0.5f, 0.25f, 0.125f, 1.f};
+  auto out_offset = [&](int tl) {                             // (rows >= M land beyond c_bytes: stores dropped, mask loads zero)
+    const uint32_t m = (uint32_t)tl * 16u + (uint32_t)lx;
+    if (MODE == 0) return m * (unsigned)(p.ldc * 4) + (unsigned)(kq * 16);
+    uint32_t img, rem;
+    p.d_g.divmod(m, img, rem);
+    return img * c_img_bytes + tab_out[rem] + (unsigned)(kq * 16);
+  };
+  u32x4_t mnext[NT];                                          // MPF: the next tile's mask vectors
+  unsigned at_next = 0;
+  if (MPF) {
+    at_next = out_offset(tile);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) mnext[t] = __builtin_amdgcn_raw_buffer_load_b128(m_rsrc, at_next, coff[t], 0);
+  }
   for (; tile < p.ntiles; tile += wstride) {
     setup(tile + wstride);
-    // output address of this lane's data row m = 16 tile + lx (columns 4 kq .. of every n-tile); rows >= M land beyond
-    // c_bytes: their stores are dropped, their mask loads return zeros
-    const uint32_t m = (uint32_t)tile * 16u + (uint32_t)lx;
-    unsigned at;
-    if (MODE == 0) at = m * (unsigned)(p.ldc * 4) + (unsigned)(kq * 16);
-    else {
-      uint32_t img, rem;
-      p.d_g.divmod(m, img, rem);
-      at = img * c_img_bytes + tab_out[rem] + (unsigned)(kq * 16);
-    }
+    // output address of this lane's data row m = 16 tile + lx (columns 4 kq .. of every n-tile)
+    const unsigned at = MPF ? at_next : out_offset(tile);
     u32x4_t mpre[NT];
     int mbit[NT];
-    if (BITS) {                                               // one byte per accumulator: this lane's four channels
+    if (MPF) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) mpre[t] = mnext[t];
+    } else if (BITS) {                                               // one byte per accumulator: this lane's four channels
 #pragma unroll
       for (int t = 0; t < NT; ++t) mbit[t] = (int)__builtin_amdgcn_raw_buffer_load_b8(m_rsrc, at >> 4, cbit[t], 0);
     } else if (MODE == 1 && has_mask) {
@@ -596,6 +609,11 @@ ws_tab_kernel(const Params p) {
         else *reinterpret_cast<u32x4_t*>(Aw + (srow + 8 * i) * LDA + kc) = rg[kt][i];
       }
       wave_fence();
+      if (MPF && kt == 0) {                                   // behind the tile's operand wait: in flight for a whole tile
+        at_next = out_offset(tile + wstride);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mnext[t] = __builtin_amdgcn_raw_buffer_load_b128(m_rsrc, at_next, coff[t], 0);
+      }
       fetch(kt);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -684,6 +702,13 @@ inline int launch(Params& p, Plan& pl, hipStream_t s, bool dry = false) {
         return check_launch("ws_tab_kernel(byte mask)");
       }
       if (dry) return SEEDHIP_OK;
+      static const int mpf = getenv("SEEDHIP_WS_MPF") ? atoi(getenv("SEEDHIP_WS_MPF")) : 1;
+      if (mpf && p.mask && pl.nr == 4 && p.nkt == 4 && p.mode == 1 && lds <= 72 * 1024) {
+        if (lds > 64 * 1024)
+          (void)hipFuncSetAttribute((const void*)ws_tab_kernel<4, 4, 1, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ws_tab_kernel<4, 4, 1, 0, false, true>), dim3(pl.grid), dim3(512), lds, s, p);
+        return check_launch("ws_tab_kernel(mask a tile ahead)");
+      }
 #define SEEDHIP_WST(NT_, NKT_, MODE_)                                                                             \
       if (pl.nr == NT_ && p.nkt == NKT_ && p.mode == MODE_ && lds <= 72 * 1024) {                                 \
         if (lds > 64 * 1024)                                                                                      \
