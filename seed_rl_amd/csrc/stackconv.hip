@@ -1347,15 +1347,10 @@ extern "C" int seedhip_conv2d_stack_bwd_weight_fused(const seedhip_stack_conv_ge
   stackconv::decompose(p.T1, p.B, stackconv::max_grid_for(1), &p.spc, &p.items, &grid);
   p.partial_w = (float*)workspace;
   p.partial_b = (float*)workspace + (size_t)grid * 256 * 16;
-  static const int exp_ = getenv("SEEDHIP_FUSE_EXP") ? atoi(getenv("SEEDHIP_FUSE_EXP")) : 0;
-#define SEEDHIP_FU(E_)                                                                                            \
-  if (exp_ == E_) {                                                                                               \
-    (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_fused_kernel<E_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)stackconv::kFusedLds);                                                         \
-    hipLaunchKernelGGL(stackconv::stackconv_wgrad_fused_kernel<E_>, dim3(grid), dim3(64 * stackconv::kCW), stackconv::kFusedLds, s, p); \
-  }
-  SEEDHIP_FU(0) SEEDHIP_FU(1) SEEDHIP_FU(2) SEEDHIP_FU(4) SEEDHIP_FU(8) SEEDHIP_FU(16) SEEDHIP_FU(3) SEEDHIP_FU(12)
-#undef SEEDHIP_FU
+  // (EXP != 0 instances of the kernel are leave-one-out timing probes with WRONG results: the library only has EXP = 0)
+  (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)stackconv::kFusedLds);
+  hipLaunchKernelGGL(stackconv::stackconv_wgrad_fused_kernel<0>, dim3(grid), dim3(64 * stackconv::kCW), stackconv::kFusedLds, s, p);
   rc = check_launch("stackconv_wgrad_fused_kernel"); if (rc) return rc;
   reduce_slices2(p.partial_w, 256LL * 16, dw0, p.partial_b, 16, dbias0, grid, s);
   return check_launch("conv2d_stack_bwd_weight_fused");
