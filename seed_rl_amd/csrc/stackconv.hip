@@ -922,10 +922,10 @@ struct FusedParams {
   int T1, B, fsz, spc, items;
 };
 
-template <int NT, int EXP>                               // row tiles of this wave: 4 (tiles 0, 2, 4, 6) or 3 (1, 3, 5)
+template <int NT, int EXP, int NTM>                      // NT row tiles of this wave (NTM or NTM - 1)
 __device__ __forceinline__ void fused_phase_a(const unsigned char* ybytes, unsigned char* dxp, const float* mask_f,
-                                              const float (&wreg)[8][4], const int (&aoff)[4][4], const int (&moff)[4][4],
-                                              const int (&doff)[4][4], float& bsum) {
+                                              const float (&wreg)[8][4], const int (&aoff)[NTM][4], const int (&moff)[NTM][4],
+                                              const int (&doff)[NTM][4], float& bsum) {
   float mk[NT][4];
 #pragma unroll
   for (int u = 0; u < NT; ++u)
@@ -973,9 +973,13 @@ __device__ __forceinline__ void fused_phase_a(const unsigned char* ybytes, unsig
     }
 }
 
-template <int EXP>                                       // EXP != 0: timing probes that skip work (wrong results)
-__global__ void __launch_bounds__(64 * kCW) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// NW waves per workgroup: 8 (two per SIMD, up to 256 VGPRs) or 16 (four per SIMD, 128 VGPRs: more waves to run while
+// one waits for LDS or sits at a barrier).  The row tiles of phase A and the pixel groups of phase B are dealt out over
+// NW / 4 partitions per parity class / stack channel.
+template <int EXP, int NW>                               // EXP != 0: timing probes that skip work (wrong results)
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
 stackconv_wgrad_fused_kernel(const FusedParams p) {
+  constexpr int kPart = NW / 4, NTM = (7 + kPart - 1) / kPart;   // partitions; row tiles of a partition (at most)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ybytes = smem + kFrameSlots * kFrame16;
   unsigned char* dxp = ybytes + kYPix * kYStride * 4;
@@ -983,7 +987,7 @@ stackconv_wgrad_fused_kernel(const FusedParams p) {
   const int kq = lane >> 4, i = lane & 15;
   constexpr int kVec = kIH * kIW / 16, kYVec = 81 * 32 / 4;       // 441 uint4 per frame, 648 per dY image
 
-  // ---- phase A: wave = (parity class, half of the row tiles) ----
+  // ---- phase A: wave = (parity class, partition of the 7 row tiles) ----
   const int ncls = wave & 3, cy = ncls >> 1, cx = ncls & 1, mpar = wave >> 2;
   float wreg[8][4];                                       // W'[k = (tap, co)][n = (class, cin = i)]: k = 16 blk + 4 kq + s
 #pragma unroll
@@ -993,10 +997,10 @@ stackconv_wgrad_fused_kernel(const FusedParams p) {
     for (int s4 = 0; s4 < 4; ++s4)
       wreg[blk][s4] = p.w1[(((2 * a + cy) * 4 + (2 * b2 + cx)) * 16 + i) * 32 + 16 * (blk & 1) + 4 * kq + s4];
   }
-  int aoff[4][4], moff[4][4], doff[4][4];
+  int aoff[NTM][4], moff[NTM][4], doff[NTM][4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int mt = mpar + 2 * u;
+  for (int u = 0; u < NTM; ++u) {
+    const int mt = mpar + kPart * u;
     {                                                     // A operand: data row m = 16 mt + i, its pixel under each tap
       const int m = 16 * mt + i, sy = m / 10, sx = m - 10 * sy;
 #pragma unroll
@@ -1016,15 +1020,15 @@ stackconv_wgrad_fused_kernel(const FusedParams p) {
                       : (i * kDxChunks + 52) * 16;         // chunk 52: written (zeros), never read
     }
   }
-  // ---- phase B: wave = (stack channel, half of the pixel groups), as stackconv_wgrad_cw_kernel ----
-  const int c = wave & 3, half = wave >> 2;
+  // ---- phase B: wave = (stack channel, partition of the pixel groups), as stackconv_wgrad_cw_kernel ----
+  const int c = wave & 3, part = wave >> 2;
   f32x4_t acc[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
   // the zero pixel of dY and the zero chunks of the dX parts are written once and never touched again
-  for (int idx = tid; idx < kYStride; idx += 64 * kCW) reinterpret_cast<float*>(ybytes)[81 * kYStride + idx] = 0.f;
-  for (int idx = tid; idx < 3 * 16 * 3 * 4; idx += 64 * kCW) {
+  for (int idx = tid; idx < kYStride; idx += 64 * NW) reinterpret_cast<float*>(ybytes)[81 * kYStride + idx] = 0.f;
+  for (int idx = tid; idx < 3 * 16 * 3 * 4; idx += 64 * NW) {
     const int part = idx / (16 * 3 * 4), rem = idx - part * (16 * 3 * 4), n = rem / 12, w = rem - n * 12;
     reinterpret_cast<uint32_t*>(dxp + part * kDxPart + (n * kDxChunks + 50) * 16)[w] = 0u;
   }
@@ -1036,11 +1040,11 @@ stackconv_wgrad_fused_kernel(const FusedParams p) {
     __syncthreads();                                      // previous item's last step is done with the ring / dY / dX parts
     for (int e = 0; e < 4; ++e) {                         // ext rows t0 .. t0+3 -> slots
       const uint4* src = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t0 + e) * p.B + b) * p.fsz);
-      for (int idx = tid; idx < kVec; idx += 64 * kCW) frame_store16(smem + ((t0 + e) % kFrameSlots) * kFrame16, src[idx], idx);
+      for (int idx = tid; idx < kVec; idx += 64 * NW) frame_store16(smem + ((t0 + e) % kFrameSlots) * kFrame16, src[idx], idx);
     }
     {
       const uint4* ysrc = reinterpret_cast<const uint4*>(p.dy1 + ((long long)t0 * p.B + b) * (81 * 32));
-      for (int idx = tid; idx < kYVec; idx += 64 * kCW)
+      for (int idx = tid; idx < kYVec; idx += 64 * NW)
         *reinterpret_cast<uint4*>(ybytes + (idx >> 3) * (kYStride * 4) + (idx & 7) * 16) = ysrc[idx];
     }
     __syncthreads();
@@ -1052,24 +1056,24 @@ stackconv_wgrad_fused_kernel(const FusedParams p) {
         if (tid < kVec) pf = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t + 4) * p.B + b) * p.fsz)[tid];
         const uint4* ysrc = reinterpret_cast<const uint4*>(p.dy1 + ((long long)(t + 1) * p.B + b) * (81 * 32));
         py0 = ysrc[tid];
-        if (tid + 64 * kCW < kYVec) py1 = ysrc[tid + 64 * kCW];
+        if (tid + 64 * NW < kYVec) py1 = ysrc[tid + 64 * NW];
       }
       if (nv > 0 && !(EXP & 8)) {
         const float* mask_f = p.act0 + ((long long)t * p.B + b) * (400 * 16);
-        if (mpar == 0) fused_phase_a<4, EXP>(ybytes, dxp, mask_f, wreg, aoff, moff, doff, bsum);
-        else fused_phase_a<3, EXP>(ybytes, dxp, mask_f, wreg, aoff, moff, doff, bsum);
+        if ((7 - mpar + kPart - 1) / kPart == NTM) fused_phase_a<NTM, EXP, NTM>(ybytes, dxp, mask_f, wreg, aoff, moff, doff, bsum);
+        else fused_phase_a<NTM - 1, EXP, NTM>(ybytes, dxp, mask_f, wreg, aoff, moff, doff, bsum);
       }
       __syncthreads();                                    // the frame's dX parts are complete; dY is free
       if (more) {
         *reinterpret_cast<uint4*>(ybytes + (tid >> 3) * (kYStride * 4) + (tid & 7) * 16) = py0;
-        if (tid + 64 * kCW < kYVec) {
-          const int idx = tid + 64 * kCW;
+        if (tid + 64 * NW < kYVec) {
+          const int idx = tid + 64 * NW;
           *reinterpret_cast<uint4*>(ybytes + (idx >> 3) * (kYStride * 4) + (idx & 7) * 16) = py1;
         }
       }
       if (c < nv && !(EXP & 4)) {
         const unsigned char* frame = smem + ((t + 3 - c) % kFrameSlots) * kFrame16;
-        for (int g = half; g < kGroups32; g += 2) {
+        for (int g = part; g < kGroups32; g += kPart) {
           const int ch = 4 * g + kq;                      // chunks 50, 51 (last group) read the zero chunks of the parts
           const int cc = ch < kChunks ? ch : 0, rp = cc / 5, xc = cc - rp * 5;
           const unsigned char* src = frame + ((8 * rp + (i >> 1)) * kIW + 16 * xc + 4 * (i & 1)) * 2;
@@ -1105,37 +1109,39 @@ stackconv_wgrad_fused_kernel(const FusedParams p) {
     }
   }
 
-  // ---- the two halves of a channel -> one tile (half 1 through LDS), written straight into the partial slice ----
+  // ---- the partitions of a channel -> one tile (partitions 1.. through LDS, fixed order), straight into the partial slice ----
   __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);            // [c][q][lane][4]
-  if (half == 1) {
+  float* red = reinterpret_cast<float*>(smem);            // [part - 1][c][q][lane][4]: at most 48 KB of the ring
+  if (part > 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4_t*>(red + ((c * 4 + q) * 64 + lane) * 4) = acc[q];
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4_t*>(red + ((((part - 1) * 4 + c) * 4 + q) * 64 + lane) * 4) = acc[q];
   }
   __syncthreads();
-  if (half == 0) {
+  if (part == 0) {
     float* pw = p.partial_w + (long long)blockIdx.x * 256 * 16;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4_t o = *reinterpret_cast<const f32x4_t*>(red + ((c * 4 + q) * 64 + lane) * 4);
+      f32x4_t o = acc[q];
+#pragma unroll
+      for (int pp = 0; pp < kPart - 1; ++pp) o += *reinterpret_cast<const f32x4_t*>(red + (((pp * 4 + c) * 4 + q) * 64 + lane) * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 4 * kq + r;                       // k-row within the m-tile
         const int ky = row >> 1, kx = 4 * (row & 1) + q;
-        pw[((ky * 8 + kx) * 4 + c) * 16 + i] = (acc[q][r] + o[r]) / 255.0f;
+        pw[((ky * 8 + kx) * 4 + c) * 16 + i] = o[r] / 255.0f;
       }
     }
   }
   // bias gradient: every wave holds the sum over ITS (class, row tiles) of channel i in its four kq lane groups
   bsum += __shfl_xor(bsum, 16, 64);
   bsum += __shfl_xor(bsum, 32, 64);
-  float* redb = red + 16 * 64 * 4;
+  float* redb = red + (kPart - 1) * 16 * 64 * 4;
   if (lane < 16) redb[wave * 16 + lane] = bsum;
   __syncthreads();
   if (tid < 16) {
     float sum = 0.f;
 #pragma unroll
-    for (int w = 0; w < kCW; ++w) sum += redb[w * 16 + tid];
+    for (int w = 0; w < NW; ++w) sum += redb[w * 16 + tid];
     p.partial_b[(long long)blockIdx.x * 16 + tid] = sum;
   }
 }
@@ -1348,9 +1354,17 @@ extern "C" int seedhip_conv2d_stack_bwd_weight_fused(const seedhip_stack_conv_ge
   p.partial_w = (float*)workspace;
   p.partial_b = (float*)workspace + (size_t)grid * 256 * 16;
   // (EXP != 0 instances of the kernel are leave-one-out timing probes with WRONG results: the library only has EXP = 0)
-  (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)stackconv::kFusedLds);
-  hipLaunchKernelGGL(stackconv::stackconv_wgrad_fused_kernel<0>, dim3(grid), dim3(64 * stackconv::kCW), stackconv::kFusedLds, s, p);
+  // measured (same box): 8 waves 348 us, 16 waves 405 us (15 spilled VGPRs at the 128 cap, 16-wave barriers), the two-kernel path 300
+  static const int nw = getenv("SEEDHIP_FUSE_WAVES") ? atoi(getenv("SEEDHIP_FUSE_WAVES")) : 8;
+  if (nw == 8) {
+    (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_fused_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)stackconv::kFusedLds);
+    hipLaunchKernelGGL((stackconv::stackconv_wgrad_fused_kernel<0, 8>), dim3(grid), dim3(512), stackconv::kFusedLds, s, p);
+  } else {
+    (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_fused_kernel<0, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)stackconv::kFusedLds);
+    hipLaunchKernelGGL((stackconv::stackconv_wgrad_fused_kernel<0, 16>), dim3(grid), dim3(1024), stackconv::kFusedLds, s, p);
+  }
   rc = check_launch("stackconv_wgrad_fused_kernel"); if (rc) return rc;
   reduce_slices2(p.partial_w, 256LL * 16, dw0, p.partial_b, 16, dbias0, grid, s);
   return check_launch("conv2d_stack_bwd_weight_fused");
