@@ -1,0 +1,80 @@
+"""Structure of the compiled gfx950 kernels that this round's speed-ups rest on, checked on the ISA (no GPU): the
+properties below were found by reading `tools/isa_waits.py` output and each was worth 1-13 % of a kernel when it broke
+("what the waits say").  A compiler or source change that silently brings a stall back -- a
+vector load of `nvalid` at the head of the time loop, spills in the first conv, an unpinned prefetch -- fails here
+instead of showing up as a slower bench line."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+LIB = os.path.join(ROOT, 'seed_rl_amd', 'lib', 'libseedhip.so')
+
+
+@pytest.fixture(scope='module')
+def code_objects():
+  import isa_waits
+  if not os.path.exists(LIB):
+    pytest.skip('libseedhip.so is not built')
+  for tool in ('llvm-objcopy', 'clang-offload-bundler', 'llvm-readelf', 'llvm-objdump'):
+    if not os.path.exists(os.path.join(isa_waits.LLVM, tool)) and shutil.which(tool) is None:
+      pytest.skip('ROCm LLVM tools not found')
+  cos = isa_waits.device_code(LIB)
+  assert cos and cos != [LIB], 'no gfx950 code object inside libseedhip.so'
+  return isa_waits, cos
+
+
+def _find(code_objects, pattern):
+  isa_waits, cos = code_objects
+  hits = [(co, name, meta) for co in cos for name, meta in isa_waits.kernels(co, pattern).items()]
+  assert hits, 'kernel %r is not in the library' % pattern
+  return hits
+
+
+def _ops(code_objects, co, name):
+  isa_waits, _ = code_objects
+  return [line.split()[1] for line in isa_waits.trace(co, name, False)]
+
+
+def test_first_conv_reads_nvalid_through_the_scalar_cache(code_objects):
+  # a vector load of nvalid[t, b] behind the band prefetch made every wave wait for that prefetch before its first MFMA
+  for pat in ('stackconv_fwd_bf16r_kernelILi0ELb0ELb1', 'stackconv_wgrad_cp_kernelILi16', 'stackconv_wgrad_fused_kernelILi0ELi8'):
+    for co, name, meta in _find(code_objects, pat):
+      ops = _ops(code_objects, co, name)
+      assert 'global_load_ubyte' not in ops, (pat, 'nvalid is read with a vector load again')
+      assert any(o.startswith('s_load_dword') for o in ops)
+
+
+def test_register_budgets_of_the_hot_kernels(code_objects):
+  budget = {                                             # pattern -> (max VGPRs, max spilled VGPRs)
+      'stackconv_fwd_bf16r_kernelILi0ELb0ELb1': (168, 16),     # three waves per SIMD
+      'stackconv_wgrad_cp_kernelILi16': (128, 0),              # two 8-wave workgroups per CU
+      'ws_tab_kernelILi4ELi4ELi1ELi0ELb0ELb1': (128, 0),       # data gradient with the mask a tile ahead: four waves per SIMD
+      'ws_tab_kernelILi2ELi8ELi0ELi0ELb0ELb0': (128, 0),
+      'wsw_kernelILb0ELi16ELi0': (256, 0),                     # one 4-wave workgroup per SIMD set: accumulators in AGPRs
+      'stackconv_wgrad_fused_kernelILi0ELi8': (256, 0),
+  }
+  for pat, (vmax, smax) in budget.items():
+    for _, name, meta in _find(code_objects, pat):
+      assert meta['.vgpr_count'] <= vmax, (pat, meta)
+      assert meta.get('.vgpr_spill_count', 0) <= smax, (pat, meta)
+
+
+def test_halo_epilogue_is_one_wait_then_stores(code_objects):
+  # forward with residual (MT = NT = 2): operands requested in front of the k loop, ONE wait, then the stores back to back
+  for co, name, _ in _find(code_objects, 'halo_fwd_kernelILi2ELi2ELb0ELi7'):
+    ops = _ops(code_objects, co, name)
+    assert not any(o.startswith('flat_load') for o in ops)
+    last_mfma = max(i for i, o in enumerate(ops) if o.startswith('v_mfma'))
+    tail = [o for o in ops[last_mfma:] if o.startswith(('global_load', 'global_store', 's_waitcnt'))]
+    assert not any(o.startswith('global_load') for o in tail), 'epilogue operands are requested behind the k loop again'
+    first_store = next(i for i, o in enumerate(tail) if o.startswith('global_store'))
+    assert 's_waitcnt' not in tail[first_store:], 'a wait between the output stores'
+
+
+def test_halo_wgrad_prefetch_is_unconditional(code_objects):
+  for co, name, _ in _find(code_objects, 'halo_wgrad_kernelILi9ELi2ELi2ELb1'):
+    assert any(o.startswith('buffer_load_dwordx4') for o in _ops(code_objects, co, name))
