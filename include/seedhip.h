@@ -193,7 +193,9 @@ int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const void* in, int
                               size_t workspace_bytes, void* stream);
 
 /* First Atari conv fused with frame stacking + /255 (atari/networks.py:57-173,234,330):
- * consumes frames_ext / nvalid directly, VALID padding, 4 stacked channels. */
+ * consumes frames_ext / nvalid directly, VALID padding, 4 stacked channels.  nvalid [T, B] (bytes) is read through the
+ * scalar cache in aligned 4-byte words: the allocation must be readable up to the next 4-byte boundary on both sides of
+ * the array (any hipMalloc / torch allocation is). */
 typedef struct { int T, B, ih, iw, oh, ow, kh, kw, stride, cout, ld_out; } seedhip_stack_conv_geom;
 int seedhip_conv2d_stack_fwd(const seedhip_stack_conv_geom* geom, const uint8_t* frames_ext,
                              const uint8_t* nvalid, const float* w, const float* bias, float* out,
