@@ -15,6 +15,7 @@
 #include "halo_wgrad.h"
 #include "halo_fwd.h"
 #include "gemm.h"
+#include "xgemm.h"
 #include "wsgemm.h"
 #include "wsw.h"
 #include "../../include/seedhip.h"
@@ -118,6 +119,21 @@ bool is_dense(const seedhip_conv_geom* g) {
          g->pad_t == 0 && g->pad_l == 0;
 }
 
+// Dense layers on the bf16 pipe through the exact three-way split (xgemm.h): the plans (ok = served) as functions of
+// the geometry alone, so that the workspace queries and the launches agree
+xg::Plan x6_fwd_plan(const seedhip_conv_geom* g) {
+  if (!is_dense(g) || g->ld_in % 4 || g->cin % 4 || g->ld_out % 4) return xg::Plan{false, 1, 0, {0, 0, 0}};
+  return xg::plan(g->n_img, g->cout, g->cin, (long long)g->n_img * g->ld_in * 4, (long long)g->cin * g->cout * 4);
+}
+xg::Plan x6_dgrad_plan(const seedhip_conv_geom* g) {
+  if (!is_dense(g) || g->ld_out % 4 || g->cout % 4 || g->ld_in % 4 || g->cin % 4) return xg::Plan{false, 1, 0, {0, 0, 0}};
+  return xg::plan(g->n_img, g->cin, g->cout, (long long)g->n_img * g->ld_out * 4, (long long)g->cin * g->cout * 4);
+}
+xg::Plan x6_wgrad_plan(const seedhip_conv_geom* g) {
+  if (!is_dense(g) || g->ld_in % 4 || g->cin % 4 || g->ld_out % 4 || g->cout % 4) return xg::Plan{false, 1, 0, {0, 0, 0}};
+  return xg::plan(g->cin, g->cout, g->n_img, (long long)g->n_img * g->ld_in * 4, (long long)g->n_img * g->ld_out * 4);
+}
+
 int check_geom(const seedhip_conv_geom* g, const char* what) {
   SEEDHIP_REQUIRE(g, "%s: null geometry", what);
   SEEDHIP_REQUIRE(g->n_img >= 1 && g->ih >= 1 && g->iw >= 1 && g->cin >= 1 && g->oh >= 1 && g->ow >= 1 &&
@@ -137,14 +153,22 @@ extern "C" size_t seedhip_conv2d_fwd_workspace_bytes(const seedhip_conv_geom* g)
   if (!g || !is_dense(g)) return 0;
   const int sl = dense_slices(g->n_img, g->cout, g->cin);
   const size_t core = sl > 1 ? (size_t)sl * g->n_img * g->cout * sizeof(float) : 0;
-  const size_t mm = gemm_fwd_ok(g) ? gemm_partial_bytes(g->n_img, g->cout, g->cin) : 0;
+  size_t mm = gemm_fwd_ok(g) ? gemm_partial_bytes(g->n_img, g->cout, g->cin) : 0;
+  if (xg::mode() & 1) {
+    const xg::Plan xp = x6_fwd_plan(g);
+    if (xp.ok && xg::partial_bytes(g->n_img, g->cout, xp) > mm) mm = xg::partial_bytes(g->n_img, g->cout, xp);
+  }
   return mm > core ? mm : core;
 }
 extern "C" size_t seedhip_conv2d_bwd_data_workspace_bytes(const seedhip_conv_geom* g) {
   if (!g || !is_dense(g)) return 0;
   const int sl = dense_slices(g->n_img, g->cin, g->cout);
   const size_t core = sl > 1 ? (size_t)sl * g->n_img * g->cin * sizeof(float) : 0;
-  const size_t mm = gemm_dgrad_ok(g) ? gemm_partial_bytes(g->n_img, g->cin, g->cout) : 0;
+  size_t mm = gemm_dgrad_ok(g) ? gemm_partial_bytes(g->n_img, g->cin, g->cout) : 0;
+  if (xg::mode() & 2) {
+    const xg::Plan xp = x6_dgrad_plan(g);
+    if (xp.ok && xg::partial_bytes(g->n_img, g->cin, xp) > mm) mm = xg::partial_bytes(g->n_img, g->cin, xp);
+  }
   return mm > core ? mm : core;
 }
 
@@ -201,6 +225,27 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
       halo::ClassSpec cs = {geom->kh, geom->kw, geom->pad_t, geom->pad_l, geom->oh, geom->ow, 0, 0, 0, 0};
       const halo::FwdPlan pl = halo::plan_fwd(hp, &cs, 1, in_dtype == kInU8Div255);
       if (pl.ok) return halo::launch_fwd_kernel(hp, pl, (hipStream_t)stream);
+    }
+  }
+  if ((xg::mode() & 1) && is_dense(geom) && in_dtype == kInF32 && al16(in) && al16(w) && al16(out) && al16(workspace) &&
+      al16(bias) && al16(residual)) {
+    const xg::Plan xp = x6_fwd_plan(geom);
+    const int M = geom->n_img, N = geom->cout, K = geom->cin;
+    if (xp.ok && (xp.slices == 1 || (workspace && workspace_bytes >= xg::partial_bytes(M, N, xp)))) {
+      hipStream_t s = (hipStream_t)stream;
+      gemm::Params gp;
+      memset(&gp, 0, sizeof(gp));
+      gp.A = (const float*)in; gp.lda = geom->ld_in; gp.a_relu = in_relu; gp.B = w; gp.ldb = N;
+      gp.M = M; gp.N = N; gp.K = K; gp.C = out; gp.ldc = geom->ld_out;
+      gp.bias = bias; gp.residual = residual; gp.out_relu = out_relu;
+      if (xp.slices > 1) gp.partial = (float*)workspace;
+      xg::launch<true, false>(gp, xp, s);
+      if (xp.slices > 1) {
+        int blocks = cdiv((long long)M * N, 256); if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(dense_epilogue_kernel, dim3(blocks), dim3(256), 0, s, gp.partial, xp.slices, M, N, bias,
+                           residual, out_relu, (const float*)nullptr, (const float*)nullptr, out, geom->ld_out);
+      }
+      return check_launch("conv2d_fwd(dense, bf16x6)");
     }
   }
   if (is_dense(geom) && in_dtype == kInF32 && geom->ld_in % 4 == 0 && (((uintptr_t)in) & 15) == 0) {
@@ -352,6 +397,25 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
       }
     }
   }
+  if ((xg::mode() & 2) && is_dense(geom) && al16(dy) && al16(w) && al16(dx) && al16(relu_mask) && al16(add) && al16(workspace)) {
+    const xg::Plan xp = x6_dgrad_plan(geom);
+    const int M = geom->n_img, N = geom->cin, K = geom->cout;
+    if (xp.ok && (xp.slices == 1 || (workspace && workspace_bytes >= xg::partial_bytes(M, N, xp)))) {
+      hipStream_t s = (hipStream_t)stream;
+      gemm::Params gp;
+      memset(&gp, 0, sizeof(gp));
+      gp.A = dy; gp.lda = geom->ld_out; gp.B = w; gp.ldb = K; gp.M = M; gp.N = N; gp.K = K;
+      gp.C = dx; gp.ldc = geom->ld_in; gp.mask = relu_mask; gp.add = add;
+      if (xp.slices > 1) gp.partial = (float*)workspace;
+      xg::launch<true, true>(gp, xp, s);
+      if (xp.slices > 1) {
+        int blocks = cdiv((long long)M * N, 256); if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(dense_epilogue_kernel, dim3(blocks), dim3(256), 0, s, gp.partial, xp.slices, M, N,
+                           (const float*)nullptr, (const float*)nullptr, 0, relu_mask, add, dx, geom->ld_in);
+      }
+      return check_launch("conv2d_bwd_data(dense, bf16x6)");
+    }
+  }
   if (is_dense(geom) && geom->cout % 4 == 0 && geom->ld_out % 4 == 0 && (((uintptr_t)dy | (uintptr_t)w) & 15) == 0) {
     if (gemm_dgrad_ok(geom)) {
       const int M = geom->n_img, N = geom->cin, K = geom->cout;
@@ -414,6 +478,11 @@ extern "C" size_t seedhip_conv2d_bwd_weight_workspace_bytes(const seedhip_conv_g
     const size_t mm = (size_t)gpl.slices * ((size_t)M * N + N) * sizeof(float);
     if (mm > need) need = mm;
   }
+  if (xg::mode() & 4) {
+    const xg::Plan xp = x6_wgrad_plan(g);
+    const size_t mm = xp.ok ? (size_t)xp.slices * ((size_t)M * N + N) * sizeof(float) : 0;
+    if (mm > need) need = mm;
+  }
   {
     wsw::Params wp;
     if (wsw::plan(wp, g)) {
@@ -466,6 +535,24 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
     const halo::WgradPlan pl = halo::plan_wgrad(geom);
     if (pl.ok && (((uintptr_t)in) & 15) == 0 && (((uintptr_t)dy) & 15) == 0)
       return halo::launch_wgrad(geom, pl, in, in_dtype, in_relu, dy, dw, dbias, workspace, (hipStream_t)stream);
+  }
+  if ((xg::mode() & 4) && is_dense(geom) && in_dtype == kInF32 && al16(in) && al16(dy) && al16(dw) && al16(dbias) && al16(workspace)) {
+    const xg::Plan xp = x6_wgrad_plan(geom);
+    if (xp.ok) {
+      const int M = geom->cin, N = geom->cout, K = geom->n_img;
+      hipStream_t s = (hipStream_t)stream;
+      gemm::Params gp;
+      memset(&gp, 0, sizeof(gp));
+      gp.A = (const float*)in; gp.lda = geom->ld_in; gp.a_relu = in_relu; gp.B = dy; gp.ldb = geom->ld_out;
+      gp.M = M; gp.N = N; gp.K = K;
+      float* pw = (float*)workspace;
+      float* pb = pw + (size_t)xp.slices * M * N;
+      gp.partial = xp.slices > 1 ? pw : dw;                      // one slice: the raw sums are the result
+      gp.partial_colsum = dbias ? (xp.slices > 1 ? pb : dbias) : nullptr;
+      xg::launch<false, false>(gp, xp, s);
+      if (xp.slices > 1) reduce_slices2(pw, (long long)M * N, dw, pb, N, dbias, xp.slices, s);
+      return check_launch("conv2d_bwd_weight(dense, bf16x6)");
+    }
   }
   if (is_dense(geom) && in_dtype == kInF32 && geom->ld_in % 4 == 0 && (((uintptr_t)in) & 15) == 0) {
     if (gemm_wgrad_ok(geom) && al16(dy) && al16(workspace)) {

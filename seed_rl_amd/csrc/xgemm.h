@@ -1,0 +1,378 @@
+// fp32 GEMM on the BF16 matrix pipe through the exact three-way split ("bf16x6"), for the large Dense layers
+// (atari/networks.py:176-251 Dense(256) / dmlab/networks.py:105-124,152-171 Dense + LSTM input projections):
+//     C[m, n] = epilogue( sum_k A(m, k) * B(k, n) ),        A, B, C fp32 in HBM.
+//
+// Why: v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate (64 FLOP/clk/SIMD, 157 TF/s) and shares the SIMD's issue
+// with every VALU instruction of the kernel; v_mfma_f32_32x32x16_bf16 is a separate pipe at 16x that rate.  Any fp32
+// number is the exact sum of three bf16 numbers, v = h + m + l with h = bf16_rn(v), m = bf16_rn(v - h),
+// l = v - h - m (8 + 8 + 8 significant bits; both subtractions are exact in fp32; tests/test_bf16_split.py), so
+//     a * b = (ah + am + al) * (bh + bm + bl)
+// and the six products  ah bh, ah bm, am bh, ah bl, al bh, am bm  carry everything above 2^-25 |a b|: what is dropped
+// (am bl + al bm + al bl) is bounded by 2^-26 |a b| per term pair -- a quarter of ONE fp32 rounding of the accumulator,
+// with random sign (round-to-nearest splits).  Every product of two bf16 numbers is exact in fp32 and the matrix core
+// accumulates in fp32: the kernel evaluates the same real-number sum as the fp32 MFMA up to that term and fp32
+// summation order, at 6/16 of its matrix-pipe time (ceiling 2500 / 6 = 417 algorithmic TF/s against 157).
+// tests/test_gpu_kernels.py::test_x6_gemm_fp32_accuracy holds it to the error of torch's own fp32 matmul against an
+// fp64 evaluation at K = 2592 / 3136.
+//
+// Structure (256 threads = 2 x 2 waves, 128 x 128 x 32 tiles, one LDS buffer + register prefetch like gemm.h):
+//   * operands come from HBM as fp32, 16 bytes per lane and load, through buffer views (hardware zero fill for ragged
+//     tiles; ONE byte-offset register per thread, the k-tile / row advance is a uniform soffset);
+//     waves 0-1 stage operand A, waves 2-3 operand B: eight float4 per thread and k-tile;
+//   * the split happens ONCE per staged element, on the way from the load registers into LDS (v_cvt_pk_bf16_f32:
+//     11 VALU per element pair -- VALU work that runs beside the bf16 matrix pipe, unlike beside the fp32 one);
+//   * LDS holds three bf16 planes per operand with the reduction index contiguous in runs of 8 (one ds_read_b128 = one
+//     MFMA operand): k-contiguous operands as [x][32 k] rows of 64 bytes with the 16-byte chunk index XOR-swizzled by
+//     (x >> 2) & 3, outer-contiguous operands as [k / 8][x][8 k] -- the thread that loaded rows k..k+7 of four x
+//     packs them into four 16-byte chunks, no transposition pass; both are conflict free for the fragment reads;
+//   * the MFMA's row operand (i) is GEMM-B's n, its column operand (j) GEMM-A's m: a lane ends up with four
+//     consecutive n of one row m per accumulator quad -> 16-byte epilogue loads / stores.
+// Split-K over the grid with the deterministic second pass of gemm.h's callers; the workgroup -> tile map gives each
+// XCD a contiguous run of tiles (neighbouring tiles share an operand panel in that XCD's L2).
+#pragma once
+#include "gemm.h"
+
+namespace seedhip {
+namespace xg {
+
+using gemm::Params;
+using gemm::kViewOOB;
+using gemm::make_view;
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int BK = 32;                       // fp32 reduction elements per k-tile = two 16-deep MFMA steps
+constexpr int BX = 128;                      // rows of A / columns of B per workgroup tile
+constexpr int kPlane = BX * 64;              // bytes of one bf16 plane of one operand tile
+constexpr int kOperand = 3 * kPlane;
+constexpr int kLds = 2 * kOperand;           // 48 KB: three workgroups per CU
+
+// (a, b) -> packed bf16 pairs of the three parts (element a in the low half)
+__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  const f32x2_t v = {a, b};
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+  const f32x2_t r1 = {a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xFFFF0000u)};
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
+  const f32x2_t r2 = {r1[0] - __uint_as_float(m << 16), r1[1] - __uint_as_float(m & 0xFFFF0000u)};
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
+}
+
+__device__ __forceinline__ float4 view_load_s(const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
+  const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, __builtin_amdgcn_readfirstlane(soff), 0);
+  return make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
+}
+__device__ __forceinline__ void relu4(float4& v) {
+  v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+}
+
+// LDS byte offset (inside one plane) of the 16-byte chunk holding k = 8 c .. 8 c + 7 of row / column x
+SH_HD int kc_chunk(int x, int c) { return x * 64 + ((c ^ ((x >> 2) & 3)) << 4); }
+SH_HD int oc_slot(int x) { return 4 * (x >> 2) + ((x & 3) ^ ((x >> 3) & 3)); }
+SH_HD int oc_chunk(int x, int c) { return (c * BX + oc_slot(x)) << 4; }
+
+// ---- staging of one operand tile [BX][32] by 128 threads (u = 0..127), eight float4 each ------------------------ //
+// k-contiguous: element (x, k) at base[x * ld + k].  Thread (row = u >> 3, q = u & 7) loads k = 4 q .. 4 q + 3 of rows
+// row + 16 i (a wave instruction = 8 rows x 128 contiguous bytes) and writes 8 bytes per plane and vector.
+struct StageKC {
+  unsigned voff, step, wofs;
+  int nvalid, kq4;
+  __device__ void init(int u, long long ld, int x0, int X) {
+    const int q = u & 7, row = u >> 3;
+    voff = (unsigned)(((long long)(x0 + row) * ld + 4 * q) * 4);
+    int nv = (X - x0 - row + 15) >> 4;
+    nvalid = nv < 0 ? 0 : (nv > 8 ? 8 : nv);
+    step = (unsigned)(ld * 64);                              // 16 rows
+    kq4 = 4 * q;
+    wofs = (unsigned)(kc_chunk(row, q >> 1) + (q & 1) * 8);  // rows 16 apart share the swizzle
+  }
+  __device__ void load(float4 (&r)[8], const __amdgpu_buffer_rsrc_t& rs, int k, int k1) {
+    const bool kin = k + kq4 < k1;                           // K % 4 == 0: a vector is entirely in or out
+    const unsigned kb = (unsigned)k * 4u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = view_load_s(rs, (kin && i < nvalid) ? voff : kViewOOB, kb + (unsigned)i * step);
+  }
+  // (the ReLU of an operand is applied here, not behind the loads: a use of the load registers right where they are
+  // requested would wait for them and kill the prefetch)
+  __device__ void store(float4 (&r)[8], unsigned char* lds, bool relu) const {
+    if (relu) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) relu4(r[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      unsigned h0, m0, l0, h1, m1, l1;
+      split2(r[i].x, r[i].y, h0, m0, l0);
+      split2(r[i].z, r[i].w, h1, m1, l1);
+      unsigned char* d = lds + wofs + i * (16 * 64);
+      *reinterpret_cast<u32x2_t*>(d) = u32x2_t{h0, h1};
+      *reinterpret_cast<u32x2_t*>(d + kPlane) = u32x2_t{m0, m1};
+      *reinterpret_cast<u32x2_t*>(d + 2 * kPlane) = u32x2_t{l0, l1};
+    }
+  }
+  __device__ float4 colsum(const float4 (&)[8]) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+// outer-contiguous: element (x, k) at base[k * ld + x].  Thread (c = u >> 5, xg = u & 31) loads x = 4 xg .. 4 xg + 3
+// of rows k = 8 c + i (a wave instruction = 2 rows x 512 contiguous bytes) and writes, per plane, the four 16-byte
+// chunks (x, k = 8 c .. 8 c + 7): element pairs (k, k + 1) come from two load registers, so the "transposition" is
+// the choice of cvt_pk operands.
+struct StageOC {
+  unsigned voff, ld4;
+  int c8, xg;
+  bool xin;
+  __device__ void init(int u, long long ld, int x0, int X) {
+    xg = u & 31; c8 = (u >> 5) * 8;
+    xin = x0 + 4 * xg < X;                                   // X % 4 == 0
+    voff = (unsigned)(((long long)c8 * ld + x0 + 4 * xg) * 4);
+    ld4 = (unsigned)(ld * 4);
+  }
+  __device__ void load(float4 (&r)[8], const __amdgpu_buffer_rsrc_t& rs, int k, int k1) {
+    const unsigned kb = (unsigned)k * ld4;
+    const int nrow = k1 - k - c8;                            // rows of this thread inside the operand
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = view_load_s(rs, (xin && i < nrow) ? voff : kViewOOB, kb + (unsigned)i * ld4);
+  }
+  static __device__ __forceinline__ float comp(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+  __device__ void store(float4 (&r)[8], unsigned char* lds, bool relu) const {
+    if (relu) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) relu4(r[i]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {                            // e, j are compile-time constants after unrolling
+      unsigned h[4], m[4], l[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split2(comp(r[2 * j], e), comp(r[2 * j + 1], e), h[j], m[j], l[j]);
+      unsigned char* d = lds + oc_chunk(4 * xg + e, c8 >> 3);
+      *reinterpret_cast<u32x4_t*>(d) = u32x4_t{h[0], h[1], h[2], h[3]};
+      *reinterpret_cast<u32x4_t*>(d + kPlane) = u32x4_t{m[0], m[1], m[2], m[3]};
+      *reinterpret_cast<u32x4_t*>(d + 2 * kPlane) = u32x4_t{l[0], l[1], l[2], l[3]};
+    }
+  }
+  __device__ float4 colsum(const float4 (&r)[8]) const {     // sum over this thread's 8 rows (bias gradient)
+    float4 t = r[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { t.x += r[i].x; t.y += r[i].y; t.z += r[i].z; t.w += r[i].w; }
+    return t;
+  }
+};
+template <bool KC> struct PickStage { typedef StageKC type; };
+template <> struct PickStage<false> { typedef StageOC type; };
+
+// fragment byte offset of lane (x, half) for 16-deep step s inside one plane (tile t adds 32 rows / columns)
+template <bool KC> __device__ __forceinline__ int frag_off(int x, int half, int s) {
+  return KC ? kc_chunk(x, 2 * s + half) : oc_chunk(x, 2 * s + half);
+}
+template <bool KC> constexpr int tile_stride() { return KC ? 32 * 64 : 32 * 16; }
+
+struct Grid { int mt, nt, slices; };
+
+// workgroup b -> work item: XCD b % 8 runs a contiguous range of the (m-tile, slice, n-tile) items, n-tile fastest
+__device__ __forceinline__ int work_item(int b, int total) {
+  const int xcd = b & 7, idx = b >> 3, per = total >> 3, rem = total & 7;
+  return xcd * per + (xcd < rem ? xcd : rem) + idx;
+}
+
+// EXP (measurement builds only): 1 = one accumulator chain per k-tile, summed into the result by VALU adds
+template <bool AKC, bool BKC, int EXP = 0>
+__global__ void __launch_bounds__(256, 2)
+xgemm_kernel(const Params p, const Grid g) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kLds];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + kOperand;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lx = lane & 31, half = lane >> 5;
+
+  const int item = work_item(blockIdx.x, g.mt * g.nt * g.slices);
+  const int ntile = item % g.nt, rest = item / g.nt, slice = rest % g.slices, mtile = rest / g.slices;
+  const int m0 = mtile * BX, n0 = ntile * BX;
+  const int k0 = slice * p.k_per_slice;
+  int k1 = k0 + p.k_per_slice; if (k1 > p.K) k1 = p.K;
+  const int nkt = (k1 - k0 + BK - 1) / BK;
+
+  typedef typename PickStage<AKC>::type SA;
+  typedef typename PickStage<BKC>::type SB;
+  // one of the two stagers is live per wave (waves 0-1: A, waves 2-3: B); the load registers are shared
+  SA sa; SB sb;
+  float4 r[8];
+  const bool stage_a = __builtin_amdgcn_readfirstlane(tid) < 128;      // a scalar branch
+  const int u = tid & 127;
+  const __amdgpu_buffer_rsrc_t ra = make_view(p.A, (AKC ? (long long)p.M * p.lda : (long long)p.K * p.lda) * 4);
+  const __amdgpu_buffer_rsrc_t rb = make_view(p.B, (BKC ? (long long)p.N * p.ldb : (long long)p.K * p.ldb) * 4);
+  if (stage_a) sa.init(u, p.lda, m0, p.M); else sb.init(u, p.ldb, n0, p.N);
+  const bool do_colsum = !BKC && p.partial_colsum && mtile == 0;
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    a_off[s] = frag_off<AKC>(wm * 64 + lx, half, s);
+    b_off[s] = frag_off<BKC>(wn * 64 + lx, half, s);
+  }
+
+  if (nkt > 0) {
+    if (stage_a) sa.load(r, ra, k0, k1); else sb.load(r, rb, k0, k1);
+  }
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();                                         // previous tile consumed
+    if (stage_a) sa.store(r, As, p.a_relu != 0);
+    else {
+      sb.store(r, Bs, false);
+      if (do_colsum) { const float4 t = sb.colsum(r); csum.x += t.x; csum.y += t.y; csum.z += t.z; csum.w += t.w; }
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      const int k = k0 + (kt + 1) * BK;
+      if (stage_a) sa.load(r, ra, k, k1); else sb.load(r, rb, k, k1);
+    }
+    f32x16_t part[2][2];
+    if (EXP & 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_t fa[2][3], fb[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          fa[t][q] = *reinterpret_cast<const bf16x8_t*>(As + a_off[s] + t * tile_stride<AKC>() + q * kPlane);
+          fb[t][q] = *reinterpret_cast<const bf16x8_t*>(Bs + b_off[s] + t * tile_stride<BKC>() + q * kPlane);
+        }
+      // six products per (m-tile, n-tile), smallest first; MFMA rows = n (operand B), columns = m (operand A)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16_t c = (EXP & 1) ? part[i][j] : acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][2], fa[i][0], c, 0, 0, 0);   // bl ah
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][0], fa[i][2], c, 0, 0, 0);   // bh al
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][1], fa[i][1], c, 0, 0, 0);   // bm am
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][1], fa[i][0], c, 0, 0, 0);   // bm ah
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][0], fa[i][1], c, 0, 0, 0);   // bh am
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][0], fa[i][0], c, 0, 0, 0);   // bh ah
+          if (EXP & 1) part[i][j] = c; else acc[i][j] = c;
+        }
+    }
+    if (EXP & 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] += part[i][j];
+    }
+  }
+
+  // bias-gradient column sums of this slice: the four row-chunk threads of a column quad are summed in fixed order
+  if (do_colsum) {
+    __syncthreads();
+    float4* scr = reinterpret_cast<float4*>(smem);
+    if (!stage_a) scr[u] = csum;                             // u = c * 32 + xg
+    __syncthreads();
+    if (tid < 32 && n0 + 4 * tid < p.N) {
+      float4 t = scr[tid];
+#pragma unroll
+      for (int c = 1; c < 4; ++c) { const float4 o = scr[c * 32 + tid]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+      *reinterpret_cast<float4*>(p.partial_colsum + (long long)slice * p.N + n0 + 4 * tid) = t;
+    }
+  }
+
+  // epilogue.  Accumulator (i, j) register r of lane (lx, half): m = m0 + wm*64 + 32 i + lx,
+  //   n = n0 + wn*64 + 32 j + 8 (r >> 2) + 4 half + (r & 3): quads of four consecutive n
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 64 + 32 * i + lx;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + 32 * j + 8 * q + 4 * half;
+        if (n >= p.N) continue;                              // N % 4 == 0
+        f32x4_t v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        if (p.partial) {
+          *reinterpret_cast<f32x4_t*>(p.partial + ((long long)slice * p.M + m) * p.N + n) = v;
+          continue;
+        }
+        const long long at = (long long)m * p.ldc + n;
+        if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + n);
+        if (p.residual) v += *reinterpret_cast<const f32x4_t*>(p.residual + at);
+        if (p.out_relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (p.mask) {
+          const f32x4_t mv = *reinterpret_cast<const f32x4_t*>(p.mask + at);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = mv[r] > 0.f ? v[r] : 0.f;
+        }
+        if (p.add) v += *reinterpret_cast<const f32x4_t*>(p.add + at);
+        *reinterpret_cast<f32x4_t*>(p.C + at) = v;
+      }
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------- //
+struct Plan { bool ok; int slices, k_per_slice; Grid grid; };
+
+inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+// mode bits (SEEDHIP_X6, default 7): 1 Dense forward, 2 Dense data gradient, 4 Dense weight gradient
+inline int mode() { static const int m = env_int("SEEDHIP_X6", 7); return m; }
+
+// Served: operands of 16-byte aligned rows (ld % 4 == 0, K % 4 == 0, N % 4 == 0) below 2 GB each, and enough work
+// to fill the chip with 128 x 128 tiles; small GEMMs (recurrent steps, inference batches, the heads) stay on gemm.h.
+inline Plan plan(int M, int N, int K, long long a_bytes, long long b_bytes, bool must_split = false) {
+  Plan pl{false, 1, 0, {0, 0, 0}};
+  if (M < 256 || N < 128 || K < 64 || (K & 3) || (N & 3)) return pl;
+  if (a_bytes >= (1LL << 31) - 64 || b_bytes >= (1LL << 31) - 64) return pl;
+  const int mt = (M + BX - 1) / BX, nt = (N + BX - 1) / BX;
+  const long long tiles = (long long)mt * nt;
+  if (tiles > (1 << 20)) return pl;
+  // slices: fill 2 workgroups per CU; at least 8 k-tiles per slice
+  const int nkt = (K + BK - 1) / BK;
+  int s = 1;
+  static const int force = env_int("SEEDHIP_X6_SLICES", 0);
+  if (force > 0) s = force;
+  else if (tiles < 384) {
+    s = (int)((512 + tiles - 1) / tiles);
+    if (s > nkt / 8) s = nkt / 8;
+    if (s < 1) s = 1;
+  }
+  if (must_split && s < 2 && nkt >= 2) s = 2;
+  int per = (nkt + s - 1) / s;
+  s = (nkt + per - 1) / per;
+  pl.ok = true; pl.slices = s; pl.k_per_slice = per * BK;
+  pl.grid = Grid{mt, nt, s};
+  return pl;
+}
+inline size_t partial_bytes(int M, int N, const Plan& pl) { return pl.slices > 1 ? (size_t)pl.slices * M * N * sizeof(float) : 0; }
+
+template <bool AKC, bool BKC>
+inline void launch(Params p, const Plan& pl, hipStream_t s) {
+  p.k_per_slice = pl.k_per_slice;
+  const int blocks = pl.grid.mt * pl.grid.nt * pl.grid.slices;
+  static const int exp1 = env_int("SEEDHIP_X6_EXP", 0);
+  if (exp1 & 1) hipLaunchKernelGGL((xgemm_kernel<AKC, BKC, 1>), dim3(blocks), dim3(256), 0, s, p, pl.grid);
+  else hipLaunchKernelGGL((xgemm_kernel<AKC, BKC, 0>), dim3(blocks), dim3(256), 0, s, p, pl.grid);
+}
+
+}  // namespace xg
+}  // namespace seedhip

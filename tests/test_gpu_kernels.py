@@ -331,6 +331,9 @@ CONV_CASES = [
     (5, 9, 12, 16, 3, 3, 1, 'same', 32),      # weight gradient: one band per 9x12 image (6 dY prefetch vectors)
     (130, 9, 9, 64, 3, 3, 1, 'valid', 64),    # data gradient in image-block x position order: two blocks + a padded third, taps skipped at the border
     (70, 20, 20, 32, 4, 4, 2, 'valid', 64),   # the same for the stride-2 super-pixel GEMM (DQN conv2)
+    (1000, 1, 1, 68, 1, 1, 1, 'valid', 132),  # xgemm.h (bf16x6): ragged in M, N and K at once
+    (257, 1, 1, 100, 1, 1, 1, 'valid', 128),  # xgemm.h: one row past a tile, K = 3 k-tiles + 4
+    (640, 1, 1, 4100, 1, 1, 1, 'valid', 384), # xgemm.h: split-K forward / data gradient with a ragged last slice
 ]
 
 
@@ -513,6 +516,43 @@ def test_stack_conv_fwd_fp32_accuracy(device):
   e_hip = np.max(np.abs(dw.cpu().numpy().astype(np.float64) - g64))
   e_f32 = np.max(np.abs(w32.grad.numpy().astype(np.float64) - g64))
   assert e_hip <= max(2.0 * e_f32, 2e-6 * np.abs(g64).max()), (e_hip, e_f32, np.abs(g64).max())
+
+
+@pytest.mark.parametrize('n,cin,cout', [(1024, 2592, 256), (768, 3136, 512)])
+def test_x6_gemm_fp32_accuracy(device, n, cin, cout):
+  """The Dense kernels of xgemm.h evaluate fp32 x fp32 products on the bf16 matrix pipe through the exact three-way
+  operand split, keeping the six partial products above 2^-25 of a product.  They must be as close to an fp64
+  evaluation as an fp32 evaluation is: max error <= 2x that of torch's fp32 matmul on the same inputs (forward, data
+  gradient, weight gradient; K = 2592 / 3136 as in the Atari agents, reduction over n rows for the weight gradient)."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(cin)
+  x = rng.normal(size=(n, cin)).astype(np.float32)
+  w = (rng.normal(size=(cin, cout)) / np.sqrt(cin)).astype(np.float32)
+  b = rng.normal(size=cout).astype(np.float32)
+  dy = rng.normal(size=(n, cout)).astype(np.float32)
+  x64, w64, dy64 = x.astype(np.float64), w.astype(np.float64), dy.astype(np.float64)
+  tx, tw, tdy = torch.tensor(x), torch.tensor(w), torch.tensor(dy)
+  g = ops.dense_geom(n, cin, cout)
+  xd, wd, bd, dyd = dev(x, device), dev(w, device), dev(b, device), dev(dy, device)
+
+  def check(name, hip, f32, f64):
+    e_hip = np.max(np.abs(hip.astype(np.float64) - f64))
+    e_f32 = np.max(np.abs(f32.astype(np.float64) - f64))
+    scale = np.abs(f64).max()
+    print('x6 %s n=%d cin=%d cout=%d: err hip %.3e  torch fp32 %.3e  scale %.3e' % (name, n, cin, cout, e_hip, e_f32, scale))
+    assert e_hip <= max(2.0 * e_f32, 2e-6 * scale), (name, e_hip, e_f32, scale)
+
+  out = torch.empty((n, cout), device=device)
+  ops.conv2d_fwd(g, xd, wd, bd, out)
+  check('fwd', out.cpu().numpy(), (tx @ tw + torch.tensor(b)).numpy(), x64 @ w64 + b.astype(np.float64))
+  dx = torch.empty((n, cin), device=device)
+  ops.conv2d_bwd_data(g, dyd, wd, dx)
+  check('dgrad', dx.cpu().numpy(), (tdy @ tw.T).numpy(), dy64 @ w64.T)
+  dw = torch.empty((cin, cout), device=device); db = torch.empty(cout, device=device)
+  ws = torch.empty(ops.conv2d_bwd_weight_workspace_bytes(g) // 4 + 4, device=device)
+  ops.conv2d_bwd_weight(g, xd, dyd, dw, db, ws)
+  check('wgrad', dw.cpu().numpy(), (tx.T @ tdy).numpy(), x64.T @ dy64)
+  check('bias grad', db.cpu().numpy(), tdy.sum(0).numpy(), dy64.sum(0))
 
 
 @pytest.mark.parametrize('T1,B', [(3, 5), (6, 37)])
