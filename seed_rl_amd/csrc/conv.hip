@@ -601,3 +601,7 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
   return check_launch("conv2d_bwd_weight");
 }
 
+
+// Debug hook for tools/trace_x6.py: device buffer that xgemm_ws_kernel's probe builds (SEEDHIP_X6_WEXP & 128) fill with
+// s_memtime stamps of workgroup 0 ([4 roles][64 steps][8] 64-bit words).  Not part of the served API.
+extern "C" void seedhip_debug_x6_trace(void* device_buffer) { xg::trace_ptr() = (unsigned long long*)device_buffer; }
