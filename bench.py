@@ -37,6 +37,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0  # the same guide: 6.29 TB/s measured (float4 copy) -- the whole-step floor is priced with this
 MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA dense peak (v_mfma_f32_16x16x4_f32)
 MFMA_BF16_PEAK_TF = 2500.0 # bf16 dense MFMA peak (MI355X_MICROARCH.md; no sparsity)
 # Kernels that evaluate their fp32 algorithm on the bf16 pipe through the exact three-way operand split
@@ -76,6 +77,9 @@ def parse():
                   help="process group for --gpus > 1: nccl (= RCCL over xGMI, one rank per GPU) or gloo -- a DRY RUN of "
                        'the N-rank code path on fewer devices (ranks share GPUs, the exchange goes through host memory); '
                        'its throughput is not a scaling measurement and the line says so')
+  ap.add_argument('--force-exchange', action='store_true',
+                  help='run the N-replica launch mode (graph segments, asynchronous range all-reduces on the collective '
+                       'stream, update graph) even with ONE rank: the RCCL rehearsal of the multi-GPU line on a 1-GPU box')
   ap.add_argument('--quick', action='store_true',
                   help='only the timed learner step: no parity / other_configs / inference / ingest / cpu_baseline records')
   return ap.parse_args()
@@ -133,9 +137,38 @@ def vtrace_checks(dev):
   return err, err_ref, sweep
 
 
-def _peak(kernel):
-  bf16x3 = kernel in BF16X3_KERNELS and os.environ.get('SEEDHIP_STACK_BF16', '1') != '0'
-  return (MFMA_BF16_PEAK_TF / 3.0 if bf16x3 else MFMA_F32_PEAK_TF), bf16x3
+PIPES = {
+    'f32': (MFMA_F32_PEAK_TF, 'fp32 MFMA (v_mfma_f32_16x16x4_f32)'),
+    'bf16x3': (MFMA_BF16_PEAK_TF / 3.0, 'bf16 MFMA, exact 3-way split of the fp32 operand (the other is uint8): peak = 2500 / 3 '
+                                        'algorithmic TFLOP/s'),
+    'bf16x6': (MFMA_BF16_PEAK_TF / 6.0, 'bf16 MFMA, exact 3-way split of BOTH fp32 operands, six of the nine products (every '
+                                        'term above 2^-25 relative; csrc/xgemm.h): peak = 2500 / 6 algorithmic TFLOP/s'),
+}
+
+
+def _peak(entry):
+  """(peak algorithmic TFLOP/s, pipe description) of a Profiler.summary() entry."""
+  return PIPES[entry.get('pipe', 'f32')]
+
+
+def step_roofline(kern, ms_per_step):
+  """Whole-step roofline (VERDICT r3 task 4): sum over the step's kernels of max(algorithmic bytes / achievable HBM
+  rate, algorithmic flops / that kernel's pipe peak), divided by the measured step.  Bytes and flops are the figures
+  every ops.* wrapper states for its launch; the HBM rate is the chip's measured 6.3 TB/s
+  (MI355X_MICROARCH.md), not the 8 TB/s spec, so that the floor is one a kernel could actually reach."""
+  floor, parts = 0.0, {}
+  for k, v in kern.items():
+    t_hbm = v['bytes'] / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3
+    t_mfma = v['flops'] / (_peak(v)[0] * 1e12) * 1e3
+    f = max(t_hbm, t_mfma) * v['calls']
+    floor += f
+    if f >= 0.02 * ms_per_step or v['total_ms'] >= 0.02 * ms_per_step:
+      parts[k] = dict(floor_ms=round(f, 4), measured_ms=round(v['total_ms'], 4), bound='hbm' if t_hbm > t_mfma else 'mfma',
+                      pipe=v.get('pipe', 'f32'))
+  return dict(floor_ms=round(floor, 4), ms_per_step=round(ms_per_step, 4), frac=round(floor / ms_per_step, 4),
+              hbm_GBs=HBM_ACHIEVABLE_GBS, kernels=parts,
+              note='sum over kernels of max(algorithmic bytes / 6.3 TB/s, algorithmic flops / pipe peak) / ms_per_step; '
+                   'measured_ms is the serialized attribution pass (sums above the free-running step)')
 
 
 def _release():
@@ -145,7 +178,7 @@ def _release():
   torch.cuda.empty_cache()
 
 
-def build_workload(config, torso, T, B, A, dev, reduction, graph, world, seed):
+def build_workload(config, torso, T, B, A, dev, reduction, graph, world, seed, force_exchange=False):
   """Agent + learner + one synthetic unroll resident in HBM for a BASELINE config."""
   from seed_rl_amd import learner, networks, optimizers, parametric_distribution as pd, smoke_step
   T1 = T + 1
@@ -179,18 +212,19 @@ def build_workload(config, torso, T, B, A, dev, reduction, graph, world, seed):
     unroll = unroll._replace(env_outputs=unroll.env_outputs._replace(
         observation=ext[3:].view(T1, B, agent._obs[0], agent._obs[1], 1)))
     workload = 'Atari 84x84x4 IMPALA %s ConvNet learner step' % torso
-  lrn = learner.Learner(agent, opt, pd.categorical_distribution(A), reduction=reduction)
+  lrn = learner.Learner(agent, opt, pd.categorical_distribution(A), reduction=reduction, force_exchange=force_exchange)
   return agent, lrn, unroll, extra, workload
 
 
 def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, torso='shallow', batch=0, unroll_len=0,
-                actions=0, reduction='mean', graph=1, attribution_steps=3):
+                actions=0, reduction='mean', graph=1, attribution_steps=3, force_exchange=False):
   """Times `steps` learner steps of one BASELINE config; returns the record the JSON line is built from."""
   from seed_rl_amd import learner, ops
   T = unroll_len or (120 if config == 'r2d2' else 20)
   B = batch or (256 if config in ('dmlab', 'r2d2') else 512)
   A = actions or (9 if config == 'dmlab' else 18)
-  agent, lrn, unroll, extra, workload = build_workload(config, torso, T, B, A, dev, reduction, graph, world, 1000 + rank)
+  agent, lrn, unroll, extra, workload = build_workload(config, torso, T, B, A, dev, reduction, graph, world, 1000 + rank,
+                                                       force_exchange and config != 'r2d2')
 
   def barrier():
     if distributed:
@@ -254,7 +288,7 @@ def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, 
       lrn.minimize(unroll, *extra)
     ops.set_profiler(None)
   exchange = None
-  if world > 1:
+  if world > 1 or (force_exchange and distributed):
     # per-rank wall time of the timed region, then its maximum (the contract's clock)
     mine = torch.tensor([dt], device=dev, dtype=torch.float64)
     every = [torch.zeros_like(mine) for _ in range(world)]
@@ -298,12 +332,11 @@ def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, 
     d = dict(d, avg_ms=1e-6); free = dict(free, avg_ms=1e-6)
   flops, nbytes = d['flops'], d['bytes']
   if flops > 0:
-    peak, bf16x3 = _peak(dominant)
+    peak, pipe_desc = _peak(d)
     ach, ach_free = flops / (d['avg_ms'] * 1e-3) / 1e12, flops / (free['avg_ms'] * 1e-3) / 1e12
     roofline = dict(bound='mfma', kernel=dominant, achieved=round(ach, 2), peak=round(peak, 1),
                     unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
-                    pipe=('bf16 MFMA, exact 3-way split of the fp32 operand: peak = 2500 / 3 algorithmic TFLOP/s'
-                          if bf16x3 else 'fp32 MFMA (v_mfma_f32_16x16x4_f32)'),
+                    pipe=pipe_desc,
                     algorithmic_flops=flops, algorithmic_bytes=nbytes)
   else:
     peak = HBM_PEAK_GBS
@@ -319,11 +352,12 @@ def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, 
   rec = dict(
       T=T, B=B, A=A, workload=workload, mode=mode, params=agent.flat.num_params(), loss=loss_val,
       ms_per_step=dt / steps * 1e3, frames_per_s=world * B * T / (dt / steps), roofline=roofline, dominant=dominant,
+      step_roofline=step_roofline(kern, dt / steps * 1e3),
       kernels_ms_per_step={k: round(v['total_ms'], 4) for k, v in kern.items()}, exchange=exchange,
       # the other MFMA kernels of the attribution pass (>= 50 us per launch), same (serialized) accounting as `roofline`
       mfma_kernels={
           k: dict(avg_ms=round(v['avg_ms'], 4), tflops=round(v['flops'] / (v['avg_ms'] * 1e-3) / 1e12, 1),
-                  frac=round(v['flops'] / (v['avg_ms'] * 1e-3) / 1e12 / _peak(k)[0], 3))
+                  frac=round(v['flops'] / (v['avg_ms'] * 1e-3) / 1e12 / _peak(v)[0], 3), pipe=v.get('pipe', 'f32'))
           for k, v in kern.items() if v['flops'] > 0 and v['avg_ms'] >= 0.05})
   del agent, lrn, unroll, extra
   _release()
@@ -549,7 +583,7 @@ def main():
   dev_index = local_rank % ndev
   torch.cuda.set_device(dev_index)
   dev = torch.device('cuda', dev_index)
-  distributed = world > 1 or 'RANK' in os.environ       # launched by torch.distributed.run (also at N=1)
+  distributed = world > 1 or 'RANK' in os.environ or args.force_exchange   # launched by torch.distributed.run (also at N=1)
   if distributed:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
@@ -561,7 +595,7 @@ def main():
   deep, r2 = args.config == 'dmlab', args.config == 'r2d2'
 
   rec = run_learner(args.config, args.steps, args.warmup, dev, rank, world, distributed, args.torso, args.batch,
-                    args.unroll, args.actions, args.reduction, args.graph)
+                    args.unroll, args.actions, args.reduction, args.graph, force_exchange=args.force_exchange)
   T, B, A = rec['T'], rec['B'], rec['A']
   roofline = rec['roofline']
   headline = args.config == 'atari' and args.torso == 'shallow' and B == 512 and T == 20 and A == 18
@@ -569,13 +603,21 @@ def main():
   # HBM traffic of the dominant kernel from the committed PMC passes (same config only; latest profiling round)
   tfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_cfg2_traffic.json')))
   if headline and tfiles:
+    from seed_rl_amd import build as _build
     tj = json.load(open(tfiles[-1]))
     tb = tj['traffic_bytes']
-    if rec['dominant'] in tb:
+    here = _build.csrc_digest()
+    fresh = tj.get('csrc_sha256') == here
+    stamp = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; taken at git %s, kernel sources sha256 %s)' % (
+        os.path.basename(tfiles[-1]), (tj.get('git_sha') or 'unrecorded')[:12], (tj.get('csrc_sha256') or 'unrecorded')[:12])
+    if not fresh:
+      # the committed counters describe OTHER kernels than the ones this run timed: say so instead of printing them
+      roofline['traffic'] = None
+      roofline['traffic_source'] = stamp + ' -- STALE: this tree\'s kernel sources hash to %s; traffic withheld' % here[:12]
+    elif rec['dominant'] in tb:
       roofline['traffic'] = tb[rec['dominant']]
-      roofline['traffic_source'] = ('profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'
-                                    % os.path.basename(tfiles[-1]))
-    if rec['dominant'] in tj.get('mfma_pmc', {}):
+      roofline['traffic_source'] = stamp
+    if fresh and rec['dominant'] in tj.get('mfma_pmc', {}):
       # the matrix pipe's busy share from the SQ counters of the committed profiling round (same kernel, same shape)
       roofline['mfma_pmc'] = tj['mfma_pmc'][rec['dominant']]
   if rank != 0:
@@ -593,6 +635,7 @@ def main():
                  'ingest': 'resident (unroll in HBM before the timed region)',
                  'process_group': (('rccl' if args.backend == 'nccl' else 'gloo') if distributed else None)},
       'roofline': roofline,
+      'step_roofline': rec['step_roofline'],
       'exchange': rec['exchange'],
       'loss': round(rec['loss'], 6),
       'kernels_ms_per_step': rec['kernels_ms_per_step'],
@@ -630,6 +673,7 @@ def main():
               ms_per_step=round(r['ms_per_step'], 3), env_frames_per_s=round(r['frames_per_s'], 1), launch=r['mode'],
               roofline={k: r['roofline'][k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
                                                       'frac_free_running', 'avg_kernel_ms')},
+              step_roofline={k: r['step_roofline'][k] for k in ('floor_ms', 'frac')},
               loss=round(r['loss'], 6))
           # one train step at THAT shape against the CPU oracle (tests/test_gpu_fullsize.py runs the same comparison)
           pf = parity.deep_step if cfg == 'dmlab' else parity.r2d2_step
@@ -690,19 +734,45 @@ def main():
       cb = args.cpu_batch or 16
       fps, sec, thr = cpu_learner.time_cpu_deep_learner(A, T1, cb, steps=CS, warmup=CW)
     else:
-      cb = args.cpu_batch or 256
+      cb = args.cpu_batch or B              # the quoted configuration itself (B=512: ~2 s per step on 128 threads)
       kind = 'atari_shallow' if args.torso == 'shallow' else 'atari_dqn_body'
       fps, sec, thr = cpu_learner.time_cpu_learner(kind, A, T1, cb, steps=CS, warmup=CW)
     result['cpu_baseline'] = {
         'value': round(fps, 1), 'unit': 'env-frames/s', 'cores': thr, 'kind': 'port',
         'sample': 'same learner step as eager PyTorch-CPU fp32 restatement of the reference graph '
-                  '(oracle/cpu_learner.py; NOT the reference\'s TF graph), T=%d B=%d (a bounded sample of the workload: whole columns, same T), '
+                  '(oracle/cpu_learner.py; NOT the reference\'s TF graph), T=%d B=%d (%s), '
                   '%d warm-up steps then the median of %d timed steps (BASELINE.md section 3), %.2f s/step; '
-                  'host cpu_count=%d, torch threads=%d' % (T, cb, CW, CS, sec, os.cpu_count(), thr)}
+                  'host cpu_count=%d, torch threads=%d' % (
+                      T, cb, 'the benched configuration itself' if cb == B else 'a bounded sample of the workload: whole columns, same T',
+                      CW, CS, sec, os.cpu_count(), thr)}
     result['speedup_vs_cpu_baseline'] = round(rec['frames_per_s'] / fps, 1)
-  print(json.dumps(result))
+  # the numbers the driver's tail (last ~2000 characters of stdout) must keep: repeated compactly as the LAST key
+  tail = {'cfg2': dict(ms_per_step=result['ms_per_step'], env_frames_per_s=result['value'],
+                       dominant=roofline['kernel'], frac=roofline['frac'], step_frac=rec['step_roofline']['frac'],
+                       step_floor_ms=rec['step_roofline']['floor_ms'])}
+  for name, key in (('dmlab', 'cfg3'), ('r2d2', 'cfg5')):
+    o = result.get('other_configs', {}).get(name)
+    if o and 'ms_per_step' in o:
+      tail[key] = dict(ms_per_step=o['ms_per_step'], env_frames_per_s=o['env_frames_per_s'],
+                       dominant=o['roofline']['kernel'], frac=o['roofline']['frac'], step_frac=o.get('step_roofline', {}).get('frac'))
+    elif o:
+      tail[key] = dict(error=o.get('error'))
+  sv = result.get('serving') or {}
+  if 'inprocess' in sv:
+    tail['serving'] = dict(inprocess=sv['inprocess'].get('env_steps_per_s_served'),
+                           transport=(sv.get('transport') or {}).get('env_steps_per_s_served'))
+  if 'cpu_baseline' in result:
+    tail['cpu_baseline'] = dict(value=result['cpu_baseline']['value'], B=cb, speedup=result['speedup_vs_cpu_baseline'])
+  if result.get('exchange'):
+    tail['exchange'] = dict(backend=result['exchange']['backend'], ranks=result['exchange']['ranks'],
+                            exposed_ms_per_step=result['exchange']['exposed_ms_per_step'])
+  result['tail_summary'] = tail
+  # the process group is torn down BEFORE the line is printed: RCCL writes to stdout on teardown ("Librccl path : ...")
+  # and the JSON line must stay the last line
   if distributed:
     torch.distributed.destroy_process_group()
+  sys.stdout.flush()
+  print(json.dumps(result), flush=True)
 
 
 if __name__ == '__main__':

@@ -31,7 +31,7 @@ extern "C" {
  * (seedhip_adam_flat*, seedhip_inference_pre/post signatures, impala-loss workspace size); 3 = round 3.
  * Bindings must compare seedhip_abi_version() with the version they were written against before the first call
  * (seed_rl_amd/_lib.py does): a stale library would otherwise be called with shifted arguments. */
-#define SEEDHIP_ABI_VERSION 3
+#define SEEDHIP_ABI_VERSION 4
 
 const char* seedhip_last_error(void);
 int seedhip_abi_version(void);
@@ -186,6 +186,10 @@ size_t seedhip_conv2d_bwd_data_workspace_bytes(const seedhip_conv_geom* geom);
 int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
                                const float* relu_mask, const float* add, void* workspace, size_t workspace_bytes,
                                void* stream);
+/* Which matrix pipe serves this geometry; pass 0 forward, 1 data gradient, 2 weight gradient.  Returns 1 = fp32 MFMA,
+ * 6 = bf16 MFMA through the exact three-way split of both fp32 operands (six bf16 MACs per algorithmic MAC: ceiling
+ * 2500 / 6 algorithmic TFLOP/s); 0 on a null geometry / unknown pass.  Reporting only (bench.py's roofline). */
+int seedhip_conv2d_pipe(const seedhip_conv_geom* geom, int pass);
 size_t seedhip_conv2d_bwd_weight_workspace_bytes(const seedhip_conv_geom* geom);
 /* dw[kh,kw,cin,cout] and dbias[cout] (dbias may be NULL) are OVERWRITTEN. */
 int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const void* in, int in_dtype, int in_relu,

@@ -15,7 +15,7 @@ import torch  # noqa: F401  pylint: disable=unused-import
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEEDHIP_LIB: another build of the same library (same-box A/B runs of two builds; nothing else changes: no fallback)
 LIB_PATH = os.environ.get('SEEDHIP_LIB') or os.path.join(_HERE, 'lib', 'libseedhip.so')
-ABI_VERSION = 3          # include/seedhip.h SEEDHIP_ABI_VERSION this binding was written against
+ABI_VERSION = 4          # include/seedhip.h SEEDHIP_ABI_VERSION this binding was written against
 
 c_int, c_ll, c_float, c_size_t, c_void_p = (
     ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p)
@@ -72,6 +72,7 @@ SIGNATURES = {
     'seedhip_stack_pack_state_indexed': (c_int, [P, P, c_int, c_int, c_ll, P, P, P, P]),
     'seedhip_conv2d_fwd': (c_int, [ctypes.POINTER(ConvGeom), P, c_int, c_int, P, P, P, c_int, P, P]),
     'seedhip_conv2d_bwd_data': (c_int, [ctypes.POINTER(ConvGeom), P, P, P, P, P, P]),
+    'seedhip_conv2d_pipe': (c_int, [ctypes.POINTER(ConvGeom), c_int]),
     'seedhip_conv2d_fwd_workspace_bytes': (c_size_t, [ctypes.POINTER(ConvGeom)]),
     'seedhip_conv2d_fwd_ws': (c_int, [ctypes.POINTER(ConvGeom), P, c_int, c_int, P, P, P, c_int, P, P, c_size_t, P]),
     'seedhip_conv2d_bwd_data_workspace_bytes': (c_size_t, [ctypes.POINTER(ConvGeom)]),

@@ -17,5 +17,22 @@ def build(verbose=False, jobs=None):
   return os.path.join(_HERE, 'lib', 'libseedhip.so')
 
 
+def csrc_digest():
+  """sha256 over the HIP sources libseedhip.so is built from (names + contents, sorted): what a committed hardware
+  profile is stamped with, so that bench.py can tell whether `profiles/*_traffic.json` still describes HEAD's kernels."""
+  import hashlib
+  h = hashlib.sha256()
+  d = os.path.join(_HERE, 'csrc')
+  for name in sorted(os.listdir(d)):
+    if name.endswith(('.hip', '.h', '.cpp')):
+      h.update(name.encode())
+      with open(os.path.join(d, name), 'rb') as f:
+        h.update(f.read())
+  return h.hexdigest()
+
+
 if __name__ == '__main__':
-  print(build(verbose=True))
+  if len(sys.argv) > 1 and sys.argv[1] == 'digest':
+    print(csrc_digest())
+  else:
+    print(build(verbose=True))

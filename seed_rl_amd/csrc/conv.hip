@@ -149,6 +149,16 @@ int check_geom(const seedhip_conv_geom* g, const char* what) {
 
 }  // namespace
 
+// Which matrix pipe serves this geometry (pass 0 forward, 1 data gradient, 2 weight gradient): 1 = fp32 MFMA
+// (v_mfma_f32_16x16x4_f32), 6 = bf16 MFMA through the exact three-way split of both operands (xgemm.h: six bf16 MACs per
+// algorithmic MAC).  What the bench prices a kernel's roofline with; 0 = unknown pass / null geometry.
+extern "C" int seedhip_conv2d_pipe(const seedhip_conv_geom* g, int pass) {
+  if (!g || pass < 0 || pass > 2) return 0;
+  if (!(xg::mode() & (1 << pass))) return 1;
+  const xg::Plan xp = pass == 0 ? x6_fwd_plan(g) : pass == 1 ? x6_dgrad_plan(g) : x6_wgrad_plan(g);
+  return xp.ok ? 6 : 1;
+}
+
 extern "C" size_t seedhip_conv2d_fwd_workspace_bytes(const seedhip_conv_geom* g) {
   if (!g || !is_dense(g)) return 0;
   const int sl = dense_slices(g->n_img, g->cout, g->cin);

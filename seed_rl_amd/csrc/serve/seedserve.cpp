@@ -365,6 +365,27 @@ std::string verify_args(const std::vector<Spec>& specs, int batching_dims, const
   return "";
 }
 
+// Dry run of copy_rows' parse: true iff copying `count` rows of this argument cannot fail.  Called BEFORE rows are
+// reserved (a request whose tensor bytes are malformed -- tensor_content of the wrong length, a truncated
+// *_val run -- must be answered INVALID_ARGUMENT like the reference's Tensor::FromProto failure (grpc.cc:176-182) and
+// must never reach a batch: the rows it had reserved kept an EARLIER batch's bytes -- another env's observation and
+// run id -- and were computed on).
+bool payload_ok(const Spec& s, const TensorView& a, int count) {
+  const int64_t n = (int64_t)count * s.row_elems;
+  if (a.content && a.content_len == (size_t)(n * s.wire_size)) return true;
+  if (a.content_len != 0) return false;
+  if (!a.vals) return true;                                  // no values at all: zeros
+  Reader r(a.vals, a.vals_len);
+  for (int64_t i = 0; i < n && !r.done(); ++i) {
+    switch (a.vals_field) {
+      case 5: if (r.end - r.p < 4) return false; r.p += 4; break;
+      case 6: if (r.end - r.p < 8) return false; r.p += 8; break;
+      default: (void)r.varint(); if (!r.ok) return false;
+    }
+  }
+  return true;
+}
+
 // Copies `count` rows of one argument into the batch buffer at row `start` (the ONE copy of the tensor bytes).
 bool copy_rows(const Spec& s, const TensorView& a, void* base, int start, int count) {
   const int64_t n = (int64_t)count * s.row_elems;
@@ -433,6 +454,15 @@ int place(Server_* srv, Fn* fn, Request& rq, bool* counted) {
   bool ok = true;
   for (size_t i = 0; i < rq.args.size() && ok; ++i)
     ok = copy_rows(fn->in[i], rq.args[i], fn->inbuf[(size_t)slot * fn->in.size() + i], start, rq.count);
+  if (!ok) {
+    // cannot happen after handle_call's payload_ok(); if it ever does, the reserved rows must not keep an earlier
+    // batch's bytes: zero them in every argument (the caller still gets its slice of the result)
+    for (size_t i = 0; i < rq.args.size(); ++i) {
+      const Spec& sp = fn->in[i];
+      memset((uint8_t*)fn->inbuf[(size_t)slot * fn->in.size() + i] + (int64_t)start * sp.row_elems * sp.store_size, 0,
+             (size_t)((int64_t)rq.count * sp.row_elems * sp.store_size));
+    }
+  }
   bool full;
   {
     std::lock_guard<std::mutex> l(fn->mu);
@@ -442,7 +472,7 @@ int place(Server_* srv, Fn* fn, Request& rq, bool* counted) {
     full = s.num_ready == fn->N;
     if (full) { s.state = Slot::READY; fn->ready.push_back(slot); }
   }
-  if (!ok) srv->n_err++;                                      // malformed tensor bytes: rows stay as they are
+  if (!ok) srv->n_err++;
   if (full) { srv->n_batch++; fn->cv.notify_all(); *counted = true; }
   return 1;
 }
@@ -504,6 +534,12 @@ void handle_call(Server_* srv, Conn* c, int32_t stream_id, const uint8_t* data, 
   }
   rq.direct = direct;
   if (!err.empty()) { srv->n_err++; respond(srv, to, error_response(INVALID_ARGUMENT, err)); return; }
+  for (size_t i = 0; i < rq.args.size(); ++i)
+    if (!payload_ok(fn->in[i], rq.args[i], rq.count)) {      // before any row is reserved
+      srv->n_err++;
+      respond(srv, to, error_response(INVALID_ARGUMENT, "Cannot parse TensorProto."));
+      return;
+    }
   bool counted = false;
   place(srv, fn, rq, &counted);
   if (counted) bk->counter++;

@@ -687,6 +687,11 @@ inline int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 // mode bits (SEEDHIP_X6, default 7): 1 Dense forward, 2 Dense data gradient, 4 Dense weight gradient
 inline int mode() { static const int m = env_int("SEEDHIP_X6", 7); return m; }
 
+inline int cu_count() {
+  static const int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
+  return n;
+}
+
 // Served: operands of 16-byte aligned rows (ld % 4 == 0, K % 4 == 0, N % 4 == 0) below 2 GB each, and enough work
 // to fill the chip with 128 x 128 tiles; small GEMMs (recurrent steps, inference batches, the heads) stay on gemm.h.
 inline Plan plan(int M, int N, int K, long long a_bytes, long long b_bytes, bool must_split = false) {
@@ -696,15 +701,26 @@ inline Plan plan(int M, int N, int K, long long a_bytes, long long b_bytes, bool
   const int mt = (M + BX - 1) / BX, nt = (N + BX - 1) / BX;
   const long long tiles = (long long)mt * nt;
   if (tiles > (1 << 20)) return pl;
-  // slices: fill 2 workgroups per CU; at least 8 k-tiles per slice
+  // slices: the kernel holds 200 registers per lane = two workgroups per CU, so the chip runs 2 x CUs workgroups at a
+  // time and a grid of 1.3 such rounds costs two (r4: the forward's 672 workgroups on 512 slots took two rounds of
+  // 21 k-tiles where 504 take one of 27).  Cost of s slices ~ rounds(tiles * s) * (k-tiles per slice + kFixed), the
+  // fixed part being a workgroup's prologue and epilogue, plus the partial sums' round trip; at least 8 k-tiles each.
   const int nkt = (K + BK - 1) / BK;
   int s = 1;
   static const int force = env_int("SEEDHIP_X6_SLICES", 0);
   if (force > 0) s = force;
-  else if (tiles < 384) {
-    s = (int)((512 + tiles - 1) / tiles);
-    if (s > nkt / 8) s = nkt / 8;
-    if (s < 1) s = 1;
+  else {
+    const long long slots = 2LL * cu_count();
+    const double kFixed = 6.0, us_per_ktile = 2.0, bytes_per_us = 4.0e6;   // measured on the cfg2 / cfg5 Dense shapes
+    int smax = nkt / 8; if (smax > 64) smax = 64; if (smax < 1) smax = 1;
+    double best = -1.0;
+    for (int c = 1; c <= smax; ++c) {
+      const int per = (nkt + c - 1) / c;
+      const long long rounds = (tiles * c + slots - 1) / slots;
+      double cost = (double)rounds * (per + kFixed) * us_per_ktile;
+      if (c > 1) cost += (double)(c + 1) * M * N * 4.0 / bytes_per_us;     // the partial sums' round trip
+      if (best < 0.0 || cost < best) { best = cost; s = c; }
+    }
   }
   if (must_split && s < 2 && nkt >= 2) s = 2;
   int per = (nkt + s - 1) / s;
@@ -716,16 +732,12 @@ inline Plan plan(int M, int N, int K, long long a_bytes, long long b_bytes, bool
 inline size_t partial_bytes(int M, int N, const Plan& pl) { return pl.slices > 1 ? (size_t)pl.slices * M * N * sizeof(float) : 0; }
 
 inline unsigned long long*& trace_ptr() { static unsigned long long* p = nullptr; return p; }
-inline int cu_count() {
-  static const int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
-  return n;
-}
 
 template <bool AKC, bool BKC>
 inline void launch(Params p, const Plan& pl, hipStream_t s) {
   p.k_per_slice = pl.k_per_slice;
   const int blocks = pl.grid.mt * pl.grid.nt * pl.grid.slices;
-  static const int ws = env_int("SEEDHIP_X6_WS", 1);
+  static const int ws = env_int("SEEDHIP_X6_WS", 0);
   if (ws) {
     // persistent wave-specialised kernel: one 512-thread workgroup per CU, grid a multiple of 8 (XCD round robin)
     int grid = cu_count() & ~7; if (grid < 8) grid = 8;

@@ -118,14 +118,14 @@ def shard_columns(num_columns, rank, world):
   return slice(rank * per, (rank + 1) * per)
 
 
-def all_reduce_gradients(flat_grads, process_group=None):
+def all_reduce_gradients(flat_grads, process_group=None, force=False):
   """The one exchange step of a train step: SUM of the flat fp32 gradient bucket over the replicas
   (RCCL over xGMI on GPUs; the reference does this implicitly inside Keras apply_gradients on TPU,
   learner.py:272-275).  With reduction='mean' each replica has already divided its loss by the GLOBAL
   number of (t,b) elements, so the sum equals the single-replica gradient of the global batch; with
   'sum' it reproduces the reference's cross-replica gradient SUM (tests/utils_test.py:609-650)."""
   if torch.distributed.is_available() and torch.distributed.is_initialized() and \
-      torch.distributed.get_world_size(process_group) > 1:
+      (force or torch.distributed.get_world_size(process_group) > 1):
     torch.distributed.all_reduce(flat_grads, op=torch.distributed.ReduceOp.SUM, group=process_group)
   return flat_grads
 
@@ -135,7 +135,7 @@ class Learner(object):
   gradient all-reduce + Adam (learner.py:255-280)."""
 
   def __init__(self, agent, optimizer, parametric_action_distribution, config=None,
-               reduction='mean', process_group=None, logger=None):
+               reduction='mean', process_group=None, logger=None, force_exchange=False):
     """reduction: 'mean' -> the summed gradient equals a single-replica step at the
     global batch (what matches the reference CPU learner on identical trajectories);
     'sum' -> the reference's multi-replica semantics: per-replica mean losses, gradients
@@ -150,6 +150,9 @@ class Learner(object):
     self.world = 1
     if torch.distributed.is_available() and torch.distributed.is_initialized():
       self.world = torch.distributed.get_world_size(process_group)
+    if force_exchange and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+      raise ValueError('force_exchange needs an initialised process group')
+    self.exchanging = self.world > 1 or bool(force_exchange)
     self._pending = []
     # learner.py:225-234: an agent without an entropy_cost of its own gets the learnable one
     if hasattr(agent, 'has_own_entropy_cost') and not agent.has_own_entropy_cost():
@@ -162,7 +165,7 @@ class Learner(object):
     loss, session = compute_loss(self.logger, self.dist, self.agent, *unroll, config=self.config,
                                  mean_denominator=n)
     self._pending = []
-    self.agent.grad_ready_hook = self._on_grads_ready if self.world > 1 else None
+    self.agent.grad_ready_hook = self._on_grads_ready if self.exchanging else None
     try:
       self.agent.backward()
     finally:
@@ -176,7 +179,7 @@ class Learner(object):
   # exchange of the conv gradients stays exposed.  Ranges that were never reported (agents without hooks, HIP-graph
   # capture) are exchanged in reduce_gradients(): the result is always the SUM of the whole bucket.
   def _on_grads_ready(self, lo, hi):
-    if self.world <= 1 or hi <= lo:
+    if not self.exchanging or hi <= lo:
       return
     if self.agent.flat.grads.is_cuda and torch.cuda.is_current_stream_capturing():
       cut = getattr(self, '_capture_cut', None)          # GraphedStep (data parallel): end this graph segment here
@@ -192,14 +195,14 @@ class Learner(object):
     n = self.agent.flat.grads.numel()
     for _, _, work in pending:
       work.wait()
-    if self.world <= 1:
+    if not self.exchanging:
       return
     covered, pos = sorted((lo, hi) for lo, hi, _ in pending), 0
     for lo, hi in covered + [(n, n)]:
       if lo < pos:
         raise RuntimeError('overlapping gradient ranges reported by the agent: [%d, %d) after %d' % (lo, hi, pos))
       if lo > pos:
-        all_reduce_gradients(self.agent.flat.grads[pos:lo], self.pg)
+        all_reduce_gradients(self.agent.flat.grads[pos:lo], self.pg, force=True)
       pos = max(pos, hi)
 
   def update(self):
@@ -256,7 +259,7 @@ class GraphedStep(object):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     opt.begin_step(learner.agent.flat.params.device)
-    self.split = getattr(learner, 'world', 1) > 1
+    self.split = bool(getattr(learner, 'exchanging', getattr(learner, 'world', 1) > 1))
     self.graph = torch.cuda.CUDAGraph()
     self.graph2 = None
     if not self.split:

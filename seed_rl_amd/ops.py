@@ -1,5 +1,6 @@
 """Thin torch-tensor wrappers over the C ABI (pointers + sizes only cross it)."""
 import collections
+import os
 import contextlib
 import ctypes
 
@@ -25,6 +26,7 @@ class Profiler(object):
     self.only = set(only) if only is not None else None
     self.events = collections.OrderedDict()
     self.meta = {}
+    self.pipes = {}
 
   @staticmethod
   def event_overhead_ms(n=50, serialize=False):
@@ -54,7 +56,7 @@ class Profiler(object):
       # code-object load (seen: 0.34 ms for a 15 us kernel) must not re-rank the kernels or move a roofline fraction
       med = ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2])
       out[name] = dict(calls=len(ms), total_ms=med * len(ms), avg_ms=med, mean_ms=sum(ms) / len(ms), flops=flops,
-                       bytes=nbytes)
+                       bytes=nbytes, pipe=self.pipes.get(name, 'f32'))
     return out
 
 
@@ -67,7 +69,9 @@ def set_profiler(p):
 
 
 @contextlib.contextmanager
-def _region(name, flops=0, nbytes=0):
+def _region(name, flops=0, nbytes=0, pipe='f32'):
+  """pipe: what bounds the region's flops -- 'f32' (fp32 MFMA), 'bf16x3' / 'bf16x6' (bf16 MFMA through the exact
+  operand splits: 3 / 6 bf16 MACs per algorithmic MAC); bench.py prices rooflines with it."""
   p = _PROFILER
   if p is None or (p.only is not None and name not in p.only):
     yield
@@ -80,10 +84,19 @@ def _region(name, flops=0, nbytes=0):
   e.record()
   p.events.setdefault(name, []).append((s, e))
   p.meta[name] = (flops, nbytes)
+  p.pipes[name] = pipe() if callable(pipe) else pipe
 
 
 def _conv_name(kind, g):
   return '%s[%dx%d/%d %d->%d @%dx%d]' % (kind, g.kh, g.kw, g.stride, g.cin, g.cout, g.ih, g.iw)
+
+
+def _conv_pipe(g, which):
+  return 'bf16x6' if _lib.lib().seedhip_conv2d_pipe(ctypes.byref(g), which) == 6 else 'f32'
+
+
+def _stack_pipe():
+  return 'f32' if os.environ.get('SEEDHIP_STACK_BF16', '1') == '0' else 'bf16x3'
 
 
 def _conv_cost(g, in_bytes_per_el=4):
@@ -133,7 +146,7 @@ def _splitk_ws(nbytes, like):
 
 
 def conv2d_fwd(g, x, w, bias, out, in_dtype=IN_F32, in_relu=False, out_relu=False, residual=None):
-  with _region(_conv_name('conv_fwd', g), *_conv_cost(g, 1 if in_dtype else 4)):
+  with _region(_conv_name('conv_fwd', g), *_conv_cost(g, 1 if in_dtype else 4), pipe=lambda: _conv_pipe(g, 0)):
     with _dev(out):
       ws, wsb = _splitk_ws(int(_lib.lib().seedhip_conv2d_fwd_workspace_bytes(ctypes.byref(g))), out)
       _lib.check(_lib.lib().seedhip_conv2d_fwd_ws(
@@ -160,7 +173,7 @@ def conv2d_bwd_data(g, dy, w, dx, relu_mask=None, add=None, relu_bits=None):
             ctypes.byref(g), _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(relu_bits), _lib.stream()),
             'seedhip_conv2d_bwd_data_bits')
       return dx
-  with _region(_conv_name('conv_dgrad', g), flops, nbytes):
+  with _region(_conv_name('conv_dgrad', g), flops, nbytes, pipe=lambda: _conv_pipe(g, 1)):
     with _dev(dx):
       ws, wsb = _splitk_ws(int(_lib.lib().seedhip_conv2d_bwd_data_workspace_bytes(ctypes.byref(g))), dx)
       _lib.check(_lib.lib().seedhip_conv2d_bwd_data_ws(
@@ -174,7 +187,7 @@ def conv2d_bwd_weight_workspace_bytes(g):
 
 
 def conv2d_bwd_weight(g, x, dy, dw, dbias, workspace, in_dtype=IN_F32, in_relu=False):
-  with _region(_conv_name('conv_wgrad', g), *_conv_cost(g, 1 if in_dtype else 4)):
+  with _region(_conv_name('conv_wgrad', g), *_conv_cost(g, 1 if in_dtype else 4), pipe=lambda: _conv_pipe(g, 2)):
     with _dev(dw):
       _lib.check(_lib.lib().seedhip_conv2d_bwd_weight(
           ctypes.byref(g), _lib.ptr(x), in_dtype, int(in_relu), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(dbias),
@@ -237,7 +250,7 @@ def conv2d_stack_fwd_bits_supported(g):
 def conv2d_stack_fwd(g, frames_ext, nvalid, w, bias, out, out_relu=True, relu_bits=None):
   """relu_bits (uint8 [T * B * oh * ow, ld_out / 4], where conv2d_stack_fwd_bits_supported): also receives the ReLU mask
   of `out` as bytes, for conv2d_bwd_data(..., relu_bits=) of the next layer."""
-  with _region('stack_conv_fwd', 2.0 * g.T * g.B * g.oh * g.ow * g.cout * g.kh * g.kw * 4, g.T * g.B * g.ih * g.iw + g.T * g.B * g.oh * g.ow * g.cout * 4):
+  with _region('stack_conv_fwd', 2.0 * g.T * g.B * g.oh * g.ow * g.cout * g.kh * g.kw * 4, g.T * g.B * g.ih * g.iw + g.T * g.B * g.oh * g.ow * g.cout * 4, pipe=_stack_pipe):
     with _dev(out):
       if relu_bits is not None:
         if not out_relu:
@@ -256,7 +269,7 @@ def conv2d_stack_bwd_weight_workspace_bytes(g):
 
 
 def conv2d_stack_bwd_weight(g, frames_ext, nvalid, dy, dw, dbias, workspace):
-  with _region('stack_conv_wgrad', 2.0 * g.T * g.B * g.oh * g.ow * g.cout * g.kh * g.kw * 4, g.T * g.B * g.ih * g.iw + g.T * g.B * g.oh * g.ow * g.cout * 4):
+  with _region('stack_conv_wgrad', 2.0 * g.T * g.B * g.oh * g.ow * g.cout * g.kh * g.kw * 4, g.T * g.B * g.ih * g.iw + g.T * g.B * g.oh * g.ow * g.cout * 4, pipe=_stack_pipe):
     with _dev(dw):
       _lib.check(_lib.lib().seedhip_conv2d_stack_bwd_weight(
           ctypes.byref(g), _lib.ptr(frames_ext), _lib.ptr(nvalid), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(dbias),

@@ -167,6 +167,53 @@ def test_typed_value_fields_and_widening(address):
   server.shutdown()
 
 
+def test_malformed_payload_never_reaches_a_batch(address):
+  """ADVICE r3 (seedserve.cpp place()): a TensorProto that parses as a message but whose BYTES are wrong -- tensor_content
+  of the wrong length, a truncated float_val run -- is answered INVALID_ARGUMENT 'Cannot parse TensorProto.' (the
+  reference's Tensor::FromProto failure, grpc.cc:176-182) BEFORE any row is reserved: the batch it would have joined is
+  later filled by well-formed calls only and computes on their bytes, not on whatever an earlier batch left in the
+  pinned buffer."""
+  import threading
+  n = 2
+  ibuf = [np.zeros((n, 3), np.float32)]
+  obuf = [np.zeros(n, np.float32)]
+  seen = []
+  server = gn.NativeServer([address], num_io_threads=1)
+
+  def compute(slot):
+    seen.append(ibuf[0].copy())
+    obuf[0][...] = ibuf[0].sum(axis=1)
+  server.bind_buffers('f', [((n, 3), gs.DT_FLOAT)], [((n,), gs.DT_FLOAT)], 1, [[a.ctypes.data for a in ibuf]],
+                      [[a.ctypes.data for a in obuf]], compute, output_nest=TensorSpec((n,), np.float32))
+  server.start()
+  client, other = gs.Client(address), gs.Client(address)
+  # a full batch first, so that the pinned rows hold "an earlier batch's bytes"
+  out, = _raw_call(client, _req('f', np.full((2, 3), 9.0, np.float32)))
+  assert out.tolist() == [27.0, 27.0]
+  errors0 = server.stats()['errors']
+  bad = gs.TensorProto(); bad.dtype = gs.DT_FLOAT; bad.tensor_shape.dim.add().size = 3
+  bad.tensor_content = b'\x00' * 8                                   # 3 floats announced, 8 bytes sent
+  req = gs.CallRequest(); req.function = 'f'; req.tensor.append(bad.SerializeToString())
+  with pytest.raises(gs.InvalidArgumentError, match='Cannot parse TensorProto.'):
+    _raw_call(client, req)
+  trunc = gs.encode_tensor(np.zeros(3, np.float32))
+  tp = gs.TensorProto(); tp.ParseFromString(trunc); tp.tensor_content = b''
+  raw = tp.SerializeToString() + b'\x2a\x06' + b'\x00\x00\x80\x3f\x00\x00'   # packed float_val: one value + 2 stray bytes
+  req = gs.CallRequest(); req.function = 'f'; req.tensor.append(raw)
+  with pytest.raises(gs.InvalidArgumentError, match='Cannot parse TensorProto.'):
+    _raw_call(client, req)
+  assert server.stats()['errors'] == errors0 + 2
+  # no row was reserved by the rejected calls: two single-row calls fill ONE batch with their own bytes
+  res = {}
+  t = threading.Thread(target=lambda: res.setdefault('b', _raw_call(other, _req('f', np.array([4.0, 5.0, 6.0], np.float32)))))
+  t.start()
+  a, = _raw_call(client, _req('f', np.array([1.0, 2.0, 3.0], np.float32)))
+  t.join(10)
+  assert sorted([float(a), float(res['b'][0])]) == [6.0, 15.0]
+  assert len(seen) == 2 and sorted(seen[1].sum(axis=1).tolist()) == [6.0, 15.0]
+  server.shutdown()
+
+
 def test_init_signatures_nests_and_round_robin(address):             # ops.py:80-83, grpc.cc:191-205; ops_test.py:356-382
   Out = collections.namedtuple('Out', 'action value')
 

@@ -21,6 +21,10 @@ def main():
     for r in rows:
       w.writerow([r['Name'][:160], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'],
                   r['MaxNs']])
+  dig = os.path.join(src, tag + '_csrc.sha256')               # kernel-source digest written on the GPU box
+  if os.path.exists(dig):
+    with open(out + '_csrc.sha256', 'w') as f:
+      f.write(open(dig).read())
   pmc = collections.OrderedDict()
   for suffix, counter in (('_fetch', 'FETCH_SIZE'), ('_write', 'WRITE_SIZE')):
     p = os.path.join(src, tag + suffix + '_counter_collection.csv')

@@ -10,7 +10,9 @@ TAG=${1:-r01x}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
+python -m seed_rl_amd.build digest > $OUT/${TAG}_cfg2_csrc.sha256     # which kernels this profile describes
 cd /tmp; export TMPDIR=/tmp
+export PYTHONPATH=$R
 B="python $R/bench.py --steps 5 --warmup 3 --quick --graph 0"
 rocprofv3 --kernel-trace --stats -d $OUT -o ${TAG}_cfg2 --output-format csv -- $B > $OUT/${TAG}_cfg2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT -o ${TAG}_cfg2_fetch --output-format csv -- $B > /dev/null 2>&1
