@@ -16,6 +16,7 @@
 #include "halo_fwd.h"
 #include "gemm.h"
 #include "xgemm.h"
+#include "xgemm8.h"
 #include "wsgemm.h"
 #include "wsw.h"
 #include "../../include/seedhip.h"
@@ -51,6 +52,35 @@ dense_epilogue_kernel(const float* __restrict__ partial, int slices, int M, int 
     if (mask && !(mask[o] > 0.f)) v = 0.f;
     if (add) v += add[o];
     out[o] = v;
+  }
+}
+
+// The same, four columns per thread (N % 4 == 0, 16-byte aligned rows): the x6 / x8 paths' second pass.
+__global__ void __launch_bounds__(256)
+dense_epilogue4_kernel(const float* __restrict__ partial, int slices, int M, int N, const float* __restrict__ bias,
+                       const float* __restrict__ residual, int out_relu, const float* __restrict__ mask,
+                       const float* __restrict__ add, float* __restrict__ out, int ld) {
+  const int nq = N >> 2;
+  const long long total4 = (long long)M * nq, total = (long long)M * N;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+    const int m = (int)(i / nq), n = 4 * (int)(i - (long long)m * nq);
+    const float* src = partial + (long long)m * N + n;
+    float4 v = *reinterpret_cast<const float4*>(src);
+    for (int z = 1; z < slices; ++z) {
+      const float4 t = *reinterpret_cast<const float4*>(src + (long long)z * total);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const long long o = (long long)m * ld + n;
+    if (bias) { const float4 t = *reinterpret_cast<const float4*>(bias + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    if (residual) { const float4 t = *reinterpret_cast<const float4*>(residual + o); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    if (out_relu) { if (v.x < 0.f) v.x = 0.f; if (v.y < 0.f) v.y = 0.f; if (v.z < 0.f) v.z = 0.f; if (v.w < 0.f) v.w = 0.f; }
+    if (mask) {
+      const float4 t = *reinterpret_cast<const float4*>(mask + o);
+      if (!(t.x > 0.f)) v.x = 0.f; if (!(t.y > 0.f)) v.y = 0.f; if (!(t.z > 0.f)) v.z = 0.f; if (!(t.w > 0.f)) v.w = 0.f;
+    }
+    if (add) { const float4 t = *reinterpret_cast<const float4*>(add + o); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    *reinterpret_cast<float4*>(out + o) = v;
   }
 }
 
@@ -134,6 +164,29 @@ xg::Plan x6_wgrad_plan(const seedhip_conv_geom* g) {
   return xg::plan(g->cin, g->cout, g->n_img, (long long)g->n_img * g->ld_in * 4, (long long)g->n_img * g->ld_out * 4);
 }
 
+// The 8-wave structure with the small operand pre-split (xgemm8.h); workspace = [partial sums][slabs]
+xg8::Plan x8_fwd_plan(const seedhip_conv_geom* g) {
+  if (!is_dense(g) || g->ld_in % 4 || g->cin % 4 || g->ld_out % 4) return xg8::Plan{false, 0, 0, 0, 1, 0, 0, 0, 0};
+  return xg8::plan(g->n_img, g->cout, g->cin, (long long)g->n_img * g->ld_in * 4, false, false);
+}
+xg8::Plan x8_dgrad_plan(const seedhip_conv_geom* g) {
+  if (!is_dense(g) || g->ld_out % 4 || g->cout % 4 || g->ld_in % 4 || g->cin % 4) return xg8::Plan{false, 0, 0, 0, 1, 0, 0, 0, 0};
+  return xg8::plan(g->n_img, g->cin, g->cout, 0, true, false);
+}
+xg8::Plan x8_wgrad_plan(const seedhip_conv_geom* g) {
+  if (!is_dense(g) || g->ld_in % 4 || g->cin % 4 || g->ld_out % 4 || g->cout % 4) return xg8::Plan{false, 0, 0, 0, 1, 0, 0, 0, 0};
+  // the PRE-SPLIT operand is dY [rows x cout]: worth it only while it is the smaller of the two (an LSTM input projection,
+  // 532 -> 2048, would spend more on splitting 170 MB of dY than the kernel saves: 413 vs 328 us, r4)
+  if (g->cout > g->cin) return xg8::Plan{false, 0, 0, 0, 1, 0, 0, 0, 0};
+  return xg8::plan(g->cin, g->cout, g->n_img, (long long)g->n_img * g->ld_in * 4, false, true);
+}
+size_t x8_ws(const xg8::Plan& xp, int M, int N, bool colsum_partials) {
+  if (!xp.ok) return 0;
+  size_t part = xg8::partial_bytes(M, N, xp);
+  if (colsum_partials) part = (size_t)xp.slices * ((size_t)M * N + N) * sizeof(float);
+  return xg8::al256(part) + xg8::planes_bytes(xp);
+}
+
 int check_geom(const seedhip_conv_geom* g, const char* what) {
   SEEDHIP_REQUIRE(g, "%s: null geometry", what);
   SEEDHIP_REQUIRE(g->n_img >= 1 && g->ih >= 1 && g->iw >= 1 && g->cin >= 1 && g->oh >= 1 && g->ow >= 1 &&
@@ -154,6 +207,10 @@ int check_geom(const seedhip_conv_geom* g, const char* what) {
 // algorithmic MAC).  What the bench prices a kernel's roofline with; 0 = unknown pass / null geometry.
 extern "C" int seedhip_conv2d_pipe(const seedhip_conv_geom* g, int pass) {
   if (!g || pass < 0 || pass > 2) return 0;
+  if (xg8::mode() & (1 << pass)) {
+    const xg8::Plan x8 = pass == 0 ? x8_fwd_plan(g) : pass == 1 ? x8_dgrad_plan(g) : x8_wgrad_plan(g);
+    if (x8.ok) return 6;
+  }
   if (!(xg::mode() & (1 << pass))) return 1;
   const xg::Plan xp = pass == 0 ? x6_fwd_plan(g) : pass == 1 ? x6_dgrad_plan(g) : x6_wgrad_plan(g);
   return xp.ok ? 6 : 1;
@@ -168,6 +225,7 @@ extern "C" size_t seedhip_conv2d_fwd_workspace_bytes(const seedhip_conv_geom* g)
     const xg::Plan xp = x6_fwd_plan(g);
     if (xp.ok && xg::partial_bytes(g->n_img, g->cout, xp) > mm) mm = xg::partial_bytes(g->n_img, g->cout, xp);
   }
+  if (xg8::mode() & 1) { const size_t w8 = x8_ws(x8_fwd_plan(g), g->n_img, g->cout, false); if (w8 > mm) mm = w8; }
   return mm > core ? mm : core;
 }
 extern "C" size_t seedhip_conv2d_bwd_data_workspace_bytes(const seedhip_conv_geom* g) {
@@ -179,6 +237,7 @@ extern "C" size_t seedhip_conv2d_bwd_data_workspace_bytes(const seedhip_conv_geo
     const xg::Plan xp = x6_dgrad_plan(g);
     if (xp.ok && xg::partial_bytes(g->n_img, g->cin, xp) > mm) mm = xg::partial_bytes(g->n_img, g->cin, xp);
   }
+  if (xg8::mode() & 2) { const size_t w8 = x8_ws(x8_dgrad_plan(g), g->n_img, g->cin, false); if (w8 > mm) mm = w8; }
   return mm > core ? mm : core;
 }
 
@@ -235,6 +294,31 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
       halo::ClassSpec cs = {geom->kh, geom->kw, geom->pad_t, geom->pad_l, geom->oh, geom->ow, 0, 0, 0, 0};
       const halo::FwdPlan pl = halo::plan_fwd(hp, &cs, 1, in_dtype == kInU8Div255);
       if (pl.ok) return halo::launch_fwd_kernel(hp, pl, (hipStream_t)stream);
+    }
+  }
+  if ((xg8::mode() & 1) && is_dense(geom) && in_dtype == kInF32 && al16(in) && al16(w) && al16(out) && workspace &&
+      al16(workspace) && al16(bias) && al16(residual)) {
+    const xg8::Plan xp = x8_fwd_plan(geom);
+    const int M = geom->n_img, N = geom->cout, K = geom->cin;
+    if (xp.ok && workspace_bytes >= x8_ws(xp, M, N, false)) {
+      hipStream_t s = (hipStream_t)stream;
+      unsigned char* ws = (unsigned char*)workspace;
+      float* partial = xp.slices > 1 ? (float*)ws : nullptr;
+      void* Bp = ws + xg8::al256(xg8::partial_bytes(M, N, xp));
+      xg8::launch_split<256>(w, N, N, K, false, false, Bp, nullptr, s);        // B(k, n) = w[k][n]
+      gemm::Params gp;
+      memset(&gp, 0, sizeof(gp));
+      gp.A = (const float*)in; gp.lda = geom->ld_in; gp.a_relu = in_relu; gp.B = w; gp.ldb = N;
+      gp.M = M; gp.N = N; gp.K = K; gp.C = out; gp.ldc = geom->ld_out;
+      gp.bias = bias; gp.residual = residual; gp.out_relu = out_relu; gp.partial = partial;
+      if (xg8::launch<0>(gp, xp, nullptr, Bp, nullptr, s)) {
+        if (xp.slices > 1) {
+          int blocks = cdiv((long long)M * N / 4, 256); if (blocks > 2048) blocks = 2048;
+          hipLaunchKernelGGL(dense_epilogue4_kernel, dim3(blocks), dim3(256), 0, s, partial, xp.slices, M, N, bias,
+                             residual, out_relu, (const float*)nullptr, (const float*)nullptr, out, geom->ld_out);
+        }
+        return check_launch("conv2d_fwd(dense, bf16x6 / 8 waves)");
+      }
     }
   }
   if ((xg::mode() & 1) && is_dense(geom) && in_dtype == kInF32 && al16(in) && al16(w) && al16(out) && al16(workspace) &&
@@ -407,6 +491,32 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
       }
     }
   }
+  if ((xg8::mode() & 2) && is_dense(geom) && al16(dy) && al16(w) && al16(dx) && al16(relu_mask) && al16(add) && workspace &&
+      al16(workspace)) {
+    const xg8::Plan xp = x8_dgrad_plan(geom);
+    const int M = geom->n_img, N = geom->cin, K = geom->cout;
+    if (xp.ok && workspace_bytes >= x8_ws(xp, M, N, false)) {
+      hipStream_t s = (hipStream_t)stream;
+      unsigned char* ws = (unsigned char*)workspace;
+      float* partial = xp.slices > 1 ? (float*)ws : nullptr;
+      unsigned char* Ap = ws + xg8::al256(xg8::partial_bytes(M, N, xp));
+      unsigned char* Bp = Ap + xg8::al256(xp.a_planes);
+      xg8::launch_split<128>(dy, geom->ld_out, M, K, true, false, Ap, nullptr, s);   // A(m, k) = dy[m][k]
+      xg8::launch_split<256>(w, K, N, K, true, false, Bp, nullptr, s);               // B(k, n) = w[n][k]
+      gemm::Params gp;
+      memset(&gp, 0, sizeof(gp));
+      gp.A = dy; gp.lda = geom->ld_out; gp.B = w; gp.ldb = K; gp.M = M; gp.N = N; gp.K = K;
+      gp.C = dx; gp.ldc = geom->ld_in; gp.mask = relu_mask; gp.add = add; gp.partial = partial;
+      if (xg8::launch<2>(gp, xp, Ap, Bp, nullptr, s)) {
+        if (xp.slices > 1) {
+          int blocks = cdiv((long long)M * N / 4, 256); if (blocks > 2048) blocks = 2048;
+          hipLaunchKernelGGL(dense_epilogue4_kernel, dim3(blocks), dim3(256), 0, s, partial, xp.slices, M, N,
+                             (const float*)nullptr, (const float*)nullptr, 0, relu_mask, add, dx, geom->ld_in);
+        }
+        return check_launch("conv2d_bwd_data(dense, bf16x6 / 8 waves)");
+      }
+    }
+  }
   if ((xg::mode() & 2) && is_dense(geom) && al16(dy) && al16(w) && al16(dx) && al16(relu_mask) && al16(add) && al16(workspace)) {
     const xg::Plan xp = x6_dgrad_plan(geom);
     const int M = geom->n_img, N = geom->cin, K = geom->cout;
@@ -493,6 +603,7 @@ extern "C" size_t seedhip_conv2d_bwd_weight_workspace_bytes(const seedhip_conv_g
     const size_t mm = xp.ok ? (size_t)xp.slices * ((size_t)M * N + N) * sizeof(float) : 0;
     if (mm > need) need = mm;
   }
+  if (xg8::mode() & 4) { const size_t w8 = x8_ws(x8_wgrad_plan(g), M, N, true); if (w8 > need) need = w8; }
   {
     wsw::Params wp;
     if (wsw::plan(wp, g)) {
@@ -545,6 +656,30 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
     const halo::WgradPlan pl = halo::plan_wgrad(geom);
     if (pl.ok && (((uintptr_t)in) & 15) == 0 && (((uintptr_t)dy) & 15) == 0)
       return halo::launch_wgrad(geom, pl, in, in_dtype, in_relu, dy, dw, dbias, workspace, (hipStream_t)stream);
+  }
+  if ((xg8::mode() & 4) && is_dense(geom) && in_dtype == kInF32 && al16(in) && al16(dy) && al16(dw) && al16(dbias) && workspace &&
+      al16(workspace)) {
+    const xg8::Plan xp = x8_wgrad_plan(geom);
+    const int M = geom->cin, N = geom->cout, K = geom->n_img;
+    if (xp.ok && workspace_bytes >= x8_ws(xp, M, N, true)) {
+      hipStream_t s = (hipStream_t)stream;
+      unsigned char* ws = (unsigned char*)workspace;
+      float* pw = (float*)ws;
+      float* pb = pw + (size_t)xp.slices * M * N;
+      unsigned char* Bp = ws + xg8::al256((size_t)xp.slices * ((size_t)M * N + N) * sizeof(float));
+      float* cs = dbias ? (float*)(Bp + xg8::al256(xp.b_planes)) : nullptr;
+      xg8::launch_split<256>(dy, geom->ld_out, N, K, false, false, Bp, cs, s);        // B(k, n) = dy[k][n]
+      gemm::Params gp;
+      memset(&gp, 0, sizeof(gp));
+      gp.A = (const float*)in; gp.lda = geom->ld_in; gp.a_relu = in_relu; gp.B = dy; gp.ldb = geom->ld_out;
+      gp.M = M; gp.N = N; gp.K = K;
+      gp.partial = xp.slices > 1 ? pw : dw;                      // one slice: the raw sums are the result
+      gp.partial_colsum = dbias ? (xp.slices > 1 ? pb : dbias) : nullptr;
+      if (xg8::launch<1>(gp, xp, nullptr, Bp, cs, s)) {
+        if (xp.slices > 1) reduce_slices2(pw, (long long)M * N, dw, pb, N, dbias, xp.slices, s);
+        return check_launch("conv2d_bwd_weight(dense, bf16x6 / 8 waves)");
+      }
+    }
   }
   if ((xg::mode() & 4) && is_dense(geom) && in_dtype == kInF32 && al16(in) && al16(dy) && al16(dw) && al16(dbias) && al16(workspace)) {
     const xg::Plan xp = x6_wgrad_plan(geom);

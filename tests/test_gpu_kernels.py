@@ -555,6 +555,66 @@ def test_x6_gemm_fp32_accuracy(device, n, cin, cout):
   check('bias grad', db.cpu().numpy(), tdy.sum(0).numpy(), dy64.sum(0))
 
 
+@pytest.mark.parametrize('n,cin,cout', [(1000, 520, 264), (384, 2592, 256), (2048, 256, 1024)])
+def test_x8_gemm_epilogues_and_tails(device, n, cin, cout):
+  """The 8-wave bf16x6 Dense kernels (xgemm8.h: 128 x 256 tiles, the small operand pre-split into k-tile slabs) on ragged
+  shapes -- rows not a multiple of 128, K not a multiple of 32, a last column tile of 8 columns -- with every fused
+  epilogue the layers use: bias + residual + ReLU and input ReLU (forward), ReLU mask + accumulate (data gradient),
+  input ReLU + bias gradient (weight gradient).  Held to an fp64 evaluation at the error of torch's fp32 matmul."""
+  from seed_rl_amd import _lib, ops
+  import ctypes
+  rng = np.random.default_rng(n + cin)
+  x = rng.normal(size=(n, cin)).astype(np.float32)
+  w = (rng.normal(size=(cin, cout)) / np.sqrt(cin)).astype(np.float32)
+  b = rng.normal(size=cout).astype(np.float32)
+  res = rng.normal(size=(n, cout)).astype(np.float32)
+  dy = rng.normal(size=(n, cout)).astype(np.float32)
+  mask = rng.normal(size=(n, cin)).astype(np.float32)
+  add = rng.normal(size=(n, cin)).astype(np.float32)
+  g = ops.dense_geom(n, cin, cout)
+  for which in range(3):
+    assert _lib.lib().seedhip_conv2d_pipe(ctypes.byref(g), which) == 6
+  f64 = lambda a: a.astype(np.float64)
+  xr = np.maximum(x, 0.0)
+
+  def check(name, hip, f32, ref):
+    e_hip, e_f32, scale = np.max(np.abs(f64(hip) - ref)), np.max(np.abs(f64(f32) - ref)), np.abs(ref).max()
+    print('x8 %s n=%d cin=%d cout=%d: err hip %.3e  torch fp32 %.3e  scale %.3e' % (name, n, cin, cout, e_hip, e_f32, scale))
+    assert e_hip <= max(2.0 * e_f32, 2e-6 * scale), (name, e_hip, e_f32, scale)
+
+  t = torch.tensor
+  out = torch.empty((n, cout), device=device)
+  ops.conv2d_fwd(g, dev(x, device), dev(w, device), dev(b, device), out, in_relu=True, out_relu=True, residual=dev(res, device))
+  check('fwd', out.cpu().numpy(), torch.relu(t(xr) @ t(w) + t(b) + t(res)).numpy(), np.maximum(f64(xr) @ f64(w) + f64(b) + f64(res), 0.0))
+  out2 = torch.empty((n, cout), device=device)
+  ops.conv2d_fwd(g, dev(x, device), dev(w, device), None, out2)
+  check('fwd plain', out2.cpu().numpy(), (t(x) @ t(w)).numpy(), f64(x) @ f64(w))
+  dx = torch.empty((n, cin), device=device)
+  ops.conv2d_bwd_data(g, dev(dy, device), dev(w, device), dx, relu_mask=dev(mask, device), add=dev(add, device))
+  check('dgrad', dx.cpu().numpy(), ((t(dy) @ t(w).T) * (t(mask) > 0) + t(add)).numpy(), (f64(dy) @ f64(w).T) * (mask > 0) + f64(add))
+  dw = torch.empty((cin, cout), device=device); db = torch.empty(cout, device=device)
+  ws = torch.empty(ops.conv2d_bwd_weight_workspace_bytes(g) // 4 + 4, device=device)
+  ops.conv2d_bwd_weight(g, dev(x, device), dev(dy, device), dw, db, ws, in_relu=True)
+  check('wgrad', dw.cpu().numpy(), (t(xr).T @ t(dy)).numpy(), f64(xr).T @ f64(dy))
+  check('bias grad', db.cpu().numpy(), t(dy).sum(0).numpy(), f64(dy).sum(0))
+  dw2 = torch.empty((cin, cout), device=device)
+  ops.conv2d_bwd_weight(g, dev(x, device), dev(dy, device), dw2, None, ws)
+  check('wgrad no bias', dw2.cpu().numpy(), (t(x).T @ t(dy)).numpy(), f64(x).T @ f64(dy))
+
+
+def test_x8_data_gradient_path_in_child():
+  """The library reads SEEDHIP_X8 once: the 8-wave DATA-GRADIENT kernel (both operands pre-split; off by default, the
+  xgemm.h kernel is faster at these K) is exercised by the same test in a child process with every x8 path on."""
+  import os, subprocess, sys
+  if os.environ.get('SEEDHIP_X8') == '7':
+    pytest.skip('this IS the child')
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_kernels.py'), '-q', '-x', '-m', 'gpu',
+                      '-k', 'test_x8_gemm_epilogues_and_tails', '-p', 'no:cacheprovider'],
+                     env=dict(os.environ, SEEDHIP_X8='7'), capture_output=True, text=True, timeout=600, cwd=root)
+  assert r.returncode == 0 and '3 passed' in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+
+
 @pytest.mark.parametrize('T1,B', [(3, 5), (6, 37)])
 def test_relu_byte_mask_pair(device, T1, B):
   """The shallow Atari torso's ReLU mask as bytes (seedhip_conv2d_stack_fwd_bits -> seedhip_conv2d_bwd_data_bits): the
