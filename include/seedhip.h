@@ -129,6 +129,14 @@ int seedhip_adam_flat(float* params, const float* grads, float* m, float* v, lon
 int seedhip_adam_flat_dev_lr(float* params, const float* grads, float* m, float* v, long long n,
                              const float* lr_t_device, float beta_1, float beta_2, float epsilon,
                              float grad_scale, long long clamp_index, float clamp_lo, float clamp_hi, void* stream);
+/* Both of the above (lr_t_device NULL: lr_t is used) with a GUARD: when int32 *skip_if_nonzero (device memory, may be
+ * NULL) is non-zero at launch time on the device, the update is skipped altogether -- parameters and moments stay as
+ * they are.  The word is the sticky abort flag of the LSTM sequence kernels: a step whose gradients are invalid is
+ * dropped instead of applied, inside a replayed HIP graph too (no host decision on the step's critical path). */
+int seedhip_adam_flat_guarded(float* params, const float* grads, float* m, float* v, long long n,
+                              float lr_t, const float* lr_t_device, float beta_1, float beta_2, float epsilon,
+                              float grad_scale, long long clamp_index, float clamp_lo, float clamp_hi,
+                              const int* skip_if_nonzero, void* stream);
 /* tf.clip_by_global_norm(grads, clip_norm) of agents/r2d2/learner.py:606-609; sumsq_out[0] = |g|^2.
  * clip_norm <= 0: only compute the norm. */
 size_t seedhip_global_norm_workspace_bytes(void);
@@ -297,6 +305,13 @@ int seedhip_lstm_step_fwd(const float* hin, const float* up, const float* zx, co
 int seedhip_lstm_seq_supported(int T1, int B, int H);
 int seedhip_lstm_seq_fwd(const float* up, const float* zx, const uint8_t* done, int T1, int B, int H, float* z,
                          float* h_out, int ld_h, float* hin, float* cin, void* sync_ws, void* stream);
+/* The same with a STICKY abort word: when a wait times out, int32 *sticky_abort (device memory, may be NULL) is set
+ * to 1 together with sync_ws[1] and -- unlike sync_ws, which every launch zeroes -- is never cleared by the library:
+ * it tells seedhip_adam_flat_guarded to drop the step whose gradients came from an aborted sequence kernel, and the
+ * host (which clears it) to fall back to seedhip_lstm_step_fwd. */
+int seedhip_lstm_seq_fwd_sticky(const float* up, const float* zx, const uint8_t* done, int T1, int B, int H, float* z,
+                                float* h_out, int ld_h, float* hin, float* cin, void* sync_ws, int* sticky_abort,
+                                void* stream);
 /* The whole BACKWARD recurrence in one launch: for t = T1-1 .. 0, dz_t = cell backward of step t (as
  * seedhip_lstm_gates_bwd: dh = dh_out_t + keep_{t+1} * dh_rec, dc = keep_{t+1} * dc_rec) and dh_rec = dz_t U^T (the
  * per-step seedhip_conv2d_bwd_data of the dense geometry [B, H] -> [B, 4H]).  Same residency / tiling as
@@ -309,6 +324,9 @@ size_t seedhip_lstm_seq_bwd_workspace_bytes(int B, int H);
 int seedhip_lstm_seq_bwd(const float* up, const float* z, const float* cin, const float* dh_out, int ld_dh,
                          const uint8_t* done, int T1, int B, int H, float* dz, void* ring_ws, void* sync_ws,
                          void* stream);
+int seedhip_lstm_seq_bwd_sticky(const float* up, const float* z, const float* cin, const float* dh_out, int ld_dh,
+                                const uint8_t* done, int T1, int B, int H, float* dz, void* ring_ws, void* sync_ws,
+                                int* sticky_abort, void* stream);   /* sticky_abort as in seedhip_lstm_seq_fwd_sticky */
 int seedhip_lstm_gates_fwd(const float* z, const float* cin, const uint8_t* done_next, int B, int H, float* h_out,
                            int ld_h, float* hin_next, float* cin_next, void* stream);
 int seedhip_lstm_gates_bwd(const float* z, const float* cin, const float* dh_out, int ld_dh, const float* dh_rec,

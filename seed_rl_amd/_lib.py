@@ -62,6 +62,8 @@ SIGNATURES = {
                                   c_ll, c_float, c_float, P]),
     'seedhip_adam_flat_dev_lr': (c_int, [P, P, P, P, c_ll, P, c_float, c_float, c_float, c_float,
                                          c_ll, c_float, c_float, P]),
+    'seedhip_adam_flat_guarded': (c_int, [P, P, P, P, c_ll, c_float, P, c_float, c_float, c_float, c_float,
+                                          c_ll, c_float, c_float, P, P]),
     'seedhip_global_norm_workspace_bytes': (c_size_t, []),
     'seedhip_clip_by_global_norm': (c_int, [P, c_ll, c_float, P, P, c_size_t, P]),
     'seedhip_unpackbits_u16': (c_int, [P, c_ll, P, P]),
@@ -105,8 +107,10 @@ SIGNATURES = {
     'seedhip_lstm_step_fwd': (c_int, [P, P, P, P, P, c_int, c_int, P, P, c_int, P, P, P]),
     'seedhip_lstm_seq_supported': (c_int, [c_int, c_int, c_int]),
     'seedhip_lstm_seq_fwd': (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_int, P, P, P, P]),
+    'seedhip_lstm_seq_fwd_sticky': (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P]),
     'seedhip_lstm_seq_bwd_workspace_bytes': (c_size_t, [c_int, c_int]),
     'seedhip_lstm_seq_bwd': (c_int, [P, P, P, P, c_int, P, c_int, c_int, c_int, P, P, P, P]),
+    'seedhip_lstm_seq_bwd_sticky': (c_int, [P, P, P, P, c_int, P, c_int, c_int, c_int, P, P, P, P, P]),
     'seedhip_lstm_gates_bwd': (c_int, [P, P, P, c_int, P, P, P, c_int, c_int, P, P, P]),
     'seedhip_rows_move': (c_int, [P, P, P, P, c_ll, c_ll, P]),
     'seedhip_rows_move_masked': (c_int, [P, P, P, P, c_ll, c_ll, P, c_int, P]),

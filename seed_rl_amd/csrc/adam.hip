@@ -18,7 +18,11 @@ __global__ void __launch_bounds__(256)
 adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                  float* __restrict__ v, long long n, float lr_host, const float* __restrict__ lr_dev,
                  float one_minus_b1, float one_minus_b2, float eps, float grad_scale,
-                 long long clamp_index, float clamp_lo, float clamp_hi) {
+                 long long clamp_index, float clamp_lo, float clamp_hi, const int* __restrict__ guard) {
+  // guard (may be null): a device word that is non-zero when this step's gradients are INVALID (a bounded wait of the
+  // LSTM sequence kernels timed out: lstm_step.hip) -- the whole update is skipped, parameters and moments stay as
+  // they are, and the host demotes the agent to the per-step kernels when it sees the flag (networks.py)
+  if (guard && guard[0] != 0) return;
   const float lr_t = lr_dev ? lr_dev[0] : lr_host;   // device scalar: the step can sit in a captured HIP graph
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long n4 = n >> 2;
@@ -89,6 +93,22 @@ constexpr int kSumsqBlocks = 512;
 extern "C" int seedhip_adam_flat(float* params, const float* grads, float* m, float* v, long long n,
                                  float lr_t, float beta_1, float beta_2, float epsilon, float grad_scale,
                                  long long clamp_index, float clamp_lo, float clamp_hi, void* stream) {
+  return seedhip_adam_flat_guarded(params, grads, m, v, n, lr_t, nullptr, beta_1, beta_2, epsilon, grad_scale, clamp_index,
+                                   clamp_lo, clamp_hi, nullptr, stream);
+}
+extern "C" int seedhip_adam_flat_dev_lr(float* params, const float* grads, float* m, float* v, long long n,
+                                        const float* lr_t_device, float beta_1, float beta_2, float epsilon,
+                                        float grad_scale, long long clamp_index, float clamp_lo, float clamp_hi,
+                                        void* stream) {
+  SEEDHIP_REQUIRE(n == 0 || lr_t_device, "adam: null pointer");
+  return seedhip_adam_flat_guarded(params, grads, m, v, n, 0.f, lr_t_device, beta_1, beta_2, epsilon, grad_scale, clamp_index,
+                                   clamp_lo, clamp_hi, nullptr, stream);
+}
+
+extern "C" int seedhip_adam_flat_guarded(float* params, const float* grads, float* m, float* v, long long n,
+                                         float lr_t, const float* lr_t_device, float beta_1, float beta_2, float epsilon,
+                                         float grad_scale, long long clamp_index, float clamp_lo, float clamp_hi,
+                                         const int* skip_if_nonzero, void* stream) {
   SEEDHIP_REQUIRE(n >= 0, "adam: negative n");
   SEEDHIP_REQUIRE(clamp_index < n, "adam: clamp_index %lld out of range", clamp_index);
   if (n == 0) return SEEDHIP_OK;
@@ -98,26 +118,8 @@ extern "C" int seedhip_adam_flat(float* params, const float* grads, float* m, fl
   int blocks = seedhip::cdiv(n / 4 + 1, 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n,
-                     lr_t, (const float*)nullptr, 1.0f - beta_1, 1.0f - beta_2, epsilon, grad_scale, clamp_index,
-                     clamp_lo, clamp_hi);
-  return seedhip::check_launch("adam_flat_kernel");
-}
-
-extern "C" int seedhip_adam_flat_dev_lr(float* params, const float* grads, float* m, float* v, long long n,
-                                        const float* lr_t_device, float beta_1, float beta_2, float epsilon,
-                                        float grad_scale, long long clamp_index, float clamp_lo, float clamp_hi,
-                                        void* stream) {
-  SEEDHIP_REQUIRE(n >= 0, "adam: negative n");
-  SEEDHIP_REQUIRE(clamp_index < n, "adam: clamp_index %lld out of range", clamp_index);
-  if (n == 0) return SEEDHIP_OK;
-  SEEDHIP_REQUIRE(params && grads && m && v && lr_t_device, "adam: null pointer");
-  SEEDHIP_REQUIRE(((((uintptr_t)params) | ((uintptr_t)grads) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0,
-                  "adam: buffers must be 16-byte aligned");
-  int blocks = seedhip::cdiv(n / 4 + 1, 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n,
-                     0.f, lr_t_device, 1.0f - beta_1, 1.0f - beta_2, epsilon, grad_scale, clamp_index, clamp_lo,
-                     clamp_hi);
+                     lr_t, lr_t_device, 1.0f - beta_1, 1.0f - beta_2, epsilon, grad_scale, clamp_index,
+                     clamp_lo, clamp_hi, skip_if_nonzero);
   return seedhip::check_launch("adam_flat_kernel");
 }
 

@@ -209,6 +209,7 @@ struct SeqParams {
   const float* up; const float* zx; const uint8_t* done; int T1, B, H;
   float* z; float* h_out; int ld_h; float* hin; float* cin;          // hin / cin [T1 + 1, B, H]; slot 0 = initial state
   int* abort_flag; int fault;
+  int* sticky;                                               // set together with abort_flag, never cleared by a launch (may be null)
   int xcd_local;                                             // try the same-XCD exchange (plain producer stores)
 };
 
@@ -340,7 +341,10 @@ lstm_seq_fwd_kernel(const SeqParams p) {
       if (!__any(stale)) break;
       ++spins;
       if (spins > kMaxSpins || ((spins & 31) == 0 && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-        if (lane == 0) __hip_atomic_store(p.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+          __hip_atomic_store(p.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (p.sticky) __hip_atomic_store(p.sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         dead = true;
         break;
       }
@@ -436,6 +440,7 @@ struct SeqBwdParams {
   const float* up; const float* z; const float* cin; const float* dh_out; int ld_dh; const uint8_t* done;
   int T1, B, H;
   float* dz; float* ring; int* abort_flag; int fault;
+  int* sticky;                                               // as SeqParams::sticky
 };
 
 constexpr int LDT = kCols + 4;                            // dz tile row stride (bank spread for the b128 fragment reads)
@@ -513,7 +518,10 @@ lstm_seq_bwd_kernel(const SeqBwdParams p) {
         if (dead || !__any(stale) || (p.fault & 8)) break;
         ++spins;
         if (spins > kMaxSpins || ((spins & 31) == 0 && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-          if (lane == 0) __hip_atomic_store(p.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) {
+            __hip_atomic_store(p.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.sticky) __hip_atomic_store(p.sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           dead = true;
           break;
         }
@@ -659,6 +667,12 @@ extern "C" int seedhip_lstm_seq_supported(int T1, int B, int H) {
 extern "C" int seedhip_lstm_seq_fwd(const float* up, const float* zx, const uint8_t* done, int T1, int B, int H,
                                     float* z, float* h_out, int ld_h, float* hin, float* cin, void* sync_ws,
                                     void* stream) {
+  return seedhip_lstm_seq_fwd_sticky(up, zx, done, T1, B, H, z, h_out, ld_h, hin, cin, sync_ws, nullptr, stream);
+}
+
+extern "C" int seedhip_lstm_seq_fwd_sticky(const float* up, const float* zx, const uint8_t* done, int T1, int B, int H,
+                                           float* z, float* h_out, int ld_h, float* hin, float* cin, void* sync_ws,
+                                           int* sticky_abort, void* stream) {
   SEEDHIP_REQUIRE(up && zx && done && z && h_out && hin && cin && sync_ws, "lstm_seq_fwd: null pointer");
   SEEDHIP_REQUIRE(seedhip_lstm_seq_supported(T1, B, H),
                   "lstm_seq_fwd: unsupported (T1 = %d, B = %d, H = %d): need T1 >= 2, H %% 128 == 0, H <= 512 and a co-resident grid",
@@ -667,7 +681,7 @@ extern "C" int seedhip_lstm_seq_fwd(const float* up, const float* zx, const uint
   SEEDHIP_REQUIRE(((((uintptr_t)hin) | ((uintptr_t)up)) & 15) == 0, "lstm_seq_fwd: hin / up must be 16-byte aligned");
   SeqParams p;
   p.up = up; p.zx = zx; p.done = done; p.T1 = T1; p.B = B; p.H = H; p.z = z; p.h_out = h_out; p.ld_h = ld_h;
-  p.hin = hin; p.cin = cin; p.abort_flag = (int*)sync_ws + 1;
+  p.hin = hin; p.cin = cin; p.abort_flag = (int*)sync_ws + 1; p.sticky = sticky_abort;
   { const char* e = getenv("SEEDHIP_LSTM_SEQ_FAULT"); p.fault = e ? atoi(e) : 0; }   // tests: exercise the bounded wait (read per call on purpose: tests flip it)
   { static const int x = getenv("SEEDHIP_LSTM_SEQ_XCD") ? atoi(getenv("SEEDHIP_LSTM_SEQ_XCD")) : 1; p.xcd_local = x; }
   const size_t lds = seq_lds_bytes(H);
@@ -713,6 +727,12 @@ extern "C" size_t seedhip_lstm_seq_bwd_workspace_bytes(int B, int H) {
 extern "C" int seedhip_lstm_seq_bwd(const float* up, const float* z, const float* cin, const float* dh_out, int ld_dh,
                                     const uint8_t* done, int T1, int B, int H, float* dz, void* ring_ws, void* sync_ws,
                                     void* stream) {
+  return seedhip_lstm_seq_bwd_sticky(up, z, cin, dh_out, ld_dh, done, T1, B, H, dz, ring_ws, sync_ws, nullptr, stream);
+}
+
+extern "C" int seedhip_lstm_seq_bwd_sticky(const float* up, const float* z, const float* cin, const float* dh_out, int ld_dh,
+                                           const uint8_t* done, int T1, int B, int H, float* dz, void* ring_ws,
+                                           void* sync_ws, int* sticky_abort, void* stream) {
   SEEDHIP_REQUIRE(up && z && cin && dh_out && done && dz && ring_ws && sync_ws, "lstm_seq_bwd: null pointer");
   SEEDHIP_REQUIRE(seedhip_lstm_seq_supported(T1, B, H),
                   "lstm_seq_bwd: unsupported (T1 = %d, B = %d, H = %d): need T1 >= 2, H %% 128 == 0, H <= 512 and a co-resident grid",
@@ -721,7 +741,7 @@ extern "C" int seedhip_lstm_seq_bwd(const float* up, const float* z, const float
   SEEDHIP_REQUIRE((((uintptr_t)up) | ((uintptr_t)ring_ws)) % 16 == 0, "lstm_seq_bwd: up / ring_ws must be 16-byte aligned");
   SeqBwdParams p;
   p.up = up; p.z = z; p.cin = cin; p.dh_out = dh_out; p.ld_dh = ld_dh; p.done = done; p.T1 = T1; p.B = B; p.H = H;
-  p.dz = dz; p.ring = (float*)ring_ws; p.abort_flag = (int*)sync_ws + 1;
+  p.dz = dz; p.ring = (float*)ring_ws; p.abort_flag = (int*)sync_ws + 1; p.sticky = sticky_abort;
   // bit 0: tests, exercise the bounded wait; bits 1-3: timing attribution only (tools/bench_lstm_step.py SEQ_DBG):
   // 2 = no MFMA, 4 = no partial stores, 8 = do not wait for the partials -- results are garbage with any of them
   { const char* e = getenv("SEEDHIP_LSTM_SEQ_FAULT"); p.fault = e ? atoi(e) : 0; }

@@ -240,6 +240,7 @@ class GraphedStep(object):
     if not getattr(learner.optimizer, 'capturable', False):
       raise ValueError('GraphedStep needs optimizers.Adam(..., capturable=True)')
     self.learner, self.unroll, self.extra = learner, unroll, extra
+    self._max_cuts = max_cuts
     # The warm-up below runs REAL optimizer steps on whatever the static unroll buffers hold: everything they touch
     # is put back after the capture, so that a graphed learner starts from exactly the state an eager one would
     # (parameters, Adam moments and step counter -- with it the LR-schedule position --, R2D2 target network and
@@ -340,10 +341,16 @@ class GraphedStep(object):
       post()
     # the persistent LSTM kernels' abort flags: mirrored to pinned host memory after every replay and looked at
     # before the next one (by then the copy has landed: no sync) -- a wait that timed out during a replay raises here
+    demoted = False
     for a in self._agents:
       if getattr(a, '_last_lstm', None) is not None:
-        a._lstm_seq_check()                         # pylint: disable=protected-access
+        demoted = bool(a._lstm_seq_check()) or demoted   # pylint: disable=protected-access
         a.mirror_error_flags()
+    if demoted:
+      # an agent fell back to the per-step LSTM kernels (a sequence kernel's wait timed out in an earlier replay; the
+      # update kernel dropped those steps): the captured graphs still hold the sequence kernels -- capture again
+      torch.cuda.synchronize()
+      self.__init__(self.learner, self.unroll, *self.extra, warmup=1, max_cuts=self._max_cuts)
     return self.outputs
 
   def check_errors(self):

@@ -334,23 +334,25 @@ def impala_loss_fwd_bwd(logits, logits_ld, baseline, baseline_ld, beh_logits, ac
           'seedhip_impala_loss_fwd_bwd')
 
 
-def adam_flat(params, grads, m, v, lr_t, beta_1, beta_2, epsilon, grad_scale=1.0, clamp=None):
-  """clamp = (index, lo, hi): params[index] is clipped to [lo, hi] after its update (Keras variable constraint)."""
+def adam_flat(params, grads, m, v, lr_t, beta_1, beta_2, epsilon, grad_scale=1.0, clamp=None, guard=None):
+  """clamp = (index, lo, hi): params[index] is clipped to [lo, hi] after its update (Keras variable constraint).
+  guard: int32[1] device tensor; non-zero on the device = the update is skipped (seedhip_adam_flat_guarded)."""
   ci, lo, hi = clamp if clamp is not None else (-1, 0.0, 0.0)
   with _region('adam_flat', 0, params.numel() * 28):
     with _dev(params):
-      _lib.check(_lib.lib().seedhip_adam_flat(
-          _lib.ptr(params), _lib.ptr(grads), _lib.ptr(m), _lib.ptr(v), params.numel(), lr_t, beta_1, beta_2,
-          epsilon, grad_scale, int(ci), float(lo), float(hi), _lib.stream()), 'seedhip_adam_flat')
+      _lib.check(_lib.lib().seedhip_adam_flat_guarded(
+          _lib.ptr(params), _lib.ptr(grads), _lib.ptr(m), _lib.ptr(v), params.numel(), lr_t, None, beta_1, beta_2,
+          epsilon, grad_scale, int(ci), float(lo), float(hi), _lib.ptr(guard), _lib.stream()), 'seedhip_adam_flat')
 
 
-def adam_flat_dev_lr(params, grads, m, v, lr_t_dev, beta_1, beta_2, epsilon, grad_scale=1.0, clamp=None):
+def adam_flat_dev_lr(params, grads, m, v, lr_t_dev, beta_1, beta_2, epsilon, grad_scale=1.0, clamp=None, guard=None):
   ci, lo, hi = clamp if clamp is not None else (-1, 0.0, 0.0)
   with _region('adam_flat', 0, params.numel() * 28):
     with _dev(params):
-      _lib.check(_lib.lib().seedhip_adam_flat_dev_lr(
-          _lib.ptr(params), _lib.ptr(grads), _lib.ptr(m), _lib.ptr(v), params.numel(), _lib.ptr(lr_t_dev), beta_1,
-          beta_2, epsilon, grad_scale, int(ci), float(lo), float(hi), _lib.stream()), 'seedhip_adam_flat_dev_lr')
+      _lib.check(_lib.lib().seedhip_adam_flat_guarded(
+          _lib.ptr(params), _lib.ptr(grads), _lib.ptr(m), _lib.ptr(v), params.numel(), 0.0, _lib.ptr(lr_t_dev), beta_1,
+          beta_2, epsilon, grad_scale, int(ci), float(lo), float(hi), _lib.ptr(guard), _lib.stream()),
+          'seedhip_adam_flat_dev_lr')
 
 
 def global_norm_workspace_bytes():
@@ -451,27 +453,28 @@ def lstm_seq_supported(T1, B, H):
   return bool(_lib.lib().seedhip_lstm_seq_supported(T1, B, H))
 
 
-def lstm_seq_fwd(up, zx, done_u8, T1, B, H, z, h_out, ld_h, hin, cin, sync_ws):
+def lstm_seq_fwd(up, zx, done_u8, T1, B, H, z, h_out, ld_h, hin, cin, sync_ws, sticky=None):
   """All T1 LSTM steps in one launch (resident workgroups + grid barrier); bit-identical to T1 lstm_step_fwd calls.
-  sync_ws: int32[2] device tensor; sync_ws[1] != 0 afterwards = barrier timed out, outputs invalid."""
+  sync_ws: int32[2] device tensor; sync_ws[1] != 0 afterwards = barrier timed out, outputs invalid.
+  sticky: int32[1] device tensor set to 1 on a timeout and never cleared by the library (adam_flat*(guard=))."""
   with _region('lstm_seq_fwd', 2.0 * T1 * B * H * 4 * H, (H * 4 * H + T1 * B * H * 12) * 4):
     with _dev(z):
-      _lib.check(_lib.lib().seedhip_lstm_seq_fwd(
+      _lib.check(_lib.lib().seedhip_lstm_seq_fwd_sticky(
           _lib.ptr(up), _lib.ptr(zx), _lib.ptr(done_u8), T1, B, H, _lib.ptr(z), _lib.ptr(h_out), ld_h, _lib.ptr(hin),
-          _lib.ptr(cin), _lib.ptr(sync_ws), _lib.stream()), 'seedhip_lstm_seq_fwd')
+          _lib.ptr(cin), _lib.ptr(sync_ws), _lib.ptr(sticky), _lib.stream()), 'seedhip_lstm_seq_fwd')
 
 
 def lstm_seq_bwd_workspace_bytes(B, H):
   return int(_lib.lib().seedhip_lstm_seq_bwd_workspace_bytes(B, H))
 
 
-def lstm_seq_bwd(up, z, cin, dh_out, ld_dh, done_u8, T1, B, H, dz, ring_ws, sync_ws):
+def lstm_seq_bwd(up, z, cin, dh_out, ld_dh, done_u8, T1, B, H, dz, ring_ws, sync_ws, sticky=None):
   """The whole backward recurrence (cell backward + dh_rec = dz U^T per step) in one launch."""
   with _region('lstm_seq_bwd', 2.0 * (T1 - 1) * B * H * 4 * H, (H * 4 * H + T1 * B * H * 11) * 4):
     with _dev(dz):
-      _lib.check(_lib.lib().seedhip_lstm_seq_bwd(
+      _lib.check(_lib.lib().seedhip_lstm_seq_bwd_sticky(
           _lib.ptr(up), _lib.ptr(z), _lib.ptr(cin), _lib.ptr(dh_out), ld_dh, _lib.ptr(done_u8), T1, B, H, _lib.ptr(dz),
-          _lib.ptr(ring_ws), _lib.ptr(sync_ws), _lib.stream()), 'seedhip_lstm_seq_bwd')
+          _lib.ptr(ring_ws), _lib.ptr(sync_ws), _lib.ptr(sticky), _lib.stream()), 'seedhip_lstm_seq_bwd')
 
 
 def lstm_gates_fwd(z, cin, done_next_u8, B, H, h_out, ld_h, hin_next, cin_next):

@@ -57,14 +57,17 @@ class Adam(object):
       self._m = torch.zeros_like(flat.params)
       self._v = torch.zeros_like(flat.params)
     t = self.iterations + 1
+    # flat.step_guard (int32[1] on the device, set by agents with LSTM sequence kernels): non-zero = this step's gradients
+    # are invalid and the update is dropped on the device (csrc/adam.hip)
+    guard = getattr(flat, 'step_guard', None)
     if self.capturable:
       if self._lr_dev is None:
         self.begin_step(flat.params.device)
       ops.adam_flat_dev_lr(flat.params, flat.grads, self._m, self._v, self._lr_dev, self.beta_1, self.beta_2,
-                           self.epsilon, float(grad_scale), clamp=getattr(flat, 'constraint', None))
+                           self.epsilon, float(grad_scale), clamp=getattr(flat, 'constraint', None), guard=guard)
     else:
       ops.adam_flat(flat.params, flat.grads, self._m, self._v, float(self.lr_t()), self.beta_1, self.beta_2,
-                    self.epsilon, float(grad_scale), clamp=getattr(flat, 'constraint', None))
+                    self.epsilon, float(grad_scale), clamp=getattr(flat, 'constraint', None), guard=guard)
     self.iterations = t
 
   def state_dict(self):

@@ -84,6 +84,10 @@ class R2D2Learner(object):
     if torch.distributed.is_available() and torch.distributed.is_initialized():
       self.world = torch.distributed.get_world_size(process_group)
     self.iterations = 0
+    # one sticky abort word for both networks: a timed-out LSTM sequence kernel of the TARGET network invalidates the
+    # training network's gradients just the same, and the update kernel is guarded by the training agent's word
+    if hasattr(training_agent, '_seq_sticky') and hasattr(target_agent, '_ws'):
+      target_agent._ws[('lstm_seq_sticky', (1,), torch.int32)] = training_agent._seq_sticky()   # pylint: disable=protected-access
     self.update_target()
 
   def update_target(self):

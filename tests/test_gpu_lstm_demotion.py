@@ -1,0 +1,125 @@
+"""LSTM sequence kernels under concurrency (VERDICT r3 task 9; dmlab/networks.py:152-171 is the loop they replace).
+
+The persistent whole-unroll kernels assume a co-resident grid; with another stream holding CUs a bounded wait can time
+out.  What must happen then: (1) the step whose gradients came from the aborted kernel is DROPPED on the device (the
+update kernel is guarded by the kernel's sticky abort word: parameters and Adam moments untouched), (2) the host, one
+step later and without a sync, demotes the agent to one launch per LSTM step and training goes on, (3) the same through
+a replayed HIP graph (the graphs are captured again).  The timeout is provoked with the library's test hook
+(SEEDHIP_LSTM_SEQ_FAULT=1: a producer that never delivers)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(device, capturable):
+  from seed_rl_amd import learner, networks, optimizers, parametric_distribution as pd, smoke_step
+  A, T1, B = 6, 21, 32
+  agent = networks.ImpalaDeep(A, observation_shape=(24, 32, 3), device=device, seed=0)
+  opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, 50), beta_1=0.0, epsilon=3.125e-7, capturable=capturable)
+  unroll = smoke_step.make_deep_unroll(agent, T1, B, A, device, seed=3, done_p=0.2)
+  return learner.Learner(agent, opt, pd.categorical_distribution(A)), unroll
+
+
+def test_aborted_step_is_dropped_and_agent_demoted(device, monkeypatch):
+  from seed_rl_amd import ops
+  if not ops.lstm_seq_supported(21, 32, 256):
+    pytest.skip('sequence kernels not available for this shape')
+  lrn, unroll = _mk(device, False)
+  agent = lrn.agent
+  lrn.minimize(unroll)
+  torch.cuda.synchronize()
+  assert agent._last_lstm['fused_seq'] and not getattr(agent, '_seq_demoted', False)
+  p1 = agent.flat.params.clone()
+  sd = lrn.optimizer.state_dict()
+  v1 = sd['v'].clone()
+  monkeypatch.setenv('SEEDHIP_LSTM_SEQ_FAULT', '1')
+  lrn.minimize(unroll)                                        # the forward (and backward) sequence kernel times out
+  torch.cuda.synchronize()
+  monkeypatch.delenv('SEEDHIP_LSTM_SEQ_FAULT')
+  assert torch.equal(agent.flat.params, p1), 'the aborted step must not be applied'
+  assert torch.equal(lrn.optimizer.state_dict()['v'], v1)
+  loss3, _ = lrn.minimize(unroll)                             # notices the flag, demotes, runs the per-step kernels
+  torch.cuda.synchronize()
+  assert agent._seq_demoted and not agent._last_lstm['fused_seq']
+  assert np.isfinite(float(loss3)) and bool(torch.isfinite(agent.flat.params).all())
+  assert not torch.equal(agent.flat.params, p1), 'training goes on'
+  # its loss is the loss a never-aborted learner sees in ITS second step: both are evaluated at the parameters after ONE
+  # update (the sequence kernels' forward is bit-identical to the per-step kernels').  The parameters themselves are
+  # not compared: the dropped step still advanced the host's step counter, i.e. Adam's bias correction.
+  ref, uref = _mk(device, False)
+  ref.minimize(uref)
+  lref, _ = ref.minimize(uref)
+  torch.cuda.synchronize()
+  assert abs(float(loss3) - float(lref)) <= 1e-6 * max(1.0, abs(float(lref))), (float(loss3), float(lref))
+  assert agent.check_errors() is False                        # nothing pending
+
+
+def test_aborted_replay_recaptures_the_graph(device, monkeypatch):
+  from seed_rl_amd import learner, ops
+  if not ops.lstm_seq_supported(21, 32, 256):
+    pytest.skip('sequence kernels not available for this shape')
+  lrn, unroll = _mk(device, True)
+  agent = lrn.agent
+  step = learner.GraphedStep(lrn, unroll, warmup=2)
+  step(); torch.cuda.synchronize()
+  p1 = agent.flat.params.clone()
+  # the fault hook is read at LAUNCH time, i.e. at capture: provoke the abort by arming the sticky word the way the
+  # kernel would (the guard and the host path are what this test is about; the kernel side is covered above)
+  agent._seq_sticky().fill_(1)
+  step(); torch.cuda.synchronize()
+  assert torch.equal(agent.flat.params, p1), 'a replayed step with the abort word set must be dropped'
+  step(); torch.cuda.synchronize()                            # mirrored flag seen after this replay: demote + re-capture
+  out = step(); torch.cuda.synchronize()
+  assert agent._seq_demoted and not agent._last_lstm['fused_seq']
+  assert np.isfinite(float(out[0])) and not torch.equal(agent.flat.params, p1)
+  assert int(agent._seq_sticky()[0]) == 0
+
+
+def test_sequence_kernel_beside_a_saturating_stream(device):
+  """lstm_seq_fwd on one stream while another stream keeps every CU busy (what LearnerServer does: inference beside the
+  train step).  The grid may or may not become co-resident in time; either the kernel finishes with the per-step
+  kernels' bits, or its bounded wait expires and the sticky word says so -- it never hangs and never returns garbage
+  silently."""
+  import time
+  from seed_rl_amd import ops
+  T1, B, H = 8, 64, 256
+  if not ops.lstm_seq_supported(T1, B, H):
+    pytest.skip('not co-resident')
+  rng = np.random.default_rng(5)
+  t = lambda a: torch.as_tensor(a).to(device)
+  U = t((rng.normal(size=(H, 4 * H)) / np.sqrt(H)).astype(np.float32))
+  zx = t(rng.normal(size=(T1, B, 4 * H)).astype(np.float32))
+  done = torch.zeros((T1, B), dtype=torch.uint8, device=device)
+  up = torch.empty((H, 4 * H), device=device)
+  ops.lstm_permute_u(U, H, up)
+
+  def run(seq, sticky=None):
+    hin = torch.zeros((T1 + 1, B, H), device=device); cin = torch.zeros((T1 + 1, B, H), device=device)
+    z = torch.empty((T1, B, 4 * H), device=device); hout = torch.empty((T1 * B, H), device=device)
+    if seq:
+      sync = torch.zeros(2, dtype=torch.int32, device=device)
+      ops.lstm_seq_fwd(up, zx, done, T1, B, H, z, hout, H, hin, cin, sync, sticky)
+    else:
+      for s in range(T1):
+        ops.lstm_step_fwd(hin[s], up, zx[s], cin[s], done[s + 1] if s + 1 < T1 else None, B, H, z[s], hout.view(T1, B, H)[s],
+                          H, hin[s + 1], cin[s + 1])
+    return hout
+
+  ref = run(False)
+  torch.cuda.synchronize()
+  hog = torch.cuda.Stream()
+  a = torch.randn((8192, 8192), device=device)
+  sticky = torch.zeros(1, dtype=torch.int32, device=device)
+  t0 = time.time()
+  with torch.cuda.stream(hog):
+    for _ in range(40):                                       # ~100+ ms of kernels that fill every CU
+      a = torch.tanh(a @ a * 1e-4)
+  got = run(True, sticky)                                     # launched while the other stream is busy
+  torch.cuda.synchronize()
+  assert time.time() - t0 < 60.0
+  if int(sticky[0]) == 0:
+    assert torch.equal(got, ref)
+  else:
+    print('sequence kernel aborted beside the saturating stream (sticky word set): bounded wait worked')
