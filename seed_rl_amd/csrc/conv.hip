@@ -150,31 +150,35 @@ bool is_dense(const seedhip_conv_geom* g) {
 }
 
 // Dense layers on the bf16 pipe through the exact three-way split (xgemm.h): the plans (ok = served) as functions of
-// the geometry alone, so that the workspace queries and the launches agree
+// the geometry alone, so that the workspace queries and the launches agree.  Row thresholds (r4, inference batches
+// through FusedInferenceState): at 256 / 1024 rows the fp32-MFMA kernels of gemm.h are FASTER (92 / 163 us per inference
+// call against 104 / 164 with xgemm.h and 111 / 172 with xgemm8.h, whose pre-split pass and 128-row tiles need a
+// training-sized batch to pay)
+constexpr int kX6MinRows = 2048, kX8MinRows = 4096;
 xg::Plan x6_fwd_plan(const seedhip_conv_geom* g) {
-  if (!is_dense(g) || g->ld_in % 4 || g->cin % 4 || g->ld_out % 4) return xg::Plan{false, 1, 0, {0, 0, 0}};
+  if (!is_dense(g) || g->n_img < kX6MinRows || g->ld_in % 4 || g->cin % 4 || g->ld_out % 4) return xg::Plan{false, 1, 0, {0, 0, 0}};
   return xg::plan(g->n_img, g->cout, g->cin, (long long)g->n_img * g->ld_in * 4, (long long)g->cin * g->cout * 4);
 }
 xg::Plan x6_dgrad_plan(const seedhip_conv_geom* g) {
-  if (!is_dense(g) || g->ld_out % 4 || g->cout % 4 || g->ld_in % 4 || g->cin % 4) return xg::Plan{false, 1, 0, {0, 0, 0}};
+  if (!is_dense(g) || g->n_img < kX6MinRows || g->ld_out % 4 || g->cout % 4 || g->ld_in % 4 || g->cin % 4) return xg::Plan{false, 1, 0, {0, 0, 0}};
   return xg::plan(g->n_img, g->cin, g->cout, (long long)g->n_img * g->ld_out * 4, (long long)g->cin * g->cout * 4);
 }
 xg::Plan x6_wgrad_plan(const seedhip_conv_geom* g) {
-  if (!is_dense(g) || g->ld_in % 4 || g->cin % 4 || g->ld_out % 4 || g->cout % 4) return xg::Plan{false, 1, 0, {0, 0, 0}};
+  if (!is_dense(g) || g->n_img < kX6MinRows || g->ld_in % 4 || g->cin % 4 || g->ld_out % 4 || g->cout % 4) return xg::Plan{false, 1, 0, {0, 0, 0}};
   return xg::plan(g->cin, g->cout, g->n_img, (long long)g->n_img * g->ld_in * 4, (long long)g->n_img * g->ld_out * 4);
 }
 
 // The 8-wave structure with the small operand pre-split (xgemm8.h); workspace = [partial sums][slabs]
 xg8::Plan x8_fwd_plan(const seedhip_conv_geom* g) {
-  if (!is_dense(g) || g->ld_in % 4 || g->cin % 4 || g->ld_out % 4) return xg8::Plan{false, 0, 0, 0, 1, 0, 0, 0, 0};
+  if (!is_dense(g) || g->n_img < kX8MinRows || g->ld_in % 4 || g->cin % 4 || g->ld_out % 4) return xg8::Plan{false, 0, 0, 0, 1, 0, 0, 0, 0};
   return xg8::plan(g->n_img, g->cout, g->cin, (long long)g->n_img * g->ld_in * 4, false, false);
 }
 xg8::Plan x8_dgrad_plan(const seedhip_conv_geom* g) {
-  if (!is_dense(g) || g->ld_out % 4 || g->cout % 4 || g->ld_in % 4 || g->cin % 4) return xg8::Plan{false, 0, 0, 0, 1, 0, 0, 0, 0};
+  if (!is_dense(g) || g->n_img < kX8MinRows || g->ld_out % 4 || g->cout % 4 || g->ld_in % 4 || g->cin % 4) return xg8::Plan{false, 0, 0, 0, 1, 0, 0, 0, 0};
   return xg8::plan(g->n_img, g->cin, g->cout, 0, true, false);
 }
 xg8::Plan x8_wgrad_plan(const seedhip_conv_geom* g) {
-  if (!is_dense(g) || g->ld_in % 4 || g->cin % 4 || g->ld_out % 4 || g->cout % 4) return xg8::Plan{false, 0, 0, 0, 1, 0, 0, 0, 0};
+  if (!is_dense(g) || g->n_img < kX8MinRows || g->ld_in % 4 || g->cin % 4 || g->ld_out % 4 || g->cout % 4) return xg8::Plan{false, 0, 0, 0, 1, 0, 0, 0, 0};
   // the PRE-SPLIT operand is dY [rows x cout]: worth it only while it is the smaller of the two (an LSTM input projection,
   // 532 -> 2048, would spend more on splitting 170 MB of dY than the kernel saves: 413 vs 328 us, r4)
   if (g->cout > g->cin) return xg8::Plan{false, 0, 0, 0, 1, 0, 0, 0, 0};

@@ -518,7 +518,7 @@ def test_stack_conv_fwd_fp32_accuracy(device):
   assert e_hip <= max(2.0 * e_f32, 2e-6 * np.abs(g64).max()), (e_hip, e_f32, np.abs(g64).max())
 
 
-@pytest.mark.parametrize('n,cin,cout', [(1024, 2592, 256), (768, 3136, 512)])
+@pytest.mark.parametrize('n,cin,cout', [(2048, 2592, 256), (2304, 3136, 512)])   # (>= 2048 rows: below, gemm.h serves)
 def test_x6_gemm_fp32_accuracy(device, n, cin, cout):
   """The Dense kernels of xgemm.h evaluate fp32 x fp32 products on the bf16 matrix pipe through the exact three-way
   operand split, keeping the six partial products above 2^-25 of a product.  They must be as close to an fp64
@@ -555,7 +555,7 @@ def test_x6_gemm_fp32_accuracy(device, n, cin, cout):
   check('bias grad', db.cpu().numpy(), tdy.sum(0).numpy(), dy64.sum(0))
 
 
-@pytest.mark.parametrize('n,cin,cout', [(1000, 520, 264), (384, 2592, 256), (2048, 256, 1024)])
+@pytest.mark.parametrize('n,cin,cout', [(4100, 520, 264), (4096, 2592, 256), (4224, 256, 1024)])   # (>= 4096 rows)
 def test_x8_gemm_epilogues_and_tails(device, n, cin, cout):
   """The 8-wave bf16x6 Dense kernels (xgemm8.h: 128 x 256 tiles, the small operand pre-split into k-tile slabs) on ragged
   shapes -- rows not a multiple of 128, K not a multiple of 32, a last column tile of 8 columns -- with every fused
