@@ -19,6 +19,7 @@
 #include "xgemm8.h"
 #include "wsgemm.h"
 #include "wsw.h"
+#include "wfw.h"
 #include "../../include/seedhip.h"
 
 using namespace seedhip;
@@ -257,6 +258,16 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
   int rc = check_geom(geom, "conv2d_fwd"); if (rc) return rc;
   SEEDHIP_REQUIRE(in && w && out, "conv2d_fwd: null pointer");
   SEEDHIP_REQUIRE(in_dtype == kInF32 || in_dtype == kInU8Div255, "conv2d_fwd: bad in_dtype %d", in_dtype);
+  {
+    // image-resident forward (wfw.h): the second Atari conv at training batch sizes
+    static const int wfw_on = getenv("SEEDHIP_WFW") ? atoi(getenv("SEEDHIP_WFW")) : 1;
+    wfw::Params fp;
+    if (wfw_on && in_dtype == kInF32 && !residual && al16(in) && al16(w) && al16(out) && al16(bias) && wfw::plan(fp, geom)) {
+      fp.X = (const float*)in; fp.W = w; fp.bias = bias; fp.Y = out; fp.in_relu = in_relu; fp.out_relu = out_relu;
+      const int rc2 = wfw::launch(fp, (hipStream_t)stream);
+      if (rc2 >= 0) return rc2;
+    }
+  }
   if ((gemm_mode() & 8) && in_dtype == kInF32 && al16(in) && al16(w) && al16(out) && al16(bias) && al16(residual)) {
     // whole kernel resident in LDS, A rows gathered as 128-byte segments (wsgemm.h): the second Atari conv
     wsgemm::Params wp;

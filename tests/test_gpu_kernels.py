@@ -331,9 +331,11 @@ CONV_CASES = [
     (5, 9, 12, 16, 3, 3, 1, 'same', 32),      # weight gradient: one band per 9x12 image (6 dY prefetch vectors)
     (130, 9, 9, 64, 3, 3, 1, 'valid', 64),    # data gradient in image-block x position order: two blocks + a padded third, taps skipped at the border
     (70, 20, 20, 32, 4, 4, 2, 'valid', 64),   # the same for the stride-2 super-pixel GEMM (DQN conv2)
-    (1000, 1, 1, 68, 1, 1, 1, 'valid', 132),  # xgemm.h (bf16x6): ragged in M, N and K at once
-    (257, 1, 1, 100, 1, 1, 1, 'valid', 128),  # xgemm.h: one row past a tile, K = 3 k-tiles + 4
-    (640, 1, 1, 4100, 1, 1, 1, 'valid', 384), # xgemm.h: split-K forward / data gradient with a ragged last slice
+    (2100, 1, 1, 68, 1, 1, 1, 'valid', 132),  # xgemm.h (bf16x6; served from 2048 rows): ragged in M, N and K at once
+    (2049, 1, 1, 100, 1, 1, 1, 'valid', 128), # xgemm.h: one row past a tile, K = 3 k-tiles + 4
+    (2112, 1, 1, 4100, 1, 1, 1, 'valid', 384),# xgemm.h: split-K forward / data gradient with a ragged last slice
+    (2050, 20, 20, 16, 4, 4, 2, 'valid', 32), # wfw.h (image-resident forward, from 2048 images): 5 images per workgroup, ragged last tile
+    (2100, 19, 21, 16, 4, 4, 2, 'valid', 32), # wfw.h: odd map (72 pixels per image), slot rounded up to a KB multiple
 ]
 
 
