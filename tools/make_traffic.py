@@ -14,6 +14,14 @@ import json
 import sys
 
 REGIONS = [
+    ('conv_fwd[4x4/2 16->32 @20x20]', 'wfw::wfw_kernel'),                      # r4: image-resident forward
+    ('conv_wgrad[4x4/2 16->32 @20x20]', 'wsw::wsw_lds_kernel'),                # r4: LDS-staged weight gradient
+    ('conv_fwd[1x1/1 2592->256 @1x1]', 'xg8::xg8_kernel<0'),                   # r4: bf16x6 Dense kernels
+    ('conv_wgrad[1x1/1 2592->256 @1x1]', 'xg8::xg8_kernel<1'),
+    ('conv_dgrad[1x1/1 2592->256 @1x1]', 'xg8::xg8_kernel<2'),
+    ('conv_fwd[1x1/1 2592->256 @1x1]', 'xg::xgemm_kernel<true, false'),
+    ('conv_dgrad[1x1/1 2592->256 @1x1]', 'xg::xgemm_kernel<true, true'),
+    ('conv_wgrad[1x1/1 2592->256 @1x1]', 'xg::xgemm_kernel<false, false'),
     ('stack_conv_fwd', 'stackconv::stackconv_fwd'),
     ('stack_conv_wgrad', 'stackconv::stackconv_wgrad'),
     ('conv_fwd[4x4/2 16->32 @20x20]', 'wsgemm::ws_tab_kernel<2, 8, 0'),
@@ -35,6 +43,8 @@ def main():
   rows = list(csv.reader(open(src)))[1:]
   traffic, fetch, write, kernel = {}, {}, {}, {}
   for region, pat in REGIONS:
+    if region in traffic:
+      continue                                               # an earlier (newer-kernel) pattern already matched
     best = None
     for r in rows:
       if pat not in r[0] or not r[3] or not r[4]:
