@@ -24,6 +24,7 @@ import asyncio
 import collections
 import concurrent.futures
 import threading
+import time
 
 import grpc
 import numpy as np
@@ -616,14 +617,24 @@ class Client(object):
   def __init__(self, server_address, timeout=None):
     if not isinstance(server_address, str):
       raise InvalidArgumentError('server_address must be a scalar, got shape: %s' % _shape_str(np.shape(server_address)))
-    self._channel = grpc.insecure_channel(server_address, options=[('grpc.max_receive_message_length', -1),
-                                                                   ('grpc.max_send_message_length', -1)])
-    init = self._channel.unary_unary('/%s/Init' % SERVICE, request_serializer=InitRequest.SerializeToString,
-                                     response_deserializer=InitResponse.FromString)
-    try:
-      resp = init(InitRequest(), wait_for_ready=True, timeout=timeout)
-    except grpc.RpcError as e:
-      raise UnavailableError(e.details() or 'server closed')
+    # Init waits for the server (wait_for_ready), like the reference's client.  With no caller deadline the wait is cut into
+    # attempts on FRESH channels: a channel that started connecting while a previous server on the same address was going
+    # down can sit in its reconnect back-off long after the new server is up (seen once as a 300 s test timeout, r4).
+    opts = [('grpc.max_receive_message_length', -1), ('grpc.max_send_message_length', -1)]
+    deadline = None if timeout is None else time.time() + timeout
+    while True:
+      self._channel = grpc.insecure_channel(server_address, options=opts)
+      init = self._channel.unary_unary('/%s/Init' % SERVICE, request_serializer=InitRequest.SerializeToString,
+                                       response_deserializer=InitResponse.FromString)
+      attempt = 10.0 if deadline is None else max(0.05, min(10.0, deadline - time.time()))
+      try:
+        resp = init(InitRequest(), wait_for_ready=True, timeout=attempt)
+        break
+      except grpc.RpcError as e:
+        retry = e.code() == grpc.StatusCode.DEADLINE_EXCEEDED and (deadline is None or time.time() < deadline)
+        self._channel.close()
+        if not retry:
+          raise UnavailableError(e.details() or 'server closed')
     self._mu = threading.Lock()
     self._queue = collections.deque()
     self._cv = threading.Condition()
