@@ -43,6 +43,7 @@ namespace stackconv {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+typedef unsigned su32x4_t __attribute__((ext_vector_type(4)));
 constexpr int kWaves = 5;
 constexpr int kThreads = kWaves * 64;
 constexpr int kMT = 5;         // MFMA tiles in flight per wave (forward)
@@ -60,6 +61,7 @@ struct Params {
   int T1, B, ih, iw, oh, ow, cout, ld_out, out_relu;
   int fsz;                     // ih*iw bytes, multiple of 16, <= 2*kThreads*16
   int spc, items;              // steps per chunk; items = B * nchunks
+  int buf32;                   // fwd (bf16x3 kernel): frames_ext and out are < 2 GB: the time loop addresses them as buffers (uniform 32-bit step offsets)
   unsigned char* relu_bits;    // fwd (bf16x3 kernel), optional: [T1*B*oh*ow, ld_out / 4] bytes, bit r of byte q = out[.., 4q + r] > 0
 };
 
@@ -437,7 +439,13 @@ __device__ __forceinline__ void band_prologue16(const Params& p, unsigned char* 
 // BITS: also write the ReLU byte mask (Params::relu_bits).  RELU: the output activation as a template parameter -- a
 // run-time `if (p.out_relu)` is a branch per output tile, and every branch in the epilogue is a basic-block boundary the
 // scheduler cannot move the stores / the next frame's work across (an untaken one around the byte store cost 20 us).
-template <int EXP, bool BITS = false, bool RELU = true>
+// BUF (r4): the time loop reaches frames_ext and out through buffer resources -- a step's base is a UNIFORM 32-bit byte
+// offset (SGPR soffset), the lane's part a loop-invariant 32-bit register.  With 64-bit per-lane pointers the kernel
+// recomputed five output addresses per step (v_mad_u64 chains) from loop invariants that did not fit its 168 registers:
+// four 64-bit values were SPILLED and reloaded at the head of every step, each reload behind an s_waitcnt vmcnt(0) --
+// i.e. every step first waited for the previous step's five output stores to reach memory (found in the ISA:
+// tools/isa_waits.py prints "spilled VGPRs 8"; the matrix pipe was 26 % busy).
+template <int EXP, bool BITS = false, bool RELU = true, bool BUF = false>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
 stackconv_fwd_bf16r_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -484,6 +492,16 @@ stackconv_fwd_bf16r_kernel(const Params p) {
   }
   __syncthreads();                                    // lo parts visible; the only workgroup barrier
 
+  // BUF: views of the two big tensors and the lane's loop-invariant byte offsets into a step's slice of them
+  const __amdgpu_buffer_rsrc_t fview = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.frames_ext), 0, BUF ? (int)((long long)(3 + p.T1) * p.B * p.fsz) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t oview = __builtin_amdgcn_make_buffer_rsrc(
+      p.out, 0, BUF ? (int)((long long)p.T1 * p.B * 400 * p.ld_out * 4) : 0, 0x00020000);
+  const unsigned fv0 = 16u * (unsigned)lane, fv1 = lane + 64 < kBandVec ? 16u * (unsigned)(lane + 64) : 0x80000000u;
+  unsigned ov[kMT];
+#pragma unroll
+  for (int m = 0; m < kMT; ++m) ov[m] = (unsigned)(((wave * 80 + m * 16 + j) * p.ld_out + co0 + 4 * kq) * 4);
+
   for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
     const int b = item % p.B, chunk = item / p.B;
     const int t0 = chunk * p.spc;
@@ -494,6 +512,13 @@ stackconv_fwd_bf16r_kernel(const Params p) {
       const int nv = nvalid_at(p.nvalid, (long long)t * p.B + b);
       BandPrefetch pf;
       if (EXP & 2) { pf.v0 = make_uint4(lane, t, 3, 4); pf.v1 = pf.v0; }
+      else if (BUF) {
+        if (more) {
+          const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(((t + 4) * p.B + b) * p.fsz + wave * 16 * kIW));
+          pf.v0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(fview, fv0, so, 0));
+          pf.v1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(fview, fv1, so, 0));
+        }
+      }
       else if (more) pf = band_load(band_src(p, t + 4, b, wave), lane);
       f32x4_t acc[kMT];
 #pragma unroll
@@ -548,16 +573,29 @@ stackconv_fwd_bf16r_kernel(const Params p) {
         else band_store16(myring + ((t + 4) % kSlots) * kBand16, pf, lane);
         wave_lds_fence();
       }
+      const unsigned oso = __builtin_amdgcn_readfirstlane((unsigned)((t * p.B + b) * 400 * p.ld_out) * 4u);   // BUF: this step's slice of out
+      // Every output is FINISHED before the first store (pinned): a 16-byte store reads its data registers over several
+      // cycles, and hipcc put the next tile's `v_pk_add_f32` -- which reuses them -- into the very next issue slot
+      // behind `buffer_store_dwordx4` (no wait state: the stored quad's upper half came out as the next tile's;
+      // tools/isa_store_hazard.py finds the pattern in a compiled object, tests/test_isa_structure.py runs it)
+      f32x4_t vout[kMT];
+#pragma unroll
+      for (int m = 0; m < kMT; ++m) {
+        vout[m] = acc[m] + bias4;
+        if (RELU) {                                    // one v_med3 each (fmaxf is two: it first quiets its operand)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vout[m][r] = __builtin_amdgcn_fmed3f(vout[m][r], 0.f, __builtin_inff());
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < kMT; ++m) asm volatile("" : "+v"(vout[m]));
 #pragma unroll
       for (int m = 0; m < kMT; ++m) {
         const int pix = wave * 80 + m * 16 + j;
-        f32x4_t v = acc[m] + bias4;
-        if (RELU) {                                    // one v_med3 each (fmaxf is two: it first quiets its operand)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], 0.f, __builtin_inff());
-        }
+        const f32x4_t v = vout[m];
         float* o = p.out + (((long long)t * p.B + b) * 400 + pix) * p.ld_out + co0 + 4 * kq;
         if (EXP & 4) asm volatile("" :: "v"(v));
+        else if (BUF) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(su32x4_t, v), oview, ov[m], oso, 0);
         else *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         // the ReLU mask the next layer's data gradient needs, as one byte per lane (its four channels): that kernel then
         // reads 1 byte where it read the 16 of the activation (wsgemm.h, ws_tab_kernel<.., BITS>)
@@ -1207,15 +1245,19 @@ int launch_fwd(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, cons
     const size_t lds = (size_t)kGroups * 64 * 16 + (size_t)kWaves * kWaveRing16;
     int grid;
     decompose(p.T1, p.B, max_grid_for(2), &p.spc, &p.items, &grid);
-#define SEEDHIP_SCF(BITS_, RELU_)                                                                                 \
+#define SEEDHIP_SCF(BITS_, RELU_, BUF_)                                                                           \
     {                                                                                                             \
-      (void)hipFuncSetAttribute((const void*)stackconv_fwd_bf16r_kernel<0, BITS_, RELU_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      hipLaunchKernelGGL((stackconv_fwd_bf16r_kernel<0, BITS_, RELU_>), dim3(grid, 1, g->cout / 16), dim3(kThreads), lds, s, p); \
+      (void)hipFuncSetAttribute((const void*)stackconv_fwd_bf16r_kernel<0, BITS_, RELU_, BUF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((stackconv_fwd_bf16r_kernel<0, BITS_, RELU_, BUF_>), dim3(grid, 1, g->cout / 16), dim3(kThreads), lds, s, p); \
       return check_launch("stackconv_fwd_bf16r_kernel");                                                          \
     }
-    if (relu_bits) SEEDHIP_SCF(true, true)
-    if (out_relu) SEEDHIP_SCF(false, true)
-    SEEDHIP_SCF(false, false)
+    static const int buf_on = getenv("SEEDHIP_STACK_BUF") ? atoi(getenv("SEEDHIP_STACK_BUF")) : 1;
+    const long long lim = (1LL << 31) - (1 << 20);
+    p.buf32 = buf_on && (long long)(3 + p.T1) * p.B * p.fsz < lim && (long long)p.T1 * p.B * 400 * p.ld_out * 4 < lim;
+    if (relu_bits) SEEDHIP_SCF(true, true, false)
+    if (p.buf32) { if (out_relu) SEEDHIP_SCF(false, true, true) else SEEDHIP_SCF(false, false, true) }
+    if (out_relu) SEEDHIP_SCF(false, true, false)
+    SEEDHIP_SCF(false, false, false)
 #undef SEEDHIP_SCF
   }
   const size_t lds = kWFloats * sizeof(float) + (size_t)kWaves * kWaveRing;

@@ -50,7 +50,14 @@ def test_first_conv_reads_nvalid_through_the_scalar_cache(code_objects):
 
 def test_register_budgets_of_the_hot_kernels(code_objects):
   budget = {                                             # pattern -> (max VGPRs, max spilled VGPRs)
-      'stackconv_fwd_bf16r_kernelILi0ELb0ELb1': (168, 16),     # three waves per SIMD
+      'stackconv_fwd_bf16r_kernelILi0ELb0ELb1ELb0': (168, 16),  # three waves per SIMD (64-bit pointers: tensors >= 2 GB)
+      'stackconv_fwd_bf16r_kernelILi0ELb0ELb1ELb1': (168, 0),   # r4, buffer-addressed time loop: NO spill (8 spilled VGPRs were
+                                                                 # reloaded behind s_waitcnt vmcnt(0) at the head of every step)
+      'stackconv_fwd_bf16r_kernelILi0ELb0ELb0ELb1': (168, 0),
+      'wsw_lds_kernelILb0ELi21ELi0': (256, 0),                  # two 4-wave workgroups per CU (LDS)
+      'wfw_kernelILb0': (256, 0),
+      'xg8_kernelILi0ELi0': (256, 0),                           # one 8-wave workgroup per CU: two waves per SIMD
+      'xg8_kernelILi1ELi0': (256, 0),
       'stackconv_wgrad_cp_kernelILi16': (128, 0),              # two 8-wave workgroups per CU
       'ws_tab_kernelILi4ELi4ELi1ELi0ELb0ELb1': (128, 0),       # data gradient with the mask a tile ahead: four waves per SIMD
       'ws_tab_kernelILi2ELi8ELi0ELi0ELb0ELb0': (128, 0),
@@ -78,3 +85,17 @@ def test_halo_epilogue_is_one_wait_then_stores(code_objects):
 def test_halo_wgrad_prefetch_is_unconditional(code_objects):
   for co, name, _ in _find(code_objects, 'halo_wgrad_kernelILi9ELi2ELi2ELb1'):
     assert any(o.startswith('buffer_load_dwordx4') for o in _ops(code_objects, co, name))
+
+
+def test_no_wide_store_followed_by_a_write_of_its_data():
+  """A 12/16-byte VMEM store reads its data registers over several cycles; hipcc (ROCm 7.2, gfx950) has been seen to put a
+  VALU instruction that REWRITES them into the very next issue slot behind a `buffer_store_dwordx4` -- the stored quad then
+  carries the next tile's values (r4: the first conv's forward without ReLU).  No compiled kernel may contain the pattern
+  (tools/isa_store_hazard.py; outputs are finished and pinned before the first store where it appeared)."""
+  import subprocess, sys
+  lib = os.path.join(ROOT, 'seed_rl_amd', 'lib', 'libseedhip.so')
+  if not os.path.exists(lib):
+    pytest.skip('library not built')
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'isa_store_hazard.py'), lib], capture_output=True, text=True,
+                     timeout=600)
+  assert r.returncode == 0, r.stdout[-3000:]
