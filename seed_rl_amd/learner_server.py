@@ -90,7 +90,13 @@ class LearnerServer(object):
     ao_specs = networks.AgentOutput(Spec((), torch.int64), Spec((A,), torch.float32), Spec((), torch.float32))
     # room for every env completing an unroll at once (lock-stepped actors do) on top of a batch being assembled and
     # the inference batches in flight: back-pressure (BatchGate) then only engages when the learner really lags
-    cap = batch_capacity or (2 * batch_size + num_envs + inference_batch_size * (inference_slots + 1))
+    #  a full training batch plus every inference batch that can be admitted or staged ahead must fit, or
+    # neither the learner (fill < B) nor inference (no room) could ever make progress
+    need = batch_size + inference_batch_size * (inference_slots + 2)
+    cap = batch_capacity or max(need, 2 * batch_size + num_envs + inference_batch_size * (inference_slots + 1))
+    if cap < need:
+      raise ValueError('batch_capacity %d is too small: need >= batch_size + inference_batch_size * (inference_slots + 2) = %d'
+                       % (cap, need))
     with torch.cuda.device(dev):
       self.infer_stream = torch.cuda.Stream(device=dev, priority=-1)
       self.train_stream = torch.cuda.Stream(device=dev)
@@ -141,7 +147,22 @@ class LearnerServer(object):
       return buf
     return torch.zeros((T1, B) + tuple(shape), dtype=dtype, device=self.device)
 
+  def prepare(self):
+    """Captures every slot's train-step graph BEFORE actors are served: GraphedStep's warm-up runs real
+    optimizer steps on the shared flat parameter buffer and only then restores it, and capture synchronises the device
+    -- neither belongs in the middle of serving, where the inference twin would act on perturbed weights."""
+    if not self._use_graph:
+      return
+    with torch.cuda.device(self.device), torch.cuda.stream(self.train_stream):
+      for slot in range(len(self.unrolls)):
+        if self._graphs[slot] is None:
+          if hasattr(self.agent, 'frames_slot'):
+            self.agent.frames_slot = slot
+          self._graphs[slot] = learner_lib.GraphedStep(self.learner, self.unrolls[slot])
+    torch.cuda.synchronize(self.device)
+
   def start(self):
+    self.prepare()
     self.server.start()
 
   def shutdown(self):

@@ -26,6 +26,8 @@ class PrioritizedReplay(object):
     """FIFO insertion with wrap-around (utils.py:277-307).  Returns the int64 slot indices."""
     flat_v = utils.flatten(values)
     n = flat_v[0].shape[0]
+    if n > self._size:                 # duplicate slots would race in the row mover (the reference's scatter is undefined there too)
+      raise ValueError('insert of %d values into a replay buffer of size %d' % (n, self._size))
     idx = (torch.arange(self.num_inserted, self.num_inserted + n, dtype=torch.int64, device=self.device)
            % self._size).contiguous()
     bufs = utils.flatten(self._buffer)
@@ -106,6 +108,8 @@ class UnrollReplay(PrioritizedReplay):
     [T1, n, ...]; `unroll.priority` itself is stored too when the specs hold it.  Returns the slot indices."""
     tv, sv = self._leaves(unroll)
     n = int(torch.as_tensor(priorities).shape[0])
+    if n > self._size:
+      raise ValueError('insert of %d unrolls into a replay buffer of size %d' % (n, self._size))
     slots = (torch.arange(self.num_inserted, self.num_inserted + n, dtype=torch.int64, device=self.device)
              % self._size).contiguous()
     rr = self._rows(slots)
