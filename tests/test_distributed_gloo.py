@@ -172,3 +172,50 @@ def test_shard_columns():
   assert learner.shard_columns(4096, 3, 8) == slice(1536, 2048)
   with pytest.raises(ValueError):
     learner.shard_columns(10, 0, 4)
+
+
+def _force_worker(rank, world, port, out):
+  sys.path.insert(0, ROOT)
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from seed_rl_amd import learner
+    from seed_rl_amd.flat import FlatParams
+
+    class _Agent(object):
+      grad_ready_hook = None
+
+      def __init__(self):
+        self.flat = FlatParams([('conv', (37,)), ('fc', (101,))], torch.device('cpu'))
+
+      def backward(self):
+        self.flat.grads.copy_(torch.arange(self.flat.size, dtype=torch.float32) + 1.0)
+        if self.grad_ready_hook is not None:
+          self.grad_ready_hook(self.flat.offsets['fc'], self.flat.size)
+
+    plain = learner.Learner(_Agent(), None, None)
+    assert plain.world == 1 and not plain.exchanging
+    forced = learner.Learner(_Agent(), None, None, force_exchange=True)
+    assert forced.world == 1 and forced.exchanging
+    forced.agent.grad_ready_hook = forced._on_grads_ready
+    forced.agent.backward()
+    forced.agent.grad_ready_hook = None
+    assert len(forced._pending) == 1                 # the reported range flew as an asynchronous all-reduce of ONE rank
+    forced.reduce_gradients()                        # ... and the remainder is exchanged here
+    assert forced._pending == []
+    assert torch.equal(forced.agent.flat.grads, torch.arange(forced.agent.flat.size, dtype=torch.float32) + 1.0)   # a one-rank SUM is the identity
+    open(out, 'w').write('ok')
+  finally:
+    torch.distributed.destroy_process_group()
+
+
+def test_force_exchange_with_one_rank(tmp_path):
+  """Learner(force_exchange=True): the N-replica exchange path (ready-range hook, asynchronous range all-reduce, remainder
+  in reduce_gradients) in a process group of ONE rank -- the CPU twin of tests/test_gpu_rccl_rehearsal.py."""
+  out = str(tmp_path / 'ok.txt')
+  mp.spawn(_force_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+  assert open(out).read() == 'ok'
+  from seed_rl_amd import learner
+  with pytest.raises(ValueError):
+    learner.Learner(object(), None, None, force_exchange=True)      # no process group in THIS process
