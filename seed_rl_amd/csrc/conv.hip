@@ -20,6 +20,7 @@
 #include "wsgemm.h"
 #include "wsw.h"
 #include "wfw.h"
+#include "wfx.h"
 #include "../../include/seedhip.h"
 
 using namespace seedhip;
@@ -258,6 +259,16 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
   int rc = check_geom(geom, "conv2d_fwd"); if (rc) return rc;
   SEEDHIP_REQUIRE(in && w && out, "conv2d_fwd: null pointer");
   SEEDHIP_REQUIRE(in_dtype == kInF32 || in_dtype == kInU8Div255, "conv2d_fwd: bad in_dtype %d", in_dtype);
+  {
+    // the second Atari conv at training batch sizes on the bf16 matrix pipe (wfx.h: exact three-way split, six products)
+    static const int wfx_on = getenv("SEEDHIP_WFX") ? atoi(getenv("SEEDHIP_WFX")) : 1;
+    wfx::Params xp;
+    if (wfx_on && in_dtype == kInF32 && !residual && al16(in) && al16(w) && al16(out) && al16(bias) && wfx::plan(xp, geom)) {
+      xp.X = (const float*)in; xp.W = w; xp.bias = bias; xp.Y = out; xp.in_relu = in_relu; xp.out_relu = out_relu;
+      const int rc2 = wfx::launch(xp, (hipStream_t)stream);
+      if (rc2 >= 0) return rc2;
+    }
+  }
   {
     // image-resident forward (wfw.h): the second Atari conv at training batch sizes
     static const int wfw_on = getenv("SEEDHIP_WFW") ? atoi(getenv("SEEDHIP_WFW")) : 1;

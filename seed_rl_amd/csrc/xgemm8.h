@@ -153,6 +153,7 @@ struct Args {
   const unsigned char* Bp;      // pre-split B slabs, XT = 256
   const float* colsum_kt;       // [nkt][N] per-k-tile column sums of B (xsplit), or null; summed per slice by m-tile 0
   int mt, nt, slices, kt_per_slice, nkt;
+  unsigned long long* trace;    // EXP & 128 builds: s_memtime stamps of workgroup 0 (tools/trace_x8.py), [group][k-tile][8]
   int slice_major;              // item order (slice, m-tile, n-tile) instead of (m-tile, slice, n-tile)
   int prio;                     // s_setprio of a wave's MEM segment (its COMP segment runs at 0)
 };
@@ -243,6 +244,74 @@ struct StageOC4 {
     }
   }
 };
+// ---- the same for ALL 512 threads, two vectors each (DMA builds: group 1's B slab comes by LDS-DMA, so both groups
+// share the split of operand A: r4b trace, 2174 cycles of MEM for waves 0-3 against 1600 of COMP) ------------------- //
+struct StageKC2 {
+  unsigned voff, step, wofs;
+  int nvalid, kq4;
+  __device__ void init(int u, long long ld, int x0, int X) {
+    const int q = u & 7, row = u >> 3;                       // row 0..63; rows row + 64 i
+    voff = (unsigned)(((long long)(x0 + row) * ld + 4 * q) * 4);
+    int nv = (X - x0 - row + 63) >> 6;
+    nvalid = nv < 0 ? 0 : (nv > 2 ? 2 : nv);
+    step = (unsigned)(ld * 256);
+    kq4 = 4 * q;
+    wofs = (unsigned)(xg::kc_chunk(row, q >> 1) + (q & 1) * 8);
+  }
+  __device__ void load(f32x4_t (&r)[2], const __amdgpu_buffer_rsrc_t& rs, int k, int k1) {
+    const bool kin = k + kq4 < k1;
+    const unsigned kb = (unsigned)k * 4u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) r[i] = xg::view_load_s(rs, (kin && i < nvalid) ? voff : kViewOOB, kb + (unsigned)i * step);
+  }
+  __device__ void store(f32x4_t (&r)[2], unsigned char* lds, bool relu) const {
+    if (relu) { xg::relu4(r[0]); xg::relu4(r[1]); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned h0, m0, l0, h1, m1, l1;
+      xg::split2(r[i][0], r[i][1], h0, m0, l0);
+      xg::split2(r[i][2], r[i][3], h1, m1, l1);
+      unsigned char* d = lds + wofs + i * (64 * 64);
+      *reinterpret_cast<xg::u32x2_t*>(d) = xg::u32x2_t{h0, h1};
+      *reinterpret_cast<xg::u32x2_t*>(d + kAPlane) = xg::u32x2_t{m0, m1};
+      *reinterpret_cast<xg::u32x2_t*>(d + 2 * kAPlane) = xg::u32x2_t{l0, l1};
+    }
+  }
+};
+// outer-contiguous: thread (c = u >> 7, kp = (u >> 5) & 3, xq = u & 31) loads x = 4 xq .. 4 xq + 3 of rows k = 8 c + 2 kp
+// and + 1 and writes, per plane and x, the 4-byte word (k, k + 1) of chunk (x, c)
+struct StageOC2 {
+  unsigned voff, ld4;
+  int kr, xq, c, kp;
+  bool xin;
+  __device__ void init(int u, long long ld, int x0, int X) {
+    xq = u & 31; kp = (u >> 5) & 3; c = u >> 7;
+    kr = 8 * c + 2 * kp;
+    xin = x0 + 4 * xq < X;
+    voff = (unsigned)(((long long)kr * ld + x0 + 4 * xq) * 4);
+    ld4 = (unsigned)(ld * 4);
+  }
+  __device__ void load(f32x4_t (&r)[2], const __amdgpu_buffer_rsrc_t& rs, int k, int k1) {
+    const unsigned kb = (unsigned)k * ld4;
+    const int nrow = k1 - k - kr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) r[i] = xg::view_load_s(rs, (xin && i < nrow) ? voff : kViewOOB, kb + (unsigned)i * ld4);
+  }
+  __device__ void store(f32x4_t (&r)[2], unsigned char* lds, bool relu) const {
+    if (relu) { xg::relu4(r[0]); xg::relu4(r[1]); }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned h, m, l;
+      xg::split2(r[0][e], r[1][e], h, m, l);
+      unsigned char* d = lds + xg::oc_chunk(4 * xq + e, c) + kp * 4;
+      *reinterpret_cast<unsigned*>(d) = h;
+      *reinterpret_cast<unsigned*>(d + kAPlane) = m;
+      *reinterpret_cast<unsigned*>(d + 2 * kAPlane) = l;
+    }
+  }
+};
+template <int AMODE> struct PickStage2 { typedef StageKC2 type; };
+template <> struct PickStage2<1> { typedef StageOC2 type; };
 template <int AMODE> struct PickStage4 { typedef StageKC4 type; };
 template <> struct PickStage4<1> { typedef StageOC4 type; };
 
@@ -255,7 +324,12 @@ template <> struct PickStage4<1> { typedef StageOC4 type; };
 // between 2j + 1 and 2j + 2) into the stage whose previous tile j - 1 both groups finished READING before barrier 2j;
 // it is complete at barrier 2j + 2, before either group's MEM(j + 1).
 // EXP (probes, garbage results): 4 no split arithmetic, 8 no MFMAs, 32 no fragment reads
-template <int AMODE, int EXP, int GROUP>
+// DMA (r4b): group 1 brings its B slab by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KB per wave instruction: no VGPRs, no
+// ds_write) -- the slab IS the LDS image.  Tile j + 1 is requested right behind barrier 2j, at the HEAD of the group's
+// COMP(j - 1) segment (the stage's previous tile j - 1 was last read before that barrier), flies under the whole period
+// and is waited for (vmcnt(0)) at the end of the group's MEM(j), before barrier 2j + 2.  The hand-over barriers are raw
+// `s_barrier`s behind `s_waitcnt lgkmcnt(0)`: `__syncthreads()` would drain the DMA at EVERY barrier (it waits vmcnt(0)).
+template <int AMODE, int EXP, int GROUP, bool DMA>
 __device__ __forceinline__ void xg8_body(const Args& g, unsigned char* smem, const int wave) {
   const Params& p = g.p;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -275,7 +349,11 @@ __device__ __forceinline__ void xg8_body(const Args& g, unsigned char* smem, con
   // ---- staging ---- //
   constexpr bool kSplitA = AMODE != 2;
   constexpr bool kSplitter = kSplitA && GROUP == 0;
-  constexpr int kCopies = GROUP == 1 ? 12 : 6;          // 16-byte chunks of a slab per thread and k-tile
+  constexpr bool kDmaB = DMA && GROUP == 1;
+  constexpr bool kShare = DMA && kSplitA;               // DMA builds: all 512 threads split operand A, two vectors each
+  constexpr int kCopies = GROUP == 1 ? (kDmaB ? 1 : 12) : 6;   // 16-byte chunks of a slab per thread and k-tile (registers)
+  typename PickStage2<AMODE>::type sa2;
+  f32x4_t ra2[2];
   typename PickStage4<AMODE>::type sa;
   f32x4_t ra[4];
   u32x4_t rc[kCopies];
@@ -283,14 +361,29 @@ __device__ __forceinline__ void xg8_body(const Args& g, unsigned char* smem, con
   const __amdgpu_buffer_rsrc_t va = make_view(p.A, kSplitter ? ((AMODE == 0 ? (long long)p.M : (long long)p.K) * p.lda * 4) : 0);
   const __amdgpu_buffer_rsrc_t vs = GROUP == 1 ? make_view((const float*)g.Bp, (long long)((size_t)g.nt * g.nkt * kBImg))
                                                : make_view((const float*)g.Ap, kSplitA ? 0 : (long long)((size_t)g.mt * g.nkt * kAImg));
-  if constexpr (kSplitter) sa.init(u, p.lda, m0, p.M);
+  if constexpr (kSplitter && !kShare) sa.init(u, p.lda, m0, p.M);
+  const __amdgpu_buffer_rsrc_t va2 = make_view(p.A, kShare ? ((AMODE == 0 ? (long long)p.M : (long long)p.K) * p.lda * 4) : 0);
+  if constexpr (kShare) sa2.init(tid, p.lda, m0, p.M);
   const unsigned slab0 = GROUP == 1 ? (unsigned)((ntile * g.nkt + kt0) * kBImg) : (unsigned)((mtile * g.nkt + kt0) * kAImg);
   constexpr unsigned kSlab = GROUP == 1 ? kBImg : kAImg;
   constexpr int kImgOff = GROUP == 1 ? kAImg : 0;        // where this group's image starts inside a stage
 
+  auto dma_tile = [&](int j, unsigned char* stage) {     // DMA: k-tile j of the B slab -> stage (asynchronous)
+    const int jj = j < nkt ? j : nkt - 1;
+    const unsigned so = slab0 + (unsigned)jj * kSlab;
+    typedef __attribute__((address_space(3))) void lds_void_t;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int piece = (wave - 4) + 4 * i;              // 48 pieces of 1 KB, twelve per wave
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(vs, (lds_void_t*)(stage + kAImg + piece * 1024), 16, 16u * (unsigned)lane,
+                                               __builtin_amdgcn_readfirstlane(so + (unsigned)piece * 1024u), 0, 0);
+    }
+  };
   auto load_tile = [&](int j) {                          // k-tile j of this slice -> registers (clamped past the end)
     const int jj = j < nkt ? j : nkt - 1;
-    if constexpr (kSplitter) { sa.load(ra, va, (kt0 + jj) * BK, k_end); }
+    if constexpr (kShare) { sa2.load(ra2, va2, (kt0 + jj) * BK, k_end); }
+    else if constexpr (kDmaB) { (void)jj; }
+    else if constexpr (kSplitter) { sa.load(ra, va, (kt0 + jj) * BK, k_end); }
     else {
       const unsigned so = slab0 + (unsigned)jj * kSlab;
 #pragma unroll
@@ -299,7 +392,9 @@ __device__ __forceinline__ void xg8_body(const Args& g, unsigned char* smem, con
     }
   };
   auto store_tile = [&](unsigned char* stage) {          // registers -> LDS stage (the image IS the slab: chunk i at 16 i)
-    if constexpr (kSplitter) { sa.template store<EXP>(ra, stage, p.a_relu != 0); }
+    if constexpr (kShare) { sa2.store(ra2, stage, p.a_relu != 0); }
+    else if constexpr (kDmaB) { (void)stage; }
+    else if constexpr (kSplitter) { sa.template store<EXP>(ra, stage, p.a_relu != 0); }
     else {
 #pragma unroll
       for (int i = 0; i < kCopies; ++i) *reinterpret_cast<u32x4_t*>(stage + kImgOff + (u + 256 * i) * 16) = rc[i];
@@ -376,17 +471,54 @@ __device__ __forceinline__ void xg8_body(const Args& g, unsigned char* smem, con
     __builtin_amdgcn_sched_barrier(0);
     if (prio) __builtin_amdgcn_s_setprio(0);
   };
-  auto hand_over = [&]() { __builtin_amdgcn_sched_barrier(0); __syncthreads(); };
+  auto hand_over = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DMA) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // NOT vmcnt: a DMA may be in flight
+    else __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  };
 
-  load_tile(0);
-  store_tile(st0);
-  load_tile(1);
-  __syncthreads();
+  const bool tr = (EXP & 128) && g.trace != nullptr && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0;
+  unsigned long long* tb = g.trace + GROUP * 64 * 8;
+  auto stamp = [&](int j, int k) { if ((EXP & 128) && tr && j < 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tb[j * 8 + k] = __builtin_amdgcn_s_memtime(); } };
+  // publish: the group's DMA pieces have landed (its own newer register loads -- kShare: two -- may stay in flight)
+  auto publish = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (kShare) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if constexpr (kDmaB) dma_tile(0, st0);
+  if constexpr (!kDmaB || kShare) { load_tile(0); store_tile(st0); load_tile(1); }
+  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else __syncthreads();
   if constexpr (GROUP == 0) {
-    for (int j = 0; j < nkt; ++j) { mem(j); hand_over(); comp(); hand_over(); }
+    for (int j = 0; j < nkt; ++j) { stamp(j, 0); mem(j); stamp(j, 1); hand_over(); stamp(j, 2); comp(); stamp(j, 3); hand_over(); stamp(j, 4); }
+  } else if constexpr (kDmaB) {
+    // MEM of this group: fragments, its share of operand A (kShare), then the wait for the DMA pieces requested a period ago
+    auto mem1 = [&](int j) {
+      read_frags((j & 1) ? st1 : st0);
+      if constexpr (kShare) { store_tile((j & 1) ? st0 : st1); load_tile(j + 2); }
+    };
+    dma_tile(1, st1);                                    // behind barrier 0: tile 1 flies under group 0's MEM(0)
+    hand_over();                                         // barrier 1
+    mem1(0);
+    publish();                                           // barrier 2: tile 1 complete
+    for (int j = 1; j < nkt; ++j) {
+      stamp(j, 0);
+      dma_tile(j + 1, (j & 1) ? st0 : st1);              // behind barrier 2j: stage (j + 1) & 1, tile j - 1 is read out
+      comp();                                            // COMP(j - 1)
+      stamp(j, 1);
+      hand_over();                                       // barrier 2j + 1
+      stamp(j, 2);
+      mem1(j);                                           // MEM(j)
+      stamp(j, 3);
+      publish();                                         // barrier 2j + 2: tile j + 1 complete
+      stamp(j, 4);
+    }
+    comp();
   } else {
     hand_over(); mem(0); hand_over();
-    for (int j = 1; j < nkt; ++j) { comp(); hand_over(); mem(j); hand_over(); }
+    for (int j = 1; j < nkt; ++j) { stamp(j, 0); comp(); stamp(j, 1); hand_over(); stamp(j, 2); mem(j); stamp(j, 3); hand_over(); stamp(j, 4); }
     comp();
   }
 
@@ -466,13 +598,13 @@ __device__ __forceinline__ void xg8_body(const Args& g, unsigned char* smem, con
   }
 }
 
-template <int AMODE, int EXP = 0>
+template <int AMODE, int EXP = 0, bool DMA = false>
 __global__ void __launch_bounds__(512, 2)
 xg8_kernel(const Args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  if (wave < 4) xg8_body<AMODE, EXP, 0>(g, smem, wave);
-  else xg8_body<AMODE, EXP, 1>(g, smem, wave);
+  if (wave < 4) xg8_body<AMODE, EXP, 0, DMA>(g, smem, wave);
+  else xg8_body<AMODE, EXP, 1, DMA>(g, smem, wave);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------ //
@@ -530,7 +662,7 @@ inline bool launch(const Params& p, const Plan& pl, const void* Ap, const void* 
   g.p = p; g.Ap = (const unsigned char*)Ap; g.Bp = (const unsigned char*)Bp; g.colsum_kt = colsum_kt;
   g.mt = pl.mt; g.nt = pl.nt; g.slices = pl.slices; g.kt_per_slice = pl.kt_per_slice; g.nkt = pl.nkt;
   static const int order = xg::env_int("SEEDHIP_X8_ORDER", 1), prio = xg::env_int("SEEDHIP_X8_PRIO", 0);
-  g.slice_major = order; g.prio = prio;
+  g.slice_major = order; g.prio = prio; g.trace = xg::trace_ptr();
   const int blocks = pl.mt * pl.nt * pl.slices;
   static const int ex = xg::env_int("SEEDHIP_X8_EXP", 0);
 #define XG8_GO(E) { \
@@ -538,7 +670,19 @@ inline bool launch(const Params& p, const Plan& pl, const void* Ap, const void* 
     if (!ok) return false; \
     hipLaunchKernelGGL((xg8_kernel<AMODE, E>), dim3(blocks), dim3(512), kLds, s, g); return true; }
   if constexpr (AMODE == 0) {
-    if (ex == 4) XG8_GO(4) if (ex == 8) XG8_GO(8) if (ex == 32) XG8_GO(32) if (ex == 44) XG8_GO(44)
+    if (ex == 4) XG8_GO(4) if (ex == 8) XG8_GO(8) if (ex == 32) XG8_GO(32) if (ex == 44) XG8_GO(44) if (ex == 128 && !xg::env_int("SEEDHIP_X8_DMA", 0)) XG8_GO(128)
+    if (ex == 132) XG8_GO(132) if (ex == 160) XG8_GO(160)
+  }
+  static const int dma = xg::env_int("SEEDHIP_X8_DMA", 0);
+  if constexpr (AMODE == 0) {
+    if (dma && ex == 128) {
+      static const bool ok = hipFuncSetAttribute((const void*)xg8_kernel<AMODE, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
+      if (ok) { hipLaunchKernelGGL((xg8_kernel<AMODE, 128, true>), dim3(blocks), dim3(512), kLds, s, g); return true; }
+    }
+  }
+  if (dma && ex == 0) {
+    static const bool ok = hipFuncSetAttribute((const void*)xg8_kernel<AMODE, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
+    if (ok) { hipLaunchKernelGGL((xg8_kernel<AMODE, 0, true>), dim3(blocks), dim3(512), kLds, s, g); return true; }
   }
   XG8_GO(0)
 #undef XG8_GO

@@ -557,6 +557,37 @@ def test_x6_gemm_fp32_accuracy(device, n, cin, cout):
   check('bias grad', db.cpu().numpy(), tdy.sum(0).numpy(), dy64.sum(0))
 
 
+@pytest.mark.parametrize('n,in_relu,out_relu,bias', [(2048, False, True, True), (2049, True, True, True), (2309, False, False, False),
+                                                     (8448, False, True, True)])
+def test_wfx_conv2_forward_fp32_accuracy(device, n, in_relu, out_relu, bias):
+  """The second Atari conv's forward on the bf16 matrix pipe (wfx.h: exact three-way split of activations and weights,
+  six plane products, rows of the run staged once into an LDS ring).  As close to an fp64 evaluation as torch's fp32
+  convolution is (max error <= 2x), for runs of 8 / 9 / 10 / 33 images per workgroup with ragged last workgroups and
+  dead lanes in the last round; and bit-identical from call to call."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(n)
+  x = rng.normal(size=(n, 20, 20, 16)).astype(np.float32)
+  w = (rng.normal(size=(4, 4, 16, 32)) / 16).astype(np.float32)
+  b = rng.normal(size=32).astype(np.float32) if bias else None
+  tx, tw = torch.tensor(x).permute(0, 3, 1, 2), torch.tensor(w).permute(3, 2, 0, 1)
+  if in_relu: tx = F.relu(tx)
+  y32 = F.conv2d(tx, tw, torch.tensor(b) if bias else None, stride=2).permute(0, 2, 3, 1)
+  y64 = F.conv2d(tx.double(), tw.double(), torch.tensor(b).double() if bias else None, stride=2).permute(0, 2, 3, 1)
+  if out_relu: y32, y64 = F.relu(y32), F.relu(y64)
+  g = ops.conv_geom(n, 20, 20, 16, 4, 4, 2, 'valid', 32)
+  xd, wd = dev(x, device), dev(w, device)
+  bd = dev(b, device) if bias else None
+  out = torch.full((n, 9, 9, 32), 7.0, device=device)
+  ops.conv2d_fwd(g, xd, wd, bd, out, in_relu=in_relu, out_relu=out_relu)
+  got = out.cpu().numpy().astype(np.float64)
+  e_hip = np.max(np.abs(got - y64.numpy())); e_f32 = np.max(np.abs(y32.numpy().astype(np.float64) - y64.numpy()))
+  print('wfx n=%d: err hip %.3e  torch fp32 %.3e' % (n, e_hip, e_f32))
+  assert e_hip <= max(2.0 * e_f32, 2e-6 * np.abs(y64.numpy()).max()), (e_hip, e_f32)
+  out2 = torch.full((n, 9, 9, 32), -3.0, device=device)
+  ops.conv2d_fwd(g, xd, wd, bd, out2, in_relu=in_relu, out_relu=out_relu)
+  assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize('n,cin,cout', [(4100, 520, 264), (4096, 2592, 256), (4224, 256, 1024)])   # (>= 4096 rows)
 def test_x8_gemm_epilogues_and_tails(device, n, cin, cout):
   """The 8-wave bf16x6 Dense kernels (xgemm8.h: 128 x 256 tiles, the small operand pre-split into k-tile slabs) on ragged

@@ -1,0 +1,57 @@
+"""Host-side enumeration of the two facts seed_rl_amd/csrc/wfx.h's LDS ring rests on (the bf16x6 forward of the second
+Atari conv, atari/networks.py:236): (1) rounds r and r + 1 of a run of images never span more than kRU rows of one
+parity, so the rows written for round r + 1 cannot land on a row round r still reads; (2) with rows of one parity 41
+sixteen-byte slots apart, the 16 lanes of a ds_read_b128 phase hit 16 different slots unless their pixels cross an
+image boundary or the ring's wrap.  The constants are read from the header, not restated."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _consts():
+  src = open(os.path.join(ROOT, 'seed_rl_amd', 'csrc', 'wfx.h')).read()
+  get = lambda n: int(re.search(r'constexpr int %s = (\d+);' % n, src).group(1))
+  m = re.search(r'constexpr int kIH = (\d+), kIW = (\d+), kOW = (\d+), kP = (\d+);', src)
+  return dict(IH=int(m.group(1)), IW=int(m.group(2)), OW=int(m.group(3)), P=int(m.group(4)), RU=get('kRU'),
+              PITCH=get('kPitch'), ROUND=get('kRound'), ITEMS=get('kItems'))
+
+
+def _end_row(r, total, rows, c):
+  pl = min(c['ROUND'] * r + c['ROUND'] - 1, total - 1)
+  li, pix = divmod(pl, c['P'])
+  return min(c['IH'] * li + 2 * (pix // c['OW']) + 4, rows)
+
+
+def test_ring_holds_two_rounds_and_a_set_holds_a_round():
+  c = _consts()
+  for nimg in (1, 2, 3, 5, 8, 9, 33, 34, 81, 128):
+    total, rows = nimg * c['P'], nimg * c['IH']
+    rounds = -(-total // c['ROUND'])
+    for r in range(rounds):
+      li, pix = divmod(c['ROUND'] * r, c['P'])
+      first = c['IH'] * li + 2 * (pix // c['OW'])                 # first row round r reads
+      last = _end_row(r + 1, total, rows, c) - 1                  # last row written while it reads
+      assert (last >> 1) - (first >> 1) + 1 <= c['RU'], (nimg, r)
+      new = _end_row(r, total, rows, c) - (_end_row(r - 1, total, rows, c) if r else 0)
+      assert 0 <= new * 40 <= 256 * c['ITEMS'], (nimg, r, new)    # 32-byte items of a round fit one register set
+    assert _end_row(rounds - 1, total, rows, c) == rows
+
+
+def test_pixel_operand_reads_spread_over_the_banks():
+  c = _consts()
+  assert c['PITCH'] % 16 == 0 and (c['PITCH'] // 16) % 16 == c['OW'] % 16
+  worst, total, n = 0, 0, 0
+  for start in range(0, c['P'] * 40, 16):                         # every 16-lane phase of 40 images' tiles
+    for ky in range(4):
+      for kx in range(4):
+        slots = {}
+        for l in range(16):
+          li, pix = divmod(start + l, c['P'])
+          oy, ox = divmod(pix, c['OW'])
+          u = (c['IH'] // 2) * li + oy + (ky >> 1)
+          a = (u % c['RU']) * c['PITCH'] + (kx & 1) * 160 + (ox + (kx >> 1)) * 16
+          s = (a // 16) % 16
+          slots[s] = slots.get(s, 0) + 1
+        worst = max(worst, max(slots.values())); total += max(slots.values()); n += 1
+  assert worst <= 3 and total / n < 1.25, (worst, total / n)

@@ -56,16 +56,17 @@ def device_code(obj):
 
 def kernels(co, pattern):
   notes = subprocess.run([os.path.join(LLVM, 'llvm-readelf'), '--notes', co], capture_output=True, text=True).stdout
-  info, cur = {}, None
-  for line in notes.splitlines():
-    m = re.search(r'\.name:\s+(\S+)', line)
-    if m:
-      cur = m.group(1)
-      info[cur] = {}
+  info = {}
+  # one YAML list item per kernel ("  - .agpr_count: ..." opens it: keys are sorted, .name comes in the middle)
+  for item in re.split(r'\n  - (?=\.)', notes):
+    m = re.search(r'\.name:\s+(\S+)', item)
+    if not m:
+      continue
+    cur = info.setdefault(m.group(1), {})
     for key in ('.vgpr_count', '.agpr_count', '.sgpr_count', '.vgpr_spill_count', '.group_segment_fixed_size'):
-      m = re.search(re.escape(key) + r':\s+(\d+)', line)
-      if m and cur:
-        info[cur][key] = int(m.group(1))
+      k = re.search(r'(?m)^\s*(?:- )?' + re.escape(key) + r':\s+(\d+)', item)
+      if k:
+        cur[key] = int(k.group(1))
   return {k: v for k, v in info.items() if pattern in k}
 
 
