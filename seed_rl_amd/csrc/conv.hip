@@ -211,8 +211,11 @@ int check_geom(const seedhip_conv_geom* g, const char* what) {
 // Which matrix pipe serves this geometry (pass 0 forward, 1 data gradient, 2 weight gradient): 1 = fp32 MFMA
 // (v_mfma_f32_16x16x4_f32), 6 = bf16 MFMA through the exact three-way split of both operands (xgemm.h: six bf16 MACs per
 // algorithmic MAC).  What the bench prices a kernel's roofline with; 0 = unknown pass / null geometry.
+static int wfx_enabled() { static const int on = getenv("SEEDHIP_WFX") ? atoi(getenv("SEEDHIP_WFX")) : 1; return on; }
+
 extern "C" int seedhip_conv2d_pipe(const seedhip_conv_geom* g, int pass) {
   if (!g || pass < 0 || pass > 2) return 0;
+  if (pass == 0 && wfx_enabled()) { wfx::Params xp; if (wfx::plan(xp, g)) return 6; }
   if (xg8::mode() & (1 << pass)) {
     const xg8::Plan x8 = pass == 0 ? x8_fwd_plan(g) : pass == 1 ? x8_dgrad_plan(g) : x8_wgrad_plan(g);
     if (x8.ok) return 6;
@@ -261,9 +264,8 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
   SEEDHIP_REQUIRE(in_dtype == kInF32 || in_dtype == kInU8Div255, "conv2d_fwd: bad in_dtype %d", in_dtype);
   {
     // the second Atari conv at training batch sizes on the bf16 matrix pipe (wfx.h: exact three-way split, six products)
-    static const int wfx_on = getenv("SEEDHIP_WFX") ? atoi(getenv("SEEDHIP_WFX")) : 1;
     wfx::Params xp;
-    if (wfx_on && in_dtype == kInF32 && !residual && al16(in) && al16(w) && al16(out) && al16(bias) && wfx::plan(xp, geom)) {
+    if (wfx_enabled() && in_dtype == kInF32 && !residual && al16(in) && al16(w) && al16(out) && al16(bias) && wfx::plan(xp, geom)) {
       xp.X = (const float*)in; xp.W = w; xp.bias = bias; xp.Y = out; xp.in_relu = in_relu; xp.out_relu = out_relu;
       const int rc2 = wfx::launch(xp, (hipStream_t)stream);
       if (rc2 >= 0) return rc2;

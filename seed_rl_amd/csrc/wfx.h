@@ -2,27 +2,40 @@
 // (/root/reference/atari/networks.py:236) -- on the BF16 matrix pipe through the exact three-way operand split of
 // xgemm.h ("bf16x6": fp32 = h + m + l, six of the nine plane products; same arithmetic, same error bound).
 //
-// Why: wfw.h's fp32-MFMA kernel needs 140 us for 11.2 GFLOP (80 TF/s of the fp32 pipe's 157; its 128 MFMAs per round
-// already run back to back), and v_mfma_f32_32x32x16_bf16 does the six products of one (32 pixel x 32 channel x 16 k)
-// block in 192 cycles against 1024 for the fp32 instruction's 128 passes -- 27 us of matrix time for the layer.
+// Why: wfw.h's fp32-MFMA kernel needs 140 us in the step for 11.2 GFLOP (80 TF/s of the fp32 pipe's 157; its 128 MFMAs
+// per round already run back to back), and v_mfma_f32_32x32x16_bf16 does the six products of one (32 pixel x 32 channel
+// x 16 k) block in 192 cycles against 1024 for the fp32 instruction's 128 passes -- 27 us of matrix time for the layer.
 //
-// Structure: one 4-wave workgroup per CU (141.7 KB of LDS), a persistent run of images per workgroup.
-//   * WEIGHTS: lane (co = lane & 31, kq = lane >> 5) holds W[tap][ci = 8 kq .. 8 kq + 7][co] of all 16 taps as three
-//     bf16 planes -- 192 registers, split once in the prologue; they are the MFMA's row operand, so a lane ends up with
-//     four consecutive output channels of one pixel per accumulator quad (16-byte stores, bias and ReLU fused);
+// Structure: one 8-wave workgroup per CU (157.7 KB of LDS), a persistent run of images per workgroup.
+//   * a ROUND is 128 consecutive pixels of the run = four tiles of 32 (tiles cross image boundaries).  Two waves share a
+//     tile and split the REDUCTION: wave (tile, kh) multiplies the eight taps of kernel rows 2 kh, 2 kh + 1 -- 48 MFMAs
+//     per round -- and the pair lands on one SIMD, so one wave's split / address / store work overlaps the other's
+//     multiplications.  (One wave per SIMD with all 16 taps needed 412 registers and serialised everything: 91 us.)
+//   * WEIGHTS: lane (co = lane & 31, kq = lane >> 5) holds W[tap][ci = 8 kq .. 8 kq + 7][co] of its eight taps as three
+//     bf16 planes -- 96 registers, split once in the prologue (round to nearest); they are the MFMA's row operand, so a
+//     lane ends up with four consecutive output channels of one pixel per accumulator quad;
 //   * INPUT: the run is a contiguous array of image rows (20 per image, 1 280 bytes each).  Every row is loaded ONCE
-//     (32-byte items, coalesced), split in registers and written as three bf16 planes into a ring of 72 rows; rows of
-//     one parity sit `kPitch` = 41 sixteen-byte slots apart, 41 = 9 (mod 16): a step to the next output row (two input
-//     rows down, nine pixels on) continues the slot sequence of the previous one, so the 16 lanes of a ds_read_b128
-//     phase -- 16 consecutive pixels of the run, any tap -- hit 16 different slots except across an image boundary
-//     (average conflict factor 1.19, against 2.0 for a plain [row][ix][ci] layout);
-//   * a ROUND is 128 consecutive pixels of the run (32 per wave, tiles cross image boundaries): 16 taps x 6 MFMAs per
-//     wave, the pixel operand of tap t + 1 read while tap t multiplies.  The rows of round r + 1 are split and written
-//     between the taps of round r (from registers loaded during round r - 1), the loads for round r + 2 are issued at
-//     its start: two register sets, the loads are asm statements with counted waits (the compiler's own bookkeeping
-//     would drain the queue at the loop head, see xgemm.h); one `s_barrier` per round, without `vmcnt(0)`.
+//     (32-byte items, coalesced), split in registers (by truncation: full-rate VALU) and written as three bf16 planes
+//     into a ring of 72 rows; rows of one parity sit `kPitch` = 41 sixteen-byte slots apart, 41 = 9 (mod 16): a step
+//     to the next output row (two input rows down, nine pixels on) continues the slot sequence of the previous one, and
+//     the 16 lanes of a ds_read_b128 phase ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}: the pixel -> lane map follows
+//     these groups) take 16 consecutive pixels: 16 different slots except across an image boundary (average conflict
+//     factor 1.2, against 2.0 for a plain [row][ix][ci] layout);
+//   * per round and wave: pixel operands two taps ahead (three register buffers), one row-item request per tap in
+//     taps 0-5 (for round r + 2), one half item split and written per tap in taps 2-7 (for round r + 1, from the
+//     registers requested a round ago: asm loads with counted waits -- the compiler's own bookkeeping would drain the
+//     queue at the loop head, see xgemm.h), pieces pinned between the MFMAs with sched_barrier;
+//   * OUTPUT: the second half's waves hand their partial sums over through a 4 KB block per tile; the first half's add
+//     theirs (bias in the accumulator's start), activate, and write the sums back into the block as [pixel][32 channel]
+//     rows with the 16-byte chunk index XOR-swizzled by the pixel -- read back at the end of the round they leave as
+//     1 KB of consecutive addresses per store instruction.  Two barriers per round (block free / block + rows published).
 // Ring safety: rounds r and r + 1 together span at most 35 rows of one parity (enumerated in
 // tests/test_wfx_layout.py); kRU = 36.
+//
+// Measured (8 442 images, MI355X): 74 us against wfw.h's 121.  Where the rest goes (SEEDHIP_WFX_EXP builds, results
+// wrong): without the split 72, without split and loads 59, without MFMAs 58, nothing but operand reads + outputs 37:
+// the pieces ADD rather than overlap -- VALU work does not hide beside the streaming bf16 MFMAs of the SIMD's other
+// wave (the same finding as xgemm8.h), and the in-kernel split is 5.5 VALU instructions per input element.
 #pragma once
 #include "common.h"
 #include <vector>
@@ -46,13 +59,14 @@ constexpr int kPar = kRU * kPitch;                           // 23 616
 constexpr int kPlane = 2 * kPar;                             // 47 232
 constexpr int kLds = 3 * kPlane;                             // 141 696
 constexpr int kRound = 128;                                  // pixels per round
-constexpr int kItems = 6;                                    // 32-byte items per thread and round (<= 38 rows)
+constexpr int kItems = 3;                                    // 32-byte items per thread and round (512 threads: <= 38 rows)
+constexpr int kPart = 4 * 4096;                              // partial sums of the second tap half, one 4 KB block per tile
 constexpr unsigned kOut = 0x80000000u;
 
 struct Params {
   const float* X; const float* W; const float* bias; float* Y;
   int n_img, per_wg, in_relu, out_relu;
-  unsigned long long* trace;              // SEEDHIP_WFX_TRACE: [workgroup][wave][32 rounds][8 stamps]
+  unsigned long long* trace;              // SEEDHIP_WFX_TRACE: [workgroup][8 waves][32 rounds][8 stamps]
 };
 
 __device__ __forceinline__ f32x4_t load16(const sgpr128_t& d, unsigned voff, unsigned soff) {
@@ -67,10 +81,13 @@ __device__ __forceinline__ f32x4_t load16b(const sgpr128_t& d, unsigned voff, un
 }
 template <int N>
 __device__ __forceinline__ void wait_set(f32x4_t (&r)[kItems][2]) {
-  static_assert(kItems == 6, "operand list below");
-  asm volatile("s_waitcnt vmcnt(%12)"
-               : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[2][0]), "+v"(r[2][1]),
-                 "+v"(r[3][0]), "+v"(r[3][1]), "+v"(r[4][0]), "+v"(r[4][1]), "+v"(r[5][0]), "+v"(r[5][1]) : "n"(N));
+  static_assert(kItems == 3, "operand list below");
+  asm volatile("s_waitcnt vmcnt(%6)"
+               : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[2][0]), "+v"(r[2][1]) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void wait_item(f32x4_t (&r)[2]) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r[0]), "+v"(r[1]) : "n"(N));
 }
 
 // rows [0, end_row(r)) of the run are what rounds 0..r read
@@ -82,12 +99,18 @@ __device__ __forceinline__ int end_row(int r, int total, int rows) {
   return e < rows ? e : rows;
 }
 
-template <bool TRACE, bool RELU_IN>
-__global__ void __launch_bounds__(256, 1)
+// EXP (timing experiments only, results wrong): 1 no split / LDS writes, 2 no loads, 4 no MFMAs, 8 no operand reads
+template <bool TRACE, bool RELU_IN, int EXP = 0>
+__global__ void __launch_bounds__(512, 2)
 wfx_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, px = lane & 31, kq = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = wave & 3, kh = wave >> 2;                 // pixel tile of the round; half of the taps (ky = 2 kh, 2 kh + 1)
+  // ds_read_b128 serves a wave in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (and + 32): the lanes of a
+  // group take 16 CONSECUTIVE pixels of the tile, which is what the ring's slot sequence keeps apart
+  const int l5 = lane & 31;
+  const int px = l5 < 4 ? l5 : l5 < 12 ? l5 + 12 : l5 < 16 ? l5 - 8 : l5 < 20 ? l5 + 8 : l5 < 28 ? l5 - 12 : l5;
   const int img0 = blockIdx.x * p.per_wg;
   int nimg = p.n_img - img0; if (nimg > p.per_wg) nimg = p.per_wg;
   if (nimg <= 0) return;
@@ -95,42 +118,37 @@ wfx_kernel(const Params p) {
   const int rounds = (total + kRound - 1) / kRound;
   const sgpr128_t xd = xg::make_view_words(p.X + (long long)img0 * (kIH * kIW * 16), (long long)rows * kRowBytes);
 
-  // ---- weights: three planes of W[t][8 kq + e][co = px], e = 0..7 ------------------------------------------------ //
-  bf16x8_t wh[16], wm[16], wl[16];
+  // ---- weights of this wave's eight taps: three planes of W[8 kh + t][8 kq + e][co = lane & 31], e = 0..7 -------- //
+  bf16x8_t wh[8], wm[8], wl[8];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
+  for (int t = 0; t < 8; ++t) {
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = p.W[(t * 16 + 8 * kq + e) * 32 + px];
+    for (int e = 0; e < 8; ++e) v[e] = p.W[((8 * kh + t) * 16 + 8 * kq + e) * 32 + l5];
     u32x4_t h, m, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { unsigned a, b, c; xg::split2(v[2 * e], v[2 * e + 1], a, b, c); h[e] = a; m[e] = b; l[e] = c; }
     wh[t] = __builtin_bit_cast(bf16x8_t, h); wm[t] = __builtin_bit_cast(bf16x8_t, m); wl[t] = __builtin_bit_cast(bf16x8_t, l);
   }
-  f32x16_t bias16;
+  f32x16_t acc0;                                             // the accumulator's start: bias in the first half's waves
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bias16[4 * g + q] = p.bias ? p.bias[8 * g + 4 * kq + q] : 0.f;
+    for (int q = 0; q < 4; ++q) acc0[4 * g + q] = (p.bias && kh == 0) ? p.bias[8 * g + 4 * kq + q] : 0.f;
 
   // ---- staging ------------------------------------------------------------------------------------------------- //
   f32x4_t ld[2][kItems][2];
-  auto issue = [&](f32x4_t (&s)[kItems][2], int lo, int hi, int k0 = 0, int k1 = kItems) {   // rows [lo, hi) of the run -> registers
+  auto issue1 = [&](f32x4_t (&s)[kItems][2], int lo, int hi, int i) {   // load i (item i / 2, half i % 2) of rows [lo, hi)
     const unsigned n = (unsigned)(hi - lo) * 40u;
     const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)lo * (unsigned)kRowBytes);
-#pragma unroll
-    for (int k = k0; k < k1; ++k) {
-      const unsigned q = (unsigned)tid + 256u * k;
-      const unsigned voff = q < n ? q * 32u : kOut;
-      s[k][0] = load16(xd, voff, soff);
-      s[k][1] = load16b(xd, voff, soff);
-    }
+    const unsigned q = (unsigned)tid + 512u * (i >> 1);
+    const unsigned voff = (q < n && !(EXP & 64)) ? q * 32u : kOut;
+    if (i & 1) s[i >> 1][1] = load16b(xd, voff, soff); else s[i >> 1][0] = load16(xd, voff, soff);
   };
-  // Item k of rows [lo, hi) goes to LDS in two halves (four values -> 8 bytes per plane), each in three pieces that the
-  // round places into the gaps between its MFMAs: address, two pair splits, the writes.  Branch free: items past the
+  // Item k of rows [lo, hi) goes to LDS in two halves (four values -> 8 bytes per plane).  Branch free: items past the
   // rows were loaded as zeros and go to a pad slot nobody reads.
   auto put_addr = [&](int k, int lo, int hi) -> unsigned {
-    const unsigned q = (unsigned)tid + 256u * k;
+    const unsigned q = (unsigned)tid + 512u * k;
     const unsigned rr = q / 40u, c = q - rr * 40u, grow = (unsigned)lo + rr, ix = c >> 1, half = c & 1u;
     const unsigned u = (grow >> 1) % (unsigned)kRU;
     const unsigned dst = (grow & 1u) * kPar + u * kPitch + (half * 2u + (ix & 1u)) * 160u + (ix >> 1) * 16u;
@@ -141,122 +159,153 @@ wfx_kernel(const Params p) {
     // by truncation (plain full-rate VALU; v_cvt_pk_bf16_f32 issues at a quarter of that): still h + m + l == f exactly.
     // The weights are split with round-to-nearest, so the dropped products am wl + al wm keep a random sign; their
     // bound doubles to 2^-24 |x w|, half an ulp of the product.
-    xg::split2_trunc(f0, f1, h, m, l);
-  };
-  auto put_write = [&](unsigned dst, const unsigned (&h)[2], const unsigned (&m)[2], const unsigned (&l)[2]) {
-    *reinterpret_cast<xg::u32x2_t*>(smem + dst) = xg::u32x2_t{h[0], h[1]};
-    *reinterpret_cast<xg::u32x2_t*>(smem + dst + kPlane) = xg::u32x2_t{m[0], m[1]};
-    *reinterpret_cast<xg::u32x2_t*>(smem + dst + 2 * kPlane) = xg::u32x2_t{l[0], l[1]};
+    const xg::f32x2_t x = {f0, f1};
+    const xg::u32x2_t xu = __builtin_bit_cast(xg::u32x2_t, x) & 0xFFFF0000u;
+    const xg::f32x2_t r1 = x - __builtin_bit_cast(xg::f32x2_t, xu);                 // (v_pk_add_f32)
+    const xg::u32x2_t ru = __builtin_bit_cast(xg::u32x2_t, r1) & 0xFFFF0000u;
+    const xg::u32x2_t r2 = __builtin_bit_cast(xg::u32x2_t, r1 - __builtin_bit_cast(xg::f32x2_t, ru));
+    h = __builtin_amdgcn_perm(xu[1], xu[0], 0x07060302u);
+    m = __builtin_amdgcn_perm(ru[1], ru[0], 0x07060302u);
+    l = __builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u);
   };
   auto put_half = [&](const f32x4_t& it, int k, int j, int lo, int hi) {
     unsigned h[2], m[2], l[2];
     put_pair(it[0], it[1], h[0], m[0], l[0]); put_pair(it[2], it[3], h[1], m[1], l[1]);
-    put_write(put_addr(k, lo, hi) + 8 * j, h, m, l);
+    const unsigned dst = put_addr(k, lo, hi) + 8 * j;
+    *reinterpret_cast<xg::u32x2_t*>(smem + dst) = xg::u32x2_t{h[0], h[1]};
+    *reinterpret_cast<xg::u32x2_t*>(smem + dst + kPlane) = xg::u32x2_t{m[0], m[1]};
+    *reinterpret_cast<xg::u32x2_t*>(smem + dst + 2 * kPlane) = xg::u32x2_t{l[0], l[1]};
   };
-  auto put = [&](const f32x4_t (&it)[2], int k, int lo, int hi) { put_half(it[0], k, 0, lo, hi); put_half(it[1], k, 1, lo, hi); };
 
-  unsigned long long* tl = reinterpret_cast<unsigned long long*>(smem + kLds) + wave * 256;   // (TRACE builds: 8 KB more)
+  unsigned long long* tg = TRACE ? p.trace + ((long long)blockIdx.x * 8 + wave) * 256 : nullptr;
   auto stamp = [&](int r, int k) {
-    if (TRACE && r < 32) { const unsigned long long c = __builtin_amdgcn_s_memtime(); if (lane == 0) tl[r * 8 + k] = c; }
+    if (TRACE && r < 32) { const unsigned long long c = __builtin_amdgcn_s_memtime(); if (lane == 0) tg[r * 8 + k] = c; }
   };
   const int e0 = end_row(0, total, rows), e1 = end_row(1, total, rows);
-  issue(ld[0], 0, e0);
-  issue(ld[1], e0, e1);
+#pragma unroll
+  for (int i = 0; i < 2 * kItems; ++i) issue1(ld[0], 0, e0, i);
+#pragma unroll
+  for (int i = 0; i < 2 * kItems; ++i) issue1(ld[1], e0, e1, i);
   wait_set<2 * kItems>(ld[0]);
 #pragma unroll
-  for (int k = 0; k < kItems; ++k) put(ld[0][k], k, 0, e0);
+  for (int k = 0; k < kItems; ++k) { put_half(ld[0][k][0], k, 0, 0, e0); put_half(ld[0][k][1], k, 1, 0, e0); }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   const long long ybase = (long long)img0 * kP * 32;
-  // one round: reads rows of round r, writes the rows of r + 1 from `wr`, requests the rows of r + 2 into `nx`
-  // outputs of the previous round: stored behind this round's wait for `wr` (see there)
-  f32x16_t pv = bias16; float* po = nullptr; bool plive = false;
-  auto flush = [&]() {
-    if (plive) {
+  unsigned char* blk = smem + kLds + tile * 4096;            // this tile's 4 KB exchange block
+  unsigned char* part = blk + lane * 16;                     // the second half's partial sums: [quad][lane] x 16 bytes
+  f32x16_t acc = acc0;
+  // The first half's waves finish round r - 1 at the start of round r: their partner's partial sums were published by
+  // the barrier in between, and while they add and activate, the partner (same SIMD) is multiplying already.  The sums
+  // go back into the block as [pixel][32 channels] rows (16-byte chunk c of pixel x at chunk c ^ (x & 7)); the wave
+  // stores them at the END of its round, 1 KB of consecutive addresses per instruction -- behind the round's counted
+  // waits, which a pending store would stretch (stores and loads share vmcnt and do not retire in order).
+  auto finish = [&]() {
+    if (kh == 0) {
+      f32x4_t q4[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4_t*>(po + 8 * g) = f32x4_t{pv[4 * g], pv[4 * g + 1], pv[4 * g + 2], pv[4 * g + 3]};
+      for (int g = 0; g < 4; ++g) q4[g] = *reinterpret_cast<const f32x4_t*>(part + g * 1024);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4_t v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float y = acc[4 * g + q] + q4[g][q];
+          v[q] = p.out_relu ? __builtin_amdgcn_fmed3f(y, 0.f, __builtin_inff()) : y;
+        }
+        *reinterpret_cast<f32x4_t*>(blk + px * 128 + (((2 * g + kq) ^ (px & 7)) << 4)) = v;
+      }
     }
   };
+  // outputs of round r, from the block: piece i = 8 pixels = 1 KB
+  f32x4_t ov;
+  auto out_read = [&](int i) {
+    const int pr = 8 * i + (lane >> 3);
+    ov = *reinterpret_cast<const f32x4_t*>(blk + pr * 128 + (((lane & 7) ^ (pr & 7)) << 4));
+  };
+  auto out_store = [&](int r, int i) {
+    const int P = kRound * r + 32 * tile + 8 * i + (lane >> 3);
+    if (P < total) *reinterpret_cast<f32x4_t*>(p.Y + ybase + (long long)P * 32 + 4 * (lane & 7)) = ov;
+  };
+  // one round: reads rows of round r, writes the rows of r + 1 from `wr`, requests the rows of r + 2 into `nx`
   auto round = [&](int r, f32x4_t (&wr)[kItems][2], f32x4_t (&nx)[kItems][2]) {
     stamp(r, 0);
     const int lo1 = end_row(r, total, rows), hi1 = end_row(r + 1, total, rows), hi2 = end_row(r + 2, total, rows);
-    const int P = kRound * r + 32 * wave + px;
-    const bool live = P < total;
-    const unsigned Pc = (unsigned)(live ? P : total - 1);
+    const int P = kRound * r + 32 * tile + px;
+    const unsigned Pc = (unsigned)(P < total ? P : total - 1);
     const unsigned li = Pc / (unsigned)kP, pix = Pc - li * kP, oy = pix / (unsigned)kOW, ox = pix - oy * kOW;
-    const unsigned u0 = 10u * li + oy;
-    const unsigned inrow = ox * 16u + (unsigned)kq * 320u;
-    const unsigned char* b0 = smem + (u0 % (unsigned)kRU) * kPitch + inrow;
-    const unsigned char* b1 = smem + ((u0 + 1u) % (unsigned)kRU) * kPitch + inrow;
-    f32x16_t acc = bias16;
+    const unsigned u0 = 10u * li + oy + (unsigned)kh;        // both of this wave's kernel rows sit in row pair u0
+    const unsigned o0 = (u0 % (unsigned)kRU) * kPitch + ox * 16u + (unsigned)kq * 320u;
+    unsigned o1 = o0 + kPlane, o2 = o0 + 2 * kPlane;        // a base per plane: every tap offset is an immediate
+    asm volatile("" : "+v"(o1), "+v"(o2));                   // (pinned: otherwise re-derived from o0 with an add per read)
+    const unsigned char* bpl[3] = {smem + o0, smem + o1, smem + o2};
     bf16x8_t xb[3][3];
-    auto fetch = [&](bf16x8_t (&x)[3], int t) {
-      const int ky = t >> 2, kx = t & 3;
-      const unsigned char* b = ((ky >> 1) ? b1 : b0) + (ky & 1) * kPar + (kx & 1) * 160 + (kx >> 1) * 16;
+    auto fetch = [&](bf16x8_t (&x)[3], int t) {              // tap t of this wave: ky = 2 kh + (t >> 2), kx = t & 3
+      const int off = (t >> 2) * kPar + (t & 1) * 160 + ((t >> 1) & 1) * 16;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) x[pl] = *reinterpret_cast<const bf16x8_t*>(b + pl * kPlane);
+      for (int pl = 0; pl < 3; ++pl) {
+        if (EXP & 8) x[pl] = wl[(t + pl) & 7]; else x[pl] = *reinterpret_cast<const bf16x8_t*>(bpl[pl] + off);
+      }
     };
-    fetch(xb[0], 0);                                         // the LDS round trip is longer than a tap's six MFMAs:
-    fetch(xb[1], 1);                                         // operands are requested two taps ahead (three buffers)
-    __builtin_amdgcn_sched_barrier(0);
-    // `wr` was requested over the first taps of the previous round, the outputs stored before that: everything in the
-    // queue is at least 13 taps old.  (No counted wait: loads and stores do not retire in order with each other.)
-    wait_set<0>(wr);
+    fetch(xb[0], 0);                                         // operands are requested two taps ahead (three buffers)
+    fetch(xb[1], 1);
+    if (r > 0) finish();
+    acc = acc0;
     stamp(r, 1);
-    flush();
-    stamp(r, 2);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      if (t + 2 < 16) fetch(xb[(t + 2) % 3], t + 2);
-      const bf16x8_t (&x)[3] = xb[t % 3];
-      // six MFMAs, the pieces of one half item pinned into the gaps between them (one wave per SIMD: nothing else
-      // would overlap the split's VALU work with the matrix pipe)
-      const bool has = t >= 2 && t < 2 + 2 * kItems;
-      const int pk = has ? (t - 2) >> 1 : 0, pj = (t - 2) & 1;
-      const f32x4_t& it = wr[pk][pj];
-      unsigned dst = 0, sh[2], sm[2], sl[2];
 #define WFX_SB __builtin_amdgcn_sched_barrier(0);
-      WFX_SB
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[t], x[0], acc, 0, 0, 0);
-      if (has) dst = put_addr(pk, lo1, hi1) + 8 * pj;
-      WFX_SB
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t], x[2], acc, 0, 0, 0);
-      if (has) put_pair(it[0], it[1], sh[0], sm[0], sl[0]);
-      WFX_SB
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[t], x[1], acc, 0, 0, 0);
-      WFX_SB
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[t], x[0], acc, 0, 0, 0);
-      if (has) put_pair(it[2], it[3], sh[1], sm[1], sl[1]);
-      WFX_SB
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t], x[1], acc, 0, 0, 0);
-      WFX_SB
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t], x[0], acc, 0, 0, 0);
-      if (has) put_write(dst, sh, sm, sl);
-      WFX_SB
-#undef WFX_SB
-      if (t < 3) issue(nx, hi1, hi2, 2 * t, 2 * t + 2);        // 48 KB per CU and round: not in one burst behind the barrier
-      if (t == 0) stamp(r, 3);
-      if (t == 1) stamp(r, 4);
-      if (t == 1 + 2 * kItems) stamp(r, 5);
-    }
-    stamp(r, 6);
-    po = p.Y + ybase + (long long)P * 32 + 4 * kq; plive = live;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) pv[q] = p.out_relu ? __builtin_amdgcn_fmed3f(acc[q], 0.f, __builtin_inff()) : acc[q];
+    for (int t = 0; t < 8; ++t) {
+      WFX_SB
+      if (t + 2 < 8) fetch(xb[(t + 2) % 3], t + 2);
+      const bf16x8_t (&x)[3] = xb[t % 3];
+      // `wr` item k was requested in taps 2k, 2k + 1 of the previous round.  Younger LOADS at tap 2 + 2k: the rest of
+      // `wr` (4 - 2k) and this round's first 2 + 2k requests, 6 in all; stores do not retire in order with loads, but
+      // they can only make the counter larger (the wait longer), never let a load of item k pass for complete.
+      if (t >= 2 && !(t & 1) && !(EXP & 2) && !(EXP & 32)) wait_item<2 * kItems>(wr[(t - 2) >> 1]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[t], x[0], acc, 0, 0, 0);
+      if (t < 2 * kItems && !(EXP & 2)) issue1(nx, hi1, hi2, t);
+      WFX_SB
+      if (!(EXP & 4)) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t], x[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[t], x[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[t], x[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t], x[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t], x[0], acc, 0, 0, 0);
+      } else {
+        acc[t] += (float)x[1][0] + (float)x[2][1];
+      }
+      if (t >= 2 && !(EXP & 1)) put_half(wr[(t - 2) >> 1][(t - 2) & 1], (t - 2) >> 1, (t - 2) & 1, lo1, hi1);
+    }
+    WFX_SB
+#undef WFX_SB
+    if (kh == 0 && r > 0) {                                  // behind the taps (early in the round they slowed it by 5 %)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { out_read(i); out_store(r - 1, i); }
+    }
+    stamp(r, 2);
+    // two barriers: behind the first every first-half wave has read the previous round's outputs out of the block, so
+    // the block can be rewritten; the second publishes it together with the rows.
+    // (A flag from the partner instead of the first barrier was not faster.)
+    asm volatile("s_barrier" ::: "memory");
+    if (kh == 1) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4_t*>(part + g * 1024) = f32x4_t{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    }
+    stamp(r, 3);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    stamp(r, 7);
+    stamp(r, 4);
   };
   for (int r = 0; r < rounds; r += 2) {
     round(r, ld[1], ld[0]);
     if (r + 1 < rounds) round(r + 1, ld[0], ld[1]);
   }
-  flush();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (TRACE && p.trace && lane < 32) {
-    for (int k = lane; k < 256; k += 32) p.trace[((long long)blockIdx.x * 4 + wave) * 256 + k] = tl[k];
+  finish();
+  if (kh == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { out_read(i); out_store(rounds - 1, i); }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 inline bool plan(Params& p, const seedhip_conv_geom* g) {
@@ -273,41 +322,47 @@ inline int launch(Params& p, hipStream_t s) {
   static const int cus = xg::cu_count();
   p.per_wg = (p.n_img + cus - 1) / cus;
   const int grid = (p.n_img + p.per_wg - 1) / p.per_wg;
+  constexpr int kBytes = kLds + kPart;
   static const int trace = xg::env_int("SEEDHIP_WFX_TRACE", 0);
-  if (trace && !p.in_relu) {                                               // per-round cycle stamps of workgroup 0 and one in the middle, to stderr
+  if (trace && !p.in_relu) {                                 // per-round cycle stamps of two workgroups, to stderr
     static unsigned long long* buf = nullptr;
-    const size_t n = (size_t)grid * 4 * 256;
-    if (!buf && hipMalloc(&buf, (size_t)1024 * 4 * 256 * 8) != hipSuccess) return -1;
-    if (hipFuncSetAttribute((const void*)wfx_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds + 8192) != hipSuccess) return -1;
+    const size_t n = (size_t)grid * 8 * 256;
+    if (!buf && hipMalloc(&buf, (size_t)1024 * 8 * 256 * 8) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)wfx_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kBytes) != hipSuccess) return -1;
     (void)hipMemsetAsync(buf, 0, n * 8, s);
     p.trace = buf;
-    hipLaunchKernelGGL((wfx_kernel<true, false>), dim3(grid), dim3(256), kLds + 8192, s, p);
+    hipLaunchKernelGGL((wfx_kernel<true, false>), dim3(grid), dim3(512), kBytes, s, p);
     std::vector<unsigned long long> h(n);
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h.data(), buf, n * 8, hipMemcpyDeviceToHost);
     static int shown = 0;
-    if (shown++ < 2) {
+    if (shown++ < 1) {
       for (int wg : {0, grid / 2}) {
-        for (int w = 0; w < 4; w += 3) {
-          const unsigned long long* t = h.data() + ((size_t)wg * 4 + w) * 256;
-          fprintf(stderr, "wfx trace wg %d wave %d: round | wait | flush+addr | tap 0 | tap 1 | taps 2-13 | taps 14-15 | relu+barrier | (s_memtime ticks)\n", wg, w);
+        for (int w : {0, 4}) {
+          const unsigned long long* t = h.data() + ((size_t)wg * 8 + w) * 256;
+          fprintf(stderr, "wfx trace wg %d wave %d: round | addr+finish | 8 taps | barrier 1 | partials+barrier 2 | (s_memtime ticks)\n", wg, w);
           for (int r = 0; r < 24 && t[r * 8]; ++r)
-            fprintf(stderr, "  %2d | %6llu %6llu %6llu %6llu %6llu %6llu %6llu | round %6llu\n", r, t[r * 8 + 1] - t[r * 8], t[r * 8 + 2] - t[r * 8 + 1],
-                    t[r * 8 + 3] - t[r * 8 + 2], t[r * 8 + 4] - t[r * 8 + 3], t[r * 8 + 5] - t[r * 8 + 4], t[r * 8 + 6] - t[r * 8 + 5],
-                    t[r * 8 + 7] - t[r * 8 + 6], t[r * 8 + 7] - t[r * 8]);
+            fprintf(stderr, "  %2d | %6llu %6llu %6llu %6llu | round %6llu\n", r, t[r * 8 + 1] - t[r * 8], t[r * 8 + 2] - t[r * 8 + 1],
+                    t[r * 8 + 3] - t[r * 8 + 2], t[r * 8 + 4] - t[r * 8 + 3], t[r * 8 + 4] - t[r * 8]);
         }
       }
     }
     return check_launch("wfx_kernel(trace)");
   }
+  static const int ex = xg::env_int("SEEDHIP_WFX_EXP", 0);
+#define WFX_EXP(E_) if (ex == E_) { \
+    if (hipFuncSetAttribute((const void*)wfx_kernel<false, false, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, kBytes) != hipSuccess) return -1; \
+    hipLaunchKernelGGL((wfx_kernel<false, false, E_>), dim3(grid), dim3(512), kBytes, s, p); return check_launch("wfx_kernel(exp)"); }
+  WFX_EXP(1) WFX_EXP(3) WFX_EXP(33) WFX_EXP(65)
+#undef WFX_EXP
   if (p.in_relu) {
-    static const bool ok = hipFuncSetAttribute((const void*)wfx_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
+    static const bool ok = hipFuncSetAttribute((const void*)wfx_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kBytes) == hipSuccess;
     if (!ok) return -1;
-    hipLaunchKernelGGL((wfx_kernel<false, true>), dim3(grid), dim3(256), kLds, s, p);
+    hipLaunchKernelGGL((wfx_kernel<false, true>), dim3(grid), dim3(512), kBytes, s, p);
   } else {
-    static const bool ok = hipFuncSetAttribute((const void*)wfx_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
+    static const bool ok = hipFuncSetAttribute((const void*)wfx_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kBytes) == hipSuccess;
     if (!ok) return -1;
-    hipLaunchKernelGGL((wfx_kernel<false, false>), dim3(grid), dim3(256), kLds, s, p);
+    hipLaunchKernelGGL((wfx_kernel<false, false>), dim3(grid), dim3(512), kBytes, s, p);
   }
   return check_launch("wfx_kernel");
 }

@@ -14,7 +14,8 @@ def _consts():
   get = lambda n: int(re.search(r'constexpr int %s = (\d+);' % n, src).group(1))
   m = re.search(r'constexpr int kIH = (\d+), kIW = (\d+), kOW = (\d+), kP = (\d+);', src)
   return dict(IH=int(m.group(1)), IW=int(m.group(2)), OW=int(m.group(3)), P=int(m.group(4)), RU=get('kRU'),
-              PITCH=get('kPitch'), ROUND=get('kRound'), ITEMS=get('kItems'))
+              PITCH=get('kPitch'), ROUND=get('kRound'), ITEMS=get('kItems'),
+              THREADS=int(re.search(r'__launch_bounds__\((\d+)', src).group(1)))
 
 
 def _end_row(r, total, rows, c):
@@ -34,7 +35,7 @@ def test_ring_holds_two_rounds_and_a_set_holds_a_round():
       last = _end_row(r + 1, total, rows, c) - 1                  # last row written while it reads
       assert (last >> 1) - (first >> 1) + 1 <= c['RU'], (nimg, r)
       new = _end_row(r, total, rows, c) - (_end_row(r - 1, total, rows, c) if r else 0)
-      assert 0 <= new * 40 <= 256 * c['ITEMS'], (nimg, r, new)    # 32-byte items of a round fit one register set
+      assert 0 <= new * 40 <= c['THREADS'] * c['ITEMS'], (nimg, r, new)    # 32-byte items of a round fit one register set
     assert _end_row(rounds - 1, total, rows, c) == rows
 
 
