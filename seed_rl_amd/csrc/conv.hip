@@ -21,6 +21,7 @@
 #include "wsw.h"
 #include "wfw.h"
 #include "wfx.h"
+#include "wdx.h"
 #include "../../include/seedhip.h"
 
 using namespace seedhip;
@@ -211,11 +212,13 @@ int check_geom(const seedhip_conv_geom* g, const char* what) {
 // Which matrix pipe serves this geometry (pass 0 forward, 1 data gradient, 2 weight gradient): 1 = fp32 MFMA
 // (v_mfma_f32_16x16x4_f32), 6 = bf16 MFMA through the exact three-way split of both operands (xgemm.h: six bf16 MACs per
 // algorithmic MAC).  What the bench prices a kernel's roofline with; 0 = unknown pass / null geometry.
+static int wdx_enabled() { static const int on = getenv("SEEDHIP_WDX") ? atoi(getenv("SEEDHIP_WDX")) : 1; return on; }
 static int wfx_enabled() { static const int on = getenv("SEEDHIP_WFX") ? atoi(getenv("SEEDHIP_WFX")) : 1; return on; }
 
 extern "C" int seedhip_conv2d_pipe(const seedhip_conv_geom* g, int pass) {
   if (!g || pass < 0 || pass > 2) return 0;
   if (pass == 0 && wfx_enabled()) { wfx::Params xp; if (wfx::plan(xp, g)) return 6; }
+  if (pass == 1 && wdx_enabled()) { wdx::Params dp; if (wdx::plan(dp, g)) return 6; }
   if (xg8::mode() & (1 << pass)) {
     const xg8::Plan x8 = pass == 0 ? x8_fwd_plan(g) : pass == 1 ? x8_dgrad_plan(g) : x8_wgrad_plan(g);
     if (x8.ok) return 6;
@@ -451,6 +454,15 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
                                           size_t workspace_bytes, void* stream) {
   int rc = check_geom(geom, "conv2d_bwd_data"); if (rc) return rc;
   SEEDHIP_REQUIRE(dy && w && dx, "conv2d_bwd_data: null pointer");
+  {
+    // the second Atari conv at training batch sizes on the bf16 matrix pipe (wdx.h)
+    wdx::Params dp;
+    if (wdx_enabled() && !add && al16(dy) && al16(w) && al16(dx) && al16(relu_mask) && wdx::plan(dp, geom)) {
+      dp.dY = dy; dp.W = w; dp.X = relu_mask; dp.dX = dx;
+      const int rc2 = wdx::launch(dp, (hipStream_t)stream);
+      if (rc2 >= 0) return rc2;
+    }
+  }
   if ((gemm_mode() & 16) && al16(dy) && al16(w) && al16(dx) && al16(relu_mask) && al16(add)) {
     // all stride-parity classes as ONE weight-stationary GEMM over super-pixels (wsgemm.h)
     wsgemm::Params wp;

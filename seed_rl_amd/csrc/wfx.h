@@ -179,7 +179,8 @@ wfx_kernel(const Params p) {
 
   unsigned long long* tg = TRACE ? p.trace + ((long long)blockIdx.x * 8 + wave) * 256 : nullptr;
   auto stamp = [&](int r, int k) {
-    if (TRACE && r < 32) { const unsigned long long c = __builtin_amdgcn_s_memtime(); if (lane == 0) tg[r * 8 + k] = c; }
+    if (TRACE && r < 31) { const unsigned long long c = __builtin_amdgcn_s_memtime(); if (lane == 0) tg[r * 8 + k] = c; }
+    if (TRACE && r < 31 && k == 0) { const unsigned long long c = __builtin_amdgcn_s_memrealtime(); if (lane == 0) tg[r * 8 + 7] = c; }   // (100 MHz)
   };
   const int e0 = end_row(0, total, rows), e1 = end_row(1, total, rows);
 #pragma unroll
@@ -341,6 +342,7 @@ inline int launch(Params& p, hipStream_t s) {
         for (int w : {0, 4}) {
           const unsigned long long* t = h.data() + ((size_t)wg * 8 + w) * 256;
           fprintf(stderr, "wfx trace wg %d wave %d: round | addr+finish | 8 taps | barrier 1 | partials+barrier 2 | (s_memtime ticks)\n", wg, w);
+          if (t[0] && t[20 * 8]) fprintf(stderr, "  s_memtime ticks per microsecond over rounds 0-20: %.1f\n", (double)(t[20 * 8] - t[0]) / ((double)(t[20 * 8 + 7] - t[7]) / 100.0));
           for (int r = 0; r < 24 && t[r * 8]; ++r)
             fprintf(stderr, "  %2d | %6llu %6llu %6llu %6llu | round %6llu\n", r, t[r * 8 + 1] - t[r * 8], t[r * 8 + 2] - t[r * 8 + 1],
                     t[r * 8 + 3] - t[r * 8 + 2], t[r * 8 + 4] - t[r * 8 + 3], t[r * 8 + 4] - t[r * 8]);
@@ -353,7 +355,7 @@ inline int launch(Params& p, hipStream_t s) {
 #define WFX_EXP(E_) if (ex == E_) { \
     if (hipFuncSetAttribute((const void*)wfx_kernel<false, false, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, kBytes) != hipSuccess) return -1; \
     hipLaunchKernelGGL((wfx_kernel<false, false, E_>), dim3(grid), dim3(512), kBytes, s, p); return check_launch("wfx_kernel(exp)"); }
-  WFX_EXP(1) WFX_EXP(3) WFX_EXP(33) WFX_EXP(65)
+  WFX_EXP(1) WFX_EXP(3)
 #undef WFX_EXP
   if (p.in_relu) {
     static const bool ok = hipFuncSetAttribute((const void*)wfx_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kBytes) == hipSuccess;

@@ -588,6 +588,38 @@ def test_wfx_conv2_forward_fp32_accuracy(device, n, in_relu, out_relu, bias):
   assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize('n,mask', [(2048, True), (2049, True), (2309, False), (8448, True)])
+def test_wdx_conv2_data_gradient_fp32_accuracy(device, n, mask):
+  """The second Atari conv's data gradient on the bf16 matrix pipe (wdx.h: super-pixel GEMM, dY staged once as padded
+  rows, ReLU mask by LDS-DMA).  As close to an fp64 evaluation as torch's fp32 gradient is (max error <= 2x), masked
+  positions exactly zero, bit-identical from call to call; runs of 8 / 9 / 10 / 33 images per workgroup."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(n + 1)
+  x = rng.normal(size=(n, 20, 20, 16)).astype(np.float32)
+  w = (rng.normal(size=(4, 4, 16, 32)) / 16).astype(np.float32)
+  dy = rng.normal(size=(n, 9, 9, 32)).astype(np.float32)
+  tw = torch.tensor(w).permute(3, 2, 0, 1)
+  tdy = torch.tensor(dy).permute(0, 3, 1, 2)
+  g32 = F.conv_transpose2d(tdy, tw, stride=2).permute(0, 2, 3, 1)
+  g64 = F.conv_transpose2d(tdy.double(), tw.double(), stride=2).permute(0, 2, 3, 1)
+  if mask:
+    keep = torch.tensor(x > 0)
+    g32, g64 = g32 * keep, g64 * keep
+  g = ops.conv_geom(n, 20, 20, 16, 4, 4, 2, 'valid', 32)
+  xd, wd, dyd = dev(x, device), dev(w, device), dev(dy, device)
+  dx = torch.full((n, 20, 20, 16), 7.0, device=device)
+  ops.conv2d_bwd_data(g, dyd, wd, dx, relu_mask=xd if mask else None)
+  got = dx.cpu().numpy().astype(np.float64)
+  e_hip = np.max(np.abs(got - g64.numpy())); e_f32 = np.max(np.abs(g32.numpy().astype(np.float64) - g64.numpy()))
+  print('wdx n=%d: err hip %.3e  torch fp32 %.3e' % (n, e_hip, e_f32))
+  assert e_hip <= max(2.0 * e_f32, 2e-6 * np.abs(g64.numpy()).max()), (e_hip, e_f32)
+  if mask:
+    assert np.all(got[x <= 0] == 0.0)
+  dx2 = torch.full((n, 20, 20, 16), -3.0, device=device)
+  ops.conv2d_bwd_data(g, dyd, wd, dx2, relu_mask=xd if mask else None)
+  assert torch.equal(dx, dx2)
+
+
 @pytest.mark.parametrize('n,cin,cout', [(4100, 520, 264), (4096, 2592, 256), (4224, 256, 1024)])   # (>= 4096 rows)
 def test_x8_gemm_epilogues_and_tails(device, n, cin, cout):
   """The 8-wave bf16x6 Dense kernels (xgemm8.h: 128 x 256 tiles, the small operand pre-split into k-tile slabs) on ragged

@@ -56,7 +56,9 @@ def test_register_budgets_of_the_hot_kernels(code_objects):
       'stackconv_fwd_bf16r_kernelILi0ELb0ELb0ELb1': (168, 0),
       'wsw_lds_kernelILb0ELi21ELi0': (256, 0),                  # two 4-wave workgroups per CU (LDS)
       'wfw_kernelILb0': (256, 0),
-      'wfx_kernelILb0ELb0ELi0': (256, 4),                       # r4: one 8-wave workgroup per CU; the spilled registers are prologue-only
+      'wfx_kernelILb0ELb0ELi0': (256, 4),
+      'wdx_kernelILb1ELi0': (256, 0),                           # r4: the same for the data gradient
+                       # r4: one 8-wave workgroup per CU; the spilled registers are prologue-only
       'xg8_kernelILi0ELi0': (256, 0),                           # one 8-wave workgroup per CU: two waves per SIMD
       'xg8_kernelILi1ELi0': (256, 0),
       'stackconv_wgrad_cp_kernelILi16': (128, 0),              # two 8-wave workgroups per CU

@@ -56,3 +56,31 @@ def test_pixel_operand_reads_spread_over_the_banks():
           slots[s] = slots.get(s, 0) + 1
         worst = max(worst, max(slots.values())); total += max(slots.values()); n += 1
   assert worst <= 3 and total / n < 1.25, (worst, total / n)
+
+
+def test_wdx_ring_holds_two_rounds_and_a_set_holds_a_round():
+  """seed_rl_amd/csrc/wdx.h (data gradient of the same conv as a super-pixel GEMM): padded dY rows, 11 per image; rounds
+  r and r + 1 together never span more than the ring's rows, a round never brings more new rows than one register set
+  of 32-byte items holds, and rows one super-pixel row apart continue the 16-byte slot sequence."""
+  src = open(os.path.join(ROOT, 'seed_rl_amd', 'csrc', 'wdx.h')).read()
+  get = lambda n: int(re.search(r'constexpr int %s = (\d+)' % n, src).group(1))
+  R, ROUND, ITEMS, SP, PR = get('kR'), get('kRound'), get('kItems'), get('kSP'), get('kPR')
+  rs = re.search(r'constexpr int kRS = (\d+) \* 16;', src)
+  assert int(rs.group(1)) % 16 == 10 % 16                    # ten super-pixels per row
+  threads = int(re.search(r'__launch_bounds__\((\d+)', src).group(1))
+
+  def end_row(r, total, rows):
+    s = min(ROUND * r + ROUND - 1, total - 1)
+    li, sp = divmod(s, SP)
+    return min(PR * li + sp // 10 + 2, rows)
+
+  for nimg in (1, 2, 3, 8, 9, 10, 33, 34, 64):
+    total, rows = nimg * SP, nimg * PR
+    rounds = -(-total // ROUND)
+    for r in range(rounds):
+      li, sp = divmod(ROUND * r, SP)
+      first = PR * li + sp // 10                              # dy = 1 of the round's first super-pixel
+      assert end_row(r + 1, total, rows) - first <= R, (nimg, r)
+      new = end_row(r, total, rows) - (end_row(r - 1, total, rows) if r else 0)
+      assert 0 <= new * 44 <= threads * ITEMS, (nimg, r, new)
+    assert end_row(rounds - 1, total, rows) == rows
