@@ -557,13 +557,14 @@ def test_x6_gemm_fp32_accuracy(device, n, cin, cout):
   check('bias grad', db.cpu().numpy(), tdy.sum(0).numpy(), dy64.sum(0))
 
 
-@pytest.mark.parametrize('n,in_relu,out_relu,bias', [(2048, False, True, True), (2049, True, True, True), (2309, False, False, False),
+@pytest.mark.parametrize('n,in_relu,out_relu,bias', [(256, False, True, True), (300, True, True, False), (1029, False, True, True),
+                                                     (2048, False, True, True), (2049, True, True, True), (2309, False, False, False),
                                                      (8448, False, True, True)])
 def test_wfx_conv2_forward_fp32_accuracy(device, n, in_relu, out_relu, bias):
   """The second Atari conv's forward on the bf16 matrix pipe (wfx.h: exact three-way split of activations and weights,
   six plane products, rows of the run staged once into an LDS ring).  As close to an fp64 evaluation as torch's fp32
-  convolution is (max error <= 2x), for runs of 8 / 9 / 10 / 33 images per workgroup with ragged last workgroups and
-  dead lanes in the last round; and bit-identical from call to call."""
+  convolution is (max error <= 2x), for runs of 1 / 2 / 5 / 8 / 9 / 10 / 33 images per workgroup with ragged last
+  workgroups and dead lanes in the last round; and bit-identical from call to call."""
   from seed_rl_amd import ops
   rng = np.random.default_rng(n)
   x = rng.normal(size=(n, 20, 20, 16)).astype(np.float32)
@@ -588,11 +589,11 @@ def test_wfx_conv2_forward_fp32_accuracy(device, n, in_relu, out_relu, bias):
   assert torch.equal(out, out2)
 
 
-@pytest.mark.parametrize('n,mask', [(2048, True), (2049, True), (2309, False), (8448, True)])
+@pytest.mark.parametrize('n,mask', [(256, True), (300, False), (1029, True), (2048, True), (2049, True), (2309, False), (8448, True)])
 def test_wdx_conv2_data_gradient_fp32_accuracy(device, n, mask):
   """The second Atari conv's data gradient on the bf16 matrix pipe (wdx.h: super-pixel GEMM, dY staged once as padded
   rows, ReLU mask by LDS-DMA).  As close to an fp64 evaluation as torch's fp32 gradient is (max error <= 2x), masked
-  positions exactly zero, bit-identical from call to call; runs of 8 / 9 / 10 / 33 images per workgroup."""
+  positions exactly zero, bit-identical from call to call; runs of 1 / 2 / 5 / 8 / 9 / 10 / 33 images per workgroup."""
   from seed_rl_amd import ops
   rng = np.random.default_rng(n + 1)
   x = rng.normal(size=(n, 20, 20, 16)).astype(np.float32)
