@@ -1,3 +1,6 @@
+"""HBM write / copy / read rates of plain torch kernels at the second conv's output size and beyond (MI355X: fill 88 MB in
+14 us = 6.1 TB/s, copy 7.0 TB/s read + write, sum 3.8 TB/s): the 33 us that wfx.h's output path takes for 87.5 MB are not
+a write-bandwidth limit.  python tools/probes/hbm_write_bw.py"""
 import torch
 def t(fn,reps=20):
     for _ in range(3): fn()
