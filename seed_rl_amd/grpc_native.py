@@ -204,6 +204,7 @@ class NativeServer(object):
     issued before the current batch's launch; when nothing is queued the current batch is launched at once."""
     l, h = lib(), self._h
     stage, launch = getattr(b.compute, 'stage', None), getattr(b.compute, 'launch', None)
+    would_block = getattr(b.compute, 'would_block', None)
     pending = None                                   # (slot, token): staged, not launched
 
     def launch_pending():
@@ -222,6 +223,9 @@ class NativeServer(object):
           pending = None
         continue
       if stage is not None:
+        if pending is not None and would_block is not None and would_block():
+          launch_pending()                           # do not hold an admitted batch while the next one waits at the gate
+          pending = None
         token, ok = self._guarded(b, slot, stage, slot, 0 if pending is None else 1)
         if pending is not None:
           launch_pending()
@@ -438,6 +442,9 @@ def bind_inference(server, fused_states, inference_batch_size, observation_shape
       # i+1 is already waiting, so the PCIe copy runs under the host's graph-launch time (a lone batch is never held)
       if len(graphs) >= 3:                           # with two instances staging batch i+2 would wait for batch i's replay
         compute.stage, compute.launch = stage, launch
+        #  staging the next batch may wait at the gate: the compute loop asks first and launches the batch it
+        # holds before it blocks -- an admitted batch's callers are never kept behind the back-pressure of the next one
+        compute.would_block = (lambda: gate.would_block(1)) if gate is not None else None
     fids.append(server.bind_buffers('inference', in_specs, out_specs, num_slots, in_ptrs, out_ptrs, compute,
                                     output_nest=gs.TensorSpec((n,), action_dtype, 'action'),
                                     keep=(req, obs, act, out, graphs, s_inf, s_copy)))

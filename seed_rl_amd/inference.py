@@ -389,7 +389,11 @@ class FusedInferenceState(object):
     of a captured GraphedStep) and advances the ring head: the batch is a ring of columns, nothing is compacted.  Returns
     False (nothing copied) when fewer than batch_size unrolls are complete.  One host read of the fill count.
     Call it on the stream the inference calls are submitted to (`with torch.cuda.stream(s)`: the read then orders after
-    every inference call in flight) and under the lock that serialises those submissions."""
+    every inference call in flight) and under the lock that serialises those submissions.  That read BLOCKS until the
+    replays already submitted to the stream are through (up to `inference_slots` of them: hundreds of microseconds, not
+    the copies' few): it is what makes the count exact -- the host mirror the caller gates on (BatchGate.fill) is only
+    a lower bound of what is complete and an upper bound would be needed for back-pressure at the same time.  Callers
+    therefore attempt it only when the mirror already says a batch is there (LearnerServer.train_step)."""
     k = int(self.batch_count[0])
     self.last_fill = k                               # exact fill after this call (learner_server.BatchGate)
     if k < batch_size:

@@ -17,8 +17,8 @@ Concurrency (round 3).  Inference and training share ONE GPU the way the referen
 inference and training cores: inference batches run on a HIGH-PRIORITY stream through an `inference_twin()` of the
 agent (same parameter buffer, own workspaces), the train step on its own stream, replayed from a HIP graph -- nothing
 serialises a whole train step against inference any more.  The only ordered hand-over is the dequeue: it is submitted
-to the inference stream under the lock that also orders the inference submissions (microseconds: one count read, the
-column copies), writes into one of two static training unrolls, and the train stream waits for its event.  The
+to the inference stream under the lock that also orders the inference submissions (one count read, which waits for the
+replays in flight on that stream, and the column copies), writes into one of two static training unrolls, and the train stream waits for its event.  The
 transport is the native front-end (grpc_native / libseedserve.so) unless transport='python'.
 """
 import collections
@@ -44,6 +44,10 @@ class BatchGate(object):
     self.mirror = torch.zeros(1, dtype=torch.int32).pin_memory()
     self.waits = 0
     self.open = True
+
+  def would_block(self, ahead=0):
+    """True while admit(ahead) would wait (grpc_native's compute loop launches an already staged batch first)."""
+    return self.open and self.fill + self.n * (self.inflight + ahead + 1) > self.state.cap
 
   def admit(self, ahead=0, poll_s=0.0001):
     """Blocks while this batch, on top of the ones still in flight, could overflow the device batch.  Once the gate is
