@@ -2,10 +2,13 @@
 write) and the variable-name map of the reference agents -- SURVEY.md 8(f) rank 4: a reference checkpoint
 (/root/reference/agents/vtrace/learner.py:286-296: tf.train.Checkpoint(agent=agent, optimizer=optimizer);
 agents/r2d2/learner.py:646-647: + target_agent) can be loaded into the agents here.  The WRITER emits the same keys,
-dtypes and shapes for the VARIABLE_VALUE tensors but NOT the serialized TrackableObjectGraph that TensorFlow stores
-under `_CHECKPOINTABLE_OBJECT_GRAPH` and that tf.train.Checkpoint.restore() walks: files written here round-trip
-through this module (and are readable tensor by tensor with tf.train.load_checkpoint), they are not a drop-in for
-Checkpoint.restore().
+dtypes and shapes for the VARIABLE_VALUE tensors and (r4) a serialized TrackableObjectGraph under
+`_CHECKPOINTABLE_OBJECT_GRAPH`, derived from those keys: one node per attribute path, `VARIABLE_VALUE` attributes with
+their checkpoint keys, Adam's slots as `slot_variables` of the optimizer node, `save_counter` -- the structure
+tf.train.Checkpoint.restore() walks.  Restated from TF's published sources like the rest of this module and NOT checked
+against a TF-written file or a TF reader ("format unpinned"): files written here round-trip through this module
+(tests/test_tf_checkpoint.py walks the emitted graph from the root to every key); whether TensorFlow's restore()
+accepts them is untested.
 
 Format (TF 2.4.1; no TensorFlow in this image, so restated from its published sources and NOT checked against a
 TF-written file -- "format unpinned"; the writer and the reader here round-trip, tests/test_tf_checkpoint.py):
@@ -30,6 +33,8 @@ from seed_rl_amd import tf_wire
 
 BundleHeaderProto = tf_wire.message_class('tensorflow.BundleHeaderProto')
 BundleEntryProto = tf_wire.message_class('tensorflow.BundleEntryProto')
+TrackableObjectGraph = tf_wire.message_class('tensorflow.TrackableObjectGraph')
+OBJECT_GRAPH_KEY = '_CHECKPOINTABLE_OBJECT_GRAPH'
 _MAGIC = 0xdb4775248b80fb57
 _SUFFIX = '/.ATTRIBUTES/VARIABLE_VALUE'
 DT_FLOAT, DT_INT32, DT_INT64, DT_STRING, DT_BOOL, DT_DOUBLE, DT_UINT8 = 1, 3, 9, 7, 10, 2, 4
@@ -200,11 +205,21 @@ def read_checkpoint(prefix):
       continue
     e = BundleEntryProto()
     e.ParseFromString(v)
-    if e.dtype not in _NP or len(e.slices):
-      continue                                       # strings (the object graph), variants, partitioned variables
+    if (e.dtype not in _NP and e.dtype != DT_STRING) or len(e.slices):
+      continue                                       # variants, partitioned variables
     if e.shard_id not in shards:
       shards[e.shard_id] = open('%s.data-%05d-of-%05d' % (prefix, e.shard_id, max(header.num_shards, 1)), 'rb').read()
     raw = shards[e.shard_id][e.offset:e.offset + e.size]
+    if e.dtype == DT_STRING:                          # (the object graph: a scalar string)
+      n = 1
+      for d in e.shape.dim:
+        n *= int(d.size)
+      strings, crc = _parse_string_tensor(raw, n)
+      if e.crc32c and _mask(crc) != e.crc32c:
+        raise ValueError('checkpoint data: checksum mismatch for %s' % k.decode())
+      out[k.decode()] = strings[0] if not len(e.shape.dim) else np.array(strings, dtype=object).reshape(
+          tuple(int(d.size) for d in e.shape.dim))
+      continue
     if e.crc32c and _mask(crc32c(raw)) != e.crc32c:
       raise ValueError('checkpoint data: checksum mismatch for %s' % k.decode())
     shape = tuple(int(d.size) for d in e.shape.dim)
@@ -212,14 +227,123 @@ def read_checkpoint(prefix):
   return out
 
 
+def _string_tensor(strings):
+  """tensor_bundle.cc WriteStringTensor: [varint64 length]* [4-byte masked crc32c of the lengths as uint64s] [bytes]*;
+  the entry's checksum runs over the lengths (as uint64), the 4 checksum bytes and the string bytes."""
+  out, crc = bytearray(), 0
+  for b in strings:
+    out += _varint(len(b))
+    crc = crc32c(struct.pack('<Q', len(b)), crc)
+  lc = struct.pack('<I', _mask(crc))
+  out += lc
+  crc = crc32c(lc, crc)
+  for b in strings:
+    out += b
+    crc = crc32c(b, crc)
+  return bytes(out), crc
+
+
+def _parse_string_tensor(raw, n):
+  lengths, p, crc = [], 0, 0
+  for _ in range(n):
+    v, p = _read_varint(raw, p)
+    lengths.append(v)
+    crc = crc32c(struct.pack('<Q', v), crc)
+  if struct.unpack('<I', raw[p:p + 4])[0] != _mask(crc):
+    raise ValueError('checkpoint data: string-length checksum mismatch')
+  crc = crc32c(raw[p:p + 4], crc)
+  p += 4
+  strings = []
+  for v in lengths:
+    strings.append(bytes(raw[p:p + v]))
+    p += v
+  for b in strings:
+    crc = crc32c(b, crc)
+  return strings, crc
+
+
+def object_graph(keys, optimizer_root='optimizer'):
+  """TrackableObjectGraph for a set of tf.train.Checkpoint keys (those ending in /.ATTRIBUTES/VARIABLE_VALUE): node 0 is
+  the Checkpoint object, every path component a child edge (`local_name`), a key's last node carries the
+  VARIABLE_VALUE attribute; <variable path>/.OPTIMIZER_SLOT/<optimizer>/<slot> keys become nodes without a parent
+  edge, referenced from the optimizer node's slot_variables (training/tracking/graph_view.py serialises them so)."""
+  g = TrackableObjectGraph()
+  g.nodes.add()
+  ids = {(): 0}
+
+  def node(path):
+    path = tuple(path)
+    if path not in ids:
+      parent = node(path[:-1])
+      ids[path] = len(g.nodes)
+      g.nodes.add()
+      ref = g.nodes[parent].children.add()
+      ref.node_id, ref.local_name = ids[path], path[-1]
+    return ids[path]
+
+  def attribute(n, key, full_name):
+    a = g.nodes[n].attributes.add()
+    a.name, a.full_name, a.checkpoint_key = 'VARIABLE_VALUE', full_name, key
+
+  slots = []
+  for key in sorted(keys, key=lambda k: k.encode()):
+    if not key.endswith(_SUFFIX):
+      continue
+    parts = key[:-len(_SUFFIX)].split('/')
+    if '.OPTIMIZER_SLOT' in parts:
+      slots.append((key, parts))
+      continue
+    attribute(node(parts), key, '/'.join(parts[1:]) or parts[0])
+  for key, parts in slots:
+    i = parts.index('.OPTIMIZER_SLOT')
+    var, opt, slot = parts[:i], parts[i + 1:-1], parts[-1]
+    n = len(g.nodes)
+    g.nodes.add()
+    attribute(n, key, '/'.join(var[1:]) + '/' + slot)
+    ref = g.nodes[node(opt)].slot_variables.add()
+    ref.original_variable_node_id, ref.slot_name, ref.slot_variable_node_id = node(var), slot, n
+  return g
+
+
+def walk_object_graph(graph_bytes):
+  """{checkpoint key: path of local names from the root} of a serialized TrackableObjectGraph; slot variables as
+  <variable path> + ['.OPTIMIZER_SLOT'] + <optimizer path> + [slot name] -- what restore() matches objects by."""
+  g = TrackableObjectGraph()
+  g.ParseFromString(graph_bytes)
+  paths, out = {0: []}, {}
+  todo = [0]
+  while todo:
+    n = todo.pop()
+    for c in g.nodes[n].children:
+      if c.node_id not in paths:
+        paths[c.node_id] = paths[n] + [c.local_name]
+        todo.append(c.node_id)
+  for n, obj in enumerate(g.nodes):
+    for s in obj.slot_variables:
+      paths[s.slot_variable_node_id] = paths[s.original_variable_node_id] + ['.OPTIMIZER_SLOT'] + paths[n] + [s.slot_name]
+  for n, obj in enumerate(g.nodes):
+    for a in obj.attributes:
+      out[a.checkpoint_key] = paths[n]
+  return out
+
+
 def write_checkpoint(prefix, tensors):
-  """Writes <prefix>.index and <prefix>.data-00000-of-00001 for {name: array} (one shard, uncompressed blocks)."""
+  """Writes <prefix>.index and <prefix>.data-00000-of-00001 for {name: array} (one shard, uncompressed blocks); a
+  `bytes` value becomes a scalar string tensor."""
   data, entries = bytearray(), []
   header = BundleHeaderProto()
   header.num_shards = 1
   header.version.producer = 1
   entries.append((b'', header.SerializeToString()))
   for name in sorted(tensors, key=lambda n: n.encode()):
+    if isinstance(tensors[name], (bytes, bytearray)):
+      raw, crc = _string_tensor([bytes(tensors[name])])
+      e = BundleEntryProto()
+      e.dtype = DT_STRING
+      e.shard_id, e.offset, e.size, e.crc32c = 0, len(data), len(raw), _mask(crc)
+      data += raw
+      entries.append((name.encode(), e.SerializeToString()))
+      continue
     a = np.asarray(tensors[name])                   # (np.ascontiguousarray would turn scalars into shape (1,))
     a = a if a.flags.c_contiguous else a.copy()
     e = BundleEntryProto()
@@ -362,5 +486,8 @@ def save_agent(prefix, agent, root='agent', optimizer=None, optimizer_root='opti
           key = '%s/%s/.OPTIMIZER_SLOT/%s/%s%s' % (root, paths.get(name, name), optimizer_root, slot, _SUFFIX)
           a = view.detach().cpu().numpy()
           tensors[key] = a.reshape(()) if name == 'entropy_cost_param' else a
+  if 'save_counter' + _SUFFIX not in tensors:         # tf.train.Checkpoint.save() counts its calls there
+    tensors['save_counter' + _SUFFIX] = np.asarray(1, np.int64)
+  tensors[OBJECT_GRAPH_KEY] = object_graph(tensors, optimizer_root).SerializeToString()
   write_checkpoint(prefix, tensors)
   return sorted(tensors)

@@ -73,6 +73,17 @@ def _build_pool():
   _msg(tf, 'BundleEntryProto', [('dtype', 1, 'int32', False), ('shape', 2, '.tensorflow.TensorShapeProto', False),
                                 ('shard_id', 3, 'int32', False), ('offset', 4, 'int64', False), ('size', 5, 'int64', False),
                                 ('crc32c', 6, 'fixed32', False), ('slices', 7, '.tensorflow.TensorSliceProto', True)])
+  # tensorflow/core/protobuf/trackable_object_graph.proto (TF 2.4.1): what tf.train.Checkpoint stores under the key
+  # _CHECKPOINTABLE_OBJECT_GRAPH and walks in restore()
+  og = _msg(tf, 'TrackableObjectGraph', [('nodes', 1, '.tensorflow.TrackableObjectGraph.TrackableObject', True)])
+  T = '.tensorflow.TrackableObjectGraph.TrackableObject'
+  to = _msg(og, 'TrackableObject', [('children', 1, T + '.ObjectReference', True), ('attributes', 2, T + '.SerializedTensor', True),
+                                    ('slot_variables', 3, T + '.SlotVariableReference', True)])
+  _msg(to, 'ObjectReference', [('node_id', 1, 'int32', False), ('local_name', 2, 'string', False)])
+  _msg(to, 'SerializedTensor', [('name', 1, 'string', False), ('full_name', 2, 'string', False),
+                                ('checkpoint_key', 3, 'string', False), ('optional_restore', 4, 'bool', False)])
+  _msg(to, 'SlotVariableReference', [('original_variable_node_id', 1, 'int32', False), ('slot_name', 2, 'string', False),
+                                     ('slot_variable_node_id', 3, 'int32', False)])
   pool.Add(tf)
   # grpc/service.proto:28-57
   sv = descriptor_pb2.FileDescriptorProto(name='seed_rl_amd/service.proto', package='seed_rl', syntax='proto3')

@@ -68,3 +68,39 @@ def test_reference_key_names():
   q = tc.reference_variable_paths(d)
   assert q['body/fc/kernel'] == '_body/layer_with_weights-3/kernel' and q['advantage/head/kernel'].endswith('-1/kernel')
   assert 'advantage/head/bias' not in q
+
+
+def test_object_graph_reaches_every_key(tmp_path):
+  """The TrackableObjectGraph emitted under _CHECKPOINTABLE_OBJECT_GRAPH (agents/vtrace/learner.py:286-296: what
+  tf.train.Checkpoint(agent=..., optimizer=...).restore() walks): every VARIABLE_VALUE key of the file is reachable from
+  the root by exactly the attribute path its name spells, Adam's slots hang off the optimizer node with the variable
+  they belong to, and the scalar string tensor survives the bundle's checksums."""
+  keys = {}
+  names = ['agent/_stacks/0/_conv/kernel', 'agent/_stacks/0/_conv/bias', 'agent/_core/recurrent_kernel',
+           'agent/entropy_cost_param']
+  for i, n in enumerate(names):
+    keys[n + tc._SUFFIX] = np.full((2, i + 1), i, np.float32) if i < 3 else np.asarray(0.5, np.float32)
+    for slot in ('m', 'v'):
+      keys['%s/.OPTIMIZER_SLOT/optimizer/%s%s' % (n, slot, tc._SUFFIX)] = keys[n + tc._SUFFIX] * 0
+  keys['optimizer/iter' + tc._SUFFIX] = np.asarray(7, np.int64)
+  keys['save_counter' + tc._SUFFIX] = np.asarray(1, np.int64)
+  graph = tc.object_graph(keys)
+  # structure: node 0 has exactly the three top-level children; the optimizer node references 8 slot variables
+  assert sorted(c.local_name for c in graph.nodes[0].children) == ['agent', 'optimizer', 'save_counter']
+  opt = [n for n in graph.nodes if len(n.slot_variables)]
+  assert len(opt) == 1 and len(opt[0].slot_variables) == 2 * len(names)
+  assert sorted(set(s.slot_name for s in opt[0].slot_variables)) == ['m', 'v']
+  keys[tc.OBJECT_GRAPH_KEY] = graph.SerializeToString()
+  prefix = str(tmp_path / 'ckpt-1')
+  tc.write_checkpoint(prefix, keys)
+  back = tc.read_checkpoint(prefix)
+  assert back[tc.OBJECT_GRAPH_KEY] == keys[tc.OBJECT_GRAPH_KEY]
+  walked = tc.walk_object_graph(back[tc.OBJECT_GRAPH_KEY])
+  want = {k: k[:-len(tc._SUFFIX)].split('/') for k in keys if k.endswith(tc._SUFFIX)}
+  assert walked == want
+  # a flipped byte in the string tensor is caught by its checksum
+  data = bytearray(open(prefix + '.data-00000-of-00001', 'rb').read())
+  data[5] ^= 0x40
+  open(prefix + '.data-00000-of-00001', 'wb').write(bytes(data))
+  with pytest.raises(ValueError):
+    tc.read_checkpoint(prefix)
