@@ -22,6 +22,7 @@
 #include "wfw.h"
 #include "wfx.h"
 #include "wdx.h"
+#include "wsx.h"
 #include "../../include/seedhip.h"
 
 using namespace seedhip;
@@ -212,6 +213,7 @@ int check_geom(const seedhip_conv_geom* g, const char* what) {
 // Which matrix pipe serves this geometry (pass 0 forward, 1 data gradient, 2 weight gradient): 1 = fp32 MFMA
 // (v_mfma_f32_16x16x4_f32), 6 = bf16 MFMA through the exact three-way split of both operands (xgemm.h: six bf16 MACs per
 // algorithmic MAC).  What the bench prices a kernel's roofline with; 0 = unknown pass / null geometry.
+static int wsx_enabled() { static const int on = getenv("SEEDHIP_WSX") ? atoi(getenv("SEEDHIP_WSX")) : 1; return on; }
 static int wdx_enabled() { static const int on = getenv("SEEDHIP_WDX") ? atoi(getenv("SEEDHIP_WDX")) : 1; return on; }
 static int wfx_enabled() { static const int on = getenv("SEEDHIP_WFX") ? atoi(getenv("SEEDHIP_WFX")) : 1; return on; }
 
@@ -219,6 +221,7 @@ extern "C" int seedhip_conv2d_pipe(const seedhip_conv_geom* g, int pass) {
   if (!g || pass < 0 || pass > 2) return 0;
   if (pass == 0 && wfx_enabled()) { wfx::Params xp; if (wfx::plan(xp, g)) return 6; }
   if (pass == 1 && wdx_enabled()) { wdx::Params dp; if (wdx::plan(dp, g)) return 6; }
+  if (pass <= 1 && wsx_enabled() && wsx::geometry(g)) return 6;
   if (xg8::mode() & (1 << pass)) {
     const xg8::Plan x8 = pass == 0 ? x8_fwd_plan(g) : pass == 1 ? x8_dgrad_plan(g) : x8_wgrad_plan(g);
     if (x8.ok) return 6;
@@ -306,6 +309,18 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
       pl.slices = 1; pl.k_per_slice = gp.K;
       gemm::launch<true, false, true, false, false>(gp, pl, (hipStream_t)stream);
       return check_launch("conv2d_fwd(gather gemm)");
+    }
+  }
+  {
+    // the 32 -> 32 3x3 'same' layers of ImpalaDeep on the bf16 matrix pipe (wsx.h)
+    const int geo = wsx_enabled() && in_dtype == kInF32 ? wsx::geometry(geom) : 0;
+    if (geo && al16(in) && al16(w) && al16(out) && al16(bias) && al16(residual)) {
+      wsx::Params sp;
+      memset(&sp, 0, sizeof(sp));
+      sp.X = (const float*)in; sp.Wt = w; sp.bias = bias; sp.A = residual; sp.Y = out; sp.n_img = geom->n_img;
+      sp.in_relu = in_relu; sp.out_relu = out_relu;
+      const int rc2 = wsx::launch(geo, false, sp, (hipStream_t)stream);
+      if (rc2 >= 0) return rc2;
     }
   }
   {
@@ -495,6 +510,17 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
       }
       gemm::launch<true, true, true, true, true>(gp, pl, (hipStream_t)stream);
       return check_launch("conv2d_bwd_data(gather gemm)");
+    }
+  }
+  {
+    // the same layers' data gradient: wsx.h with the weights flipped and transposed
+    const int geo = wsx_enabled() ? wsx::geometry(geom) : 0;
+    if (geo && al16(dy) && al16(w) && al16(dx) && al16(relu_mask) && al16(add)) {
+      wsx::Params sp;
+      memset(&sp, 0, sizeof(sp));
+      sp.X = dy; sp.Wt = w; sp.A = relu_mask; sp.B = add; sp.Y = dx; sp.n_img = geom->n_img;
+      const int rc2 = wsx::launch(geo, true, sp, (hipStream_t)stream);
+      if (rc2 >= 0) return rc2;
     }
   }
   {

@@ -621,6 +621,61 @@ def test_wdx_conv2_data_gradient_fp32_accuracy(device, n, mask):
   assert torch.equal(dx, dx2)
 
 
+@pytest.mark.parametrize('n,h,w,mode', [(512, 18, 24, 'fwd_res'), (600, 18, 24, 'fwd_plain'), (700, 9, 12, 'fwd_res'),
+                                        (515, 18, 24, 'dg_mask_add'), (640, 9, 12, 'dg_mask'), (1300, 9, 12, 'dg_plain')])
+def test_wsx_conv3x3_fp32_accuracy(device, n, h, w, mode):
+  """ImpalaDeep's 32 -> 32 3x3 'same' layers on the bf16 matrix pipe (wsx.h: padded rows staged once, K split between
+  the two waves of a tile, epilogue operands by LDS-DMA): forward with ReLU on the input, bias, residual and without;
+  data gradient (weights flipped / transposed in the kernel) with ReLU mask and skip-path add and without.  As close to
+  an fp64 evaluation as torch's fp32 convolution is (<= 2x), bit-identical from call to call; ragged last workgroups."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(n + h)
+  x = rng.normal(size=(n, h, w, 32)).astype(np.float32)
+  wt = (rng.normal(size=(3, 3, 32, 32)) / 17).astype(np.float32)
+  b = rng.normal(size=32).astype(np.float32)
+  extra = rng.normal(size=(n, h, w, 32)).astype(np.float32)
+  extra2 = rng.normal(size=(n, h, w, 32)).astype(np.float32)
+  g = ops.conv_geom(n, h, w, 32, 3, 3, 1, 'same', 32)
+  xd, wd, bd, ed, e2d = dev(x, device), dev(wt, device), dev(b, device), dev(extra, device), dev(extra2, device)
+  tx = torch.tensor(x).permute(0, 3, 1, 2)
+  tw = torch.tensor(wt).permute(3, 2, 0, 1)               # [co, ci, kh, kw]
+  te, te2 = torch.tensor(extra), torch.tensor(extra2)
+
+  def run():
+    out = torch.full((n, h, w, 32), 7.0, device=device)
+    if mode == 'fwd_res':
+      ops.conv2d_fwd(g, xd, wd, bd, out, in_relu=True, out_relu=False, residual=ed)
+    elif mode == 'fwd_plain':
+      ops.conv2d_fwd(g, xd, wd, None, out, in_relu=False, out_relu=True)
+    elif mode == 'dg_mask_add':
+      ops.conv2d_bwd_data(g, xd, wd, out, relu_mask=ed, add=e2d)
+    elif mode == 'dg_mask':
+      ops.conv2d_bwd_data(g, xd, wd, out, relu_mask=ed)
+    else:
+      ops.conv2d_bwd_data(g, xd, wd, out)
+    return out
+
+  def ref(dt):
+    a, k = tx.to(dt), tw.to(dt)
+    if mode == 'fwd_res':
+      return F.conv2d(F.relu(a), k, torch.tensor(b).to(dt), padding=1).permute(0, 2, 3, 1) + te.to(dt)
+    if mode == 'fwd_plain':
+      return F.relu(F.conv2d(a, k, None, padding=1)).permute(0, 2, 3, 1)
+    y = F.conv_transpose2d(a, k, padding=1).permute(0, 2, 3, 1)     # gradient of conv2d(., k) wrt its input, at dY = a
+    if mode == 'dg_mask_add':
+      return y * (te > 0).to(dt) + te2.to(dt)
+    if mode == 'dg_mask':
+      return y * (te > 0).to(dt)
+    return y
+
+  got = run()
+  r32, r64 = ref(torch.float32).numpy().astype(np.float64), ref(torch.float64).numpy()
+  e_hip = np.max(np.abs(got.cpu().numpy().astype(np.float64) - r64)); e_f32 = np.max(np.abs(r32 - r64))
+  print('wsx %s n=%d %dx%d: err hip %.3e  torch fp32 %.3e' % (mode, n, h, w, e_hip, e_f32))
+  assert e_hip <= max(2.0 * e_f32, 2e-6 * np.abs(r64).max()), (mode, e_hip, e_f32)
+  assert torch.equal(got, run())
+
+
 @pytest.mark.parametrize('n,cin,cout', [(4100, 520, 264), (4096, 2592, 256), (4224, 256, 1024)])   # (>= 4096 rows)
 def test_x8_gemm_epilogues_and_tails(device, n, cin, cout):
   """The 8-wave bf16x6 Dense kernels (xgemm8.h: 128 x 256 tiles, the small operand pre-split into k-tile slabs) on ragged

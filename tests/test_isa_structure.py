@@ -57,7 +57,9 @@ def test_register_budgets_of_the_hot_kernels(code_objects):
       'wsw_lds_kernelILb0ELi21ELi0': (256, 0),                  # two 4-wave workgroups per CU (LDS)
       'wfw_kernelILb0': (256, 0),
       'wfx_kernelILb0ELb0ELi0': (256, 4),
-      'wdx_kernelILb1ELi0': (256, 0),                           # r4: the same for the data gradient
+      'wdx_kernelILb1ELi0': (256, 0),
+      'wsx_kernelINS0_3GeoILi18ELi24EEELb0': (256, 0),         # r4: ImpalaDeep's 32 -> 32 3x3 layers, forward / data gradient
+      'wsx_kernelINS0_3GeoILi18ELi24EEELb1': (256, 0),                           # r4: the same for the data gradient
                        # r4: one 8-wave workgroup per CU; the spilled registers are prologue-only
       'xg8_kernelILi0ELi0': (256, 0),                           # one 8-wave workgroup per CU: two waves per SIMD
       'xg8_kernelILi1ELi0': (256, 0),

@@ -84,3 +84,34 @@ def test_wdx_ring_holds_two_rounds_and_a_set_holds_a_round():
       new = end_row(r, total, rows) - (end_row(r - 1, total, rows) if r else 0)
       assert 0 <= new * 44 <= threads * ITEMS, (nimg, r, new)
     assert end_row(rounds - 1, total, rows) == rows
+
+
+def test_wsx_rings_and_row_pitch():
+  """seed_rl_amd/csrc/wsx.h (ImpalaDeep's 32 -> 32 3x3 'same' layers): for both served maps, rounds r and r + 1 never
+  span more padded rows than the ring holds, a round's new rows fit one register set of 32-byte items, and the row pitch
+  continues the 16-byte slot sequence from one image row to the next (= map width mod 16)."""
+  src = open(os.path.join(ROOT, 'seed_rl_amd', 'csrc', 'wsx.h')).read()
+  ROUND = int(re.search(r'constexpr int kRound = (\d+);', src).group(1))
+  ITEMS = int(re.search(r'constexpr int kItems = (\d+);', src).group(1))
+  threads = int(re.search(r'__launch_bounds__\((\d+)', src).group(1))
+  assert 'kR = W >= 24 ? 16 : 32' in src and 'kRSslots = 4 * kWP + ((W - 4 * kWP) % 16 + 16) % 16' in src
+  for H, W in ((18, 24), (9, 12)):
+    HP, WP, PX = H + 2, W + 2, H * W
+    R = 16 if W >= 24 else 32
+    rs = 4 * WP + ((W - 4 * WP) % 16 + 16) % 16
+    assert rs % 16 == W % 16 and rs >= 4 * WP
+    for nimg in (1, 2, 3, 7, 21, 22):
+      total, rows = nimg * PX, nimg * HP
+
+      def end_row(r):
+        pl = min(ROUND * r + ROUND - 1, total - 1)
+        li, rem = divmod(pl, PX)
+        return min(HP * li + rem // W + 3, rows)
+      rounds = -(-total // ROUND)
+      for r in range(rounds):
+        li, rem = divmod(ROUND * r, PX)
+        first = HP * li + rem // W
+        assert end_row(r + 1) - first <= R, (H, W, nimg, r)
+        new = end_row(r) - (end_row(r - 1) if r else 0)
+        assert 0 <= new * 4 * WP <= threads * ITEMS, (H, W, nimg, r, new)
+      assert end_row(rounds - 1) == rows
