@@ -23,6 +23,7 @@
 #include "wfx.h"
 #include "wdx.h"
 #include "wsx.h"
+#include "wsy.h"
 #include "../../include/seedhip.h"
 
 using namespace seedhip;
@@ -221,7 +222,7 @@ extern "C" int seedhip_conv2d_pipe(const seedhip_conv_geom* g, int pass) {
   if (!g || pass < 0 || pass > 2) return 0;
   if (pass == 0 && wfx_enabled()) { wfx::Params xp; if (wfx::plan(xp, g)) return 6; }
   if (pass == 1 && wdx_enabled()) { wdx::Params dp; if (wdx::plan(dp, g)) return 6; }
-  if (pass <= 1 && wsx_enabled() && wsx::geometry(g)) return 6;
+  if (pass <= 1 && wsx_enabled() && (wsx::geometry(g) || wsy::geometry(g))) return 6;
   if (xg8::mode() & (1 << pass)) {
     const xg8::Plan x8 = pass == 0 ? x8_fwd_plan(g) : pass == 1 ? x8_dgrad_plan(g) : x8_wgrad_plan(g);
     if (x8.ok) return 6;
@@ -320,6 +321,15 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
       sp.X = (const float*)in; sp.Wt = w; sp.bias = bias; sp.A = residual; sp.Y = out; sp.n_img = geom->n_img;
       sp.in_relu = in_relu; sp.out_relu = out_relu;
       const int rc2 = wsx::launch(geo, false, sp, (hipStream_t)stream);
+      if (rc2 >= 0) return rc2;
+    }
+    const int geo16 = wsx_enabled() && in_dtype == kInF32 ? wsy::geometry(geom) : 0;      // the 16 -> 16 layers (wsy.h)
+    if (geo16 && al16(in) && al16(w) && al16(out) && al16(bias) && al16(residual)) {
+      wsx::Params sp;
+      memset(&sp, 0, sizeof(sp));
+      sp.X = (const float*)in; sp.Wt = w; sp.bias = bias; sp.A = residual; sp.Y = out; sp.n_img = geom->n_img;
+      sp.in_relu = in_relu; sp.out_relu = out_relu;
+      const int rc2 = wsy::launch(geo16, false, sp, (hipStream_t)stream);
       if (rc2 >= 0) return rc2;
     }
   }
@@ -520,6 +530,14 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
       memset(&sp, 0, sizeof(sp));
       sp.X = dy; sp.Wt = w; sp.A = relu_mask; sp.B = add; sp.Y = dx; sp.n_img = geom->n_img;
       const int rc2 = wsx::launch(geo, true, sp, (hipStream_t)stream);
+      if (rc2 >= 0) return rc2;
+    }
+    const int geo16 = wsx_enabled() ? wsy::geometry(geom) : 0;
+    if (geo16 && al16(dy) && al16(w) && al16(dx) && al16(relu_mask) && al16(add)) {
+      wsx::Params sp;
+      memset(&sp, 0, sizeof(sp));
+      sp.X = dy; sp.Wt = w; sp.A = relu_mask; sp.B = add; sp.Y = dx; sp.n_img = geom->n_img;
+      const int rc2 = wsy::launch(geo16, true, sp, (hipStream_t)stream);
       if (rc2 >= 0) return rc2;
     }
   }

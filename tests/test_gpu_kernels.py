@@ -622,27 +622,31 @@ def test_wdx_conv2_data_gradient_fp32_accuracy(device, n, mask):
 
 
 @pytest.mark.parametrize('n,h,w,mode', [(512, 18, 24, 'fwd_res'), (600, 18, 24, 'fwd_plain'), (700, 9, 12, 'fwd_res'),
-                                        (515, 18, 24, 'dg_mask_add'), (640, 9, 12, 'dg_mask'), (1300, 9, 12, 'dg_plain')])
+                                        (515, 18, 24, 'dg_mask_add'), (640, 9, 12, 'dg_mask'), (1300, 9, 12, 'dg_plain'),
+                                        (256, 36, 48, 'fwd_res'), (300, 36, 48, 'fwd_plain'), (259, 36, 48, 'dg_mask_add'),
+                                        (513, 36, 48, 'dg_mask'), (270, 36, 48, 'dg_plain')])
 def test_wsx_conv3x3_fp32_accuracy(device, n, h, w, mode):
-  """ImpalaDeep's 32 -> 32 3x3 'same' layers on the bf16 matrix pipe (wsx.h: padded rows staged once, K split between
-  the two waves of a tile, epilogue operands by LDS-DMA): forward with ReLU on the input, bias, residual and without;
+  """ImpalaDeep's 32 -> 32 (18 x 24, 9 x 12 maps) and 16 -> 16 (36 x 48) 3x3 'same' layers on the bf16 matrix pipe
+  (wsx.h: padded rows staged once, K split between the two waves of a tile, epilogue operands by LDS-DMA; wsy.h: all
+  weights per wave, 16 x 16 x 32 MFMAs, outputs from the registers): forward with ReLU on the input, bias, residual and without;
   data gradient (weights flipped / transposed in the kernel) with ReLU mask and skip-path add and without.  As close to
   an fp64 evaluation as torch's fp32 convolution is (<= 2x), bit-identical from call to call; ragged last workgroups."""
   from seed_rl_amd import ops
   rng = np.random.default_rng(n + h)
-  x = rng.normal(size=(n, h, w, 32)).astype(np.float32)
-  wt = (rng.normal(size=(3, 3, 32, 32)) / 17).astype(np.float32)
-  b = rng.normal(size=32).astype(np.float32)
-  extra = rng.normal(size=(n, h, w, 32)).astype(np.float32)
-  extra2 = rng.normal(size=(n, h, w, 32)).astype(np.float32)
-  g = ops.conv_geom(n, h, w, 32, 3, 3, 1, 'same', 32)
+  C = 16 if h == 36 else 32
+  x = rng.normal(size=(n, h, w, C)).astype(np.float32)
+  wt = (rng.normal(size=(3, 3, C, C)) / np.sqrt(9 * C)).astype(np.float32)
+  b = rng.normal(size=C).astype(np.float32)
+  extra = rng.normal(size=(n, h, w, C)).astype(np.float32)
+  extra2 = rng.normal(size=(n, h, w, C)).astype(np.float32)
+  g = ops.conv_geom(n, h, w, C, 3, 3, 1, 'same', C)
   xd, wd, bd, ed, e2d = dev(x, device), dev(wt, device), dev(b, device), dev(extra, device), dev(extra2, device)
   tx = torch.tensor(x).permute(0, 3, 1, 2)
   tw = torch.tensor(wt).permute(3, 2, 0, 1)               # [co, ci, kh, kw]
   te, te2 = torch.tensor(extra), torch.tensor(extra2)
 
   def run():
-    out = torch.full((n, h, w, 32), 7.0, device=device)
+    out = torch.full((n, h, w, C), 7.0, device=device)
     if mode == 'fwd_res':
       ops.conv2d_fwd(g, xd, wd, bd, out, in_relu=True, out_relu=False, residual=ed)
     elif mode == 'fwd_plain':

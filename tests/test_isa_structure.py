@@ -59,7 +59,9 @@ def test_register_budgets_of_the_hot_kernels(code_objects):
       'wfx_kernelILb0ELb0ELi0': (256, 4),
       'wdx_kernelILb1ELi0': (256, 0),
       'wsx_kernelINS0_3GeoILi18ELi24EEELb0': (256, 0),         # r4: ImpalaDeep's 32 -> 32 3x3 layers, forward / data gradient
-      'wsx_kernelINS0_3GeoILi18ELi24EEELb1': (256, 0),                           # r4: the same for the data gradient
+      'wsx_kernelINS0_3GeoILi18ELi24EEELb1': (256, 0),
+      'wsy_kernelINS0_3GeoILi36ELi48EEELb0': (256, 0),         # r4: the 16 -> 16 layers
+      'wsy_kernelINS0_3GeoILi36ELi48EEELb1': (256, 0),                           # r4: the same for the data gradient
                        # r4: one 8-wave workgroup per CU; the spilled registers are prologue-only
       'xg8_kernelILi0ELi0': (256, 0),                           # one 8-wave workgroup per CU: two waves per SIMD
       'xg8_kernelILi1ELi0': (256, 0),

@@ -115,3 +115,31 @@ def test_wsx_rings_and_row_pitch():
         new = end_row(r) - (end_row(r - 1) if r else 0)
         assert 0 <= new * 4 * WP <= threads * ITEMS, (H, W, nimg, r, new)
       assert end_row(rounds - 1) == rows
+
+
+def test_wsy_ring_and_tiles():
+  """seed_rl_amd/csrc/wsy.h (ImpalaDeep's 16 -> 16 3x3 layers on 36 x 48 maps, rounds of 256 pixels): two rounds span at
+  most the ring's 16 padded rows, a round's new rows fit one register set, and a 16-pixel tile never crosses an image
+  row (48 and 36 x 48 are multiples of 16), which is what makes its operand reads conflict free."""
+  src = open(os.path.join(ROOT, 'seed_rl_amd', 'csrc', 'wsy.h')).read()
+  ROUND = int(re.search(r'constexpr int kRound = (\d+);', src).group(1))
+  ITEMS = int(re.search(r'constexpr int kItems = (\d+);', src).group(1))
+  R = int(re.search(r'static constexpr int kR = (\d+);', src).group(1))
+  threads = int(re.search(r'__launch_bounds__\((\d+)', src).group(1))
+  H, W = 36, 48
+  HP, WP, PX = H + 2, W + 2, H * W
+  assert W % 16 == 0 and PX % 16 == 0 and ROUND % 16 == 0
+  for nimg in (1, 2, 3, 20, 21):
+    total, rows = nimg * PX, nimg * HP
+
+    def end_row(r):
+      pl = min(ROUND * r + ROUND - 1, total - 1)
+      li, rem = divmod(pl, PX)
+      return min(HP * li + rem // W + 3, rows)
+    rounds = -(-total // ROUND)
+    for r in range(rounds):
+      li, rem = divmod(ROUND * r, PX)
+      assert end_row(r + 1) - (HP * li + rem // W) <= R, (nimg, r)
+      new = end_row(r) - (end_row(r - 1) if r else 0)
+      assert 0 <= new * 2 * WP <= threads * ITEMS, (nimg, r, new)
+    assert end_row(rounds - 1) == rows
