@@ -158,9 +158,14 @@ def step_roofline(kern, ms_per_step):
   (MI355X_MICROARCH.md), not the 8 TB/s spec, so that the floor is one a kernel could actually reach."""
   floor, parts = 0.0, {}
   for k, v in kern.items():
-    t_hbm = v['bytes'] / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3
-    t_mfma = v['flops'] / (_peak(v)[0] * 1e12) * 1e3
-    f = max(t_hbm, t_mfma) * v['calls']
+    # per group of equally sized calls (ops.aggregate): a region name can cover launches of different sizes
+    groups = v.get('groups') or [dict(calls=v['calls'], flops=v['flops'], bytes=v['bytes'])]
+    f, t_hbm, t_mfma = 0.0, 0.0, 0.0
+    for g in groups:
+      g_hbm = g['bytes'] / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3
+      g_mfma = g['flops'] / (_peak(v)[0] * 1e12) * 1e3
+      f += max(g_hbm, g_mfma) * g['calls']
+      t_hbm += g_hbm * g['calls']; t_mfma += g_mfma * g['calls']
     floor += f
     if f >= 0.02 * ms_per_step or v['total_ms'] >= 0.02 * ms_per_step:
       parts[k] = dict(floor_ms=round(f, 4), measured_ms=round(v['total_ms'], 4), bound='hbm' if t_hbm > t_mfma else 'mfma',
@@ -244,6 +249,8 @@ def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, 
   nattr = min(attribution_steps, max(warmup, 1))
   for v in kern.values():
     v['total_ms'] /= nattr; v['calls'] //= nattr
+    for g in v['groups']:
+      g['calls'] /= nattr
   # dominant kernel = largest share of the step in that pass (averaged over the attribution steps so that two kernels
   # a few microseconds apart do not swap places between runs), among the MFMA kernels and the HBM kernels that move
   # >= 32 MB, averaging >= 50 us per launch and launched at most 64 times per step: event pairs around

@@ -24,6 +24,7 @@
 #include "wdx.h"
 #include "wsx.h"
 #include "wsy.h"
+#include "wgx_api.h"
 #include "../../include/seedhip.h"
 
 using namespace seedhip;
@@ -216,6 +217,7 @@ int check_geom(const seedhip_conv_geom* g, const char* what) {
 // algorithmic MAC).  What the bench prices a kernel's roofline with; 0 = unknown pass / null geometry.
 static int wsx_enabled() { static const int on = getenv("SEEDHIP_WSX") ? atoi(getenv("SEEDHIP_WSX")) : 1; return on; }
 static int wdx_enabled() { static const int on = getenv("SEEDHIP_WDX") ? atoi(getenv("SEEDHIP_WDX")) : 1; return on; }
+static int wgx_enabled() { static const int on = getenv("SEEDHIP_WGX") ? atoi(getenv("SEEDHIP_WGX")) : 1; return on; }
 static int wfx_enabled() { static const int on = getenv("SEEDHIP_WFX") ? atoi(getenv("SEEDHIP_WFX")) : 1; return on; }
 
 extern "C" int seedhip_conv2d_pipe(const seedhip_conv_geom* g, int pass) {
@@ -223,6 +225,7 @@ extern "C" int seedhip_conv2d_pipe(const seedhip_conv_geom* g, int pass) {
   if (pass == 0 && wfx_enabled()) { wfx::Params xp; if (wfx::plan(xp, g)) return 6; }
   if (pass == 1 && wdx_enabled()) { wdx::Params dp; if (wdx::plan(dp, g)) return 6; }
   if (pass <= 1 && wsx_enabled() && (wsx::geometry(g) || wsy::geometry(g))) return 6;
+  if (pass == 2 && wgx_enabled() && wgx::plan(g)) return 6;
   if (xg8::mode() & (1 << pass)) {
     const xg8::Plan x8 = pass == 0 ? x8_fwd_plan(g) : pass == 1 ? x8_dgrad_plan(g) : x8_wgrad_plan(g);
     if (x8.ok) return 6;
@@ -695,6 +698,10 @@ extern "C" size_t seedhip_conv2d_bwd_weight_workspace_bytes(const seedhip_conv_g
       if (mm > need) need = mm;
     }
   }
+  if (const int k = wgx::plan(g)) {
+    const size_t mm = (size_t)wgx::grid_for(k, g->n_img) * ((size_t)M * N + N) * sizeof(float);
+    if (mm > need) need = mm;
+  }
   return need;
 }
 
@@ -706,6 +713,19 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
   SEEDHIP_REQUIRE(in_dtype == kInF32 || in_dtype == kInU8Div255, "conv2d_bwd_weight: bad in_dtype %d", in_dtype);
   SEEDHIP_REQUIRE(workspace_bytes >= seedhip_conv2d_bwd_weight_workspace_bytes(geom),
                   "conv2d_bwd_weight: workspace too small");
+  if (wgx_enabled() && in_dtype == kInF32 && al16(in) && al16(dy) && al16(workspace)) {
+    // bf16x6 through transposing LDS reads (wgx.h): the second Atari conv and ImpalaDeep's 3 x 3 layers
+    if (const int k = wgx::plan(geom)) {
+      const int M = geom->kh * geom->kw * geom->cin, N = geom->cout;
+      hipStream_t s = (hipStream_t)stream;
+      float* pw = (float*)workspace;
+      float* pb = pw + (size_t)wgx::grid_for(k, geom->n_img) * M * N;
+      int slices = 0;
+      rc = wgx::launch(k, geom, (const float*)in, in_relu, dy, pw, dbias ? pb : nullptr, &slices, s); if (rc) return rc;
+      reduce_slices2(pw, (long long)M * N, dw, pb, N, dbias, slices, s);
+      return check_launch("conv2d_bwd_weight(wgx)");
+    }
+  }
   {
     // streaming kernel (wsw.h): 64-float tap rows, 32 output channels -- the second Atari conv
     static const int wsw_on = getenv("SEEDHIP_WSW") ? atoi(getenv("SEEDHIP_WSW")) : 1;

@@ -33,22 +33,35 @@ reduce_slices_kernel(const ReduceJob ja, const ReduceJob jb, int blocks_a, int s
   }
 }
 
-// Many slices (persistent split-K workgroups write one slice each): 16 float4 columns x 16 slice lanes per
-// block; lane q sums slices q, q+16, ... (independent loads in flight), then the 16 lanes are combined through
-// LDS in a fixed order.  Deterministic, and 16x more parallel than one thread walking all slices of a column.
+// Many slices (persistent split-K workgroups write one slice each): 8 float4 columns x 32 slice lanes per block (a wave
+// touches eight 128-byte runs per load instruction); lane q sums slices q, q + 32, ... with four independent loads in
+// flight per round, then the 32 lanes are combined through LDS in a fixed order.  Deterministic.  (r5: 16 columns x 16
+// lanes left half the chip idle on an [8192]-float gradient -- 128 blocks -- and walked 32 slices per thread: 10.4 us
+// for 512 slices of the second Atari conv's gradient, 135 launches per cfg3 step.)
 static __global__ void __launch_bounds__(256)
 reduce_slices_wide_kernel(const ReduceJob ja, const ReduceJob jb, int blocks_a, int slices) {
-  __shared__ float4 red[16][17];
+  __shared__ float4 red[32][9];
   const bool first = (int)blockIdx.x < blocks_a;
   const ReduceJob j = first ? ja : jb;
   const long long bx = first ? blockIdx.x : blockIdx.x - blocks_a;
   const float* __restrict__ partial = j.partial; float* __restrict__ out = j.out; const long long n = j.n;
-  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int col = threadIdx.x & 7, sl = threadIdx.x >> 3;
   const long long n4 = n >> 2;
-  const long long c4 = bx * 16 + col;
+  const long long c4 = bx * 8 + col;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c4 < n4) {
-    for (int z = sl; z < slices; z += 16) {
+    int z = sl;
+    for (; z + 96 < slices; z += 128) {
+      const float4 b0 = reinterpret_cast<const float4*>(partial + (long long)z * n)[c4];
+      const float4 b1 = reinterpret_cast<const float4*>(partial + (long long)(z + 32) * n)[c4];
+      const float4 b2 = reinterpret_cast<const float4*>(partial + (long long)(z + 64) * n)[c4];
+      const float4 b3 = reinterpret_cast<const float4*>(partial + (long long)(z + 96) * n)[c4];
+      a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+      a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
+      a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
+      a.x += b3.x; a.y += b3.y; a.z += b3.z; a.w += b3.w;
+    }
+    for (; z < slices; z += 32) {
       const float4 b = reinterpret_cast<const float4*>(partial + (long long)z * n)[c4];
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
@@ -57,7 +70,7 @@ reduce_slices_wide_kernel(const ReduceJob ja, const ReduceJob jb, int blocks_a, 
   __syncthreads();
   if (sl == 0 && c4 < n4) {
     float4 t = red[0][col];
-    for (int q = 1; q < 16; ++q) { const float4 b = red[q][col]; t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w; }
+    for (int q = 1; q < 32; ++q) { const float4 b = red[q][col]; t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w; }
     reinterpret_cast<float4*>(out)[c4] = t;
   }
 }
@@ -78,7 +91,7 @@ static inline void reduce_slices2(const float* pw, long long nw, float* dw, cons
   const ReduceJob ja{pw, nw, dw};
   const ReduceJob jb{db ? pb : pw, db ? nb : 0, db ? db : dw};
   if (wa) {
-    const int ba = cdiv(nw >> 2, 16), bb = jb.n ? cdiv(jb.n >> 2, 16) : 0;
+    const int ba = cdiv(nw >> 2, 8), bb = jb.n ? cdiv(jb.n >> 2, 8) : 0;
     hipLaunchKernelGGL(reduce_slices_wide_kernel, dim3(ba + bb), dim3(256), 0, s, ja, jb, ba, slices);
     return;
   }

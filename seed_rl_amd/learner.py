@@ -318,6 +318,10 @@ class GraphedStep(object):
     for k, v in counters.items():
       setattr(learner, k, v)
     self._agents = agents
+    # did THIS capture record LSTM sequence kernels?  (with several GraphedSteps over one agent -- one per
+    # unroll slot of LearnerServer -- only the first caller sees `_lstm_seq_check()` return True; every graph that still
+    # holds the sequence kernels of a demoted agent has to be captured again, so the decision is taken from state)
+    self._captured_seq = any(bool(c.get('fused_seq')) for a in agents for c in getattr(a, '_lstm_ctx', {}).values())
     self.exchange = True          # bench.py clears it for a few steps to price the EXPOSED part of the exchange
     torch.cuda.synchronize()
 
@@ -341,16 +345,24 @@ class GraphedStep(object):
       post()
     # the persistent LSTM kernels' abort flags: mirrored to pinned host memory after every replay and looked at
     # before the next one (by then the copy has landed: no sync) -- a wait that timed out during a replay raises here
-    demoted = False
     for a in self._agents:
       if getattr(a, '_last_lstm', None) is not None:
-        demoted = bool(a._lstm_seq_check()) or demoted   # pylint: disable=protected-access
+        a._lstm_seq_check()                       # pylint: disable=protected-access
         a.mirror_error_flags()
-    if demoted:
-      # an agent fell back to the per-step LSTM kernels (a sequence kernel's wait timed out in an earlier replay; the
-      # update kernel dropped those steps): the captured graphs still hold the sequence kernels -- capture again
+    if self._captured_seq and any(getattr(a, '_seq_demoted', False) for a in self._agents):
+      # an agent fell back to the per-step LSTM kernels (a sequence kernel's wait timed out in an earlier replay -- of
+      # this graph or of another slot's; the update kernel dropped those steps): this graph still holds the sequence
+      # kernels -- capture again.  The step that timed out was dropped ON THE DEVICE; the host-side step counter (Adam's
+      # bias correction, the LR schedule position) still advanced for it: a rare fallback, not rolled back.
+      if self.split:
+        # the abort and the demotion are rank-local but the gradients are all-reduced: the other ranks applied this
+        # rank's invalid gradients, and a re-capture here would post warm-up all-reduces nobody matches
+        raise RuntimeError('seed_rl_amd: an LSTM sequence kernel timed out on this rank of a data-parallel learner; '
+                           'replicas have diverged -- restart from the last checkpoint with SEEDHIP_LSTM_SEQ=0')
+      out = self.outputs                          # this call's results (the new capture's outputs are not written yet)
       torch.cuda.synchronize()
       self.__init__(self.learner, self.unroll, *self.extra, warmup=1, max_cuts=self._max_cuts)
+      return out
     return self.outputs
 
   def check_errors(self):

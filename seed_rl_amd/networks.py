@@ -381,13 +381,20 @@ class _Agent(object):
       return False
     if wait:
       self._seq_event.synchronize()
-    if self._seq_event.query() and int(self._seq_flag[0]) != 0 and not getattr(self, '_seq_demoted', False):
+    if self._seq_event.query() and int(self._seq_flag[0]) != 0:
       import sys
-      self._seq_demoted = True
       self._seq_flag.zero_()
       t = self._ws.get(('lstm_seq_sticky', (1,), torch.int32))
       if t is not None:
         t.zero_()                                  # stream-ordered: behind every step that saw it set
+      if getattr(self, '_seq_demoted', False):
+        # already demoted: a graph captured BEFORE the demotion (another unroll slot's) replayed its sequence kernels
+        # and timed out again.  Clear the word all the same -- left set, the update kernel would drop every later step
+        # of every slot without an error -- and say so; learner.GraphedStep re-captures that graph.
+        sys.stderr.write('seed_rl_amd: a graph captured before the demotion replayed an LSTM sequence kernel that timed out '
+                         'again; step dropped, sticky word cleared\n')
+        return False
+      self._seq_demoted = True
       sys.stderr.write('seed_rl_amd: an LSTM sequence kernel timed out waiting for its co-resident grid (another stream '
                        'held CUs); the affected step(s) were dropped, this agent now runs one launch per LSTM step\n')
       return True

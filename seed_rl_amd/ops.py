@@ -25,7 +25,7 @@ class Profiler(object):
     self.serialize = serialize
     self.only = set(only) if only is not None else None
     self.events = collections.OrderedDict()
-    self.meta = {}
+    self.costs = {}                                  # name -> [(flops, bytes) per call]
     self.pipes = {}
 
   @staticmethod
@@ -48,16 +48,40 @@ class Profiler(object):
   def summary(self):
     torch.cuda.synchronize()
     ovh = self.event_overhead_ms(serialize=self.serialize)
-    out = collections.OrderedDict()
-    for name, evs in self.events.items():
-      ms = sorted(max(s.elapsed_time(e) - ovh, 0.0) for s, e in evs)
-      flops, nbytes = self.meta[name]
-      # the per-launch figure is the MEDIAN: one launch that catches a clock ramp, a page fault or a first-use
-      # code-object load (seen: 0.34 ms for a 15 us kernel) must not re-rank the kernels or move a roofline fraction
-      med = ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2])
-      out[name] = dict(calls=len(ms), total_ms=med * len(ms), avg_ms=med, mean_ms=sum(ms) / len(ms), flops=flops,
-                       bytes=nbytes, pipe=self.pipes.get(name, 'f32'))
-    return out
+    durations = collections.OrderedDict(
+        (name, [max(s.elapsed_time(e) - ovh, 0.0) for s, e in evs]) for name, evs in self.events.items())
+    return aggregate(durations, self.costs, self.pipes)
+
+
+def _median(ms):
+  ms = sorted(ms)
+  return ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2])
+
+
+def aggregate(durations, costs, pipes=None):
+  """Per-region totals from per-CALL records (pure bookkeeping, no GPU: tests/test_bench_accounting.py).
+
+  durations[name] = [ms of call 0, ...]; costs[name] = [(flops, bytes) of call 0, ...].  One region name can cover calls
+  of different sizes (R2D2 runs each torso layer on 40 x B and on 81 x B frames): the calls are grouped by their
+  (flops, bytes), each group is priced at its own MEDIAN duration (one launch that catches a clock ramp, a page fault or
+  a first-use code-object load -- seen: 0.34 ms for a 15 us kernel -- must not re-rank the kernels), and the region
+  reports sums over the groups: total_ms, flops_total, bytes_total, and per-call AVERAGES avg_ms / flops / bytes, so that
+  flops / avg_ms == sum(flops) / sum(time).  (r4 kept the LAST call's flops and the median over ALL calls: cfg5's
+  conv layers were priced 1.34x too fast.)"""
+  out = collections.OrderedDict()
+  for name, ms in durations.items():
+    cs = costs[name]
+    assert len(cs) == len(ms), name
+    groups = collections.OrderedDict()
+    for d, c in zip(ms, cs):
+      groups.setdefault(tuple(c), []).append(d)
+    glist = [dict(calls=len(v), flops=k[0], bytes=k[1], med_ms=_median(v)) for k, v in groups.items()]
+    n = len(ms)
+    total = sum(g['med_ms'] * g['calls'] for g in glist)
+    fl, by = sum(g['flops'] * g['calls'] for g in glist), sum(g['bytes'] * g['calls'] for g in glist)
+    out[name] = dict(calls=n, total_ms=total, avg_ms=total / n, mean_ms=sum(ms) / n, flops=fl / n, bytes=by / n,
+                     flops_total=fl, bytes_total=by, groups=glist, pipe=(pipes or {}).get(name, 'f32'))
+  return out
 
 
 _PROFILER = None
@@ -83,7 +107,7 @@ def _region(name, flops=0, nbytes=0, pipe='f32'):
   yield
   e.record()
   p.events.setdefault(name, []).append((s, e))
-  p.meta[name] = (flops, nbytes)
+  p.costs.setdefault(name, []).append((flops, nbytes))
   p.pipes[name] = pipe() if callable(pipe) else pipe
 
 
@@ -91,8 +115,13 @@ def _conv_name(kind, g):
   return '%s[%dx%d/%d %d->%d @%dx%d]' % (kind, g.kh, g.kw, g.stride, g.cin, g.cout, g.ih, g.iw)
 
 
+def conv2d_pipe(g, which):
+  """seedhip_conv2d_pipe: 1 = fp32 MFMA, 6 = bf16 MFMA through the exact three-way split; which: 0 fwd, 1 dgrad, 2 wgrad."""
+  return int(_lib.lib().seedhip_conv2d_pipe(ctypes.byref(g), which))
+
+
 def _conv_pipe(g, which):
-  return 'bf16x6' if _lib.lib().seedhip_conv2d_pipe(ctypes.byref(g), which) == 6 else 'f32'
+  return 'bf16x6' if conv2d_pipe(g, which) == 6 else 'f32'
 
 
 def _stack_pipe():
@@ -163,11 +192,14 @@ def conv2d_bwd_data_bits_supported(g):
 def conv2d_bwd_data(g, dy, w, dx, relu_mask=None, add=None, relu_bits=None):
   """relu_bits (uint8, one byte per four input channels) replaces relu_mask where conv2d_bwd_data_bits_supported."""
   flops, nbytes = _conv_cost(g)
-  nbytes += 4 * g.n_img * g.ih * g.iw * g.cin * ((relu_mask is not None) + (add is not None))   # mask / accumulate reads
+  # ALGORITHMIC bytes: a ReLU mask is one BIT per element whatever tensor the kernel reads for it today (an fp32
+  # activation read for its sign is avoidable traffic and must not raise the floor); the skip-path add is 4 bytes
+  elems = g.n_img * g.ih * g.iw * g.cin
+  nbytes += (elems // 8 if relu_mask is not None else 0) + (4 * elems if add is not None else 0)
   if relu_bits is not None:
     if relu_mask is not None or add is not None:
       raise ValueError('conv2d_bwd_data: relu_bits excludes relu_mask / add')
-    with _region(_conv_name('conv_dgrad', g), flops, nbytes + g.n_img * g.ih * g.iw * g.cin // 4):
+    with _region(_conv_name('conv_dgrad', g), flops, nbytes + g.n_img * g.ih * g.iw * g.cin // 8):
       with _dev(dx):
         _lib.check(_lib.lib().seedhip_conv2d_bwd_data_bits(
             ctypes.byref(g), _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(relu_bits), _lib.stream()),

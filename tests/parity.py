@@ -49,14 +49,17 @@ def _truth_errs(agent, p32, p64, floor=1e-3):
   """Both fp32 evaluations against the fp64 evaluation of the same graph, per tensor as max and as 99th percentile of
   |g - g64| / max(max|g64|, floor); returns the worst tensor of each."""
   grads = agent.reference_gradients()
-  out = dict(hip_max=(0.0, None), hip_q99=(0.0, None), oracle_max=(0.0, None), oracle_q99=(0.0, None))
+  out = dict(hip_max=(0.0, None), hip_q99=(0.0, None), oracle_max=(0.0, None), oracle_q99=(0.0, None), gate=(0.0, None))
   for n, t64 in p64.items():
     r = t64.grad.numpy()
     den = max(float(np.abs(r).max()), floor)
     dh = np.abs(grads[n].cpu().numpy().astype(np.float64) - r) / den
     do = np.abs(p32[n].grad.numpy().astype(np.float64) - r) / den
-    for key, v in (('hip_max', dh.max()), ('hip_q99', np.quantile(dh, 0.99)), ('oracle_max', do.max()),
-                   ('oracle_q99', np.quantile(do, 0.99))):
+    hq, oq = float(np.quantile(dh, 0.99)), float(np.quantile(do, 0.99))
+    for key, v in (('hip_max', dh.max()), ('hip_q99', hq), ('oracle_max', do.max()), ('oracle_q99', oq),
+                   # the PER-TENSOR gate (VERDICT r4 task 7a): HIP's q99 distance to fp64 over (1.25 x the fp32 oracle's
+                   # + 5e-5); <= 1 means this tensor is as close to the truth as the fp32 oracle's, to a quarter
+                   ('gate', hq / (1.25 * oq + 5e-5))):
       if v >= out[key][0]:
         out[key] = (float(v), n)
   return out
@@ -79,6 +82,7 @@ def _truth(out, agent, p32, run64, floor=1e-3):
   out['grad_q99_rel_err_vs_fp64'], out['grad_q99_worst_vs_fp64'] = e['hip_q99']
   out['oracle_grad_max_rel_err_vs_fp64'], out['oracle_grad_worst_vs_fp64'] = e['oracle_max']
   out['oracle_grad_q99_rel_err_vs_fp64'] = e['oracle_q99'][0]
+  out['grad_q99_gate_vs_fp64'], out['grad_q99_gate_worst'] = e['gate']
   out['fp64_s'] = round(time.perf_counter() - t0, 2)
 
 

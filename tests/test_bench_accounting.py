@@ -27,6 +27,42 @@ def test_step_roofline_sums_per_kernel_floors():
   assert r['kernels']['a']['bound'] == 'hbm' and r['kernels']['b']['bound'] == 'mfma' and r['kernels']['d']['bound'] == 'hbm'
 
 
+def test_regions_with_calls_of_different_sizes_are_priced_per_call():
+  """R2D2 runs each torso layer on 40 x 256 and on 81 x 256 frames under ONE region name; the r4 profiler kept
+  the LAST call's flops and the median duration over ALL calls (cfg5's conv fraction came out 1.34x too high).  The
+  aggregation now prices each group of equally sized calls at its own median and reports sum(flops) / sum(time)."""
+  from seed_rl_amd import ops
+  small, big = (54.3e9, 100e6), (110.0e9, 200e6)            # (flops, bytes) of the 40- and 81-step calls
+  durations = {'conv': [0.40, 0.41, 0.80, 0.82, 9.9]}       # ms; the last one caught a page fault
+  costs = {'conv': [small, small, big, big, big]}
+  r = ops.aggregate(durations, costs, {'conv': 'bf16x6'})['conv']
+  assert r['calls'] == 5 and r['pipe'] == 'bf16x6'
+  want_ms = 2 * 0.405 + 3 * 0.82                           # medians per group: 0.405 and 0.82 (the outlier does not move it)
+  assert abs(r['total_ms'] - want_ms) < 1e-9
+  assert abs(r['flops_total'] - (2 * small[0] + 3 * big[0])) < 1 and abs(r['bytes_total'] - (2 * small[1] + 3 * big[1])) < 1
+  # the rate every consumer computes, flops / avg_ms, is sum(flops) / sum(time)
+  assert abs(r['flops'] / r['avg_ms'] - r['flops_total'] / r['total_ms']) < 1e-3
+  last_call_over_global_median = big[0] / 0.80             # what r4 reported
+  assert r['flops'] / r['avg_ms'] < 0.99 * last_call_over_global_median
+  # and the whole-step floor sums the groups' own floors (here: all MFMA-bound on bf16x6)
+  bench = importlib.import_module('bench')
+  fl = bench.step_roofline({'conv': r}, 5.0)
+  want = (2 * small[0] + 3 * big[0]) / (2500e12 / 6) * 1e3
+  assert abs(fl['floor_ms'] - want) < 1e-3, (fl['floor_ms'], want)
+  # a group can be HBM-bound while another of the same name is MFMA-bound: each takes its own maximum
+  mixed = ops.aggregate({'k': [1.0, 1.0]}, {'k': [(1e9, 630e6), (157.3e9, 1e6)]})['k']
+  fl = bench.step_roofline({'k': mixed}, 5.0)
+  assert abs(fl['floor_ms'] - (0.1 + 1.0)) < 1e-3, fl['floor_ms']
+
+
+def test_relu_mask_is_one_bit_per_element_in_the_algorithmic_bytes():
+  """a data gradient's ReLU mask counts 1 bit per element in the floor whatever tensor the kernel reads."""
+  import inspect
+  from seed_rl_amd import ops
+  src = inspect.getsource(ops.conv2d_bwd_data)
+  assert 'elems // 8 if relu_mask is not None' in src and '4 * elems if add is not None' in src
+
+
 def test_kernel_source_digest_tracks_the_sources(tmp_path, monkeypatch):
   from seed_rl_amd import build
   d0 = build.csrc_digest()

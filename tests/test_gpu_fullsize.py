@@ -49,7 +49,9 @@ def _check_params(r):
 
 def _check_grads_fp64(r):
   assert r['grad_q99_rel_err_vs_fp64'] <= 1e-3, _show(r)
-  assert r['grad_q99_rel_err_vs_fp64'] <= 3 * r['oracle_grad_q99_rel_err_vs_fp64'] + 1e-4, _show(r)
+  # per tensor: HIP's q99 distance to the fp64 evaluation <= 1.25 x the fp32 oracle's own + 5e-5 (r4: 3x + 1e-4 on the
+  # worst tensors only, three times looser than what was measured)
+  assert r['grad_q99_gate_vs_fp64'] <= 1.0, _show(r)
   assert r['grad_max_rel_err_vs_fp64'] <= 1e-2, _show(r)
   assert r['grad_max_rel_err'] <= 1.1 * (r['grad_max_rel_err_vs_fp64'] + r['oracle_grad_max_rel_err_vs_fp64']) + 1e-6, \
       _show(r)
@@ -123,9 +125,10 @@ def test_cfg3_dmlab_T20_B256(device):
   assert r['grad_max_rel_err_post_pool'] <= 2e-3, _show(r)
   assert r['grad_max_rel_err'] <= 1e-2, _show(r)
   if truth:
-    # the gate: against fp64 the HIP gradients may be no further away than 3x the fp32 oracle's own distance (+1e-4)
+    # the gate, PER TENSOR: against fp64 the HIP gradient's q99 distance may exceed the fp32 oracle's own by a quarter
+    # (+5e-5) at most (r4: 3x + 1e-4 on the worst tensors; measured 1.05x)
     assert r['grad_q99_rel_err_vs_fp64'] <= 1.5e-3, _show(r)
-    assert r['grad_q99_rel_err_vs_fp64'] <= 3 * r['oracle_grad_q99_rel_err_vs_fp64'] + 1e-4, _show(r)
+    assert r['grad_q99_gate_vs_fp64'] <= 1.0, _show(r)
     assert r['grad_max_rel_err_vs_fp64'] <= 1e-2, _show(r)
   _check_params(r)
 

@@ -680,6 +680,203 @@ def test_wsx_conv3x3_fp32_accuracy(device, n, h, w, mode):
   assert torch.equal(got, run())
 
 
+WGX_SHAPES = {                                             # name -> (ih, iw, cin, k, stride, padding, cout)
+    'atari2': (20, 20, 16, 4, 2, 'valid', 32), 'deep16': (36, 48, 16, 3, 1, 'same', 16), 'deep16x32': (36, 48, 16, 3, 1, 'same', 32),
+    'deep32a': (18, 24, 32, 3, 1, 'same', 32), 'deep32b': (9, 12, 32, 3, 1, 'same', 32)}
+
+
+def _wgrad_refs(x, dy, k, stride, padding, cout, in_relu):
+  """(dW, db) of conv2d(relu?(x), W) wrt W / bias at upstream gradient dy: torch fp32 and fp64, [kh, kw, cin, cout]."""
+  out = []
+  for dt in (torch.float32, torch.float64):
+    tx = torch.tensor(x).to(dt).permute(0, 3, 1, 2)
+    if in_relu: tx = F.relu(tx)
+    w = torch.zeros((cout, x.shape[3], k, k), dtype=dt, requires_grad=True)
+    y = F.conv2d(tx, w, None, stride=stride, padding=1 if padding == 'same' else 0)
+    tdy = torch.tensor(dy).to(dt).permute(0, 3, 1, 2)
+    y.backward(tdy)
+    out.append((w.grad.permute(2, 3, 1, 0).numpy().astype(np.float64), tdy.sum((0, 2, 3)).numpy().astype(np.float64)))
+  return out
+
+
+@pytest.mark.parametrize('name,n,in_relu', [('atari2', 33, False), ('atari2', 300, True), ('atari2', 1029, False), ('atari2', 10752, False),
+                                            ('deep16', 40, True), ('deep16', 259, False), ('deep16x32', 70, True), ('deep16x32', 300, False),
+                                            ('deep32a', 64, False), ('deep32a', 515, True), ('deep32b', 70, True), ('deep32b', 1300, False)])
+def test_wgx_weight_gradient_fp32_accuracy(device, name, n, in_relu):
+  """Weight gradients on the bf16 matrix pipe (wgx.h: exact three-way split of X and dY, six plane products, MFMA
+  operands by transposing LDS reads; second Atari conv and ImpalaDeep's 3x3 layers): as close to an fp64 evaluation as
+  torch's fp32 gradient is (max error <= 2x), dW and the bias gradient; one unit per workgroup up to long runs with a
+  ragged last workgroup, bands at the top / bottom of 'same'-padded images; bit-identical from call to call."""
+  from seed_rl_amd import ops
+  ih, iw, cin, k, stride, padding, cout = WGX_SHAPES[name]
+  rng = np.random.default_rng(n + ih)
+  g = ops.conv_geom(n, ih, iw, cin, k, k, stride, padding, cout)
+  x = rng.normal(size=(n, ih, iw, cin)).astype(np.float32)
+  dy = rng.normal(size=(n, g.oh, g.ow, cout)).astype(np.float32)
+  (w32, b32), (w64, b64) = _wgrad_refs(x, dy, k, stride, padding, cout, in_relu)
+  xd, dyd = dev(x, device), dev(dy, device)
+  ws = torch.empty(ops.conv2d_bwd_weight_workspace_bytes(g) // 4 + 4, device=device)
+
+  def run(fill):
+    dw = torch.full((k, k, cin, cout), fill, device=device); db = torch.full((cout,), fill, device=device)
+    ops.conv2d_bwd_weight(g, xd, dyd, dw, db, ws, in_relu=in_relu)
+    return dw, db
+  dw, db = run(7.0)
+  assert ops.conv2d_pipe(g, 2) == 6
+  for what, got, r32, r64 in (('dW', dw, w32, w64), ('db', db, b32, b64)):
+    e_hip = np.max(np.abs(got.cpu().numpy().astype(np.float64) - r64)); e_f32 = np.max(np.abs(r32 - r64))
+    print('wgx %s %s n=%d: err hip %.3e  torch fp32 %.3e  scale %.3e' % (name, what, n, e_hip, e_f32, np.abs(r64).max()))
+    assert e_hip <= max(2.0 * e_f32, 2e-6 * np.abs(r64).max()), (name, what, e_hip, e_f32)
+  dw2, db2 = run(-3.0)
+  assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize('name,n', [('atari2', 300), ('deep16', 64), ('deep32a', 96)])
+def test_wgx_weight_gradient_ill_conditioned(device, name, n):
+  """The same kernels on inputs a split into bf16 parts could get wrong: channels scaled by 2^+-40 (wide exponent
+  spread across the rows of dW), post-ReLU activations with 90 % zeros, a block of values below 2^-110 (the low parts
+  are bf16 subnormals / flush to zero: bounded by 2^-126 per product, invisible next to the fp32 reference's own
+  rounding), and non-finite inputs: an inf / NaN in X or dY must make exactly the entries of dW non-finite that
+  torch's fp32 gradient has non-finite."""
+  from seed_rl_amd import ops
+  ih, iw, cin, k, stride, padding, cout = WGX_SHAPES[name]
+  rng = np.random.default_rng(n)
+  g = ops.conv_geom(n, ih, iw, cin, k, k, stride, padding, cout)
+  x = rng.normal(size=(n, ih, iw, cin)).astype(np.float32)
+  x *= (rng.random(size=x.shape) < 0.1)                     # 90 % zeros
+  x *= np.exp2(rng.integers(-40, 41, size=cin)).astype(np.float32)
+  x[: n // 4, :, :, 0] = (rng.normal(size=(n // 4, ih, iw)) * 2.0 ** -115).astype(np.float32)
+  dy = rng.normal(size=(n, g.oh, g.ow, cout)).astype(np.float32)
+  dy *= np.exp2(rng.integers(-40, 41, size=cout)).astype(np.float32)
+  ws = torch.empty(ops.conv2d_bwd_weight_workspace_bytes(g) // 4 + 4, device=device)
+
+  def run(xa, dya):
+    dw = torch.full((k, k, cin, cout), 7.0, device=device); db = torch.full((cout,), 7.0, device=device)
+    ops.conv2d_bwd_weight(g, dev(xa, device), dev(dya, device), dw, db, ws)
+    return dw.cpu().numpy().astype(np.float64), db.cpu().numpy().astype(np.float64)
+  (w32, b32), (w64, b64) = _wgrad_refs(x, dy, k, stride, padding, cout, False)
+  dw, db = run(x, dy)
+  # per (input channel, output channel) block: the scales differ by up to 2^160 between blocks
+  for ci in range(cin):
+    for co in range(0, cout, 8):
+      blk = np.s_[:, :, ci, co:co + 8]
+      for j in range(8):
+        sl = (slice(None), slice(None), ci, co + j)
+        e_hip = np.max(np.abs(dw[sl] - w64[sl])); e_f32 = np.max(np.abs(w32[sl] - w64[sl]))
+        assert e_hip <= max(2.0 * e_f32, 2e-6 * np.abs(w64[sl]).max(), 1e-37), (name, ci, co + j, e_hip, e_f32)
+  # bias gradient: a plain sum of dY -- any fp32 summation order is within a few ulps of sum |dy| of the column
+  assert np.all(np.abs(db - b64) <= np.maximum(2.0 * np.abs(b32 - b64), 2e-7 * np.abs(dy.astype(np.float64)).sum((0, 1, 2))))
+  # non-finite inputs
+  xi, dyi = x.copy(), dy.copy()
+  xi[1, ih // 2, iw // 2, 3] = np.inf
+  xi[2, 0, 0, 5] = np.nan
+  dyi[3, g.oh - 1, g.ow - 1, 7] = -np.inf
+  # reference: the im2col evaluation with the zero padding as explicit zeros (0 * inf = NaN, which is what the kernel's
+  # zero-filled halo computes; torch's padded convolution skips out-of-image taps instead -- the two differ only in
+  # entries (tap, ci, co) whose tap leaves the image at a pixel where dY[., co] is non-finite: pinned here)
+  xp = np.pad(xi, ((0, 0), (1, 1), (1, 1), (0, 0))) if padding == 'same' else xi
+  (w32, b32), _ = _wgrad_refs(xp, dyi, k, stride, 'valid', cout, False)
+  dw, db = run(xi, dyi)
+  assert np.array_equal(np.isfinite(dw), np.isfinite(w32)), (np.sum(~np.isfinite(dw)), np.sum(~np.isfinite(w32)))
+  assert np.array_equal(np.isfinite(db), np.isfinite(b32))
+  if padding == 'same':                                   # ... and it is a superset of torch's own non-finite set
+    (t32, _), _ = _wgrad_refs(xi, dyi, k, stride, padding, cout, False)
+    assert not np.any(np.isfinite(dw) & ~np.isfinite(t32))
+
+
+def _ill_scale(rng, n):
+  return np.exp2(rng.integers(-40, 41, size=n)).astype(np.float32)
+
+
+def _col_check(name, got, r32, r64, axis_last=True):
+  """Per output column (last axis): |got - fp64| <= max(2 |torch fp32 - fp64|, 2e-6 max|fp64|) taken over the column --
+  the columns of an ill-scaled problem differ by up to 2^160, a whole-tensor maximum would only test the largest."""
+  g, a, b = (np.asarray(t, np.float64).reshape(-1, np.shape(t)[-1]) for t in (got, r32, r64))
+  e_hip, e_f32, sc = np.abs(g - b).max(0), np.abs(a - b).max(0), np.abs(b).max(0)
+  bad = e_hip > np.maximum(np.maximum(2.0 * e_f32, 2e-6 * sc), 1e-37)
+  assert not bad.any(), (name, np.nonzero(bad)[0][:8], e_hip[bad][:4], e_f32[bad][:4], sc[bad][:4])
+
+
+@pytest.mark.parametrize('kind', ['x6', 'x8', 'wfx', 'wdx', 'wsx_fwd', 'wsx_dg', 'wsy_fwd', 'wsy_dg'])
+def test_bf16x6_kernels_ill_conditioned(device, kind):
+  """VERDICT r4 task 7b.  Every kernel that evaluates fp32 x fp32 on the bf16 pipe through the three-way split, on inputs
+  the split could get wrong: input channels / output channels scaled by 2^+-40 (wide exponent spread across the
+  reduction AND across the outputs), post-ReLU activations with 90 % zeros, a block of values below 2^-110 (low parts
+  become bf16 subnormals), and non-finite inputs: the output must be non-finite exactly where torch's fp32 result is
+  (an inf splits into h = inf, m = inf - inf = NaN: non-finite either way; the zero halo of a 'same' layer is compared
+  with the explicit-zero-padding evaluation, in which 0 * inf = NaN like in the kernels' zero-filled LDS rows)."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(hash(kind) % 1000)
+  if kind in ('x6', 'x8'):
+    n, cin, cout = (2304, 1000, 256) if kind == 'x6' else (4224, 520, 264)
+    x = rng.normal(size=(n, cin)).astype(np.float32) * (rng.random(size=(n, cin)) < 0.1) * _ill_scale(rng, cin)
+    x[: n // 4, 0] = (rng.normal(size=n // 4) * 2.0 ** -115).astype(np.float32)
+    w = (rng.normal(size=(cin, cout)) / np.sqrt(cin)).astype(np.float32) * _ill_scale(rng, cout)
+    dy = rng.normal(size=(n, cout)).astype(np.float32) * _ill_scale(rng, cout)
+    g = ops.dense_geom(n, cin, cout)
+    ws = torch.empty(ops.conv2d_bwd_weight_workspace_bytes(g) // 4 + 4, device=device)
+
+    def run(xa, wa, dya):
+      xd, wd, dyd = dev(xa, device), dev(wa, device), dev(dya, device)
+      out = torch.empty((n, cout), device=device); dx = torch.empty((n, cin), device=device)
+      dw = torch.empty((cin, cout), device=device); db = torch.empty(cout, device=device)
+      ops.conv2d_fwd(g, xd, wd, None, out)
+      ops.conv2d_bwd_data(g, dyd, wd, dx)
+      ops.conv2d_bwd_weight(g, xd, dyd, dw, db, ws)
+      return [t.cpu().numpy() for t in (out, dx, dw)]
+
+    def ref(xa, wa, dya, dt):
+      tx, tw, tdy = (torch.tensor(a).to(dt) for a in (xa, wa, dya))
+      return [(tx @ tw).numpy(), (tdy @ tw.T).numpy(), (tx.T @ tdy).numpy()]
+    names = ('fwd', 'dgrad', 'wgrad')
+    inj = lambda xa, wa, dya: (xa.__setitem__((5, 7), np.inf), xa.__setitem__((9, 3), np.nan), dya.__setitem__((11, 2), -np.inf))
+    args = (x, w, dy)
+  else:
+    if kind in ('wfx', 'wdx'):
+      n, ih, iw, cin, k, stride, padding, cout = 300, 20, 20, 16, 4, 2, 'valid', 32
+    elif kind.startswith('wsx'):
+      n, ih, iw, cin, k, stride, padding, cout = 520, 18, 24, 32, 3, 1, 'same', 32
+    else:
+      n, ih, iw, cin, k, stride, padding, cout = 260, 36, 48, 16, 3, 1, 'same', 16
+    g = ops.conv_geom(n, ih, iw, cin, k, k, stride, padding, cout)
+    fwd = kind in ('wfx', 'wsx_fwd', 'wsy_fwd')
+    src_c, dst_c = (cin, cout) if fwd else (cout, cin)
+    shape = (n, ih, iw, cin) if fwd else (n, g.oh, g.ow, cout)
+    x = rng.normal(size=shape).astype(np.float32) * (rng.random(size=shape) < 0.1) * _ill_scale(rng, src_c)
+    x[: n // 4, :, :, 0] = (rng.normal(size=(n // 4,) + shape[1:3]) * 2.0 ** -115).astype(np.float32)
+    w = (rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    w = w * (_ill_scale(rng, cout) if fwd else _ill_scale(rng, cin)[:, None])
+    pad = 1 if padding == 'same' else 0
+
+    def run(xa, wa, _):
+      xd, wd = dev(xa, device), dev(wa, device)
+      out = torch.full((n, g.oh, g.ow, cout) if fwd else (n, ih, iw, cin), 7.0, device=device)
+      if fwd: ops.conv2d_fwd(g, xd, wd, None, out)
+      else: ops.conv2d_bwd_data(g, xd, wd, out)
+      return [out.cpu().numpy()]
+
+    def ref(xa, wa, _, dt, explicit_pad=False):
+      tx = torch.tensor(xa).to(dt).permute(0, 3, 1, 2); tw = torch.tensor(wa).to(dt).permute(3, 2, 0, 1)
+      if fwd:
+        if explicit_pad and pad:
+          return [F.conv2d(F.pad(tx, (1, 1, 1, 1)), tw, None, stride=stride).permute(0, 2, 3, 1).numpy()]
+        return [F.conv2d(tx, tw, None, stride=stride, padding=pad).permute(0, 2, 3, 1).numpy()]
+      return [F.conv_transpose2d(tx, tw, stride=stride, padding=pad).permute(0, 2, 3, 1).numpy()]
+    names = (kind,)
+    inj = lambda xa, wa, dya: (xa.__setitem__((1, shape[1] // 2, shape[2] // 2, 3), np.inf), xa.__setitem__((2, 0, 0, 5), np.nan),
+                               xa.__setitem__((3, shape[1] - 1, shape[2] - 1, 7), -np.inf))
+    args = (x, w, None)
+    assert ops.conv2d_pipe(g, 0 if fwd else 1) == 6
+  got, r32, r64 = run(*args), ref(*args, torch.float32), ref(*args, torch.float64)
+  for nm, a, b, c in zip(names, got, r32, r64):
+    _col_check(kind + ' ' + nm, a, b, c)
+  bad = tuple(None if a is None else a.copy() for a in args)
+  inj(*bad)
+  got, r32 = run(*bad), ref(*bad, torch.float32)
+  for nm, a, b in zip(names, got, r32):
+    assert np.array_equal(np.isfinite(a), np.isfinite(b)), (kind, nm, int((~np.isfinite(a)).sum()), int((~np.isfinite(b)).sum()))
+
+
 @pytest.mark.parametrize('n,cin,cout', [(4100, 520, 264), (4096, 2592, 256), (4224, 256, 1024)])   # (>= 4096 rows)
 def test_x8_gemm_epilogues_and_tails(device, n, cin, cout):
   """The 8-wave bf16x6 Dense kernels (xgemm8.h: 128 x 256 tiles, the small operand pre-split into k-tile slabs) on ragged

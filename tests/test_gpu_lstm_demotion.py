@@ -77,6 +77,40 @@ def test_aborted_replay_recaptures_the_graph(device, monkeypatch):
   assert int(agent._seq_sticky()[0]) == 0
 
 
+def test_two_graph_slots_over_one_agent_are_both_recaptured(device):
+  """LearnerServer keeps one GraphedStep per unroll slot over the SAME agent.  After a timeout in slot 0
+  the agent is demoted once; slot 1's graph still holds the sequence kernels and must be captured again as well (the
+  decision is taken from the agent's state, not from the one-shot return value of the check), and a sticky word set by
+  a pre-demotion graph is cleared instead of silently dropping every later update."""
+  from seed_rl_amd import learner, ops, smoke_step
+  if not ops.lstm_seq_supported(21, 32, 256):
+    pytest.skip('sequence kernels not available for this shape')
+  lrn, unroll0 = _mk(device, True)
+  agent = lrn.agent
+  unroll1 = smoke_step.make_deep_unroll(agent, 21, 32, 6, device, seed=4, done_p=0.2)
+  s0 = learner.GraphedStep(lrn, unroll0, warmup=2)
+  s1 = learner.GraphedStep(lrn, unroll1, warmup=1)
+  assert s0._captured_seq and s1._captured_seq
+  s0(); s1(); torch.cuda.synchronize()
+  agent._seq_sticky().fill_(1)                                # a sequence kernel of slot 0's replay "timed out"
+  p1 = agent.flat.params.clone()
+  s0(); torch.cuda.synchronize()
+  assert torch.equal(agent.flat.params, p1)
+  s0(); torch.cuda.synchronize()                              # sees the mirrored flag: demotes, re-captures slot 0
+  assert agent._seq_demoted and not s0._captured_seq
+  assert s1._captured_seq                                     # slot 1 still holds the sequence kernels ...
+  s1(); torch.cuda.synchronize()                              # ... until its next call
+  assert not s1._captured_seq
+  # a pre-demotion graph timing out again must not leave the guard set for ever
+  agent._seq_sticky().fill_(1)
+  s0(); torch.cuda.synchronize()                              # dropped
+  p2 = agent.flat.params.clone()
+  s1(); torch.cuda.synchronize()                              # flag seen (already demoted): cleared behind this step
+  s0(); torch.cuda.synchronize()
+  assert int(agent._seq_sticky()[0]) == 0
+  assert not torch.equal(agent.flat.params, p2), 'updates resume after the word is cleared'
+
+
 def test_sequence_kernel_beside_a_saturating_stream(device):
   """lstm_seq_fwd on one stream while another stream keeps every CU busy (what LearnerServer does: inference beside the
   train step).  The grid may or may not become co-resident in time; either the kernel finishes with the per-step

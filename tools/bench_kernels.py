@@ -51,6 +51,9 @@ def bench_stack(B, T1=21, cout=16):
          T1 * B * HW + out.numel() * 4)
 
 
+ONLY = None                                                # --only fwd|dgrad|wgrad
+
+
 def bench_conv(name, n, ih, iw, cin, k, s, padding, cout):
   dev = torch.device('cuda')
   g = ops.conv_geom(n, ih, iw, cin, k, k, s, padding, cout)
@@ -64,16 +67,22 @@ def bench_conv(name, n, ih, iw, cin, k, s, padding, cout):
   ws = torch.empty(ops.conv2d_bwd_weight_workspace_bytes(g) // 4 + 4, device=dev)
   fl = 2.0 * n * g.oh * g.ow * cout * k * k * cin
   by = (x.numel() + out.numel() + w.numel()) * 4
-  report(name + ' fwd', timeit(lambda: ops.conv2d_fwd(g, x, w, b, out, out_relu=True)), fl, by)
-  report(name + ' dgrad', timeit(lambda: ops.conv2d_bwd_data(g, dy, w, dx, relu_mask=x)), fl, by)
-  report(name + ' wgrad', timeit(lambda: ops.conv2d_bwd_weight(g, x, dy, dw, db, ws)), fl, by)
+  if ONLY in (None, 'fwd'):
+    report(name + ' fwd', timeit(lambda: ops.conv2d_fwd(g, x, w, b, out, out_relu=True)), fl, by)
+  if ONLY in (None, 'dgrad'):
+    report(name + ' dgrad', timeit(lambda: ops.conv2d_bwd_data(g, dy, w, dx, relu_mask=x)), fl, by)
+  if ONLY in (None, 'wgrad'):
+    report(name + ' wgrad', timeit(lambda: ops.conv2d_bwd_weight(g, x, dy, dw, db, ws)), fl, by)
 
 
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('what', nargs='?', default='all')
   ap.add_argument('--B', type=int, default=512)
+  ap.add_argument('--only', default=None, choices=['fwd', 'dgrad', 'wgrad'])
   a = ap.parse_args()
+  global ONLY
+  ONLY = a.only
   N = 21 * a.B
   if a.what in ('stack', 'all'):
     bench_stack(a.B)
