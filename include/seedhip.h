@@ -28,10 +28,11 @@ extern "C" {
 
 /* Bumped whenever an EXISTING entry point changes its signature or a *_workspace_bytes() contract changes (new entry
  * points alone do not bump it: a missing symbol already fails at load).  History: 1 = round 1; 2 = round 2
- * (seedhip_adam_flat*, seedhip_inference_pre/post signatures, impala-loss workspace size); 3 = round 3.
+ * (seedhip_adam_flat*, seedhip_inference_pre/post signatures, impala-loss workspace size); 3 = round 3; 4 = round 4;
+ * 5 = round 5 (seedhip_conv2d_stack_bwd_weight_fused* REMOVED: the fused pair lost to the two-call path).
  * Bindings must compare seedhip_abi_version() with the version they were written against before the first call
  * (seed_rl_amd/_lib.py does): a stale library would otherwise be called with shifted arguments. */
-#define SEEDHIP_ABI_VERSION 4
+#define SEEDHIP_ABI_VERSION 5
 
 const char* seedhip_last_error(void);
 int seedhip_abi_version(void);
@@ -223,21 +224,15 @@ int seedhip_conv2d_stack_fwd_bits_supported(const seedhip_stack_conv_geom* geom)
 int seedhip_conv2d_stack_fwd_bits(const seedhip_stack_conv_geom* geom, const uint8_t* frames_ext,
                                   const uint8_t* nvalid, const float* w, const float* bias, float* out,
                                   uint8_t* relu_bits, void* stream);
+/* r5: the same pair one layer up -- seedhip_conv2d_fwd_bits is seedhip_conv2d_fwd with out_relu = 1 (no residual) that
+ * also writes relu_bits [n_img * oh * ow, cout / 4] for the layer that consumes `out` (the shallow torso's Dense layer:
+ * seedhip_conv2d_bwd_data_bits also serves Dense geometries, relu_bits indexed like dx / 4 floats). */
+int seedhip_conv2d_fwd_bits_supported(const seedhip_conv_geom* geom);
+int seedhip_conv2d_fwd_bits(const seedhip_conv_geom* geom, const void* in, int in_dtype, int in_relu, const float* w,
+                            const float* bias, float* out, uint8_t* relu_bits, void* stream);
 int seedhip_conv2d_bwd_data_bits_supported(const seedhip_conv_geom* geom);
 int seedhip_conv2d_bwd_data_bits(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
                                  const uint8_t* relu_bits, void* stream);
-/* First conv's weight gradient FUSED with the second conv's data gradient (r3; shallow Atari torso Conv 8x8/4 x16 ->
- * ReLU -> Conv 4x4/2 x32): dw0 / dbias0 = seedhip_conv2d_stack_bwd_weight(g0, .., dy = relu_mask(act0) *
- * seedhip_conv2d_bwd_data(g1, dy1, w1)) without ever writing that dy -- a workgroup computes each frame's data gradient
- * from conv1's dy1 [T * B, 9, 9, 32] in LDS, masks it with act0 [T * B, 400, 16] > 0, splits it and feeds the weight
- * gradient.  Equal to the two-call path up to fp32 summation order.  Served for exactly that pair of geometries
- * (*_supported: 1 / 0); workspace from *_workspace_bytes; 16-byte aligned operands. */
-int seedhip_conv2d_stack_bwd_weight_fused_supported(const seedhip_stack_conv_geom* g0, const seedhip_conv_geom* g1);
-size_t seedhip_conv2d_stack_bwd_weight_fused_workspace_bytes(const seedhip_stack_conv_geom* g0);
-int seedhip_conv2d_stack_bwd_weight_fused(const seedhip_stack_conv_geom* g0, const seedhip_conv_geom* g1,
-                                          const uint8_t* frames_ext, const uint8_t* nvalid, const float* act0,
-                                          const float* dy1, const float* w1, float* dw0, float* dbias0,
-                                          void* workspace, size_t workspace_bytes, void* stream);
 size_t seedhip_conv2d_stack_bwd_weight_workspace_bytes(const seedhip_stack_conv_geom* geom);
 int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* geom, const uint8_t* frames_ext,
                                     const uint8_t* nvalid, const float* dy, float* dw, float* dbias,

@@ -15,7 +15,7 @@ import torch  # noqa: F401  pylint: disable=unused-import
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEEDHIP_LIB: another build of the same library (same-box A/B runs of two builds; nothing else changes: no fallback)
 LIB_PATH = os.environ.get('SEEDHIP_LIB') or os.path.join(_HERE, 'lib', 'libseedhip.so')
-ABI_VERSION = 4          # include/seedhip.h SEEDHIP_ABI_VERSION this binding was written against
+ABI_VERSION = 5          # include/seedhip.h SEEDHIP_ABI_VERSION this binding was written against
 
 c_int, c_ll, c_float, c_size_t, c_void_p = (
     ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p)
@@ -83,12 +83,10 @@ SIGNATURES = {
     'seedhip_conv2d_bwd_weight':
         (c_int, [ctypes.POINTER(ConvGeom), P, c_int, c_int, P, P, P, P, c_size_t, P]),
     'seedhip_conv2d_stack_fwd': (c_int, [ctypes.POINTER(StackConvGeom), P, P, P, P, P, c_int, P]),
-    'seedhip_conv2d_stack_bwd_weight_fused_supported': (c_int, [ctypes.POINTER(StackConvGeom), ctypes.POINTER(ConvGeom)]),
-    'seedhip_conv2d_stack_bwd_weight_fused_workspace_bytes': (c_size_t, [ctypes.POINTER(StackConvGeom)]),
-    'seedhip_conv2d_stack_bwd_weight_fused': (c_int, [ctypes.POINTER(StackConvGeom), ctypes.POINTER(ConvGeom), P, P, P, P, P, P, P,
-                                              P, c_size_t, P]),
     'seedhip_conv2d_stack_fwd_bits_supported': (c_int, [ctypes.POINTER(StackConvGeom)]),
     'seedhip_conv2d_stack_fwd_bits': (c_int, [ctypes.POINTER(StackConvGeom), P, P, P, P, P, P, P]),
+    'seedhip_conv2d_fwd_bits_supported': (c_int, [ctypes.POINTER(ConvGeom)]),
+    'seedhip_conv2d_fwd_bits': (c_int, [ctypes.POINTER(ConvGeom), P, c_int, c_int, P, P, P, P, P]),
     'seedhip_conv2d_bwd_data_bits_supported': (c_int, [ctypes.POINTER(ConvGeom)]),
     'seedhip_conv2d_bwd_data_bits': (c_int, [ctypes.POINTER(ConvGeom), P, P, P, P, P]),
     'seedhip_conv2d_stack_bwd_weight_workspace_bytes': (c_size_t, [ctypes.POINTER(StackConvGeom)]),

@@ -18,8 +18,6 @@
 #include "xgemm.h"
 #include "xgemm8.h"
 #include "wsgemm.h"
-#include "wsw.h"
-#include "wfw.h"
 #include "wfx.h"
 #include "wdx.h"
 #include "wsx.h"
@@ -266,6 +264,24 @@ extern "C" int seedhip_conv2d_fwd(const seedhip_conv_geom* geom, const void* in,
   return seedhip_conv2d_fwd_ws(geom, in, in_dtype, in_relu, w, bias, out, out_relu, residual, nullptr, 0, stream);
 }
 
+// out = relu(conv(relu?(in)) + bias) AND its ReLU mask as bytes [pixel][cout / 4] (bit r of byte q = out[pixel][4 q + r] > 0):
+// what seedhip_conv2d_bwd_data_bits of the NEXT layer reads instead of `out` (r5; served by wfx.h for its one geometry).
+extern "C" int seedhip_conv2d_fwd_bits_supported(const seedhip_conv_geom* geom) {
+  if (!geom || check_geom(geom, "conv2d_fwd_bits_supported") || !wfx_enabled()) return 0;
+  wfx::Params xp;
+  return wfx::plan(xp, geom) ? 1 : 0;
+}
+extern "C" int seedhip_conv2d_fwd_bits(const seedhip_conv_geom* geom, const void* in, int in_dtype, int in_relu,
+                                       const float* w, const float* bias, float* out, uint8_t* relu_bits, void* stream) {
+  int rc = check_geom(geom, "conv2d_fwd_bits"); if (rc) return rc;
+  SEEDHIP_REQUIRE(in && w && out && relu_bits, "conv2d_fwd_bits: null pointer");
+  wfx::Params xp;
+  if (!(wfx_enabled() && in_dtype == kInF32 && al16(in) && al16(w) && al16(out) && al16(bias) && wfx::plan(xp, geom)))
+    return fail(SEEDHIP_ERR_UNSUPPORTED, "conv2d_fwd_bits: geometry / alignment not served (ask seedhip_conv2d_fwd_bits_supported)");
+  xp.X = (const float*)in; xp.W = w; xp.bias = bias; xp.Y = out; xp.in_relu = in_relu; xp.out_relu = 1; xp.bits = relu_bits;
+  return wfx::launch(xp, (hipStream_t)stream);
+}
+
 extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* in, int in_dtype, int in_relu,
                                      const float* w, const float* bias, float* out, int out_relu,
                                      const float* residual, void* workspace, size_t workspace_bytes, void* stream) {
@@ -278,16 +294,6 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
     if (wfx_enabled() && in_dtype == kInF32 && !residual && al16(in) && al16(w) && al16(out) && al16(bias) && wfx::plan(xp, geom)) {
       xp.X = (const float*)in; xp.W = w; xp.bias = bias; xp.Y = out; xp.in_relu = in_relu; xp.out_relu = out_relu;
       const int rc2 = wfx::launch(xp, (hipStream_t)stream);
-      if (rc2 >= 0) return rc2;
-    }
-  }
-  {
-    // image-resident forward (wfw.h): the second Atari conv at training batch sizes
-    static const int wfw_on = getenv("SEEDHIP_WFW") ? atoi(getenv("SEEDHIP_WFW")) : 1;
-    wfw::Params fp;
-    if (wfw_on && in_dtype == kInF32 && !residual && al16(in) && al16(w) && al16(out) && al16(bias) && wfw::plan(fp, geom)) {
-      fp.X = (const float*)in; fp.W = w; fp.bias = bias; fp.Y = out; fp.in_relu = in_relu; fp.out_relu = out_relu;
-      const int rc2 = wfw::launch(fp, (hipStream_t)stream);
       if (rc2 >= 0) return rc2;
     }
   }
@@ -456,8 +462,18 @@ extern "C" int seedhip_conv2d_bwd_data(const seedhip_conv_geom* geom, const floa
 }
 
 // Data gradient with the ReLU mask as bytes (one per four input channels, written by seedhip_conv2d_stack_fwd_bits).
+// Dense data gradient with the byte mask: the bf16x6 kernel of xgemm.h, unsplit reduction only (the split-K epilogue
+// kernel reads the fp32 mask)
+static bool dense_bits_ok(const seedhip_conv_geom* g) {
+  if (!(xg::mode() & 2) || !is_dense(g)) return false;
+  const xg::Plan xp = x6_dgrad_plan(g);
+  return xp.ok && xp.slices == 1;
+}
+
 extern "C" int seedhip_conv2d_bwd_data_bits_supported(const seedhip_conv_geom* geom) {
-  if (!geom || check_geom(geom, "conv2d_bwd_data_bits_supported") || !(gemm_mode() & 16)) return 0;
+  if (!geom || check_geom(geom, "conv2d_bwd_data_bits_supported")) return 0;
+  if (dense_bits_ok(geom)) return 1;
+  if (!(gemm_mode() & 16)) return 0;
   wsgemm::Params wp;
   wsgemm::Plan pl = wsgemm::plan_dgrad(wp, geom);
   if (!pl.ok) return 0;
@@ -469,7 +485,27 @@ extern "C" int seedhip_conv2d_bwd_data_bits(const seedhip_conv_geom* geom, const
                                             const uint8_t* relu_bits, void* stream) {
   int rc = check_geom(geom, "conv2d_bwd_data_bits"); if (rc) return rc;
   SEEDHIP_REQUIRE(dy && w && dx && relu_bits, "conv2d_bwd_data_bits: null pointer");
-  SEEDHIP_REQUIRE((gemm_mode() & 16) && al16(dy) && al16(w) && al16(dx), "conv2d_bwd_data_bits: not served (ask seedhip_conv2d_bwd_data_bits_supported; 16-byte aligned operands)");
+  SEEDHIP_REQUIRE(al16(dy) && al16(w) && al16(dx), "conv2d_bwd_data_bits: operands must be 16-byte aligned");
+  if (dense_bits_ok(geom)) {
+    const xg::Plan xp = x6_dgrad_plan(geom);
+    const int M = geom->n_img, N = geom->cin, K = geom->cout;
+    gemm::Params gp;
+    memset(&gp, 0, sizeof(gp));
+    gp.A = dy; gp.lda = geom->ld_out; gp.B = w; gp.ldb = K; gp.M = M; gp.N = N; gp.K = K;
+    gp.C = dx; gp.ldc = geom->ld_in; gp.mask_bits = relu_bits;
+    xg::launch<true, true>(gp, xp, (hipStream_t)stream);
+    return check_launch("conv2d_bwd_data_bits(dense, bf16x6)");
+  }
+  SEEDHIP_REQUIRE(gemm_mode() & 16, "conv2d_bwd_data_bits: not served (ask seedhip_conv2d_bwd_data_bits_supported)");
+  {
+    // the second Atari conv at training batch sizes on the bf16 matrix pipe, the mask byte per 16 output bytes (wdx.h)
+    wdx::Params dp;
+    if (wdx_enabled() && wdx::plan(dp, geom)) {
+      dp.dY = dy; dp.W = w; dp.X = nullptr; dp.bits = relu_bits; dp.dX = dx;
+      const int rc2 = wdx::launch(dp, (hipStream_t)stream);
+      if (rc2 >= 0) return rc2;
+    }
+  }
   wsgemm::Params wp;
   wsgemm::Plan pl = wsgemm::plan_dgrad(wp, geom);
   if (!pl.ok) return fail(SEEDHIP_ERR_UNSUPPORTED, "conv2d_bwd_data_bits: geometry not served (ask seedhip_conv2d_bwd_data_bits_supported)");
@@ -691,13 +727,6 @@ extern "C" size_t seedhip_conv2d_bwd_weight_workspace_bytes(const seedhip_conv_g
     if (mm > need) need = mm;
   }
   if (xg8::mode() & 4) { const size_t w8 = x8_ws(x8_wgrad_plan(g), M, N, true); if (w8 > need) need = w8; }
-  {
-    wsw::Params wp;
-    if (wsw::plan(wp, g)) {
-      const size_t mm = (size_t)wsw::grid_for(g->n_img) * ((size_t)M * N + N) * sizeof(float);
-      if (mm > need) need = mm;
-    }
-  }
   if (const int k = wgx::plan(g)) {
     const size_t mm = (size_t)wgx::grid_for(k, g->n_img) * ((size_t)M * N + N) * sizeof(float);
     if (mm > need) need = mm;
@@ -724,21 +753,6 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
       rc = wgx::launch(k, geom, (const float*)in, in_relu, dy, pw, dbias ? pb : nullptr, &slices, s); if (rc) return rc;
       reduce_slices2(pw, (long long)M * N, dw, pb, N, dbias, slices, s);
       return check_launch("conv2d_bwd_weight(wgx)");
-    }
-  }
-  {
-    // streaming kernel (wsw.h): 64-float tap rows, 32 output channels -- the second Atari conv
-    static const int wsw_on = getenv("SEEDHIP_WSW") ? atoi(getenv("SEEDHIP_WSW")) : 1;
-    wsw::Params wp;
-    if (wsw_on && in_dtype == kInF32 && al16(in) && al16(dy) && al16(workspace) && wsw::plan(wp, geom)) {
-      const int M = geom->kh * geom->kw * geom->cin, N = geom->cout, slices = wsw::grid_for(geom->n_img);
-      hipStream_t s = (hipStream_t)stream;
-      float* pw = (float*)workspace;
-      float* pb = pw + (size_t)slices * M * N;
-      wp.X = (const float*)in; wp.dY = dy; wp.partial_w = pw; wp.partial_b = dbias ? pb : nullptr; wp.in_relu = in_relu;
-      rc = wsw::launch(wp, s); if (rc) return rc;
-      reduce_slices2(pw, (long long)M * N, dw, pb, N, dbias, slices, s);
-      return check_launch("conv2d_bwd_weight(wsw)");
     }
   }
   if (in_dtype == kInF32 && conv_wgrad_gemm_ok(geom) && al16(in) && al16(dy) && al16(workspace)) {
@@ -849,8 +863,3 @@ extern "C" int seedhip_conv2d_bwd_weight(const seedhip_conv_geom* geom, const vo
   reduce_slices2(p.partial_w, (long long)M * N, dw, p.partial_b, N, dbias, slices, s);
   return check_launch("conv2d_bwd_weight");
 }
-
-
-// Debug hook for tools/trace_x6.py: device buffer that xgemm_ws_kernel's probe builds (SEEDHIP_X6_WEXP & 128) fill with
-// s_memtime stamps of workgroup 0 ([4 roles][64 steps][8] 64-bit words).  Not part of the served API.
-extern "C" void seedhip_debug_x6_trace(void* device_buffer) { xg::trace_ptr() = (unsigned long long*)device_buffer; }

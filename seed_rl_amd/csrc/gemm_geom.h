@@ -43,6 +43,7 @@ struct Params {
   float* C; long long ldc;
   const float* bias; const float* residual; int out_relu;      // forward epilogue
   const float* mask; const float* add;                         // data-gradient epilogue (indexed like C)
+  const unsigned char* mask_bits;           // xgemm.h only (r5): the ReLU mask as bytes, indexed like C / 4 (bit r = element 4 q + r > 0)
   Gather ga, gb;                            // gathered operands (conv kernels below); unused by the Dense GEMMs
   int es, eih, eiw;                         // scatter epilogue (conv data gradient): stride, input map extents
 };

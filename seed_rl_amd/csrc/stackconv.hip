@@ -497,6 +497,9 @@ stackconv_fwd_bf16r_kernel(const Params p) {
       const_cast<uint8_t*>(p.frames_ext), 0, BUF ? (int)((long long)(3 + p.T1) * p.B * p.fsz) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t oview = __builtin_amdgcn_make_buffer_rsrc(
       p.out, 0, BUF ? (int)((long long)p.T1 * p.B * 400 * p.ld_out * 4) : 0, 0x00020000);
+  // BITS + BUF: the byte mask is indexed like out / 16 (one byte per lane's four channels)
+  const __amdgpu_buffer_rsrc_t bview = __builtin_amdgcn_make_buffer_rsrc(
+      p.relu_bits, 0, (BUF && BITS) ? (int)((long long)p.T1 * p.B * 400 * p.ld_out / 4) : 0, 0x00020000);
   const unsigned fv0 = 16u * (unsigned)lane, fv1 = lane + 64 < kBandVec ? 16u * (unsigned)(lane + 64) : 0x80000000u;
   unsigned ov[kMT];
 #pragma unroll
@@ -599,8 +602,16 @@ stackconv_fwd_bf16r_kernel(const Params p) {
         else *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         // the ReLU mask the next layer's data gradient needs, as one byte per lane (its four channels): that kernel then
         // reads 1 byte where it read the 16 of the activation (wsgemm.h, ws_tab_kernel<.., BITS>)
-        if (BITS)
-          p.relu_bits[(o - p.out) >> 2] = (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
+        if (BITS) {
+          // v is post-ReLU (v_med3 with +0 and +inf never returns -0): v > 0 <=> its bit pattern != 0; seven VALU
+          // instructions per quad (4 v_min_u32 + 3 v_lshl_or_b32) where compares + selects + ors were eleven
+          const su32x4_t bu = __builtin_bit_cast(su32x4_t, v);
+          const unsigned m01 = ((bu[1] < 1u ? bu[1] : 1u) << 1) | (bu[0] < 1u ? bu[0] : 1u);
+          const unsigned m23 = ((bu[3] < 1u ? bu[3] : 1u) << 1) | (bu[2] < 1u ? bu[2] : 1u);
+          const unsigned char mk = (unsigned char)((m23 << 2) | m01);
+          if (BUF) __builtin_amdgcn_raw_buffer_store_b8(mk, bview, ov[m] >> 4, oso >> 4, 0);
+          else p.relu_bits[(o - p.out) >> 2] = mk;
+        }
       }
     }
   }
@@ -932,259 +943,6 @@ stackconv_wgrad_cp_kernel(const Params p) {
 }
 
 // ------------------------------------------------------------------------------------ //
-// FUSED: second conv's data gradient -> ReLU mask -> exact bf16 split -> first conv's weight gradient, per frame.
-// (Shallow Atari torso: Conv 8x8/4 x16 -> ReLU -> Conv 4x4/2 x32; TF autodiff's Conv2DBackpropInput + ReluGrad +
-// Conv2DBackpropFilter of atari torso layers 2 -> 1.)  The first conv has no data gradient of its own, so the second
-// conv's dX [frames, 400, 16] (275 MB at cfg2: written once, read once, plus 275 MB of ReLU mask read by its producer)
-// exists only to be consumed by the weight gradient above.  Here a workgroup that walks one batch column over time
-//   phase A  computes the frame's dX from the 10 KB of conv1's dY (staged in LDS; super-pixel GEMM M = 100 (112),
-//            N = 4 parity classes x 16, K = 4 taps x 32 on v_mfma_f32_16x16x4_f32: wave = (class, half of the 7 row
-//            tiles), its 128 x 16 slice of W' in 32 REGISTERS for the whole launch), masks it with act0 > 0, splits it
-//            into three bf16 parts ONCE and leaves them in LDS as [part][channel][8-pixel chunk] -- the B operand
-//            layout of phase B;
-//   phase B  is stackconv_wgrad_cw_kernel's step with its dY fragments coming from LDS (three ds_read_b128 per group)
-//            instead of global loads + a split per wave.
-// Two barriers per frame; LDS 70.6 KB frame ring + 11.8 KB dY + 40.7 KB dX parts: one 8-wave workgroup per CU.
-// ------------------------------------------------------------------------------------ //
-constexpr int kYPix = 82, kYStride = 36;                 // conv1 dY pixels (81 + one all-zero pixel), floats per pixel in LDS
-constexpr int kDxChunks = 53;                            // 50 chunks + 3 zero chunks (the last group's lanes without a chunk)
-constexpr int kDxPart = 16 * kDxChunks * 16;             // bytes of one bf16 part: [channel 16][chunk][8 pixels]
-constexpr int kFusedLds = kFrameSlots * kFrame16 + kYPix * kYStride * 4 + 3 * kDxPart;
-
-struct FusedParams {
-  const uint8_t* frames_ext; const uint8_t* nvalid;
-  const float* dy1;                                      // [T1 * B, 9, 9, 32]
-  const float* w1;                                       // [4, 4, 16, 32]
-  const float* act0;                                     // [T1 * B, 400, 16]: ReLU mask = act0 > 0
-  float* partial_w; float* partial_b;                    // [grid][256 * 16], [grid][16]
-  int T1, B, fsz, spc, items;
-};
-
-template <int NT, int EXP, int NTM>                      // NT row tiles of this wave (NTM or NTM - 1)
-__device__ __forceinline__ void fused_phase_a(const unsigned char* ybytes, unsigned char* dxp, const float* mask_f,
-                                              const float (&wreg)[8][4], const int (&aoff)[NTM][4], const int (&moff)[NTM][4],
-                                              const int (&doff)[NTM][4], float& bsum) {
-  float mk[NT][4];
-#pragma unroll
-  for (int u = 0; u < NT; ++u)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) mk[u][r] = (EXP & 16) ? 1.f : *reinterpret_cast<const float*>(reinterpret_cast<const char*>(mask_f) + moff[u][r]);
-  f32x4_t acc[NT];
-#pragma unroll
-  for (int u = 0; u < NT; ++u) acc[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int tap = 0; tap < 4; ++tap)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      f32x4_t av[NT];
-#pragma unroll
-      for (int u = 0; u < NT; ++u) av[u] = *reinterpret_cast<const f32x4_t*>(ybytes + aoff[u][tap] + h * 64);
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-          if (EXP & 1) { if (s4 == 0) acc[u] += av[u]; }
-          else acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][s4], wreg[tap * 2 + h][s4], acc[u], 0, 0, 0);
-        }
-    }
-  if (EXP & 2) {
-#pragma unroll
-    for (int u = 0; u < NT; ++u) bsum += acc[u][0] + acc[u][1] + acc[u][2] + acc[u][3] + mk[u][0] + mk[u][1] + mk[u][2] + mk[u][3];
-    return;
-  }
-#pragma unroll
-  for (int u = 0; u < NT; ++u)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      // (rows 100 .. 111 of the last tile: their A rows are the zero pixel, so acc = 0 -- they add 0 to the bias sum and
-      // write zeros into a chunk nobody reads: no branch, no predicate)
-      const float v = mk[u][r] > 0.f ? acc[u][r] : 0.f;
-      bsum += v;
-      const uint32_t hb = __float_as_uint(v) & 0xFFFF0000u;              // exact three-way split (split3_pack)
-      const float r1 = v - __uint_as_float(hb);
-      const uint32_t mb = __float_as_uint(r1) & 0xFFFF0000u;
-      const uint32_t lb = __float_as_uint(r1 - __uint_as_float(mb));
-      unsigned char* d = dxp + doff[u][r];
-      *reinterpret_cast<unsigned short*>(d) = (unsigned short)(hb >> 16);
-      *reinterpret_cast<unsigned short*>(d + kDxPart) = (unsigned short)(mb >> 16);
-      *reinterpret_cast<unsigned short*>(d + 2 * kDxPart) = (unsigned short)(lb >> 16);
-    }
-}
-
-// NW waves per workgroup: 8 (two per SIMD, up to 256 VGPRs) or 16 (four per SIMD, 128 VGPRs: more waves to run while
-// one waits for LDS or sits at a barrier).  The row tiles of phase A and the pixel groups of phase B are dealt out over
-// NW / 4 partitions per parity class / stack channel.
-template <int EXP, int NW>                               // EXP != 0: timing probes that skip work (wrong results)
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
-stackconv_wgrad_fused_kernel(const FusedParams p) {
-  constexpr int kPart = NW / 4, NTM = (7 + kPart - 1) / kPart;   // partitions; row tiles of a partition (at most)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* ybytes = smem + kFrameSlots * kFrame16;
-  unsigned char* dxp = ybytes + kYPix * kYStride * 4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kq = lane >> 4, i = lane & 15;
-  constexpr int kVec = kIH * kIW / 16, kYVec = 81 * 32 / 4;       // 441 uint4 per frame, 648 per dY image
-
-  // ---- phase A: wave = (parity class, partition of the 7 row tiles) ----
-  const int ncls = wave & 3, cy = ncls >> 1, cx = ncls & 1, mpar = wave >> 2;
-  float wreg[8][4];                                       // W'[k = (tap, co)][n = (class, cin = i)]: k = 16 blk + 4 kq + s
-#pragma unroll
-  for (int blk = 0; blk < 8; ++blk) {
-    const int tap = blk >> 1, a = tap >> 1, b2 = tap & 1;
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
-      wreg[blk][s4] = p.w1[(((2 * a + cy) * 4 + (2 * b2 + cx)) * 16 + i) * 32 + 16 * (blk & 1) + 4 * kq + s4];
-  }
-  int aoff[NTM][4], moff[NTM][4], doff[NTM][4];
-#pragma unroll
-  for (int u = 0; u < NTM; ++u) {
-    const int mt = mpar + kPart * u;
-    {                                                     // A operand: data row m = 16 mt + i, its pixel under each tap
-      const int m = 16 * mt + i, sy = m / 10, sx = m - 10 * sy;
-#pragma unroll
-      for (int tap = 0; tap < 4; ++tap) {
-        const int y = sy - (tap >> 1), x = sx - (tap & 1);
-        const bool ok = m < 100 && y >= 0 && y < 9 && x >= 0 && x < 9;
-        aoff[u][tap] = (ok ? y * 9 + x : 81) * (kYStride * 4) + kq * 16;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {                         // D: rows m = 16 mt + 4 kq + r of column (class, cin = i)
-      const int m = 16 * mt + 4 * kq + r, sy = m / 10, sx = m - 10 * sy;
-      const int py = 2 * sy + cy, px = 2 * sx + cx;
-      const bool ok = m < 100;
-      moff[u][r] = ok ? ((py * kOW + px) * 16 + i) * 4 : 0;
-      doff[u][r] = ok ? (i * kDxChunks + (py >> 1) * 5 + (px >> 2)) * 16 + ((py & 1) * 4 + (px & 3)) * 2
-                      : (i * kDxChunks + 52) * 16;         // chunk 52: written (zeros), never read
-    }
-  }
-  // ---- phase B: wave = (stack channel, partition of the pixel groups), as stackconv_wgrad_cw_kernel ----
-  const int c = wave & 3, part = wave >> 2;
-  f32x4_t acc[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
-  // the zero pixel of dY and the zero chunks of the dX parts are written once and never touched again
-  for (int idx = tid; idx < kYStride; idx += 64 * NW) reinterpret_cast<float*>(ybytes)[81 * kYStride + idx] = 0.f;
-  for (int idx = tid; idx < 3 * 16 * 3 * 4; idx += 64 * NW) {
-    const int part = idx / (16 * 3 * 4), rem = idx - part * (16 * 3 * 4), n = rem / 12, w = rem - n * 12;
-    reinterpret_cast<uint32_t*>(dxp + part * kDxPart + (n * kDxChunks + 50) * 16)[w] = 0u;
-  }
-
-  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
-    const int b = item % p.B, chunk = item / p.B;
-    const int t0 = chunk * p.spc;
-    const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
-    __syncthreads();                                      // previous item's last step is done with the ring / dY / dX parts
-    for (int e = 0; e < 4; ++e) {                         // ext rows t0 .. t0+3 -> slots
-      const uint4* src = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t0 + e) * p.B + b) * p.fsz);
-      for (int idx = tid; idx < kVec; idx += 64 * NW) frame_store16(smem + ((t0 + e) % kFrameSlots) * kFrame16, src[idx], idx);
-    }
-    {
-      const uint4* ysrc = reinterpret_cast<const uint4*>(p.dy1 + ((long long)t0 * p.B + b) * (81 * 32));
-      for (int idx = tid; idx < kYVec; idx += 64 * NW)
-        *reinterpret_cast<uint4*>(ybytes + (idx >> 3) * (kYStride * 4) + (idx & 7) * 16) = ysrc[idx];
-    }
-    __syncthreads();
-    for (int t = t0; t < t1; ++t) {
-      const bool more = t + 1 < t1;
-      const int nv = nvalid_at(p.nvalid, (long long)t * p.B + b);
-      uint4 pf = make_uint4(0, 0, 0, 0), py0 = pf, py1 = pf;
-      if (more) {                                         // next step's frame and dY: in flight under this step's work
-        if (tid < kVec) pf = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t + 4) * p.B + b) * p.fsz)[tid];
-        const uint4* ysrc = reinterpret_cast<const uint4*>(p.dy1 + ((long long)(t + 1) * p.B + b) * (81 * 32));
-        py0 = ysrc[tid];
-        if (tid + 64 * NW < kYVec) py1 = ysrc[tid + 64 * NW];
-      }
-      if (nv > 0 && !(EXP & 8)) {
-        const float* mask_f = p.act0 + ((long long)t * p.B + b) * (400 * 16);
-        if ((7 - mpar + kPart - 1) / kPart == NTM) fused_phase_a<NTM, EXP, NTM>(ybytes, dxp, mask_f, wreg, aoff, moff, doff, bsum);
-        else fused_phase_a<NTM - 1, EXP, NTM>(ybytes, dxp, mask_f, wreg, aoff, moff, doff, bsum);
-      }
-      __syncthreads();                                    // the frame's dX parts are complete; dY is free
-      if (more) {
-        *reinterpret_cast<uint4*>(ybytes + (tid >> 3) * (kYStride * 4) + (tid & 7) * 16) = py0;
-        if (tid + 64 * NW < kYVec) {
-          const int idx = tid + 64 * NW;
-          *reinterpret_cast<uint4*>(ybytes + (idx >> 3) * (kYStride * 4) + (idx & 7) * 16) = py1;
-        }
-      }
-      if (c < nv && !(EXP & 4)) {
-        const unsigned char* frame = smem + ((t + 3 - c) % kFrameSlots) * kFrame16;
-        for (int g = part; g < kGroups32; g += kPart) {
-          const int ch = 4 * g + kq;                      // chunks 50, 51 (last group) read the zero chunks of the parts
-          const int cc = ch < kChunks ? ch : 0, rp = cc / 5, xc = cc - rp * 5;
-          const unsigned char* src = frame + ((8 * rp + (i >> 1)) * kIW + 16 * xc + 4 * (i & 1)) * 2;
-          Frag8 bf[3];
-#pragma unroll
-          for (int s3 = 0; s3 < 3; ++s3) bf[s3].u = *reinterpret_cast<const uint4*>(dxp + s3 * kDxPart + (i * kDxChunks + ch) * 16);
-          uint2 d[2][4];
-#pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb)
-              d[a][bb] = *reinterpret_cast<const uint2*>(src + (a * 4 * kIW + 4 * bb) * 2);
-          Frag8 xa[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const uint32_t sel = (q & 1) ? 0x07060302u : 0x05040100u;
-            if (q < 2)
-              xa[q].u = make_uint4(__builtin_amdgcn_perm(d[0][1].x, d[0][0].x, sel), __builtin_amdgcn_perm(d[0][3].x, d[0][2].x, sel),
-                                   __builtin_amdgcn_perm(d[1][1].x, d[1][0].x, sel), __builtin_amdgcn_perm(d[1][3].x, d[1][2].x, sel));
-            else
-              xa[q].u = make_uint4(__builtin_amdgcn_perm(d[0][1].y, d[0][0].y, sel), __builtin_amdgcn_perm(d[0][3].y, d[0][2].y, sel),
-                                   __builtin_amdgcn_perm(d[1][1].y, d[1][0].y, sel), __builtin_amdgcn_perm(d[1][3].y, d[1][2].y, sel));
-          }
-#pragma unroll
-          for (int s3 = 2; s3 >= 0; --s3)                   // lo, mid, hi; the four accumulators alternate
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[q].v, bf[s3].v, acc[q], 0, 0, 0);
-        }
-      }
-      if (more && tid < kVec) frame_store16(smem + ((t + 4) % kFrameSlots) * kFrame16, pf, tid);   // a slot no wave reads in step t
-      __syncthreads();                                    // every wave is done with the dX parts; frame t+4 and dY t+1 visible
-    }
-  }
-
-  // ---- the partitions of a channel -> one tile (partitions 1.. through LDS, fixed order), straight into the partial slice ----
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);            // [part - 1][c][q][lane][4]: at most 48 KB of the ring
-  if (part > 0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4_t*>(red + ((((part - 1) * 4 + c) * 4 + q) * 64 + lane) * 4) = acc[q];
-  }
-  __syncthreads();
-  if (part == 0) {
-    float* pw = p.partial_w + (long long)blockIdx.x * 256 * 16;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4_t o = acc[q];
-#pragma unroll
-      for (int pp = 0; pp < kPart - 1; ++pp) o += *reinterpret_cast<const f32x4_t*>(red + (((pp * 4 + c) * 4 + q) * 64 + lane) * 4);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 4 * kq + r;                       // k-row within the m-tile
-        const int ky = row >> 1, kx = 4 * (row & 1) + q;
-        pw[((ky * 8 + kx) * 4 + c) * 16 + i] = o[r] / 255.0f;
-      }
-    }
-  }
-  // bias gradient: every wave holds the sum over ITS (class, row tiles) of channel i in its four kq lane groups
-  bsum += __shfl_xor(bsum, 16, 64);
-  bsum += __shfl_xor(bsum, 32, 64);
-  float* redb = red + (kPart - 1) * 16 * 64 * 4;
-  if (lane < 16) redb[wave * 16 + lane] = bsum;
-  __syncthreads();
-  if (tid < 16) {
-    float sum = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) sum += redb[w * 16 + tid];
-    p.partial_b[(long long)blockIdx.x * 16 + tid] = sum;
-  }
-}
-
-// ------------------------------------------------------------------------------------ //
 // Host side: eligibility, work decomposition, launch.
 // ------------------------------------------------------------------------------------ //
 bool eligible(const seedhip_stack_conv_geom* g, const void* frames_ext, const void* io) {
@@ -1254,7 +1012,7 @@ int launch_fwd(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, cons
     static const int buf_on = getenv("SEEDHIP_STACK_BUF") ? atoi(getenv("SEEDHIP_STACK_BUF")) : 1;
     const long long lim = (1LL << 31) - (1 << 20);
     p.buf32 = buf_on && (long long)(3 + p.T1) * p.B * p.fsz < lim && (long long)p.T1 * p.B * 400 * p.ld_out * 4 < lim;
-    if (relu_bits) SEEDHIP_SCF(true, true, false)
+    if (relu_bits) { if (p.buf32) SEEDHIP_SCF(true, true, true) else SEEDHIP_SCF(true, true, false) }
     if (p.buf32) { if (out_relu) SEEDHIP_SCF(false, true, true) else SEEDHIP_SCF(false, false, true) }
     if (out_relu) SEEDHIP_SCF(false, true, false)
     SEEDHIP_SCF(false, false, false)
@@ -1354,62 +1112,6 @@ extern "C" int seedhip_conv2d_stack_fwd_bits(const seedhip_stack_conv_geom* geom
         (!bias || (((uintptr_t)bias) & 15) == 0)))
     return fail(SEEDHIP_ERR_UNSUPPORTED, "conv2d_stack_fwd_bits: geometry / alignment not served (ask seedhip_conv2d_stack_fwd_bits_supported)");
   return stackconv::launch_fwd(geom, frames_ext, nvalid, w, bias, out, 1, (hipStream_t)stream, relu_bits);
-}
-
-// First conv's weight gradient fused with the second conv's data gradient (seedhip.h).
-extern "C" int seedhip_conv2d_stack_bwd_weight_fused_supported(const seedhip_stack_conv_geom* g0, const seedhip_conv_geom* g1) {
-  if (!g0 || !g1) return 0;
-  return g0->kh == 8 && g0->kw == 8 && g0->stride == 4 && g0->ih == stackconv::kIH && g0->iw == stackconv::kIW &&
-         g0->oh == 20 && g0->ow == 20 && g0->cout == 16 && g0->ld_out == 16 && stackconv::bf16x3_enabled() &&
-         g1->n_img == g0->T * g0->B && g1->ih == 20 && g1->iw == 20 && g1->cin == 16 && g1->ld_in == 16 && g1->kh == 4 &&
-         g1->kw == 4 && g1->stride == 2 && g1->pad_t == 0 && g1->pad_l == 0 && g1->oh == 9 && g1->ow == 9 &&
-         g1->cout == 32 && g1->ld_out == 32 && (long long)g0->T * g0->B * 400 * 16 < (1LL << 31);
-}
-
-extern "C" size_t seedhip_conv2d_stack_bwd_weight_fused_workspace_bytes(const seedhip_stack_conv_geom* g0) {
-  if (!g0) return 0;
-  int spc, items, grid;
-  stackconv::decompose(g0->T, g0->B, stackconv::max_grid_for(1), &spc, &items, &grid);
-  return (size_t)grid * (256 * 16 + 16) * sizeof(float);
-}
-
-extern "C" int seedhip_conv2d_stack_bwd_weight_fused(const seedhip_stack_conv_geom* g0, const seedhip_conv_geom* g1,
-                                                     const uint8_t* frames_ext, const uint8_t* nvalid,
-                                                     const float* act0, const float* dy1, const float* w1, float* dw0,
-                                                     float* dbias0, void* workspace, size_t workspace_bytes,
-                                                     void* stream) {
-  int rc = check_stack(g0, "conv2d_stack_bwd_weight_fused"); if (rc) return rc;
-  SEEDHIP_REQUIRE(seedhip_conv2d_stack_bwd_weight_fused_supported(g0, g1),
-                  "conv2d_stack_bwd_weight_fused: geometry not served (ask seedhip_conv2d_stack_bwd_weight_fused_supported)");
-  SEEDHIP_REQUIRE(frames_ext && nvalid && act0 && dy1 && w1 && dw0 && dbias0 && workspace, "conv2d_stack_bwd_weight_fused: null pointer");
-  SEEDHIP_REQUIRE(((((uintptr_t)frames_ext) | ((uintptr_t)dy1) | ((uintptr_t)act0) | ((uintptr_t)workspace)) & 15) == 0,
-                  "conv2d_stack_bwd_weight_fused: operands must be 16-byte aligned");
-  SEEDHIP_REQUIRE(workspace_bytes >= seedhip_conv2d_stack_bwd_weight_fused_workspace_bytes(g0),
-                  "conv2d_stack_bwd_weight_fused: workspace too small");
-  hipStream_t s = (hipStream_t)stream;
-  stackconv::FusedParams p;
-  memset(&p, 0, sizeof(p));
-  p.frames_ext = frames_ext; p.nvalid = nvalid; p.dy1 = dy1; p.w1 = w1; p.act0 = act0;
-  p.T1 = g0->T; p.B = g0->B; p.fsz = g0->ih * g0->iw;
-  int grid;
-  stackconv::decompose(p.T1, p.B, stackconv::max_grid_for(1), &p.spc, &p.items, &grid);
-  p.partial_w = (float*)workspace;
-  p.partial_b = (float*)workspace + (size_t)grid * 256 * 16;
-  // (EXP != 0 instances of the kernel are leave-one-out timing probes with WRONG results: the library only has EXP = 0)
-  // measured (same box): 8 waves 348 us, 16 waves 405 us (15 spilled VGPRs at the 128 cap, 16-wave barriers), the two-kernel path 300
-  static const int nw = getenv("SEEDHIP_FUSE_WAVES") ? atoi(getenv("SEEDHIP_FUSE_WAVES")) : 8;
-  if (nw == 8) {
-    (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_fused_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)stackconv::kFusedLds);
-    hipLaunchKernelGGL((stackconv::stackconv_wgrad_fused_kernel<0, 8>), dim3(grid), dim3(512), stackconv::kFusedLds, s, p);
-  } else {
-    (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_fused_kernel<0, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)stackconv::kFusedLds);
-    hipLaunchKernelGGL((stackconv::stackconv_wgrad_fused_kernel<0, 16>), dim3(grid), dim3(1024), stackconv::kFusedLds, s, p);
-  }
-  rc = check_launch("stackconv_wgrad_fused_kernel"); if (rc) return rc;
-  reduce_slices2(p.partial_w, 256LL * 16, dw0, p.partial_b, 16, dbias0, grid, s);
-  return check_launch("conv2d_stack_bwd_weight_fused");
 }
 
 extern "C" size_t seedhip_conv2d_stack_bwd_weight_workspace_bytes(const seedhip_stack_conv_geom* g) {

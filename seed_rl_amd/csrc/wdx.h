@@ -28,7 +28,6 @@
 #pragma once
 #include <type_traits>
 #include "wfx.h"
-#include "wsw.h"
 
 namespace seedhip {
 namespace wdx {
@@ -53,7 +52,8 @@ constexpr unsigned kOut = 0x80000000u;
 
 struct Params {
   const float* dY; const float* W; const float* X; float* dX;
-  int n_img, per_wg;
+  const unsigned char* bits;              // r5: the ReLU mask as bytes [pixel][cin / 4], bit r of byte q = X[pixel][4 q + r] > 0
+  int n_img, per_wg;                      //     (seedhip_conv2d_stack_fwd_bits): 17 MB at cfg2 where X is 275 MB
 };
 
 template <int N>
@@ -75,8 +75,10 @@ __device__ __forceinline__ int end_row(int r, int total, int rows) {
   return e < rows ? e : rows;
 }
 
-// EXP (timing experiments only, results wrong): 1 no split / LDS writes, 2 no row loads, 4 no MFMAs, 8 no output path
-template <bool MASK, int EXP = 0>
+// MASK: 0 none, 1 the fp32 activation read for its sign (by LDS-DMA), 2 the byte mask (one byte per lane and piece, straight
+// into a register a round ahead).  EXP (timing experiments only, results wrong; not instantiated by the library):
+// 1 no split / LDS writes, 2 no row loads, 4 no MFMAs, 8 no output path
+template <int MASK, int EXP = 0>
 __global__ void __launch_bounds__(512, 2)
 wdx_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -91,8 +93,11 @@ wdx_kernel(const Params p) {
   const int total = nimg * kSP, rows = nimg * kPR;
   const int rounds = (total + kRound - 1) / kRound;
   const sgpr128_t yd = xg::make_view_words(p.dY + (long long)img0 * (81 * 32), (long long)nimg * (81 * 32 * 4));
-  const __amdgpu_buffer_rsrc_t xv = wsw::view(MASK ? p.X + (long long)img0 * 6400 : p.dX, (long long)nimg * 25600);
-  const __amdgpu_buffer_rsrc_t ov = wsw::view(p.dX + (long long)img0 * 6400, (long long)nimg * 25600);
+  const __amdgpu_buffer_rsrc_t xv = gemm::make_view(MASK == 1 ? p.X + (long long)img0 * 6400 : p.dX, (long long)nimg * 25600);
+  const sgpr128_t bv = xg::make_view_words(reinterpret_cast<const float*>(MASK == 2 ? p.bits + (long long)img0 * 1600 : (const unsigned char*)p.dX),
+                                           (long long)nimg * 1600);
+  unsigned mb[4] = {0u, 0u, 0u, 0u};                         // MASK == 2: the lane's mask byte of piece j
+  const __amdgpu_buffer_rsrc_t ov = gemm::make_view(p.dX + (long long)img0 * 6400, (long long)nimg * 25600);
 
   // ---- weights: step s = 4 dy + 2 dx + c: W[py + 2 dy][px + 2 dx][ci][16 c + 8 kq + e], e = 0..7 ------------------ //
   bf16x8_t wh[8], wm[8], wl[8];
@@ -170,13 +175,26 @@ wdx_kernel(const Params p) {
     typedef __attribute__((address_space(3))) void lds_void_t;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(xv, (lds_void_t*)(msk + j * 1024), 16, oofs[j], 0, 0, 0);
   };
+  // the byte of the lane's 16 output bytes: the mask is indexed like dX / 16
+  // (an asm load like the row items': with the builtin hipcc guards the re-used register with counted waits that also
+  // wait for the output stores in flight -- vmcnt(1) in front of the fourth request -- and drains the queue at every
+  // step of the first round; the wave's own full wait at the head of its memory phase covers these loads)
+  auto bits_request = [&](int j) {
+    const unsigned voff = oofs[j] == kOut ? kOut : oofs[j] >> 4;
+    asm volatile("buffer_load_ubyte %0, %1, %2, 0 offen" : "=v"(mb[j]) : "v"(voff), "s"(bv));
+  };
+  auto bits_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(mb[0]), "+v"(mb[1]), "+v"(mb[2]), "+v"(mb[3])); };
   auto out_piece = [&](int j) {                              // 8 super-pixels = 1 KB of consecutive addresses
     const int spl = 8 * j + (lane >> 3);
     f32x4_t v = *reinterpret_cast<const f32x4_t*>(blk + spl * 128 + (((lane & 7) ^ (spl & 7)) << 4));
-    if (MASK) {
+    if (MASK == 1) {
       const f32x4_t mk = *reinterpret_cast<const f32x4_t*>(msk + j * 1024 + lane * 16);
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = mk[q] > 0.f ? v[q] : 0.f;
+    }
+    if (MASK == 2) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = ((mb[j] >> q) & 1u) ? v[q] : 0.f;
     }
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ov, oofs[j], 0, 0);
   };
@@ -222,7 +240,7 @@ wdx_kernel(const Params p) {
       const bf16x8_t (&x)[3] = xb[s & 1];
       const int j = s & 3;
       const bool mine = (s >> 2) == ph;
-      if (mine && j == 0) wait_set<0>(wr);
+      if (mine && j == 0) { wait_set<0>(wr); if (MASK == 2) bits_wait(); }
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[s], x[0], acc, 0, 0, 0);
       if (mine && !(EXP & 2)) issue1(nx, hi1, hi2, j);
       WDX_SB
@@ -242,7 +260,8 @@ wdx_kernel(const Params p) {
           // this step of the previous round), then the same slot takes the mask of THIS round's tile
           if (r > 0) out_piece(j);
           out_offset(r, j);
-          if (MASK) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); mask_request(j); }
+          if (MASK == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); mask_request(j); }
+          if (MASK == 2) bits_request(j);
         }
       }
     }
@@ -273,16 +292,21 @@ wdx_kernel(const Params p) {
   // the last round's outputs (all four pieces read before the first store: a 16-byte store's data registers are not
   // handed to the next read at once, tools/isa_store_hazard.py)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (MASK == 2) bits_wait();
   if (!(EXP & 8)) {
     f32x4_t v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int spl = 8 * j + (lane >> 3);
       v[j] = *reinterpret_cast<const f32x4_t*>(blk + spl * 128 + (((lane & 7) ^ (spl & 7)) << 4));
-      if (MASK) {
+      if (MASK == 1) {
         const f32x4_t mk = *reinterpret_cast<const f32x4_t*>(msk + j * 1024 + lane * 16);
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[j][q] = mk[q] > 0.f ? v[j][q] : 0.f;
+      }
+      if (MASK == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[j][q] = ((mb[j] >> q) & 1u) ? v[j][q] : 0.f;
       }
       asm volatile("" : "+v"(v[j]));
     }
@@ -296,7 +320,7 @@ inline bool plan(Params& p, const seedhip_conv_geom* g) {
   if (g->pad_t || g->pad_l || g->kh != 4 || g->kw != 4 || g->stride != 2 || g->cin != 16 || g->cout != 32 || g->ld_in != 16 ||
       g->ld_out != 32 || g->ih != 20 || g->iw != 20 || g->oh != 9 || g->ow != 9)
     return false;
-  static const int min_img = xg::env_int("SEEDHIP_WDX_MIN", 256);      // faster than the fp32 kernels from inference batches on (273 images: 9.9 vs 12.7 us forward)
+  constexpr int min_img = 256;      // faster than the fp32 kernels from inference batches on (273 images: 9.9 vs 12.7 us forward)
   if (g->n_img < min_img) return false;
   memset(&p, 0, sizeof(p));
   p.n_img = g->n_img;
@@ -307,22 +331,12 @@ inline int launch(Params& p, hipStream_t s) {
   static const int cus = xg::cu_count();
   p.per_wg = (p.n_img + cus - 1) / cus;
   const int grid = (p.n_img + p.per_wg - 1) / p.per_wg;
-  static const int ex = xg::env_int("SEEDHIP_WDX_EXP", 0);
-  if (ex == 16) p.X = nullptr;                               // (timing: no mask)
-#define WDX_EXP(E_) if (ex == E_ && p.X) { \
-    if (hipFuncSetAttribute((const void*)wdx_kernel<true, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return -1; \
-    hipLaunchKernelGGL((wdx_kernel<true, E_>), dim3(grid), dim3(512), kLds, s, p); return check_launch("wdx_kernel(exp)"); }
-  WDX_EXP(8) WDX_EXP(11)
-#undef WDX_EXP
-  if (p.X) {
-    static const bool ok = hipFuncSetAttribute((const void*)wdx_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
-    if (!ok) return -1;
-    hipLaunchKernelGGL((wdx_kernel<true>), dim3(grid), dim3(512), kLds, s, p);
-  } else {
-    static const bool ok = hipFuncSetAttribute((const void*)wdx_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
-    if (!ok) return -1;
-    hipLaunchKernelGGL((wdx_kernel<false>), dim3(grid), dim3(512), kLds, s, p);
-  }
+#define WDX_GO(M_) { \
+    static const bool ok = hipFuncSetAttribute((const void*)wdx_kernel<M_>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess; \
+    if (!ok) return -1; \
+    hipLaunchKernelGGL((wdx_kernel<M_>), dim3(grid), dim3(512), kLds, s, p); }
+  if (p.bits) WDX_GO(2) else if (p.X) WDX_GO(1) else WDX_GO(0)
+#undef WDX_GO
   return check_launch("wdx_kernel");
 }
 

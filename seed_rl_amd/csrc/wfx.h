@@ -66,7 +66,8 @@ constexpr unsigned kOut = 0x80000000u;
 struct Params {
   const float* X; const float* W; const float* bias; float* Y;
   int n_img, per_wg, in_relu, out_relu;
-  unsigned long long* trace;              // SEEDHIP_WFX_TRACE: [workgroup][8 waves][32 rounds][8 stamps]
+  unsigned long long* trace;              // (TRACE builds only: [workgroup][8 waves][32 rounds][8 stamps])
+  unsigned char* bits;                    // r5, optional (needs out_relu): [pixel][8] bytes, bit r of byte q = Y[pixel][4 q + r] > 0
 };
 
 __device__ __forceinline__ f32x4_t load16(const sgpr128_t& d, unsigned voff, unsigned soff) {
@@ -201,8 +202,9 @@ wfx_kernel(const Params p) {
   // go back into the block as [pixel][32 channels] rows (16-byte chunk c of pixel x at chunk c ^ (x & 7)); the wave
   // stores them at the END of its round, 1 KB of consecutive addresses per instruction -- behind the round's counted
   // waits, which a pending store would stretch (stores and loads share vmcnt and do not retire in order).
-  auto finish = [&]() {
+  auto finish = [&](int rr) {                                // rr: the round whose tile is being finished
     if (kh == 0) {
+      const int Pf = kRound * rr + 32 * tile + px;
       f32x4_t q4[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) q4[g] = *reinterpret_cast<const f32x4_t*>(part + g * 1024);
@@ -215,6 +217,12 @@ wfx_kernel(const Params p) {
           v[q] = p.out_relu ? __builtin_amdgcn_fmed3f(y, 0.f, __builtin_inff()) : y;
         }
         *reinterpret_cast<f32x4_t*>(blk + px * 128 + (((2 * g + kq) ^ (px & 7)) << 4)) = v;
+        if (p.bits && Pf < total) {                          // the next layer's data gradient reads this byte instead of the 16
+          const u32x4_t bu = __builtin_bit_cast(u32x4_t, v);  // (post-ReLU: > 0 <=> bit pattern != 0, see stackconv.hip)
+          const unsigned m01 = ((bu[1] < 1u ? bu[1] : 1u) << 1) | (bu[0] < 1u ? bu[0] : 1u);
+          const unsigned m23 = ((bu[3] < 1u ? bu[3] : 1u) << 1) | (bu[2] < 1u ? bu[2] : 1u);
+          p.bits[((long long)img0 * kP + Pf) * 8 + 2 * g + kq] = (unsigned char)((m23 << 2) | m01);
+        }
       }
     }
   };
@@ -250,7 +258,7 @@ wfx_kernel(const Params p) {
     };
     fetch(xb[0], 0);                                         // operands are requested two taps ahead (three buffers)
     fetch(xb[1], 1);
-    if (r > 0) finish();
+    if (r > 0) finish(r - 1);
     acc = acc0;
     stamp(r, 1);
 #define WFX_SB __builtin_amdgcn_sched_barrier(0);
@@ -301,7 +309,7 @@ wfx_kernel(const Params p) {
     round(r, ld[1], ld[0]);
     if (r + 1 < rounds) round(r + 1, ld[0], ld[1]);
   }
-  finish();
+  finish(rounds - 1);
   if (kh == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { out_read(i); out_store(rounds - 1, i); }
@@ -313,7 +321,7 @@ inline bool plan(Params& p, const seedhip_conv_geom* g) {
   if (g->pad_t || g->pad_l || g->kh != 4 || g->kw != 4 || g->stride != 2 || g->cin != 16 || g->cout != 32 || g->ld_in != 16 ||
       g->ld_out != 32 || g->ih != kIH || g->iw != kIW || g->oh != kOW || g->ow != kOW)
     return false;
-  static const int min_img = xg::env_int("SEEDHIP_WFX_MIN", 256);      // faster than the fp32 kernels from inference batches on (273 images: 9.9 vs 12.7 us forward)
+  constexpr int min_img = 256;      // faster than the fp32 kernels from inference batches on (273 images: 9.9 vs 12.7 us forward)
   if (g->n_img < min_img) return false;
   memset(&p, 0, sizeof(p));
   p.n_img = g->n_img;
@@ -325,39 +333,6 @@ inline int launch(Params& p, hipStream_t s) {
   p.per_wg = (p.n_img + cus - 1) / cus;
   const int grid = (p.n_img + p.per_wg - 1) / p.per_wg;
   constexpr int kBytes = kLds + kPart;
-  static const int trace = xg::env_int("SEEDHIP_WFX_TRACE", 0);
-  if (trace && !p.in_relu) {                                 // per-round cycle stamps of two workgroups, to stderr
-    static unsigned long long* buf = nullptr;
-    const size_t n = (size_t)grid * 8 * 256;
-    if (!buf && hipMalloc(&buf, (size_t)1024 * 8 * 256 * 8) != hipSuccess) return -1;
-    if (hipFuncSetAttribute((const void*)wfx_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kBytes) != hipSuccess) return -1;
-    (void)hipMemsetAsync(buf, 0, n * 8, s);
-    p.trace = buf;
-    hipLaunchKernelGGL((wfx_kernel<true, false>), dim3(grid), dim3(512), kBytes, s, p);
-    std::vector<unsigned long long> h(n);
-    (void)hipStreamSynchronize(s);
-    (void)hipMemcpy(h.data(), buf, n * 8, hipMemcpyDeviceToHost);
-    static int shown = 0;
-    if (shown++ < 1) {
-      for (int wg : {0, grid / 2}) {
-        for (int w : {0, 4}) {
-          const unsigned long long* t = h.data() + ((size_t)wg * 8 + w) * 256;
-          fprintf(stderr, "wfx trace wg %d wave %d: round | addr+finish | 8 taps | barrier 1 | partials+barrier 2 | (s_memtime ticks)\n", wg, w);
-          if (t[0] && t[20 * 8]) fprintf(stderr, "  s_memtime ticks per microsecond over rounds 0-20: %.1f\n", (double)(t[20 * 8] - t[0]) / ((double)(t[20 * 8 + 7] - t[7]) / 100.0));
-          for (int r = 0; r < 24 && t[r * 8]; ++r)
-            fprintf(stderr, "  %2d | %6llu %6llu %6llu %6llu | round %6llu\n", r, t[r * 8 + 1] - t[r * 8], t[r * 8 + 2] - t[r * 8 + 1],
-                    t[r * 8 + 3] - t[r * 8 + 2], t[r * 8 + 4] - t[r * 8 + 3], t[r * 8 + 4] - t[r * 8]);
-        }
-      }
-    }
-    return check_launch("wfx_kernel(trace)");
-  }
-  static const int ex = xg::env_int("SEEDHIP_WFX_EXP", 0);
-#define WFX_EXP(E_) if (ex == E_) { \
-    if (hipFuncSetAttribute((const void*)wfx_kernel<false, false, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, kBytes) != hipSuccess) return -1; \
-    hipLaunchKernelGGL((wfx_kernel<false, false, E_>), dim3(grid), dim3(512), kBytes, s, p); return check_launch("wfx_kernel(exp)"); }
-  WFX_EXP(1) WFX_EXP(3)
-#undef WFX_EXP
   if (p.in_relu) {
     static const bool ok = hipFuncSetAttribute((const void*)wfx_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kBytes) == hipSuccess;
     if (!ok) return -1;

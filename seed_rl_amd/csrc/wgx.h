@@ -12,10 +12,13 @@
 // address: stride, tap offset and zero padding of the im2col matrix are just per-lane addresses, nothing is gathered.
 //
 // Structure (256 threads = 4 waves, two workgroups per CU, each a persistent run of UNITS; unit = BR output rows of one
-// image -- the whole image where it fits):
+// image -- the whole image where it fits).  Measured (MI355X, r5, rocprofv3 clock): second Atari conv 100.5 us against
+// wsw.h's 143, ImpalaDeep 16->16 @36x48 288 (halo_wgrad.h: 525), 16->32 @36x48 475 (820), 32->32 @18x24 220 (427),
+// 32->32 @9x12 66 (127); cfg2 step 1.036 -> 1.013 ms, cfg3 16.09 -> 14.30 ms on one box.
 //   * a unit's input rows ((BR - 1) S + KH of them; rows outside a 'same'-padded image are requested out of range and
 //     come back as zeros) and its dY rows are contiguous in HBM: 16-byte items, coalesced, every byte once per unit;
-//     loaded into registers ONE UNIT AHEAD (the requests fly under the MFMA phase of the current unit);
+//     loaded into registers ONE UNIT AHEAD, each item requested again the moment its registers are consumed (the
+//     requests fly under the rest of the split and the whole MFMA phase of the current unit);
 //   * each element is split ONCE (by truncation: plain full-rate VALU, xgemm.h split2_trunc) on its way into LDS:
 //     three bf16 planes of X as [row][x + pad][ci] (pad columns zeroed once) and of dY as [pixel][co] (+ zero pixels up to
 //     a k-step multiple); one ds_write_b64 per plane and item;
@@ -112,23 +115,17 @@ template <class G> struct Acc { typedef f32x16_t type; };
 template <class G, bool M32 = G::M32> struct AccT { typedef f32x16_t type; };
 template <class G> struct AccT<G, false> { typedef f32x4_t type; };
 
-// EXP (timing experiments, results WRONG; SEEDHIP_WGX_EXP): 1 no global loads after the first unit's, 2 no MFMAs,
-// 4 no split / plane writes
-// TEAMS: 2 = one 8-wave workgroup per CU, its two teams of four waves half a step apart (one splits while the other
-// multiplies); 1 = independent 4-wave workgroups, two per CU, drifting freely
-template <class G, bool RELU, int TEAMS, int EXP = 0>
-__global__ void __launch_bounds__(256 * TEAMS, 2)
+template <class G, bool RELU>
+__global__ void __launch_bounds__(256, 2)
 wgx_kernel(const Params p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef typename AccT<G>::type acc_t;
-  const int tid = threadIdx.x & 255, lane = tid & 63;        // thread within its TEAM of four waves
-  const int wave8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int team = TEAMS == 2 ? wave8 >> 2 : 0, wave = wave8 & 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / G::WK, wk = wave - wm * G::WK;
   const int u0 = blockIdx.x * p.per_wg;
   int u1 = u0 + p.per_wg; if (u1 > p.units) u1 = p.units;
   if (u0 >= u1) return;
-  unsigned char* smem = smem_all + team * G::LDS;            // the team's planes
 
   for (int i = tid * 16; i < G::LDS; i += 256 * 16) *reinterpret_cast<xg::u32x4_t*>(smem + i) = xg::u32x4_t{0u, 0u, 0u, 0u};
 
@@ -159,7 +156,11 @@ wgx_kernel(const Params p) {
     const unsigned ys = (unsigned)img * (unsigned)G::YIMGB + (unsigned)band * (unsigned)G::YUNITB;
     ly[j] = xg::view_load_s(yr, (j + 1 < G::NYI || tid + 256 * j < G::YITEMS) ? i16 : kOut, ys + (unsigned)(4096 * j));
   };
-  f32x4_t bsum = {0.f, 0.f, 0.f, 0.f};
+  // bias gradient: a plain sum of dY over ~10^6 largely cancelling terms -- the per-thread running sums are kept in
+  // fp64 (one conversion + add per unit and component; a unit's own <= 6 items are added in fp32 first) and combined in
+  // fp64 across the workgroup's threads: only the 512 per-workgroup partials are added in fp32 (r5: the per-tensor fp64
+  // gate of the full-size test had a bias gradient 1.8x further from the truth than torch's pairwise fp32 sum)
+  double bsum[4] = {0.0, 0.0, 0.0, 0.0};
   auto put3 = [&](const f32x4_t& v, unsigned dst, int plane) {
     unsigned h0, m0, l0, h1, m1, l1;
     xg::split2_trunc(v[0], v[1], h0, m0, l0);
@@ -168,25 +169,26 @@ wgx_kernel(const Params p) {
     *reinterpret_cast<u32x2_t*>(smem + dst + plane) = u32x2_t{m0, m1};
     *reinterpret_cast<u32x2_t*>(smem + dst + 2 * plane) = u32x2_t{l0, l1};
   };
-  // registers -> three planes in LDS; every item is requested again (for the team's NEXT unit `un`) as soon as its
-  // registers are free: the requests fly under the rest of this split and the whole MFMA phase
+  // registers -> three planes in LDS; every item is requested again (for the NEXT unit `un`) as soon as its registers
+  // are free: the requests fly under the rest of this split and the whole MFMA phase
   auto put = [&](int un) {
-    const bool more = un < u1 && !(EXP & 1);
+    const bool more = un < u1;
 #pragma unroll
     for (int j = 0; j < G::NXI; ++j) {
       f32x4_t v = lx[j];
       if (more) issue_x(un, j);
       if (RELU) xg::relu4(v);
-      if (EXP & 4) { asm volatile("" :: "v"(v)); continue; }
       if (j + 1 < G::NXI || tid + 256 * j < G::XITEMS) put3(v, xdst[j], G::XPL);
     }
+    f32x4_t usum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < G::NYI; ++j) {
       const f32x4_t v = ly[j];
       if (more) issue_y(un, j);
-      if (EXP & 4) { asm volatile("" :: "v"(v)); continue; }
-      if (j + 1 < G::NYI || tid + 256 * j < G::YITEMS) { bsum += v; put3(v, (unsigned)G::YOFF + (unsigned)tid * 8u + 2048u * j, G::YPL); }
+      if (j + 1 < G::NYI || tid + 256 * j < G::YITEMS) { usum += v; put3(v, (unsigned)G::YOFF + (unsigned)tid * 8u + 2048u * j, G::YPL); }
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bsum[c] += (double)usum[c];
   };
 
   // ---- per-lane operand addresses of this wave's k-steps (unit independent) ------------------------------------ //
@@ -215,7 +217,6 @@ wgx_kernel(const Params p) {
     for (int r = 0; r < G::ACCN; ++r) acc[t][r] = 0.f;
 
   auto mfma = [&](const bf16x8_t& a, const bf16x8_t& b, acc_t& c) {
-    if (EXP & 2) { asm volatile("" :: "v"(a), "v"(b)); return; }
     if constexpr (G::M32) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   };
@@ -275,51 +276,48 @@ wgx_kernel(const Params p) {
   };
 
   // The unit loop, instantiated per tap group (branching on wm inside it makes hipcc copy the accumulators around).
-  // Team 0 takes units u0, u0 + 2, ..., team 1 the others, HALF A STEP APART: every barrier interval has one team
-  // splitting (VALU, LDS writes) while the other multiplies (matrix pipe, LDS reads) -- the two waves of a SIMD never
-  // want the same pipe.  Barriers are workgroup wide, so both teams execute the same number of them: T = 2 n0 + 1.
-  const int n0 = TEAMS == 2 ? (u1 - u0 + 1) >> 1 : u1 - u0, nmine = team == 0 ? n0 : (u1 - u0) >> 1;
+  // Two such workgroups share a CU and drift freely: one's split phase (VALU, LDS writes) under the other's MFMAs.  (r5
+  // also tried ONE 8-wave workgroup whose two teams of four waves run exactly half a step apart behind workgroup-wide
+  // barriers -- half the partial slices --: 1.015 vs 1.013 ms for cfg2's step, 14.43 vs 14.30 for cfg3's; a team's
+  // latency bubbles are lost when the other team may not run ahead.  profiles/r05_wgx_step_ab.txt)
   auto run = [&](auto wmi) {
-    if (team == 1) __syncthreads();                          // (half a step behind)
-    for (int i = 0; i < nmine; ++i) {
-      put(u0 + team + TEAMS * (i + 1));
+    for (int u = u0; u < u1; ++u) {
+      put(u + 1);
       __syncthreads();
       phase(wmi);
       __syncthreads();
     }
-    if (TEAMS == 2)
-      for (int i = (team == 1 ? 1 : 0) + 2 * nmine; i < 2 * n0 + 1; ++i) __syncthreads();
   };
-  if (u0 + team < u1) {
 #pragma unroll
-    for (int j = 0; j < G::NXI; ++j) issue_x(u0 + team, j);
+  for (int j = 0; j < G::NXI; ++j) issue_x(u0, j);
 #pragma unroll
-    for (int j = 0; j < G::NYI; ++j) issue_y(u0 + team, j);
-  }
+  for (int j = 0; j < G::NYI; ++j) issue_y(u0, j);
   __syncthreads();                                           // LDS zeroed
   if (G::WM == 1 || wm == 0) run(std::integral_constant<int, 0>());
   else if (G::WM == 2 || wm == 1) run(std::integral_constant<int, 1>());
   else if (wm == 2) run(std::integral_constant<int, G::WM == 4 ? 2 : 0>());
   else run(std::integral_constant<int, G::WM == 4 ? 3 : 0>());
 
-  // ---- bias gradient: thread t of either team summed output channels 4 (t % (COUT / 4)) .. + 3 -------------------- //
-  const int tid8 = threadIdx.x;
+  // ---- bias gradient: thread t summed output channels 4 (t % (COUT / 4)) .. + 3 ---------------------------------- //
   if (p.partial_b) {
-    *reinterpret_cast<f32x4_t*>(smem_all + G::RED + tid8 * 16) = bsum;
-    __syncthreads();
-    if (tid8 < G::COUT) {
-      constexpr int per = G::COUT / 4;
-      float s = 0.f;
-      for (int t = tid8 >> 2; t < 256 * TEAMS; t += per) s += *reinterpret_cast<const float*>(smem_all + G::RED + t * 16 + (tid8 & 3) * 4);
-      p.partial_b[(long long)blockIdx.x * G::COUT + tid8] = s;
-    }
-  }
-  // ---- the workgroup's slice: the (team, wk) waves add their tiles into an [M][COUT] block in LDS one after the other
-  // (fixed order), which then leaves as consecutive 16-byte stores ---------------------------------------------------- //
-  float* red = reinterpret_cast<float*>(smem_all);
+    double* bred = reinterpret_cast<double*>(smem);          // [256 threads][4] (the planes are dead by now)
 #pragma unroll
-  for (int w2 = 0; w2 < TEAMS * G::WK; ++w2) {
-    if (team * G::WK + wk == w2) {
+    for (int c = 0; c < 4; ++c) bred[tid * 4 + c] = bsum[c];
+    __syncthreads();
+    if (tid < G::COUT) {
+      constexpr int per = G::COUT / 4;
+      double s = 0.0;
+      for (int t = tid >> 2; t < 256; t += per) s += bred[t * 4 + (tid & 3)];
+      p.partial_b[(long long)blockIdx.x * G::COUT + tid] = (float)s;
+    }
+    __syncthreads();                                         // (the slice block below reuses these bytes)
+  }
+  // ---- the workgroup's slice: the wk-waves add their tiles into an [M][COUT] block in LDS one after the other (fixed
+  // order), which then leaves as consecutive 16-byte stores -------------------------------------------------------- //
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int w2 = 0; w2 < G::WK; ++w2) {
+    if (wk == w2) {
 #pragma unroll
       for (int t = 0; t < G::TPW; ++t) {
         const int tt = wm * G::TPW + t;
@@ -337,7 +335,7 @@ wgx_kernel(const Params p) {
     __syncthreads();
   }
   f32x4_t* pw = reinterpret_cast<f32x4_t*>(p.partial_w + (long long)blockIdx.x * (G::M * G::COUT));
-  for (int i = tid8; i < G::M * G::COUT / 4; i += 256 * TEAMS) pw[i] = *reinterpret_cast<const f32x4_t*>(smem_all + i * 16);
+  for (int i = tid; i < G::M * G::COUT / 4; i += 256) pw[i] = *reinterpret_cast<const f32x4_t*>(smem + i * 16);
 }
 
 // ---- the served geometries ----------------------------------------------------------------------------------------- //
@@ -364,14 +362,11 @@ inline int which(const seedhip_conv_geom* g) {
 }
 inline int units_per_image(int k) { return k == 1 ? GeoAtari2::NB : k == 2 ? GeoDeep16::NB : k == 3 ? GeoDeep16x32::NB : k == 4 ? GeoDeep32a::NB : GeoDeep32b::NB; }
 
-inline int teams() { static const int t = xg::env_int("SEEDHIP_WGX_TEAMS", 1) == 2 ? 2 : 1; return t; }
-
-// grid (= partial slices) for n_img images of geometry k: one 8-wave workgroup per CU, contiguous runs of units
+// grid (= partial slices) for n_img images of geometry k: two workgroups per CU, contiguous runs of units
 int grid_for(int k, int n_img, int* per_wg_out) {
   static const int cus = xg::cu_count();
   const int units = n_img * units_per_image(k);
-  const int slots = cus * (3 - teams());                     // workgroups per CU: 2 four-wave ones or 1 eight-wave one
-  int grid = units < slots ? units : slots;
+  int grid = units < 2 * cus ? units : 2 * cus;
   const int per_wg = (units + grid - 1) / grid;
   grid = (units + per_wg - 1) / per_wg;
   if (per_wg_out) *per_wg_out = per_wg;
@@ -382,32 +377,22 @@ int grid_for(int k, int n_img, int* per_wg_out) {
 int plan(const seedhip_conv_geom* g) {
   const int k = which(g);
   if (!k) return 0;
-  static const int min_img = xg::env_int("SEEDHIP_WGX_MIN", 32);
-  if (g->n_img < min_img) return 0;
+  if (g->n_img < 32) return 0;                               // (a handful of images: the generic kernels' grids fill better)
   const long long xb = (long long)g->n_img * g->ih * g->iw * g->cin * 4, yb = (long long)g->n_img * g->oh * g->ow * g->cout * 4;
   if (xb >= (1LL << 31) - (1 << 22) || yb >= (1LL << 31) - (1 << 22)) return 0;
   return k;
 }
 
-template <class G, bool RELU, int TEAMS, int EXP>
+template <class G, bool RELU>
 inline int launch_one(Params& p, int grid, hipStream_t s) {
-  static const bool ok = hipFuncSetAttribute((const void*)wgx_kernel<G, RELU, TEAMS, EXP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             TEAMS * G::LDS) == hipSuccess;
+  static const bool ok = hipFuncSetAttribute((const void*)wgx_kernel<G, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) == hipSuccess;
   if (!ok) return fail(SEEDHIP_ERR_LAUNCH, "wgx_kernel: LDS attribute");
-  hipLaunchKernelGGL((wgx_kernel<G, RELU, TEAMS, EXP>), dim3(grid), dim3(256 * TEAMS), TEAMS * G::LDS, s, p);
+  hipLaunchKernelGGL((wgx_kernel<G, RELU>), dim3(grid), dim3(256), G::LDS, s, p);
   return check_launch("wgx_kernel");
 }
-
 template <class G>
 inline int launch_geo(Params& p, int in_relu, int grid, hipStream_t s) {
-  static const int ex = xg::env_int("SEEDHIP_WGX_EXP", 0);
-  if (ex && !in_relu && std::is_same<G, GeoAtari2>::value) {
-#define WGX_EXP(E_) if (ex == E_) return teams() == 2 ? launch_one<GeoAtari2, false, 2, E_>(p, grid, s) : launch_one<GeoAtari2, false, 1, E_>(p, grid, s);
-    WGX_EXP(1) WGX_EXP(2) WGX_EXP(3) WGX_EXP(4) WGX_EXP(5) WGX_EXP(6) WGX_EXP(7)
-#undef WGX_EXP
-  }
-  if (teams() == 2) return in_relu ? launch_one<G, true, 2, 0>(p, grid, s) : launch_one<G, false, 2, 0>(p, grid, s);
-  return in_relu ? launch_one<G, true, 1, 0>(p, grid, s) : launch_one<G, false, 1, 0>(p, grid, s);
+  return in_relu ? launch_one<G, true>(p, grid, s) : launch_one<G, false>(p, grid, s);
 }
 
 // partial_w [grid][M][COUT], partial_b [grid][COUT] (or null); returns the slice count through *slices

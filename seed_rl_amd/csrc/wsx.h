@@ -25,7 +25,6 @@
 #pragma once
 #include <type_traits>
 #include "wfx.h"
-#include "wsw.h"
 
 namespace seedhip {
 namespace wsx {
@@ -93,9 +92,9 @@ wsx_kernel(const Params p) {
   const int rounds = (total + kRound - 1) / kRound;
   const long long run_bytes = (long long)nimg * G::kPX * 128;
   const sgpr128_t xd = xg::make_view_words(p.X + (long long)img0 * G::kPX * 32, run_bytes);
-  const __amdgpu_buffer_rsrc_t av = wsw::view((p.A ? p.A : p.Y) + (long long)img0 * G::kPX * 32, run_bytes);
-  const __amdgpu_buffer_rsrc_t bv = wsw::view((p.B ? p.B : p.Y) + (long long)img0 * G::kPX * 32, run_bytes);
-  const __amdgpu_buffer_rsrc_t ov = wsw::view(p.Y + (long long)img0 * G::kPX * 32, run_bytes);
+  const __amdgpu_buffer_rsrc_t av = gemm::make_view((p.A ? p.A : p.Y) + (long long)img0 * G::kPX * 32, run_bytes);
+  const __amdgpu_buffer_rsrc_t bv = gemm::make_view((p.B ? p.B : p.Y) + (long long)img0 * G::kPX * 32, run_bytes);
+  const __amdgpu_buffer_rsrc_t ov = gemm::make_view(p.Y + (long long)img0 * G::kPX * 32, run_bytes);
   const bool has_a = p.A != nullptr, has_b = p.B != nullptr;
 
   // ---- weights of this wave's channel half: step t = 3 ky + kx, W_eff[t][ci = 16 kh + 8 kq + e][co = lane & 31] ----- //
@@ -335,7 +334,7 @@ inline int geometry(const seedhip_conv_geom* g) {
   if (g->kh != 3 || g->kw != 3 || g->stride != 1 || g->pad_t != 1 || g->pad_l != 1 || g->cin != 32 || g->cout != 32 ||
       g->ld_in != 32 || g->ld_out != 32 || g->oh != g->ih || g->ow != g->iw)
     return 0;
-  static const int min_img = xg::env_int("SEEDHIP_WSX_MIN", 512);
+  constexpr int min_img = 512;
   if (g->n_img < min_img) return 0;
   if (g->ih == 18 && g->iw == 24) return 1;
   if (g->ih == 9 && g->iw == 12) return 2;

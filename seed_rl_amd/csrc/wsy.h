@@ -72,7 +72,7 @@ wsy_kernel(const Params p) {
   const sgpr128_t xd = xg::make_view_words(p.X + (long long)img0 * G::kPX * 16, run_bytes);
   const sgpr128_t ad = xg::make_view_words((p.A ? p.A : p.Y) + (long long)img0 * G::kPX * 16, run_bytes);
   const sgpr128_t bd = xg::make_view_words((p.B ? p.B : p.Y) + (long long)img0 * G::kPX * 16, run_bytes);
-  const __amdgpu_buffer_rsrc_t ov = wsw::view(p.Y + (long long)img0 * G::kPX * 16, run_bytes);
+  const __amdgpu_buffer_rsrc_t ov = gemm::make_view(p.Y + (long long)img0 * G::kPX * 16, run_bytes);
   const bool has_a = p.A != nullptr, has_b = DG && p.B != nullptr;
 
   // ---- weights: step s, lane (co = lane & 15, kq): tap t = 2 s + (kq >> 1), ci = 8 (kq & 1) + e; tap 9 = zeros ------ //
@@ -283,7 +283,7 @@ inline int geometry(const seedhip_conv_geom* g) {
   if (g->kh != 3 || g->kw != 3 || g->stride != 1 || g->pad_t != 1 || g->pad_l != 1 || g->cin != 16 || g->cout != 16 ||
       g->ld_in != 16 || g->ld_out != 16 || g->oh != g->ih || g->ow != g->iw)
     return 0;
-  static const int min_img = xg::env_int("SEEDHIP_WSY_MIN", 256);
+  constexpr int min_img = 256;
   if (g->n_img < min_img) return 0;
   return (g->ih == 36 && g->iw == 48) ? 1 : 0;
 }

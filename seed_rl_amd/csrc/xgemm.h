@@ -385,296 +385,13 @@ xgemm_kernel(const Params p, const Grid g) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = mv[r] > 0.f ? v[r] : 0.f;
         }
+        if (p.mask_bits) {                                   // (ldc % 4 == 0: `at` is a multiple of four)
+          const unsigned mb = p.mask_bits[at >> 2];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = ((mb >> r) & 1u) ? v[r] : 0.f;
+        }
         if (p.add) v += *reinterpret_cast<const f32x4_t*>(p.add + at);
         *reinterpret_cast<f32x4_t*>(p.C + at) = v;
-      }
-    }
-  }
-}
-
-// ---- wave-specialised variant ------------------------------------------------------------------------------- //
-// The kernel above runs its phases in lockstep inside a workgroup (load wait -> split + LDS writes -> barrier -> MFMAs
-// -> barrier) and relies on OTHER workgroups of the CU to fill the matrix pipe meanwhile; the leave-one-out probes
-//  show the phases adding instead: matrix pipe 45 % busy.  Here the roles are split between the
-// waves of ONE 512-thread workgroup per CU:
-//   * waves 0-3 (one per SIMD) only read fragments and issue MFMAs (+ the epilogue of a finished tile);
-//   * waves 4-7 (their SIMD partners) only stage: global loads two k-tiles ahead through a static register ring,
-//     split, LDS writes -- VALU / memory work that runs beside the partner's MFMAs;
-//   * three LDS buffers; the stagers stay one tile further ahead than the consumers need, so that the MFMA waves
-//     prefetch the first fragments of tile g + 1 while they compute tile g: ONE barrier per k-tile, no LDS latency
-//     at the head of a tile;
-//   * persistent: a workgroup walks its (m-tile, slice, n-tile) items without draining the pipeline -- the stagers
-//     fill the next item's first tiles during the epilogue of the previous one.
-// Round r of workgroup b (XCD b % 8) is item r * grid + (b % 8) * (grid / 8) + b / 8: the workgroups of one XCD hold
-// consecutive items (neighbouring tiles share operand panels in that XCD's L2).
-constexpr int kNBuf = 3;
-constexpr int kWsScratch = 2 * 1024;
-constexpr int kWsLds = kNBuf * kLds + kWsScratch;
-
-struct Item { int m0, n0, slice, k0, k1, nkt, mtile; };
-__device__ __forceinline__ Item decode_item(const Params& p, const Grid& g, int item) {
-  Item it;
-  const int ntile = item % g.nt, rest = item / g.nt;
-  it.slice = rest % g.slices; it.mtile = rest / g.slices;
-  it.m0 = it.mtile * BX; it.n0 = ntile * BX;
-  it.k0 = it.slice * p.k_per_slice;
-  it.k1 = it.k0 + p.k_per_slice; if (it.k1 > p.K) it.k1 = p.K;
-  it.nkt = (it.k1 - it.k0 + BK - 1) / BK;
-  return it;
-}
-
-// One stager role: the two waves (u = 0..127) that stage operand A (IS_B = false) or B of every tile of the workgroup.
-// D: k-tiles of global loads in flight per thread (static register ring).
-template <bool KC, bool IS_B, int D, int EXP>
-__device__ __forceinline__ void stager_role(const Params& p, const Grid& g, unsigned char* smem, int first, int grid,
-                                            int rounds, int G, int u, int wave, int lane) {
-  typedef typename PickStage<KC>::type S;
-  if (EXP & 512) __builtin_amdgcn_s_setprio(3);          // the stagers' VALU / LDS / VMEM issue ahead of the partner's MFMAs
-  const float* base = IS_B ? p.B : p.A;
-  const long long ld = IS_B ? p.ldb : p.lda;
-  const int X = IS_B ? p.N : p.M;
-  const sgpr128_t words = make_view_words(base, (KC ? (long long)X * ld : (long long)p.K * ld) * 4);
-  const bool relu = !IS_B && p.a_relu != 0;
-  S st;
-  // load cursor, D k-tiles ahead of the write cursor.  Loads are UNCONDITIONAL (out-of-range offsets behind the last
-  // tile) and hidden from the compiler's wait bookkeeping (asm_load / wait_slot)
-  int lr = 0, lkt = 0;
-  bool lvalid = true;
-  Item li;
-  auto l_setup = [&]() {
-    li = decode_item(p, g, first + lr * grid);
-    st.init(u, ld, IS_B ? li.n0 : li.m0, X);
-  };
-  auto l_load = [&](f32x4_t (&r)[8]) {
-    const int k = li.k0 + lkt * BK;
-    const bool ok = lvalid && !(EXP & 2);
-    st.load(r, words, k, ok ? li.k1 : 0);
-    if (lvalid && ++lkt == li.nkt) { lkt = 0; if (++lr < rounds) l_setup(); else lvalid = false; }
-  };
-  // write cursor
-  int wr = 0, wkt = 0;
-  Item wi = decode_item(p, g, first);
-  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool colsum_on = IS_B && !KC && p.partial_colsum != nullptr;
-  unsigned char* scratch = smem + kNBuf * kLds;
-  int bufw = 0;
-  // the bias-gradient column sums of a finished item leave through the scratch: lanes l / l + 32 of a wave hold row
-  // chunks c / c + 1 of one column quad, wave 7 hands its pair to wave 6 (slot = item parity; wave 6 flushes behind
-  // the next barrier)
-  int pending = -1, pend_slice = 0, pend_n0 = 0;
-  auto write = [&](f32x4_t (&r)[8]) {
-    unsigned char* dst = smem + bufw * kLds + (IS_B ? kOperand : 0);
-    bufw = bufw == kNBuf - 1 ? 0 : bufw + 1;
-    st.template store<EXP>(r, dst, relu);
-    if (colsum_on && wr < rounds && wi.mtile == 0) { const float4 t = st.colsum(r); csum.x += t.x; csum.y += t.y; csum.z += t.z; csum.w += t.w; }
-    if (wr >= rounds || ++wkt < wi.nkt) return;
-    if (colsum_on && wi.mtile == 0) {
-      float4 t = csum;
-      t.x += __shfl_xor(t.x, 32, 64); t.y += __shfl_xor(t.y, 32, 64); t.z += __shfl_xor(t.z, 32, 64); t.w += __shfl_xor(t.w, 32, 64);
-      if (wave == 7) { if (lane < 32) reinterpret_cast<float4*>(scratch + (wr & 1) * 1024)[lane] = t; csum = make_float4(0.f, 0.f, 0.f, 0.f); }
-      else { csum = t; pending = wr & 1; pend_slice = wi.slice; pend_n0 = wi.n0; }
-    }
-    wkt = 0;
-    if (++wr < rounds) wi = decode_item(p, g, first + wr * grid);
-  };
-  auto flush = [&]() {
-    if (!colsum_on || pending < 0) return;
-    if (lane < 32 && pend_n0 + 4 * lane < p.N) {
-      const float4 o = reinterpret_cast<const float4*>(scratch + pending * 1024)[lane];
-      float4 t = csum;
-      t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
-      *reinterpret_cast<float4*>(p.partial_colsum + (long long)pend_slice * p.N + pend_n0 + 4 * lane) = t;
-    }
-    csum = make_float4(0.f, 0.f, 0.f, 0.f);
-    pending = -1;
-  };
-  l_setup();
-  f32x4_t ring[D][8];
-#pragma unroll
-  for (int d = 0; d < D; ++d) l_load(ring[d]);
-  // tile t lives in ring slot t % D.  The stagers write tile gs + 1 BEFORE barrier gs: the MFMA waves prefetch its
-  // first fragments while they compute tile gs.  (Behind the last tile the writes carry zeros into a buffer nobody
-  // reads.)
-  wait_slot<8 * (D - 1)>(ring[0]);
-  write(ring[0]); l_load(ring[0]);
-  const bool tr = (EXP & 128) && g.trace && blockIdx.x == 0 && (wave & 1) == 0 && lane == 0;
-  unsigned long long* tb = g.trace + (wave >> 1) * 64 * 8;      // [role][step][8 stamps]
-  for (int base_g = 0; base_g < G; base_g += D) {
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      if (base_g + j >= G) break;
-      const int gs = base_g + j;
-      if (tr && gs < 64) tb[gs * 8 + 0] = __builtin_amdgcn_s_memtime();
-      wait_slot<8 * (D - 1)>(ring[(j + 1) % D]);         // the D - 1 younger slots stay in flight
-      if (tr && gs < 64) tb[gs * 8 + 1] = __builtin_amdgcn_s_memtime();
-      write(ring[(j + 1) % D]);
-      if (tr && gs < 64) { asm volatile("s_waitcnt lgkmcnt(0)"); tb[gs * 8 + 2] = __builtin_amdgcn_s_memtime(); }
-      l_load(ring[(j + 1) % D]);
-      if (tr && gs < 64) tb[gs * 8 + 3] = __builtin_amdgcn_s_memtime();
-      __syncthreads();                                   // barrier base_g + j
-      if (tr && gs < 64) tb[gs * 8 + 4] = __builtin_amdgcn_s_memtime();
-      flush();
-    }
-  }
-}
-
-// EXP (probes; garbage results): 2 no global loads (every offset out of range), 4 no split arithmetic, 8 no MFMAs;
-// 64: MFMA waves at s_setprio 1.
-template <bool AKC, bool BKC, int D = 3, int EXP = 0>
-__global__ void __launch_bounds__(512, 2)
-xgemm_ws_kernel(const Params p, const Grid g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int items = g.mt * g.nt * g.slices;
-  const int grid = (int)gridDim.x, g8 = grid >> 3;
-  const int first = ((int)blockIdx.x & 7) * g8 + ((int)blockIdx.x >> 3);
-  const int rounds = first < items ? (items - first + grid - 1) / grid : 0;
-  int G = 0;
-  for (int r = 0; r < rounds; ++r) G += decode_item(p, g, first + r * grid).nkt;
-  if (G == 0) return;
-
-  if (wave >= 6) { stager_role<BKC, true, D, EXP>(p, g, smem, first, grid, rounds, G, tid & 127, wave, lane); return; }
-  if (wave >= 4) { stager_role<AKC, false, D, EXP>(p, g, smem, first, grid, rounds, G, tid & 127, wave, lane); return; }
-
-  // ---------------- MFMA waves ---------------- //
-  if (EXP & 64) __builtin_amdgcn_s_setprio(1);
-  const int wm = wave >> 1, wn = wave & 1, lx = lane & 31, half = lane >> 5;
-  int a_off[2], b_off[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    a_off[s] = frag_off<AKC>(wm * 64 + lx, half, s);
-    b_off[s] = kOperand + frag_off<BKC>(wn * 64 + lx, half, s);
-  }
-  bf16x8_t fa0[2][3], fb0[2][3], fa1[2][3], fb1[2][3];
-  auto read_frags = [&](const unsigned char* base, int s, bf16x8_t (&fa)[2][3], bf16x8_t (&fb)[2][3]) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        fa[t][q] = *reinterpret_cast<const bf16x8_t*>(base + a_off[s] + t * tile_stride<AKC>() + q * kPlane);
-        fb[t][q] = *reinterpret_cast<const bf16x8_t*>(base + b_off[s] + t * tile_stride<BKC>() + q * kPlane);
-      }
-  };
-  int bufr = 0;
-  bool primed = false;
-  for (int r = 0; r < rounds; ++r) {
-    const Item it = decode_item(p, g, first + r * grid);
-    f32x16_t acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    auto mfmas = [&](bf16x8_t (&fa)[2][3], bf16x8_t (&fb)[2][3]) {
-      if (EXP & 8) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int q = 0; q < 3; ++q) asm volatile("" :: "v"(fa[t][q]), "v"(fb[t][q]));
-        return;
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x16_t c = acc[i][j];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][2], fa[i][0], c, 0, 0, 0);   // bl ah
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][0], fa[i][2], c, 0, 0, 0);   // bh al
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][1], fa[i][1], c, 0, 0, 0);   // bm am
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][1], fa[i][0], c, 0, 0, 0);   // bm ah
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][0], fa[i][1], c, 0, 0, 0);   // bh am
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][0], fa[i][0], c, 0, 0, 0);   // bh ah
-          acc[i][j] = c;
-        }
-    };
-    const bool tr = (EXP & 128) && g.trace && blockIdx.x == 0 && wave == 0 && lane == 0 && r == 0;
-    for (int kt = 0; kt < it.nkt; ++kt) {
-      if (tr && kt < 64) g.trace[kt * 8 + 0] = __builtin_amdgcn_s_memtime();
-      __syncthreads();                                   // barrier g: tiles g and g + 1 are in LDS
-      if (tr && kt < 64) g.trace[kt * 8 + 1] = __builtin_amdgcn_s_memtime();
-      const unsigned char* cur = smem + bufr * kLds;
-      bufr = bufr == kNBuf - 1 ? 0 : bufr + 1;
-      const unsigned char* nxt = smem + bufr * kLds;
-      if (!primed) { read_frags(cur, 0, fa0, fb0); primed = true; }     // very first tile only
-      // (sched_barrier: hipcc otherwise sinks each group of fragment reads to just in front of its MFMAs -- lower
-      // register pressure, but the LDS latency lands in the middle of the tile)
-      read_frags(cur, 1, fa1, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(fa0, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (tr && kt < 64) g.trace[kt * 8 + 2] = __builtin_amdgcn_s_memtime();
-      read_frags(nxt, 0, fa0, fb0);                      // first half of the NEXT tile (stale bytes behind the last one)
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(fa1, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (tr && kt < 64) g.trace[kt * 8 + 3] = __builtin_amdgcn_s_memtime();
-    }
-    // epilogue.  Accumulator (i, j) register e of lane (lx, half): m = m0 + wm*64 + 32 i + lx,
-    //   n = n0 + wn*64 + 32 j + 8 (e >> 2) + 4 half + (e & 3): quads of four consecutive n.
-    // Optional operands are requested for a whole row (8 quads) before the first use -- one memory round trip per
-    // row instead of one per quad -- under uniform branches that enclose whole blocks
-    const int nb = it.n0 + wn * 64 + 4 * half;          // quad (j, q) starts at nb + 32 j + 8 q
-    const bool has_bias = p.bias != nullptr, has_mask = p.mask != nullptr, has_res = p.residual != nullptr, has_add = p.add != nullptr;
-    f32x4_t bv[8];
-#pragma unroll
-    for (int jq = 0; jq < 8; ++jq) bv[jq] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (has_bias && !p.partial) {
-#pragma unroll
-      for (int jq = 0; jq < 8; ++jq) {
-        const int n = nb + 32 * (jq >> 2) + 8 * (jq & 3);
-        if (n < p.N) bv[jq] = *reinterpret_cast<const f32x4_t*>(p.bias + n);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = it.m0 + wm * 64 + 32 * i + lx;
-      const bool m_ok = m < p.M;
-      if (p.partial) {
-#pragma unroll
-        for (int jq = 0; jq < 8; ++jq) {
-          const int j = jq >> 2, q = jq & 3, n = nb + 32 * j + 8 * q;
-          if (m_ok && n < p.N) {
-            const f32x4_t v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-            *reinterpret_cast<f32x4_t*>(p.partial + ((long long)it.slice * p.M + m) * p.N + n) = v;
-          }
-        }
-        continue;
-      }
-      const long long row = (long long)m * p.ldc;
-      f32x4_t ex[8], ad[8];
-      if (has_mask || has_res) {                         // (mask and residual never come together: backward / forward)
-        const float* src = has_mask ? p.mask : p.residual;
-#pragma unroll
-        for (int jq = 0; jq < 8; ++jq) {
-          const int n = nb + 32 * (jq >> 2) + 8 * (jq & 3);
-          ex[jq] = (m_ok && n < p.N) ? *reinterpret_cast<const f32x4_t*>(src + row + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-      if (has_add) {
-#pragma unroll
-        for (int jq = 0; jq < 8; ++jq) {
-          const int n = nb + 32 * (jq >> 2) + 8 * (jq & 3);
-          ad[jq] = (m_ok && n < p.N) ? *reinterpret_cast<const f32x4_t*>(p.add + row + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-#pragma unroll
-      for (int jq = 0; jq < 8; ++jq) {
-        const int j = jq >> 2, q = jq & 3, n = nb + 32 * j + 8 * q;
-        f32x4_t v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        v += bv[jq];
-        if (has_res) v += ex[jq];
-        if (p.out_relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (has_mask) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ex[jq][e] > 0.f ? v[e] : 0.f;
-        }
-        if (has_add) v += ad[jq];
-        if (m_ok && n < p.N) *reinterpret_cast<f32x4_t*>(p.C + row + n) = v;
       }
     }
   }
@@ -731,32 +448,11 @@ inline Plan plan(int M, int N, int K, long long a_bytes, long long b_bytes, bool
 }
 inline size_t partial_bytes(int M, int N, const Plan& pl) { return pl.slices > 1 ? (size_t)pl.slices * M * N * sizeof(float) : 0; }
 
-inline unsigned long long*& trace_ptr() { static unsigned long long* p = nullptr; return p; }
-
 template <bool AKC, bool BKC>
 inline void launch(Params p, const Plan& pl, hipStream_t s) {
   p.k_per_slice = pl.k_per_slice;
   const int blocks = pl.grid.mt * pl.grid.nt * pl.grid.slices;
-  static const int ws = env_int("SEEDHIP_X6_WS", 0);
-  if (ws) {
-    // persistent wave-specialised kernel: one 512-thread workgroup per CU, grid a multiple of 8 (XCD round robin)
-    int grid = cu_count() & ~7; if (grid < 8) grid = 8;
-    if (blocks < grid) grid = (blocks + 7) & ~7;
-    static const int depth = env_int("SEEDHIP_X6_DEPTH", 3), wex = env_int("SEEDHIP_X6_WEXP", 0);
-    Plan plt = pl; plt.grid.trace = trace_ptr();
-#define XG_WS(D_, E_) if (depth == D_ && wex == E_) { \
-      static const bool ok = hipFuncSetAttribute((const void*)xgemm_ws_kernel<AKC, BKC, D_, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, kWsLds) == hipSuccess; \
-      if (ok) { hipLaunchKernelGGL((xgemm_ws_kernel<AKC, BKC, D_, E_>), dim3(grid), dim3(512), kWsLds, s, p, plt.grid); return; } }
-    XG_WS(3, 0) XG_WS(3, 256) XG_WS(3, 512) XG_WS(3, 768) XG_WS(2, 768) XG_WS(4, 768)
-    if constexpr (AKC && !BKC) { XG_WS(3, 2) XG_WS(3, 4) XG_WS(3, 8) XG_WS(3, 64) XG_WS(3, 14) XG_WS(3, 128) XG_WS(3, 384) XG_WS(3, 142) XG_WS(3, 136) XG_WS(3, 132) XG_WS(3, 896) XG_WS(3, 832) }
-#undef XG_WS
-  }
-  static const int ex = env_int("SEEDHIP_X6_EXP", 0);
-  if constexpr (AKC && !BKC) {
-#define XG_EXP(E) if (ex == E) { hipLaunchKernelGGL((xgemm_kernel<AKC, BKC, E>), dim3(blocks), dim3(256), 0, s, p, pl.grid); return; }
-    XG_EXP(2) XG_EXP(4) XG_EXP(8) XG_EXP(16) XG_EXP(32) XG_EXP(6) XG_EXP(10) XG_EXP(30) XG_EXP(62)
-#undef XG_EXP
-  }
+  // (r4's persistent wave-specialised variant -- 142 vs 110 us forward -- and the leave-one-out timing builds are gone)
   hipLaunchKernelGGL((xgemm_kernel<AKC, BKC, 0>), dim3(blocks), dim3(256), 0, s, p, pl.grid);
 }
 

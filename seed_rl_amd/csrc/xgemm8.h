@@ -661,31 +661,12 @@ inline bool launch(const Params& p, const Plan& pl, const void* Ap, const void* 
   Args g;
   g.p = p; g.Ap = (const unsigned char*)Ap; g.Bp = (const unsigned char*)Bp; g.colsum_kt = colsum_kt;
   g.mt = pl.mt; g.nt = pl.nt; g.slices = pl.slices; g.kt_per_slice = pl.kt_per_slice; g.nkt = pl.nkt;
-  static const int order = xg::env_int("SEEDHIP_X8_ORDER", 1), prio = xg::env_int("SEEDHIP_X8_PRIO", 0);
-  g.slice_major = order; g.prio = prio; g.trace = xg::trace_ptr();
+  g.slice_major = 1; g.prio = 0; g.trace = nullptr;           // (r4's order / priority / timing-experiment knobs measured +-3 %: gone)
   const int blocks = pl.mt * pl.nt * pl.slices;
-  static const int ex = xg::env_int("SEEDHIP_X8_EXP", 0);
-#define XG8_GO(E) { \
-    static const bool ok = hipFuncSetAttribute((const void*)xg8_kernel<AMODE, E>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess; \
-    if (!ok) return false; \
-    hipLaunchKernelGGL((xg8_kernel<AMODE, E>), dim3(blocks), dim3(512), kLds, s, g); return true; }
-  if constexpr (AMODE == 0) {
-    if (ex == 4) XG8_GO(4) if (ex == 8) XG8_GO(8) if (ex == 32) XG8_GO(32) if (ex == 44) XG8_GO(44) if (ex == 128 && !xg::env_int("SEEDHIP_X8_DMA", 0)) XG8_GO(128)
-    if (ex == 132) XG8_GO(132) if (ex == 160) XG8_GO(160)
-  }
-  static const int dma = xg::env_int("SEEDHIP_X8_DMA", 0);
-  if constexpr (AMODE == 0) {
-    if (dma && ex == 128) {
-      static const bool ok = hipFuncSetAttribute((const void*)xg8_kernel<AMODE, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
-      if (ok) { hipLaunchKernelGGL((xg8_kernel<AMODE, 128, true>), dim3(blocks), dim3(512), kLds, s, g); return true; }
-    }
-  }
-  if (dma && ex == 0) {
-    static const bool ok = hipFuncSetAttribute((const void*)xg8_kernel<AMODE, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
-    if (ok) { hipLaunchKernelGGL((xg8_kernel<AMODE, 0, true>), dim3(blocks), dim3(512), kLds, s, g); return true; }
-  }
-  XG8_GO(0)
-#undef XG8_GO
+  static const bool ok = hipFuncSetAttribute((const void*)xg8_kernel<AMODE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
+  if (!ok) return false;
+  hipLaunchKernelGGL((xg8_kernel<AMODE, 0>), dim3(blocks), dim3(512), kLds, s, g);
+  return true;
 }
 
 }  // namespace xg8

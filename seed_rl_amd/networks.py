@@ -31,8 +31,7 @@ AgentOutput = collections.namedtuple('AgentOutput', 'action policy_logits baseli
 # by the torso (csrc/frames.hip: *_indexed): column b's state is table[rows[b]]; zero_mask[b] != 0: counts as zeros
 # (restarted actor); valid_mask[b] == 0: the row is not written back.  Passed by inference.FusedInferenceState.
 IndexedFrameState = collections.namedtuple('IndexedFrameState', 'table rows zero_mask valid_mask')
-_RELU_BITS = os.environ.get('SEEDHIP_RELU_BITS', '0') == '1'      # A/B knob, see _AtariTorso._torso_fwd
-_FUSE01 = os.environ.get('SEEDHIP_FUSE01', '0') == '1'            # A/B knob, see _AtariTorso._torso_bwd
+_RELU_BITS = os.environ.get('SEEDHIP_RELU_BITS', '1') == '1'      # A/B knob, see _AtariTorso._torso_fwd
 AgentState = collections.namedtuple('AgentState', 'core_state frame_stacking_state')
 
 
@@ -500,11 +499,10 @@ class _AtariTorso(object):
     ih, iw, cin, k, s, ch, oh, ow = self._shapes[0]
     g0 = ops.StackConvGeom(T1, B, ih, iw, oh, ow, k, k, s, ch, ch)
     a = self._buf('act0', (N, oh, ow, ch))
-    # SEEDHIP_RELU_BITS=1: the ReLU mask of the first conv as bytes, where both it and the second conv's data gradient
-    # have the kernel for it (the shallow torso) -- that gradient then reads 1 byte where it read 16 of act0.  OFF by
-    # default: bit-identical, but measured a net loss on MI355X (cfg2: data gradient 172 -> 161 us, first conv forward
-    # 179 -> 198 us: the 10 VALU instructions per tile that form the nibble cost the producer more than the consumer's
-    # memory side gains)
+    # The ReLU mask of the first conv as bytes (one per four channels), where both it and the second conv's data
+    # gradient have the kernel for it (the shallow torso): that gradient then reads 1 byte where it read 16 of act0
+    # (17 MB instead of 275 MB at cfg2).  r3 measured a net loss against the fp32-MFMA data gradient (not byte-bound);
+    # r5: wdx.h IS byte-bound (0.82 of its byte floor, 275 of its 663 MB the mask).  SEEDHIP_RELU_BITS=0: fp32 mask.
     bits0 = None
     if _RELU_BITS and for_backward and len(self._shapes) > 1 and ops.conv2d_stack_fwd_bits_supported(g0):
       ih1, iw1, cin1, k1, s1, ch1, _, _ = self._shapes[1]
@@ -513,11 +511,16 @@ class _AtariTorso(object):
     ops.conv2d_stack_fwd(g0, ext, nvalid, fl.p(tp + 'conv0/kernel'), fl.p(tp + 'conv0/bias'), a, out_relu=True,
                          relu_bits=bits0)
     acts.append(a); geoms.append(g0)
+    bits_last = None
     for i in range(1, len(self._shapes)):
       ih, iw, cin, k, s, ch, oh, ow = self._shapes[i]
       g = ops.conv_geom(N, ih, iw, cin, k, k, s, 'valid', ch)
       a2 = self._buf('act%d' % i, (N, oh, ow, ch))
-      ops.conv2d_fwd(g, a, fl.p('%sconv%d/kernel' % (tp, i)), fl.p('%sconv%d/bias' % (tp, i)), a2, out_relu=True)
+      bits_i = None
+      if (_RELU_BITS and for_backward and i == len(self._shapes) - 1 and ops.conv2d_fwd_bits_supported(g) and
+          ops.conv2d_bwd_data_bits_supported(ops.dense_geom(N, self._flat_dim, self._fc, ld_out=ld_out))):
+        bits_i = bits_last = self._buf('act%d_bits' % i, (N, oh, ow, ch // 4), torch.uint8)   # for the Dense layer's data gradient
+      ops.conv2d_fwd(g, a, fl.p('%sconv%d/kernel' % (tp, i)), fl.p('%sconv%d/bias' % (tp, i)), a2, out_relu=True, relu_bits=bits_i)
       acts.append(a2); geoms.append(g); a = a2
     gfc = ops.dense_geom(N, self._flat_dim, self._fc, ld_out=ld_out)
     ops.conv2d_fwd(gfc, a, fl.p(tp + 'fc/kernel'), fl.p(tp + 'fc/bias'), out, out_relu=True)
@@ -528,7 +531,7 @@ class _AtariTorso(object):
     elif need_state:                              # the learner discards it (agents/vtrace/learner.py:75-79 `learner_outputs, _ =`)
       new_fs = torch.empty_like(frame_state)
       ops.stack_pack_state(ext, nvalid, T1, B, HW, new_fs)
-    return new_fs, dict(ext=ext, nvalid=nvalid, acts=acts, geoms=geoms, gfc=gfc, bits0=bits0)
+    return new_fs, dict(ext=ext, nvalid=nvalid, acts=acts, geoms=geoms, gfc=gfc, bits0=bits0, bits_last=bits_last)
 
   def _torso_bwd(self, ctx, dz, wsb):
     """dz: gradient wrt the Dense pre-activation (already masked by its ReLU), row stride = gfc.ld_out."""
@@ -540,18 +543,13 @@ class _AtariTorso(object):
     # buffer is final now -- its exchange overlaps the conv backward
     self._grads_ready_from(tp + 'fc/kernel')
     da = self._buf('d_act%d' % (len(acts) - 1), tuple(a_last.shape))
-    ops.conv2d_bwd_data(gfc, dz, fl.p(tp + 'fc/kernel'), da, relu_mask=a_last)
+    if ctx.get('bits_last') is not None:
+      ops.conv2d_bwd_data(gfc, dz, fl.p(tp + 'fc/kernel'), da, relu_bits=ctx['bits_last'])
+    else:
+      ops.conv2d_bwd_data(gfc, dz, fl.p(tp + 'fc/kernel'), da, relu_mask=a_last)
     for i in range(len(acts) - 1, 0, -1):
       g, a_in = geoms[i], acts[i - 1]
       ops.conv2d_bwd_weight(g, a_in, da, fl.g('%sconv%d/kernel' % (tp, i)), fl.g('%sconv%d/bias' % (tp, i)), wsb)
-      if i == 1 and _FUSE01 and ops.conv2d_stack_bwd_weight_fused_supported(geoms[0], g):
-        # shallow torso: the second conv's data gradient exists only to feed the first conv's weight gradient -- one
-        # kernel computes it per frame in LDS and consumes it there (d_act0 is never written)
-        ws0 = self._buf('stack_ws', (ops.conv2d_stack_bwd_weight_fused_workspace_bytes(geoms[0]) // 4 + 4,))
-        ops.conv2d_stack_bwd_weight_fused(geoms[0], g, ctx['ext'], ctx['nvalid'], a_in, da, fl.p('%sconv%d/kernel' % (tp, i)),
-                                          fl.g(tp + 'conv0/kernel'), fl.g(tp + 'conv0/bias'), ws0)
-        self._grads_ready_from(None, upto=tp + 'fc/kernel')
-        return
       d_in = self._buf('d_act%d' % (i - 1), tuple(a_in.shape))
       if i == 1 and ctx.get('bits0') is not None:
         ops.conv2d_bwd_data(g, da, fl.p('%sconv%d/kernel' % (tp, i)), d_in, relu_bits=ctx['bits0'])

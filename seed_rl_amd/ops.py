@@ -174,7 +174,24 @@ def _splitk_ws(nbytes, like):
   return t, t.numel() * 4
 
 
-def conv2d_fwd(g, x, w, bias, out, in_dtype=IN_F32, in_relu=False, out_relu=False, residual=None):
+def conv2d_fwd_bits_supported(g):
+  """conv2d_fwd(..., relu_bits=) is served for this geometry (the next layer's data gradient then takes the byte mask)."""
+  return bool(_lib.lib().seedhip_conv2d_fwd_bits_supported(ctypes.byref(g)))
+
+
+def conv2d_fwd(g, x, w, bias, out, in_dtype=IN_F32, in_relu=False, out_relu=False, residual=None, relu_bits=None):
+  """relu_bits (uint8 [n_img * oh * ow, cout / 4], where conv2d_fwd_bits_supported; needs out_relu, no residual): also
+  receives the ReLU mask of `out` as bytes -- bit r of byte q = out[pixel][4 q + r] > 0."""
+  if relu_bits is not None:
+    if residual is not None or not out_relu:
+      raise ValueError('conv2d_fwd: relu_bits needs out_relu=True and no residual')
+    flops, nbytes = _conv_cost(g, 1 if in_dtype else 4)
+    with _region(_conv_name('conv_fwd', g), flops, nbytes + g.n_img * g.oh * g.ow * g.cout // 8, pipe=lambda: _conv_pipe(g, 0)):
+      with _dev(out):
+        _lib.check(_lib.lib().seedhip_conv2d_fwd_bits(
+            ctypes.byref(g), _lib.ptr(x), in_dtype, int(in_relu), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out),
+            _lib.ptr(relu_bits), _lib.stream()), 'seedhip_conv2d_fwd_bits')
+      return out
   with _region(_conv_name('conv_fwd', g), *_conv_cost(g, 1 if in_dtype else 4), pipe=lambda: _conv_pipe(g, 0)):
     with _dev(out):
       ws, wsb = _splitk_ws(int(_lib.lib().seedhip_conv2d_fwd_workspace_bytes(ctypes.byref(g))), out)
@@ -199,7 +216,7 @@ def conv2d_bwd_data(g, dy, w, dx, relu_mask=None, add=None, relu_bits=None):
   if relu_bits is not None:
     if relu_mask is not None or add is not None:
       raise ValueError('conv2d_bwd_data: relu_bits excludes relu_mask / add')
-    with _region(_conv_name('conv_dgrad', g), flops, nbytes + g.n_img * g.ih * g.iw * g.cin // 8):
+    with _region(_conv_name('conv_dgrad', g), flops, nbytes + g.n_img * g.ih * g.iw * g.cin // 8, pipe=lambda: _conv_pipe(g, 1)):
       with _dev(dx):
         _lib.check(_lib.lib().seedhip_conv2d_bwd_data_bits(
             ctypes.byref(g), _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(relu_bits), _lib.stream()),
@@ -307,28 +324,6 @@ def conv2d_stack_bwd_weight(g, frames_ext, nvalid, dy, dw, dbias, workspace):
           ctypes.byref(g), _lib.ptr(frames_ext), _lib.ptr(nvalid), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(dbias),
           _lib.ptr(workspace), workspace.numel() * workspace.element_size(), _lib.stream()),
           'seedhip_conv2d_stack_bwd_weight')
-
-
-def conv2d_stack_bwd_weight_fused_supported(g0, g1):
-  """The first conv's weight gradient can be fused with the second conv's data gradient for this pair of geometries."""
-  return bool(_lib.lib().seedhip_conv2d_stack_bwd_weight_fused_supported(ctypes.byref(g0), ctypes.byref(g1)))
-
-
-def conv2d_stack_bwd_weight_fused_workspace_bytes(g0):
-  return int(_lib.lib().seedhip_conv2d_stack_bwd_weight_fused_workspace_bytes(ctypes.byref(g0)))
-
-
-def conv2d_stack_bwd_weight_fused(g0, g1, frames_ext, nvalid, act0, dy1, w1, dw0, dbias0, workspace):
-  """dw0 / dbias0 of the first conv from the SECOND conv's output gradient dy1: its data gradient, the ReLU mask (act0 > 0)
-  and the weight gradient in one kernel (seedhip.h); flops / bytes of both folded kernels."""
-  flops = 2.0 * g0.T * g0.B * g0.oh * g0.ow * g0.cout * g0.kh * g0.kw * 4 + _conv_cost(g1)[0]
-  nbytes = g0.T * g0.B * (g0.ih * g0.iw + g0.oh * g0.ow * g0.cout * 4 + g1.oh * g1.ow * g1.cout * 4)
-  with _region('stack_conv_wgrad_fused', flops, nbytes):
-    with _dev(dw0):
-      _lib.check(_lib.lib().seedhip_conv2d_stack_bwd_weight_fused(
-          ctypes.byref(g0), ctypes.byref(g1), _lib.ptr(frames_ext), _lib.ptr(nvalid), _lib.ptr(act0), _lib.ptr(dy1),
-          _lib.ptr(w1), _lib.ptr(dw0), _lib.ptr(dbias0), _lib.ptr(workspace),
-          workspace.numel() * workspace.element_size(), _lib.stream()), 'seedhip_conv2d_stack_bwd_weight_fused')
 
 
 def impala_loss_workspace_bytes(T, B):

@@ -50,6 +50,7 @@ def _truth_errs(agent, p32, p64, floor=1e-3):
   |g - g64| / max(max|g64|, floor); returns the worst tensor of each."""
   grads = agent.reference_gradients()
   out = dict(hip_max=(0.0, None), hip_q99=(0.0, None), oracle_max=(0.0, None), oracle_q99=(0.0, None), gate=(0.0, None))
+  gates = []
   for n, t64 in p64.items():
     r = t64.grad.numpy()
     den = max(float(np.abs(r).max()), floor)
@@ -62,6 +63,8 @@ def _truth_errs(agent, p32, p64, floor=1e-3):
                    ('gate', hq / (1.25 * oq + 5e-5))):
       if v >= out[key][0]:
         out[key] = (float(v), n)
+    gates.append((round(hq / (1.25 * oq + 5e-5), 3), n, float('%.3g' % hq), float('%.3g' % oq)))
+  out['gate_top'] = sorted(gates, reverse=True)[:6]
   return out
 
 
@@ -83,6 +86,7 @@ def _truth(out, agent, p32, run64, floor=1e-3):
   out['oracle_grad_max_rel_err_vs_fp64'], out['oracle_grad_worst_vs_fp64'] = e['oracle_max']
   out['oracle_grad_q99_rel_err_vs_fp64'] = e['oracle_q99'][0]
   out['grad_q99_gate_vs_fp64'], out['grad_q99_gate_worst'] = e['gate']
+  out['grad_q99_gate_top'] = e['gate_top']      # (ratio, tensor, HIP q99, oracle q99) of the six worst tensors
   out['fp64_s'] = round(time.perf_counter() - t0, 2)
 
 

@@ -937,7 +937,7 @@ def test_x8_data_gradient_path_in_child():
   assert r.returncode == 0 and '3 passed' in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize('T1,B', [(3, 5), (6, 37)])
+@pytest.mark.parametrize('T1,B', [(3, 5), (6, 37), (6, 50), (21, 37)])   # (300 / 777 images: the data gradient on wdx.h, byte mask in registers)
 def test_relu_byte_mask_pair(device, T1, B):
   """The shallow Atari torso's ReLU mask as bytes (seedhip_conv2d_stack_fwd_bits -> seedhip_conv2d_bwd_data_bits): the
   forward's activation is bit-identical to the plain call, byte [pixel][q] bit r = act[pixel][4 q + r] > 0, and the
@@ -985,60 +985,38 @@ def test_relu_byte_mask_pair(device, T1, B):
     ops.conv2d_bwd_data(ops.conv_geom(N, 20, 20, 32, 4, 4, 2, 'valid', 64), dy, w1, dx, relu_bits=bits)
 
 
-@pytest.mark.parametrize('T1,B,done_p', [(3, 5, 0.0), (6, 37, 0.3), (21, 3, 0.1)])
-def test_stack_wgrad_fused_with_conv1_dgrad(device, T1, B, done_p):
-  """seedhip_conv2d_stack_bwd_weight_fused (conv1 data gradient -> ReLU mask -> first conv's weight gradient in one
-  kernel) against the two-call path it replaces (conv2d_bwd_data with the fp32 mask, then conv2d_stack_bwd_weight) and
-  against an fp64 evaluation of the same chain: as close to the truth as the two-call path is (both are fp32
-  summation-order noise).  Episode ends inside the unroll exercise the nvalid channel skipping."""
+@pytest.mark.parametrize('n', [2100, 2304])
+def test_dense_relu_byte_mask_pair(device, n):
+  """The same pair one layer up (r5): the second Atari conv's forward also writes the ReLU mask of its output as bytes
+  (seedhip_conv2d_fwd_bits, wfx.h), and the Dense layer's data gradient (xgemm.h) reads those bytes -- indexed like
+  dX / 4 floats -- instead of the 111 MB fp32 activation.  Bit-identical to the fp32-mask path on both sides."""
   from seed_rl_amd import ops
-  N = T1 * B
-  u = synth.atari_unroll(11, T1, B, done_p=done_p, zero_state=False)
-  stacked, _ = frames_np.stack_frames(u['frames'], u['frame_state'], u['done'], 4)
-  rng = np.random.default_rng(3)
-  w0 = (rng.normal(size=(8, 8, 4, 16)) / 16).astype(np.float32)
-  b0 = (rng.normal(size=16) * 0.3).astype(np.float32)
-  w1 = (rng.normal(size=(4, 4, 16, 32)) / 16).astype(np.float32)
-  dy1 = rng.normal(size=(N, 9, 9, 32)).astype(np.float32)
-  HW = 84 * 84
-  ext = torch.zeros((T1 + 3, B, HW), dtype=torch.uint8, device=device)
-  ext[3:] = dev(u['frames'].reshape(T1, B, HW), device)
-  nv = torch.zeros((T1, B), dtype=torch.uint8, device=device)
-  ops.stack_prepare(dev(u['frame_state'], device), dev(u['done'].astype(np.uint8), device), T1, B, HW, ext, nv)
-  g0 = ops.StackConvGeom(T1, B, 84, 84, 20, 20, 8, 8, 4, 16, 16)
-  g1 = ops.conv_geom(N, 20, 20, 16, 4, 4, 2, 'valid', 32)
-  assert ops.conv2d_stack_bwd_weight_fused_supported(g0, g1)
-  assert not ops.conv2d_stack_bwd_weight_fused_supported(ops.StackConvGeom(T1, B, 84, 84, 20, 20, 8, 8, 4, 32, 32),
-                                                        ops.conv_geom(N, 20, 20, 32, 4, 4, 2, 'valid', 64))
-  act0 = torch.empty((N, 20, 20, 16), device=device)
-  ops.conv2d_stack_fwd(g0, ext, nv, dev(w0, device), dev(b0, device), act0, out_relu=True)
-  dy1d, w1d = dev(dy1, device), dev(w1, device)
-  # two-call path
-  dx = torch.empty((N, 20, 20, 16), device=device)
-  ops.conv2d_bwd_data(g1, dy1d, w1d, dx, relu_mask=act0)
-  dw_ref = torch.empty((8, 8, 4, 16), device=device); db_ref = torch.empty(16, device=device)
-  ws = torch.empty(ops.conv2d_stack_bwd_weight_workspace_bytes(g0) // 4 + 4, device=device)
-  ops.conv2d_stack_bwd_weight(g0, ext, nv, dx, dw_ref, db_ref, ws)
-  # fused
-  dw = torch.full((8, 8, 4, 16), float('nan'), device=device); db = torch.full((16,), float('nan'), device=device)
-  wsf = torch.empty(ops.conv2d_stack_bwd_weight_fused_workspace_bytes(g0) // 4 + 4, device=device)
-  ops.conv2d_stack_bwd_weight_fused(g0, g1, ext, nv, act0, dy1d, w1d, dw, db, wsf)
-  # fp64 truth of the chain from the SAME mask (the device's act0 > 0)
-  mask = (act0 > 0).cpu().numpy()
-  dy64 = torch.tensor(dy1.astype(np.float64))
-  x1 = torch.zeros((N, 20, 20, 16), dtype=torch.float64, requires_grad=True)
-  nets_torch.conv2d(x1, torch.tensor(w1.astype(np.float64)), None, 2, 'valid').backward(dy64)
-  dx64 = x1.grad.numpy() * mask
-  x0 = torch.tensor(stacked.astype(np.float64) / 255.0).reshape(N, 84, 84, 4)
-  w064 = torch.tensor(w0.astype(np.float64), requires_grad=True)
-  nets_torch.conv2d(x0, w064, None, 4, 'valid').backward(torch.tensor(dx64))
-  dw64, db64 = w064.grad.numpy(), dx64.sum(axis=(0, 1, 2))
-  for got, ref, truth in ((dw, dw_ref, dw64), (db, db_ref, db64)):
-    g_, r_ = got.cpu().numpy().astype(np.float64), ref.cpu().numpy().astype(np.float64)
-    scale = np.abs(truth).max()
-    e_fused, e_two = np.abs(g_ - truth).max(), np.abs(r_ - truth).max()
-    assert np.isfinite(g_).all()
-    assert e_fused <= max(2.0 * e_two, 4e-6 * scale), (e_fused, e_two, scale)
+  rng = np.random.default_rng(n)
+  g1 = ops.conv_geom(n, 20, 20, 16, 4, 4, 2, 'valid', 32)
+  gfc = ops.dense_geom(n, 2592, 256)
+  assert ops.conv2d_fwd_bits_supported(g1) and ops.conv2d_bwd_data_bits_supported(gfc)
+  assert not ops.conv2d_fwd_bits_supported(ops.conv_geom(n, 20, 20, 32, 4, 4, 2, 'valid', 64))
+  assert not ops.conv2d_bwd_data_bits_supported(ops.dense_geom(64, 2592, 256))          # (below the bf16x6 kernel's row count)
+  x = dev(rng.normal(size=(n, 20, 20, 16)).astype(np.float32), device)
+  w = dev((rng.normal(size=(4, 4, 16, 32)) / 16).astype(np.float32), device)
+  b = dev((rng.normal(size=32) * 0.5).astype(np.float32), device)
+  ref = torch.empty((n, 9, 9, 32), device=device)
+  ops.conv2d_fwd(g1, x, w, b, ref, out_relu=True)
+  out = torch.empty_like(ref)
+  bits = torch.full((n, 9, 9, 8), 0xAA, dtype=torch.uint8, device=device)
+  ops.conv2d_fwd(g1, x, w, b, out, out_relu=True, relu_bits=bits)
+  assert torch.equal(out, ref)
+  pos = (ref > 0).reshape(n, 9, 9, 8, 4).to(torch.uint8)
+  assert torch.equal(bits, pos[..., 0] | (pos[..., 1] << 1) | (pos[..., 2] << 2) | (pos[..., 3] << 3))
+  assert 0.2 < float(pos.float().mean()) < 0.8
+  dz = dev(rng.normal(size=(n, 256)).astype(np.float32), device)
+  wfc = dev((rng.normal(size=(2592, 256)) / 50).astype(np.float32), device)
+  dx_ref = torch.full((n, 2592), float('nan'), device=device)
+  ops.conv2d_bwd_data(gfc, dz, wfc, dx_ref, relu_mask=ref.view(n, 2592))
+  dx = torch.full((n, 2592), float('nan'), device=device)
+  ops.conv2d_bwd_data(gfc, dz, wfc, dx, relu_bits=bits)
+  assert torch.equal(dx, dx_ref)
+  assert bool((dx[~(ref.view(n, 2592) > 0)] == 0).all())
 
 
 @pytest.mark.parametrize('n,ih,iw', [(3, 72, 96), (2, 11, 9), (5, 8, 12), (1, 3, 3)])

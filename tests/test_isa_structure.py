@@ -41,7 +41,7 @@ def _ops(code_objects, co, name):
 
 def test_first_conv_reads_nvalid_through_the_scalar_cache(code_objects):
   # a vector load of nvalid[t, b] behind the band prefetch made every wave wait for that prefetch before its first MFMA
-  for pat in ('stackconv_fwd_bf16r_kernelILi0ELb0ELb1', 'stackconv_wgrad_cp_kernelILi16', 'stackconv_wgrad_fused_kernelILi0ELi8'):
+  for pat in ('stackconv_fwd_bf16r_kernelILi0ELb0ELb1', 'stackconv_wgrad_cp_kernelILi16'):
     for co, name, meta in _find(code_objects, pat):
       ops = _ops(code_objects, co, name)
       assert 'global_load_ubyte' not in ops, (pat, 'nvalid is read with a vector load again')
@@ -54,10 +54,15 @@ def test_register_budgets_of_the_hot_kernels(code_objects):
       'stackconv_fwd_bf16r_kernelILi0ELb0ELb1ELb1': (168, 0),   # r4, buffer-addressed time loop: NO spill (8 spilled VGPRs were
                                                                  # reloaded behind s_waitcnt vmcnt(0) at the head of every step)
       'stackconv_fwd_bf16r_kernelILi0ELb0ELb0ELb1': (168, 0),
-      'wsw_lds_kernelILb0ELi21ELi0': (256, 0),                  # two 4-wave workgroups per CU (LDS)
-      'wfw_kernelILb0': (256, 0),
+      # r5: the bf16x6 weight gradients (wgx.h), two 4-wave workgroups per CU: no spill in any geometry
+      'wgx_kernelINS0_3GeoILi4ELi4ELi2ELi0ELi16ELi32': (256, 0),
+      'wgx_kernelINS0_3GeoILi3ELi3ELi1ELi1ELi16ELi16': (256, 0),
+      'wgx_kernelINS0_3GeoILi3ELi3ELi1ELi1ELi16ELi32': (256, 0),
+      'wgx_kernelINS0_3GeoILi3ELi3ELi1ELi1ELi32ELi32ELi18': (256, 0),
+      'wgx_kernelINS0_3GeoILi3ELi3ELi1ELi1ELi32ELi32ELi9': (256, 0),
       'wfx_kernelILb0ELb0ELi0': (256, 4),
-      'wdx_kernelILb1ELi0': (256, 0),
+      'wdx_kernelILi1ELi0': (256, 0),
+      'wdx_kernelILi2ELi0': (256, 0),                          # r5: the byte-mask variant
       'wsx_kernelINS0_3GeoILi18ELi24EEELb0': (256, 0),         # r4: ImpalaDeep's 32 -> 32 3x3 layers, forward / data gradient
       'wsx_kernelINS0_3GeoILi18ELi24EEELb1': (256, 0),
       'wsy_kernelINS0_3GeoILi36ELi48EEELb0': (256, 0),         # r4: the 16 -> 16 layers
@@ -68,8 +73,6 @@ def test_register_budgets_of_the_hot_kernels(code_objects):
       'stackconv_wgrad_cp_kernelILi16': (128, 0),              # two 8-wave workgroups per CU
       'ws_tab_kernelILi4ELi4ELi1ELi0ELb0ELb1': (128, 0),       # data gradient with the mask a tile ahead: four waves per SIMD
       'ws_tab_kernelILi2ELi8ELi0ELi0ELb0ELb0': (128, 0),
-      'wsw_kernelILb0ELi16ELi0': (256, 0),                     # one 4-wave workgroup per SIMD set: accumulators in AGPRs
-      'stackconv_wgrad_fused_kernelILi0ELi8': (256, 0),
   }
   for pat, (vmax, smax) in budget.items():
     for _, name, meta in _find(code_objects, pat):

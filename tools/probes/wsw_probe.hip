@@ -2,7 +2,7 @@
 // and the kernel with its MFMAs / its loads left out.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iseed_rl_amd/csrc -Iinclude tools/probes/wsw_probe.hip \
 //         seed_rl_amd/csrc/error.cpp -o tools/probes/wsw_probe.bin
-#include "wsw.h"
+#include "wsw.h"   // (moved here from csrc/ in r5; build with -I seed_rl_amd/csrc -I tools/probes)
 #include <vector>
 using namespace seedhip;
 using namespace seedhip::wsw;
