@@ -103,8 +103,8 @@ int slice_k(int K, int slices) { int per = (K + slices - 1) / slices; return (pe
 
 // Dense layers on gemm.h (see there).  mode bits (SEEDHIP_GEMM, default 255): 1 forward, 2 data gradient, 4 weight
 // gradient (8 / 16: wsgemm.h conv forward / data gradient; 32 / 64 / 128: gather-GEMM conv forward / data gradient / weight gradient); a cleared bit falls back to the Dense accessors of the implicit-GEMM core (A/B measurements).
-int conv_min_n() { static int v = getenv("SEEDHIP_CONV_MINN") ? atoi(getenv("SEEDHIP_CONV_MINN")) : 64; return v; }
-int gemm_mode() { static int m = getenv("SEEDHIP_GEMM") ? atoi(getenv("SEEDHIP_GEMM")) : 255; return m; }
+constexpr int conv_min_n() { return 64; }
+constexpr int gemm_mode() { return 255; }    // (r1-r3: bit mask of the GEMM-core dispatch for A/B runs; every bit is on)
 bool al16(const void* q) { return (((uintptr_t)q) & 15) == 0; }
 bool gemm_fwd_ok(const seedhip_conv_geom* g) {
   // rows may carry up to 3 pad columns (ld_in >= cin rounded up to 4; pads finite): the last k-vector of a row is
@@ -116,10 +116,7 @@ bool gemm_fwd_ok(const seedhip_conv_geom* g) {
 // per step): r02d before the second tiling budget of halo_fwd.h: 0 -> 25.0, 1 -> 24.3, 2 -> 25.4, 3 -> 24.7; with it:
 // 1 -> 21.25, 3 -> 21.17.  Stand-alone the gather-GEMM forward used to be the faster one (0.52 vs 0.56 ms) -- with the
 // ReLU'd input and the residual add of the real layers it was not; the halo forward now takes 0.47 ms.
-int halo_all() {
-  static const int v = getenv("SEEDHIP_HALO_ALL") ? atoi(getenv("SEEDHIP_HALO_ALL")) : 3;
-  return v;
-}
+constexpr int halo_all() { return 3; }
 bool gemm_dgrad_ok(const seedhip_conv_geom* g) { return (gemm_mode() & 2) && g->cout % 4 == 0 && g->ld_out % 4 == 0; }
 bool gemm_wgrad_ok(const seedhip_conv_geom* g) {
   return (gemm_mode() & 4) && g->ld_in % 4 == 0 && g->ld_in >= (g->cin + 3) / 4 * 4 && g->cout % 4 == 0 && g->ld_out % 4 == 0;
@@ -213,16 +210,20 @@ int check_geom(const seedhip_conv_geom* g, const char* what) {
 // Which matrix pipe serves this geometry (pass 0 forward, 1 data gradient, 2 weight gradient): 1 = fp32 MFMA
 // (v_mfma_f32_16x16x4_f32), 6 = bf16 MFMA through the exact three-way split of both operands (xgemm.h: six bf16 MACs per
 // algorithmic MAC).  What the bench prices a kernel's roofline with; 0 = unknown pass / null geometry.
-static int wsx_enabled() { static const int on = getenv("SEEDHIP_WSX") ? atoi(getenv("SEEDHIP_WSX")) : 1; return on; }
-static int wdx_enabled() { static const int on = getenv("SEEDHIP_WDX") ? atoi(getenv("SEEDHIP_WDX")) : 1; return on; }
-static int wgx_enabled() { static const int on = getenv("SEEDHIP_WGX") ? atoi(getenv("SEEDHIP_WGX")) : 1; return on; }
-static int wfx_enabled() { static const int on = getenv("SEEDHIP_WFX") ? atoi(getenv("SEEDHIP_WFX")) : 1; return on; }
+// ONE switch for the conv layers' bf16x6 kernels (wfx / wdx / wsx / wsy / wgx): SEEDHIP_CONV_BF16X6=0 puts those layers back
+// on the fp32-MFMA kernels (same-box A/B of the two pipes; tests/test_gpu_kernels.py runs the parity cases under it).
+// Bits: 1 forward, 2 data gradient, 4 weight gradient; default 7.
+static int conv_x6() { static const int on = getenv("SEEDHIP_CONV_BF16X6") ? atoi(getenv("SEEDHIP_CONV_BF16X6")) : 7; return on; }
+static int wsx_enabled(int pass) { return conv_x6() & (1 << pass); }
+static int wdx_enabled() { return conv_x6() & 2; }
+static int wgx_enabled() { return conv_x6() & 4; }
+static int wfx_enabled() { return conv_x6() & 1; }
 
 extern "C" int seedhip_conv2d_pipe(const seedhip_conv_geom* g, int pass) {
   if (!g || pass < 0 || pass > 2) return 0;
   if (pass == 0 && wfx_enabled()) { wfx::Params xp; if (wfx::plan(xp, g)) return 6; }
   if (pass == 1 && wdx_enabled()) { wdx::Params dp; if (wdx::plan(dp, g)) return 6; }
-  if (pass <= 1 && wsx_enabled() && (wsx::geometry(g) || wsy::geometry(g))) return 6;
+  if (pass <= 1 && wsx_enabled(pass) && (wsx::geometry(g) || wsy::geometry(g))) return 6;
   if (pass == 2 && wgx_enabled() && wgx::plan(g)) return 6;
   if (xg8::mode() & (1 << pass)) {
     const xg8::Plan x8 = pass == 0 ? x8_fwd_plan(g) : pass == 1 ? x8_dgrad_plan(g) : x8_wgrad_plan(g);
@@ -323,7 +324,7 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
   }
   {
     // the 32 -> 32 3x3 'same' layers of ImpalaDeep on the bf16 matrix pipe (wsx.h)
-    const int geo = wsx_enabled() && in_dtype == kInF32 ? wsx::geometry(geom) : 0;
+    const int geo = wsx_enabled(0) && in_dtype == kInF32 ? wsx::geometry(geom) : 0;
     if (geo && al16(in) && al16(w) && al16(out) && al16(bias) && al16(residual)) {
       wsx::Params sp;
       memset(&sp, 0, sizeof(sp));
@@ -332,7 +333,7 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
       const int rc2 = wsx::launch(geo, false, sp, (hipStream_t)stream);
       if (rc2 >= 0) return rc2;
     }
-    const int geo16 = wsx_enabled() && in_dtype == kInF32 ? wsy::geometry(geom) : 0;      // the 16 -> 16 layers (wsy.h)
+    const int geo16 = wsx_enabled(0) && in_dtype == kInF32 ? wsy::geometry(geom) : 0;      // the 16 -> 16 layers (wsy.h)
     if (geo16 && al16(in) && al16(w) && al16(out) && al16(bias) && al16(residual)) {
       wsx::Params sp;
       memset(&sp, 0, sizeof(sp));
@@ -549,7 +550,7 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
       pl.slices = 1; pl.k_per_slice = gp.K;
       // 'valid' convs with several taps: rows in image-block x position order, so that a workgroup tile shares one
       // super-pixel and skips the taps that fall outside dY (gemm_geom.h Gather::blk; A/B: SEEDHIP_DGRAD_POS=0)
-      static const int pos_major = getenv("SEEDHIP_DGRAD_POS") ? atoi(getenv("SEEDHIP_DGRAD_POS")) : 1;
+      constexpr int pos_major = 1;
       const int bm = (4 / pl.wn) * pl.mr * 16, nkt = (gp.K + gemm::BK - 1) / gemm::BK;
       const long long m_blk = (long long)((geom->n_img + bm - 1) / bm) * gp.ga.d1.d * bm;
       if (pos_major && geom->pad_t == 0 && geom->pad_l == 0 && gp.ga.ntaps > 1 && nkt <= 32 && geom->cout % gemm::BK == 0 &&
@@ -563,7 +564,7 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
   }
   {
     // the same layers' data gradient: wsx.h with the weights flipped and transposed
-    const int geo = wsx_enabled() ? wsx::geometry(geom) : 0;
+    const int geo = wsx_enabled(1) ? wsx::geometry(geom) : 0;
     if (geo && al16(dy) && al16(w) && al16(dx) && al16(relu_mask) && al16(add)) {
       wsx::Params sp;
       memset(&sp, 0, sizeof(sp));
@@ -571,7 +572,7 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
       const int rc2 = wsx::launch(geo, true, sp, (hipStream_t)stream);
       if (rc2 >= 0) return rc2;
     }
-    const int geo16 = wsx_enabled() ? wsy::geometry(geom) : 0;
+    const int geo16 = wsx_enabled(1) ? wsy::geometry(geom) : 0;
     if (geo16 && al16(dy) && al16(w) && al16(dx) && al16(relu_mask) && al16(add)) {
       wsx::Params sp;
       memset(&sp, 0, sizeof(sp));

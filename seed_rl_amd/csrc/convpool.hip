@@ -833,7 +833,7 @@ extern "C" int seedhip_conv3x3_u8_pool_fwd(const uint8_t* x, int n, int ih, int 
                   "conv3x3_u8_pool_fwd: w / bias / pooled must be 16-byte aligned, argmax 4-byte aligned");
   static const int use_mfma = getenv("SEEDHIP_CONVPOOL_MFMA") ? atoi(getenv("SEEDHIP_CONVPOOL_MFMA")) : 1;
   if (use_mfma && 4 * g.pw * 4 <= kMaxPoolItems && 9 * iw <= kMaxGroups * 16) {
-    static const int nthr = getenv("SEEDHIP_CONVPOOL_NT") ? atoi(getenv("SEEDHIP_CONVPOOL_NT")) : 256;
+    constexpr int nthr = 256;
     const bool row8 = iw % 8 == 0 && (2 * 4 + 3) * (iw / 8) <= 256 && (((uintptr_t)x) & 7) == 0;
     hipStream_t s = (hipStream_t)stream;
 #define SEEDHIP_CPF(R8_, NT_)                                                                                     \

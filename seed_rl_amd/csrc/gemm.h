@@ -574,8 +574,7 @@ inline Plan plan(int M, int N, int K, double bias44 = 1.0) {
   static const Tile kTiles[5] = {{2, 2, 5, 4.0, 2.7, 2}, {4, 2, 3, 2.5, 4.7, 2}, {4, 4, 2, 2.0, 6.0, 2},
                                  {2, 2, 5, 4.0, 2.7, 1}, {4, 2, 3, 2.5, 4.7, 1}};
   static const int kSlices[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512};
-  static const int force = getenv("SEEDHIP_GEMM_TILE") ? atoi(getenv("SEEDHIP_GEMM_TILE")) : 0;
-  static const int force_s = getenv("SEEDHIP_GEMM_SLICES") ? atoi(getenv("SEEDHIP_GEMM_SLICES")) : 0;
+  constexpr int force = 0, force_s = 0;                     // (r2 / r3: plans forced from the environment for the cost model's calibration)
   Plan best{2, 2, 1, (K + BK - 1) / BK * BK, 1e30, 2};
   for (const Tile& t : kTiles) {
     if (force && force != t.mr * 10 + t.nr + 100 * (t.wn == 1)) continue;
@@ -598,15 +597,6 @@ inline Plan plan(int M, int N, int K, double bias44 = 1.0) {
       if (slices > 1) us += 4.0 + (slices + 1.0) * M * N * 4.0 / 3.0e6;
       if (t.mr == 4 && t.nr == 4) us *= bias44;
       if (us < best.model_us) best = Plan{t.mr, t.nr, slices, per, us, t.wn};
-    }
-  }
-  if (getenv("SEEDHIP_GEMM_DEBUG")) {
-    static long long last = -1;
-    const long long key = ((long long)M << 40) ^ ((long long)N << 20) ^ K;
-    if (key != last) {
-      last = key;
-      fprintf(stderr, "[gemm] M=%d N=%d K=%d -> tile %dx%d slices %d (model %.1f us)\n", M, N, K,
-              (4 / best.wn) * best.mr * 16, best.wn * best.nr * 16, best.slices, best.model_us);
     }
   }
   return best;

@@ -419,15 +419,6 @@ inline FwdPlan plan_fwd(FwdParams& p, const ClassSpec* cs, int ncls, bool u8) {
 
 inline int launch_fwd_kernel(const FwdParams& p, const FwdPlan& pl, hipStream_t s) {
   const bool dg = p.wmode == 1;
-  if (getenv("SEEDHIP_HALO_DEBUG")) {
-    static long long last = -1;
-    const long long key = ((long long)p.ih << 40) ^ ((long long)p.iw << 28) ^ ((long long)p.cin << 16) ^ (p.cout << 4) ^ p.wmode ^ ((long long)p.ncls << 50);
-    if (key != last) {
-      last = key;
-      fprintf(stderr, "[halo_fwd] %s %dx%d cin %d cout %d stride %d classes %d -> TH %d (bands %d) MT %d NT %d XV %d lds %zu twp %d xs %d slices %d\n",
-              dg ? "dgrad" : "fwd", p.ih, p.iw, p.cin, p.cout, p.stride, p.ncls, pl.TH, p.bands, pl.MT, pl.NT, pl.XV, pl.lds, p.twp, p.xs, p.total_slices);
-    }
-  }
   if (dg ? (p.bias || p.residual || p.out_relu) : (p.mask || p.add))
     return fail(SEEDHIP_ERR_UNSUPPORTED, "halo_fwd: forward and data-gradient epilogues do not mix");
   if ((long long)p.OH * p.OW * p.ld_out * 4 >= (1LL << 31) || (long long)(p.thp + p.ih) * p.iw * p.ld_in * 4 >= (1LL << 31))

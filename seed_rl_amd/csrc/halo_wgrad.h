@@ -383,7 +383,7 @@ inline WgradPlan plan_wgrad(const seedhip_conv_geom* g) {
   pl.TH = th;
   const int bands = (g->oh + th - 1) / th;
   const long long ntiles = (long long)g->n_img * bands;
-  static const int cap = getenv("SEEDHIP_HALO_PERCU") ? atoi(getenv("SEEDHIP_HALO_PERCU")) : 2;
+  constexpr int cap = 2;
   int per_cu = (int)((160 * 1024) / pl.lds); if (per_cu > cap) per_cu = cap; if (per_cu < 1) per_cu = 1;
   const long long mg = 256LL * per_cu;
   pl.grid = (int)(ntiles < mg ? ntiles : mg);
@@ -401,19 +401,9 @@ inline int launch_wgrad(const seedhip_conv_geom* g, const WgradPlan& pl, const v
   p.kh = g->kh; p.kw = g->kw; p.stride = g->stride;
   p.TH = pl.TH; p.bands = (g->oh + pl.TH - 1) / pl.TH; p.ntiles = g->n_img * p.bands;
   p.rows = g->kh * g->kw * g->cin; p.xs = g->cin;
-  static const int ilv_on = getenv("SEEDHIP_HALO_ILV") ? atoi(getenv("SEEDHIP_HALO_ILV")) : 1;
-  p.ilv = (ilv_on && in_dtype == 0 && g->cin % 4 == 0 && g->ld_in % 4 == 0) ? 1 : 0;
+  p.ilv = (in_dtype == 0 && g->cin % 4 == 0 && g->ld_in % 4 == 0) ? 1 : 0;
   p.twp = (g->ow - 1) * g->stride + g->kw; p.thp = (pl.TH - 1) * g->stride + g->kh;
   p.d_ow.init(g->ow);
-  if (getenv("SEEDHIP_HALO_DEBUG")) {
-    static long long last = -1;
-    const long long key = ((long long)g->ih << 40) ^ ((long long)g->iw << 28) ^ ((long long)g->cin << 16) ^ g->cout;
-    if (key != last) {
-      last = key;
-      fprintf(stderr, "[halo_wgrad] %dx%d cin %d cout %d k %d stride %d -> TH %d (bands %d) MTW %d NT %d MSPLIT %d grid %d lds %zu\n",
-              g->ih, g->iw, g->cin, g->cout, g->kh, g->stride, pl.TH, p.bands, pl.MTW, pl.NT, pl.MSPLIT, pl.grid, pl.lds);
-    }
-  }
   p.partial_w = (float*)workspace;
   p.partial_b = dbias ? (float*)workspace + (size_t)pl.grid * p.rows * g->cout : nullptr;
 #define SEEDHIP_HALO_LAUNCH(MTW_, NT_, MS_)                                                                        \

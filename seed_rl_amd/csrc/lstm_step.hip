@@ -683,7 +683,7 @@ extern "C" int seedhip_lstm_seq_fwd_sticky(const float* up, const float* zx, con
   p.up = up; p.zx = zx; p.done = done; p.T1 = T1; p.B = B; p.H = H; p.z = z; p.h_out = h_out; p.ld_h = ld_h;
   p.hin = hin; p.cin = cin; p.abort_flag = (int*)sync_ws + 1; p.sticky = sticky_abort;
   { const char* e = getenv("SEEDHIP_LSTM_SEQ_FAULT"); p.fault = e ? atoi(e) : 0; }   // tests: exercise the bounded wait (read per call on purpose: tests flip it)
-  { static const int x = getenv("SEEDHIP_LSTM_SEQ_XCD") ? atoi(getenv("SEEDHIP_LSTM_SEQ_XCD")) : 1; p.xcd_local = x; }
+  p.xcd_local = 1;                                      // (plain stores where a row tile's workgroups share an XCD: verified at run time)
   const size_t lds = seq_lds_bytes(H);
   static const hipError_t attr_rc = hipFuncSetAttribute(
       (const void*)lstm_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)seq_lds_bytes(512));

@@ -1009,7 +1009,7 @@ int launch_fwd(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, cons
       hipLaunchKernelGGL((stackconv_fwd_bf16r_kernel<0, BITS_, RELU_, BUF_>), dim3(grid, 1, g->cout / 16), dim3(kThreads), lds, s, p); \
       return check_launch("stackconv_fwd_bf16r_kernel");                                                          \
     }
-    static const int buf_on = getenv("SEEDHIP_STACK_BUF") ? atoi(getenv("SEEDHIP_STACK_BUF")) : 1;
+    constexpr int buf_on = 1;
     const long long lim = (1LL << 31) - (1 << 20);
     p.buf32 = buf_on && (long long)(3 + p.T1) * p.B * p.fsz < lim && (long long)p.T1 * p.B * 400 * p.ld_out * 4 < lim;
     if (relu_bits) { if (p.buf32) SEEDHIP_SCF(true, true, true) else SEEDHIP_SCF(true, true, false) }
@@ -1154,7 +1154,7 @@ extern "C" int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* ge
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);                         \
         hipLaunchKernelGGL(stackconv::stackconv_wgrad_cp_kernel<LD_>, dim3(grid, 1, N / 16), dim3(64 * stackconv::kCW), ldsc, s, p); \
       }
-      static const int pair = getenv("SEEDHIP_STACK_PAIR") ? atoi(getenv("SEEDHIP_STACK_PAIR")) : 1;
+      constexpr int pair = 1;                              // (the channel-per-wave kernel of r1 is gone from the dispatch)
       if (pair) { if (geom->ld_out == 16) SEEDHIP_CP(16) else if (geom->ld_out == 32) SEEDHIP_CP(32) else SEEDHIP_CP(0) }
       else if (geom->ld_out == 16) SEEDHIP_CW(16) else if (geom->ld_out == 32) SEEDHIP_CW(32) else SEEDHIP_CW(0)
 #undef SEEDHIP_CW

@@ -101,7 +101,7 @@ __device__ __forceinline__ int end_row(int r, int total, int rows) {
 }
 
 // EXP (timing experiments only, results wrong): 1 no split / LDS writes, 2 no loads, 4 no MFMAs, 8 no operand reads
-template <bool TRACE, bool RELU_IN, int EXP = 0>
+template <bool TRACE, bool RELU_IN, int EXP = 0, bool BITS = false>
 __global__ void __launch_bounds__(512, 2)
 wfx_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -217,7 +217,7 @@ wfx_kernel(const Params p) {
           v[q] = p.out_relu ? __builtin_amdgcn_fmed3f(y, 0.f, __builtin_inff()) : y;
         }
         *reinterpret_cast<f32x4_t*>(blk + px * 128 + (((2 * g + kq) ^ (px & 7)) << 4)) = v;
-        if (p.bits && Pf < total) {                          // the next layer's data gradient reads this byte instead of the 16
+        if (BITS && Pf < total) {                          // the next layer's data gradient reads this byte instead of the 16
           const u32x4_t bu = __builtin_bit_cast(u32x4_t, v);  // (post-ReLU: > 0 <=> bit pattern != 0, see stackconv.hip)
           const unsigned m01 = ((bu[1] < 1u ? bu[1] : 1u) << 1) | (bu[0] < 1u ? bu[0] : 1u);
           const unsigned m23 = ((bu[3] < 1u ? bu[3] : 1u) << 1) | (bu[2] < 1u ? bu[2] : 1u);
@@ -333,15 +333,13 @@ inline int launch(Params& p, hipStream_t s) {
   p.per_wg = (p.n_img + cus - 1) / cus;
   const int grid = (p.n_img + p.per_wg - 1) / p.per_wg;
   constexpr int kBytes = kLds + kPart;
-  if (p.in_relu) {
-    static const bool ok = hipFuncSetAttribute((const void*)wfx_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kBytes) == hipSuccess;
-    if (!ok) return -1;
-    hipLaunchKernelGGL((wfx_kernel<false, true>), dim3(grid), dim3(512), kBytes, s, p);
-  } else {
-    static const bool ok = hipFuncSetAttribute((const void*)wfx_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kBytes) == hipSuccess;
-    if (!ok) return -1;
-    hipLaunchKernelGGL((wfx_kernel<false, false>), dim3(grid), dim3(512), kBytes, s, p);
-  }
+#define WFX_GO(R_, B_) { \
+    static const bool ok = hipFuncSetAttribute((const void*)wfx_kernel<false, R_, 0, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, kBytes) == hipSuccess; \
+    if (!ok) return -1; \
+    hipLaunchKernelGGL((wfx_kernel<false, R_, 0, B_>), dim3(grid), dim3(512), kBytes, s, p); }
+  if (p.bits) { if (p.in_relu) WFX_GO(true, true) else WFX_GO(false, true) }
+  else if (p.in_relu) WFX_GO(true, false) else WFX_GO(false, false)
+#undef WFX_GO
   return check_launch("wfx_kernel");
 }
 

@@ -335,7 +335,12 @@ wgx_kernel(const Params p) {
     __syncthreads();
   }
   f32x4_t* pw = reinterpret_cast<f32x4_t*>(p.partial_w + (long long)blockIdx.x * (G::M * G::COUT));
-  for (int i = tid; i < G::M * G::COUT / 4; i += 256) pw[i] = *reinterpret_cast<const f32x4_t*>(smem + i * 16);
+  for (int i = tid; i < G::M * G::COUT / 4; i += 256) {
+    pw[i] = *reinterpret_cast<const f32x4_t*>(smem + i * 16);
+    // (a 16-byte store reads its data registers over several cycles; hipcc reuses them for the next ds_read in the very
+    // next issue slot -- tools/isa_store_hazard.py -- so keep a wait state between the two)
+    asm volatile("s_nop 4" ::: "memory");
+  }
 }
 
 // ---- the served geometries ----------------------------------------------------------------------------------------- //

@@ -667,10 +667,8 @@ ws_tab_kernel(const Params p) {
 
 // `dry`: no launch -- SEEDHIP_OK iff the call would be served (the byte-mask query of conv.hip).
 inline int launch(Params& p, Plan& pl, hipStream_t s, bool dry = false) {
-  static const int force_mr = getenv("SEEDHIP_WS_MR") ? atoi(getenv("SEEDHIP_WS_MR")) : 0;
-  static const int force_w = getenv("SEEDHIP_WS_WAVES") ? atoi(getenv("SEEDHIP_WS_WAVES")) : 0;
-  pl.mr = force_mr ? force_mr : 1;                           // measured (cfg2 step): 16-row wave tiles, 8 waves per workgroup
-  const int waves = force_w ? force_w : 8;
+  pl.mr = 1;                                                 // measured (cfg2 step): 16-row wave tiles, 8 waves per workgroup
+  constexpr int waves = 8;
   const int ldb = pl.nr == 2 ? p.N + 8 : p.N;
   pl.lds = ((size_t)p.K * ldb + (size_t)waves * 16 * pl.mr * LDA) * sizeof(float);
   p.ntiles = (p.M + 16 * pl.mr - 1) / (16 * pl.mr);          // wave tiles
@@ -678,16 +676,14 @@ inline int launch(Params& p, Plan& pl, hipStream_t s, bool dry = false) {
   const int wgs = (p.ntiles + waves - 1) / waves;
   pl.grid = wgs < 256 * per_cu ? wgs : 256 * per_cu;
   // the specialised kernel: MR = 1, 8 waves, static k-tile count
-  static const int fast = getenv("SEEDHIP_WS_FAST") ? atoi(getenv("SEEDHIP_WS_FAST")) : 1;
-  if (fast && pl.mr == 1 && waves == 8 && p.gw >= 8 && !p.a_relu && p.a_bytes < (1LL << 31) - (1 << 20) && p.c_bytes < (1LL << 31) &&
+  if (pl.mr == 1 && waves == 8 && p.gw >= 8 && !p.a_relu && p.a_bytes < (1LL << 31) - (1 << 20) && p.c_bytes < (1LL << 31) &&
       (p.mode == 1 || (long long)p.M * p.ldc < (1LL << 32) - 64)) {
     // 100-128 VGPRs: four waves per SIMD, i.e. two 8-wave workgroups per CU are resident whatever LDS allows; a
     // persistent grid of exactly the resident workgroups avoids a second, ragged round (data gradient 0.196 -> 0.189 ms)
     if (wgs > 256 * 2) pl.grid = 256 * 2;
     // table-driven variant (ws_tab_kernel): dense output rows, no residual / add, data gradient with whole super-pixels
     // and 16-channel-aligned classes
-    static const int tab = getenv("SEEDHIP_WS_TAB") ? atoi(getenv("SEEDHIP_WS_TAB")) : 1;
-    const bool tab_ok = tab && !p.residual && !p.add && p.gh * p.gw <= 1024 &&
+    const bool tab_ok = !p.residual && !p.add && p.gh * p.gw <= 1024 &&
         (p.mode == 0 ? (p.ldc == p.N && p.ldc % 4 == 0)
                      : (p.cin % 16 == 0 && p.gh * p.s == p.ih && p.gw * p.s == p.iw && p.c_bytes < (1LL << 31) - (1 << 20)));
     if (tab_ok) {
@@ -702,8 +698,7 @@ inline int launch(Params& p, Plan& pl, hipStream_t s, bool dry = false) {
         return check_launch("ws_tab_kernel(byte mask)");
       }
       if (dry) return SEEDHIP_OK;
-      static const int mpf = getenv("SEEDHIP_WS_MPF") ? atoi(getenv("SEEDHIP_WS_MPF")) : 1;
-      if (mpf && p.mask && pl.nr == 4 && p.nkt == 4 && p.mode == 1 && lds <= 72 * 1024) {
+      if (p.mask && pl.nr == 4 && p.nkt == 4 && p.mode == 1 && lds <= 72 * 1024) {
         if (lds > 64 * 1024)
           (void)hipFuncSetAttribute((const void*)ws_tab_kernel<4, 4, 1, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((ws_tab_kernel<4, 4, 1, 0, false, true>), dim3(pl.grid), dim3(512), lds, s, p);
@@ -743,8 +738,7 @@ inline int launch(Params& p, Plan& pl, hipStream_t s, bool dry = false) {
     hipLaunchKernelGGL((ws_kernel<MR_, NR_, W_>), dim3(pl.grid), dim3(64 * W_), pl.lds, s, p);                    \
     return check_launch("ws_kernel");                                                                             \
   }
-  SEEDHIP_WS(2, 2, 8) SEEDHIP_WS(2, 4, 8) SEEDHIP_WS(1, 2, 8) SEEDHIP_WS(1, 4, 8) SEEDHIP_WS(2, 2, 4) SEEDHIP_WS(2, 4, 4)
-  SEEDHIP_WS(2, 2, 16) SEEDHIP_WS(2, 4, 16) SEEDHIP_WS(4, 2, 8) SEEDHIP_WS(4, 4, 8) SEEDHIP_WS(1, 2, 16) SEEDHIP_WS(1, 4, 16)
+  SEEDHIP_WS(1, 2, 8) SEEDHIP_WS(1, 4, 8)     // (r2 swept MR 1 / 2 / 4 and 4 / 8 / 16 waves: these won and are the only ones built)
 #undef SEEDHIP_WS
   return fail(SEEDHIP_ERR_UNSUPPORTED, "wsgemm: no kernel for MR=%d NR=%d waves=%d", pl.mr, pl.nr, waves);
 }

@@ -75,9 +75,16 @@ __device__ __forceinline__ void split2_trunc(float a, float b, unsigned& h, unsi
   m = __builtin_amdgcn_perm(mb, ma, 0x07060302u);
   l = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
 }
+// The split the IN-KERNEL stagers of xgemm.h / xgemm8.h use for the operand they split on the way into LDS: by truncation
+// since r5 (plain full-rate VALU; the three v_cvt_pk_bf16_f32 of the round-to-nearest split issue at a quarter of that
+// rate and were most of the staging half's period: cfg2 Dense forward 97 -> 90 us, weight gradient 108 -> 97, data
+// gradient 117 -> 107, step 1.009 -> 0.987 ms, same-box A/B of two builds through SEEDHIP_LIB).  The operand that is
+// split ONCE per call (xsplit_kernel) keeps round-to-nearest, as do the weights of wfx.h / wdx.h / wsx.h / wsy.h: one
+// truncated and one rounded operand leave the dropped products am bl + al bm without a common sign.
+__device__ __forceinline__ void split2s(float a, float b, unsigned& h, unsigned& m, unsigned& l) { split2_trunc(a, b, h, m, l); }
 template <int EXP>
 __device__ __forceinline__ void split2x(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-  if (EXP & 256) split2_trunc(a, b, h, m, l); else split2(a, b, h, m, l);
+  if (EXP & 256) split2_trunc(a, b, h, m, l); else split2s(a, b, h, m, l);
 }
 
 __device__ __forceinline__ f32x4_t view_load_s(const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
@@ -424,7 +431,7 @@ inline Plan plan(int M, int N, int K, long long a_bytes, long long b_bytes, bool
   // fixed part being a workgroup's prologue and epilogue, plus the partial sums' round trip; at least 8 k-tiles each.
   const int nkt = (K + BK - 1) / BK;
   int s = 1;
-  static const int force = env_int("SEEDHIP_X6_SLICES", 0);
+  constexpr int force = 0;
   if (force > 0) s = force;
   else {
     const long long slots = 2LL * cu_count();

@@ -192,8 +192,8 @@ struct StageKC4 {
         h0 = m0 = l0 = __builtin_amdgcn_perm(__float_as_uint(r[i][1]), __float_as_uint(r[i][0]), 0x07060302u);
         h1 = m1 = l1 = __builtin_amdgcn_perm(__float_as_uint(r[i][3]), __float_as_uint(r[i][2]), 0x07060302u);
       } else {
-        xg::split2(r[i][0], r[i][1], h0, m0, l0);
-        xg::split2(r[i][2], r[i][3], h1, m1, l1);
+        xg::split2s(r[i][0], r[i][1], h0, m0, l0);
+        xg::split2s(r[i][2], r[i][3], h1, m1, l1);
       }
       unsigned char* d = lds + wofs + i * (32 * 64);
       *reinterpret_cast<xg::u32x2_t*>(d) = xg::u32x2_t{h0, h1};
@@ -234,8 +234,8 @@ struct StageOC4 {
         h0 = m0 = l0 = __builtin_amdgcn_perm(__float_as_uint(r[1][e]), __float_as_uint(r[0][e]), 0x07060302u);
         h1 = m1 = l1 = __builtin_amdgcn_perm(__float_as_uint(r[3][e]), __float_as_uint(r[2][e]), 0x07060302u);
       } else {
-        xg::split2(r[0][e], r[1][e], h0, m0, l0);
-        xg::split2(r[2][e], r[3][e], h1, m1, l1);
+        xg::split2s(r[0][e], r[1][e], h0, m0, l0);
+        xg::split2s(r[2][e], r[3][e], h1, m1, l1);
       }
       unsigned char* d = lds + xg::oc_chunk(4 * xq + e, c) + kh * 8;
       *reinterpret_cast<xg::u32x2_t*>(d) = xg::u32x2_t{h0, h1};
@@ -630,7 +630,7 @@ inline Plan plan(int M, int N, int K, long long a_bytes, bool a_pre, bool want_c
   if (tiles > (1 << 20)) return pl;
   // slices: one workgroup per CU; cost ~ rounds(tiles * s) * (k-tiles per slice + fixed) + the partial sums' round trip
   int s = 1;
-  static const int force = xg::env_int("SEEDHIP_X8_SLICES", 0);
+  constexpr int force = 0;
   if (force > 0) s = force;
   else {
     const long long slots = xg::cu_count();

@@ -241,7 +241,7 @@ class _Agent(object):
     return head
 
   def _skinny_heads(self, feat_dim):
-    return os.environ.get('SEEDHIP_HEADS', '1') != '0' and ops.heads_supported(feat_dim, self._ldh)
+    return ops.heads_supported(feat_dim, self._ldh)
 
   def _head_bwd(self, feat, feat_dim, d_head, rows, dx, relu_mask, wsb):
     """Gradients of the packed heads: heads/kernel, heads/bias into the flat gradient buffer and dx [rows, feat_dim] =

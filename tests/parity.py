@@ -49,7 +49,8 @@ def _truth_errs(agent, p32, p64, floor=1e-3):
   """Both fp32 evaluations against the fp64 evaluation of the same graph, per tensor as max and as 99th percentile of
   |g - g64| / max(max|g64|, floor); returns the worst tensor of each."""
   grads = agent.reference_gradients()
-  out = dict(hip_max=(0.0, None), hip_q99=(0.0, None), oracle_max=(0.0, None), oracle_q99=(0.0, None), gate=(0.0, None))
+  out = dict(hip_max=(0.0, None), hip_q99=(0.0, None), oracle_max=(0.0, None), oracle_q99=(0.0, None), gate=(0.0, None),
+             gate_bias=(0.0, None))
   gates = []
   for n, t64 in p64.items():
     r = t64.grad.numpy()
@@ -60,7 +61,7 @@ def _truth_errs(agent, p32, p64, floor=1e-3):
     for key, v in (('hip_max', dh.max()), ('hip_q99', hq), ('oracle_max', do.max()), ('oracle_q99', oq),
                    # the PER-TENSOR gate (VERDICT r4 task 7a): HIP's q99 distance to fp64 over (1.25 x the fp32 oracle's
                    # + 5e-5); <= 1 means this tensor is as close to the truth as the fp32 oracle's, to a quarter
-                   ('gate', hq / (1.25 * oq + 5e-5))):
+                   ('gate_bias' if n.endswith('bias') else 'gate', hq / (1.25 * oq + 5e-5))):
       if v >= out[key][0]:
         out[key] = (float(v), n)
     gates.append((round(hq / (1.25 * oq + 5e-5), 3), n, float('%.3g' % hq), float('%.3g' % oq)))
@@ -85,7 +86,8 @@ def _truth(out, agent, p32, run64, floor=1e-3):
   out['grad_q99_rel_err_vs_fp64'], out['grad_q99_worst_vs_fp64'] = e['hip_q99']
   out['oracle_grad_max_rel_err_vs_fp64'], out['oracle_grad_worst_vs_fp64'] = e['oracle_max']
   out['oracle_grad_q99_rel_err_vs_fp64'] = e['oracle_q99'][0]
-  out['grad_q99_gate_vs_fp64'], out['grad_q99_gate_worst'] = e['gate']
+  out['grad_q99_gate_vs_fp64'], out['grad_q99_gate_worst'] = e['gate']                 # kernels (matrices)
+  out['grad_q99_gate_bias_vs_fp64'], out['grad_q99_gate_bias_worst'] = e['gate_bias']   # bias vectors
   out['grad_q99_gate_top'] = e['gate_top']      # (ratio, tensor, HIP q99, oracle q99) of the six worst tensors
   out['fp64_s'] = round(time.perf_counter() - t0, 2)
 

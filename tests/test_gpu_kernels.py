@@ -937,6 +937,34 @@ def test_x8_data_gradient_path_in_child():
   assert r.returncode == 0 and '3 passed' in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
 
 
+# Every switch the library / the agents still read from the environment selects a DIFFERENT kernel path than the default
+# one; each is exercised once, in a child process (the library reads its switches once), by the tests that cover the
+# default path.  ("every knob that stays gets one GPU test in a child process".)
+KNOB_CHILDREN = [
+    # (environment, test file, -k expression)
+    (dict(SEEDHIP_CONV_BF16X6='0'), 'test_gpu_kernels.py', 'conv_fwd_bwd_parity or conv_residual'),   # conv layers back on the fp32 pipe
+    (dict(SEEDHIP_X6='0', SEEDHIP_X8='0'), 'test_gpu_kernels.py', 'dense_padded_rows or test_conv_fwd_bwd_parity'),   # Dense layers on gemm.h
+    (dict(SEEDHIP_STACK_BF16='0'), 'test_gpu_kernels.py', 'test_stack_conv_parity'),                    # fp32-MFMA first conv
+    (dict(SEEDHIP_CONVPOOL_MFMA='0'), 'test_gpu_kernels.py', 'test_convpool_fused_parity'),             # round-1 vector-ALU first stage
+    (dict(SEEDHIP_RELU_BITS='0'), 'test_gpu_agent.py', ''),                                             # fp32 ReLU masks through the shallow torso
+    (dict(SEEDHIP_LSTM_SEQ='0'), 'test_gpu_deep.py', ''),                                               # one launch per LSTM step
+]
+
+
+@pytest.mark.parametrize('k', range(len(KNOB_CHILDREN)))
+def test_environment_switches_in_child(k):
+  import os, subprocess, sys
+  env, fname, expr = KNOB_CHILDREN[k]
+  if os.environ.get('SEEDHIP_KNOB_CHILD') == '1':
+    pytest.skip('this IS a child')
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  cmd = [sys.executable, '-m', 'pytest', os.path.join(root, 'tests', fname), '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider']
+  if expr:
+    cmd += ['-k', expr]
+  r = subprocess.run(cmd, env=dict(os.environ, SEEDHIP_KNOB_CHILD='1', **env), capture_output=True, text=True, timeout=900, cwd=root)
+  assert r.returncode == 0 and ' passed' in r.stdout and ' failed' not in r.stdout, (env, r.stdout[-3000:], r.stderr[-2000:])
+
+
 @pytest.mark.parametrize('T1,B', [(3, 5), (6, 37), (6, 50), (21, 37)])   # (300 / 777 images: the data gradient on wdx.h, byte mask in registers)
 def test_relu_byte_mask_pair(device, T1, B):
   """The shallow Atari torso's ReLU mask as bytes (seedhip_conv2d_stack_fwd_bits -> seedhip_conv2d_bwd_data_bits): the

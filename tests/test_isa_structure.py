@@ -60,7 +60,8 @@ def test_register_budgets_of_the_hot_kernels(code_objects):
       'wgx_kernelINS0_3GeoILi3ELi3ELi1ELi1ELi16ELi32': (256, 0),
       'wgx_kernelINS0_3GeoILi3ELi3ELi1ELi1ELi32ELi32ELi18': (256, 0),
       'wgx_kernelINS0_3GeoILi3ELi3ELi1ELi1ELi32ELi32ELi9': (256, 0),
-      'wfx_kernelILb0ELb0ELi0': (256, 4),
+      'wfx_kernelILb0ELb0ELi0ELb0': (256, 4),
+      'wfx_kernelILb0ELb0ELi0ELb1': (256, 6),                   # r5: + the byte mask of its output (one scratch round trip per round)
       'wdx_kernelILi1ELi0': (256, 0),
       'wdx_kernelILi2ELi0': (256, 0),                          # r5: the byte-mask variant
       'wsx_kernelINS0_3GeoILi18ELi24EEELb0': (256, 0),         # r4: ImpalaDeep's 32 -> 32 3x3 layers, forward / data gradient
