@@ -34,6 +34,7 @@
 // the ring held in bf16, weight gradient with a channel-per-wave organisation.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 #include "conv_problems.h"
 #include "conv_launch.h"
 #include "../../include/seedhip.h"
@@ -617,22 +618,9 @@ stackconv_fwd_bf16r_kernel(const Params p) {
   }
 }
 
-// ------------------------------------------------------------------------------------ //
-// bf16x3 weight gradient, channel-per-wave decomposition.
-// A band-per-wave kernel (as the fp32 one) keeps all 16 m-tiles (256 k-rows x 16 channels = 64 accumulator VGPRs) in
-// every wave and ended up at ~250 VGPRs: one 5-wave workgroup per CU, the matrix pipe idling on LDS latency (0.27 ms).
-// Here the OUTPUT is split instead (0.24 ms): wave (c, half) owns stack channel c -- the four m-tiles (c, q = 0..3),
-// 16 accumulator VGPRs -- and walks half of the frame's 13 pixel groups; its A operand is frame t - c, whole, from a
-// workgroup-shared ring of bf16 frames (5 slots: frame t+4 is staged while step t computes, ONE barrier per step).
-// 124 VGPRs, 8 waves per workgroup, 2 workgroups per CU.  dY fragments are loaded and split per wave (the 4 channel
-// waves repeat it: 44 VALU per 12 MFMAs), no cross-channel reduction exists, the two halves of a channel are summed
-// through LDS at the end.  Channels c >= nvalid skip the step (forward: cumulative-OR done mask).
-// ------------------------------------------------------------------------------------ //
+// (r1-r4: the channel-per-wave / channel-pair weight-gradient kernels lived here; r5: the transposing-read kernel below)
 constexpr int kFrame16 = kIH * kIW * 2;                  // 14112 B: one frame in bf16
 constexpr int kFrameSlots = 5;
-constexpr int kChunks = 50, kGroups32 = 13;              // 8-pixel chunks (2 rows x 4) and 32-pixel MFMA groups per frame
-constexpr int kCW = 8;                                   // waves: (channel c = w & 3, half = w >> 2)
-
 __device__ __forceinline__ void frame_store16(unsigned char* slot, const uint4& v, int idx) {   // 16 bytes -> 16 bf16
   uint4 a, b;
   cvt16(v, a, b);
@@ -640,305 +628,209 @@ __device__ __forceinline__ void frame_store16(unsigned char* slot, const uint4& 
   reinterpret_cast<uint4*>(slot)[2 * idx + 1] = b;
 }
 
+// ------------------------------------------------------------------------------------ //
+// bf16x3 weight gradient through TRANSPOSING LDS reads (r5).
+// The channel-pair kernel of r2-r4 built every MFMA A operand -- eight pixels of one kernel position -- from sixteen
+// 8-byte LDS reads and sixteen v_perm per channel and group, and loads dY with 4-byte global loads: ~6 VALU per MFMA
+// on a matrix pipe that was 0.36 busy (125 us in rocprofv3; this kernel: 123.5 us at 2.9 VALU per MFMA, matrix pipe 0.38 busy,
+// and 134-138 us against 140-145 inside the cfg2 step, where its 16-byte dY loads contend less).  ds_read_b64_tr_b16 (wgx.h) hands a lane the four k-values (pixels) of one
+// column of a [4 pixels][16 columns] block whose rows are addressed per lane: with the frames as bf16 rows in LDS
+// (what the ring already holds), the 16 columns of a block are kernel positions (ky, kx = 0..7), (ky + 1, kx = 0..7)
+// -- two runs of 16 contiguous bytes of two frame rows -- and the rows are output pixels (their windows start 4 input
+// pixels = 8 bytes apart: neighbouring pixels' reads overlap and broadcast).  No permutes, no gathers:
+//   * dW[(ky, kx, c), co] = sum over steps and pixels of X[pixel; ky, kx, c] dY[pixel, co]: MFMA 16 x 16 x 32, rows =
+//     16 kernel positions of one stack channel (tile = (c, ky pair)), columns = 16 output channels, reduction = 32
+//     pixels; pixels are exact in bf16, dY is split ONCE per element into three bf16 planes [pixel][16] in LDS (16-byte
+//     items from registers requested a step ahead) and read through the same transposing reads;
+//   * 8 waves: wave (c = w & 3, wk = w >> 2) owns the four tiles of stack channel c (16 accumulator registers for the
+//     whole launch) and the k-steps of parity wk; per k-step 6 reads for dY's planes, 8 for the frames, 12 MFMAs;
+//   * double-buffered dY planes: the planes of step t + 1 are written (and frame t + 4 converted into the ring) in the
+//     same barrier interval in which step t is multiplied -- waves 0-3 prepare first and multiply second, waves 4-7
+//     the other way round, so a SIMD's two waves want different pipes; ONE barrier per step;
+//   * a stack channel outside the episode (c >= nvalid[t, b]) skips its wave's MFMAs of that step.
+// LDS: 5 frame slots (70.6 KB) + 2 x 39.9 KB of dY planes: one 8-wave workgroup per CU.
+// ------------------------------------------------------------------------------------ //
+constexpr int kTrKS = 13;                                 // 32-pixel k-steps of a 400-pixel frame (416: 16 zero pixels)
+constexpr int kTrYPlane = kTrKS * 32 * 32;                // bytes of one bf16 plane of dY: [416 pixels][16 channels]
+constexpr int kTrYBuf = 3 * kTrYPlane;                    // 39 936
+constexpr int kTrLds = kFrameSlots * kFrame16 + 2 * kTrYBuf;   // 150 432
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8_t tr_operand(const unsigned char* base, unsigned o0, unsigned o1) {
+  typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+  const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(base + o0));
+  const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(base + o1));
+  const s16x8_t v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
 template <int LD>                                        // row stride of dY (floats) when it is 16 or 32, else 0 = run time
-__global__ void __launch_bounds__(64 * kCW)
-stackconv_wgrad_cw_kernel(const Params p) {
+__global__ void __launch_bounds__(512, 2)
+stackconv_wgrad_tr_kernel(const Params p) {
   const int ld_out = LD ? LD : p.ld_out;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = wave & 3, half = wave >> 2;
-  const int kq = lane >> 4, i = lane & 15;
+  unsigned char* ybuf = smem + kFrameSlots * kFrame16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = wave & 3, wk = wave >> 2;                 // stack channel; parity of this wave's k-steps
+  const int g = lane >> 4, c16 = lane & 15, jrow = c16 >> 2, q = c16 & 3;
   const int co0 = blockIdx.z * 16;
   constexpr int P = 400, kVec = kIH * kIW / 16;           // 441 uint4 per uint8 frame
+  constexpr int kKPW = (kTrKS + 1) / 2;                   // k-steps per wave (7 / 6)
+
+  for (int i = tid * 16; i < 2 * kTrYBuf; i += 512 * 16) *reinterpret_cast<uint4*>(ybuf + i) = make_uint4(0, 0, 0, 0);
+
+  // per-lane operand offsets of this wave's k-steps (step independent): pixel of element j of read rd in 16-lane group
+  // g is 16 (g >> 1) + 8 rd + 4 (g & 1) + j (a half-wave covers 8 consecutive pixels: no bank conflicts)
+  unsigned xb[kKPW][2], yb[kKPW][2];
+#pragma unroll
+  for (int jj = 0; jj < kKPW; ++jj)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int pix = (wk + 2 * jj) * 32 + 16 * (g >> 1) + 8 * rd + 4 * (g & 1) + jrow;
+      const int pc = pix < P ? pix : P - 1;               // (padding pixels: dY's zero rows; X at the last real pixel)
+      const int oy = pc / kOW, ox = pc - oy * kOW;
+      // lanes q = 0, 1 supply kernel row 2 kyp (columns kx = 0..3 / 4..7), q = 2, 3 the row below
+      xb[jj][rd] = (unsigned)(((4 * oy + (q >> 1)) * kIW + 4 * ox + 4 * (q & 1)) * 2);
+      yb[jj][rd] = (unsigned)(pix * 32 + q * 8);
+    }
 
   f32x4_t acc[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
+  for (int t4 = 0; t4 < 4; ++t4) acc[t4] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  f32x4_t bsum = {0.f, 0.f, 0.f, 0.f};
 
-  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
-    const int b = item % p.B, chunk = item / p.B;
-    const int t0 = chunk * p.spc;
-    const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
-    __syncthreads();                                      // previous item's last step is done with the ring
-    for (int e = 0; e < 4; ++e) {                         // ext rows t0 .. t0+3 -> slots
-      const uint4* src = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t0 + e) * p.B + b) * p.fsz);
-      for (int idx = tid; idx < kVec; idx += 64 * kCW) frame_store16(smem + ((t0 + e) % kFrameSlots) * kFrame16, src[idx], idx);
+  // dY of one step: 1600 16-byte items (pixel = item >> 2, channel quad = item & 3), four per thread (the last partly)
+  const char* dy_base = reinterpret_cast<const char*>(p.dy);
+  f32x4_t ly[4];
+  auto issue_dy = [&](int t, int b) {
+    const unsigned dy_t = (unsigned)(((long long)t * p.B + b) * P * ld_out + co0) * 4u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int it = tid + 512 * j;
+      if (j < 3 || it < 4 * P)
+        ly[j] = *reinterpret_cast<const f32x4_t*>(dy_base + (dy_t + (unsigned)(((it >> 2) * ld_out + 4 * (it & 3)) * 4)));
     }
-    __syncthreads();
-    for (int t = t0; t < t1; ++t) {
-      const bool more = t + 1 < t1;
-      uint4 pf = make_uint4(0, 0, 0, 0);                  // 441 vectors over 512 threads: one each
-      if (more && tid < kVec)
-        pf = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t + 4) * p.B + b) * p.fsz)[tid];
-      const int nv = p.nvalid[(long long)t * p.B + b];
-      if (c < nv) {
-        const unsigned char* frame = smem + ((t + 3 - c) % kFrameSlots) * kFrame16;
-        // dY of this step as 32-bit offsets from the uniform base (saddr + voffset loads: no 64-bit VALU adds)
-        const char* dy_base = reinterpret_cast<const char*>(p.dy);
-        const unsigned dy_t = ((unsigned)(((long long)t * p.B + b) * P * ld_out) + (unsigned)(co0 + i)) * 4u;   // bytes
-        auto chunk_geom = [&](int g, bool& ok, int& aoff, unsigned& doff) {
-          const int ch = 4 * g + kq;
-          ok = ch < kChunks;
-          const int cc = ok ? ch : 0, rp = cc / 5, xc = cc - rp * 5;
-          aoff = ((8 * rp + (i >> 1)) * kIW + 16 * xc + 4 * (i & 1)) * 2;
-          doff = dy_t + (unsigned)((2 * rp * kOW + 4 * xc) * ld_out) * 4u;
-        };
-        // dY of a group: 8 pixels (2 rows x 4) of this lane's output channel.  Only the last group has lanes without a
-        // chunk (50 chunks = 12.5 groups): the zero-select is confined to it by a uniform branch.
-        auto load_dy = [&](int g, float (&dst)[8], int& aoff) {
-          bool ok; unsigned doff;
-          chunk_geom(g, ok, aoff, doff);
-          if (g == kGroups32 - 1) {
+  };
+  auto put_dy = [&](unsigned char* dst) {                 // registers -> three planes (split by truncation, exact)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+    for (int j = 0; j < 4; ++j) {
+      const int it = tid + 512 * j;
+      if (j < 3 || it < 4 * P) {
+        const f32x4_t v = ly[j];
+        bsum += v;
+        uint32_t h[4], m[4], l[4];
 #pragma unroll
-              for (int bb = 0; bb < 4; ++bb) { const float tv = *reinterpret_cast<const float*>(dy_base + (doff + (unsigned)((a * kOW + bb) * ld_out) * 4u)); dst[4 * a + bb] = ok ? tv : 0.f; }
-          } else {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-              for (int bb = 0; bb < 4; ++bb) dst[4 * a + bb] = *reinterpret_cast<const float*>(dy_base + (doff + (unsigned)((a * kOW + bb) * ld_out) * 4u));
-          }
-        };
-        // one group: split this group's dY, request the next group's (in flight under the MFMAs), 12 MFMAs.  The two
-        // dY register sets alternate STATICALLY (the loop below is unrolled by two): no copies.
-        auto group = [&](int g, const float (&cur)[8], int aoff_cur, float (&nxt)[8], int& aoff_nxt) {
-          Frag8 bf[3];
-          if (c == 0) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bsum += cur[e];
-          }
-          split3_pack(cur, bf);
-          const unsigned char* src = frame + aoff_cur;
-          if (g + 2 < kGroups32) load_dy(g + 2, nxt, aoff_nxt);
-          uint2 d[2][4];
-#pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb)
-              d[a][bb] = *reinterpret_cast<const uint2*>(src + (a * 4 * kIW + 4 * bb) * 2);
-          Frag8 xa[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const uint32_t sel = (q & 1) ? 0x07060302u : 0x05040100u;
-            if (q < 2)
-              xa[q].u = make_uint4(__builtin_amdgcn_perm(d[0][1].x, d[0][0].x, sel), __builtin_amdgcn_perm(d[0][3].x, d[0][2].x, sel),
-                                   __builtin_amdgcn_perm(d[1][1].x, d[1][0].x, sel), __builtin_amdgcn_perm(d[1][3].x, d[1][2].x, sel));
-            else
-              xa[q].u = make_uint4(__builtin_amdgcn_perm(d[0][1].y, d[0][0].y, sel), __builtin_amdgcn_perm(d[0][3].y, d[0][2].y, sel),
-                                   __builtin_amdgcn_perm(d[1][1].y, d[1][0].y, sel), __builtin_amdgcn_perm(d[1][3].y, d[1][2].y, sel));
-          }
-#pragma unroll
-          for (int s3 = 2; s3 >= 0; --s3)                   // lo, mid, hi; the four accumulators alternate
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[q].v, bf[s3].v, acc[q], 0, 0, 0);
-        };
-        float dyA[8], dyB[8];
-        int aoffA, aoffB = 0;
-        load_dy(half, dyA, aoffA);
-        for (int g = half; g < kGroups32; g += 4) {
-          group(g, dyA, aoffA, dyB, aoffB);
-          if (g + 2 < kGroups32) group(g + 2, dyB, aoffB, dyA, aoffA);
+        for (int e = 0; e < 4; ++e) {
+          h[e] = __float_as_uint(v[e]) & 0xFFFF0000u;
+          const float r1 = v[e] - __uint_as_float(h[e]);
+          m[e] = __float_as_uint(r1) & 0xFFFF0000u;
+          l[e] = __float_as_uint(r1 - __uint_as_float(m[e]));
         }
-      }
-      if (more) {
-        if (tid < kVec) frame_store16(smem + ((t + 4) % kFrameSlots) * kFrame16, pf, tid);   // a slot no wave reads in step t
-        __syncthreads();                                  // frame t+4 visible; every wave is done with step t
+        unsigned char* d = dst + it * 8;
+        *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
+        *reinterpret_cast<uint2*>(d + kTrYPlane) = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
+        *reinterpret_cast<uint2*>(d + 2 * kTrYPlane) = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
       }
     }
-  }
-
-  // ---- the two halves of a channel -> one tile (half 1 through LDS), written straight into the partial slice ----
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);            // [c][q][lane][4]
-  if (half == 1) {
+  };
+  // the MFMAs of one step: frames of ext rows t .. t + 3 in the ring, dY planes in `yp`; the operands of k-step jj + 1 are
+  // requested before the twelve MFMAs of k-step jj (pinned)
+  auto multiply = [&](auto wkc, int t, const unsigned char* yp) {
+    constexpr int WK = decltype(wkc)::value;              // (compile time: the k-step list is static, no branches inside)
+    const unsigned char* frame = smem + ((t + 3 - c) % kFrameSlots) * kFrame16;
+    bf16x8_t bf[2][3], xa[2][4];
+    auto fetch = [&](int jj, bf16x8_t (&b3)[3], bf16x8_t (&a4)[4]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4_t*>(red + ((c * 4 + q) * 64 + lane) * 4) = acc[q];
+      for (int s3 = 0; s3 < 3; ++s3) b3[s3] = tr_operand(yp, yb[jj][0] + s3 * kTrYPlane, yb[jj][1] + s3 * kTrYPlane);
+#pragma unroll
+      for (int kyp = 0; kyp < 4; ++kyp) a4[kyp] = tr_operand(frame, xb[jj][0] + kyp * (2 * kIW * 2), xb[jj][1] + kyp * (2 * kIW * 2));
+    };
+    fetch(0, bf[0], xa[0]);
+#pragma unroll
+    for (int jj = 0; jj < kKPW; ++jj) {
+      if (WK + 2 * jj < kTrKS) {
+        if (jj + 1 < kKPW && WK + 2 * (jj + 1) < kTrKS) fetch(jj + 1, bf[(jj + 1) & 1], xa[(jj + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s3 = 2; s3 >= 0; --s3)                   // lo, mid, hi; the four accumulators alternate
+#pragma unroll
+          for (int kyp = 0; kyp < 4; ++kyp)
+            acc[kyp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[jj & 1][kyp], bf[jj & 1][s3], acc[kyp], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  auto run = [&](auto wkc) {
+    constexpr int WK = decltype(wkc)::value;
+    for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+      const int b = item % p.B, chunk = item / p.B;
+      const int t0 = chunk * p.spc;
+      const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
+      __syncthreads();                                      // previous item's last step is done with the ring and the planes
+      for (int e = 0; e < 4; ++e) {                         // ext rows t0 .. t0 + 3 -> slots
+        const uint4* src = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t0 + e) * p.B + b) * p.fsz);
+        for (int idx = tid; idx < kVec; idx += 512) frame_store16(smem + ((t0 + e) % kFrameSlots) * kFrame16, src[idx], idx);
+      }
+      issue_dy(t0, b);
+      put_dy(ybuf + (t0 & 1) * kTrYBuf);
+      if (t0 + 1 < t1) issue_dy(t0 + 1, b);
+      __syncthreads();
+      for (int t = t0; t < t1; ++t) {
+        const bool more = t + 1 < t1;
+        const int nv = nvalid_at(p.nvalid, (long long)t * p.B + b);
+        uint4 pf = make_uint4(0, 0, 0, 0);
+        if (more && tid < kVec)
+          pf = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t + 4) * p.B + b) * p.fsz)[tid];
+        const unsigned char* yp = ybuf + (t & 1) * kTrYBuf;
+        auto prepare = [&]() {                              // step t + 1: its dY planes; step t + 2's dY requested
+          if (more) {
+            put_dy(ybuf + ((t + 1) & 1) * kTrYBuf);
+            if (t + 2 < t1) issue_dy(t + 2, b);
+          }
+        };
+        if (WK == 0) { prepare(); if (c < nv) multiply(wkc, t, yp); }
+        else { if (c < nv) multiply(wkc, t, yp); prepare(); }
+        // the frame requested at the head of this step goes into the ring LAST (its load has had the whole step)
+        if (more && tid < kVec) frame_store16(smem + ((t + 4) % kFrameSlots) * kFrame16, pf, tid);   // a slot no wave reads in step t
+        __syncthreads();                                    // planes / frame of step t + 1 visible; every wave done with step t
+      }
+    }
+  };
+  if (wk == 0) run(std::integral_constant<int, 0>()); else run(std::integral_constant<int, 1>());
+
+  // ---- the two k-step parities of a channel -> one tile set per channel (parity 1 through LDS), straight into the slice
+  float* red = reinterpret_cast<float*>(smem);            // [c][tile][lane][4]
+  if (wk == 1) {
+#pragma unroll
+    for (int kyp = 0; kyp < 4; ++kyp) *reinterpret_cast<f32x4_t*>(red + ((c * 4 + kyp) * 64 + lane) * 4) = acc[kyp];
   }
   __syncthreads();
-  if (half == 0) {
+  if (wk == 0) {
     float* pw = p.partial_w + (long long)blockIdx.x * 256 * p.cout;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4_t o = *reinterpret_cast<const f32x4_t*>(red + ((c * 4 + q) * 64 + lane) * 4);
+    for (int kyp = 0; kyp < 4; ++kyp) {
+      const f32x4_t o = acc[kyp] + *reinterpret_cast<const f32x4_t*>(red + ((c * 4 + kyp) * 64 + lane) * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 4 * kq + r;                       // k-row within the m-tile
-        const int ky = row >> 1, kx = 4 * (row & 1) + q;
-        pw[((ky * 8 + kx) * 4 + c) * p.cout + co0 + i] = (acc[q][r] + o[r]) / 255.0f;
+        const int m = 4 * g + r;                          // row of the tile: kernel position (2 kyp + m / 8, m % 8)
+        const int ky = 2 * kyp + (m >> 3), kx = m & 7;
+        pw[((ky * 8 + kx) * 4 + c) * p.cout + co0 + c16] = o[r] / 255.0f;
       }
     }
   }
-  if (p.partial_b) {                                      // sum over the pixels of dY: the two c = 0 waves hold it
-    bsum += __shfl_xor(bsum, 16, 64);
-    bsum += __shfl_xor(bsum, 32, 64);
-    float* redb = red + 16 * 64 * 4;
-    if (c == 0 && lane < 16) redb[half * 16 + lane] = bsum;
+  if (p.partial_b) {                                      // thread t summed output channels 4 (t & 3) .. + 3 of its dY items
     __syncthreads();
-    if (tid < 16) p.partial_b[(long long)blockIdx.x * p.cout + co0 + tid] = redb[tid] + redb[16 + tid];
-  }
-}
-
-// Channel-PAIR variant of the kernel above: a wave owns two stack channels and a quarter of the pixel groups, so the
-// exact three-way bf16 split of a group's dY (5.5 VALU per element -- and VALU work does not overlap MFMAs) is done
-// once for 24 MFMAs instead of once for 12: wave = (cp = w & 1, quarter = w >> 1), 32 accumulator VGPRs.
-template <int LD>                                        // row stride of dY (floats) when it is 16 or 32, else 0 = run time
-__global__ void __launch_bounds__(64 * kCW) __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: two workgroups per CU
-stackconv_wgrad_cp_kernel(const Params p) {
-  const int ld_out = LD ? LD : p.ld_out;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cp = wave & 1, quarter = wave >> 1;          // stack channels 2cp, 2cp + 1; pixel groups quarter, quarter + 4, ...
-  const int kq = lane >> 4, i = lane & 15;
-  const int co0 = blockIdx.z * 16;
-  constexpr int P = 400, kVec = kIH * kIW / 16;           // 441 uint4 per uint8 frame
-
-  f32x4_t acc[2][4];
-#pragma unroll
-  for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[ch][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
-
-  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
-    const int b = item % p.B, chunk = item / p.B;
-    const int t0 = chunk * p.spc;
-    const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
-    __syncthreads();                                      // previous item's last step is done with the ring
-    for (int e = 0; e < 4; ++e) {                         // ext rows t0 .. t0+3 -> slots
-      const uint4* src = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t0 + e) * p.B + b) * p.fsz);
-      for (int idx = tid; idx < kVec; idx += 64 * kCW) frame_store16(smem + ((t0 + e) % kFrameSlots) * kFrame16, src[idx], idx);
+    f32x4_t* redb = reinterpret_cast<f32x4_t*>(smem + 16384);
+    redb[tid] = bsum;
+    __syncthreads();
+    if (tid < 16) {
+      float sacc = 0.f;
+      for (int u = tid >> 2; u < 512; u += 4) sacc += reinterpret_cast<const float*>(redb + u)[tid & 3];
+      p.partial_b[(long long)blockIdx.x * p.cout + co0 + tid] = sacc;
     }
-    __syncthreads();
-    for (int t = t0; t < t1; ++t) {
-      const bool more = t + 1 < t1;
-      const int nv = nvalid_at(p.nvalid, (long long)t * p.B + b);
-      uint4 pf = make_uint4(0, 0, 0, 0);                  // 441 vectors over 512 threads: one each
-      if (more && tid < kVec)
-        pf = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t + 4) * p.B + b) * p.fsz)[tid];
-      if (2 * cp < nv) {
-        const bool two = 2 * cp + 1 < nv;                   // the pair's second channel is inside the episode too
-        const unsigned char* frame0 = smem + ((t + 3 - 2 * cp) % kFrameSlots) * kFrame16;
-        const unsigned char* frame1 = smem + ((t + 2 - 2 * cp) % kFrameSlots) * kFrame16;
-        // dY of this step as 32-bit offsets from the uniform base (saddr + voffset loads: no 64-bit VALU adds)
-        const char* dy_base = reinterpret_cast<const char*>(p.dy);
-        const unsigned dy_t = ((unsigned)(((long long)t * p.B + b) * P * ld_out) + (unsigned)(co0 + i)) * 4u;   // bytes
-        auto chunk_geom = [&](int g, bool& ok, int& aoff, unsigned& doff) {
-          const int ch = 4 * g + kq;
-          ok = ch < kChunks;
-          const int cc = ok ? ch : 0, rp = cc / 5, xc = cc - rp * 5;
-          aoff = ((8 * rp + (i >> 1)) * kIW + 16 * xc + 4 * (i & 1)) * 2;
-          doff = dy_t + (unsigned)((2 * rp * kOW + 4 * xc) * ld_out) * 4u;
-        };
-        // dY of a group: 8 pixels (2 rows x 4) of this lane's output channel.  Only the last group has lanes without a
-        // chunk (50 chunks = 12.5 groups): the zero-select is confined to it by a uniform branch.
-        auto load_dy = [&](int g, float (&dst)[8], int& aoff) {
-          bool ok; unsigned doff;
-          chunk_geom(g, ok, aoff, doff);
-          if (g == kGroups32 - 1) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-              for (int bb = 0; bb < 4; ++bb) { const float tv = *reinterpret_cast<const float*>(dy_base + (doff + (unsigned)((a * kOW + bb) * ld_out) * 4u)); dst[4 * a + bb] = ok ? tv : 0.f; }
-          } else {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-              for (int bb = 0; bb < 4; ++bb) dst[4 * a + bb] = *reinterpret_cast<const float*>(dy_base + (doff + (unsigned)((a * kOW + bb) * ld_out) * 4u));
-          }
-        };
-        // one group: split this group's dY, request the next group's (in flight under the MFMAs), 12 MFMAs.  The two
-        // dY register sets alternate STATICALLY (the loop below is unrolled by two): no copies.
-        auto group = [&](int g, const float (&cur)[8], int aoff_cur, float (&nxt)[8], int& aoff_nxt) {
-          Frag8 bf[3];
-          if (cp == 0) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bsum += cur[e];
-          }
-          split3_pack(cur, bf);                           // ONCE for both channels of the pair
-          const int ao = aoff_cur;
-          if (g + 4 < kGroups32) load_dy(g + 4, nxt, aoff_nxt);
-#pragma unroll
-          for (int ch = 0; ch < 2; ++ch) {
-            if (ch == 1 && !two) break;
-            const unsigned char* src = (ch ? frame1 : frame0) + ao;
-            uint2 d[2][4];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-              for (int bb = 0; bb < 4; ++bb)
-                d[a][bb] = *reinterpret_cast<const uint2*>(src + (a * 4 * kIW + 4 * bb) * 2);
-            Frag8 xa[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const uint32_t sel = (q & 1) ? 0x07060302u : 0x05040100u;
-              if (q < 2)
-                xa[q].u = make_uint4(__builtin_amdgcn_perm(d[0][1].x, d[0][0].x, sel), __builtin_amdgcn_perm(d[0][3].x, d[0][2].x, sel),
-                                     __builtin_amdgcn_perm(d[1][1].x, d[1][0].x, sel), __builtin_amdgcn_perm(d[1][3].x, d[1][2].x, sel));
-              else
-                xa[q].u = make_uint4(__builtin_amdgcn_perm(d[0][1].y, d[0][0].y, sel), __builtin_amdgcn_perm(d[0][3].y, d[0][2].y, sel),
-                                     __builtin_amdgcn_perm(d[1][1].y, d[1][0].y, sel), __builtin_amdgcn_perm(d[1][3].y, d[1][2].y, sel));
-            }
-#pragma unroll
-            for (int s3 = 2; s3 >= 0; --s3)                 // lo, mid, hi; the four accumulators alternate
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-                acc[ch][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[q].v, bf[s3].v, acc[ch][q], 0, 0, 0);
-          }
-        };
-        float dyA[8], dyB[8];
-        int aoffA, aoffB = 0;
-        load_dy(quarter, dyA, aoffA);
-        for (int g = quarter; g < kGroups32; g += 8) {
-          group(g, dyA, aoffA, dyB, aoffB);
-          if (g + 4 < kGroups32) group(g + 4, dyB, aoffB, dyA, aoffA);
-        }
-      }
-      if (more) {
-        if (tid < kVec) frame_store16(smem + ((t + 4) % kFrameSlots) * kFrame16, pf, tid);   // a slot no wave reads in step t
-        __syncthreads();                                  // frame t+4 visible; every wave is done with step t
-      }
-    }
-  }
-
-  // ---- the four pixel quarters of a channel pair -> one tile per channel (quarters 1..3 through LDS, fixed order),
-  // written straight into the partial slice ----
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);            // [cp][quarter - 1][ch][q][lane][4]: 48 KB of the 70 KB ring
-  if (quarter > 0) {
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<f32x4_t*>(red + ((((cp * 3 + quarter - 1) * 2 + ch) * 4 + q) * 64 + lane) * 4) = acc[ch][q];
-  }
-  __syncthreads();
-  if (quarter == 0) {
-    float* pw = p.partial_w + (long long)blockIdx.x * 256 * p.cout;
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4_t o = acc[ch][q];
-#pragma unroll
-        for (int qq = 0; qq < 3; ++qq) o += *reinterpret_cast<const f32x4_t*>(red + ((((cp * 3 + qq) * 2 + ch) * 4 + q) * 64 + lane) * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 4 * kq + r;                     // k-row within the m-tile
-          const int ky = row >> 1, kx = 4 * (row & 1) + q;
-          pw[((ky * 8 + kx) * 4 + 2 * cp + ch) * p.cout + co0 + i] = o[r] / 255.0f;
-        }
-      }
-  }
-  if (p.partial_b) {                                      // sum over the pixels of dY: the four cp = 0 waves hold it
-    bsum += __shfl_xor(bsum, 16, 64);
-    bsum += __shfl_xor(bsum, 32, 64);
-    float* redb = red + 2 * 3 * 2 * 4 * 64 * 4;
-    if (cp == 0 && lane < 16) redb[quarter * 16 + lane] = bsum;
-    __syncthreads();
-    if (tid < 16) p.partial_b[(long long)blockIdx.x * p.cout + co0 + tid] = (redb[tid] + redb[16 + tid]) + (redb[32 + tid] + redb[48 + tid]);
   }
 }
 
@@ -1036,7 +928,7 @@ int wgrad_grid(const seedhip_stack_conv_geom* g, int* spc, int* items) {
   if (per_cu > 2) per_cu = 2;                     // measured: 2 workgroups per CU beat 3 (0.43 vs 0.48 ms at cfg2)
   if (per_cu < 1) per_cu = 1;
   static const int bf16x3 = getenv("SEEDHIP_STACK_BF16") ? atoi(getenv("SEEDHIP_STACK_BF16")) : 1;
-  if (bf16x3) per_cu = 2;                             // channel-per-wave kernel: 70 KB LDS, 124 VGPRs x 8 waves
+  if (bf16x3) per_cu = 1;                             // transposing-read kernel: 150 KB of LDS, one 8-wave workgroup per CU
   int grid;
   decompose(g->T, g->B, max_grid_for(per_cu), spc, items, &grid);
   return grid;
@@ -1142,23 +1034,14 @@ extern "C" int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* ge
     static const int bf16x3 = getenv("SEEDHIP_STACK_BF16") ? atoi(getenv("SEEDHIP_STACK_BF16")) : 1;
     if (bf16x3) {
       const size_t ldsc = (size_t)stackconv::kFrameSlots * stackconv::kFrame16;
-#define SEEDHIP_CW(LD_)                                                                                            \
+#define SEEDHIP_TR(LD_)                                                                                            \
       {                                                                                                           \
-        (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_cw_kernel<LD_>,                          \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);                         \
-        hipLaunchKernelGGL(stackconv::stackconv_wgrad_cw_kernel<LD_>, dim3(grid, 1, N / 16), dim3(64 * stackconv::kCW), ldsc, s, p); \
+        (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_tr_kernel<LD_>,                          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)stackconv::kTrLds);            \
+        hipLaunchKernelGGL(stackconv::stackconv_wgrad_tr_kernel<LD_>, dim3(grid, 1, N / 16), dim3(512), stackconv::kTrLds, s, p); \
       }
-#define SEEDHIP_CP(LD_)                                                                                            \
-      {                                                                                                           \
-        (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_cp_kernel<LD_>,                          \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);                         \
-        hipLaunchKernelGGL(stackconv::stackconv_wgrad_cp_kernel<LD_>, dim3(grid, 1, N / 16), dim3(64 * stackconv::kCW), ldsc, s, p); \
-      }
-      constexpr int pair = 1;                              // (the channel-per-wave kernel of r1 is gone from the dispatch)
-      if (pair) { if (geom->ld_out == 16) SEEDHIP_CP(16) else if (geom->ld_out == 32) SEEDHIP_CP(32) else SEEDHIP_CP(0) }
-      else if (geom->ld_out == 16) SEEDHIP_CW(16) else if (geom->ld_out == 32) SEEDHIP_CW(32) else SEEDHIP_CW(0)
-#undef SEEDHIP_CW
-#undef SEEDHIP_CP
+      if (geom->ld_out == 16) SEEDHIP_TR(16) else if (geom->ld_out == 32) SEEDHIP_TR(32) else SEEDHIP_TR(0)
+#undef SEEDHIP_TR
     }
     else
       hipLaunchKernelGGL(stackconv::stackconv_wgrad_kernel, dim3(grid, 1, N / 16), dim3(stackconv::kThreads), lds, s, p);

@@ -41,7 +41,7 @@ def _ops(code_objects, co, name):
 
 def test_first_conv_reads_nvalid_through_the_scalar_cache(code_objects):
   # a vector load of nvalid[t, b] behind the band prefetch made every wave wait for that prefetch before its first MFMA
-  for pat in ('stackconv_fwd_bf16r_kernelILi0ELb0ELb1', 'stackconv_wgrad_cp_kernelILi16'):
+  for pat in ('stackconv_fwd_bf16r_kernelILi0ELb0ELb1', 'stackconv_wgrad_tr_kernelILi16'):
     for co, name, meta in _find(code_objects, pat):
       ops = _ops(code_objects, co, name)
       assert 'global_load_ubyte' not in ops, (pat, 'nvalid is read with a vector load again')
@@ -71,7 +71,7 @@ def test_register_budgets_of_the_hot_kernels(code_objects):
                        # r4: one 8-wave workgroup per CU; the spilled registers are prologue-only
       'xg8_kernelILi0ELi0': (256, 0),                           # one 8-wave workgroup per CU: two waves per SIMD
       'xg8_kernelILi1ELi0': (256, 0),
-      'stackconv_wgrad_cp_kernelILi16': (128, 0),              # two 8-wave workgroups per CU
+      'stackconv_wgrad_tr_kernelILi16': (256, 0),              # r5: one 8-wave workgroup per CU (150 KB of LDS)
       'ws_tab_kernelILi4ELi4ELi1ELi0ELb0ELb1': (128, 0),       # data gradient with the mask a tile ahead: four waves per SIMD
       'ws_tab_kernelILi2ELi8ELi0ELi0ELb0ELb0': (128, 0),
   }

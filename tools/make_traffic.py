@@ -16,8 +16,7 @@ import sys
 REGIONS = [
     ('conv_fwd[4x4/2 16->32 @20x20]', 'wfx::wfx_kernel'),                      # r4: bf16x6 forward / data gradient
     ('conv_dgrad[4x4/2 16->32 @20x20]', 'wdx::wdx_kernel'),
-    ('conv_fwd[4x4/2 16->32 @20x20]', 'wfw::wfw_kernel'),                      # r4: image-resident forward
-    ('conv_wgrad[4x4/2 16->32 @20x20]', 'wsw::wsw_lds_kernel'),                # r4: LDS-staged weight gradient
+    ('conv_wgrad[4x4/2 16->32 @20x20]', 'wgx::wgx_kernel'),                    # r5: bf16x6 weight gradient (transposing LDS reads)
     ('conv_fwd[1x1/1 2592->256 @1x1]', 'xg8::xg8_kernel<0'),                   # r4: bf16x6 Dense kernels
     ('conv_wgrad[1x1/1 2592->256 @1x1]', 'xg8::xg8_kernel<1'),
     ('conv_dgrad[1x1/1 2592->256 @1x1]', 'xg8::xg8_kernel<2'),
