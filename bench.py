@@ -338,7 +338,10 @@ def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, 
   if not d['avg_ms'] > 0.0:
     d = dict(d, avg_ms=1e-6); free = dict(free, avg_ms=1e-6)
   flops, nbytes = d['flops'], d['bytes']
-  if flops > 0:
+  # the roofline that BOUNDS the kernel: the larger of its two floors at the spec peaks (r5: the first conv's kernels have
+  # flops, but their 351 MB at 8 TB/s take longer than their 35 GF on the bf16x3 ceiling -- they are priced against HBM)
+  mfma_bound = flops > 0 and flops / (_peak(d)[0] * 1e12) >= nbytes / (HBM_PEAK_GBS * 1e9)
+  if mfma_bound:
     peak, pipe_desc = _peak(d)
     ach, ach_free = flops / (d['avg_ms'] * 1e-3) / 1e12, flops / (free['avg_ms'] * 1e-3) / 1e12
     roofline = dict(bound='mfma', kernel=dominant, achieved=round(ach, 2), peak=round(peak, 1),
@@ -350,6 +353,9 @@ def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, 
     ach, ach_free = nbytes / (d['avg_ms'] * 1e-3) / 1e9, nbytes / (free['avg_ms'] * 1e-3) / 1e9
     roofline = dict(bound='hbm', kernel=dominant, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, algorithmic_bytes=nbytes)
+    if flops > 0:                                            # (its matrix-pipe side, for reference)
+      roofline.update(algorithmic_flops=flops, mfma_tflops=round(flops / (d['avg_ms'] * 1e-3) / 1e12, 2),
+                      mfma_frac=round(flops / (d['avg_ms'] * 1e-3) / 1e12 / _peak(d)[0], 4), pipe=_peak(d)[1])
   # two clocks, both reported: `frac` / `frac_serialized` divide by the kernel's duration with the device drained before
   # it (what rocprofv3 --kernel-trace --stats shows: profiles/ must agree with THIS one); `frac_free_running` by its
   # duration in back-to-back steps, where it starts behind its producer with operands still in L2 / MALL

@@ -39,8 +39,32 @@ REGIONS = [
 ]
 
 
+REGIONS_CFG3 = [
+    ('conv_fwd[3x3/1 16->16 @36x48]', 'wsy::wsy_kernel<seedhip::wsy::Geo<36, 48>, false>'),
+    ('conv_dgrad[3x3/1 16->16 @36x48]', 'wsy::wsy_kernel<seedhip::wsy::Geo<36, 48>, true>'),
+    ('conv_fwd[3x3/1 32->32 @18x24]', 'wsx::wsx_kernel<seedhip::wsx::Geo<18, 24>, false>'),
+    ('conv_dgrad[3x3/1 32->32 @18x24]', 'wsx::wsx_kernel<seedhip::wsx::Geo<18, 24>, true>'),
+    ('conv_fwd[3x3/1 32->32 @9x12]', 'wsx::wsx_kernel<seedhip::wsx::Geo<9, 12>, false>'),
+    ('conv_dgrad[3x3/1 32->32 @9x12]', 'wsx::wsx_kernel<seedhip::wsx::Geo<9, 12>, true>'),
+    ('conv_wgrad[3x3/1 16->16 @36x48]', 'wgx::wgx_kernel<seedhip::wgx::Geo<3, 3, 1, 1, 16, 16'),
+    ('conv_wgrad[3x3/1 16->32 @36x48]', 'wgx::wgx_kernel<seedhip::wgx::Geo<3, 3, 1, 1, 16, 32'),
+    ('conv_wgrad[3x3/1 32->32 @18x24]', 'wgx::wgx_kernel<seedhip::wgx::Geo<3, 3, 1, 1, 32, 32, 18'),
+    ('conv_wgrad[3x3/1 32->32 @9x12]', 'wgx::wgx_kernel<seedhip::wgx::Geo<3, 3, 1, 1, 32, 32, 9'),
+    ('conv_fwd[3x3/1 16->32 @36x48]', 'halo::halo_fwd_kernel<3, 2, false'),
+    ('conv_dgrad[3x3/1 16->32 @36x48]', 'halo::halo_fwd_kernel<3, 1, true'),
+    ('convpool_fwd[72x96x3->16]', 'convpool_fwd_mfma_kernel'),
+    ('convpool_bwd[72x96x3->16]', 'convpool_bwd_mfma_kernel'),
+    ('maxpool_fwd[36x48x32]', 'maxpool_fwd_kernel'),
+    ('maxpool_bwd[36x48x32]', 'maxpool_bwd_kernel'),
+]
+
+
 def main():
   src, out = sys.argv[1], sys.argv[2]
+  global REGIONS
+  cfg = sys.argv[3] if len(sys.argv) > 3 else 'cfg2'
+  if cfg == 'cfg3':
+    REGIONS = REGIONS_CFG3
   rows = list(csv.reader(open(src)))[1:]
   traffic, fetch, write, kernel = {}, {}, {}, {}
   for region, pat in REGIONS:
@@ -91,7 +115,7 @@ def main():
       'git_sha': sha, 'git_csrc_dirty': dirty, 'csrc_sha256': digest,
       'note': 'HBM bytes per launch from rocprofv3 PMC passes (%s): (2 x FETCH_SIZE + WRITE_SIZE) x 1024; FETCH_SIZE '
               'doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced read stream)' % src,
-      'config': 'cfg2 Atari shallow T=20 B=512 A=18',
+      'config': 'cfg2 Atari shallow T=20 B=512 A=18' if cfg == 'cfg2' else 'cfg3 DMLab ImpalaDeep + LSTM T=20 B=256 A=9',
       'traffic_bytes': traffic, 'fetch_kb_raw': fetch, 'write_kb': write, 'kernel': kernel,
       'mfma_pmc': mfma,
       'mfma_note': 'mfma_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), separate --pmc pass; '

@@ -18,6 +18,9 @@ rocprofv3 --kernel-trace --stats -d $OUT -o ${TAG}_cfg2 --output-format csv -- $
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT -o ${TAG}_cfg2_fetch --output-format csv -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT -o ${TAG}_cfg2_write --output-format csv -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT -o ${TAG}_cfg3 --output-format csv -- $B --config dmlab > $OUT/${TAG}_cfg3.log 2>&1
+cp $OUT/${TAG}_cfg2_csrc.sha256 $OUT/${TAG}_cfg3_csrc.sha256
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT -o ${TAG}_cfg3_fetch --output-format csv -- $B --config dmlab > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT -o ${TAG}_cfg3_write --output-format csv -- $B --config dmlab > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT -o ${TAG}_cfg5 --output-format csv -- $B --config r2d2 > $OUT/${TAG}_cfg5.log 2>&1
 if [ "${2:-}" != "nobench" ]; then
   # the unprofiled bench lines of the same build (HIP-graph launch, default K / W)
