@@ -23,6 +23,7 @@
 #include "wsx.h"
 #include "wsy.h"
 #include "wgx_api.h"
+#include "fgx_api.h"
 #include "../../include/seedhip.h"
 
 using namespace seedhip;
@@ -223,7 +224,7 @@ extern "C" int seedhip_conv2d_pipe(const seedhip_conv_geom* g, int pass) {
   if (!g || pass < 0 || pass > 2) return 0;
   if (pass == 0 && wfx_enabled()) { wfx::Params xp; if (wfx::plan(xp, g)) return 6; }
   if (pass == 1 && wdx_enabled()) { wdx::Params dp; if (wdx::plan(dp, g)) return 6; }
-  if (pass <= 1 && wsx_enabled(pass) && (wsx::geometry(g) || wsy::geometry(g))) return 6;
+  if (pass <= 1 && wsx_enabled(pass) && (wsx::geometry(g) || wsy::geometry(g) || fgx::plan(g))) return 6;
   if (pass == 2 && wgx_enabled() && wgx::plan(g)) return 6;
   if (xg8::mode() & (1 << pass)) {
     const xg8::Plan x8 = pass == 0 ? x8_fwd_plan(g) : pass == 1 ? x8_dgrad_plan(g) : x8_wgrad_plan(g);
@@ -342,6 +343,10 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
       const int rc2 = wsy::launch(geo16, false, sp, (hipStream_t)stream);
       if (rc2 >= 0) return rc2;
     }
+    // ImpalaDeep's 16 -> 32 stack-entry layer on the 36 x 48 map (fgx.h): plain convolution + bias
+    if (wsx_enabled(0) && in_dtype == kInF32 && !in_relu && !out_relu && !residual && al16(in) && al16(w) && al16(out) &&
+        al16(bias) && fgx::plan(geom))
+      return fgx::launch_fwd(geom, (const float*)in, w, bias, out, (hipStream_t)stream);
   }
   {
     // small-kernel layers: input band staged once in LDS (halo_fwd.h).  Measured on MI355X
@@ -580,6 +585,8 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
       const int rc2 = wsy::launch(geo16, true, sp, (hipStream_t)stream);
       if (rc2 >= 0) return rc2;
     }
+    if (wsx_enabled(1) && !relu_mask && !add && al16(dy) && al16(w) && al16(dx) && fgx::plan(geom))
+      return fgx::launch_dgrad(geom, dy, w, dx, (hipStream_t)stream);
   }
   {
     // Data gradient as stride-1 halo convolutions of dY, one per stride-parity class of the input pixel, all in

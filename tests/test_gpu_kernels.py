@@ -680,6 +680,43 @@ def test_wsx_conv3x3_fp32_accuracy(device, n, h, w, mode):
   assert torch.equal(got, run())
 
 
+@pytest.mark.parametrize('n,mode', [(64, 'fwd'), (257, 'fwd'), (601, 'fwd_nobias'), (65, 'dg'), (515, 'dg')])
+def test_fgx_stack_entry_conv_fp32_accuracy(device, n, mode):
+  """ImpalaDeep's 16 -> 32 stack-entry layer on the 36 x 48 map (fgx.h: bands of the batch staged once as bf16 planes,
+  weights in registers, one tap per MFMA step): forward with and without bias (an odd number of bands: the second band
+  of the last unit does not exist) and the data gradient.  As close to an fp64 evaluation as torch's fp32 convolution
+  (<= 2x), bit-identical from call to call, the bf16 pipe reported by conv2d_pipe."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(n)
+  fwd = mode != 'dg'
+  x = rng.normal(size=(n, 36, 48, 16 if fwd else 32)).astype(np.float32)
+  wt = (rng.normal(size=(3, 3, 16, 32)) / 12).astype(np.float32)
+  b = rng.normal(size=32).astype(np.float32)
+  g = ops.conv_geom(n, 36, 48, 16, 3, 3, 1, 'same', 32)
+  assert ops.conv2d_pipe(g, 0 if fwd else 1) == 6
+  xd, wd, bd = dev(x, device), dev(wt, device), dev(b, device)
+  tx = torch.tensor(x).permute(0, 3, 1, 2)
+  tw = torch.tensor(wt).permute(3, 2, 0, 1)
+
+  def run():
+    out = torch.full((n, 36, 48, 32 if fwd else 16), 7.0, device=device)
+    if fwd: ops.conv2d_fwd(g, xd, wd, bd if mode == 'fwd' else None, out)
+    else: ops.conv2d_bwd_data(g, xd, wd, out)
+    return out
+
+  def ref(dt):
+    if fwd:
+      return F.conv2d(tx.to(dt), tw.to(dt), torch.tensor(b).to(dt) if mode == 'fwd' else None, padding=1).permute(0, 2, 3, 1)
+    return F.conv_transpose2d(tx.to(dt), tw.to(dt), padding=1).permute(0, 2, 3, 1)
+
+  got = run()
+  r32, r64 = ref(torch.float32).numpy().astype(np.float64), ref(torch.float64).numpy()
+  e_hip = np.max(np.abs(got.cpu().numpy().astype(np.float64) - r64)); e_f32 = np.max(np.abs(r32 - r64))
+  print('fgx %s n=%d: err hip %.3e  torch fp32 %.3e' % (mode, n, e_hip, e_f32))
+  assert e_hip <= max(2.0 * e_f32, 2e-6 * np.abs(r64).max()), (mode, e_hip, e_f32)
+  assert torch.equal(got, run())
+
+
 WGX_SHAPES = {                                             # name -> (ih, iw, cin, k, stride, padding, cout)
     'atari2': (20, 20, 16, 4, 2, 'valid', 32), 'deep16': (36, 48, 16, 3, 1, 'same', 16), 'deep16x32': (36, 48, 16, 3, 1, 'same', 32),
     'deep32a': (18, 24, 32, 3, 1, 'same', 32), 'deep32b': (9, 12, 32, 3, 1, 'same', 32)}
@@ -797,7 +834,7 @@ def _col_check(name, got, r32, r64, axis_last=True):
   assert not bad.any(), (name, np.nonzero(bad)[0][:8], e_hip[bad][:4], e_f32[bad][:4], sc[bad][:4])
 
 
-@pytest.mark.parametrize('kind', ['x6', 'x8', 'wfx', 'wdx', 'wsx_fwd', 'wsx_dg', 'wsy_fwd', 'wsy_dg'])
+@pytest.mark.parametrize('kind', ['x6', 'x8', 'wfx', 'wdx', 'wsx_fwd', 'wsx_dg', 'wsy_fwd', 'wsy_dg', 'fgx_fwd', 'fgx_dg'])
 def test_bf16x6_kernels_ill_conditioned(device, kind):
   """VERDICT r4 task 7b.  Every kernel that evaluates fp32 x fp32 on the bf16 pipe through the three-way split, on inputs
   the split could get wrong: input channels / output channels scaled by 2^+-40 (wide exponent spread across the
@@ -836,10 +873,12 @@ def test_bf16x6_kernels_ill_conditioned(device, kind):
       n, ih, iw, cin, k, stride, padding, cout = 300, 20, 20, 16, 4, 2, 'valid', 32
     elif kind.startswith('wsx'):
       n, ih, iw, cin, k, stride, padding, cout = 520, 18, 24, 32, 3, 1, 'same', 32
+    elif kind.startswith('fgx'):
+      n, ih, iw, cin, k, stride, padding, cout = 131, 36, 48, 16, 3, 1, 'same', 32
     else:
       n, ih, iw, cin, k, stride, padding, cout = 260, 36, 48, 16, 3, 1, 'same', 16
     g = ops.conv_geom(n, ih, iw, cin, k, k, stride, padding, cout)
-    fwd = kind in ('wfx', 'wsx_fwd', 'wsy_fwd')
+    fwd = kind in ('wfx', 'wsx_fwd', 'wsy_fwd', 'fgx_fwd')
     src_c, dst_c = (cin, cout) if fwd else (cout, cin)
     shape = (n, ih, iw, cin) if fwd else (n, g.oh, g.ow, cout)
     x = rng.normal(size=shape).astype(np.float32) * (rng.random(size=shape) < 0.1) * _ill_scale(rng, src_c)

@@ -106,6 +106,15 @@ def main():
   if a.what in ('r2d2conv',):                               # the DQN convs of the cfg5 step at its 81 x 256 training frames
     bench_conv('r2d2 conv2 4x4/2 32->64 @20x20', 20736, 20, 20, 32, 4, 2, 'valid', 64)
     bench_conv('r2d2 conv3 3x3/1 64->64 @9x9', 20736, 9, 9, 64, 3, 1, 'valid', 64)
+  if a.what in ('entry',):                                  # ImpalaDeep's 16 -> 32 stack entry: plain forward / data gradient
+    dev = torch.device('cuda')
+    n = 21 * 256
+    g = ops.conv_geom(n, 36, 48, 16, 3, 3, 1, 'same', 32)
+    x = torch.randn((n, 36, 48, 16), device=dev); w = torch.randn((3, 3, 16, 32), device=dev) / 12
+    b = torch.randn(32, device=dev); out = torch.empty((n, 36, 48, 32), device=dev); dy = torch.randn_like(out); dx = torch.empty_like(x)
+    fl = 2.0 * n * 36 * 48 * 32 * 144; by = (x.numel() + out.numel()) * 4
+    report('deep entry 16->32 fwd (pipe %d)' % ops.conv2d_pipe(g, 0), timeit(lambda: ops.conv2d_fwd(g, x, w, b, out)), fl, by)
+    report('deep entry 16->32 dgrad (pipe %d)' % ops.conv2d_pipe(g, 1), timeit(lambda: ops.conv2d_bwd_data(g, dy, w, dx)), fl, by)
   if a.what in ('deep',):
     n = 21 * 256
     bench_conv('deep s0 3x3 16->16 @36x48', n, 36, 48, 16, 3, 1, 'same', 16)
