@@ -233,6 +233,20 @@ int seedhip_conv2d_fwd_bits(const seedhip_conv_geom* geom, const void* in, int i
 int seedhip_conv2d_bwd_data_bits_supported(const seedhip_conv_geom* geom);
 int seedhip_conv2d_bwd_data_bits(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
                                  const uint8_t* relu_bits, void* stream);
+/* r5, ImpalaDeep's residual blocks (dmlab/networks.py:41-51: relu -> conv -> relu -> conv -> += skip): every tensor that
+ * is read through a ReLU gets its mask written by the kernel that PRODUCES it, from the epilogue's registers.
+ * seedhip_conv2d_fwd_outbits is seedhip_conv2d_fwd with out_relu = 0 (bias / residual may be NULL) that also writes
+ * out_bits [n_img * oh * ow, cout / 4] -- bit r of byte [pixel][q] = out[pixel][4 q + r] > 0;
+ * seedhip_maxpool3x3s2_same_fwd_bits / seedhip_conv3x3_u8_pool_fwd_bits (below) do the same for the pooled tensor that
+ * enters a stack's first block.  seedhip_conv2d_bwd_data_bits_add is seedhip_conv2d_bwd_data with those bytes for
+ * relu_mask and the skip path's gradient `add` (may be NULL) added behind the mask.  Served for the 3x3 'same' 16->16
+ * (36x48) and 32->32 (18x24, 9x12) layers at training batch sizes: ask seedhip_conv2d_fwd_outbits_supported (it answers
+ * for both calls); no fallback (SEEDHIP_ERR_UNSUPPORTED). */
+int seedhip_conv2d_fwd_outbits_supported(const seedhip_conv_geom* geom);
+int seedhip_conv2d_fwd_outbits(const seedhip_conv_geom* geom, const float* in, int in_relu, const float* w,
+                               const float* bias, float* out, const float* residual, uint8_t* out_bits, void* stream);
+int seedhip_conv2d_bwd_data_bits_add(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
+                                     const uint8_t* relu_bits, const float* add, void* stream);
 size_t seedhip_conv2d_stack_bwd_weight_workspace_bytes(const seedhip_stack_conv_geom* geom);
 int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* geom, const uint8_t* frames_ext,
                                     const uint8_t* nvalid, const float* dy, float* dw, float* dbias,
@@ -246,6 +260,9 @@ int seedhip_maxpool3x3s2_same_fwd(int n, int ih, int iw, int c, const float* x, 
                                   void* stream);
 int seedhip_maxpool3x3s2_same_bwd(int n, int ih, int iw, int c, const float* dy, const uint8_t* argmax, float* dx,
                                   void* stream);
+/* fwd that also writes the ReLU mask of y as bytes y_bits [n * oh * ow, c / 4] (seedhip_conv2d_fwd_outbits; NULL: plain) */
+int seedhip_maxpool3x3s2_same_fwd_bits(int n, int ih, int iw, int c, const float* x, float* y, uint8_t* argmax,
+                                       uint8_t* y_bits, void* stream);
 
 /* ---- first ImpalaDeep stage fused: Conv2D(16, 3, 'same') on uint8 frames (x/255) + MaxPool2D(3, 2, 'same') ----
  * Replaces dmlab/networks.py:31-37 for stack 0 (with the x/255 of :98-100) and the autodiff of that pair wrt the conv
@@ -255,6 +272,9 @@ int seedhip_maxpool3x3s2_same_bwd(int n, int ih, int iw, int c, const float* dy,
  * bwd: dpooled = gradient wrt `pooled`; dw [3,3,3,16], dbias [16] or null; workspace from the _workspace_bytes call. */
 int seedhip_conv3x3_u8_pool_fwd(const uint8_t* x, int n, int ih, int iw, int cin, const float* w, const float* bias,
                                 int cout, float* pooled, uint8_t* argmax, void* stream);
+/* fwd that also writes the ReLU mask of `pooled` as bytes [n * ph * pw, 4] (seedhip_conv2d_fwd_outbits; NULL: plain) */
+int seedhip_conv3x3_u8_pool_fwd_bits(const uint8_t* x, int n, int ih, int iw, int cin, const float* w, const float* bias,
+                                     int cout, float* pooled, uint8_t* argmax, uint8_t* pooled_bits, void* stream);
 size_t seedhip_conv3x3_u8_pool_bwd_workspace_bytes(int n, int ih, int iw);
 int seedhip_conv3x3_u8_pool_bwd(const uint8_t* x, int n, int ih, int iw, int cin, const float* dpooled,
                                 const uint8_t* argmax, int cout, float* dw, float* dbias, void* workspace,

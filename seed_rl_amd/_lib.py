@@ -89,12 +89,17 @@ SIGNATURES = {
     'seedhip_conv2d_fwd_bits': (c_int, [ctypes.POINTER(ConvGeom), P, c_int, c_int, P, P, P, P, P]),
     'seedhip_conv2d_bwd_data_bits_supported': (c_int, [ctypes.POINTER(ConvGeom)]),
     'seedhip_conv2d_bwd_data_bits': (c_int, [ctypes.POINTER(ConvGeom), P, P, P, P, P]),
+    'seedhip_conv2d_fwd_outbits_supported': (c_int, [ctypes.POINTER(ConvGeom)]),
+    'seedhip_conv2d_fwd_outbits': (c_int, [ctypes.POINTER(ConvGeom), P, c_int, P, P, P, P, P, P]),
+    'seedhip_conv2d_bwd_data_bits_add': (c_int, [ctypes.POINTER(ConvGeom), P, P, P, P, P, P]),
     'seedhip_conv2d_stack_bwd_weight_workspace_bytes': (c_size_t, [ctypes.POINTER(StackConvGeom)]),
     'seedhip_conv2d_stack_bwd_weight':
         (c_int, [ctypes.POINTER(StackConvGeom), P, P, P, P, P, P, c_size_t, P]),
     'seedhip_maxpool3x3s2_same_fwd': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
+    'seedhip_maxpool3x3s2_same_fwd_bits': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P]),
     'seedhip_maxpool3x3s2_same_bwd': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
     'seedhip_conv3x3_u8_pool_fwd': (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P]),
+    'seedhip_conv3x3_u8_pool_fwd_bits': (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P, P]),
     'seedhip_conv3x3_u8_pool_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'seedhip_conv3x3_u8_pool_bwd': (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P, c_size_t, P]),
     'seedhip_lstm_assemble_inputs': (c_int, [P, c_int, c_int, c_int, P, P, c_int, c_int, c_ll, P]),

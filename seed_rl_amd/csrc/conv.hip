@@ -284,6 +284,29 @@ extern "C" int seedhip_conv2d_fwd_bits(const seedhip_conv_geom* geom, const void
   return wfx::launch(xp, (hipStream_t)stream);
 }
 
+// ImpalaDeep's residual-block layers (wsx.h / wsy.h): out = conv(relu?(in)) + bias (+ residual) AND the sign of `out` as
+// bytes [pixel][cout / 4] -- the ReLU mask of the data gradient of the layer that reads `out` through a ReLU
+// (seedhip_conv2d_bwd_data_bits_add) -- written from the epilogue's registers next to the output itself.
+extern "C" int seedhip_conv2d_fwd_outbits_supported(const seedhip_conv_geom* geom) {
+  if (!geom || check_geom(geom, "conv2d_fwd_outbits_supported") || !wsx_enabled(0) || !wsx_enabled(1)) return 0;
+  return (wsx::geometry(geom) || wsy::geometry(geom)) ? 1 : 0;
+}
+extern "C" int seedhip_conv2d_fwd_outbits(const seedhip_conv_geom* geom, const float* in, int in_relu, const float* w,
+                                          const float* bias, float* out, const float* residual, uint8_t* out_bits,
+                                          void* stream) {
+  int rc = check_geom(geom, "conv2d_fwd_outbits"); if (rc) return rc;
+  SEEDHIP_REQUIRE(in && w && out && out_bits, "conv2d_fwd_outbits: null pointer");
+  if (!(seedhip_conv2d_fwd_outbits_supported(geom) && al16(in) && al16(w) && al16(out) && al16(bias) && al16(residual)))
+    return fail(SEEDHIP_ERR_UNSUPPORTED, "conv2d_fwd_outbits: geometry / alignment not served (ask seedhip_conv2d_fwd_outbits_supported)");
+  wsx::Params sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.X = in; sp.Wt = w; sp.bias = bias; sp.A = residual; sp.Y = out; sp.n_img = geom->n_img;
+  sp.in_relu = in_relu; sp.out_relu = 0; sp.out_bits = out_bits;
+  const int geo = wsx::geometry(geom);
+  rc = geo ? wsx::launch(geo, false, sp, (hipStream_t)stream) : wsy::launch(wsy::geometry(geom), false, sp, (hipStream_t)stream);
+  return rc >= 0 ? rc : fail(SEEDHIP_ERR_LAUNCH, "conv2d_fwd_outbits: launch");
+}
+
 extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* in, int in_dtype, int in_relu,
                                      const float* w, const float* bias, float* out, int out_relu,
                                      const float* residual, void* workspace, size_t workspace_bytes, void* stream) {
@@ -476,9 +499,22 @@ static bool dense_bits_ok(const seedhip_conv_geom* g) {
   return xp.ok && xp.slices == 1;
 }
 
+// dX = mask ? dgrad : 0 (+ add) with the mask as bytes, on wsx.h / wsy.h; -1: geometry not served there
+static int wsx_dgrad_bits(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx, const uint8_t* relu_bits,
+                          const float* add, void* stream) {
+  if (!wsx_enabled(1) || !al16(dy) || !al16(w) || !al16(dx) || !al16(add)) return -1;
+  const int geo = wsx::geometry(geom), geo16 = geo ? 0 : wsy::geometry(geom);
+  if (!geo && !geo16) return -1;
+  wsx::Params sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.X = dy; sp.Wt = w; sp.B = add; sp.Y = dx; sp.n_img = geom->n_img; sp.mask_bits = relu_bits;
+  return geo ? wsx::launch(geo, true, sp, (hipStream_t)stream) : wsy::launch(geo16, true, sp, (hipStream_t)stream);
+}
+
 extern "C" int seedhip_conv2d_bwd_data_bits_supported(const seedhip_conv_geom* geom) {
   if (!geom || check_geom(geom, "conv2d_bwd_data_bits_supported")) return 0;
   if (dense_bits_ok(geom)) return 1;
+  if (wsx_enabled(1) && (wsx::geometry(geom) || wsy::geometry(geom))) return 1;
   if (!(gemm_mode() & 16)) return 0;
   wsgemm::Params wp;
   wsgemm::Plan pl = wsgemm::plan_dgrad(wp, geom);
@@ -502,6 +538,10 @@ extern "C" int seedhip_conv2d_bwd_data_bits(const seedhip_conv_geom* geom, const
     xg::launch<true, true>(gp, xp, (hipStream_t)stream);
     return check_launch("conv2d_bwd_data_bits(dense, bf16x6)");
   }
+  {
+    const int rc2 = wsx_dgrad_bits(geom, dy, w, dx, relu_bits, nullptr, stream);
+    if (rc2 >= 0) return rc2;
+  }
   SEEDHIP_REQUIRE(gemm_mode() & 16, "conv2d_bwd_data_bits: not served (ask seedhip_conv2d_bwd_data_bits_supported)");
   {
     // the second Atari conv at training batch sizes on the bf16 matrix pipe, the mask byte per 16 output bytes (wdx.h)
@@ -517,6 +557,17 @@ extern "C" int seedhip_conv2d_bwd_data_bits(const seedhip_conv_geom* geom, const
   if (!pl.ok) return fail(SEEDHIP_ERR_UNSUPPORTED, "conv2d_bwd_data_bits: geometry not served (ask seedhip_conv2d_bwd_data_bits_supported)");
   wp.A = dy; wp.W = w; wp.C = dx; wp.mask_bits = relu_bits;
   return wsgemm::launch(wp, pl, (hipStream_t)stream);
+}
+
+// The same with the skip path's gradient added behind the mask (dX = (bit ? dgrad : 0) + add): the first layer of a
+// residual block.  Served where seedhip_conv2d_fwd_outbits is; add == NULL: seedhip_conv2d_bwd_data_bits.
+extern "C" int seedhip_conv2d_bwd_data_bits_add(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
+                                                const uint8_t* relu_bits, const float* add, void* stream) {
+  if (!add) return seedhip_conv2d_bwd_data_bits(geom, dy, w, dx, relu_bits, stream);
+  int rc = check_geom(geom, "conv2d_bwd_data_bits_add"); if (rc) return rc;
+  SEEDHIP_REQUIRE(dy && w && dx && relu_bits, "conv2d_bwd_data_bits_add: null pointer");
+  rc = wsx_dgrad_bits(geom, dy, w, dx, relu_bits, add, stream);
+  return rc >= 0 ? rc : fail(SEEDHIP_ERR_UNSUPPORTED, "conv2d_bwd_data_bits_add: geometry / alignment not served (ask seedhip_conv2d_fwd_outbits_supported)");
 }
 
 extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,

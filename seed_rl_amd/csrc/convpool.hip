@@ -36,6 +36,10 @@ constexpr int CIN = 3, COUT = 16, PB = 4;                 // pooled rows per ban
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 pk_fma(float x, f2 w, f2 a) { return __builtin_elementwise_fma(f2{x, x}, w, a); }
 constexpr int kConvRows = 2 * PB + 1, kInRows = 2 * PB + 3;
+// ReLU mask of the pooled tensor as bytes: bit q of byte [pixel][quad] = pooled[pixel][4 quad + q] > 0 (wsx.h)
+__device__ __forceinline__ uint8_t sign_nibble(const float4& v) {
+  return (uint8_t)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0));
+}
 
 struct Geom {
   int n, ih, iw;                                          // conv map (input and conv output: 'same', stride 1)
@@ -96,7 +100,8 @@ __device__ __forceinline__ void load_window(const float* xin, int wp, int r, int
 // 3x3 / 2 max-pool (TF 'SAME' windows, first maximum wins) of one band out of the LDS conv buffer
 // [quad][kConvRows][iw] x float4: item = (pooled pixel, channel quad).
 __device__ __forceinline__ void pool_band(const Geom& g, const float* cbuf, int n, int i0, int cy0,
-                                          float* __restrict__ pooled, uint8_t* __restrict__ argmax, int tid) {
+                                          float* __restrict__ pooled, uint8_t* __restrict__ argmax, uint8_t* __restrict__ bits,
+                                          int tid) {
   const int rows = (i0 + PB <= g.ph) ? PB : g.ph - i0;
   for (int item = tid; item < rows * g.pw * 4; item += 256) {
     uint32_t ucq, pp, upi, upj;                          // item = (quad, pooled row, pooled col): lanes share the quad
@@ -126,12 +131,14 @@ __device__ __forceinline__ void pool_band(const Geom& g, const float* cbuf, int 
     const long long o = (((long long)n * g.ph + i0 + pi) * g.pw + pj) * 4 + cq;
     reinterpret_cast<float4*>(pooled)[o] = best;
     reinterpret_cast<uchar4*>(argmax)[o] = make_uchar4((uint8_t)bi0, (uint8_t)bi1, (uint8_t)bi2, (uint8_t)bi3);
+    if (bits) bits[o] = sign_nibble(best);
   }
 }
 
 __global__ void __launch_bounds__(256)
 convpool_fwd_kernel(const Geom g, const uint8_t* __restrict__ x, const float* __restrict__ w,
-                    const float* __restrict__ bias, float* __restrict__ pooled, uint8_t* __restrict__ argmax) {
+                    const float* __restrict__ bias, float* __restrict__ pooled, uint8_t* __restrict__ argmax,
+                         uint8_t* __restrict__ bits) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xin = smem;
   float* lut = smem + xin_floats(g.iw) - 256;
@@ -196,7 +203,7 @@ convpool_fwd_kernel(const Geom g, const uint8_t* __restrict__ x, const float* __
       reinterpret_cast<float4*>(cbuf)[(wave * kConvRows + r) * g.iw + xc] = make_float4(a01[0], a01[1], a23[0], a23[1]);
     }
     __syncthreads();
-    pool_band(g, cbuf, n, i0, cy0, pooled, argmax, tid);
+    pool_band(g, cbuf, n, i0, cy0, pooled, argmax, bits, tid);
   }
 }
 
@@ -239,7 +246,8 @@ __device__ __forceinline__ uint2 bf16_pixel(uint32_t v) {
 template <bool ROW8, int PBF, int NT>                  // PBF pooled rows per band, NT threads per workgroup
 __global__ void __launch_bounds__(NT, NT / 128)         // (threads, waves per SIMD): two workgroups per CU whatever NT
 convpool_fwd_mfma_kernel(const Geom g, const uint8_t* __restrict__ x, const float* __restrict__ w,
-                         const float* __restrict__ bias, float* __restrict__ pooled, uint8_t* __restrict__ argmax) {
+                         const float* __restrict__ bias, float* __restrict__ pooled, uint8_t* __restrict__ argmax,
+                         uint8_t* __restrict__ bits) {
   constexpr int kConvRowsF = 2 * PBF + 1, kInRowsF = 2 * PBF + 3;
   constexpr int NWV = NT / 64, kIts = (kMaxGroups + 2 * NWV - 1) / (2 * NWV), kItems = kMaxPoolItems / NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -448,6 +456,7 @@ convpool_fwd_mfma_kernel(const Geom g, const uint8_t* __restrict__ x, const floa
           }
           reinterpret_cast<float4*>(pooled)[obase + item] = best;
           reinterpret_cast<uchar4*>(argmax)[obase + item] = make_uchar4((uint8_t)bi0, (uint8_t)bi1, (uint8_t)bi2, (uint8_t)bi3);
+          if (bits) bits[obase + item] = sign_nibble(best);
         }
       }
     }
@@ -826,6 +835,14 @@ int grid_for(const Geom& g) { return g.ntiles < 512 ? g.ntiles : 512; }
 
 extern "C" int seedhip_conv3x3_u8_pool_fwd(const uint8_t* x, int n, int ih, int iw, int cin, const float* w,
                                            const float* bias, int cout, float* pooled, uint8_t* argmax, void* stream) {
+  return seedhip_conv3x3_u8_pool_fwd_bits(x, n, ih, iw, cin, w, bias, cout, pooled, argmax, nullptr, stream);
+}
+
+// The same, also writing the sign of the pooled tensor as bytes [pixel][cout / 4] (pooled_bits may be NULL): the ReLU mask
+// of the first residual block's data gradient (seedhip_conv2d_bwd_data_bits_add).
+extern "C" int seedhip_conv3x3_u8_pool_fwd_bits(const uint8_t* x, int n, int ih, int iw, int cin, const float* w,
+                                                const float* bias, int cout, float* pooled, uint8_t* argmax,
+                                                uint8_t* pooled_bits, void* stream) {
   Geom g;
   int rc = make_geom(n, ih, iw, cin, cout, &g, "conv3x3_u8_pool_fwd"); if (rc) return rc;
   SEEDHIP_REQUIRE(x && w && pooled && argmax, "conv3x3_u8_pool_fwd: null pointer");
@@ -843,7 +860,7 @@ extern "C" int seedhip_conv3x3_u8_pool_fwd(const uint8_t* x, int n, int ih, int 
       const int grid = g.ntiles < 256 * per_cu ? g.ntiles : 256 * per_cu;                                         \
       if (lds > 64 * 1024)                                                                                        \
         (void)hipFuncSetAttribute((const void*)convpool_fwd_mfma_kernel<R8_, 4, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      hipLaunchKernelGGL((convpool_fwd_mfma_kernel<R8_, 4, NT_>), dim3(grid), dim3(NT_), lds, s, g, x, w, bias, pooled, argmax); \
+      hipLaunchKernelGGL((convpool_fwd_mfma_kernel<R8_, 4, NT_>), dim3(grid), dim3(NT_), lds, s, g, x, w, bias, pooled, argmax, pooled_bits); \
       return seedhip::check_launch("convpool_fwd_mfma_kernel");                                                   \
     }
     SEEDHIP_CPF(true, 256) SEEDHIP_CPF(true, 512) SEEDHIP_CPF(false, 256) SEEDHIP_CPF(false, 512)
@@ -853,7 +870,7 @@ extern "C" int seedhip_conv3x3_u8_pool_fwd(const uint8_t* x, int n, int ih, int 
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)convpool_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(convpool_fwd_kernel, dim3(grid_for(g)), dim3(256), lds, (hipStream_t)stream, g, x, w, bias, pooled,
-                     argmax);
+                     argmax, pooled_bits);
   return seedhip::check_launch("convpool_fwd_kernel");
 }
 

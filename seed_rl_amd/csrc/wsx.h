@@ -57,7 +57,20 @@ struct Geo {
 struct Params {
   const float* X; const float* Wt; const float* bias; const float* A; const float* B; float* Y;   // A: residual / mask, B: add
   int n_img, per_wg, in_relu, out_relu;
+  // ReLU masks as bytes (one per four channels: bit q of byte [pixel][quad] = x[pixel][4 quad + q] > 0, the layout of
+  // seedhip_conv2d_fwd_bits): the forward writes the sign of its OUTPUT from the epilogue's registers (out_bits: 64
+  // consecutive bytes per wave instruction); the data gradient of the layer that consumes that tensor through a ReLU
+  // reads them (mask_bits) instead of the fp32 activation A -- 1/16 of its bytes.
+  unsigned char* out_bits; const unsigned char* mask_bits;
 };
+__device__ __forceinline__ unsigned load_u8(const sgpr128_t& d, unsigned voff) {
+  unsigned v;
+  asm volatile("buffer_load_ubyte %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(d));
+  return v;
+}
+__device__ __forceinline__ unsigned sign_bits(const f32x4_t& v) {
+  return (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+}
 
 template <int N>
 __device__ __forceinline__ void wait_set(f32x4_t (&r)[kItems][2]) {
@@ -96,6 +109,10 @@ wsx_kernel(const Params p) {
   const __amdgpu_buffer_rsrc_t bv = gemm::make_view((p.B ? p.B : p.Y) + (long long)img0 * G::kPX * 32, run_bytes);
   const __amdgpu_buffer_rsrc_t ov = gemm::make_view(p.Y + (long long)img0 * G::kPX * 32, run_bytes);
   const bool has_a = p.A != nullptr, has_b = p.B != nullptr;
+  const bool has_m = DG && p.mask_bits != nullptr, emit = !DG && p.out_bits != nullptr;
+  const sgpr128_t md = xg::make_view_words(reinterpret_cast<const float*>((has_m ? p.mask_bits : (const unsigned char*)p.Y) + (long long)img0 * G::kPX * 8), has_m ? run_bytes >> 4 : 0);
+  const __amdgpu_buffer_rsrc_t ev = gemm::make_view(reinterpret_cast<const float*>((emit ? p.out_bits : (unsigned char*)p.Y) + (long long)img0 * G::kPX * 8), emit ? run_bytes >> 4 : 0);
+  unsigned mb[4] = {0u, 0u, 0u, 0u};
 
   // ---- weights of this wave's channel half: step t = 3 ky + kx, W_eff[t][ci = 16 kh + 8 kq + e][co = lane & 31] ----- //
   bf16x8_t wh[9], wm[9], wl[9];
@@ -202,6 +219,10 @@ wsx_kernel(const Params p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = DG ? (a[q] > 0.f ? v[q] : 0.f) : v[q] + a[q];
     }
+    if (has_m) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = (mb[j] >> q) & 1u ? v[q] : 0.f;
+    }
     if (DG && has_b) {
       const f32x4_t b = *reinterpret_cast<const f32x4_t*>(ara + 4096 + j * 1024 + lane * 16);
 #pragma unroll
@@ -213,11 +234,13 @@ wsx_kernel(const Params p) {
     }
     const unsigned off = piece_ok(r, j) ? tile_offset(r) + 1024u * j : kOut;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ov, off, 0, 0);
+    if (emit) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sign_bits(v), ev, off == kOut ? kOut : off >> 4, 0, 0);
   };
   auto operands_request = [&](int r, int j) {                // piece j of round r's tile into the areas (LDS-DMA)
     typedef __attribute__((address_space(3))) void lds_void_t;
     const unsigned off = piece_ok(r, j) ? tile_offset(r) + 1024u * j : kOut;
     if (has_a) __builtin_amdgcn_raw_ptr_buffer_load_lds(av, (lds_void_t*)(ara + j * 1024), 16, off, 0, 0, 0);
+    if (has_m) mb[j] = load_u8(md, off == kOut ? kOut : off >> 4);       // this lane's four channels: one byte
     if (DG && has_b) __builtin_amdgcn_raw_ptr_buffer_load_lds(bv, (lds_void_t*)(ara + 4096 + j * 1024), 16, off, 0, 0, 0);
   };
 
@@ -255,7 +278,10 @@ wsx_kernel(const Params p) {
       const bool mine = s < 8 && (s >> 2) == ph;
       // all vector-memory work of the round in four consecutive steps, behind one full wait: everything in the queue
       // is a round old by then (wdx.h)
-      if (mine && j == 0) wait_set<0>(wr);
+      if (mine && j == 0) {
+        wait_set<0>(wr);
+        asm volatile("" : "+v"(mb[0]), "+v"(mb[1]), "+v"(mb[2]), "+v"(mb[3]));   // (requested a round ago, as the row items)
+      }
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[s], xx[0], acc, 0, 0, 0);
       if (mine) issue1(nx, hi1, hi2, j);
       WSX_SB
@@ -294,7 +320,7 @@ wsx_kernel(const Params p) {
     }
     // the last round's outputs (all four pieces read before the first store, tools/isa_store_hazard.py)
     finish();
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(mb[0]), "+v"(mb[1]), "+v"(mb[2]), "+v"(mb[3]) :: "memory");
     f32x4_t v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -304,6 +330,10 @@ wsx_kernel(const Params p) {
         const f32x4_t a = *reinterpret_cast<const f32x4_t*>(ara + j * 1024 + lane * 16);
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[j][q] = DG ? (a[q] > 0.f ? v[j][q] : 0.f) : v[j][q] + a[q];
+      }
+      if (has_m) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[j][q] = (mb[j] >> q) & 1u ? v[j][q] : 0.f;
       }
       if (DG && has_b) {
         const f32x4_t b = *reinterpret_cast<const f32x4_t*>(ara + 4096 + j * 1024 + lane * 16);
@@ -317,9 +347,11 @@ wsx_kernel(const Params p) {
       asm volatile("" : "+v"(v[j]));
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[j]), ov,
-                                             piece_ok(rounds - 1, j) ? tile_offset(rounds - 1) + 1024u * j : kOut, 0, 0);
+    for (int j = 0; j < 4; ++j) {
+      const unsigned off = piece_ok(rounds - 1, j) ? tile_offset(rounds - 1) + 1024u * j : kOut;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[j]), ov, off, 0, 0);
+      if (emit) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sign_bits(v[j]), ev, off == kOut ? kOut : off >> 4, 0, 0);
+    }
   } else {
     for (int r = 0; r < rounds; r += 2) {
       round(std::integral_constant<int, 1>(), r, ld[1], ld[0]);

@@ -74,6 +74,10 @@ wsy_kernel(const Params p) {
   const sgpr128_t bd = xg::make_view_words((p.B ? p.B : p.Y) + (long long)img0 * G::kPX * 16, run_bytes);
   const __amdgpu_buffer_rsrc_t ov = gemm::make_view(p.Y + (long long)img0 * G::kPX * 16, run_bytes);
   const bool has_a = p.A != nullptr, has_b = DG && p.B != nullptr;
+  const bool has_m = DG && p.mask_bits != nullptr, emit = !DG && p.out_bits != nullptr;   // ReLU masks as bytes: wsx.h
+  const sgpr128_t md = xg::make_view_words(reinterpret_cast<const float*>((has_m ? p.mask_bits : (const unsigned char*)p.Y) + (long long)img0 * G::kPX * 4), has_m ? run_bytes >> 4 : 0);
+  const __amdgpu_buffer_rsrc_t ev = gemm::make_view(reinterpret_cast<const float*>((emit ? p.out_bits : (unsigned char*)p.Y) + (long long)img0 * G::kPX * 4), emit ? run_bytes >> 4 : 0);
+  unsigned mb[2] = {0u, 0u};
 
   // ---- weights: step s, lane (co = lane & 15, kq): tap t = 2 s + (kq >> 1), ci = 8 (kq & 1) + e; tap 9 = zeros ------ //
   bf16x8_t wh[5], wm[5], wl[5];
@@ -173,6 +177,10 @@ wsy_kernel(const Params p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[u][q] = DG ? (oa[u][q] > 0.f ? v[u][q] : 0.f) : v[u][q] + oa[u][q];
       }
+      if (has_m) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[u][q] = (mb[u] >> q) & 1u ? v[u][q] : 0.f;
+      }
       if (has_b) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[u][q] += ob[u][q];
@@ -184,13 +192,18 @@ wsy_kernel(const Params p) {
       asm volatile("" : "+v"(v[u]));
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[u]), ov, out_offset(r, u), 0, 0);
+    for (int u = 0; u < 2; ++u) {
+      const unsigned off = out_offset(r, u);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[u]), ov, off, 0, 0);
+      if (emit) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)wsx::sign_bits(v[u]), ev, off == kOut ? kOut : off >> 4, 0, 0);
+    }
   };
   auto operands = [&](int r) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const unsigned off = out_offset(r, u);
       if (has_a) oa[u] = wfx::load16(ad, off, 0u);
+      if (has_m) mb[u] = wsx::load_u8(md, off == kOut ? kOut : off >> 4);
       if (has_b) ob[u] = wfx::load16(bd, off, 0u);
     }
   };
@@ -238,7 +251,7 @@ wsy_kernel(const Params p) {
       // a round old by then (the rows of round r + 1, the previous round's operands and stores)
       if (mine && j == 0) {
         wsx::wait_set<0>(set);
-        asm volatile("" : "+v"(oa[0]), "+v"(oa[1]), "+v"(ob[0]), "+v"(ob[1]));
+        asm volatile("" : "+v"(oa[0]), "+v"(oa[1]), "+v"(ob[0]), "+v"(ob[1]), "+v"(mb[0]), "+v"(mb[1]));
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], xx[u][0], acc[u], 0, 0, 0);
@@ -273,7 +286,7 @@ wsy_kernel(const Params p) {
     for (int r = 0; r < rounds; ++r) round(std::integral_constant<int, 1>(), r);
   }
   // the last round's outputs
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(oa[0]), "+v"(oa[1]), "+v"(ob[0]), "+v"(ob[1]));
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(oa[0]), "+v"(oa[1]), "+v"(ob[0]), "+v"(ob[1]), "+v"(mb[0]), "+v"(mb[1]));
   out_prev(rounds - 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -805,28 +805,36 @@ class ImpalaDeep(_Agent):
     saved = []
     for i, (ih, iw, cin, ch, oh, ow) in enumerate(self._stack_shapes):
       g = ops.conv_geom(N, ih, iw, cin, 3, 3, 1, 'same', ch)
+      gres = ops.conv_geom(N, oh, ow, ch, 3, 3, 1, 'same', ch)
+      # ReLU masks as bytes (one per four channels): every tensor a residual-block layer reads through its ReLU gets
+      # its sign written by the kernel that produces it (pool / conv epilogue), and that layer's data gradient reads
+      # those bytes instead of the fp32 activation (1/16 of the bytes).  SEEDHIP_RELU_BITS=0: fp32 masks.
+      bits = _RELU_BITS and unroll and ops.conv2d_fwd_outbits_supported(gres)
+      mbuf = lambda name: self._buf('s%d_%s' % (i, name), (N, oh, ow, ch // 4), torch.uint8) if bits else None
       p = self._buf('s%d_p' % i, (N, oh, ow, ch))
       arg = self._buf('s%d_arg' % i, (N, oh, ow, ch), torch.uint8)
+      mp = mbuf('p_m')
       fused = i == 0 and self._fused_first_stage
       if fused:
         # conv + max-pool of the uint8 stage in one kernel: the [N, 72, 96, 16] pre-pool tensor is never written
-        ops.conv3x3_u8_pool_fwd(x, fl.p('stack0/conv/kernel'), fl.p('stack0/conv/bias'), p, arg)
+        ops.conv3x3_u8_pool_fwd(x, fl.p('stack0/conv/kernel'), fl.p('stack0/conv/bias'), p, arg, pooled_bits=mp)
       else:
         a = self._buf('s%d_a' % i, (N, ih, iw, ch))
         ops.conv2d_fwd(g, x, fl.p('stack%d/conv/kernel' % i), fl.p('stack%d/conv/bias' % i), a,
                        in_dtype=ops.IN_U8_DIV255 if i == 0 else ops.IN_F32)        # dmlab/networks.py:98-100
-        ops.maxpool_fwd(a, p, arg)
-      gres = ops.conv_geom(N, oh, ow, ch, 3, 3, 1, 'same', ch)
+        ops.maxpool_fwd(a, p, arg, y_bits=mp)
       blocks = []
       for b in range(2):                                                             # dmlab/networks.py:52-59
         r1 = self._buf('s%d_b%d_r1' % (i, b), (N, oh, ow, ch))
+        m1 = mbuf('b%d_m1' % b)                                                      # sign of r1
         ops.conv2d_fwd(gres, p, fl.p('stack%d/res_%d/conv2d_0/kernel' % (i, b)),
-                       fl.p('stack%d/res_%d/conv2d_0/bias' % (i, b)), r1, in_relu=True)
+                       fl.p('stack%d/res_%d/conv2d_0/bias' % (i, b)), r1, in_relu=True, out_bits=m1)
         r2 = self._buf('s%d_b%d_r2' % (i, b), (N, oh, ow, ch))
+        m2 = mbuf('b%d_m2' % b) if b == 0 else None                                  # sign of r2 = the next block's input
         ops.conv2d_fwd(gres, r1, fl.p('stack%d/res_%d/conv2d_1/kernel' % (i, b)),
-                       fl.p('stack%d/res_%d/conv2d_1/bias' % (i, b)), r2, in_relu=True, residual=p)
-        blocks.append((p, r1))
-        p = r2
+                       fl.p('stack%d/res_%d/conv2d_1/bias' % (i, b)), r2, in_relu=True, residual=p, out_bits=m2)
+        blocks.append((p, r1, mp, m1))
+        p, mp = r2, m2
       saved.append(dict(g=g, gres=gres, x=x, arg=arg, a_shape=(N, ih, iw, ch), blocks=blocks, fused=fused))
       x = p
     flat = x.view(N, self._flat_dim)
@@ -878,14 +886,20 @@ class ImpalaDeep(_Agent):
       S = L['saved'][i]
       gres = S['gres']
       for b in (1, 0):
-        p_in, r1 = S['blocks'][b]
+        p_in, r1, m0, m1 = S['blocks'][b]
         k0, k1 = 'stack%d/res_%d/conv2d_0' % (i, b), 'stack%d/res_%d/conv2d_1' % (i, b)
         ops.conv2d_bwd_weight(gres, r1, dp, fl.g(k1 + '/kernel'), fl.g(k1 + '/bias'), wsb, in_relu=True)
         d_r1 = self._buf('d_s%d_b%d_r1' % (i, b), tuple(r1.shape))
-        ops.conv2d_bwd_data(gres, dp, fl.p(k1 + '/kernel'), d_r1, relu_mask=r1)
+        if m1 is not None:
+          ops.conv2d_bwd_data(gres, dp, fl.p(k1 + '/kernel'), d_r1, relu_bits=m1)
+        else:
+          ops.conv2d_bwd_data(gres, dp, fl.p(k1 + '/kernel'), d_r1, relu_mask=r1)
         ops.conv2d_bwd_weight(gres, p_in, d_r1, fl.g(k0 + '/kernel'), fl.g(k0 + '/bias'), wsb, in_relu=True)
         d_pin = self._buf('d_s%d_b%d_p' % (i, b), tuple(p_in.shape))
-        ops.conv2d_bwd_data(gres, d_r1, fl.p(k0 + '/kernel'), d_pin, relu_mask=p_in, add=dp)   # + skip path
+        if m0 is not None:
+          ops.conv2d_bwd_data(gres, d_r1, fl.p(k0 + '/kernel'), d_pin, relu_bits=m0, add=dp)  # + skip path
+        else:
+          ops.conv2d_bwd_data(gres, d_r1, fl.p(k0 + '/kernel'), d_pin, relu_mask=p_in, add=dp)
         dp = d_pin
       kc = 'stack%d/conv' % i
       if S['fused']:

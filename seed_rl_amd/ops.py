@@ -179,9 +179,28 @@ def conv2d_fwd_bits_supported(g):
   return bool(_lib.lib().seedhip_conv2d_fwd_bits_supported(ctypes.byref(g)))
 
 
-def conv2d_fwd(g, x, w, bias, out, in_dtype=IN_F32, in_relu=False, out_relu=False, residual=None, relu_bits=None):
+def conv2d_fwd_outbits_supported(g):
+  """conv2d_fwd(..., out_bits=) and conv2d_bwd_data(..., relu_bits=, add=) are served for this geometry."""
+  return bool(_lib.lib().seedhip_conv2d_fwd_outbits_supported(ctypes.byref(g)))
+
+
+def conv2d_fwd(g, x, w, bias, out, in_dtype=IN_F32, in_relu=False, out_relu=False, residual=None, relu_bits=None,
+               out_bits=None):
   """relu_bits (uint8 [n_img * oh * ow, cout / 4], where conv2d_fwd_bits_supported; needs out_relu, no residual): also
-  receives the ReLU mask of `out` as bytes -- bit r of byte q = out[pixel][4 q + r] > 0."""
+  receives the ReLU mask of `out` as bytes -- bit r of byte q = out[pixel][4 q + r] > 0.
+  out_bits (uint8 [n_img * oh * ow, cout / 4], where conv2d_fwd_outbits_supported; no out_relu, residual allowed): the
+  same bytes for an output that the NEXT layer reads through its own ReLU (ImpalaDeep's residual blocks)."""
+  if out_bits is not None:
+    if relu_bits is not None or out_relu or in_dtype != IN_F32:
+      raise ValueError('conv2d_fwd: out_bits needs fp32 input, out_relu=False and no relu_bits')
+    flops, nbytes = _conv_cost(g, 4)
+    nbytes += (4 * g.n_img * g.oh * g.ow * g.cout if residual is not None else 0) + g.n_img * g.oh * g.ow * g.cout // 8
+    with _region(_conv_name('conv_fwd', g), flops, nbytes, pipe=lambda: _conv_pipe(g, 0)):
+      with _dev(out):
+        _lib.check(_lib.lib().seedhip_conv2d_fwd_outbits(
+            ctypes.byref(g), _lib.ptr(x), int(in_relu), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(residual),
+            _lib.ptr(out_bits), _lib.stream()), 'seedhip_conv2d_fwd_outbits')
+      return out
   if relu_bits is not None:
     if residual is not None or not out_relu:
       raise ValueError('conv2d_fwd: relu_bits needs out_relu=True and no residual')
@@ -214,13 +233,18 @@ def conv2d_bwd_data(g, dy, w, dx, relu_mask=None, add=None, relu_bits=None):
   elems = g.n_img * g.ih * g.iw * g.cin
   nbytes += (elems // 8 if relu_mask is not None else 0) + (4 * elems if add is not None else 0)
   if relu_bits is not None:
-    if relu_mask is not None or add is not None:
-      raise ValueError('conv2d_bwd_data: relu_bits excludes relu_mask / add')
+    if relu_mask is not None:
+      raise ValueError('conv2d_bwd_data: relu_bits excludes relu_mask')
     with _region(_conv_name('conv_dgrad', g), flops, nbytes + g.n_img * g.ih * g.iw * g.cin // 8, pipe=lambda: _conv_pipe(g, 1)):
       with _dev(dx):
-        _lib.check(_lib.lib().seedhip_conv2d_bwd_data_bits(
-            ctypes.byref(g), _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(relu_bits), _lib.stream()),
-            'seedhip_conv2d_bwd_data_bits')
+        if add is not None:                               # (served where conv2d_fwd_outbits_supported)
+          _lib.check(_lib.lib().seedhip_conv2d_bwd_data_bits_add(
+              ctypes.byref(g), _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(relu_bits), _lib.ptr(add), _lib.stream()),
+              'seedhip_conv2d_bwd_data_bits_add')
+        else:
+          _lib.check(_lib.lib().seedhip_conv2d_bwd_data_bits(
+              ctypes.byref(g), _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(relu_bits), _lib.stream()),
+              'seedhip_conv2d_bwd_data_bits')
       return dx
   with _region(_conv_name('conv_dgrad', g), flops, nbytes, pipe=lambda: _conv_pipe(g, 1)):
     with _dev(dx):
@@ -393,7 +417,7 @@ def clip_by_global_norm(grads, clip_norm, sumsq_out, workspace):
         workspace.numel() * workspace.element_size(), _lib.stream()), 'seedhip_clip_by_global_norm')
 
 
-def conv3x3_u8_pool_fwd(x_u8, w, bias, pooled, argmax):
+def conv3x3_u8_pool_fwd(x_u8, w, bias, pooled, argmax, pooled_bits=None):
   """Fused Conv2D(16, 3, 'same')(x/255) + MaxPool2D(3, 2, 'same') of ImpalaDeep's first stage
   (dmlab/networks.py:31-37, :98-100).  x_u8 [n, ih, iw, 3]; pooled / argmax [n, ceil(ih/2), ceil(iw/2), 16]."""
   n, ih, iw, cin = x_u8.shape
@@ -401,9 +425,9 @@ def conv3x3_u8_pool_fwd(x_u8, w, bias, pooled, argmax):
   with _region('convpool_fwd[%dx%dx%d->%d]' % (ih, iw, cin, cout), 2.0 * n * ih * iw * cout * 9 * cin,
                x_u8.numel() + pooled.numel() * 5):
     with _dev(pooled):
-      _lib.check(_lib.lib().seedhip_conv3x3_u8_pool_fwd(
+      _lib.check(_lib.lib().seedhip_conv3x3_u8_pool_fwd_bits(
           _lib.ptr(x_u8), n, ih, iw, cin, _lib.ptr(w), _lib.ptr(bias), cout, _lib.ptr(pooled), _lib.ptr(argmax),
-          _lib.stream()), 'seedhip_conv3x3_u8_pool_fwd')
+          _lib.ptr(pooled_bits), _lib.stream()), 'seedhip_conv3x3_u8_pool_fwd_bits')
 
 
 def conv3x3_u8_pool_bwd_workspace_bytes(n, ih, iw):
@@ -422,13 +446,15 @@ def conv3x3_u8_pool_bwd(x_u8, dpooled, argmax, dw, dbias, workspace):
                  'seedhip_conv3x3_u8_pool_bwd')
 
 
-def maxpool_fwd(x, y, argmax):
-  """MaxPool2D(3, 2, 'same') on NHWC fp32 (dmlab/networks.py:36-37)."""
+def maxpool_fwd(x, y, argmax, y_bits=None):
+  """MaxPool2D(3, 2, 'same') on NHWC fp32 (dmlab/networks.py:36-37); y_bits (uint8 [pixels, c / 4]): the ReLU mask of y
+  as bytes (conv2d_fwd(out_bits=))."""
   n, ih, iw, c = x.shape
   with _region('maxpool_fwd[%dx%dx%d]' % (ih, iw, c), 0, x.numel() * 4 + y.numel() * 5):
     with _dev(y):
-      _lib.check(_lib.lib().seedhip_maxpool3x3s2_same_fwd(n, ih, iw, c, _lib.ptr(x), _lib.ptr(y), _lib.ptr(argmax),
-                                                         _lib.stream()), 'seedhip_maxpool3x3s2_same_fwd')
+      _lib.check(_lib.lib().seedhip_maxpool3x3s2_same_fwd_bits(n, ih, iw, c, _lib.ptr(x), _lib.ptr(y), _lib.ptr(argmax),
+                                                              _lib.ptr(y_bits), _lib.stream()),
+                 'seedhip_maxpool3x3s2_same_fwd_bits')
 
 
 def maxpool_bwd(dy, argmax, dx):

@@ -15,7 +15,8 @@ def _to(device, a):
   return torch.as_tensor(np.ascontiguousarray(a)).to(device)
 
 
-@pytest.mark.parametrize('n,ih,iw,c', [(2, 72, 96, 16), (3, 36, 48, 32), (2, 9, 12, 32), (2, 7, 5, 4), (1, 1, 1, 8)])
+@pytest.mark.parametrize('n,ih,iw,c', [(2, 72, 96, 16), (3, 36, 48, 32), (2, 9, 12, 32), (2, 7, 5, 4), (1, 1, 1, 8), (4, 18, 24, 32),
+                                        (1, 2, 2, 4), (3, 4, 6, 8), (2, 5, 8, 4)])
 def test_maxpool_same_parity(device, n, ih, iw, c):
   """TF 'SAME' 3x3/2 max-pool (asymmetric padding for even sizes) forward: exact; backward: exact
   (gradient routed to the window argmax)."""

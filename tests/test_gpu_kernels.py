@@ -717,6 +717,72 @@ def test_fgx_stack_entry_conv_fp32_accuracy(device, n, mode):
   assert torch.equal(got, run())
 
 
+def _nibbles(x):
+  """bit q of byte [..., quad] = x[..., 4 quad + q] > 0"""
+  v = (x.reshape(x.shape[:-1] + (x.shape[-1] // 4, 4)) > 0).astype(np.uint8)
+  return (v * np.array([1, 2, 4, 8], np.uint8)).sum(-1).astype(np.uint8)
+
+
+@pytest.mark.parametrize('n,h,w', [(300, 36, 48), (515, 18, 24), (700, 9, 12)])
+def test_residual_block_relu_byte_masks(device, n, h, w):
+  """ImpalaDeep's residual-block layers with their ReLU masks as bytes (wsx.h / wsy.h): conv2d_fwd(out_bits=) writes the
+  sign of its output from the epilogue -- one byte per four channels, ragged last workgroup -- next to the output of
+  the plain call, bit for bit (with and without ReLU on the input and residual); conv2d_bwd_data(relu_bits=, add=)
+  equals the fp32-mask call bit for bit (with and without the skip-path add; zeros, negative zeros and subnormals in
+  the masked tensor: > 0 is the test, as in ReluGrad)."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(n)
+  C = 16 if h == 36 else 32
+  g = ops.conv_geom(n, h, w, C, 3, 3, 1, 'same', C)
+  assert ops.conv2d_fwd_outbits_supported(g) and ops.conv2d_bwd_data_bits_supported(g)
+  x = rng.normal(size=(n, h, w, C)).astype(np.float32)
+  x[0, 0, 0, :4] = [0.0, -0.0, 1e-40, -1e-40]
+  wt = (rng.normal(size=(3, 3, C, C)) / np.sqrt(9 * C)).astype(np.float32)
+  b = rng.normal(size=C).astype(np.float32)
+  res = rng.normal(size=(n, h, w, C)).astype(np.float32)
+  dy = rng.normal(size=(n, h, w, C)).astype(np.float32)
+  xd, wd, bd, rd, dyd = dev(x, device), dev(wt, device), dev(b, device), dev(res, device), dev(dy, device)
+  for in_relu, residual in ((True, None), (True, rd), (False, None)):
+    plain = torch.full((n, h, w, C), 7.0, device=device)
+    ops.conv2d_fwd(g, xd, wd, bd, plain, in_relu=in_relu, residual=residual)
+    out = torch.full((n, h, w, C), -7.0, device=device)
+    bits = torch.full((n, h, w, C // 4), 0xA5, dtype=torch.uint8, device=device)
+    ops.conv2d_fwd(g, xd, wd, bd, out, in_relu=in_relu, residual=residual, out_bits=bits)
+    assert torch.equal(out, plain)
+    assert np.array_equal(bits.cpu().numpy(), _nibbles(out.cpu().numpy()))
+  xbits = torch.tensor(_nibbles(x), device=device)
+  for add in (None, rd):
+    ref = torch.full((n, h, w, C), 7.0, device=device)
+    ops.conv2d_bwd_data(g, dyd, wd, ref, relu_mask=xd, add=add)
+    got = torch.full((n, h, w, C), -7.0, device=device)
+    ops.conv2d_bwd_data(g, dyd, wd, got, relu_bits=xbits, add=add)
+    assert torch.equal(got, ref)
+
+
+def test_pool_outputs_relu_byte_masks(device):
+  """The pooled tensors that enter a stack's first residual block: maxpool_fwd(y_bits=) and
+  conv3x3_u8_pool_fwd(pooled_bits=) write the sign of their output as bytes and leave output and argmax unchanged."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(3)
+  x = dev(rng.normal(size=(37, 36, 48, 32)).astype(np.float32), device)
+  y0 = torch.empty((37, 18, 24, 32), device=device); a0 = torch.empty((37, 18, 24, 32), dtype=torch.uint8, device=device)
+  y1, a1 = torch.empty_like(y0), torch.empty_like(a0)
+  bits = torch.full((37, 18, 24, 8), 0xA5, dtype=torch.uint8, device=device)
+  ops.maxpool_fwd(x, y0, a0)
+  ops.maxpool_fwd(x, y1, a1, y_bits=bits)
+  assert torch.equal(y0, y1) and torch.equal(a0, a1)
+  assert np.array_equal(bits.cpu().numpy(), _nibbles(y1.cpu().numpy()))
+  fr = torch.tensor(rng.integers(0, 256, size=(21, 72, 96, 3)).astype(np.uint8), device=device)
+  w = dev((rng.normal(size=(3, 3, 3, 16)) / 5).astype(np.float32), device); b = dev(rng.normal(size=16).astype(np.float32), device)
+  p0 = torch.empty((21, 36, 48, 16), device=device); g0 = torch.empty((21, 36, 48, 16), dtype=torch.uint8, device=device)
+  p1, g1 = torch.empty_like(p0), torch.empty_like(g0)
+  pb = torch.full((21, 36, 48, 4), 0xA5, dtype=torch.uint8, device=device)
+  ops.conv3x3_u8_pool_fwd(fr, w, b, p0, g0)
+  ops.conv3x3_u8_pool_fwd(fr, w, b, p1, g1, pooled_bits=pb)
+  assert torch.equal(p0, p1) and torch.equal(g0, g1)
+  assert np.array_equal(pb.cpu().numpy(), _nibbles(p1.cpu().numpy()))
+
+
 WGX_SHAPES = {                                             # name -> (ih, iw, cin, k, stride, padding, cout)
     'atari2': (20, 20, 16, 4, 2, 'valid', 32), 'deep16': (36, 48, 16, 3, 1, 'same', 16), 'deep16x32': (36, 48, 16, 3, 1, 'same', 32),
     'deep32a': (18, 24, 32, 3, 1, 'same', 32), 'deep32b': (9, 12, 32, 3, 1, 'same', 32)}
