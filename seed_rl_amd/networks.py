@@ -286,14 +286,24 @@ class _Agent(object):
     return L['head'], d_head, self._ldh
 
   # -- LSTM core with done-reset (dmlab/networks.py:152-171; atari/networks.py:176-218) ---- #
-  def _lstm_fwd(self, X, ldx, in_dim, H, T1, B, done_u8, state, prefix='core'):
+  def _lstm_fwd(self, X, ldx, in_dim, H, T1, B, done_u8, state, prefix='core', x_pad_zero=False):
     """X [T1*B, ldx] (features | reward | one-hot action); returns core outputs [T1*B, H] and
-    the new (h, c).  Keeps what the backward needs in self._last['lstm']."""
+    the new (h, c).  Keeps what the backward needs in self._last['lstm'].
+    x_pad_zero: the caller zeroed columns in_dim .. ldx - 1 of X (lstm_assemble_inputs does).  The input projection of
+    a training-sized batch then runs as an [N, ldx] x [ldx, 4H] product on a zero-padded copy of the kernel: an input
+    width that is not a multiple of 4 (512 + 1 + 18 = 531, 256 + 1 + 9 = 266) keeps the layer off the bf16x6 GEMMs
+    (xgemm.h / xgemm8.h move 16-byte vectors of four k), and a zero column times a zero row adds exactly nothing."""
     N = T1 * B
     fl = self.flat
-    gx = ops.dense_geom(N, in_dim, 4 * H, ld_in=ldx)
+    Wx, pad = fl.p(prefix + '/kernel'), None
+    kdim = in_dim
+    if x_pad_zero and in_dim % 4 and ldx == _round4(in_dim) and N >= 4096 and os.environ.get('SEEDHIP_LSTM_PADK', '1') != '0':
+      pad = self._buf(prefix + '/kernel_pad', (ldx, 4 * H), zero=True)         # (rows in_dim .. stay zero)
+      pad[:in_dim].copy_(Wx)
+      Wx, kdim = pad, ldx
+    gx = ops.dense_geom(N, kdim, 4 * H, ld_in=ldx)
     Zx = self._buf(prefix + '/lstm_zx', (N, 4 * H))
-    ops.conv2d_fwd(gx, X, fl.p(prefix + '/kernel'), fl.p(prefix + '/bias'), Zx)
+    ops.conv2d_fwd(gx, X, Wx, fl.p(prefix + '/bias'), Zx)
     Hin = self._buf(prefix + '/lstm_hin', (T1 + 1, B, H))
     Cin = self._buf(prefix + '/lstm_cin', (T1 + 1, B, H))
     h0, c0 = state
@@ -327,7 +337,7 @@ class _Agent(object):
         ops.conv2d_fwd(gu, Hin[t], U, None, Z[t], residual=Zx3[t])
         ops.lstm_gates_fwd(Z[t], Cin[t], done_next, B, H, Hout3[t], H, Hin[t + 1], Cin[t + 1])
     self._last_lstm = dict(X=X, ldx=ldx, in_dim=in_dim, H=H, T1=T1, B=B, done=done_u8, gx=gx, gu=gu, Z=Z, Hin=Hin,
-                           Cin=Cin, Hout=Hout, prefix=prefix, fused_seq=seq_ok)
+                           Cin=Cin, Hout=Hout, prefix=prefix, fused_seq=seq_ok, Wx=Wx, padded=pad is not None)
     self._lstm_ctx[prefix] = self._last_lstm       # stacked cores (MLPandLSTM): one context per layer
     return Hout, (Hin[T1].clone(), Cin[T1].clone())
 
@@ -433,9 +443,14 @@ class _Agent(object):
     dZf = dZ.view(N, 4 * H)
     gall = ops.dense_geom(N, H, 4 * H)
     ops.conv2d_bwd_weight(gall, L['Hin'][:T1].view(N, H), dZf, fl.g(prefix + '/recurrent_kernel'), None, wsb)
-    ops.conv2d_bwd_weight(L['gx'], L['X'], dZf, fl.g(prefix + '/kernel'), fl.g(prefix + '/bias'), wsb)
+    if L['padded']:                               # gradient of the padded kernel; its rows < in_dim are the layer's
+      gpad = self._buf(prefix + '/kernel_pad_grad', (L['ldx'], 4 * H))
+      ops.conv2d_bwd_weight(L['gx'], L['X'], dZf, gpad, fl.g(prefix + '/bias'), wsb)
+      fl.g(prefix + '/kernel').copy_(gpad[:L['in_dim']])
+    else:
+      ops.conv2d_bwd_weight(L['gx'], L['X'], dZf, fl.g(prefix + '/kernel'), fl.g(prefix + '/bias'), wsb)
     dX = self._buf(prefix + '/lstm_dx', (N, L['ldx']))
-    ops.conv2d_bwd_data(L['gx'], dZf, fl.p(prefix + '/kernel'), dX, relu_mask=L['X'] if relu_mask_x else None)
+    ops.conv2d_bwd_data(L['gx'], dZf, L['Wx'], dX, relu_mask=L['X'] if relu_mask_x else None)
     return dX
 
   def _lstm_ws_bytes(self, prefix=None):
@@ -675,7 +690,7 @@ class DuelingLSTMDQNNet(_Agent, _AtariTorso):
     new_fs, ctx = self._torso_fwd(obs, done_u8, agent_state.frame_stacking_state, X, ldx)
     ops.lstm_assemble_inputs(X, ldx, 512, A, reward.to(torch.float32).contiguous(), prev_actions.contiguous(),
                              False, N)                                               # networks.py:263-271 (raw reward)
-    Hout, core_state = self._lstm_fwd(X, ldx, self._in_dim, H, T1, B, done_u8, agent_state.core_state)
+    Hout, core_state = self._lstm_fwd(X, ldx, self._in_dim, H, T1, B, done_u8, agent_state.core_state, x_pad_zero=True)
     hid = self._buf('hid', (N, 1024))
     hf = hid.view(-1)
     ghid = ops.dense_geom(N, H, 512, ld_out=1024)
@@ -847,7 +862,7 @@ class ImpalaDeep(_Agent):
       ops.lstm_assemble_inputs(X, ldx, self._fc, self._num_actions, reward.to(torch.float32).contiguous(),
                                prev_actions.contiguous(), True, N)                   # :112-114
       done_u8 = ops.as_u8(done)
-      Hout, new_state = self._lstm_fwd(X, ldx, self._in_dim, self._H, T1, B, done_u8, core_state)
+      Hout, new_state = self._lstm_fwd(X, ldx, self._in_dim, self._H, T1, B, done_u8, core_state, x_pad_zero=True)
       head = self._head_fwd(Hout, N, self._H)
     else:                                                                            # football/networks.py:147-150
       Hout, new_state = None, ()

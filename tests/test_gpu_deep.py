@@ -105,6 +105,34 @@ def test_impala_deep_train_step_parity(device, T1, B, A, obs):
     assert np.max(np.abs(v.cpu().numpy() - t.detach().numpy())) < 5e-5 + 2 * 4.8e-4 * (n.startswith('stack')), n
 
 
+def test_lstm_input_projection_on_padded_kernel(device, monkeypatch):
+  """The LSTM input projection of a training-sized batch (>= 4096 rows) runs as [N, ldx] x [ldx, 4H] on a zero-padded
+  copy of its kernel (in_dim = 256 + 1 + 9 = 266 is not a multiple of 4, which would keep it off the bf16x6 GEMMs):
+  outputs, final state and every gradient equal the un-padded path's (SEEDHIP_LSTM_PADK=0) to fp32 rounding, and the
+  layer reports the bf16 pipe."""
+  from seed_rl_amd import learner, networks, ops, parametric_distribution as pd
+  T1, B, A, obs = 16, 256, 9, (24, 32, 3)
+  u = synth.dmlab_unroll(11, T1, B, A, H=obs[0], W=obs[1], done_p=0.1)
+  unroll = _deep_unroll(device, u)
+  cfg = learner.LossConfig(lambda_=0.95, max_abs_reward=1.0)
+  res = {}
+  for mode in ('1', '0'):
+    monkeypatch.setenv('SEEDHIP_LSTM_PADK', mode)
+    agent = networks.ImpalaDeep(A, observation_shape=obs, device=device, seed=3)
+    loss, _ = learner.compute_loss(None, pd.categorical_distribution(A), agent, *unroll, config=cfg, want_vtrace=True)
+    agent.backward()
+    head, _, ldh = agent.head_buffers()
+    grads = {n: t.cpu().numpy().copy() for n, t in agent.reference_gradients().items()}
+    res[mode] = (float(loss), head.cpu().numpy().copy(), grads, agent._last_lstm['padded'], agent._last_lstm['gx'])
+  assert res['1'][3] and not res['0'][3]
+  assert ops.conv2d_pipe(res['1'][4], 0) == 6
+  assert abs(res['1'][0] - res['0'][0]) <= 1e-5 * max(1.0, abs(res['0'][0]))
+  assert np.max(np.abs(res['1'][1] - res['0'][1])) <= 2e-5
+  for n, g0 in res['0'][2].items():
+    g1 = res['1'][2][n]
+    assert np.max(np.abs(g1 - g0)) <= 1e-4 * max(np.abs(g0).max(), 1e-3), n
+
+
 def test_impala_deep_single_step_inference(device):
   """unroll=False (central inference, learner.py:386-390) == first step of the unroll; state carried."""
   from seed_rl_amd import networks, utils
