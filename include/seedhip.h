@@ -247,6 +247,15 @@ int seedhip_conv2d_fwd_outbits(const seedhip_conv_geom* geom, const float* in, i
                                const float* bias, float* out, const float* residual, uint8_t* out_bits, void* stream);
 int seedhip_conv2d_bwd_data_bits_add(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
                                      const uint8_t* relu_bits, const float* add, void* stream);
+/* r5: the data gradient of a convolution whose output went through MaxPool2D(3, 2, 'same') (ImpalaDeep's stack-entry
+ * layers, dmlab/networks.py:31-37; TF autodiff: MaxPoolGrad -> Conv2DBackpropInput) from the gradient of the POOLED map
+ * dpooled [n, oh / 2, ow / 2, cout] and the pool's argmax bytes: the max-pool backward runs in the kernel's loader, and the
+ * pre-pool gradient is also written to d_prepool [n, oh, ow, cout] (the weight gradient's operand).  Bit-identical to
+ * seedhip_maxpool3x3s2_same_bwd + seedhip_conv2d_bwd_data.  Served for the 16 -> 32 layer on 36 x 48 maps at training
+ * batch sizes (ask _supported); no fallback. */
+int seedhip_conv2d_bwd_data_pool_supported(const seedhip_conv_geom* geom);
+int seedhip_conv2d_bwd_data_pool(const seedhip_conv_geom* geom, const float* dpooled, const uint8_t* argmax,
+                                 const float* w, float* dx, float* d_prepool, void* stream);
 size_t seedhip_conv2d_stack_bwd_weight_workspace_bytes(const seedhip_stack_conv_geom* geom);
 int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* geom, const uint8_t* frames_ext,
                                     const uint8_t* nvalid, const float* dy, float* dw, float* dbias,

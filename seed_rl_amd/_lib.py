@@ -92,6 +92,8 @@ SIGNATURES = {
     'seedhip_conv2d_fwd_outbits_supported': (c_int, [ctypes.POINTER(ConvGeom)]),
     'seedhip_conv2d_fwd_outbits': (c_int, [ctypes.POINTER(ConvGeom), P, c_int, P, P, P, P, P, P]),
     'seedhip_conv2d_bwd_data_bits_add': (c_int, [ctypes.POINTER(ConvGeom), P, P, P, P, P, P]),
+    'seedhip_conv2d_bwd_data_pool_supported': (c_int, [ctypes.POINTER(ConvGeom)]),
+    'seedhip_conv2d_bwd_data_pool': (c_int, [ctypes.POINTER(ConvGeom), P, P, P, P, P, P]),
     'seedhip_conv2d_stack_bwd_weight_workspace_bytes': (c_size_t, [ctypes.POINTER(StackConvGeom)]),
     'seedhip_conv2d_stack_bwd_weight':
         (c_int, [ctypes.POINTER(StackConvGeom), P, P, P, P, P, P, c_size_t, P]),

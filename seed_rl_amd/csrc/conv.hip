@@ -570,6 +570,24 @@ extern "C" int seedhip_conv2d_bwd_data_bits_add(const seedhip_conv_geom* geom, c
   return rc >= 0 ? rc : fail(SEEDHIP_ERR_UNSUPPORTED, "conv2d_bwd_data_bits_add: geometry / alignment not served (ask seedhip_conv2d_fwd_outbits_supported)");
 }
 
+// Data gradient of a convolution whose output went through MaxPool2D(3, 2, 'same') (ImpalaDeep's stack-entry layer,
+// dmlab/networks.py:31-37), from the gradient of the POOLED map and the pool's argmax bytes: the max-pool backward runs in
+// the loader (fgx.h) and the pre-pool gradient is also written to d_prepool [n, oh, ow, cout] for the weight gradient --
+// results bit-identical to seedhip_maxpool3x3s2_same_bwd followed by seedhip_conv2d_bwd_data.
+extern "C" int seedhip_conv2d_bwd_data_pool_supported(const seedhip_conv_geom* geom) {
+  if (!geom || check_geom(geom, "conv2d_bwd_data_pool_supported") || !wsx_enabled(1)) return 0;
+  return fgx::plan(geom) ? 1 : 0;
+}
+extern "C" int seedhip_conv2d_bwd_data_pool(const seedhip_conv_geom* geom, const float* dpooled, const uint8_t* argmax,
+                                            const float* w, float* dx, float* d_prepool, void* stream) {
+  int rc = check_geom(geom, "conv2d_bwd_data_pool"); if (rc) return rc;
+  SEEDHIP_REQUIRE(dpooled && argmax && w && dx && d_prepool, "conv2d_bwd_data_pool: null pointer");
+  if (!(seedhip_conv2d_bwd_data_pool_supported(geom) && al16(dpooled) && al16(w) && al16(dx) && al16(d_prepool) &&
+        (((uintptr_t)argmax) & 3) == 0))
+    return fail(SEEDHIP_ERR_UNSUPPORTED, "conv2d_bwd_data_pool: geometry / alignment not served (ask seedhip_conv2d_bwd_data_pool_supported)");
+  return fgx::launch_dgrad_pool(geom, dpooled, argmax, w, dx, d_prepool, (hipStream_t)stream);
+}
+
 extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
                                           const float* relu_mask, const float* add, void* workspace,
                                           size_t workspace_bytes, void* stream) {

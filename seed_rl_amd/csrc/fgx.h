@@ -61,12 +61,15 @@ struct Params {
   const float* X; const float* W; const float* bias; float* Y;
   int n_img, bands, units, per_wg;
   long long x_bytes, y_bytes;
+  // POOL (data gradient behind the stack's max-pool): X = gradient of the POOLED map [n, IH / 2, IW / 2, CIN], arg = the
+  // pool's argmax bytes, DA = the pre-pool gradient [n, IH, IW, CIN] this kernel also writes (the weight gradient reads it)
+  const unsigned char* arg; float* DA; long long p_bytes;
 };
 
 template <class G, bool M32 = G::M32> struct AccT { typedef f32x16_t type; };
 template <class G> struct AccT<G, false> { typedef f32x4_t type; };
 
-template <class G>
+template <class G, bool POOL = false>
 __global__ void __launch_bounds__(256, 2)
 fgx_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -79,7 +82,7 @@ fgx_kernel(const Params p) {
   if (u0 >= u1) return;
 
   for (int i = tid * 16; i < G::LDS; i += 256 * 16) *reinterpret_cast<u32x4_t*>(smem + i) = u32x4_t{0u, 0u, 0u, 0u};
-  const __amdgpu_buffer_rsrc_t xr = gemm::make_view(p.X, p.x_bytes), yr = gemm::make_view(p.Y, p.y_bytes);
+  const __amdgpu_buffer_rsrc_t xr = gemm::make_view(p.X, POOL ? p.p_bytes : p.x_bytes), yr = gemm::make_view(p.Y, p.y_bytes);
 
   // ---- weights: the instruction's rows.  Lane (row = lane % PT, kb): reduction elements 8 kb .. 8 kb + 7 of tap t ---- //
   bf16x8_t wh[9], wm[9], wl[9];
@@ -163,6 +166,116 @@ fgx_kernel(const Params p) {
     }
   };
 
+
+  // ---- POOL staging: the max-pool's backward in the loader ------------------------------------------------------- //
+  // MaxPool2D(3, 2, 'same') on an even map: window (k, m) covers rows 2k .. 2k + 2, columns 2m .. 2m + 2, so the 2 x 2
+  // block of pre-pool pixels (2k, 2k + 1) x (2m, 2m + 1) is reached by the four windows (k - 1 | k, m - 1 | m) and by
+  // no other: an item = that block x 4 channels asks for the four windows' gradient quads and argmax bytes (1 KB of
+  // consecutive addresses per 8 lanes), rebuilds the four pixel quads with pool.hip's maxpool_bwd_pair_kernel's terms
+  // in its order (bit-identical to the separate pass), writes the band's OWN rows to DA -- the weight gradient reads
+  // that tensor; this kernel no longer does -- and splits them into the planes like the plain loader.  A unit's 6 input
+  // rows are the row pairs P = 0 .. 3 = rows 4b - 2 + 2P, + 1 (the first and the last row of those 8 are not staged):
+  // 4 x 24 x 8 = 768 items, three per thread, P the same for a whole wave.
+  constexpr int PH = G::IH / 2, PW = G::IW / 2, C = G::CIN, Q = C / 4, kPoolItems = 3;
+  static_assert(!POOL || (G::DG && G::SUB == 1 && G::BR == 4 && G::IH % 2 == 0 && G::IW % 2 == 0 && 4 * PW * Q == kPoolItems * 256), "pool items");
+  const __amdgpu_buffer_rsrc_t ar = gemm::make_view(reinterpret_cast<const float*>(POOL ? p.arg : nullptr), POOL ? p.p_bytes >> 2 : 0);
+  const __amdgpu_buffer_rsrc_t dr = gemm::make_view(POOL ? p.DA : nullptr, POOL ? p.x_bytes : 0);
+  // item j of wave w = chunk w + 4 j of the 12 (row pair P, eight column pairs) chunks; inside a chunk the 16 lanes of a
+  // ds_write_b64 group hold the two quads of ONE 8-channel block (the blocks are a multiple of 32 banks apart) of
+  // eight column pairs
+  static_assert(!POOL || (Q == 8 && PW % 8 == 0), "chunk = 8 column pairs x 8 quads");
+  const int pml = (lane >> 1) & 7, pq = 2 * (lane >> 4) + (lane & 1);
+  f32x4_t pv[kPoolItems][4];
+  unsigned pa[kPoolItems][4];
+  auto issue_pool = [&](int u, int j, bool more) __attribute__((always_inline)) {
+    const int chunk = wave + 4 * j, P = chunk / (PW / 8), m = (chunk % (PW / 8)) * 8 + pml, q = pq;
+    const int img = u / G::NB, b = u - img * G::NB, k = 2 * b - 1 + P;                 // window rows k - 1, k
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = k - 1 + (t >> 1), col = m - 1 + (t & 1);
+      const bool ok = more && (unsigned)row < (unsigned)PH && col >= 0;
+      const unsigned e = (unsigned)(((img * PH + row) * PW + col) * C + 4 * q);         // element of the pooled map
+      const unsigned vd = ok ? e * 4u : kOut, va = ok ? e : kOut;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(pv[j][t]) : "v"(vd), "s"(xr));
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(pa[j][t]) : "v"(va), "s"(ar));
+    }
+  };
+  constexpr int kStoresP = G::TPW;                           // output stores of the previous unit's compute
+  auto pool_item = [&](auto J, int un, auto first) __attribute__((always_inline)) {
+    constexpr int j = decltype(J)::value;
+    const bool more = un < u1;
+    const int u = un - 1, img = u / G::NB, b = u - img * G::NB;
+    {
+      // younger than item j's eight loads: the later items of this unit, the previous unit's output stores, and per
+      // earlier item of this pass its four DA stores and its eight new loads
+      constexpr int kYoung = (kPoolItems - 1 - j) * 8 + j * 12;
+      if (decltype(first)::value)
+        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(pv[j][0]), "+v"(pv[j][1]), "+v"(pv[j][2]), "+v"(pv[j][3]), "+v"(pa[j][0]), "+v"(pa[j][1]), "+v"(pa[j][2]), "+v"(pa[j][3]) : "n"(kYoung));
+      else
+        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(pv[j][0]), "+v"(pv[j][1]), "+v"(pv[j][2]), "+v"(pv[j][3]), "+v"(pa[j][0]), "+v"(pa[j][1]), "+v"(pa[j][2]), "+v"(pa[j][3]) : "n"(kYoung + kStoresP));
+      const int chunk = wave + 4 * j, P = chunk / (PW / 8), m = (chunk % (PW / 8)) * 8 + pml, q = pq;
+      // v[y][x]: pixel (2k + y, 2m + x); window t = 2 a + bc: rows k - 1 + a, columns m - 1 + bc; argmax code = 3 ky + kx
+      f32x4_t v[2][2];
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) v[y][x] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bc = 0; bc < 2; ++bc) {
+          const int t = 2 * a + bc;
+#pragma unroll
+          for (int y = 0; y < 2; ++y) {
+            if (y == 1 && a == 0) continue;                  // the odd row lies in window row k only
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+              if (x == 1 && bc == 0) continue;               // the odd column lies in window column m only
+              const unsigned w = (unsigned)((y == 1 ? 1 : (a == 0 ? 2 : 0)) * 3 + (x == 1 ? 1 : (bc == 0 ? 2 : 0)));
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                if (((pa[j][t] >> (8 * c)) & 255u) == w) v[y][x][c] += pv[j][t][c];
+            }
+          }
+        }
+      // the band's own rows (P = 1, 2) to DA; every item issues its four stores (out of range elsewhere: the count above)
+      const int r0 = 4 * b - 2 + 2 * P;
+      const bool own = P == 1 || P == 2;
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          f32x4_t o = v[y][x];
+          asm volatile("" : "+v"(o));
+          const unsigned off = (unsigned)((((img * G::IH + r0 + y) * G::IW + 2 * m + x) * C + 4 * q) * 4);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), dr, own ? off : kOut, 0, 0);
+          asm volatile("s_nop 1" ::: "memory");
+        }
+      // planes: LDS rows 2P - 1 and 2P of the unit's six
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        const int rl = 2 * P - 1 + y;
+        if (rl < 0 || rl >= G::XR) continue;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          const unsigned dst = (unsigned)((q >> 1) * G::CBP + (rl * G::RP + 2 * m + x + 1) * 16 + (q & 1) * 8);
+          unsigned h0, m0, l0, h1, m1, l1;
+          xg::split2_trunc(v[y][x][0], v[y][x][1], h0, m0, l0);
+          xg::split2_trunc(v[y][x][2], v[y][x][3], h1, m1, l1);
+          *reinterpret_cast<u32x2_t*>(smem + dst) = u32x2_t{h0, h1};
+          *reinterpret_cast<u32x2_t*>(smem + dst + G::XPL) = u32x2_t{m0, m1};
+          *reinterpret_cast<u32x2_t*>(smem + dst + 2 * G::XPL) = u32x2_t{l0, l1};
+        }
+      }
+      issue_pool(un, j, more);
+    }
+  };
+  auto put_pool = [&](int un, auto first) __attribute__((always_inline)) {
+    pool_item(std::integral_constant<int, 0>(), un, first);
+    pool_item(std::integral_constant<int, 1>(), un, first);
+    pool_item(std::integral_constant<int, 2>(), un, first);
+  };
+
   // ---- this wave's tiles: LDS offset of the lane's pixel (tap (0, 0)) and its output offset inside the unit ------ //
   unsigned pb[G::TPW], ob[G::TPW];
 #pragma unroll
@@ -223,11 +336,16 @@ fgx_kernel(const Params p) {
     }
   };
 
+  if constexpr (POOL) {
 #pragma unroll
-  for (int j = 0; j < G::NXI; ++j) issue_x(u0, j, true);
+    for (int j = 0; j < kPoolItems; ++j) issue_pool(u0, j, true);
+  } else {
+#pragma unroll
+    for (int j = 0; j < G::NXI; ++j) issue_x(u0, j, true);
+  }
   __syncthreads();                                           // LDS zeroed
   auto step = [&](int u, auto first) __attribute__((always_inline)) {
-    put(u + 1, first);
+    if constexpr (POOL) put_pool(u + 1, first); else put(u + 1, first);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (not __syncthreads(): its fence waits for the output
     compute(u);                                                        //  stores and the prefetch with vmcnt(0))
     asm volatile("s_barrier" ::: "memory");
@@ -250,7 +368,7 @@ bool plan(const seedhip_conv_geom* g) {
   return (long long)g->n_img * 36 * 48 * 32 * 4 < (1LL << 31) - (1 << 22);
 }
 
-template <class G>
+template <class G, bool POOL = false>
 inline int launch_geo(Params& p, hipStream_t s) {
   static const int cus = xg::cu_count();
   p.bands = p.n_img * G::NB;
@@ -258,9 +376,9 @@ inline int launch_geo(Params& p, hipStream_t s) {
   int grid = p.units < 2 * cus ? p.units : 2 * cus;
   p.per_wg = (p.units + grid - 1) / grid;
   grid = (p.units + p.per_wg - 1) / p.per_wg;
-  static const bool ok = hipFuncSetAttribute((const void*)fgx_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) == hipSuccess;
+  static const bool ok = hipFuncSetAttribute((const void*)fgx_kernel<G, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) == hipSuccess;
   if (!ok) return fail(SEEDHIP_ERR_LAUNCH, "fgx_kernel: LDS attribute");
-  hipLaunchKernelGGL((fgx_kernel<G>), dim3(grid), dim3(256), G::LDS, s, p);
+  hipLaunchKernelGGL((fgx_kernel<G, POOL>), dim3(grid), dim3(256), G::LDS, s, p);
   return check_launch("fgx_kernel");
 }
 
@@ -277,6 +395,17 @@ int launch_dgrad(const seedhip_conv_geom* g, const float* dY, const float* W, fl
   p.X = dY; p.W = W; p.bias = nullptr; p.Y = dX; p.n_img = g->n_img;
   p.x_bytes = (long long)g->n_img * 36 * 48 * 32 * 4; p.y_bytes = (long long)g->n_img * 36 * 48 * 16 * 4;
   return launch_geo<GeoDgrad>(p, s);
+}
+
+// dX AND the pre-pool gradient DA from the pooled map's gradient + the pool's argmax bytes (the max-pool backward fused)
+int launch_dgrad_pool(const seedhip_conv_geom* g, const float* dpooled, const unsigned char* argmax, const float* W, float* dX,
+                      float* DA, hipStream_t s) {
+  Params p;
+  memset(&p, 0, sizeof(p));
+  p.X = dpooled; p.arg = argmax; p.DA = DA; p.W = W; p.bias = nullptr; p.Y = dX; p.n_img = g->n_img;
+  p.p_bytes = (long long)g->n_img * 18 * 24 * 32 * 4;
+  p.x_bytes = (long long)g->n_img * 36 * 48 * 32 * 4; p.y_bytes = (long long)g->n_img * 36 * 48 * 16 * 4;
+  return launch_geo<GeoDgrad, true>(p, s);
 }
 
 }  // namespace fgx

@@ -190,7 +190,9 @@ int make_geom(int n, int ih, int iw, int c, PoolGeom* g, const char* what) {
   g->d_c4.init(c / 4); g->d_ow.init(g->ow); g->d_oh.init(g->oh); g->d_iw.init(iw); g->d_ih.init(ih);
   return SEEDHIP_OK;
 }
-int grid_for(long long n) { long long b = (n + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+// (one item per thread up to 2^18 workgroups: a streaming fill of 1.2 GB runs at 6.1 TB/s from 65 536 workgroups against 4.5
+// from 8 192 looping ones -- tools/probes/write_bw_probe.hip)
+int grid_for(long long n) { long long b = (n + 255) / 256; return (int)(b > (1 << 18) ? (1 << 18) : (b < 1 ? 1 : b)); }
 
 }  // namespace
 

@@ -923,6 +923,14 @@ class ImpalaDeep(_Agent):
         ops.conv3x3_u8_pool_bwd(S['x'], dp, S['arg'], fl.g(kc + '/kernel'), fl.g(kc + '/bias'), ws0)
         continue
       d_a = self._buf('d_s%d_a' % i, S['a_shape'])
+      if i > 0 and os.environ.get('SEEDHIP_POOL_DGRAD', '1') != '0' and ops.conv2d_bwd_data_pool_supported(S['g']):
+        # the max-pool backward inside the data gradient's loader (fgx.h): d_a is written once for the weight gradient
+        # and never read back by this layer's data gradient
+        dx = self._buf('d_s%d_x' % i, tuple(S['x'].shape))
+        ops.conv2d_bwd_data_pool(S['g'], dp, S['arg'], fl.p(kc + '/kernel'), dx, d_a)
+        ops.conv2d_bwd_weight(S['g'], S['x'], d_a, fl.g(kc + '/kernel'), fl.g(kc + '/bias'), wsb)
+        dp = dx
+        continue
       ops.maxpool_bwd(dp, S['arg'], d_a)
       ops.conv2d_bwd_weight(S['g'], S['x'], d_a, fl.g(kc + '/kernel'), fl.g(kc + '/bias'), wsb,
                             in_dtype=ops.IN_U8_DIV255 if i == 0 else ops.IN_F32)

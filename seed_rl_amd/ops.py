@@ -255,6 +255,26 @@ def conv2d_bwd_data(g, dy, w, dx, relu_mask=None, add=None, relu_bits=None):
     return dx
 
 
+def conv2d_bwd_data_pool_supported(g):
+  """conv2d_bwd_data_pool is served for this (conv) geometry."""
+  return bool(_lib.lib().seedhip_conv2d_bwd_data_pool_supported(ctypes.byref(g)))
+
+
+def conv2d_bwd_data_pool(g, dpooled, argmax, w, dx, d_prepool):
+  """Max-pool backward + data gradient of the convolution in front of the pool, in one kernel: dx, and the pre-pool
+  gradient d_prepool [n, oh, ow, cout] for the weight gradient (both bit-identical to maxpool_bwd + conv2d_bwd_data)."""
+  flops, nbytes = _conv_cost(g)
+  elems = g.n_img * g.oh * g.ow * g.cout
+  # algorithmic bytes: pooled gradient + argmax in (elems / 4 x 5 B), dx and the pre-pool gradient out, the weights
+  nbytes = (elems // 4) * 5 + 4 * elems + 4 * g.n_img * g.ih * g.iw * g.cin + 4 * g.kh * g.kw * g.cin * g.cout
+  with _region(_conv_name('conv_dgrad_pool', g), flops, nbytes, pipe=lambda: _conv_pipe(g, 1)):
+    with _dev(dx):
+      _lib.check(_lib.lib().seedhip_conv2d_bwd_data_pool(
+          ctypes.byref(g), _lib.ptr(dpooled), _lib.ptr(argmax), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(d_prepool),
+          _lib.stream()), 'seedhip_conv2d_bwd_data_pool')
+  return dx
+
+
 def conv2d_bwd_weight_workspace_bytes(g):
   return int(_lib.lib().seedhip_conv2d_bwd_weight_workspace_bytes(ctypes.byref(g)))
 

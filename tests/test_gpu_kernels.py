@@ -783,6 +783,35 @@ def test_pool_outputs_relu_byte_masks(device):
   assert np.array_equal(pb.cpu().numpy(), _nibbles(p1.cpu().numpy()))
 
 
+@pytest.mark.parametrize('n', [64, 129, 600])
+def test_pool_backward_inside_the_data_gradient(device, n):
+  """ImpalaDeep's stack-entry layer behind its max-pool (fgx.h, POOL loader): conv2d_bwd_data_pool rebuilds the pre-pool
+  gradient from the pooled map's gradient and the argmax bytes while it stages it -- dx AND the pre-pool gradient it
+  writes for the weight gradient are bit-identical to maxpool_bwd followed by conv2d_bwd_data (ties in the pool, image
+  borders, a ragged last workgroup)."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(n)
+  a = rng.normal(size=(n, 36, 48, 32)).astype(np.float32)
+  a[:, ::3, ::5] = np.round(a[:, ::3, ::5])                 # ties inside pool windows: the first maximum wins
+  wt = (rng.normal(size=(3, 3, 16, 32)) / 12).astype(np.float32)
+  dp = rng.normal(size=(n, 18, 24, 32)).astype(np.float32)
+  g = ops.conv_geom(n, 36, 48, 16, 3, 3, 1, 'same', 32)
+  assert ops.conv2d_bwd_data_pool_supported(g)
+  ad, wd, dpd = dev(a, device), dev(wt, device), dev(dp, device)
+  y = torch.empty((n, 18, 24, 32), device=device); arg = torch.empty((n, 18, 24, 32), dtype=torch.uint8, device=device)
+  ops.maxpool_fwd(ad, y, arg)
+  d_a0 = torch.full((n, 36, 48, 32), 7.0, device=device); dx0 = torch.full((n, 36, 48, 16), 7.0, device=device)
+  ops.maxpool_bwd(dpd, arg, d_a0)
+  ops.conv2d_bwd_data(g, d_a0, wd, dx0)
+  d_a1 = torch.full((n, 36, 48, 32), -7.0, device=device); dx1 = torch.full((n, 36, 48, 16), -7.0, device=device)
+  ops.conv2d_bwd_data_pool(g, dpd, arg, wd, dx1, d_a1)
+  assert torch.equal(d_a1, d_a0)
+  assert torch.equal(dx1, dx0)
+  dx2 = torch.full((n, 36, 48, 16), 3.0, device=device)
+  ops.conv2d_bwd_data_pool(g, dpd, arg, wd, dx2, d_a1)
+  assert torch.equal(dx2, dx1)
+
+
 WGX_SHAPES = {                                             # name -> (ih, iw, cin, k, stride, padding, cout)
     'atari2': (20, 20, 16, 4, 2, 'valid', 32), 'deep16': (36, 48, 16, 3, 1, 'same', 16), 'deep16x32': (36, 48, 16, 3, 1, 'same', 32),
     'deep32a': (18, 24, 32, 3, 1, 'same', 32), 'deep32b': (9, 12, 32, 3, 1, 'same', 32)}

@@ -115,6 +115,19 @@ def main():
     fl = 2.0 * n * 36 * 48 * 32 * 144; by = (x.numel() + out.numel()) * 4
     report('deep entry 16->32 fwd (pipe %d)' % ops.conv2d_pipe(g, 0), timeit(lambda: ops.conv2d_fwd(g, x, w, b, out)), fl, by)
     report('deep entry 16->32 dgrad (pipe %d)' % ops.conv2d_pipe(g, 1), timeit(lambda: ops.conv2d_bwd_data(g, dy, w, dx)), fl, by)
+  if a.what in ('entrypool',):                              # ... its data gradient with the max-pool backward in the loader
+    dev = torch.device('cuda')
+    n = 21 * 256
+    g = ops.conv_geom(n, 36, 48, 16, 3, 3, 1, 'same', 32)
+    act = torch.randn((n, 36, 48, 32), device=dev); w = torch.randn((3, 3, 16, 32), device=dev) / 12
+    y = torch.empty((n, 18, 24, 32), device=dev); arg = torch.empty((n, 18, 24, 32), dtype=torch.uint8, device=dev)
+    ops.maxpool_fwd(act, y, arg)
+    dp = torch.randn_like(y); d_a = torch.empty_like(act); dx = torch.empty((n, 36, 48, 16), device=dev)
+    fl = 2.0 * n * 36 * 48 * 32 * 144; by = dp.numel() * 5 + d_a.numel() * 4 + dx.numel() * 4
+    report('deep entry dgrad + pool backward', timeit(lambda: ops.conv2d_bwd_data_pool(g, dp, arg, w, dx, d_a)), fl, by)
+    def two():
+      ops.maxpool_bwd(dp, arg, d_a); ops.conv2d_bwd_data(g, d_a, w, dx)
+    report('maxpool_bwd, then dgrad', timeit(two), fl, by)
   if a.what in ('deep',):
     n = 21 * 256
     bench_conv('deep s0 3x3 16->16 @36x48', n, 36, 48, 16, 3, 1, 'same', 16)
