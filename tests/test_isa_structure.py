@@ -62,7 +62,8 @@ def test_register_budgets_of_the_hot_kernels(code_objects):
       'wgx_kernelINS0_3GeoILi3ELi3ELi1ELi1ELi32ELi32ELi9': (256, 0),
       # r5: the 16 -> 32 stack-entry layer (fgx.h): 108 weight registers + one unit of input items, two workgroups per CU
       'fgx_kernelINS0_3GeoILi16ELi32': (256, 0),
-      'fgx_kernelINS0_3GeoILi32ELi16': (256, 0),
+      'fgx_kernelINS0_3GeoILi32ELi16ELi36ELi48ELi4ELi1ELb1EEELb0': (256, 0),
+      'fgx_kernelINS0_3GeoILi32ELi16ELi36ELi48ELi4ELi1ELb1EEELb1': (256, 0),    # + the max-pool backward in its loader
       'wfx_kernelILb0ELb0ELi0ELb0': (256, 4),
       'wfx_kernelILb0ELb0ELi0ELb1': (256, 6),                   # r5: + the byte mask of its output (one scratch round trip per round)
       'wdx_kernelILi1ELi0': (256, 0),

@@ -50,11 +50,15 @@ REGIONS_CFG3 = [
     ('conv_wgrad[3x3/1 16->32 @36x48]', 'wgx::wgx_kernel<seedhip::wgx::Geo<3, 3, 1, 1, 16, 32'),
     ('conv_wgrad[3x3/1 32->32 @18x24]', 'wgx::wgx_kernel<seedhip::wgx::Geo<3, 3, 1, 1, 32, 32, 18'),
     ('conv_wgrad[3x3/1 32->32 @9x12]', 'wgx::wgx_kernel<seedhip::wgx::Geo<3, 3, 1, 1, 32, 32, 9'),
+    ('conv_fwd[3x3/1 16->32 @36x48]', 'fgx::fgx_kernel<seedhip::fgx::Geo<16, 32'),
+    ('conv_dgrad_pool[3x3/1 16->32 @36x48]', 'fgx::fgx_kernel<seedhip::fgx::Geo<32, 16, 36, 48, 4, 1, true>, true>'),
+    ('conv_dgrad[3x3/1 16->32 @36x48]', 'fgx::fgx_kernel<seedhip::fgx::Geo<32, 16, 36, 48, 4, 1, true>, false>'),
     ('conv_fwd[3x3/1 16->32 @36x48]', 'halo::halo_fwd_kernel<3, 2, false'),
     ('conv_dgrad[3x3/1 16->32 @36x48]', 'halo::halo_fwd_kernel<3, 1, true'),
     ('convpool_fwd[72x96x3->16]', 'convpool_fwd_mfma_kernel'),
     ('convpool_bwd[72x96x3->16]', 'convpool_bwd_mfma_kernel'),
     ('maxpool_fwd[36x48x32]', 'maxpool_fwd_kernel'),
+    ('maxpool_bwd[18x24x32]', 'maxpool_bwd_pair_kernel'),
     ('maxpool_bwd[36x48x32]', 'maxpool_bwd_kernel'),
 ]
 
