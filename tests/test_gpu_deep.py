@@ -133,6 +133,40 @@ def test_lstm_input_projection_on_padded_kernel(device, monkeypatch):
     assert np.max(np.abs(g1 - g0)) <= 1e-4 * max(np.abs(g0).max(), 1e-3), n
 
 
+def test_impala_deep_byte_masks_and_fused_pool_backward_change_no_bit(device, monkeypatch):
+  """At 512 images every ImpalaDeep layer runs on its training-size kernel.  The ReLU masks as bytes (written by the
+  producing epilogues, read by the masked data gradients) and the max-pool backward inside the entry convolution's data
+  gradient are re-arrangements of the same arithmetic: with either switched off (networks._RELU_BITS,
+  SEEDHIP_POOL_DGRAD=0) the loss and EVERY gradient are bit-identical."""
+  from seed_rl_amd import learner, networks, ops, parametric_distribution as pd
+  T1, B, A, obs = 2, 256, 9, (72, 96, 3)
+  u = synth.dmlab_unroll(5, T1, B, A, H=obs[0], W=obs[1], done_p=0.1)
+  unroll = _deep_unroll(device, u)
+  cfg = learner.LossConfig(lambda_=0.95, max_abs_reward=1.0)
+  g = ops.conv_geom(T1 * B, 36, 48, 16, 3, 3, 1, 'same', 16)
+  assert ops.conv2d_fwd_outbits_supported(g) and ops.conv2d_bwd_data_pool_supported(ops.conv_geom(T1 * B, 36, 48, 16, 3, 3, 1, 'same', 32))
+
+  def run():
+    agent = networks.ImpalaDeep(A, observation_shape=obs, device=device, seed=3)
+    loss, _ = learner.compute_loss(None, pd.categorical_distribution(A), agent, *unroll, config=cfg, want_vtrace=True)
+    agent.backward()
+    used_bits = agent._last['saved'][1]['blocks'][0][2] is not None
+    return float(loss), {n: t.clone() for n, t in agent.reference_gradients().items()}, used_bits
+
+  base = run()
+  assert base[2]
+  monkeypatch.setattr(networks, '_RELU_BITS', False)
+  plain_masks = run()
+  assert not plain_masks[2]
+  monkeypatch.setattr(networks, '_RELU_BITS', True)
+  monkeypatch.setenv('SEEDHIP_POOL_DGRAD', '0')
+  two_kernels = run()
+  for other in (plain_masks, two_kernels):
+    assert other[0] == base[0]
+    for n, t in base[1].items():
+      assert torch.equal(t, other[1][n]), n
+
+
 def test_impala_deep_single_step_inference(device):
   """unroll=False (central inference, learner.py:386-390) == first step of the unroll; state carried."""
   from seed_rl_amd import networks, utils
