@@ -149,12 +149,11 @@ fgx_kernel(const Params p) {
     const bool more = un < u1;
 #pragma unroll
     for (int j = 0; j < G::NXI; ++j) {
-      if (decltype(first)::value) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(lx[j]) : "n"(G::NXI - 1));
-      else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(lx[j]) : "n"(G::NXI - 1 + kStores));
+      const f32x4_t it = decltype(first)::value ? xg::take_item<G::NXI - 1>(lx[j]) : xg::take_item<G::NXI - 1 + kStores>(lx[j]);
       if (j + 1 < G::NXI || ti + 256 * j < G::XITEMS) {
         unsigned h0, m0, l0, h1, m1, l1;
-        xg::split2_trunc(lx[j][0], lx[j][1], h0, m0, l0);
-        xg::split2_trunc(lx[j][2], lx[j][3], h1, m1, l1);
+        xg::split2_trunc(it[0], it[1], h0, m0, l0);
+        xg::split2_trunc(it[2], it[3], h1, m1, l1);
         *reinterpret_cast<u32x2_t*>(smem + xdst[j]) = u32x2_t{h0, h1};
         *reinterpret_cast<u32x2_t*>(smem + xdst[j] + G::XPL) = u32x2_t{m0, m1};
         *reinterpret_cast<u32x2_t*>(smem + xdst[j] + 2 * G::XPL) = u32x2_t{l0, l1};
@@ -209,10 +208,11 @@ fgx_kernel(const Params p) {
       // younger than item j's eight loads: the later items of this unit, the previous unit's output stores, and per
       // earlier item of this pass its four DA stores and its eight new loads
       constexpr int kYoung = (kPoolItems - 1 - j) * 8 + j * 12;
-      if (decltype(first)::value)
-        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(pv[j][0]), "+v"(pv[j][1]), "+v"(pv[j][2]), "+v"(pv[j][3]), "+v"(pa[j][0]), "+v"(pa[j][1]), "+v"(pa[j][2]), "+v"(pa[j][3]) : "n"(kYoung));
-      else
-        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(pv[j][0]), "+v"(pv[j][1]), "+v"(pv[j][2]), "+v"(pv[j][3]), "+v"(pa[j][0]), "+v"(pa[j][1]), "+v"(pa[j][2]), "+v"(pa[j][3]) : "n"(kYoung + kStoresP));
+      constexpr int kWait = kYoung + (decltype(first)::value ? 0 : kStoresP);
+      f32x4_t tv4[4];
+      unsigned ta[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { tv4[t] = xg::take_item<kWait>(pv[j][t]); ta[t] = xg::take_word<kWait>(pa[j][t]); }
       const int chunk = wave + 4 * j, P = chunk / (PW / 8), m = (chunk % (PW / 8)) * 8 + pml, q = pq;
       // v[y][x]: pixel (2k + y, 2m + x); window t = 2 a + bc: rows k - 1 + a, columns m - 1 + bc; argmax code = 3 ky + kx
       f32x4_t v[2][2];
@@ -234,7 +234,7 @@ fgx_kernel(const Params p) {
               const unsigned w = (unsigned)((y == 1 ? 1 : (a == 0 ? 2 : 0)) * 3 + (x == 1 ? 1 : (bc == 0 ? 2 : 0)));
 #pragma unroll
               for (int c = 0; c < 4; ++c)
-                if (((pa[j][t] >> (8 * c)) & 255u) == w) v[y][x][c] += pv[j][t][c];
+                if (((ta[t] >> (8 * c)) & 255u) == w) v[y][x][c] += tv4[t][c];
             }
           }
         }
@@ -336,6 +336,9 @@ fgx_kernel(const Params p) {
     }
   };
 
+  // (the weights are finished before the first requests go out: cgx.h)
+#pragma unroll
+  for (int t = 0; t < 9; ++t) asm volatile("" :: "v"(wh[t]), "v"(wm[t]), "v"(wl[t]));
   if constexpr (POOL) {
 #pragma unroll
     for (int j = 0; j < kPoolItems; ++j) issue_pool(u0, j, true);

@@ -108,6 +108,26 @@ __device__ __forceinline__ f32x4_t asm_load(const sgpr128_t& d, unsigned voff, u
   asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(d), "s"(__builtin_amdgcn_readfirstlane(soff)));
   return v;
 }
+// An item that an earlier `asm volatile("buffer_load_dwordx4 ...")` request may still be writing.  The compiler knows
+// nothing about the request: to it the destination registers hold a value from the asm statement on, and it is free to
+// COPY them (a tied "+v" operand of a later `s_waitcnt` statement allocated elsewhere, a live-range split) before the
+// data has arrived -- cgx.h's first build read the first unit's items from such copies.  take_item waits (at most N
+// younger vector-memory operations outstanding; they retire in order) and moves the registers out INSIDE one asm
+// statement whose inputs are plain "v" operands: the only reads of the in-flight registers sit behind the wait.
+// tests/test_isa_structure.py checks the compiled kernels for reads in front of it.
+template <int N>
+__device__ __forceinline__ f32x4_t take_item(const f32x4_t& r) {
+  const f32x2_t a = __builtin_shufflevector(r, r, 0, 1), b = __builtin_shufflevector(r, r, 2, 3);
+  f32x2_t lo, hi;
+  asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(lo), "=&v"(hi) : "v"(a), "v"(b), "n"(N));
+  return f32x4_t{lo[0], lo[1], hi[0], hi[1]};
+}
+template <int N>
+__device__ __forceinline__ unsigned take_word(unsigned r) {
+  unsigned o;
+  asm volatile("s_waitcnt vmcnt(%2)\n\tv_mov_b32 %0, %1" : "=&v"(o) : "v"(r), "n"(N));
+  return o;
+}
 __device__ __forceinline__ f32x4_t any_load(const sgpr128_t& d, unsigned voff, unsigned soff) { return asm_load(d, voff, soff); }
 __device__ __forceinline__ f32x4_t any_load(const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) { return view_load_s(r, voff, soff); }
 template <int N>

@@ -812,6 +812,49 @@ def test_pool_backward_inside_the_data_gradient(device, n):
   assert torch.equal(dx2, dx1)
 
 
+@pytest.mark.parametrize('n,mode', [(1024, 'fwd'), (1030, 'fwd_plain'), (1027, 'dg_mask'), (1100, 'dg')])
+def test_cgx_dqn_conv3_fp32_accuracy(device, n, mode):
+  """The DQN torso's third convolution, 3 x 3 'valid' 64 -> 64 on 9 x 9 maps (cgx.h: units of whole images, the reduction
+  split over four waves whose partial sums meet in LDS): forward with bias + ReLU and plain, data gradient with and
+  without the ReLU mask; image counts that are not a multiple of the unit.  As close to an fp64 evaluation as torch's
+  fp32 convolution (<= 2x), bit-identical from call to call, the bf16 pipe reported by conv2d_pipe."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(n)
+  fwd = mode.startswith('fwd')
+  x = rng.normal(size=(n, 9, 9, 64) if fwd else (n, 7, 7, 64)).astype(np.float32)
+  wt = (rng.normal(size=(3, 3, 64, 64)) / 24).astype(np.float32)
+  b = rng.normal(size=64).astype(np.float32)
+  mask = rng.normal(size=(n, 9, 9, 64)).astype(np.float32)
+  g = ops.conv_geom(n, 9, 9, 64, 3, 3, 1, 'valid', 64)
+  assert ops.conv2d_pipe(g, 0 if fwd else 1) == 6
+  xd, wd, bd, md = dev(x, device), dev(wt, device), dev(b, device), dev(mask, device)
+  tx = torch.tensor(x).permute(0, 3, 1, 2)
+  tw = torch.tensor(wt).permute(3, 2, 0, 1)
+
+  def run():
+    out = torch.full((n, 7, 7, 64) if fwd else (n, 9, 9, 64), 7.0, device=device)
+    if mode == 'fwd': ops.conv2d_fwd(g, xd, wd, bd, out, out_relu=True)
+    elif mode == 'fwd_plain': ops.conv2d_fwd(g, xd, wd, None, out)
+    elif mode == 'dg_mask': ops.conv2d_bwd_data(g, xd, wd, out, relu_mask=md)
+    else: ops.conv2d_bwd_data(g, xd, wd, out)
+    return out
+
+  def ref(dt):
+    if mode == 'fwd':
+      return F.relu(F.conv2d(tx.to(dt), tw.to(dt), torch.tensor(b).to(dt))).permute(0, 2, 3, 1)
+    if mode == 'fwd_plain':
+      return F.conv2d(tx.to(dt), tw.to(dt)).permute(0, 2, 3, 1)
+    y = F.conv_transpose2d(tx.to(dt), tw.to(dt)).permute(0, 2, 3, 1)
+    return y * (torch.tensor(mask) > 0).to(dt) if mode == 'dg_mask' else y
+
+  got = run()
+  r32, r64 = ref(torch.float32).numpy().astype(np.float64), ref(torch.float64).numpy()
+  e_hip = np.max(np.abs(got.cpu().numpy().astype(np.float64) - r64)); e_f32 = np.max(np.abs(r32 - r64))
+  print('cgx %s n=%d: err hip %.3e  torch fp32 %.3e' % (mode, n, e_hip, e_f32))
+  assert e_hip <= max(2.0 * e_f32, 2e-6 * np.abs(r64).max()), (mode, e_hip, e_f32)
+  assert torch.equal(got, run())
+
+
 WGX_SHAPES = {                                             # name -> (ih, iw, cin, k, stride, padding, cout)
     'atari2': (20, 20, 16, 4, 2, 'valid', 32), 'deep16': (36, 48, 16, 3, 1, 'same', 16), 'deep16x32': (36, 48, 16, 3, 1, 'same', 32),
     'deep32a': (18, 24, 32, 3, 1, 'same', 32), 'deep32b': (9, 12, 32, 3, 1, 'same', 32)}
@@ -929,7 +972,7 @@ def _col_check(name, got, r32, r64, axis_last=True):
   assert not bad.any(), (name, np.nonzero(bad)[0][:8], e_hip[bad][:4], e_f32[bad][:4], sc[bad][:4])
 
 
-@pytest.mark.parametrize('kind', ['x6', 'x8', 'wfx', 'wdx', 'wsx_fwd', 'wsx_dg', 'wsy_fwd', 'wsy_dg', 'fgx_fwd', 'fgx_dg'])
+@pytest.mark.parametrize('kind', ['x6', 'x8', 'wfx', 'wdx', 'wsx_fwd', 'wsx_dg', 'wsy_fwd', 'wsy_dg', 'fgx_fwd', 'fgx_dg', 'cgx_fwd', 'cgx_dg'])
 def test_bf16x6_kernels_ill_conditioned(device, kind):
   """VERDICT r4 task 7b.  Every kernel that evaluates fp32 x fp32 on the bf16 pipe through the three-way split, on inputs
   the split could get wrong: input channels / output channels scaled by 2^+-40 (wide exponent spread across the
@@ -970,10 +1013,12 @@ def test_bf16x6_kernels_ill_conditioned(device, kind):
       n, ih, iw, cin, k, stride, padding, cout = 520, 18, 24, 32, 3, 1, 'same', 32
     elif kind.startswith('fgx'):
       n, ih, iw, cin, k, stride, padding, cout = 131, 36, 48, 16, 3, 1, 'same', 32
+    elif kind.startswith('cgx'):
+      n, ih, iw, cin, k, stride, padding, cout = 1025, 9, 9, 64, 3, 1, 'valid', 64
     else:
       n, ih, iw, cin, k, stride, padding, cout = 260, 36, 48, 16, 3, 1, 'same', 16
     g = ops.conv_geom(n, ih, iw, cin, k, k, stride, padding, cout)
-    fwd = kind in ('wfx', 'wsx_fwd', 'wsy_fwd', 'fgx_fwd')
+    fwd = kind in ('wfx', 'wsx_fwd', 'wsy_fwd', 'fgx_fwd', 'cgx_fwd')
     src_c, dst_c = (cin, cout) if fwd else (cout, cin)
     shape = (n, ih, iw, cin) if fwd else (n, g.oh, g.ow, cout)
     x = rng.normal(size=shape).astype(np.float32) * (rng.random(size=shape) < 0.1) * _ill_scale(rng, src_c)

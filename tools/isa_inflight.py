@@ -1,0 +1,104 @@
+#!/usr/bin/env python
+"""Reads of registers a vector-memory load may still be writing.
+
+hipcc places `s_waitcnt` for the loads IT knows; the conv kernels that keep a unit of input items in flight across a whole
+compute phase (fgx.h, cgx.h) request them through `asm volatile("buffer_load_dword...")` and wait with a hand-counted
+`s_waitcnt vmcnt(N)` -- which only works while the compiler never touches the destination registers in between (a copy
+made in front of the wait reads whatever the registers held before: cgx.h's first build).  This tool walks every
+matching kernel of an object in address order and reports, for each `buffer_load_dword[x2|x4] ... offen` with a literal 0
+scalar offset (the form the asm requests use), the first later instruction that READS one of its destination registers
+when no `s_waitcnt vmcnt` lies between the two.
+
+  python tools/isa_inflight.py build/obj/fgx.o fgx_kernel          # prints offenders, exit code 1 if any
+"""
+import re
+import subprocess
+import sys
+
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
+import isa_waits
+
+REG = re.compile(r'v\[(\d+):(\d+)\]|v(\d+)')
+
+
+def regs(tok):
+  out = set()
+  for m in REG.finditer(tok):
+    if m.group(1) is not None:
+      out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    else:
+      out.add(int(m.group(3)))
+  return out
+
+
+def kernels_text(co):
+  txt = subprocess.run([__import__('os').path.join(isa_waits.LLVM, 'llvm-objdump'), '-d', co], capture_output=True, text=True).stdout
+  name, body = None, []
+  for line in txt.splitlines():
+    m = re.match(r'^[0-9a-f]+ <(.+)>:$', line)
+    if m:
+      if name:
+        yield name, body
+      name, body = m.group(1), []
+    elif name and line.startswith('\t'):
+      ins = line.split('//')[0].strip()
+      if ins:
+        body.append(ins)
+  if name:
+    yield name, body
+
+
+def check(body):
+  """[(index of the load, index of the offending read, text)]"""
+  bad = []
+  for i, ins in enumerate(body):
+    parts = ins.split(None, 1)
+    if not parts[0].startswith('buffer_load_dword') or 'offen' not in ins or ' lds' in ins:
+      continue
+    ops = [o.strip() for o in parts[1].split(',')]
+    if len(ops) < 4 or not ops[3].startswith('0 '):          # literal soffset 0: the asm requests
+      continue
+    dest = regs(ops[0])
+    waited = False
+    for j in range(i + 1, len(body)):
+      t = body[j]
+      if t.startswith('s_waitcnt') and 'vmcnt' in t:
+        waited = True
+      p2 = t.split(None, 1)
+      if len(p2) < 2:
+        continue
+      o2 = [o.strip() for o in p2[1].split(',')]
+      mn = p2[0]
+      stores = mn.startswith(('buffer_store', 'global_store', 'ds_write', 'scratch_store', 'flat_store'))
+      reads = o2 if stores or mn.startswith(('v_cmp', 's_')) else o2[1:]
+      if mn.startswith(('v_mad_u64_u32', 'v_mad_i64_i32')):
+        # 32-bit address arithmetic widened to v_mad_u64_u32: the HIGH half of its 64-bit addend is undefined (only the low
+        # result is used) and the register allocator names any register for it, in-flight ones included -- count the low half
+        reads = o2[2:4] + ['v%d' % min(regs(o2[4]))] if len(o2) > 4 and regs(o2[4]) else o2[2:]
+      writes = [] if stores else o2[:1]
+      if any(regs(r) & dest for r in reads):
+        if not waited:
+          bad.append((i, j, '%s   <-   %s' % (t, ins)))
+        break
+      if any(regs(w) >= dest for w in writes) and not mn.startswith('v_mfma'):
+        break                                                 # overwritten: the request's value is dead
+  return bad
+
+
+def main():
+  obj, pat = sys.argv[1], sys.argv[2]
+  n_bad = 0
+  for co in isa_waits.device_code(obj):
+    for name, body in kernels_text(co):
+      if pat not in name:
+        continue
+      bad = check(body)
+      print('%s: %d request(s) read before a wait' % (name[:110], len(bad)))
+      for i, j, t in bad[:10]:
+        print('   load @%d read @%d: %s' % (i, j, t))
+      n_bad += len(bad)
+  return 1 if n_bad else 0
+
+
+if __name__ == '__main__':
+  sys.exit(main())
