@@ -225,7 +225,7 @@ extern "C" int seedhip_conv2d_pipe(const seedhip_conv_geom* g, int pass) {
   if (!g || pass < 0 || pass > 2) return 0;
   if (pass == 0 && wfx_enabled()) { wfx::Params xp; if (wfx::plan(xp, g)) return 6; }
   if (pass == 1 && wdx_enabled()) { wdx::Params dp; if (wdx::plan(dp, g)) return 6; }
-  if (pass <= 1 && wsx_enabled(pass) && (wsx::geometry(g) || wsy::geometry(g) || fgx::plan(g) || cgx::plan(g))) return 6;
+  if (pass <= 1 && wsx_enabled(pass) && (wsx::geometry(g) || wsy::geometry(g) || fgx::plan(g) || cgx::plan(g) || (pass == 0 && cgx::plan_fwd2(g)))) return 6;
   if (pass == 2 && wgx_enabled() && wgx::plan(g)) return 6;
   if (xg8::mode() & (1 << pass)) {
     const xg8::Plan x8 = pass == 0 ? x8_fwd_plan(g) : pass == 1 ? x8_dgrad_plan(g) : x8_wgrad_plan(g);
@@ -324,7 +324,7 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
     }
     // the DQN torso's 3 x 3 64 -> 64 layer on 9 x 9 maps (cgx.h): bias + ReLU
     if (wsx_enabled(0) && in_dtype == kInF32 && !in_relu && !residual && al16(in) && al16(w) && al16(out) && al16(bias) &&
-        cgx::plan(geom))
+        (cgx::plan(geom) || cgx::plan_fwd2(geom)))
       return cgx::launch_fwd(geom, (const float*)in, w, bias, out, out_relu, (hipStream_t)stream);
   }
   if ((gemm_mode() & 8) && in_dtype == kInF32 && al16(in) && al16(w) && al16(out) && al16(bias) && al16(residual)) {

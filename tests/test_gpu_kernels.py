@@ -855,6 +855,38 @@ def test_cgx_dqn_conv3_fp32_accuracy(device, n, mode):
   assert torch.equal(got, run())
 
 
+@pytest.mark.parametrize('n,relu', [(512, True), (777, False)])
+def test_cgx_dqn_conv2_forward_fp32_accuracy(device, n, relu):
+  """The DQN torso's second convolution, 4 x 4 stride 2 'valid' 32 -> 64 on 20 x 20 maps, forward (cgx.h: one image per
+  unit, even and odd columns of a row stored apart, two taps x 8 channels per reduction step).  As close to an fp64
+  evaluation as torch's fp32 convolution (<= 2x), bit-identical from call to call."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(n)
+  x = rng.normal(size=(n, 20, 20, 32)).astype(np.float32)
+  wt = (rng.normal(size=(4, 4, 32, 64)) / 22).astype(np.float32)
+  b = rng.normal(size=64).astype(np.float32)
+  g = ops.conv_geom(n, 20, 20, 32, 4, 4, 2, 'valid', 64)
+  assert ops.conv2d_pipe(g, 0) == 6
+  xd, wd, bd = dev(x, device), dev(wt, device), dev(b, device)
+  tx = torch.tensor(x).permute(0, 3, 1, 2); tw = torch.tensor(wt).permute(3, 2, 0, 1)
+
+  def run():
+    out = torch.full((n, 9, 9, 64), 7.0, device=device)
+    ops.conv2d_fwd(g, xd, wd, bd if relu else None, out, out_relu=relu)
+    return out
+
+  def ref(dt):
+    y = F.conv2d(tx.to(dt), tw.to(dt), torch.tensor(b).to(dt) if relu else None, stride=2)
+    return (F.relu(y) if relu else y).permute(0, 2, 3, 1)
+
+  got = run()
+  r32, r64 = ref(torch.float32).numpy().astype(np.float64), ref(torch.float64).numpy()
+  e_hip = np.max(np.abs(got.cpu().numpy().astype(np.float64) - r64)); e_f32 = np.max(np.abs(r32 - r64))
+  print('cgx conv2 n=%d: err hip %.3e  torch fp32 %.3e' % (n, e_hip, e_f32))
+  assert e_hip <= max(2.0 * e_f32, 2e-6 * np.abs(r64).max()), (e_hip, e_f32)
+  assert torch.equal(got, run())
+
+
 WGX_SHAPES = {                                             # name -> (ih, iw, cin, k, stride, padding, cout)
     'atari2': (20, 20, 16, 4, 2, 'valid', 32), 'deep16': (36, 48, 16, 3, 1, 'same', 16), 'deep16x32': (36, 48, 16, 3, 1, 'same', 32),
     'deep32a': (18, 24, 32, 3, 1, 'same', 32), 'deep32b': (9, 12, 32, 3, 1, 'same', 32)}
@@ -972,7 +1004,7 @@ def _col_check(name, got, r32, r64, axis_last=True):
   assert not bad.any(), (name, np.nonzero(bad)[0][:8], e_hip[bad][:4], e_f32[bad][:4], sc[bad][:4])
 
 
-@pytest.mark.parametrize('kind', ['x6', 'x8', 'wfx', 'wdx', 'wsx_fwd', 'wsx_dg', 'wsy_fwd', 'wsy_dg', 'fgx_fwd', 'fgx_dg', 'cgx_fwd', 'cgx_dg'])
+@pytest.mark.parametrize('kind', ['x6', 'x8', 'wfx', 'wdx', 'wsx_fwd', 'wsx_dg', 'wsy_fwd', 'wsy_dg', 'fgx_fwd', 'fgx_dg', 'cgx_fwd', 'cgx_dg', 'cgx2_fwd'])
 def test_bf16x6_kernels_ill_conditioned(device, kind):
   """VERDICT r4 task 7b.  Every kernel that evaluates fp32 x fp32 on the bf16 pipe through the three-way split, on inputs
   the split could get wrong: input channels / output channels scaled by 2^+-40 (wide exponent spread across the
@@ -1013,12 +1045,14 @@ def test_bf16x6_kernels_ill_conditioned(device, kind):
       n, ih, iw, cin, k, stride, padding, cout = 520, 18, 24, 32, 3, 1, 'same', 32
     elif kind.startswith('fgx'):
       n, ih, iw, cin, k, stride, padding, cout = 131, 36, 48, 16, 3, 1, 'same', 32
+    elif kind == 'cgx2_fwd':
+      n, ih, iw, cin, k, stride, padding, cout = 515, 20, 20, 32, 4, 2, 'valid', 64
     elif kind.startswith('cgx'):
       n, ih, iw, cin, k, stride, padding, cout = 1025, 9, 9, 64, 3, 1, 'valid', 64
     else:
       n, ih, iw, cin, k, stride, padding, cout = 260, 36, 48, 16, 3, 1, 'same', 16
     g = ops.conv_geom(n, ih, iw, cin, k, k, stride, padding, cout)
-    fwd = kind in ('wfx', 'wsx_fwd', 'wsy_fwd', 'fgx_fwd', 'cgx_fwd')
+    fwd = kind in ('wfx', 'wsx_fwd', 'wsy_fwd', 'fgx_fwd', 'cgx_fwd', 'cgx2_fwd')
     src_c, dst_c = (cin, cout) if fwd else (cout, cin)
     shape = (n, ih, iw, cin) if fwd else (n, g.oh, g.ow, cout)
     x = rng.normal(size=shape).astype(np.float32) * (rng.random(size=shape) < 0.1) * _ill_scale(rng, src_c)

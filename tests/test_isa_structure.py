@@ -64,6 +64,10 @@ def test_register_budgets_of_the_hot_kernels(code_objects):
       'fgx_kernelINS0_3GeoILi16ELi32': (256, 0),
       'fgx_kernelINS0_3GeoILi32ELi16ELi36ELi48ELi4ELi1ELb1EEELb0': (256, 0),
       'fgx_kernelINS0_3GeoILi32ELi16ELi36ELi48ELi4ELi1ELb1EEELb1': (256, 0),    # + the max-pool backward in its loader
+      # r5: the DQN torso's second / third convolution (cgx.h): one 8-wave workgroup per CU, 96 / 108 weight registers
+      'cgx_kernelINS0_3GeoILi4ELi32': (256, 0),
+      'cgx_kernelINS0_3GeoILi3ELi64ELi9': (256, 0),
+      'cgx_kernelINS0_3GeoILi3ELi64ELi7': (256, 0),
       'wfx_kernelILb0ELb0ELi0ELb0': (256, 4),
       'wfx_kernelILb0ELb0ELi0ELb1': (256, 6),                   # r5: + the byte mask of its output (one scratch round trip per round)
       'wdx_kernelILi1ELi0': (256, 0),
@@ -114,3 +118,24 @@ def test_no_wide_store_followed_by_a_write_of_its_data():
   r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'isa_store_hazard.py'), lib], capture_output=True, text=True,
                      timeout=600)
   assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_in_flight_load_registers_are_not_read_before_their_wait():
+  """fgx.h / cgx.h keep a unit of input items in flight across a whole compute phase through asm buffer loads the
+  compiler knows nothing about; `xg::take_item` waits and moves the registers out inside ONE asm statement.  A copy the
+  compiler makes in front of that statement reads the registers before the data arrives (cgx.h's first build did:
+  tools/isa_inflight.py) -- no such read may exist in the compiled kernels."""
+  import isa_inflight, isa_waits
+  obj_dir = os.path.join(ROOT, 'build', 'obj')
+  for obj, pat in (('fgx.o', 'fgx_kernel'), ('cgx.o', 'cgx_kernel')):
+    path = os.path.join(obj_dir, obj)
+    if not os.path.exists(path):
+      pytest.skip('%s is not built' % obj)
+    n = 0
+    for co in isa_waits.device_code(path):
+      for name, body in isa_inflight.kernels_text(co):
+        if pat in name:
+          n += 1
+          bad = isa_inflight.check(body)
+          assert not bad, (name, bad[:3])
+    assert n >= 3, (obj, n)
