@@ -12,6 +12,9 @@ bool plan(const seedhip_conv_geom* g);
 bool plan_fwd2(const seedhip_conv_geom* g);
 int launch_fwd(const seedhip_conv_geom* g, const float* X, const float* W, const float* bias, float* Y, int out_relu, hipStream_t s);
 int launch_dgrad(const seedhip_conv_geom* g, const float* dY, const float* W, float* dX, const float* relu_mask, hipStream_t s);
+// the second convolution's data gradient (cgx2.h: four stride-parity classes)
+bool plan_dgrad2(const seedhip_conv_geom* g);
+int launch_dgrad2(const seedhip_conv_geom* g, const float* dY, const float* W, float* dX, const float* relu_mask, hipStream_t s);
 
 }  // namespace cgx
 }  // namespace seedhip

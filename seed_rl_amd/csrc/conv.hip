@@ -225,7 +225,7 @@ extern "C" int seedhip_conv2d_pipe(const seedhip_conv_geom* g, int pass) {
   if (!g || pass < 0 || pass > 2) return 0;
   if (pass == 0 && wfx_enabled()) { wfx::Params xp; if (wfx::plan(xp, g)) return 6; }
   if (pass == 1 && wdx_enabled()) { wdx::Params dp; if (wdx::plan(dp, g)) return 6; }
-  if (pass <= 1 && wsx_enabled(pass) && (wsx::geometry(g) || wsy::geometry(g) || fgx::plan(g) || cgx::plan(g) || (pass == 0 && cgx::plan_fwd2(g)))) return 6;
+  if (pass <= 1 && wsx_enabled(pass) && (wsx::geometry(g) || wsy::geometry(g) || fgx::plan(g) || cgx::plan(g) || (pass == 0 && cgx::plan_fwd2(g)) || (pass == 1 && cgx::plan_dgrad2(g)))) return 6;
   if (pass == 2 && wgx_enabled() && wgx::plan(g)) return 6;
   if (xg8::mode() & (1 << pass)) {
     const xg8::Plan x8 = pass == 0 ? x8_fwd_plan(g) : pass == 1 ? x8_dgrad_plan(g) : x8_wgrad_plan(g);
@@ -609,6 +609,8 @@ extern "C" int seedhip_conv2d_bwd_data_ws(const seedhip_conv_geom* geom, const f
     // the DQN torso's 3 x 3 64 -> 64 layer (cgx.h)
     if (wsx_enabled(1) && !add && al16(dy) && al16(w) && al16(dx) && al16(relu_mask) && cgx::plan(geom))
       return cgx::launch_dgrad(geom, dy, w, dx, relu_mask, (hipStream_t)stream);
+    if (wsx_enabled(1) && !add && al16(dy) && al16(w) && al16(dx) && al16(relu_mask) && cgx::plan_dgrad2(geom))
+      return cgx::launch_dgrad2(geom, dy, w, dx, relu_mask, (hipStream_t)stream);
   }
   if ((gemm_mode() & 16) && al16(dy) && al16(w) && al16(dx) && al16(relu_mask) && al16(add)) {
     // all stride-parity classes as ONE weight-stationary GEMM over super-pixels (wsgemm.h)

@@ -887,6 +887,40 @@ def test_cgx_dqn_conv2_forward_fp32_accuracy(device, n, relu):
   assert torch.equal(got, run())
 
 
+@pytest.mark.parametrize('n,mask', [(512, True), (777, False)])
+def test_cgx_dqn_conv2_data_gradient_fp32_accuracy(device, n, mask):
+  """The data gradient of the DQN torso's second convolution (4 x 4 stride 2, 32 <- 64; cgx2.h: four stride-parity classes
+  of 2 x 2 taps, the eight waves = class x half of the dY channels, an odd image count) with and without the ReLU mask:
+  as close to fp64 as torch's fp32 transposed convolution (<= 2x), exact zeros under the mask, bit-identical call to call."""
+  from seed_rl_amd import ops
+  rng = np.random.default_rng(n)
+  dy = rng.normal(size=(n, 9, 9, 64)).astype(np.float32)
+  wt = (rng.normal(size=(4, 4, 32, 64)) / 22).astype(np.float32)
+  x = rng.normal(size=(n, 20, 20, 32)).astype(np.float32)
+  g = ops.conv_geom(n, 20, 20, 32, 4, 4, 2, 'valid', 64)
+  assert ops.conv2d_pipe(g, 1) == 6
+  dyd, wd, xd = dev(dy, device), dev(wt, device), dev(x, device)
+  tdy = torch.tensor(dy).permute(0, 3, 1, 2); tw = torch.tensor(wt).permute(3, 2, 0, 1)
+
+  def run():
+    out = torch.full((n, 20, 20, 32), 7.0, device=device)
+    ops.conv2d_bwd_data(g, dyd, wd, out, relu_mask=xd if mask else None)
+    return out
+
+  def ref(dt):
+    y = F.conv_transpose2d(tdy.to(dt), tw.to(dt), stride=2).permute(0, 2, 3, 1)
+    return y * (torch.tensor(x) > 0).to(dt) if mask else y
+
+  got = run()
+  r32, r64 = ref(torch.float32).numpy().astype(np.float64), ref(torch.float64).numpy()
+  e_hip = np.max(np.abs(got.cpu().numpy().astype(np.float64) - r64)); e_f32 = np.max(np.abs(r32 - r64))
+  print('cgx2 dgrad n=%d: err hip %.3e  torch fp32 %.3e' % (n, e_hip, e_f32))
+  assert e_hip <= max(2.0 * e_f32, 2e-6 * np.abs(r64).max()), (e_hip, e_f32)
+  if mask:
+    assert np.all(got.cpu().numpy()[x <= 0] == 0.0)
+  assert torch.equal(got, run())
+
+
 WGX_SHAPES = {                                             # name -> (ih, iw, cin, k, stride, padding, cout)
     'atari2': (20, 20, 16, 4, 2, 'valid', 32), 'deep16': (36, 48, 16, 3, 1, 'same', 16), 'deep16x32': (36, 48, 16, 3, 1, 'same', 32),
     'deep32a': (18, 24, 32, 3, 1, 'same', 32), 'deep32b': (9, 12, 32, 3, 1, 'same', 32)}
@@ -1004,7 +1038,7 @@ def _col_check(name, got, r32, r64, axis_last=True):
   assert not bad.any(), (name, np.nonzero(bad)[0][:8], e_hip[bad][:4], e_f32[bad][:4], sc[bad][:4])
 
 
-@pytest.mark.parametrize('kind', ['x6', 'x8', 'wfx', 'wdx', 'wsx_fwd', 'wsx_dg', 'wsy_fwd', 'wsy_dg', 'fgx_fwd', 'fgx_dg', 'cgx_fwd', 'cgx_dg', 'cgx2_fwd'])
+@pytest.mark.parametrize('kind', ['x6', 'x8', 'wfx', 'wdx', 'wsx_fwd', 'wsx_dg', 'wsy_fwd', 'wsy_dg', 'fgx_fwd', 'fgx_dg', 'cgx_fwd', 'cgx_dg', 'cgx2_fwd', 'cgx2_dg'])
 def test_bf16x6_kernels_ill_conditioned(device, kind):
   """VERDICT r4 task 7b.  Every kernel that evaluates fp32 x fp32 on the bf16 pipe through the three-way split, on inputs
   the split could get wrong: input channels / output channels scaled by 2^+-40 (wide exponent spread across the
@@ -1045,7 +1079,7 @@ def test_bf16x6_kernels_ill_conditioned(device, kind):
       n, ih, iw, cin, k, stride, padding, cout = 520, 18, 24, 32, 3, 1, 'same', 32
     elif kind.startswith('fgx'):
       n, ih, iw, cin, k, stride, padding, cout = 131, 36, 48, 16, 3, 1, 'same', 32
-    elif kind == 'cgx2_fwd':
+    elif kind in ('cgx2_fwd', 'cgx2_dg'):
       n, ih, iw, cin, k, stride, padding, cout = 515, 20, 20, 32, 4, 2, 'valid', 64
     elif kind.startswith('cgx'):
       n, ih, iw, cin, k, stride, padding, cout = 1025, 9, 9, 64, 3, 1, 'valid', 64

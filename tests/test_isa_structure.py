@@ -68,6 +68,7 @@ def test_register_budgets_of_the_hot_kernels(code_objects):
       'cgx_kernelINS0_3GeoILi4ELi32': (256, 0),
       'cgx_kernelINS0_3GeoILi3ELi64ELi9': (256, 0),
       'cgx_kernelINS0_3GeoILi3ELi64ELi7': (256, 0),
+      'cgx_dg2_kernel': (256, 8),                              # (tile offsets: one scratch dword per tile)
       'wfx_kernelILb0ELb0ELi0ELb0': (256, 4),
       'wfx_kernelILb0ELb0ELi0ELb1': (256, 6),                   # r5: + the byte mask of its output (one scratch round trip per round)
       'wdx_kernelILi1ELi0': (256, 0),
@@ -127,7 +128,7 @@ def test_in_flight_load_registers_are_not_read_before_their_wait():
   tools/isa_inflight.py) -- no such read may exist in the compiled kernels."""
   import isa_inflight, isa_waits
   obj_dir = os.path.join(ROOT, 'build', 'obj')
-  for obj, pat in (('fgx.o', 'fgx_kernel'), ('cgx.o', 'cgx_kernel')):
+  for obj, pat in (('fgx.o', 'fgx_kernel'), ('cgx.o', 'cgx_')):
     path = os.path.join(obj_dir, obj)
     if not os.path.exists(path):
       pytest.skip('%s is not built' % obj)
@@ -138,4 +139,4 @@ def test_in_flight_load_registers_are_not_read_before_their_wait():
           n += 1
           bad = isa_inflight.check(body)
           assert not bad, (name, bad[:3])
-    assert n >= 3, (obj, n)
+    assert n >= 3, (obj, n)                                   # (cgx.o: + cgx_dg2_kernel, matched by 'cgx_' below)
