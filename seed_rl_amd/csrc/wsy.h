@@ -120,7 +120,8 @@ wsy_kernel(const Params p) {
     const unsigned voff = item_src(i >> 1, lo, hi);
     if (i & 1) s[i >> 1][1] = wfx::load16b(xd, voff, 0u); else s[i >> 1][0] = wfx::load16(xd, voff, 0u);
   };
-  auto put_half = [&](const f32x4_t& it, int k, int j, int lo, int hi) {
+  auto put_half = [&](const f32x4_t& it_in_flight, int k, int j, int lo, int hi) {
+    const f32x4_t it = xg::move_item(it_in_flight);          // (behind the round's one wait; no other read of the item's registers)
     const unsigned q = (unsigned)tid + 512u * k;
     const unsigned rr = q / (unsigned)G::kRowItems, rem = q - rr * G::kRowItems, pc = rem >> 1, c = rem & 1u;
     const unsigned prow = (unsigned)lo + rr;
@@ -150,7 +151,7 @@ wsy_kernel(const Params p) {
   f32x4_t (&set)[kItems][2] = ld[0];
 #pragma unroll
   for (int i = 0; i < 2 * kItems; ++i) issue1(set, 0, e0, i);
-  wsx::wait_set<0>(set);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (no operands: put_half moves the items out, xg::move_item)
 #pragma unroll
   for (int k = 0; k < kItems; ++k) { put_half(set[k][0], k, 0, 0, e0); put_half(set[k][1], k, 1, 0, e0); }
 #pragma unroll
@@ -250,7 +251,7 @@ wsy_kernel(const Params p) {
       // all vector-memory work of the round in two consecutive steps behind one full wait: everything in the queue is
       // a round old by then (the rows of round r + 1, the previous round's operands and stores)
       if (mine && j == 0) {
-        wsx::wait_set<0>(set);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("" : "+v"(oa[0]), "+v"(oa[1]), "+v"(ob[0]), "+v"(ob[1]), "+v"(mb[0]), "+v"(mb[1]));
       }
 #pragma unroll

@@ -122,6 +122,16 @@ __device__ __forceinline__ f32x4_t take_item(const f32x4_t& r) {
   asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(lo), "=&v"(hi) : "v"(a), "v"(b), "n"(N));
   return f32x4_t{lo[0], lo[1], hi[0], hi[1]};
 }
+// The same without the wait, for kernels that wait ONCE for a whole set of items (`asm volatile("s_waitcnt vmcnt(0)")`, no
+// operands) and consume them one by one behind it: volatile asm statements keep their order, and an input-only operand
+// gives the compiler no reason to copy the in-flight registers (a tied "+v" operand on the wait did: wsy.h copied the
+// next round's items into the loop's registers in the loop pre-header, in front of the wait).
+__device__ __forceinline__ f32x4_t move_item(const f32x4_t& r) {
+  const f32x2_t a = __builtin_shufflevector(r, r, 0, 1), b = __builtin_shufflevector(r, r, 2, 3);
+  f32x2_t lo, hi;
+  asm volatile("v_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(lo), "=&v"(hi) : "v"(a), "v"(b));
+  return f32x4_t{lo[0], lo[1], hi[0], hi[1]};
+}
 template <int N>
 __device__ __forceinline__ unsigned take_word(unsigned r) {
   unsigned o;

@@ -48,20 +48,26 @@ def kernels_text(co):
     yield name, body
 
 
-def check(body):
-  """[(index of the load, index of the offending read, text)]"""
+def check(body, asm_only=True):
+  """[(index of the load, index of the offending read, text)].  asm_only: only requests with a literal 0 scalar offset
+  (fgx.h / cgx.h); otherwise every buffer load -- the compiler's own are followed by its waits and pass trivially.
+  The scan follows the ADDRESS order from the request: it stops at an unconditional branch or the end of the program
+  (the code behind belongs to another path), drops a destination register from the watch list when anything overwrites
+  it, and ends when the list is empty or the first watched register is read."""
   bad = []
   for i, ins in enumerate(body):
     parts = ins.split(None, 1)
     if not parts[0].startswith('buffer_load_dword') or 'offen' not in ins or ' lds' in ins:
       continue
     ops = [o.strip() for o in parts[1].split(',')]
-    if len(ops) < 4 or not ops[3].startswith('0 '):          # literal soffset 0: the asm requests
+    if len(ops) < 4 or (asm_only and not ops[3].startswith('0 ')):
       continue
-    dest = regs(ops[0])
+    live = set(regs(ops[0]))
     waited = False
     for j in range(i + 1, len(body)):
       t = body[j]
+      if t.startswith(('s_endpgm', 's_branch', 's_setpc')):
+        break
       if t.startswith('s_waitcnt') and 'vmcnt' in t:
         waited = True
       p2 = t.split(None, 1)
@@ -76,12 +82,15 @@ def check(body):
         # result is used) and the register allocator names any register for it, in-flight ones included -- count the low half
         reads = o2[2:4] + ['v%d' % min(regs(o2[4]))] if len(o2) > 4 and regs(o2[4]) else o2[2:]
       writes = [] if stores else o2[:1]
-      if any(regs(r) & dest for r in reads):
+      if any(regs(r) & live for r in reads):
         if not waited:
           bad.append((i, j, '%s   <-   %s' % (t, ins)))
         break
-      if any(regs(w) >= dest for w in writes) and not mn.startswith('v_mfma'):
-        break                                                 # overwritten: the request's value is dead
+      if not mn.startswith('v_mfma'):
+        for w in writes:
+          live -= regs(w)
+      if not live:
+        break
   return bad
 
 
@@ -92,7 +101,7 @@ def main():
     for name, body in kernels_text(co):
       if pat not in name:
         continue
-      bad = check(body)
+      bad = check(body, asm_only='--all' not in sys.argv)
       print('%s: %d request(s) read before a wait' % (name[:110], len(bad)))
       for i, j, t in bad[:10]:
         print('   load @%d read @%d: %s' % (i, j, t))
