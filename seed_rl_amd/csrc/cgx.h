@@ -115,9 +115,11 @@ cgx_kernel(const Params p) {
   const int ti = (tid & ~63) + (((lane >> 4) / (G::QP / 4)) * 4 + ((lane >> 2) & 3)) * G::QP + 4 * ((lane >> 4) % (G::QP / 4)) + (lane & 3);
   // LDS offset of item j, recomputed where it is used (eight registers the forward does not have; `tv` is pinned so that
   // the compiler does not hoist the table back out of the unit loop)
+  // (a register table where the kernel has registers left: the second conv's forward, the third conv's data gradient)
+  constexpr bool kTable = G::NSTEP < 9 || G::DG;
   auto item_dst = [&](int j) -> unsigned {
     int tv = ti;
-    asm volatile("" : "+v"(tv));
+    if (!kTable) asm volatile("" : "+v"(tv));
     const unsigned i = (unsigned)tv + 512u * j, pix = i / (unsigned)G::QP, q = i % (unsigned)G::QP;
     const unsigned img = pix / (unsigned)(G::IH * G::IW), rem = pix - img * (G::IH * G::IW), r = rem / (unsigned)G::IW, c = rem - r * G::IW;
     const unsigned col = c + G::PAD, sl = (img * G::IHP + r + G::PAD) * G::IWP + (G::S == 2 ? (col & 1u) * G::HW + (col >> 1) : col);

@@ -57,7 +57,7 @@ def check(body, asm_only=True):
   bad = []
   for i, ins in enumerate(body):
     parts = ins.split(None, 1)
-    if not parts[0].startswith('buffer_load_dword') or 'offen' not in ins or ' lds' in ins:
+    if not parts[0].startswith(('buffer_load_dword', 'buffer_load_ubyte', 'buffer_load_ushort')) or 'offen' not in ins or ' lds' in ins:
       continue
     ops = [o.strip() for o in parts[1].split(',')]
     if len(ops) < 4 or (asm_only and not ops[3].startswith('0 ')):
