@@ -59,6 +59,9 @@ class Adam(object):
     t = self.iterations + 1
     # flat.step_guard (int32[1] on the device, set by agents with LSTM sequence kernels): non-zero = this step's gradients
     # are invalid and the update is dropped on the device (csrc/adam.hip)
+    # (such a step still advances `iterations` on the host: the learning-rate schedule and the bias correction move on by
+    #  one for an update that did not happen -- accepted for a fallback that fires at most once per agent, see
+    #  networks._lstm_seq_check)
     guard = getattr(flat, 'step_guard', None)
     if self.capturable:
       if self._lr_dev is None:

@@ -25,6 +25,8 @@ Object-graph keys of tf.train.Checkpoint: <attribute path>/.ATTRIBUTES/VARIABLE_
   as layer_with_weights-<i>).
 """
 import collections
+import os
+import re
 import struct
 
 import numpy as np
@@ -486,8 +488,9 @@ def save_agent(prefix, agent, root='agent', optimizer=None, optimizer_root='opti
           key = '%s/%s/.OPTIMIZER_SLOT/%s/%s%s' % (root, paths.get(name, name), optimizer_root, slot, _SUFFIX)
           a = view.detach().cpu().numpy()
           tensors[key] = a.reshape(()) if name == 'entropy_cost_param' else a
-  if 'save_counter' + _SUFFIX not in tensors:         # tf.train.Checkpoint.save() counts its calls there
-    tensors['save_counter' + _SUFFIX] = np.asarray(1, np.int64)
+  if 'save_counter' + _SUFFIX not in tensors:         # tf.train.Checkpoint.save() counts its calls there and names the
+    m = re.search(r'-(\d+)$', os.path.basename(prefix))   # file `<dir>/ckpt-<save_counter>` (learner.py:469-475): take it back
+    tensors['save_counter' + _SUFFIX] = np.asarray(int(m.group(1)) if m else 1, np.int64)
   tensors[OBJECT_GRAPH_KEY] = object_graph(tensors, optimizer_root).SerializeToString()
   write_checkpoint(prefix, tensors)
   return sorted(tensors)
