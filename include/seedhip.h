@@ -32,7 +32,7 @@ extern "C" {
  * 5 = round 5 (seedhip_conv2d_stack_bwd_weight_fused* REMOVED: the fused pair lost to the two-call path).
  * Bindings must compare seedhip_abi_version() with the version they were written against before the first call
  * (seed_rl_amd/_lib.py does): a stale library would otherwise be called with shifted arguments. */
-#define SEEDHIP_ABI_VERSION 5
+#define SEEDHIP_ABI_VERSION 6
 
 const char* seedhip_last_error(void);
 int seedhip_abi_version(void);
@@ -462,6 +462,87 @@ typedef struct seedhip_row_op {
   const long long* dst_rows; const long long* src_rows; long long n; const uint8_t* row_mask; int zero_where_masked;
 } seedhip_row_op;
 int seedhip_rows_move_ops(int nops, const seedhip_row_op* ops, void* stream);
+
+/* ---- central inference in six launches for the frame-stacked Atari agents (r6; csrc/servestep.hip) ----------
+ * The same `inference` function (agents/vtrace/learner.py:350-405) for agents whose only recurrent state is the frame
+ * stack (atari/networks.py:57-173), with the stack kept WHERE THE UNROLL STORE ALREADY HOLDS IT: stack channel c >= 1 of
+ * env e at store slot idx is the observation at slot idx - c (slots below 0 wrap to full_length - 1 + (idx - c): slot 0
+ * is the carried copy of the last slot, common/utils.py:237-255), valid iff c <= stack_valid[e] and the step is not
+ * `done`; stack_valid' = min(3, done ? 1 : stack_valid + 1) -- the reference's cumulative-OR done masks
+ * (networks.py:131-157) as a counter.  Needs full_length >= 5.  One step =
+ *   seedhip_serve_begin              every piece of bookkeeping that does not depend on the network (what
+ *                                    seedhip_inference_pre + _post do, incl. batch columns in env_ids order), and the first
+ *                                    conv's W / 255 as three bf16 planes (conv0_split, seedhip_serve_conv0_split_bytes)
+ *   seedhip_conv2d_stack_fwd_rows    first conv from the request frames + the store's history; appends the frames
+ *   seedhip_conv2d_fwd ...           the torso's other convs (library kernels)
+ *   seedhip_dense_fwd_partial        the Dense layer's split-K partial sums (no reduce / epilogue launch)
+ *   seedhip_serve_finish             sum of the slices + bias + ReLU -> packed heads -> action sampling
+ *                                    (dmlab/networks.py:122; same (seed, call, row) function as seedhip_categorical_sample)
+ *                                    -> the step's scalar fields appended to the store, action table (:403)
+ *   seedhip_serve_emit               completed unrolls -> time-major training batch ring (:396-397, 418-432), last
+ *                                    step carried to slot 0, first agent state handed over and the next one packed
+ *                                    (:398-399; bit order of networks.py:164-169) from the store's frames.
+ * Tables are per env [num_envs], scratch per row [n]; all device memory, caller-owned, zero-initialised once.
+ * error_flag bits as seedhip_inference_pre / _post. */
+typedef struct seedhip_serve_step {
+  /* the request batch */
+  const long long* env_ids; const long long* run_ids; const float* reward; const float* raw_reward;
+  const uint8_t* done; const uint8_t* abandoned /* may be NULL */; const int* episode_step /* may be NULL */;
+  int n, num_envs, num_action_repeats, full_length, batch_capacity;
+  /* per-env tables */
+  long long* run_ids_table; long long* info_frames; float* info_return; float* info_raw_return;
+  long long* actions_table; long long* store_index;
+  uint8_t* stack_valid;         /* frames of the stack in front of the next step that are inside the episode, 0..3 */
+  uint8_t* first_zero;          /* 1: the env's current unroll starts from the initial (zero) agent state */
+  int* stamp_table; int* call_counter;
+  float* episode_stats; int stats_capacity; int* stats_count; int* error_flag;
+  int* batch_count; const int* batch_start /* may be NULL = 0 */;
+  unsigned long long* rng_state; /* [2] seed, call counter (advanced by serve_begin) */
+  /* per-call scratch */
+  long long* ids_safe; uint8_t* valid; long long* prev_actions;
+  long long* append_rows;       /* [n] store row (slot * num_envs + env) of this step, -1 for masked rows */
+  long long* hist_rows;         /* [n][4] store rows of stack channels 0..3 */
+  uint8_t* nvalid;              /* [n] stack channels inside the episode at this step, 1..4 */
+  uint8_t* prev_valid;          /* [n] stack_valid before this step */
+  long long* emit_env; long long* emit_col /* -1: dropped, batch full */; int* emit_row; int* emit_count;
+  unsigned long long* rng_snapshot; /* [2] the (seed, call) this step samples with */
+} seedhip_serve_step;
+/* the store's scalar fields, time-major [full_length, num_envs] (policy_logits [.., num_actions]) */
+typedef struct seedhip_serve_fields {
+  long long* prev_actions; float* reward; uint8_t* done; uint8_t* abandoned; int* episode_step;
+  long long* action; float* policy_logits; float* baseline;
+} seedhip_serve_fields;
+size_t seedhip_serve_conv0_split_bytes(int cout);
+/* the weight planes alone (what serve_begin's extra workgroups do): conv0_w [8,8,4,cout] fp32 -> conv0_split */
+int seedhip_serve_split_conv0(const float* conv0_w, int conv0_cout, void* conv0_split, void* stream);
+/* heads_image (may be NULL; seedhip_serve_heads_image_bytes(feat) bytes): the packed heads W [feat, ldh]
+ * (seedhip_heads_supported) as the B-operand register image serve_finish multiplies with. */
+size_t seedhip_serve_heads_image_bytes(int feat);
+int seedhip_serve_begin(const seedhip_serve_step* step, const float* conv0_w /* [8,8,4,cout] */, int conv0_cout,
+                        void* conv0_split /* may be NULL */, const float* heads_w, int feat, int ldh,
+                        void* heads_image, void* stream);
+/* geom->T == 1, geom->B == n.  obs u8 [n, ih*iw]; store_obs u8 [full_length * num_envs, ih*iw] (read: history rows
+ * hist_rows[4 b + c], c < nvalid[b]; written: row append_rows[b] when >= 0); w_split: the W / 255 planes of
+ * seedhip_serve_begin / seedhip_serve_split_conv0. */
+int seedhip_conv2d_stack_fwd_rows_supported(const seedhip_stack_conv_geom* geom);
+int seedhip_conv2d_stack_fwd_rows(const seedhip_stack_conv_geom* geom, const uint8_t* obs, uint8_t* store_obs,
+                                  const long long* hist_rows, const long long* append_rows, const uint8_t* nvalid,
+                                  const void* w_split, const float* bias, float* out, int out_relu, void* stream);
+/* Dense forward without its epilogue: partial[z][m][n], z < *slices, in `workspace`; summing the slices in order + bias
+ * (+ ReLU) equals seedhip_conv2d_fwd_ws's output for the same geometry below 4096 rows bit for bit. */
+size_t seedhip_dense_fwd_partial_workspace_bytes(const seedhip_conv_geom* geom);
+int seedhip_dense_fwd_partial(const seedhip_conv_geom* geom, const float* in, int in_relu, const float* w,
+                              void* workspace, size_t workspace_bytes, int* slices, void* stream);
+/* fc_partial [slices][n][feat]; heads_image: serve_begin's image of the packed heads [feat, ldh]; actions int64 [n] out. */
+int seedhip_serve_finish(const seedhip_serve_step* step, const seedhip_serve_fields* store_fields,
+                         const float* fc_partial, int slices, const float* fc_bias, int feat, const void* heads_image,
+                         const float* heads_b, int ldh, int num_actions, long long* actions, void* stream);
+/* nfields <= 16 fields (host arrays of device pointers; rows of row_bytes[f]): store [full_length, num_envs] -> batch
+ * [full_length, batch_capacity]; first_table int32 [num_envs, hw], batch_first int32 [batch_capacity, hw], store_obs as
+ * above (hw = ih * iw bytes per frame, % 16 == 0). */
+int seedhip_serve_emit(const seedhip_serve_step* step, int nfields, void* const* batch, void* const* store,
+                       const long long* row_bytes, int* first_table, int* batch_first, const uint8_t* store_obs,
+                       long long hw, void* stream);
 
 /* ---- prioritized replay sampling --------------------------------------------------------------------
  * Replaces PrioritizedReplay.sample of common/utils.py:309-357 for priority_exponent > 0: categorical sampling

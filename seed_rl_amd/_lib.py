@@ -15,7 +15,7 @@ import torch  # noqa: F401  pylint: disable=unused-import
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEEDHIP_LIB: another build of the same library (same-box A/B runs of two builds; nothing else changes: no fallback)
 LIB_PATH = os.environ.get('SEEDHIP_LIB') or os.path.join(_HERE, 'lib', 'libseedhip.so')
-ABI_VERSION = 5          # include/seedhip.h SEEDHIP_ABI_VERSION this binding was written against
+ABI_VERSION = 6          # include/seedhip.h SEEDHIP_ABI_VERSION this binding was written against
 
 c_int, c_ll, c_float, c_size_t, c_void_p = (
     ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p)
@@ -38,6 +38,23 @@ class RowOp(ctypes.Structure):
   _fields_ = [('dst', c_void_p), ('src', c_void_p), ('row_bytes', c_ll), ('dst_pitch', c_ll), ('src_pitch', c_ll),
               ('dst_rows', c_void_p), ('src_rows', c_void_p), ('n', c_ll), ('row_mask', c_void_p),
               ('zero_where_masked', c_int)]
+
+
+class ServeStep(ctypes.Structure):
+  """seedhip_serve_step (field order of include/seedhip.h)."""
+  _fields_ = ([(n, c_void_p) for n in 'env_ids run_ids reward raw_reward done abandoned episode_step'.split()] +
+              [(n, c_int) for n in 'n num_envs num_action_repeats full_length batch_capacity'.split()] +
+              [(n, c_void_p) for n in ('run_ids_table info_frames info_return info_raw_return actions_table store_index '
+                                       'stack_valid first_zero stamp_table call_counter episode_stats').split()] +
+              [('stats_capacity', c_int)] +
+              [(n, c_void_p) for n in ('stats_count error_flag batch_count batch_start rng_state ids_safe valid '
+                                       'prev_actions append_rows hist_rows nvalid prev_valid emit_env emit_col emit_row '
+                                       'emit_count rng_snapshot').split()])
+
+
+class ServeFields(ctypes.Structure):
+  """seedhip_serve_fields."""
+  _fields_ = [(n, c_void_p) for n in 'prev_actions reward done abandoned episode_step action policy_logits baseline'.split()]
 
 
 # name -> (restype, argtypes); every symbol include/seedhip.h declares.
@@ -127,6 +144,17 @@ SIGNATURES = {
     'seedhip_emit_unrolls': (c_int, [c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'seedhip_categorical_sample': (c_int, [P, c_int, c_ll, c_int, P, P, P]),
     'seedhip_rows_move_ops': (c_int, [c_int, P, P]),
+    'seedhip_serve_conv0_split_bytes': (c_size_t, [c_int]),
+    'seedhip_serve_split_conv0': (c_int, [P, c_int, P, P]),
+    'seedhip_serve_heads_image_bytes': (c_size_t, [c_int]),
+    'seedhip_serve_begin': (c_int, [ctypes.POINTER(ServeStep), P, c_int, P, P, c_int, c_int, P, P]),
+    'seedhip_conv2d_stack_fwd_rows_supported': (c_int, [ctypes.POINTER(StackConvGeom)]),
+    'seedhip_conv2d_stack_fwd_rows': (c_int, [ctypes.POINTER(StackConvGeom), P, P, P, P, P, P, P, P, c_int, P]),
+    'seedhip_dense_fwd_partial_workspace_bytes': (c_size_t, [ctypes.POINTER(ConvGeom)]),
+    'seedhip_dense_fwd_partial': (c_int, [ctypes.POINTER(ConvGeom), P, c_int, P, P, c_size_t, ctypes.POINTER(c_int), P]),
+    'seedhip_serve_finish': (c_int, [ctypes.POINTER(ServeStep), ctypes.POINTER(ServeFields), P, c_int, P, c_int, P, P,
+                                     c_int, c_int, P, P]),
+    'seedhip_serve_emit': (c_int, [ctypes.POINTER(ServeStep), c_int, P, P, P, P, P, P, c_ll, P]),
     'seedhip_replay_sample_workspace_bytes': (c_size_t, [c_ll]),
     'seedhip_replay_sample': (c_int, [P, c_ll, c_float, c_float, P, c_int, P, P, P, c_size_t, P]),
     'seedhip_heads_supported': (c_int, [c_int, c_int]),

@@ -490,6 +490,48 @@ extern "C" int seedhip_conv2d_fwd_ws(const seedhip_conv_geom* geom, const void* 
   return check_launch("conv2d_fwd");
 }
 
+// Dense forward WITHOUT its epilogue: partial[z][m][n] = sum over the k of slice z of in[m][k] w[k][n], z < *slices (>= 1).
+// The caller's next kernel sums the slices in order, adds the bias and applies the activation while it loads its own
+// operand (servestep.hip: the Dense layer of central inference feeds the heads) -- the reduce + epilogue launch of the
+// split-K paths and the activation's round trip through memory disappear.  Same kernels, plans and slice order as
+// seedhip_conv2d_fwd_ws takes for the shape (bf16x6 xgemm.h from 2048 rows, gemm.h below): summing the slices in order
+// + bias (+ ReLU) reproduces its output bit for bit.
+extern "C" size_t seedhip_dense_fwd_partial_workspace_bytes(const seedhip_conv_geom* g) {
+  if (!g || !is_dense(g)) return 0;
+  int sl = 1;
+  if (xg::mode() & 1) { const xg::Plan xp = x6_fwd_plan(g); if (xp.ok) sl = xp.slices; }
+  const gemm::Plan pl = gemm::plan(g->n_img, g->cout, g->cin);
+  if (pl.slices > sl) sl = pl.slices;
+  return (size_t)sl * g->n_img * g->cout * sizeof(float);
+}
+
+extern "C" int seedhip_dense_fwd_partial(const seedhip_conv_geom* geom, const float* in, int in_relu, const float* w,
+                                         void* workspace, size_t workspace_bytes, int* slices, void* stream) {
+  SEEDHIP_REQUIRE(geom && in && w && workspace && slices, "dense_fwd_partial: null pointer");
+  SEEDHIP_REQUIRE(is_dense(geom) && gemm_fwd_ok(geom) && al16(in) && al16(w) && al16(workspace),
+                  "dense_fwd_partial: needs a Dense geometry with ld_in %% 4 == 0, cout %% 4 == 0 and 16-byte aligned buffers");
+  SEEDHIP_REQUIRE(workspace_bytes >= seedhip_dense_fwd_partial_workspace_bytes(geom), "dense_fwd_partial: workspace too small");
+  const int M = geom->n_img, N = geom->cout, K = geom->cin;
+  hipStream_t s = (hipStream_t)stream;
+  gemm::Params gp;
+  memset(&gp, 0, sizeof(gp));
+  gp.A = in; gp.lda = geom->ld_in; gp.a_relu = in_relu; gp.B = w; gp.ldb = N;
+  gp.M = M; gp.N = N; gp.K = K; gp.C = (float*)workspace; gp.ldc = N; gp.partial = (float*)workspace;
+  if (xg::mode() & 1) {
+    const xg::Plan xp = x6_fwd_plan(geom);
+    if (xp.ok) {
+      xg::launch<true, false>(gp, xp, s);
+      *slices = xp.slices;
+      return check_launch("dense_fwd_partial(bf16x6)");
+    }
+  }
+  const gemm::Plan pl = gemm::plan(M, N, K);
+  gp.k_per_slice = pl.k_per_slice;
+  gemm::launch<true, false>(gp, pl, s);
+  *slices = pl.slices;
+  return check_launch("dense_fwd_partial(gemm)");
+}
+
 extern "C" int seedhip_conv2d_bwd_data(const seedhip_conv_geom* geom, const float* dy, const float* w, float* dx,
                                        const float* relu_mask, const float* add, void* stream) {
   return seedhip_conv2d_bwd_data_ws(geom, dy, w, dx, relu_mask, add, nullptr, 0, stream);

@@ -618,6 +618,133 @@ stackconv_fwd_bf16r_kernel(const Params p) {
   }
 }
 
+// ------------------------------------------------------------------------------------ //
+// The same forward for CENTRAL INFERENCE (r6; servestep.hip): one step of n independent environments.  Row b's stack is
+// its request frame obs[b] plus the three frames the unroll store already holds for that env (store_obs rows
+// hist_rows[4b + c], c = 1..3; see servestep.hip), nvalid[b] of them inside the episode; the request frame is written to
+// its store row append_rows[b] on the way (the append of the largest field, common/utils.py:187-194) -- the bit-packed
+// per-env stacking state, its unpack pass before and its re-pack pass after the conv do not exist here.  Same operands,
+// same MFMA order per accumulator as stackconv_fwd_bf16r_kernel: bit-identical outputs.  The W / 255 planes arrive
+// pre-split (w_split: serve_begin or seedhip_serve_split_conv0, the training kernel's own prologue arithmetic): a
+// workgroup lives for two or three frames, not for an unroll, and the 64 divisions + splits per lane were a third of its time.
+// ------------------------------------------------------------------------------------ //
+struct RowsParams {
+  const uint8_t* obs;          // u8 [B, fsz]
+  const uint8_t* store_obs;    // u8 [rows, fsz]: the observation field of the unroll store (read: history, written: this step)
+  const long long* hist_rows;  // [B][4]
+  const long long* append_rows;// [B], < 0: do not write
+  const uint8_t* nvalid;       // [B]
+  const float* w; const float* bias; const uint4* w_split;
+  float* out; int B, cout, ld_out, fsz;
+};
+
+template <bool RELU>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
+stackconv_rows_kernel(const RowsParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint4* wlo_lds = reinterpret_cast<uint4*>(smem);
+  unsigned char* myring = smem + kGroups * 64 * 16 + wave * kWaveRing16;
+  const int kq = lane >> 4, j = lane & 15;
+  const int co0 = blockIdx.z * 16;
+
+  Frag8 wreg[kGroups][2];
+  {
+    const uint4* img = p.w_split + (long long)blockIdx.z * kGroups * 3 * 64 + lane;
+#pragma unroll
+    for (int G = 0; G < kGroups; ++G) {
+      wreg[G][0].u = img[(G * 3 + 0) * 64];
+      wreg[G][1].u = img[(G * 3 + 1) * 64];
+      if (wave == 0) wlo_lds[G * 64 + lane] = img[(G * 3 + 2) * 64];
+    }
+  }
+  f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+    const float4 bv = *reinterpret_cast<const float4*>(p.bias + co0 + 4 * kq);
+    bias4 = f32x4_t{bv.x, bv.y, bv.z, bv.w};
+  }
+  int aoff[kMT];
+#pragma unroll
+  for (int m = 0; m < kMT; ++m) {
+    const int pix = m * 16 + j;
+    const int oy = pix / kOW, ox = pix - oy * kOW;
+    aoff[m] = ((oy * 4 + kq) * kIW + ox * 4) * 2;
+  }
+  __syncthreads();                                    // lo parts visible; the only workgroup barrier
+  // a wave WRITES rows 16 wave .. 16 wave + 15 of the request frame (the last wave its whole 20-row band): 84 / 105 vectors
+  const int own_vec = wave == kWaves - 1 ? kBandVec : 16 * kIW / 16;
+
+  for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+    const int nv = nvalid_at(p.nvalid, b);
+    const long long arow = p.append_rows[b];
+    BandPrefetch f[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {                      // stack channel c sits in ring slot 3 - c
+      if (c < nv) {
+        const uint8_t* fr = c == 0 ? p.obs + (long long)b * p.fsz : p.store_obs + p.hist_rows[4 * b + c] * p.fsz;
+        f[c] = band_load(reinterpret_cast<const uint4*>(fr + wave * 16 * kIW), lane);
+      }
+    }
+    if (arow >= 0 && blockIdx.z == 0) {
+      uint4* dst = reinterpret_cast<uint4*>(const_cast<uint8_t*>(p.store_obs) + arow * p.fsz + wave * 16 * kIW);
+      dst[lane] = f[0].v0;
+      if (lane + 64 < own_vec) dst[lane + 64] = f[0].v1;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < nv) band_store16(myring + (3 - c) * kBand16, f[c], lane);
+    wave_lds_fence();
+    f32x4_t acc[kMT];
+#pragma unroll
+    for (int m = 0; m < kMT; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto group = [&](int G) {
+      const unsigned char* base = myring + (3 - (G >> 1)) * kBand16 + (G & 1) * 4 * kIW * 2;
+      Frag8 wlo;
+      wlo.u = wlo_lds[G * 64 + lane];
+      Frag8 xf[kMT];
+#pragma unroll
+      for (int m = 0; m < kMT; ++m) {
+        typedef __attribute__((address_space(3))) const volatile unsigned long long lds_cv64_t;
+        lds_cv64_t* src = (lds_cv64_t*)(base + aoff[m]);
+        const unsigned long long x0 = src[0], x1 = src[1];
+        xf[m].u = make_uint4((unsigned)x0, (unsigned)(x0 >> 32), (unsigned)x1, (unsigned)(x1 >> 32));
+      }
+#pragma unroll
+      for (int m = 0; m < kMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo.v, xf[m].v, acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < kMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[G][1].v, xf[m].v, acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < kMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[G][0].v, xf[m].v, acc[m], 0, 0, 0);
+    };
+    if (nv == 4) {
+#pragma unroll
+      for (int G = 0; G < kGroups; ++G) group(G);
+    } else {
+#pragma unroll
+      for (int G = 0; G < kGroups; ++G) if (G < 2 * nv) group(G);
+    }
+    wave_lds_fence();                                  // the ring is rewritten by the next row
+    f32x4_t vout[kMT];
+#pragma unroll
+    for (int m = 0; m < kMT; ++m) {
+      vout[m] = acc[m] + bias4;
+      if (RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vout[m][r] = __builtin_amdgcn_fmed3f(vout[m][r], 0.f, __builtin_inff());
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < kMT; ++m) asm volatile("" : "+v"(vout[m]));   // every output finished before the first store (see above)
+#pragma unroll
+    for (int m = 0; m < kMT; ++m) {
+      const int pix = wave * 80 + m * 16 + j;
+      const f32x4_t v = vout[m];
+      float* o = p.out + ((long long)b * 400 + pix) * p.ld_out + co0 + 4 * kq;
+      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
 // (r1-r4: the channel-per-wave / channel-pair weight-gradient kernels lived here; r5: the transposing-read kernel below)
 constexpr int kFrame16 = kIH * kIW * 2;                  // 14112 B: one frame in bf16
 constexpr int kFrameSlots = 5;
@@ -1006,6 +1133,39 @@ extern "C" int seedhip_conv2d_stack_fwd_bits(const seedhip_stack_conv_geom* geom
   return stackconv::launch_fwd(geom, frames_ext, nvalid, w, bias, out, 1, (hipStream_t)stream, relu_bits);
 }
 
+// Central inference: the first conv over n = geom->B independent rows (geom->T == 1) whose stacks live in the unroll
+// store (see stackconv_rows_kernel / servestep.hip).
+extern "C" int seedhip_conv2d_stack_fwd_rows_supported(const seedhip_stack_conv_geom* g) {
+  return g && g->T == 1 && g->kh == 8 && g->kw == 8 && g->stride == 4 && g->ih == stackconv::kIH && g->iw == stackconv::kIW &&
+         g->oh == 20 && g->ow == 20 && g->cout % 16 == 0 && g->ld_out % 4 == 0 && stackconv::bf16x3_enabled();
+}
+
+extern "C" int seedhip_conv2d_stack_fwd_rows(const seedhip_stack_conv_geom* geom, const uint8_t* obs, uint8_t* store_obs,
+                                             const long long* hist_rows, const long long* append_rows,
+                                             const uint8_t* nvalid, const void* w_split, const float* bias,
+                                             float* out, int out_relu, void* stream) {
+  int rc = check_stack(geom, "conv2d_stack_fwd_rows"); if (rc) return rc;
+  SEEDHIP_REQUIRE(obs && store_obs && hist_rows && append_rows && nvalid && w_split && out, "conv2d_stack_fwd_rows: null pointer");
+  SEEDHIP_REQUIRE(seedhip_conv2d_stack_fwd_rows_supported(geom), "conv2d_stack_fwd_rows: geometry not served (ask seedhip_conv2d_stack_fwd_rows_supported)");
+  SEEDHIP_REQUIRE(((((uintptr_t)obs) | ((uintptr_t)store_obs) | ((uintptr_t)out) | ((uintptr_t)bias) | ((uintptr_t)w_split)) & 15) == 0,
+                  "conv2d_stack_fwd_rows: 16-byte aligned buffers");
+  stackconv::RowsParams p;
+  p.obs = obs; p.store_obs = store_obs; p.hist_rows = hist_rows; p.append_rows = append_rows; p.nvalid = nvalid;
+  p.w = nullptr; p.bias = bias; p.w_split = (const uint4*)w_split; p.out = out; p.B = geom->B; p.cout = geom->cout;
+  p.ld_out = geom->ld_out; p.fsz = geom->ih * geom->iw;
+  const size_t lds = (size_t)stackconv::kGroups * 64 * 16 + (size_t)stackconv::kWaves * stackconv::kWaveRing16;
+  const int grid = p.B < stackconv::max_grid_for(2) ? p.B : stackconv::max_grid_for(2);
+  hipStream_t s = (hipStream_t)stream;
+  if (out_relu) {
+    (void)hipFuncSetAttribute((const void*)stackconv::stackconv_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(stackconv::stackconv_rows_kernel<true>, dim3(grid, 1, geom->cout / 16), dim3(stackconv::kThreads), lds, s, p);
+  } else {
+    (void)hipFuncSetAttribute((const void*)stackconv::stackconv_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(stackconv::stackconv_rows_kernel<false>, dim3(grid, 1, geom->cout / 16), dim3(stackconv::kThreads), lds, s, p);
+  }
+  return check_launch("stackconv_rows_kernel");
+}
+
 extern "C" size_t seedhip_conv2d_stack_bwd_weight_workspace_bytes(const seedhip_stack_conv_geom* g) {
   if (!g) return 0;
   const size_t a = generic_wgrad_ws(g), b = fast_wgrad_ws(g);
@@ -1033,7 +1193,6 @@ extern "C" int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* ge
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     static const int bf16x3 = getenv("SEEDHIP_STACK_BF16") ? atoi(getenv("SEEDHIP_STACK_BF16")) : 1;
     if (bf16x3) {
-      const size_t ldsc = (size_t)stackconv::kFrameSlots * stackconv::kFrame16;
 #define SEEDHIP_TR(LD_)                                                                                            \
       {                                                                                                           \
         (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_tr_kernel<LD_>,                          \

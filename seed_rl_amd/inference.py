@@ -10,11 +10,13 @@ handed to `unroll_sink` time-major (what `unroll_queue.enqueue_many` + `dequeue`
 produce in the reference, learner.py:396-397,418-432), optionally straight into a training batch.
 """
 import collections
+import ctypes
+import os
 
 import torch
 
 from seed_rl_amd import learner as learner_lib
-from seed_rl_amd import ops, unroll_store, utils
+from seed_rl_amd import _lib, ops, unroll_store, utils
 from seed_rl_amd.unroll_store import Spec
 
 EpisodeInfo = collections.namedtuple('EpisodeInfo', 'episode_num_frames episode_returns episode_raw_returns')
@@ -150,7 +152,19 @@ class FusedInferenceState(object):
     state_specs = unroll_store.specs_like(agent.initial_state(1))
     mks = lambda lead: unroll_store._map_specs(
         lambda s: torch.zeros((lead,) + tuple(s.shape), dtype=s.dtype, device=dev), state_specs)
-    self.first_agent_states, self.agent_states = mks(num_envs), mks(num_envs)
+    # Agents whose only recurrent state is the frame stack (AtariShallow) are served in six launches by
+    # csrc/servestep.hip: the stack is read from the store's own observation field, the bit-packed per-env state table
+    # does not exist (only the first state of each env's CURRENT unroll is kept, packed when an unroll completes).
+    # SEEDHIP_SERVE_STEP=0: the generic sixteen-launch path below (any agent).
+    obs_spec = env_output_specs.observation
+    self._serve = (os.environ.get('SEEDHIP_SERVE_STEP', '1') != '0' and
+                   getattr(agent, 'serve_step_supported', None) is not None and agent.serve_step_supported(self.L) and
+                   obs_spec.dtype == torch.uint8 and len(obs_spec.shape) == 3 and obs_spec.shape[2] == 1 and
+                   len(utils.flatten(agent.initial_state(1))) == 1 and batch_capacity >= 1)
+    self.first_agent_states = mks(num_envs)
+    self.agent_states = None if self._serve else mks(num_envs)
+    self.stack_valid = torch.zeros(num_envs, dtype=torch.uint8, device=dev)    # serve path: frames of the stack in the episode
+    self.first_zero = torch.zeros(num_envs, dtype=torch.uint8, device=dev)     # serve path: unroll starts from the zero state
     self.batch = learner_lib.Unroll(mks(batch_capacity), *fields)
     self.batch_count = torch.zeros(1, dtype=torch.int32, device=dev)
     # the batch is a RING of columns: head on the device (read by inference_post) and mirrored on the host (it only
@@ -165,7 +179,7 @@ class FusedInferenceState(object):
     # the frame-stacking state (28 KB per Atari env) is used IN PLACE in its table by agents that support it: no gather
     # into a scratch before the forward, no scatter back after it
     self._frame_leaf = None
-    if getattr(agent, 'accepts_indexed_frame_state', False) and hasattr(self.agent_states, '_fields') and \
+    if not self._serve and getattr(agent, 'accepts_indexed_frame_state', False) and hasattr(self.agent_states, '_fields') and \
         'frame_stacking_state' in self.agent_states._fields:
       leaves = utils.flatten(self.agent_states)
       fs = self.agent_states.frame_stacking_state
@@ -186,8 +200,13 @@ class FusedInferenceState(object):
                will_complete=u8(n),
                actions=i64(n), zeros_bool=torch.zeros(n, dtype=torch.bool, device=dev),
                zeros_i32=torch.zeros(n, dtype=torch.int32, device=dev))
-      tabs = utils.flatten(self.agent_states)
-      b['prev_state'] = [torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev) for t in tabs]
+      if self._serve:
+        b.update(hist_rows=i64(4 * n), nvalid=u8(n), prev_valid=u8(n),
+                 emit_row=torch.zeros(n, dtype=torch.int32, device=dev), rng_snapshot=i64(2))
+        b['step'], b['fields'] = self._serve_structs(n, b)
+      else:
+        tabs = utils.flatten(self.agent_states)
+        b['prev_state'] = [torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev) for t in tabs]
       self._scratch[n] = b
     return b
 
@@ -207,6 +226,8 @@ class FusedInferenceState(object):
     runs = torch.as_tensor(run_ids, device=dev).to(torch.int64).contiguous()
     n = ids.numel()
     b = self._bufs(n)
+    if self._serve:
+      return self._inference_serve(ids, runs, env_outputs, raw_rewards, n, b)
     op = ops.row_op
     reward = env_outputs.reward.to(torch.float32).contiguous()
     done_u8 = ops.as_u8(env_outputs.done)
@@ -287,6 +308,64 @@ class FusedInferenceState(object):
     ops.rows_move_ops(
         [op(s_, s_, rb, n, dst_rows=sid, src_rows=b['last'], mask=b['carry']) for s_, rb in zip(stores, rbs)] +   # carry
         [op(f, p, rb, n, dst_rows=sid, mask=b['carry']) for f, p, rb in zip(firsts, prevs, srb)])   # :398-399
+    return b['actions']
+
+  def _serve_structs(self, n, b):
+    """The seedhip_serve_step / seedhip_serve_fields of batch size n: every table and scratch pointer is static; the
+    request pointers are filled in per call."""
+    p = lambda t: t.data_ptr()
+    st = _lib.ServeStep()
+    st.n, st.num_envs, st.num_action_repeats = n, self.E, self.num_action_repeats
+    st.full_length, st.batch_capacity = self.L, self.cap
+    st.run_ids_table, st.info_frames, st.info_return, st.info_raw_return = (
+        p(self.run_ids_tab), p(self.info_frames), p(self.info_return), p(self.info_raw))
+    st.actions_table, st.store_index = p(self.actions_tab), p(self.store_index)
+    st.stack_valid, st.first_zero = p(self.stack_valid), p(self.first_zero)
+    st.stamp_table, st.call_counter = p(self.stamp_tab), p(self.call_counter)
+    st.episode_stats, st.stats_capacity, st.stats_count = p(self.episode_stats), self.episode_stats.shape[0], p(self.stats_count)
+    st.error_flag, st.batch_count, st.batch_start = p(self.error_flag), p(self.batch_count), p(self.batch_start)
+    st.rng_state = p(self.agent.rng_state())
+    st.ids_safe, st.valid, st.prev_actions, st.append_rows = p(b['ids_safe']), p(b['valid']), p(b['prev_actions']), p(b['append_rows'])
+    st.hist_rows, st.nvalid, st.prev_valid = p(b['hist_rows']), p(b['nvalid']), p(b['prev_valid'])
+    st.emit_env, st.emit_col, st.emit_row, st.emit_count = p(b['emit_env']), p(b['emit_col']), p(b['emit_row']), p(b['emit_count'])
+    st.rng_snapshot = p(b['rng_snapshot'])
+    prev, env, ao = self.store
+    f = _lib.ServeFields()
+    f.prev_actions, f.reward, f.done, f.abandoned, f.episode_step = p(prev), p(env.reward), p(env.done), p(env.abandoned), p(env.episode_step)
+    f.action, f.policy_logits, f.baseline = p(ao.action), p(ao.policy_logits), p(ao.baseline)
+    return st, f
+
+  def _inference_serve(self, ids, runs, env_outputs, raw_rewards, n, b):
+    """learner.py:350-405 in SIX launches (csrc/servestep.hip): serve_begin, the first conv from the request frames +
+    the store's history (appending the frames), the second conv, the Dense partial sums, serve_finish (Dense epilogue +
+    heads + sampling + append of the scalar fields + action table) and serve_emit (completed unrolls -> training batch,
+    carry, first agent state) -- no row mover, no unpack / re-pack of the stacking state."""
+    st, fields = b['step'], b['fields']
+    reward = env_outputs.reward.to(torch.float32).contiguous()
+    raw = raw_rewards.to(torch.float32).contiguous()
+    done_u8 = ops.as_u8(env_outputs.done).contiguous()
+    obs = env_outputs.observation
+    if obs.dtype != torch.uint8 or not obs.is_contiguous():
+      raise ValueError('observations must be contiguous uint8 frames')
+    ab = None if env_outputs.abandoned is None else ops.as_u8(env_outputs.abandoned).contiguous()
+    es = None if env_outputs.episode_step is None else env_outputs.episode_step.to(torch.int32).contiguous()
+    st.env_ids, st.run_ids, st.reward, st.raw_reward, st.done = (ids.data_ptr(), runs.data_ptr(), reward.data_ptr(),
+                                                                 raw.data_ptr(), done_u8.data_ptr())
+    st.abandoned = None if ab is None else ab.data_ptr()
+    st.episode_step = None if es is None else es.data_ptr()
+    agent = self.agent
+    st.rng_state = agent.rng_state().data_ptr()
+    ops.serve_begin(st, *agent.serve_begin_weights(), like=ids)
+    store_obs = self.store[1].observation
+    part, slices, fc_b, feat, hw_, hb_, ldh, A = agent.serve_forward(n, obs, store_obs, b['hist_rows'], b['append_rows'],
+                                                                     b['nvalid'])
+    ops.serve_finish(st, fields, part, slices, fc_b, feat, hw_, hb_, ldh, A, b['actions'])
+    stores = utils.flatten(self.store)
+    outs = utils.flatten((self.batch.prev_actions, self.batch.env_outputs, self.batch.agent_outputs))
+    rbs = [self._rb(s_, 2) for s_ in stores]
+    hw = self._rb(store_obs, 2)
+    ops.serve_emit(st, outs, stores, rbs, utils.flatten(self.first_agent_states)[0],
+                   utils.flatten(self.batch.agent_state)[0], store_obs, hw)
     return b['actions']
 
   def graphed(self, n, observation_shape, warmup=3, input_slot=0):
@@ -373,7 +452,8 @@ class FusedInferenceState(object):
     return ([self.run_ids_tab, self.info_frames, self.actions_tab, self.store_index, self.info_return, self.info_raw,
              self.batch_count, self.batch_start, self.stats_count, self.error_flag, self.episode_stats, self.stamp_tab,
              self.call_counter] + rng +
-            utils.flatten(self.store) + utils.flatten(self.first_agent_states) + utils.flatten(self.agent_states) +
+            utils.flatten(self.store) + utils.flatten(self.first_agent_states) +
+            (utils.flatten(self.agent_states) if self.agent_states is not None else [self.stack_valid, self.first_zero]) +
             utils.flatten(self.batch))
 
   def check_errors(self):

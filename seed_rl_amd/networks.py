@@ -548,6 +548,37 @@ class _AtariTorso(object):
       ops.stack_pack_state(ext, nvalid, T1, B, HW, new_fs)
     return new_fs, dict(ext=ext, nvalid=nvalid, acts=acts, geoms=geoms, gfc=gfc, bits0=bits0, bits_last=bits_last)
 
+  # -- central inference in six launches (csrc/servestep.hip; inference.FusedInferenceState) ---------------------- #
+  def serve_torso_supported(self):
+    ih, iw, _, k, s, ch, oh, ow = self._shapes[0]
+    return ops.conv2d_stack_fwd_rows_supported(ops.StackConvGeom(1, 1, ih, iw, oh, ow, k, k, s, ch, ch))
+
+  def conv0_split_buffer(self):
+    """The first conv's W / 255 as bf16 planes (written by serve_begin every call: the weights train)."""
+    ch = self._shapes[0][5]
+    return self._buf('conv0_split', (ops.serve_conv0_split_bytes(ch) // 4,), torch.int32)
+
+  def _torso_fwd_rows(self, n, obs, store_obs, hist_rows, append_rows, nvalid):
+    """One inference step of n envs whose frame stacks live in the unroll store (store_obs u8 [rows, H*W]; history rows
+    hist_rows [n, 4], nvalid [n]); the request frames obs u8 [n, H*W] are appended to rows append_rows on the way.
+    Returns the Dense layer's split-K partial sums [slices][n][fc] and the slice count: bias + ReLU are applied by the
+    consumer (serve_finish)."""
+    fl, tp = self.flat, self._tp
+    ih, iw, _, k, s, ch, oh, ow = self._shapes[0]
+    g0 = ops.StackConvGeom(1, n, ih, iw, oh, ow, k, k, s, ch, ch)
+    a = self._buf('srv_act0', (n, oh, ow, ch))
+    ops.conv2d_stack_fwd_rows(g0, obs, store_obs, hist_rows, append_rows, nvalid, self.conv0_split_buffer(),
+                              fl.p(tp + 'conv0/bias'), a, out_relu=True)
+    for i in range(1, len(self._shapes)):
+      ih, iw, cin, k, s, ch, oh, ow = self._shapes[i]
+      g = ops.conv_geom(n, ih, iw, cin, k, k, s, 'valid', ch)
+      a2 = self._buf('srv_act%d' % i, (n, oh, ow, ch))
+      ops.conv2d_fwd(g, a, fl.p('%sconv%d/kernel' % (tp, i)), fl.p('%sconv%d/bias' % (tp, i)), a2, out_relu=True)
+      a = a2
+    gfc = ops.dense_geom(n, self._flat_dim, self._fc)
+    ws = self._buf('srv_fc_partial', (ops.dense_fwd_partial_workspace_bytes(gfc) // 4 + 4,))
+    return ws, ops.dense_fwd_partial(gfc, a, fl.p(tp + 'fc/kernel'), ws)
+
   def _torso_bwd(self, ctx, dz, wsb):
     """dz: gradient wrt the Dense pre-activation (already masked by its ReLU), row stride = gfc.ld_out."""
     fl, tp = self.flat, self._tp
@@ -607,6 +638,30 @@ class AtariShallow(_Agent, _AtariTorso):
   accepts_need_state = True      # need_state=False: skip re-packing the frame-stacking state the caller will not use
   accepts_sample_actions = True
   accepts_indexed_frame_state = True    # agent_state.frame_stacking_state may be an IndexedFrameState (table rows, in place)
+
+  def serve_step_supported(self, full_length):
+    """inference.FusedInferenceState may run this agent's inference step through csrc/servestep.hip (the frame stack is
+    the agent's only recurrent state and is read from the unroll store's own frames)."""
+    return (full_length >= 5 and self.serve_torso_supported() and self._skinny_heads(self._fc) and
+            self._fc % 64 == 0 and self._fc <= 512 and self._ldh <= 32 and self._num_actions < self._ldh)
+
+  def heads_image_buffer(self):
+    """The packed heads as serve_finish's B-operand register image (written by serve_begin every call)."""
+    return self._buf('heads_image', (ops.serve_heads_image_bytes(self._fc) // 4,))
+
+  def serve_begin_weights(self):
+    """serve_begin's weight arguments: (conv0 kernel, cout, planes, heads kernel, feat, ldh, heads image)."""
+    fl = self.flat
+    return (fl.p(self._tp + 'conv0/kernel'), self._shapes[0][5], self.conv0_split_buffer(), fl.p('heads/kernel'),
+            self._fc, self._ldh, self.heads_image_buffer())
+
+  def serve_forward(self, n, obs, store_obs, hist_rows, append_rows, nvalid):
+    """Torso of one inference step (see _torso_fwd_rows) + what serve_finish needs of the heads:
+    (fc_partial, slices, fc_bias, fc, heads_image, heads_b, ldh, num_actions)."""
+    ws, slices = self._torso_fwd_rows(n, obs, store_obs, hist_rows, append_rows, nvalid)
+    fl = self.flat
+    return (ws, slices, fl.p(self._tp + 'fc/bias'), self._fc, self.heads_image_buffer(), fl.p('heads/bias'), self._ldh,
+            self._num_actions)
 
   def __call__(self, prev_actions, env_outputs, agent_state, unroll=False, is_training=False, need_state=True,
                sample_actions=True):

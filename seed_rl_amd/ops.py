@@ -743,3 +743,86 @@ def heads_fwd(x, ldx, w, bias, rows, feat, ldh, y):
     with _dev(y):
       _lib.check(_lib.lib().seedhip_heads_fwd(_lib.ptr(x), int(ldx), _lib.ptr(w), _lib.ptr(bias), int(rows), int(feat),
                                               int(ldh), _lib.ptr(y), _lib.stream()), 'seedhip_heads_fwd')
+
+
+# ---- central inference in six launches for the frame-stacked Atari agents (csrc/servestep.hip) ---------------------- #
+def serve_conv0_split_bytes(cout):
+  return int(_lib.lib().seedhip_serve_conv0_split_bytes(int(cout)))
+
+
+def serve_split_conv0(w0, cout, split):
+  """The first conv's W / 255 as three bf16 planes in the register image of its kernel (what serve_begin also does)."""
+  with _dev(split):
+    _lib.check(_lib.lib().seedhip_serve_split_conv0(_lib.ptr(w0), int(cout), _lib.ptr(split), _lib.stream()),
+               'seedhip_serve_split_conv0')
+
+
+def serve_heads_image_bytes(feat):
+  return int(_lib.lib().seedhip_serve_heads_image_bytes(int(feat)))
+
+
+def serve_begin(step, w0, cout, split, heads_w, feat, ldh, heads_image, like):
+  """step: _lib.ServeStep.  All bookkeeping of learner.py:353-381 + store index / completions + the first conv's weight
+  planes and the heads' register image."""
+  with _region('serve_begin', 0, 0):
+    with _dev(like):
+      _lib.check(_lib.lib().seedhip_serve_begin(ctypes.byref(step), _lib.ptr(w0), int(cout), _lib.ptr(split),
+                                                _lib.ptr(heads_w), int(feat), int(ldh), _lib.ptr(heads_image),
+                                                _lib.stream()), 'seedhip_serve_begin')
+
+
+def conv2d_stack_fwd_rows_supported(g):
+  return bool(_lib.lib().seedhip_conv2d_stack_fwd_rows_supported(ctypes.byref(g)))
+
+
+def conv2d_stack_fwd_rows(g, obs, store_obs, hist_rows, append_rows, nvalid, w_split, bias, out, out_relu=True):
+  """First conv of one inference step: stacks = request frames + the store's history rows; appends the frames."""
+  n = g.B
+  flops = 2.0 * n * g.oh * g.ow * g.cout * g.kh * g.kw * 4
+  nbytes = n * g.ih * g.iw * 5 + n * g.oh * g.ow * g.cout * 4           # 4 frames read, 1 written, activation written
+  with _region('stack_conv_fwd_rows', flops, nbytes, pipe=_stack_pipe):
+    with _dev(out):
+      _lib.check(_lib.lib().seedhip_conv2d_stack_fwd_rows(
+          ctypes.byref(g), _lib.ptr(obs), _lib.ptr(store_obs), _lib.ptr(hist_rows), _lib.ptr(append_rows),
+          _lib.ptr(nvalid), _lib.ptr(w_split), _lib.ptr(bias), _lib.ptr(out), int(out_relu), _lib.stream()),
+          'seedhip_conv2d_stack_fwd_rows')
+  return out
+
+
+def dense_fwd_partial_workspace_bytes(g):
+  return int(_lib.lib().seedhip_dense_fwd_partial_workspace_bytes(ctypes.byref(g)))
+
+
+def dense_fwd_partial(g, x, w, workspace, in_relu=False):
+  """Split-K partial sums of a Dense layer [slices][rows][cout] in `workspace`; returns the number of slices."""
+  slices = ctypes.c_int(0)
+  with _region(_conv_name('dense_fwd_partial', g), *_conv_cost(g, 4), pipe=lambda: _conv_pipe(g, 0)):
+    with _dev(workspace):
+      _lib.check(_lib.lib().seedhip_dense_fwd_partial(
+          ctypes.byref(g), _lib.ptr(x), int(in_relu), _lib.ptr(w), _lib.ptr(workspace),
+          workspace.numel() * workspace.element_size(), ctypes.byref(slices), _lib.stream()), 'seedhip_dense_fwd_partial')
+  return slices.value
+
+
+def serve_finish(step, fields, fc_partial, slices, fc_bias, feat, heads_image, heads_b, ldh, num_actions, actions):
+  n = step.n
+  with _region('serve_finish', 2.0 * n * feat * ldh, n * (slices * feat + ldh) * 4):
+    with _dev(actions):
+      _lib.check(_lib.lib().seedhip_serve_finish(
+          ctypes.byref(step), ctypes.byref(fields), _lib.ptr(fc_partial), int(slices), _lib.ptr(fc_bias), int(feat),
+          _lib.ptr(heads_image), _lib.ptr(heads_b), int(ldh), int(num_actions), _lib.ptr(actions), _lib.stream()),
+          'seedhip_serve_finish')
+
+
+def serve_emit(step, batch, store, row_bytes, first_table, batch_first, store_obs, hw):
+  """Completed unrolls -> training batch ring, carry, first-state hand-over (<= 16 fields per call)."""
+  k = len(batch)
+  PA = ctypes.c_void_p * k
+  da, sa = PA(*[t.data_ptr() for t in batch]), PA(*[t.data_ptr() for t in store])
+  ra = (ctypes.c_longlong * k)(*row_bytes)
+  with _region('serve_emit', 0, 0):
+    with _dev(first_table):
+      _lib.check(_lib.lib().seedhip_serve_emit(
+          ctypes.byref(step), k, ctypes.cast(da, ctypes.c_void_p), ctypes.cast(sa, ctypes.c_void_p),
+          ctypes.cast(ra, ctypes.c_void_p), _lib.ptr(first_table), _lib.ptr(batch_first), _lib.ptr(store_obs), int(hw),
+          _lib.stream()), 'seedhip_serve_emit')

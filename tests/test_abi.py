@@ -33,7 +33,7 @@ def test_signature_table_matches_header(built_lib):
   from seed_rl_amd import _lib
   assert sorted(_lib.SIGNATURES) == declared_symbols()
   l = _lib.lib()
-  assert l.seedhip_abi_version() == _lib.ABI_VERSION == 5
+  assert l.seedhip_abi_version() == _lib.ABI_VERSION == 6
   assert l.seedhip_impala_loss_workspace_bytes(20, 512) == (512 // 2) * 8 * 4
   assert l.seedhip_global_norm_workspace_bytes() > 0
 

@@ -159,14 +159,17 @@ def _drive(device, st_call, E, T, A, obs_shape, steps, seed=0):
   return acts
 
 
-@pytest.mark.parametrize('kind,graphed', [('atari', False), ('deep', False), ('atari', True), ('deep', True)])
-def test_fused_inference_matches_reference_structured_inference(device, kind, graphed):
+@pytest.mark.parametrize('kind,graphed,T', [('atari', False, 3), ('deep', False, 3), ('atari', True, 3), ('deep', True, 3),
+                                            ('atari', False, 4), ('atari', True, 5), ('atari', True, 7)])
+def test_fused_inference_matches_reference_structured_inference(device, kind, graphed, T):
   """FusedInferenceState (no host syncs, masks + device scans, optional HIP-graph replay) vs InferenceState (the
   op-by-op mirror of learner.py:350-405) on identical actor traffic incl. an actor restart and episode ends:
-  same actions, same completed unrolls (bit-exact, in completion order), same episode statistics."""
+  same actions, same completed unrolls (bit-exact, in completion order), same episode statistics.
+  T >= 4 with the Atari agent: the six-launch path of csrc/servestep.hip (frame stack read from the store's own frames);
+  T = 3: the generic path (stores shorter than five slots, any agent)."""
   from seed_rl_amd import inference, networks, utils
   from seed_rl_amd.unroll_store import Spec
-  T, E, A = 3, 4, 6
+  E, A = 4, 6
   obs_shape = (84, 84, 1) if kind == 'atari' else (24, 32, 3)
   mk = (lambda: networks.AtariShallow(A, device=device, seed=0)) if kind == 'atari' else \
        (lambda: networks.ImpalaDeep(A, observation_shape=obs_shape, device=device, seed=0))
@@ -179,6 +182,7 @@ def test_fused_inference_matches_reference_structured_inference(device, kind, gr
   steps = 3 * T + 2
   acts_ref = _drive(device, ref.inference, E, T, A, obs_shape, steps)
   fused = inference.FusedInferenceState(mk(), E, T, env_specs, ao_specs, batch_capacity=16, device=device)
+  assert fused._serve == (kind == 'atari' and T >= 4)
   call = fused.graphed(2, obs_shape) if graphed else fused.inference
   acts = _drive(device, call, E, T, A, obs_shape, steps)
   fused.check_errors()
@@ -208,14 +212,16 @@ def test_fused_inference_matches_reference_structured_inference(device, kind, gr
   assert got == ref_stats and ns > 0
 
 
-def test_fused_inference_batches_above_1024_rows(device):
-  """Inference batches of 1300 rows (inference_pre / inference_post walk them in 1024-row chunks; the rank of a
+@pytest.mark.parametrize('T', [2, 4])
+def test_fused_inference_batches_above_1024_rows(device, T):
+  """(T = 4: the six-launch path, serve_begin walks the rows in 1024-row chunks too.)
+  Inference batches of 1300 rows (inference_pre / inference_post walk them in 1024-row chunks; the rank of a
   completed unroll in the training batch is its rank in env_ids order ACROSS chunks): same actions, same completed
   unrolls in the same order, same episode statistics as the op-by-op mirror, with restarts that put the envs' unroll
   phases out of step so that completions fall in both chunks of every batch."""
   from seed_rl_amd import inference, networks, utils
   from seed_rl_amd.unroll_store import Spec
-  T, n, A = 2, 1300, 6
+  n, A = 1300, 6
   E = 2 * n
   obs_shape = (84, 84, 1)
   mk = lambda: networks.AtariShallow(A, device=device, seed=0)
@@ -228,7 +234,7 @@ def test_fused_inference_batches_above_1024_rows(device):
     torch.manual_seed(5)
     run_ids = np.full(E, 1000, np.int64)
     acts = []
-    for step in range(7):
+    for step in range(3 * T + 1):
       if step in (2, 3):                                         # a third of the actors restart: their unrolls re-phase
         who = rng.uniform(size=E) < 0.33
         run_ids[who] += step
@@ -249,7 +255,9 @@ def test_fused_inference_batches_above_1024_rows(device):
   ref = inference.InferenceState(mk(), E, T, env_specs, ao_specs, Spec((), torch.int64), device=device,
                                  unroll_sink=unrolls.append, info_sink=infos.append)
   acts_ref = drive(ref.inference)
-  fused = inference.FusedInferenceState(mk(), E, T, env_specs, ao_specs, batch_capacity=4 * E, device=device)
+  fused = inference.FusedInferenceState(mk(), E, T, env_specs, ao_specs, batch_capacity=4 * E, device=device,
+                                        stats_capacity=16384)
+  assert fused._serve == (T >= 4)
   acts = drive(fused.graphed(n, obs_shape))
   fused.check_errors()
   for a, b in zip(acts, acts_ref):
@@ -330,11 +338,12 @@ def _req(device, ids, step, obs_shape, seed):
   return torch.tensor(ids, dtype=torch.int64, device=device), torch.full((n,), 7, dtype=torch.int64, device=device), env
 
 
-def test_fused_inference_bad_ids_are_masked_not_fatal(device):
+@pytest.mark.parametrize('T', [3, 4])
+def test_fused_inference_bad_ids_are_masked_not_fatal(device, T):
   """an out-of-range or duplicate env id must not touch memory it does not own.  The offending rows are
   skipped (flags 1 / 2, check_errors raises like the reference would) and the valid rows of the same batch are
   processed exactly as without them."""
-  T, E, A = 3, 4, 6
+  E, A = 4, 6
   good, obs_shape = _mk_fused(device, E, T, A, 8)
   bad, _ = _mk_fused(device, E, T, A, 8)
   for step in range(T + 2):
@@ -350,18 +359,19 @@ def test_fused_inference_bad_ids_are_masked_not_fatal(device):
   with pytest.raises(ValueError):
     bad.check_errors()
   from seed_rl_amd import utils
-  for a, b in zip(utils.flatten(good.store) + [good.store_index, good.actions_tab, good.batch_count],
-                  utils.flatten(bad.store) + [bad.store_index, bad.actions_tab, bad.batch_count]):
+  for a, b in zip(utils.flatten(good.store) + [good.store_index, good.actions_tab, good.batch_count, good.stack_valid],
+                  utils.flatten(bad.store) + [bad.store_index, bad.actions_tab, bad.batch_count, bad.stack_valid]):
     if a.dim() >= 2 and a.shape[1] == E:
       assert torch.equal(a[:, [0, 1, 3]], b[:, [0, 1, 3]])          # env 2's duplicate may have won the race; others exact
     else:
       assert torch.equal(a[[0, 1, 3]], b[[0, 1, 3]]) if a.numel() == E else torch.equal(a, b)
 
 
-def test_fused_inference_batch_overflow_keeps_store_consistent(device):
+@pytest.mark.parametrize('T', [2, 4])
+def test_fused_inference_batch_overflow_keeps_store_consistent(device, T):
   """when the training batch is full (flag 8) a completed unroll is dropped, but its last step is still
   carried to slot 0 -- the env's NEXT unroll starts with the overlap step, as utils.py:237-255 prescribes."""
-  T, E, A = 2, 2, 6
+  E, A = 2, 6
   st, obs_shape = _mk_fused(device, E, T, A, 1)                   # room for ONE unroll; two complete at once
   last_env = None
   for step in range(T + 1):
@@ -377,11 +387,12 @@ def test_fused_inference_batch_overflow_keeps_store_consistent(device):
   assert torch.equal(st.store[1].observation[0], last_env.observation)
 
 
-def test_graphed_inference_packed_request(device):
+@pytest.mark.parametrize('T', [3, 4])
+def test_graphed_inference_packed_request(device, T):
   """fn.replay_packed(request bytes, frames): the transport-facing entry (two copies per batch) equals the
   structured call."""
   from seed_rl_amd import inference
-  T, E, A, n = 3, 4, 6, 2
+  E, A, n = 4, 6, 2
   a, obs_shape = _mk_fused(device, E, T, A, 8)
   b, _ = _mk_fused(device, E, T, A, 8)
   fa, fb = a.graphed(n, obs_shape), b.graphed(n, obs_shape)

@@ -25,7 +25,7 @@ def main():
   ap.add_argument('--envs', type=int, default=512)
   ap.add_argument('--unroll', type=int, default=20)
   ap.add_argument('--calls', type=int, default=200)
-  ap.add_argument('--mode', default='all', choices=['all', 'reference', 'fused', 'graph', 'replay'])
+  ap.add_argument('--mode', default='all', choices=['all', 'reference', 'fused', 'graph', 'replay', 'packed'])
   a = ap.parse_args()
   dev = torch.device('cuda')
   A = 18 if a.agent == 'atari' else 9
@@ -67,7 +67,7 @@ def main():
   if a.mode in ('all', 'reference'):
     st = inference.InferenceState(agent, a.envs, a.unroll, env_specs, ao_specs, Spec((), torch.int64), device=dev)
     bench('reference', st.inference)
-  if a.mode in ('all', 'fused', 'graph', 'replay'):
+  if a.mode in ('all', 'fused', 'graph', 'replay', 'packed'):
     cap = 2 * a.envs
     fused = inference.FusedInferenceState(agent, a.envs, a.unroll, env_specs, ao_specs, batch_capacity=cap, device=dev)
     calls_per_round = len(groups) * (a.unroll + 1)
@@ -89,6 +89,15 @@ def main():
         gfn.static_inputs['ids'].copy_(ids)            # 256 B: which envs this batch holds
         gfn.graph.replay()
       bench('replay', replay_only, drain)
+    if a.mode in ('all', 'packed'):
+      # what bench.py's inference record times: two copies (packed request scalars, frames) + one graph replay
+      import numpy as np
+      gfn = fused.graphed(a.n, obs)
+      packed = [torch.from_numpy(inference.pack_request(
+          a.n, g_.cpu().numpy(), np.full((a.n,), 7, np.int64), e.reward.cpu().numpy(), e.reward.cpu().numpy(),
+          e.done.cpu().numpy())).to(dev) for g_, e in zip(groups, envs)]
+      idx = {id(g_): k for k, g_ in enumerate(groups)}
+      bench('packed', lambda ids, runs, env, raw: gfn.replay_packed(packed[idx[id(ids)]], env.observation), drain)
     fused.check_errors()
 
 
