@@ -473,12 +473,12 @@ int seedhip_rows_move_ops(int nops, const seedhip_row_op* ops, void* stream);
  *   seedhip_serve_begin              every piece of bookkeeping that does not depend on the network (what
  *                                    seedhip_inference_pre + _post do, incl. batch columns in env_ids order), and the first
  *                                    conv's W / 255 as three bf16 planes (conv0_split, seedhip_serve_conv0_split_bytes)
- *   seedhip_conv2d_stack_fwd_rows    first conv from the request frames + the store's history; appends the frames
+ *   seedhip_conv2d_stack_fwd_rows    first conv from the request frames + the store's history
  *   seedhip_conv2d_fwd ...           the torso's other convs (library kernels)
  *   seedhip_dense_fwd_partial        the Dense layer's split-K partial sums (no reduce / epilogue launch)
  *   seedhip_serve_finish             sum of the slices + bias + ReLU -> packed heads -> action sampling
  *                                    (dmlab/networks.py:122; same (seed, call, row) function as seedhip_categorical_sample)
- *                                    -> the step's scalar fields appended to the store, action table (:403)
+ *                                    -> the step's fields (scalars and frames) appended to the store, action table (:403)
  *   seedhip_serve_emit               completed unrolls -> time-major training batch ring (:396-397, 418-432), last
  *                                    step carried to slot 0, first agent state handed over and the next one packed
  *                                    (:398-399; bit order of networks.py:164-169) from the store's frames.
@@ -521,22 +521,25 @@ size_t seedhip_serve_heads_image_bytes(int feat);
 int seedhip_serve_begin(const seedhip_serve_step* step, const float* conv0_w /* [8,8,4,cout] */, int conv0_cout,
                         void* conv0_split /* may be NULL */, const float* heads_w, int feat, int ldh,
                         void* heads_image, void* stream);
-/* geom->T == 1, geom->B == n.  obs u8 [n, ih*iw]; store_obs u8 [full_length * num_envs, ih*iw] (read: history rows
- * hist_rows[4 b + c], c < nvalid[b]; written: row append_rows[b] when >= 0); w_split: the W / 255 planes of
- * seedhip_serve_begin / seedhip_serve_split_conv0. */
+/* geom->T == 1, geom->B == n.  obs u8 [n, ih*iw]; store_obs u8 [full_length * num_envs, ih*iw] (read only: history rows
+ * hist_rows[4 b + c], 1 <= c < nvalid[b]; the request frames are appended by seedhip_serve_finish); w_split: the W / 255
+ * planes of seedhip_serve_begin / seedhip_serve_split_conv0. */
 int seedhip_conv2d_stack_fwd_rows_supported(const seedhip_stack_conv_geom* geom);
-int seedhip_conv2d_stack_fwd_rows(const seedhip_stack_conv_geom* geom, const uint8_t* obs, uint8_t* store_obs,
-                                  const long long* hist_rows, const long long* append_rows, const uint8_t* nvalid,
-                                  const void* w_split, const float* bias, float* out, int out_relu, void* stream);
+int seedhip_conv2d_stack_fwd_rows(const seedhip_stack_conv_geom* geom, const uint8_t* obs, const uint8_t* store_obs,
+                                  const long long* hist_rows, const uint8_t* nvalid, const void* w_split,
+                                  const float* bias, float* out, int out_relu, void* stream);
 /* Dense forward without its epilogue: partial[z][m][n], z < *slices, in `workspace`; summing the slices in order + bias
  * (+ ReLU) equals seedhip_conv2d_fwd_ws's output for the same geometry below 4096 rows bit for bit. */
 size_t seedhip_dense_fwd_partial_workspace_bytes(const seedhip_conv_geom* geom);
 int seedhip_dense_fwd_partial(const seedhip_conv_geom* geom, const float* in, int in_relu, const float* w,
                               void* workspace, size_t workspace_bytes, int* slices, void* stream);
-/* fc_partial [slices][n][feat]; heads_image: serve_begin's image of the packed heads [feat, ldh]; actions int64 [n] out. */
+/* fc_partial [slices][n][feat]; heads_image: serve_begin's image of the packed heads [feat, ldh]; actions int64 [n] out.
+ * obs u8 [n, hw] -> store_obs rows append_rows[b] (the append of the largest field, common/utils.py:187-194; by the waves
+ * that are idle while one wave of each workgroup multiplies the heads and samples); hw % 16 == 0. */
 int seedhip_serve_finish(const seedhip_serve_step* step, const seedhip_serve_fields* store_fields,
                          const float* fc_partial, int slices, const float* fc_bias, int feat, const void* heads_image,
-                         const float* heads_b, int ldh, int num_actions, long long* actions, void* stream);
+                         const float* heads_b, int ldh, int num_actions, long long* actions, const uint8_t* obs,
+                         uint8_t* store_obs, long long hw, void* stream);
 /* nfields <= 16 fields (host arrays of device pointers; rows of row_bytes[f]): store [full_length, num_envs] -> batch
  * [full_length, batch_capacity]; first_table int32 [num_envs, hw], batch_first int32 [batch_capacity, hw], store_obs as
  * above (hw = ih * iw bytes per frame, % 16 == 0). */

@@ -149,11 +149,11 @@ SIGNATURES = {
     'seedhip_serve_heads_image_bytes': (c_size_t, [c_int]),
     'seedhip_serve_begin': (c_int, [ctypes.POINTER(ServeStep), P, c_int, P, P, c_int, c_int, P, P]),
     'seedhip_conv2d_stack_fwd_rows_supported': (c_int, [ctypes.POINTER(StackConvGeom)]),
-    'seedhip_conv2d_stack_fwd_rows': (c_int, [ctypes.POINTER(StackConvGeom), P, P, P, P, P, P, P, P, c_int, P]),
+    'seedhip_conv2d_stack_fwd_rows': (c_int, [ctypes.POINTER(StackConvGeom), P, P, P, P, P, P, P, c_int, P]),
     'seedhip_dense_fwd_partial_workspace_bytes': (c_size_t, [ctypes.POINTER(ConvGeom)]),
     'seedhip_dense_fwd_partial': (c_int, [ctypes.POINTER(ConvGeom), P, c_int, P, P, c_size_t, ctypes.POINTER(c_int), P]),
     'seedhip_serve_finish': (c_int, [ctypes.POINTER(ServeStep), ctypes.POINTER(ServeFields), P, c_int, P, c_int, P, P,
-                                     c_int, c_int, P, P]),
+                                     c_int, c_int, P, P, P, c_ll, P]),
     'seedhip_serve_emit': (c_int, [ctypes.POINTER(ServeStep), c_int, P, P, P, P, P, P, c_ll, P]),
     'seedhip_replay_sample_workspace_bytes': (c_size_t, [c_ll]),
     'seedhip_replay_sample': (c_int, [P, c_ll, c_float, c_float, P, c_int, P, P, P, c_size_t, P]),

@@ -218,20 +218,22 @@ serve_begin_kernel(const BeginArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------ //
-// serve_finish: one workgroup (four waves) per 16 rows.
+// serve_finish: one workgroup (sixteen waves) per 16 rows.
 //   phase 1, all waves: x = relu(sum_z partial[z] + bias) for the tile's 16 rows, dense_epilogue_kernel's order (conv.hip),
-//            into LDS -- at 1 024 rows the Dense layer's plan has 14 K-slices: 56 independent 16-byte loads per thread;
+//            into LDS -- at 1 024 rows the Dense layer's plan has 14 K-slices: one 16-byte column group per thread, eight
+//            slices in flight;
 //   phase 2, wave 0: the packed heads, heads_fwd_kernel's MFMA sequence (heads.hip: bit-identical logits), A operand
 //            from LDS, B operand from the register image serve_begin wrote;
 //   phase 3, wave 0: Gumbel-max sampling, four lanes per row (a lane takes every fourth Philox block; the first
 //            maximum wins across lanes as in sample_categorical_row), append of the scalar fields, action table.
 // ------------------------------------------------------------------------------------------------------------------ //
-constexpr int kMaxFeat = 512, kMaxN = 32, kHeadPitch = 33, kFinThreads = 256;
+constexpr int kMaxFeat = 512, kMaxN = 32, kHeadPitch = 33, kFinThreads = 1024;
 struct FinishArgs {
   seedhip_serve_step s; seedhip_serve_fields f;
   const float* partial; int slices; const float* fc_bias; int feat;
   const float4* heads_image; const float* heads_b; int ldh, A;
   long long* actions;
+  const uint8_t* obs; uint8_t* store_obs; long long hw;
 };
 
 __global__ void __launch_bounds__(kFinThreads)
@@ -252,7 +254,15 @@ serve_finish_kernel(const FinishArgs a) {
       if (r >= rows) r = rows - 1;
       const float* src = a.partial + r * F + c;
       f32x4_t v = *reinterpret_cast<const f32x4_t*>(src);
-      for (int z = 1; z < a.slices; ++z) v += *reinterpret_cast<const f32x4_t*>(src + (long long)z * total);
+      for (int z0 = 1; z0 < a.slices; z0 += 8) {                       // eight slices in flight, summed in slice order
+        f32x4_t t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (z0 + q < a.slices) t[q] = *reinterpret_cast<const f32x4_t*>(src + (long long)(z0 + q) * total);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (z0 + q < a.slices) v += t[q];
+      }
       v += *reinterpret_cast<const f32x4_t*>(a.fc_bias + c);
 #pragma unroll
       for (int q = 0; q < 4; ++q) if (v[q] < 0.f) v[q] = 0.f;
@@ -260,7 +270,22 @@ serve_finish_kernel(const FinishArgs a) {
     }
   }
   __syncthreads();
-  if (wave != 0) return;
+  if (wave != 0) {
+    // the other fifteen waves append the tile's request frames to the store (common/utils.py:187-194, the largest field)
+    // while wave 0 multiplies the heads and samples
+    const int t2 = tid - 64, nthr = kFinThreads - 64;
+    const long long vec = a.hw >> 4;
+    for (int rl = 0; rl < 16; ++rl) {
+      const long long i = row0 + rl;
+      if (i >= rows) break;
+      const long long arow = s.append_rows[i];
+      if (arow < 0) continue;
+      const uint4* src = reinterpret_cast<const uint4*>(a.obs + i * a.hw);
+      uint4* dst = reinterpret_cast<uint4*>(a.store_obs + arow * a.hw);
+      for (long long k = t2; k < vec; k += nthr) dst[k] = src[k];
+    }
+    return;
+  }
   const int ntiles = a.ldh > 16 ? 2 : 1;
   float b0 = 0.f, b1 = 0.f;
   if (a.heads_b) { b0 = j < a.ldh ? a.heads_b[j] : 0.f; b1 = 16 + j < a.ldh ? a.heads_b[16 + j] : 0.f; }
@@ -465,7 +490,8 @@ extern "C" int seedhip_serve_begin(const seedhip_serve_step* step, const float* 
 extern "C" int seedhip_serve_finish(const seedhip_serve_step* step, const seedhip_serve_fields* fields,
                                     const float* fc_partial, int slices, const float* fc_bias, int feat,
                                     const void* heads_image, const float* heads_b, int ldh, int num_actions,
-                                    long long* actions, void* stream) {
+                                    long long* actions, const uint8_t* obs, uint8_t* store_obs, long long hw,
+                                    void* stream) {
   int rc = check_step(step, "serve_finish"); if (rc) return rc;
   SEEDHIP_REQUIRE(fields && fields->prev_actions && fields->reward && fields->done && fields->abandoned &&
                   fields->episode_step && fields->action && fields->policy_logits && fields->baseline,
@@ -475,7 +501,10 @@ extern "C" int seedhip_serve_finish(const seedhip_serve_step* step, const seedhi
                   num_actions >= 1 && num_actions < ldh, "serve_finish: need feat %% 64 == 0, feat <= 512, ldh %% 4 == 0, ldh <= 32, num_actions < ldh");
   SEEDHIP_REQUIRE((((uintptr_t)fc_partial | (uintptr_t)fc_bias | (uintptr_t)heads_image) & 15) == 0,
                   "serve_finish: 16-byte aligned partial sums / bias / heads image");
-  FinishArgs a{*step, *fields, fc_partial, slices, fc_bias, feat, (const float4*)heads_image, heads_b, ldh, num_actions, actions};
+  SEEDHIP_REQUIRE(obs && store_obs && hw >= 16 && hw % 16 == 0 && ((((uintptr_t)obs) | ((uintptr_t)store_obs)) & 15) == 0,
+                  "serve_finish: frames must be 16-byte aligned rows of hw %% 16 == 0 bytes");
+  FinishArgs a{*step, *fields, fc_partial, slices, fc_bias, feat, (const float4*)heads_image, heads_b, ldh, num_actions, actions,
+               obs, store_obs, hw};
   const size_t lds = ((size_t)16 * (feat + 4) + 16 * kHeadPitch) * sizeof(float);
   const int grid = (step->n + 15) / 16;                                // n <= 65536: one workgroup per 16 rows
   hipLaunchKernelGGL(serve_finish_kernel, dim3(grid), dim3(kFinThreads), lds, (hipStream_t)stream, a);

@@ -621,20 +621,21 @@ stackconv_fwd_bf16r_kernel(const Params p) {
 // ------------------------------------------------------------------------------------ //
 // The same forward for CENTRAL INFERENCE (r6; servestep.hip): one step of n independent environments.  Row b's stack is
 // its request frame obs[b] plus the three frames the unroll store already holds for that env (store_obs rows
-// hist_rows[4b + c], c = 1..3; see servestep.hip), nvalid[b] of them inside the episode; the request frame is written to
-// its store row append_rows[b] on the way (the append of the largest field, common/utils.py:187-194) -- the bit-packed
-// per-env stacking state, its unpack pass before and its re-pack pass after the conv do not exist here.  Same operands,
-// same MFMA order per accumulator as stackconv_fwd_bf16r_kernel: bit-identical outputs.  The W / 255 planes arrive
+// hist_rows[4b + c], c = 1..3; see servestep.hip), nvalid[b] of them inside the episode -- the bit-packed per-env
+// stacking state, its unpack pass before and its re-pack pass after the conv do not exist here.  Same operands, same
+// MFMA order per accumulator as stackconv_fwd_bf16r_kernel: bit-identical outputs.  The W / 255 planes arrive
 // pre-split (w_split: serve_begin or seedhip_serve_split_conv0, the training kernel's own prologue arithmetic): a
-// workgroup lives for two or three frames, not for an unroll, and the 64 divisions + splits per lane were a third of its time.
+// workgroup lives for two or three rows, not for an unroll, and the 64 divisions + splits per lane were a third of its time.
+// Rows are software-pipelined through the ring BY STACK CHANNEL: the k-groups of channel c are the only readers of ring
+// slot 3 - c, so the next row's frame c is staged into it as soon as they are done, from one of two prefetch registers
+// (all four frames of the next row held across the MFMA phase spilled: 32 registers over the 170 of three waves per SIMD).
 // ------------------------------------------------------------------------------------ //
 struct RowsParams {
   const uint8_t* obs;          // u8 [B, fsz]
-  const uint8_t* store_obs;    // u8 [rows, fsz]: the observation field of the unroll store (read: history, written: this step)
+  const uint8_t* store_obs;    // u8 [rows, fsz]: the observation field of the unroll store (history frames)
   const long long* hist_rows;  // [B][4]
-  const long long* append_rows;// [B], < 0: do not write
   const uint8_t* nvalid;       // [B]
-  const float* w; const float* bias; const uint4* w_split;
+  const float* bias; const uint4* w_split;
   float* out; int B, cout, ld_out, fsz;
 };
 
@@ -647,22 +648,58 @@ stackconv_rows_kernel(const RowsParams p) {
   unsigned char* myring = smem + kGroups * 64 * 16 + wave * kWaveRing16;
   const int kq = lane >> 4, j = lane & 15;
   const int co0 = blockIdx.z * 16;
+  const unsigned band0 = (unsigned)__builtin_amdgcn_readfirstlane(wave * 16 * kIW);
+  const unsigned fv0 = 16u * (unsigned)lane;
 
+  // Frame c of row b as a buffer of its own: the row index comes through the scalar cache, the base is uniform, the
+  // lane's part two loop-invariant 32-bit offsets (64-bit per-lane pointers cost registers this kernel does not have).
+  // Channels outside the episode (c >= nvalid[b]) are loaded and staged like the others -- their history rows are always
+  // in range (serve_begin) and their k-groups are skipped -- so that the staging code has no branches.
+  auto band_of = [&](int b, int c) -> BandPrefetch {
+    typedef __attribute__((address_space(4))) const unsigned cu32_t;
+    long long row = b;
+    if (c) {
+      cu32_t* q = reinterpret_cast<cu32_t*>(reinterpret_cast<uintptr_t>(p.hist_rows + 4 * (long long)b + c));
+      row = (long long)(((unsigned long long)q[1] << 32) | q[0]);
+    }
+    const uint8_t* fr = (c == 0 ? p.obs : p.store_obs) + row * p.fsz;
+    const __amdgpu_buffer_rsrc_t v = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(fr), 0, p.fsz, 0x00020000);
+    BandPrefetch r;
+    r.v0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(v, fv0, band0, 0));
+    // lanes >= 41 read past the band (or, in the last wave, past the frame: zeros); band_store16 does not store them
+    r.v1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(v, fv0, band0 + 1024u, 0));
+    return r;
+  };
+  // the first row's frames are requested before the weights, and ALL of those before the first use: one memory round
+  // trip for the prologue (staged one by one, every LDS store of a lo part waited for its load: eight round trips)
+  int b = __builtin_amdgcn_readfirstlane(blockIdx.x);  // grid <= B
+  int nv = nvalid_at(p.nvalid, b);
+  BandPrefetch f0[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) f0[c] = band_of(b, c);
   Frag8 wreg[kGroups][2];
   {
     const uint4* img = p.w_split + (long long)blockIdx.z * kGroups * 3 * 64 + lane;
+    if (wave == 0) {                                   // the lo parts go memory -> LDS without passing through registers
+      typedef __attribute__((address_space(3))) void lds_void_t;
+      const __amdgpu_buffer_rsrc_t wview = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<uint4*>(p.w_split + (long long)blockIdx.z * kGroups * 3 * 64), 0, kGroups * 3 * 1024, 0x00020000);
+#pragma unroll
+      for (int G = 0; G < kGroups; ++G)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wview, (lds_void_t*)(smem + G * 1024), 16, 16u * (unsigned)lane, (G * 3 + 2) * 1024, 0, 0);
+    }
 #pragma unroll
     for (int G = 0; G < kGroups; ++G) {
       wreg[G][0].u = img[(G * 3 + 0) * 64];
       wreg[G][1].u = img[(G * 3 + 1) * 64];
-      if (wave == 0) wlo_lds[G * 64 + lane] = img[(G * 3 + 2) * 64];
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) band_store16(myring + (3 - c) * kBand16, f0[c], lane);   // stack channel c sits in ring slot 3 - c
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA writes are through before the barrier
   }
-  f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias) {
-    const float4 bv = *reinterpret_cast<const float4*>(p.bias + co0 + 4 * kq);
-    bias4 = f32x4_t{bv.x, bv.y, bv.z, bv.w};
-  }
+  // the slice's 16 biases sit in LDS behind the rings (four registers the MFMA phase does not have)
+  float* bias_lds = reinterpret_cast<float*>(smem + kGroups * 64 * 16 + kWaves * kWaveRing16);
+  if (tid < 16) bias_lds[tid] = p.bias ? p.bias[co0 + tid] : 0.f;
   int aoff[kMT];
 #pragma unroll
   for (int m = 0; m < kMT; ++m) {
@@ -670,30 +707,14 @@ stackconv_rows_kernel(const RowsParams p) {
     const int oy = pix / kOW, ox = pix - oy * kOW;
     aoff[m] = ((oy * 4 + kq) * kIW + ox * 4) * 2;
   }
-  __syncthreads();                                    // lo parts visible; the only workgroup barrier
-  // a wave WRITES rows 16 wave .. 16 wave + 15 of the request frame (the last wave its whole 20-row band): 84 / 105 vectors
-  const int own_vec = wave == kWaves - 1 ? kBandVec : 16 * kIW / 16;
+  // the lane's byte offset inside a row's [400][ld_out] output block (tile m: + a uniform m * 16 pixels)
+  const unsigned ov0 = (unsigned)(((wave * 80 + j) * p.ld_out + co0 + 4 * kq) * 4);
+  const int row_bytes = 400 * p.ld_out * 4, tile_bytes = 16 * p.ld_out * 4;
+  __syncthreads();                                    // lo parts visible (and every wave's ring staged); the only workgroup barrier
 
-  for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
-    const int nv = nvalid_at(p.nvalid, b);
-    const long long arow = p.append_rows[b];
-    BandPrefetch f[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {                      // stack channel c sits in ring slot 3 - c
-      if (c < nv) {
-        const uint8_t* fr = c == 0 ? p.obs + (long long)b * p.fsz : p.store_obs + p.hist_rows[4 * b + c] * p.fsz;
-        f[c] = band_load(reinterpret_cast<const uint4*>(fr + wave * 16 * kIW), lane);
-      }
-    }
-    if (arow >= 0 && blockIdx.z == 0) {
-      uint4* dst = reinterpret_cast<uint4*>(const_cast<uint8_t*>(p.store_obs) + arow * p.fsz + wave * 16 * kIW);
-      dst[lane] = f[0].v0;
-      if (lane + 64 < own_vec) dst[lane + 64] = f[0].v1;
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (c < nv) band_store16(myring + (3 - c) * kBand16, f[c], lane);
-    wave_lds_fence();
+  for (;;) {
+    const int bn = __builtin_amdgcn_readfirstlane(b + (int)gridDim.x);
+    const bool more = bn < p.B;
     f32x4_t acc[kMT];
 #pragma unroll
     for (int m = 0; m < kMT; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -716,14 +737,43 @@ stackconv_rows_kernel(const RowsParams p) {
 #pragma unroll
       for (int m = 0; m < kMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[G][0].v, xf[m].v, acc[m], 0, 0, 0);
     };
-    if (nv == 4) {
-#pragma unroll
-      for (int G = 0; G < kGroups; ++G) group(G);
+    int nvn = 0;
+    if (nv == 4 && more) {                             // the common case, straight-line: channel c's groups, then the next row's frame c
+      nvn = nvalid_at(p.nvalid, bn);
+      BandPrefetch pa = band_of(bn, 0), pb = band_of(bn, 1);
+      // sched_barrier: the frame's conversion (plain VALU on the loaded registers) may not be scheduled above its
+      // channel's k-groups -- hipcc hoisted it into the first one, i.e. the wave waited for the prefetch it had just issued
+      group(0); group(1);
+      __builtin_amdgcn_sched_barrier(0);
+      wave_lds_fence(); band_store16(myring + 3 * kBand16, pa, lane);
+      pa = band_of(bn, 2);
+      group(2); group(3);
+      __builtin_amdgcn_sched_barrier(0);
+      wave_lds_fence(); band_store16(myring + 2 * kBand16, pb, lane);
+      pb = band_of(bn, 3);
+      group(4); group(5);
+      __builtin_amdgcn_sched_barrier(0);
+      wave_lds_fence(); band_store16(myring + 1 * kBand16, pa, lane);
+      group(6); group(7);
+      __builtin_amdgcn_sched_barrier(0);
+      wave_lds_fence(); band_store16(myring + 0 * kBand16, pb, lane);
     } else {
+      BandPrefetch pa, pb;
+      if (more) {
+        nvn = nvalid_at(p.nvalid, bn);
+        pa = band_of(bn, 0); pb = band_of(bn, 1);
+      }
 #pragma unroll
       for (int G = 0; G < kGroups; ++G) if (G < 2 * nv) group(G);
+      wave_lds_fence();
+      if (more) {
+        band_store16(myring + 3 * kBand16, pa, lane); band_store16(myring + 2 * kBand16, pb, lane);
+        pa = band_of(bn, 2); pb = band_of(bn, 3);
+        band_store16(myring + 1 * kBand16, pa, lane); band_store16(myring + 0 * kBand16, pb, lane);
+      }
     }
-    wave_lds_fence();                                  // the ring is rewritten by the next row
+    wave_lds_fence();
+    const f32x4_t bias4 = *reinterpret_cast<const f32x4_t*>(bias_lds + 4 * kq);
     f32x4_t vout[kMT];
 #pragma unroll
     for (int m = 0; m < kMT; ++m) {
@@ -735,13 +785,14 @@ stackconv_rows_kernel(const RowsParams p) {
     }
 #pragma unroll
     for (int m = 0; m < kMT; ++m) asm volatile("" : "+v"(vout[m]));   // every output finished before the first store (see above)
+    // the row's output block as a buffer: uniform base, the lane's loop-invariant 32-bit offsets (64-bit per-lane
+    // pointers were spilled, and every store then waited for the one before it behind its address reload)
+    const __amdgpu_buffer_rsrc_t oview = __builtin_amdgcn_make_buffer_rsrc(p.out + (long long)b * (row_bytes / 4), 0, row_bytes, 0x00020000);
 #pragma unroll
-    for (int m = 0; m < kMT; ++m) {
-      const int pix = wave * 80 + m * 16 + j;
-      const f32x4_t v = vout[m];
-      float* o = p.out + ((long long)b * 400 + pix) * p.ld_out + co0 + 4 * kq;
-      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-    }
+    for (int m = 0; m < kMT; ++m)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(su32x4_t, vout[m]), oview, ov0, m * tile_bytes, 0);
+    if (!more) break;
+    b = bn; nv = nvn;
   }
 }
 
@@ -1140,20 +1191,19 @@ extern "C" int seedhip_conv2d_stack_fwd_rows_supported(const seedhip_stack_conv_
          g->oh == 20 && g->ow == 20 && g->cout % 16 == 0 && g->ld_out % 4 == 0 && stackconv::bf16x3_enabled();
 }
 
-extern "C" int seedhip_conv2d_stack_fwd_rows(const seedhip_stack_conv_geom* geom, const uint8_t* obs, uint8_t* store_obs,
-                                             const long long* hist_rows, const long long* append_rows,
-                                             const uint8_t* nvalid, const void* w_split, const float* bias,
-                                             float* out, int out_relu, void* stream) {
+extern "C" int seedhip_conv2d_stack_fwd_rows(const seedhip_stack_conv_geom* geom, const uint8_t* obs, const uint8_t* store_obs,
+                                             const long long* hist_rows, const uint8_t* nvalid, const void* w_split,
+                                             const float* bias, float* out, int out_relu, void* stream) {
   int rc = check_stack(geom, "conv2d_stack_fwd_rows"); if (rc) return rc;
-  SEEDHIP_REQUIRE(obs && store_obs && hist_rows && append_rows && nvalid && w_split && out, "conv2d_stack_fwd_rows: null pointer");
+  SEEDHIP_REQUIRE(obs && store_obs && hist_rows && nvalid && w_split && out, "conv2d_stack_fwd_rows: null pointer");
   SEEDHIP_REQUIRE(seedhip_conv2d_stack_fwd_rows_supported(geom), "conv2d_stack_fwd_rows: geometry not served (ask seedhip_conv2d_stack_fwd_rows_supported)");
   SEEDHIP_REQUIRE(((((uintptr_t)obs) | ((uintptr_t)store_obs) | ((uintptr_t)out) | ((uintptr_t)bias) | ((uintptr_t)w_split)) & 15) == 0,
                   "conv2d_stack_fwd_rows: 16-byte aligned buffers");
   stackconv::RowsParams p;
-  p.obs = obs; p.store_obs = store_obs; p.hist_rows = hist_rows; p.append_rows = append_rows; p.nvalid = nvalid;
-  p.w = nullptr; p.bias = bias; p.w_split = (const uint4*)w_split; p.out = out; p.B = geom->B; p.cout = geom->cout;
+  p.obs = obs; p.store_obs = store_obs; p.hist_rows = hist_rows; p.nvalid = nvalid;
+  p.bias = bias; p.w_split = (const uint4*)w_split; p.out = out; p.B = geom->B; p.cout = geom->cout;
   p.ld_out = geom->ld_out; p.fsz = geom->ih * geom->iw;
-  const size_t lds = (size_t)stackconv::kGroups * 64 * 16 + (size_t)stackconv::kWaves * stackconv::kWaveRing16;
+  const size_t lds = (size_t)stackconv::kGroups * 64 * 16 + (size_t)stackconv::kWaves * stackconv::kWaveRing16 + 64;
   const int grid = p.B < stackconv::max_grid_for(2) ? p.B : stackconv::max_grid_for(2);
   hipStream_t s = (hipStream_t)stream;
   if (out_relu) {

@@ -337,8 +337,8 @@ class FusedInferenceState(object):
 
   def _inference_serve(self, ids, runs, env_outputs, raw_rewards, n, b):
     """learner.py:350-405 in SIX launches (csrc/servestep.hip): serve_begin, the first conv from the request frames +
-    the store's history (appending the frames), the second conv, the Dense partial sums, serve_finish (Dense epilogue +
-    heads + sampling + append of the scalar fields + action table) and serve_emit (completed unrolls -> training batch,
+    the store's history, the second conv, the Dense partial sums, serve_finish (Dense epilogue + heads + sampling +
+    append of the step's fields + action table) and serve_emit (completed unrolls -> training batch,
     carry, first agent state) -- no row mover, no unpack / re-pack of the stacking state."""
     st, fields = b['step'], b['fields']
     reward = env_outputs.reward.to(torch.float32).contiguous()
@@ -357,13 +357,12 @@ class FusedInferenceState(object):
     st.rng_state = agent.rng_state().data_ptr()
     ops.serve_begin(st, *agent.serve_begin_weights(), like=ids)
     store_obs = self.store[1].observation
-    part, slices, fc_b, feat, hw_, hb_, ldh, A = agent.serve_forward(n, obs, store_obs, b['hist_rows'], b['append_rows'],
-                                                                     b['nvalid'])
-    ops.serve_finish(st, fields, part, slices, fc_b, feat, hw_, hb_, ldh, A, b['actions'])
+    hw = self._rb(store_obs, 2)
+    part, slices, fc_b, feat, himg, hb_, ldh, A = agent.serve_forward(n, obs, store_obs, b['hist_rows'], b['nvalid'])
+    ops.serve_finish(st, fields, part, slices, fc_b, feat, himg, hb_, ldh, A, b['actions'], obs, store_obs, hw)
     stores = utils.flatten(self.store)
     outs = utils.flatten((self.batch.prev_actions, self.batch.env_outputs, self.batch.agent_outputs))
     rbs = [self._rb(s_, 2) for s_ in stores]
-    hw = self._rb(store_obs, 2)
     ops.serve_emit(st, outs, stores, rbs, utils.flatten(self.first_agent_states)[0],
                    utils.flatten(self.batch.agent_state)[0], store_obs, hw)
     return b['actions']

@@ -558,16 +558,16 @@ class _AtariTorso(object):
     ch = self._shapes[0][5]
     return self._buf('conv0_split', (ops.serve_conv0_split_bytes(ch) // 4,), torch.int32)
 
-  def _torso_fwd_rows(self, n, obs, store_obs, hist_rows, append_rows, nvalid):
+  def _torso_fwd_rows(self, n, obs, store_obs, hist_rows, nvalid):
     """One inference step of n envs whose frame stacks live in the unroll store (store_obs u8 [rows, H*W]; history rows
-    hist_rows [n, 4], nvalid [n]); the request frames obs u8 [n, H*W] are appended to rows append_rows on the way.
+    hist_rows [n, 4], nvalid [n]) under the request frames obs u8 [n, H*W].
     Returns the Dense layer's split-K partial sums [slices][n][fc] and the slice count: bias + ReLU are applied by the
     consumer (serve_finish)."""
     fl, tp = self.flat, self._tp
     ih, iw, _, k, s, ch, oh, ow = self._shapes[0]
     g0 = ops.StackConvGeom(1, n, ih, iw, oh, ow, k, k, s, ch, ch)
     a = self._buf('srv_act0', (n, oh, ow, ch))
-    ops.conv2d_stack_fwd_rows(g0, obs, store_obs, hist_rows, append_rows, nvalid, self.conv0_split_buffer(),
+    ops.conv2d_stack_fwd_rows(g0, obs, store_obs, hist_rows, nvalid, self.conv0_split_buffer(),
                               fl.p(tp + 'conv0/bias'), a, out_relu=True)
     for i in range(1, len(self._shapes)):
       ih, iw, cin, k, s, ch, oh, ow = self._shapes[i]
@@ -655,10 +655,10 @@ class AtariShallow(_Agent, _AtariTorso):
     return (fl.p(self._tp + 'conv0/kernel'), self._shapes[0][5], self.conv0_split_buffer(), fl.p('heads/kernel'),
             self._fc, self._ldh, self.heads_image_buffer())
 
-  def serve_forward(self, n, obs, store_obs, hist_rows, append_rows, nvalid):
+  def serve_forward(self, n, obs, store_obs, hist_rows, nvalid):
     """Torso of one inference step (see _torso_fwd_rows) + what serve_finish needs of the heads:
     (fc_partial, slices, fc_bias, fc, heads_image, heads_b, ldh, num_actions)."""
-    ws, slices = self._torso_fwd_rows(n, obs, store_obs, hist_rows, append_rows, nvalid)
+    ws, slices = self._torso_fwd_rows(n, obs, store_obs, hist_rows, nvalid)
     fl = self.flat
     return (ws, slices, fl.p(self._tp + 'fc/bias'), self._fc, self.heads_image_buffer(), fl.p('heads/bias'), self._ldh,
             self._num_actions)

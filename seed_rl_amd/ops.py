@@ -775,15 +775,15 @@ def conv2d_stack_fwd_rows_supported(g):
   return bool(_lib.lib().seedhip_conv2d_stack_fwd_rows_supported(ctypes.byref(g)))
 
 
-def conv2d_stack_fwd_rows(g, obs, store_obs, hist_rows, append_rows, nvalid, w_split, bias, out, out_relu=True):
-  """First conv of one inference step: stacks = request frames + the store's history rows; appends the frames."""
+def conv2d_stack_fwd_rows(g, obs, store_obs, hist_rows, nvalid, w_split, bias, out, out_relu=True):
+  """First conv of one inference step: stacks = request frames + the store's history rows."""
   n = g.B
   flops = 2.0 * n * g.oh * g.ow * g.cout * g.kh * g.kw * 4
-  nbytes = n * g.ih * g.iw * 5 + n * g.oh * g.ow * g.cout * 4           # 4 frames read, 1 written, activation written
+  nbytes = n * g.ih * g.iw * 4 + n * g.oh * g.ow * g.cout * 4           # 4 frames read, activation written
   with _region('stack_conv_fwd_rows', flops, nbytes, pipe=_stack_pipe):
     with _dev(out):
       _lib.check(_lib.lib().seedhip_conv2d_stack_fwd_rows(
-          ctypes.byref(g), _lib.ptr(obs), _lib.ptr(store_obs), _lib.ptr(hist_rows), _lib.ptr(append_rows),
+          ctypes.byref(g), _lib.ptr(obs), _lib.ptr(store_obs), _lib.ptr(hist_rows),
           _lib.ptr(nvalid), _lib.ptr(w_split), _lib.ptr(bias), _lib.ptr(out), int(out_relu), _lib.stream()),
           'seedhip_conv2d_stack_fwd_rows')
   return out
@@ -804,14 +804,15 @@ def dense_fwd_partial(g, x, w, workspace, in_relu=False):
   return slices.value
 
 
-def serve_finish(step, fields, fc_partial, slices, fc_bias, feat, heads_image, heads_b, ldh, num_actions, actions):
+def serve_finish(step, fields, fc_partial, slices, fc_bias, feat, heads_image, heads_b, ldh, num_actions, actions, obs,
+                 store_obs, hw):
   n = step.n
-  with _region('serve_finish', 2.0 * n * feat * ldh, n * (slices * feat + ldh) * 4):
+  with _region('serve_finish', 2.0 * n * feat * ldh, n * (slices * feat + ldh) * 4 + 2 * n * hw):
     with _dev(actions):
       _lib.check(_lib.lib().seedhip_serve_finish(
           ctypes.byref(step), ctypes.byref(fields), _lib.ptr(fc_partial), int(slices), _lib.ptr(fc_bias), int(feat),
-          _lib.ptr(heads_image), _lib.ptr(heads_b), int(ldh), int(num_actions), _lib.ptr(actions), _lib.stream()),
-          'seedhip_serve_finish')
+          _lib.ptr(heads_image), _lib.ptr(heads_b), int(ldh), int(num_actions), _lib.ptr(actions), _lib.ptr(obs),
+          _lib.ptr(store_obs), int(hw), _lib.stream()), 'seedhip_serve_finish')
 
 
 def serve_emit(step, batch, store, row_bytes, first_table, batch_first, store_obs, hw):
