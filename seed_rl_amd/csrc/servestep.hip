@@ -226,8 +226,9 @@ serve_begin_kernel(const BeginArgs a) {
 //            from LDS, B operand from the register image serve_begin wrote;
 //   phase 3, wave 0: Gumbel-max sampling, four lanes per row (a lane takes every fourth Philox block; the first
 //            maximum wins across lanes as in sample_categorical_row), append of the scalar fields, action table.
+// The workgroups behind the tiles append the request frames (four each).
 // ------------------------------------------------------------------------------------------------------------------ //
-constexpr int kMaxFeat = 512, kMaxN = 32, kHeadPitch = 33, kFinThreads = 1024;
+constexpr int kMaxFeat = 512, kMaxN = 32, kHeadPitch = 33, kFinThreads = 1024, kFramesPerCopy = 4;
 struct FinishArgs {
   seedhip_serve_step s; seedhip_serve_fields f;
   const float* partial; int slices; const float* fc_bias; int feat;
@@ -242,10 +243,38 @@ serve_finish_kernel(const FinishArgs a) {
   const seedhip_serve_step& s = a.s;
   const int F = a.feat, LDX = F + 4;
   float* x = smem;                                                     // [16][F + 4]
-  float* head = smem + 16 * LDX;                                       // [16][33]
+  float* head = smem + 16 * LDX;                                       // [16][33] (+ pad to a 16-byte multiple)
+  float4* img_lds = reinterpret_cast<float4*>(head + 16 * kHeadPitch + 16);   // [F / 16][2][64]: the heads' register image
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
   const long long rows = s.n, total = rows * F;
+  const int tiles = (int)((rows + 15) / 16);
+  if ((int)blockIdx.x >= tiles) {
+    // the workgroups behind the tiles append the request frames to the store (common/utils.py:187-194, the largest
+    // field): kFramesPerCopy rows each, every thread's loads in flight before its first store
+    const long long vec = a.hw >> 4;
+    const long long i0 = (long long)((int)blockIdx.x - tiles) * kFramesPerCopy;
+    constexpr int kMaxV = 2;                                           // vectors per thread and frame held in registers
+    for (int fr = 0; fr < kFramesPerCopy; ++fr) {
+      const long long i = i0 + fr;
+      if (i >= rows) break;
+      const long long arow = s.append_rows[i];
+      if (arow < 0) continue;
+      const uint4* src = reinterpret_cast<const uint4*>(a.obs + i * a.hw);
+      uint4* dst = reinterpret_cast<uint4*>(a.store_obs + arow * a.hw);
+      for (long long k0 = tid; k0 < vec; k0 += (long long)kMaxV * kFinThreads) {
+        uint4 v[kMaxV];
+#pragma unroll
+        for (int q = 0; q < kMaxV; ++q) if (k0 + (long long)q * kFinThreads < vec) v[q] = src[k0 + (long long)q * kFinThreads];
+#pragma unroll
+        for (int q = 0; q < kMaxV; ++q) if (k0 + (long long)q * kFinThreads < vec) dst[k0 + (long long)q * kFinThreads] = v[q];
+      }
+    }
+    return;
+  }
   const long long row0 = (long long)blockIdx.x * 16;
+  // the heads' image -> LDS by every wave (wave 0's MFMA chain read it from global memory: one L2 round trip per
+  // 16-k block, sixteen in a row -- 12 of the kernel's 18 us)
+  for (int idx = tid; idx < (F / 16) * 128; idx += kFinThreads) img_lds[idx] = a.heads_image[idx];
   {
     const int fq = F >> 2;
     for (int idx = tid; idx < 16 * fq; idx += kFinThreads) {
@@ -270,28 +299,13 @@ serve_finish_kernel(const FinishArgs a) {
     }
   }
   __syncthreads();
-  if (wave != 0) {
-    // the other fifteen waves append the tile's request frames to the store (common/utils.py:187-194, the largest field)
-    // while wave 0 multiplies the heads and samples
-    const int t2 = tid - 64, nthr = kFinThreads - 64;
-    const long long vec = a.hw >> 4;
-    for (int rl = 0; rl < 16; ++rl) {
-      const long long i = row0 + rl;
-      if (i >= rows) break;
-      const long long arow = s.append_rows[i];
-      if (arow < 0) continue;
-      const uint4* src = reinterpret_cast<const uint4*>(a.obs + i * a.hw);
-      uint4* dst = reinterpret_cast<uint4*>(a.store_obs + arow * a.hw);
-      for (long long k = t2; k < vec; k += nthr) dst[k] = src[k];
-    }
-    return;
-  }
+  if (wave != 0) return;
   const int ntiles = a.ldh > 16 ? 2 : 1;
   float b0 = 0.f, b1 = 0.f;
   if (a.heads_b) { b0 = j < a.ldh ? a.heads_b[j] : 0.f; b1 = 16 + j < a.ldh ? a.heads_b[16 + j] : 0.f; }
   f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const float* xr = x + j * LDX + 4 * kq;
-  const float4* img = a.heads_image + lane;
+  const float4* img = img_lds + lane;
 #pragma unroll 4
   for (int blk = 0; blk < F / 16; ++blk) {
     const f32x4_t v = *reinterpret_cast<const f32x4_t*>(xr + 16 * blk);
@@ -372,73 +386,118 @@ serve_finish_kernel(const FinishArgs a) {
 // the carry; same thread, same element, in program order -- the one place where a row is read and rewritten), u = 1 ..
 // L - 2 moves slot u, u = L - 1 hands the first agent state over and packs the next one.
 // ------------------------------------------------------------------------------------------------------------------ //
-constexpr int kEmitFields = 16;
+constexpr int kEmitFields = 16, kEmitThreads = 256, kBigRow = 256, kStateParts = 1;
 struct EmitArgs {
   seedhip_serve_step s;
   void* batch[kEmitFields]; void* store[kEmitFields]; long long row_bytes[kEmitFields]; int w[kEmitFields]; int nfields;
   int* first_table; int* batch_first; const uint8_t* store_obs; long long hw;
 };
 
-template <typename V>
-__device__ __forceinline__ void move_row(char* d0, char* d1, const char* sp, long long nv, int tid) {
-  for (long long k = tid; k < nv; k += 256) {
-    const V v = reinterpret_cast<const V*>(sp)[k];
-    if (d0) reinterpret_cast<V*>(d0)[k] = v;
-    if (d1) reinterpret_cast<V*>(d1)[k] = v;
+// One row of every field, source row rs -> destination rows rd0 / rd1 of d0 / d1 (a null table = no such copy).  Every
+// load of the row is issued before the first store (field after field, each waiting for its own round trip, the nine
+// fields of the V-trace unroll took nine memory latencies per item): small fields one unit (16 / 4 / 1 bytes) per thread
+// across ALL small fields at once, big fields (frames) two vectors per thread in flight.
+__device__ __forceinline__ void move_fields(const EmitArgs& a, long long rs, bool to0, long long rd0, bool to1, long long rd1,
+                                            int tid) {
+  // small fields: thread -> (field, unit)
+  {
+    int f = -1, k = 0, base = 0;
+    for (int g = 0; g < a.nfields; ++g) {
+      if (a.row_bytes[g] >= kBigRow) continue;
+      const int units = (int)(a.row_bytes[g] / a.w[g]);
+      if (f < 0 && tid < base + units) { f = g; k = tid - base; }
+      base += units;
+    }
+    if (f >= 0) {
+      const long long rb = a.row_bytes[f];
+      const char* sp = (const char*)a.store[f] + rs * rb;
+      char* p0 = to0 ? (char*)a.batch[f] + rd0 * rb : nullptr;
+      char* p1 = to1 ? (char*)a.store[f] + rd1 * rb : nullptr;
+      if (a.w[f] == 16) { const uint4 v = reinterpret_cast<const uint4*>(sp)[k]; if (p0) reinterpret_cast<uint4*>(p0)[k] = v; if (p1) reinterpret_cast<uint4*>(p1)[k] = v; }
+      else if (a.w[f] == 4) { const uint32_t v = reinterpret_cast<const uint32_t*>(sp)[k]; if (p0) reinterpret_cast<uint32_t*>(p0)[k] = v; if (p1) reinterpret_cast<uint32_t*>(p1)[k] = v; }
+      else { const unsigned char v = reinterpret_cast<const unsigned char*>(sp)[k]; if (p0) reinterpret_cast<unsigned char*>(p0)[k] = v; if (p1) reinterpret_cast<unsigned char*>(p1)[k] = v; }
+    }
+  }
+  for (int f = 0; f < a.nfields; ++f) {
+    const long long rb = a.row_bytes[f];
+    if (rb < kBigRow) continue;
+    const char* sp = (const char*)a.store[f] + rs * rb;
+    char* p0 = to0 ? (char*)a.batch[f] + rd0 * rb : nullptr;
+    char* p1 = to1 ? (char*)a.store[f] + rd1 * rb : nullptr;
+    if (a.w[f] == 16) {
+      const long long nv = rb >> 4;
+      for (long long k0 = tid; k0 < nv; k0 += 2 * kEmitThreads) {
+        const bool two = k0 + kEmitThreads < nv;
+        const uint4 v0 = reinterpret_cast<const uint4*>(sp)[k0];
+        uint4 v1 = make_uint4(0, 0, 0, 0);
+        if (two) v1 = reinterpret_cast<const uint4*>(sp)[k0 + kEmitThreads];
+        if (p0) { reinterpret_cast<uint4*>(p0)[k0] = v0; if (two) reinterpret_cast<uint4*>(p0)[k0 + kEmitThreads] = v1; }
+        if (p1) { reinterpret_cast<uint4*>(p1)[k0] = v0; if (two) reinterpret_cast<uint4*>(p1)[k0 + kEmitThreads] = v1; }
+      }
+    } else {
+      const int w = a.w[f];
+      const long long nu = rb / w;
+      for (long long k = tid; k < nu; k += kEmitThreads) {
+        if (w == 4) { const uint32_t v = reinterpret_cast<const uint32_t*>(sp)[k]; if (p0) reinterpret_cast<uint32_t*>(p0)[k] = v; if (p1) reinterpret_cast<uint32_t*>(p1)[k] = v; }
+        else { const unsigned char v = reinterpret_cast<const unsigned char*>(sp)[k]; if (p0) reinterpret_cast<unsigned char*>(p0)[k] = v; if (p1) reinterpret_cast<unsigned char*>(p1)[k] = v; }
+      }
+    }
   }
 }
-__device__ __forceinline__ void move_row_w(int w, char* d0, char* d1, const char* sp, long long rb, int tid) {
-  if (w == 16) move_row<uint4>(d0, d1, sp, rb / 16, tid);
-  else if (w == 4) move_row<uint32_t>(d0, d1, sp, rb / 4, tid);
-  else move_row<unsigned char>(d0, d1, sp, rb, tid);
-}
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kEmitThreads)
 serve_emit_kernel(const EmitArgs a) {
   const seedhip_serve_step& s = a.s;
   const int L = s.full_length, E = s.num_envs, cap = s.batch_capacity, tid = threadIdx.x;
-  const int items = *s.emit_count * L;
+  const int per = L - 1 + kStateParts;                                 // items per completed unroll
+  const int items = *s.emit_count * per;
   for (int it = blockIdx.x; it < items; it += gridDim.x) {
-    const int r = it / L, u = it - r * L;
+    const int r = it / per, u = it - r * per;
     const long long e = s.emit_env[r], col = s.emit_col[r];
-    if (u == L - 1) {
+    if (u >= L - 1) {
       // learner.py:396-399: the unroll's first agent state goes with it; the state BEFORE this step (the three frames
       // in front of slot L - 1, zero outside the episode: atari/networks.py:164-169, MSB = newest) becomes the next one's
+      constexpr int part = 0;
       const int i = s.emit_row[r];
       const int nvp = s.prev_valid[i];
       const bool zero_first = s.first_zero[e] != 0;
       uint4* ft = reinterpret_cast<uint4*>(a.first_table + e * a.hw);
       uint4* bf = col >= 0 ? reinterpret_cast<uint4*>(a.batch_first + col * a.hw) : nullptr;
-      const uint8_t* f1 = a.store_obs + s.hist_rows[4 * i + 1] * a.hw;
-      const uint8_t* f2 = a.store_obs + s.hist_rows[4 * i + 2] * a.hw;
-      const uint8_t* f3 = a.store_obs + s.hist_rows[4 * i + 3] * a.hw;
-      for (long long k = tid; k < a.hw / 4; k += 256) {
-        if (bf) bf[k] = zero_first ? make_uint4(0, 0, 0, 0) : ft[k];
-        const unsigned x1 = nvp > 0 ? reinterpret_cast<const unsigned*>(f1)[k] : 0u;
-        const unsigned x2 = nvp > 1 ? reinterpret_cast<const unsigned*>(f2)[k] : 0u;
-        const unsigned x3 = nvp > 2 ? reinterpret_cast<const unsigned*>(f3)[k] : 0u;
-        unsigned o[4];
+      const unsigned* f1 = reinterpret_cast<const unsigned*>(a.store_obs + s.hist_rows[4 * i + 1] * a.hw);
+      const unsigned* f2 = reinterpret_cast<const unsigned*>(a.store_obs + s.hist_rows[4 * i + 2] * a.hw);
+      const unsigned* f3 = reinterpret_cast<const unsigned*>(a.store_obs + s.hist_rows[4 * i + 3] * a.hw);
+      const long long nq = a.hw / 4, lo = nq * part / kStateParts, hi = nq * (part + 1) / kStateParts;
+      for (long long k0 = lo + tid; k0 < hi; k0 += 2 * kEmitThreads) {
+        const long long k1 = k0 + kEmitThreads;
+        const bool two = k1 < hi;
+        uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
+        if (bf && !zero_first) { o0 = ft[k0]; if (two) o1 = ft[k1]; }
+        unsigned x[2][3] = {{0u, 0u, 0u}, {0u, 0u, 0u}};
+        if (nvp > 0) { x[0][0] = f1[k0]; if (two) x[1][0] = f1[k1]; }
+        if (nvp > 1) { x[0][1] = f2[k0]; if (two) x[1][1] = f2[k1]; }
+        if (nvp > 2) { x[0][2] = f3[k0]; if (two) x[1][2] = f3[k1]; }
+        if (bf) { bf[k0] = o0; if (two) bf[k1] = o1; }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          o[q] = (((x1 >> (8 * q)) & 0xFFu) << 16) | (((x2 >> (8 * q)) & 0xFFu) << 8) | ((x3 >> (8 * q)) & 0xFFu);
-        ft[k] = make_uint4(o[0], o[1], o[2], o[3]);
+        for (int h = 0; h < 2; ++h) {
+          if (h == 1 && !two) break;
+          unsigned o[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            o[q] = (((x[h][0] >> (8 * q)) & 0xFFu) << 16) | (((x[h][1] >> (8 * q)) & 0xFFu) << 8) | ((x[h][2] >> (8 * q)) & 0xFFu);
+          ft[h ? k1 : k0] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
       }
       __syncthreads();                                                 // every thread has read first_zero[e]
       if (tid == 0) s.first_zero[e] = 0;
       continue;
     }
-    for (int f = 0; f < a.nfields; ++f) {
-      const long long rb = a.row_bytes[f];
-      char* st = (char*)a.store[f];
-      char* bt = (char*)a.batch[f];
-      const int w = a.w[f];
-      if (u == 0) {
-        move_row_w(w, col >= 0 ? bt + col * rb : nullptr, nullptr, st + e * rb, rb, tid);
-        move_row_w(w, col >= 0 ? bt + ((long long)(L - 1) * cap + col) * rb : nullptr, st + e * rb,
-                   st + ((long long)(L - 1) * E + e) * rb, rb, tid);
-      } else if (col >= 0) {
-        move_row_w(w, bt + ((long long)u * cap + col) * rb, nullptr, st + ((long long)u * E + e) * rb, rb, tid);
-      }
+    if (u == 0) {
+      // slot 0 -> batch slot 0; slot L - 1 -> batch slot L - 1 AND slot 0 (the carry, utils.py:237-255): same thread, same
+      // element, in program order -- the one place where a row is read and rewritten
+      move_fields(a, e, col >= 0, col, false, 0, tid);
+      move_fields(a, (long long)(L - 1) * E + e, col >= 0, (long long)(L - 1) * cap + col, true, e, tid);
+    } else if (col >= 0) {
+      move_fields(a, (long long)u * E + e, true, (long long)u * cap + col, false, 0, tid);
     }
   }
 }
@@ -505,8 +564,9 @@ extern "C" int seedhip_serve_finish(const seedhip_serve_step* step, const seedhi
                   "serve_finish: frames must be 16-byte aligned rows of hw %% 16 == 0 bytes");
   FinishArgs a{*step, *fields, fc_partial, slices, fc_bias, feat, (const float4*)heads_image, heads_b, ldh, num_actions, actions,
                obs, store_obs, hw};
-  const size_t lds = ((size_t)16 * (feat + 4) + 16 * kHeadPitch) * sizeof(float);
-  const int grid = (step->n + 15) / 16;                                // n <= 65536: one workgroup per 16 rows
+  const size_t lds = ((size_t)16 * (feat + 4) + 16 * kHeadPitch + 16) * sizeof(float) + (size_t)(feat / 16) * 128 * 16;
+  // n <= 65536: one workgroup per 16 rows, then one per kFramesPerCopy frames to append
+  const int grid = (step->n + 15) / 16 + (step->n + kFramesPerCopy - 1) / kFramesPerCopy;
   hipLaunchKernelGGL(serve_finish_kernel, dim3(grid), dim3(kFinThreads), lds, (hipStream_t)stream, a);
   return seedhip::check_launch("serve_finish_kernel");
 }
@@ -528,8 +588,12 @@ extern "C" int seedhip_serve_emit(const seedhip_serve_step* step, int nfields, v
     a.w[f] = (al & 15) == 0 ? 16 : ((al & 3) == 0 ? 4 : 1);
   }
   a.nfields = nfields; a.first_table = first_table; a.batch_first = batch_first; a.store_obs = store_obs; a.hw = hw;
+  int small_units = 0;
+  for (int f = 0; f < nfields; ++f) if (row_bytes[f] < kBigRow) small_units += (int)(row_bytes[f] / a.w[f]);
+  SEEDHIP_REQUIRE(small_units <= kEmitThreads, "serve_emit: the fields below %d bytes per row have %d units together (max %d)",
+                  kBigRow, small_units, kEmitThreads);
   long long grid = (long long)step->n * step->full_length;             // upper bound; the kernel reads the count
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(serve_emit_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(serve_emit_kernel, dim3((int)grid), dim3(kEmitThreads), 0, (hipStream_t)stream, a);
   return seedhip::check_launch("serve_emit_kernel");
 }

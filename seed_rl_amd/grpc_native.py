@@ -19,6 +19,7 @@ import ctypes
 import os
 import queue
 import threading
+import time
 
 import numpy as np
 
@@ -316,6 +317,10 @@ def inference_signature(n, observation_shape, observation_dtype=np.uint8):
           T((n,), np.float32, 'raw_reward'))
 
 
+import collections as _collections
+PROF = _collections.defaultdict(float)      # host seconds per phase of the two-phase submission (tools/bench_serving.py)
+
+
 def bind_inference(server, fused_states, inference_batch_size, observation_shape, action_dtype=np.int64, num_slots=4,
                    observation_dtype=np.uint8, stream=None, gate=None, lock=None, pipeline=2):
   """Binds `inference(env_ids, run_ids, env_outputs, raw_rewards) -> actions`, one instance per FusedInferenceState
@@ -374,16 +379,21 @@ def bind_inference(server, fused_states, inference_batch_size, observation_shape
       """First half of a batch: its host->device copies, on the copy stream.  They wait only for the previous replay of
       the SAME graph instance (by the host: device-side cross-stream waits in front of graph launches were measured to
       stall the submitting thread for the whole copy).  `ahead`: batches staged before this one and not launched yet."""
+      t0 = time.perf_counter()
       if gate is not None:
         gate.admit(ahead)
       k = counter[0] % len(graphs)
       counter[0] += 1
+      t1 = time.perf_counter()
       with torch.cuda.device(st.device):
         if ran[k] is not None:
           ran[k].synchronize()                       # the previous replay of this instance has read its inputs
+        t2 = time.perf_counter()
         with torch.cuda.stream(s_copy):
           graphs[k].stage(req[slot], obs[slot])
           staged[k].record(s_copy)
+      t3 = time.perf_counter()
+      PROF['admit'] += t1 - t0; PROF['wait_ran'] += t2 - t1; PROF['stage'] += t3 - t2; PROF['calls'] += 1
       return slot, k
 
     def launch(token, graphs=graphs, act=act, out=out, st=st, s_inf=s_inf, st_lock=st_lock, done=done, staged=staged,
@@ -391,17 +401,23 @@ def bind_inference(server, fused_states, inference_batch_size, observation_shape
       """Second half: replay + action read-back on the inference stream; returns `finish`, which the server's
       completion thread runs to wait for the actions."""
       slot, k = token
+      t0 = time.perf_counter()
       with torch.cuda.device(st.device):
         staged[k].synchronize()                      # meanwhile the previous batch's graph runs on the inference stream
+        t1 = time.perf_counter()
         with st_lock:
+          t2 = time.perf_counter()
           with torch.cuda.stream(s_inf):
             actions = graphs[k].launch()
+            t3 = time.perf_counter()
             ev = torch.cuda.Event()
             ev.record(s_inf)
             ran[k] = ev
             act[slot].copy_(actions, non_blocking=True)
             token = gate.submitted() if gate is not None else None
             done[slot].record(s_inf)
+      t4 = time.perf_counter()
+      PROF['wait_staged'] += t1 - t0; PROF['lock'] += t2 - t1; PROF['graph_launch'] += t3 - t2; PROF['after'] += t4 - t3
 
       def finish():
         done[slot].synchronize()                     # the actions are on the host: the callers can be answered

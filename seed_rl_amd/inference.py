@@ -474,11 +474,16 @@ class FusedInferenceState(object):
     a lower bound of what is complete and an upper bound would be needed for back-pressure at the same time.  Callers
     therefore attempt it only when the mirror already says a batch is there (LearnerServer.train_step)."""
     k = int(self.batch_count[0])
-    self.last_fill = k                               # exact fill after this call (learner_server.BatchGate)
+    self.last_fill = k                               # exact fill after this call
     if k < batch_size:
       return False
+    self.last_fill = k - batch_size
+    self._dequeue_copy(dst, batch_size)
+    self.batch_count.fill_(k - batch_size)
+    return True
+
+  def _dequeue_copy(self, dst, batch_size):
     B, cap, L = batch_size, self.cap, self.L
-    self.last_fill = k - B
     start = self._start_host
     # columns [start, start + B) of the ring, time-major: one row move per field (the strided torch copies it replaces
     # ran at a quarter of the HBM rate, and the tail of the batch had to be cloned and shifted to the front)
@@ -507,8 +512,14 @@ class FusedInferenceState(object):
     ops.rows_move_multi(fd, fs, [self._rb(t, 2) for t in fs], None, rows, L * B)
     self._start_host = (start + B) % cap
     self.batch_start.fill_(self._start_host)
-    self.batch_count.fill_(k - B)
-    return True
+
+  def dequeue_async(self, dst, batch_size):
+    """dequeue_into WITHOUT the host read: the caller knows that batch_size unrolls are complete (learner_server.BatchGate
+    keeps a lower bound of the count from the per-batch mirrors) -- copies columns [head, head + batch_size) of the ring
+    into `dst`, advances the head and subtracts batch_size from the device count, all enqueued on the current stream (the
+    inference stream, under the submission lock).  Nothing waits for the replays in flight."""
+    self._dequeue_copy(dst, batch_size)
+    self.batch_count.sub_(batch_size)
 
   def take_batch(self):
     """Host read of the fill count; returns (count, Unroll over the filled columns, oldest first) and restarts filling

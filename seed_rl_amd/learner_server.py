@@ -17,8 +17,8 @@ Concurrency (round 3).  Inference and training share ONE GPU the way the referen
 inference and training cores: inference batches run on a HIGH-PRIORITY stream through an `inference_twin()` of the
 agent (same parameter buffer, own workspaces), the train step on its own stream, replayed from a HIP graph -- nothing
 serialises a whole train step against inference any more.  The only ordered hand-over is the dequeue: it is submitted
-to the inference stream under the lock that also orders the inference submissions (one count read, which waits for the
-replays in flight on that stream, and the column copies), writes into one of two static training unrolls, and the train stream waits for its event.  The
+to the inference stream under the lock that also orders the inference submissions (the column copies and the count
+update, no host read: BatchGate), writes into one of two static training unrolls, and the train stream waits for its event.  The
 transport is the native front-end (grpc_native / libseedserve.so) unless transport='python'.
 """
 import collections
@@ -33,28 +33,44 @@ from seed_rl_amd.unroll_store import Spec
 
 class BatchGate(object):
   """Back-pressure between central inference and the learner on one device batch (the reference blocks in
-  `unroll_queue.enqueue_many` when its queue of capacity 1 is full, learner.py:325-327,396-397): an inference batch of n
-  rows can complete at most n unrolls, so it is admitted only while fill + n <= capacity.  `fill` is an exact host copy
-  of the device's column count: the inference side mirrors the count after every batch (pinned memory, same stream),
-  the dequeue reads it exactly; a generation number keeps a mirror that was overtaken by a dequeue from being used."""
+  `unroll_queue.enqueue_many` when its queue of capacity 1 is full, learner.py:325-327,396-397) WITHOUT any blocking
+  read of the device's column count (r6; until r5 the dequeue read it, which waited for every replay in flight on the
+  inference stream while holding the submission lock: 70-120 us per inference call of the closed loop).
 
-  def __init__(self, state, n, lock):
+  Everything that changes the count is SUBMITTED in stream order under `lock` and numbered: an inference batch of n rows
+  adds between 0 and n columns, a dequeue removes exactly B.  Each batch copies the count into its own pinned word
+  behind itself; when its event has completed, that word is the exact count after submission number `base_seq`.  Then
+    lower bound = base_fill - B * (dequeues after base_seq)                   -- what the learner may rely on,
+    upper bound = lower bound + n * (batches after base_seq)                  -- what admission must assume,
+  and both are exact whenever nothing is in flight."""
+
+  def __init__(self, state, n, lock, ring=1024, mirrors=None):
     self.state, self.n, self.lock = state, n, lock
-    self.fill, self.gen, self.inflight = 0, 0, 0
-    self.mirror = torch.zeros(1, dtype=torch.int32).pin_memory()
-    self.waits = 0
-    self.open = True
+    self.mirrors = torch.zeros(ring, dtype=torch.int32).pin_memory() if mirrors is None else mirrors
+    self.seq, self.base_seq, self.base_fill = 0, 0, 0
+    self.after = collections.deque()                 # (seq, +n | -B) of the submissions behind base_seq
+    self.up, self.low = 0, 0                         # the two bounds (plain ints: read without the lock)
+    self.inflight, self.waits, self.open = 0, 0, True
+
+  def _bounds(self):
+    low = self.base_fill + sum(d for _, d in self.after if d < 0)
+    self.low, self.up = low, low + sum(d for _, d in self.after if d > 0)
+
+  @property
+  def fill(self):
+    """Completed unrolls the learner can rely on (a lower bound of the device's count; exact when nothing is in flight)."""
+    return self.low
 
   def would_block(self, ahead=0):
     """True while admit(ahead) would wait (grpc_native's compute loop launches an already staged batch first)."""
-    return self.open and self.fill + self.n * (self.inflight + ahead + 1) > self.state.cap
+    return self.open and self.up + self.n * (ahead + 1) > self.state.cap
 
   def admit(self, ahead=0, poll_s=0.0001):
-    """Blocks while this batch, on top of the ones still in flight, could overflow the device batch.  Once the gate is
-    closed (shutdown) nothing is admitted any more: the batch's callers get CANCELLED, as the reference's pending calls
-    do when its server shuts down -- letting batches through ungated then would overflow the device batch nobody
-    consumes any longer."""
-    while self.open and self.fill + self.n * (self.inflight + ahead + 1) > self.state.cap:
+    """Blocks while this batch, on top of everything submitted and the `ahead` batches staged before it, could overflow
+    the device batch.  Once the gate is closed (shutdown) nothing is admitted any more: the batch's callers get
+    CANCELLED, as the reference's pending calls do when its server shuts down -- letting batches through ungated then
+    would overflow the device batch nobody consumes any longer."""
+    while self.open and self.up + self.n * (ahead + 1) > self.state.cap:
       self.waits += 1
       time.sleep(poll_s)
     if not self.open:
@@ -62,21 +78,29 @@ class BatchGate(object):
 
   def submitted(self):
     """Under the submission lock, on the inference stream, right after the batch was enqueued."""
-    self.mirror.copy_(self.state.batch_count, non_blocking=True)
+    self.seq += 1
+    k = self.seq % self.mirrors.numel()
+    self.mirrors[k:k + 1].copy_(self.state.batch_count, non_blocking=True)
+    self.after.append((self.seq, self.n))
     self.inflight += 1
-    return self.gen
+    self._bounds()
+    return self.seq
 
   def completed(self, token):
-    """After the batch's event completed (its mirror copy -- or a later batch's -- has landed)."""
+    """After the batch's event completed: its mirror word has landed and is the exact count behind submission `token`."""
     with self.lock:
       self.inflight -= 1
-      if self.gen == token:
-        self.fill = int(self.mirror[0])
+      if token > self.base_seq:
+        self.base_seq, self.base_fill = token, int(self.mirrors[token % self.mirrors.numel()])
+        while self.after and self.after[0][0] <= token:
+          self.after.popleft()
+        self._bounds()
 
-  def dequeued(self, fill_now):
-    """Under the lock, by the dequeue: the exact fill after it (every batch submitted before is accounted for)."""
-    self.fill = fill_now
-    self.gen += 1
+  def dequeued(self, batch_size):
+    """Under the lock, right after a dequeue of batch_size columns was enqueued on the inference stream."""
+    self.seq += 1
+    self.after.append((self.seq, -batch_size))
+    self._bounds()
 
 
 class LearnerServer(object):
@@ -98,6 +122,8 @@ class LearnerServer(object):
     # neither the learner (fill < B) nor inference (no room) could ever make progress
     need = batch_size + inference_batch_size * (inference_slots + 2)
     cap = batch_capacity or max(need, 2 * batch_size + num_envs + inference_batch_size * (inference_slots + 1))
+    if not batch_capacity:
+      cap = -(-cap // batch_size) * batch_size        # the ring head then only visits cap / batch_size positions
     if cap < need:
       raise ValueError('batch_capacity %d is too small: need >= batch_size + inference_batch_size * (inference_slots + 2) = %d'
                        % (cap, need))
@@ -197,10 +223,11 @@ class LearnerServer(object):
           return None
         time.sleep(poll_s)
       with self.lock:
-        with torch.cuda.device(self.device), torch.cuda.stream(self.infer_stream):
-          ready = self.state.dequeue_into(self.unrolls[slot], self.B)
-          self.gate.dequeued(self.state.last_fill)
-          if ready:
+        ready = self.gate.fill >= self.B               # (re-read under the lock: another consumer may have been faster)
+        if ready:
+          with torch.cuda.device(self.device), torch.cuda.stream(self.infer_stream):
+            self.state.dequeue_async(self.unrolls[slot], self.B)
+            self.gate.dequeued(self.B)
             self._ready.record(self.infer_stream)
       if ready:
         break

@@ -281,3 +281,64 @@ def test_ws_kernel_index_math(emul, case):
   ok = emul.emul_ws_dgrad(ctypes.byref(g), ptr(dz), ptr(w), ptr(dx), ptr(x_raw), ptr(add))
   assert ok
   np.testing.assert_allclose(dx, x.grad.numpy() * (x_raw > 0) + add, rtol=1e-4, atol=1e-4)
+
+
+def test_batch_gate_bounds_without_device_reads():
+  """learner_server.BatchGate (r6): the learner's lower bound and admission's upper bound of the device's column count
+  from per-batch mirror words and the numbered submissions, against a simulated device that completes batches late and
+  in order -- the lower bound never exceeds the true count at the dequeue's place in the stream, admission never lets
+  the true count pass the capacity, and both bounds are exact when nothing is in flight."""
+  import collections
+  import threading
+  import numpy as np
+  import torch
+  from seed_rl_amd import learner_server
+
+  class State(object):
+    cap = 40
+    batch_count = torch.zeros(1, dtype=torch.int32)
+
+  rng = np.random.default_rng(0)
+  st, lock = State(), threading.Lock()
+  n, B = 8, 16
+  gate = learner_server.BatchGate(st, n, lock, ring=64, mirrors=torch.zeros(64, dtype=torch.int32))
+  # the "stream": submissions execute in order when the simulated device gets to them
+  stream = collections.deque()
+  true_count = 0
+  done_tokens = collections.deque()
+  peak = 0
+  for step in range(4000):
+    r = rng.uniform()
+    if r < 0.45 and not gate.would_block():
+      with lock:
+        st.batch_count[0] = -12345                      # the host must never look at the live count
+        tok = gate.submitted()
+        stream.append(('batch', tok, int(rng.integers(0, n + 1))))
+    elif r < 0.6 and gate.fill >= B:
+      with lock:
+        gate.dequeued(B)
+        stream.append(('deq', None, B))
+    elif r < 0.9 and stream:
+      kind, tok, amount = stream.popleft()              # the device executes the oldest submission
+      if kind == 'batch':
+        true_count += amount
+        gate.mirrors[tok % 64] = true_count             # the batch's own mirror word, written behind it
+        done_tokens.append(tok)
+      else:
+        assert true_count >= amount                     # the lower bound held at the dequeue's place in the stream
+        true_count -= amount
+      peak = max(peak, true_count)
+      assert true_count <= st.cap
+    elif done_tokens:
+      gate.completed(done_tokens.popleft())             # the completion thread notices, possibly much later
+    assert gate.up >= true_count + sum(a for k, _, a in stream if k == 'batch') - sum(a for k, _, a in stream if k == 'deq')
+  while stream:
+    kind, tok, amount = stream.popleft()
+    if kind == 'batch':
+      true_count += amount; gate.mirrors[tok % 64] = true_count; done_tokens.append(tok)
+    else:
+      assert true_count >= amount; true_count -= amount
+  while done_tokens:
+    gate.completed(done_tokens.popleft())
+  assert gate.low == gate.up == true_count and gate.inflight == 0
+  assert peak > B                                        # the run really filled the batch

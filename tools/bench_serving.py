@@ -138,6 +138,9 @@ def run_inprocess(dev, seconds=5.0, T=20, B=512, n=1024, envs=4096, warm_steps=3
       assert srv.train_step(timeout=60) is not None
       steps += 1
     srv.train_stream.synchronize()
+    from seed_rl_amd import grpc_native as _gn
+    _calls = max(_gn.PROF.get('calls', 0), 1)
+    submit_prof = {k: round(v / _calls * 1e6, 1) for k, v in _gn.PROF.items() if k != 'calls'}
     dt = time.perf_counter() - t0
     s1 = served[0]
   finally:
@@ -154,7 +157,8 @@ def run_inprocess(dev, seconds=5.0, T=20, B=512, n=1024, envs=4096, warm_steps=3
               env_steps_per_s_served=round((s1 - s0) / dt, 0), learner_env_frames_per_s=round(steps * B * T / dt, 0),
               train_steps=steps, ms_per_train_step_wall=round(dt / max(steps, 1) * 1e3, 3),
               inference_calls_per_s=round((s1 - s0) / n / dt, 0), gate_waits=gate.waits,
-              feeder_us_per_call={k: round(v / max(prof['calls'], 1) * 1e6, 1) for k, v in prof.items() if k != 'calls'})
+              feeder_us_per_call={k: round(v / max(prof['calls'], 1) * 1e6, 1) for k, v in prof.items() if k != 'calls'},
+              submit_us_per_call=submit_prof)
 
 
 def actor_proc(address, first_env, k, out, start, stop_at):
