@@ -80,6 +80,9 @@ def parse():
   ap.add_argument('--force-exchange', action='store_true',
                   help='run the N-replica launch mode (graph segments, asynchronous range all-reduces on the collective '
                        'stream, update graph) even with ONE rank: the RCCL rehearsal of the multi-GPU line on a 1-GPU box')
+  ap.add_argument('--windows', type=int, default=6,
+                  help='timed windows of --steps steps each: the first is the contract\'s (value), all of them give the '
+                       'median / min / max of the line\'s `windows` record')
   ap.add_argument('--quick', action='store_true',
                   help='only the timed learner step: no parity / other_configs / inference / ingest / cpu_baseline records')
   return ap.parse_args()
@@ -222,7 +225,7 @@ def build_workload(config, torso, T, B, A, dev, reduction, graph, world, seed, f
 
 
 def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, torso='shallow', batch=0, unroll_len=0,
-                actions=0, reduction='mean', graph=1, attribution_steps=3, force_exchange=False):
+                actions=0, reduction='mean', graph=1, attribution_steps=3, force_exchange=False, extra_windows=0):
   """Times `steps` learner steps of one BASELINE config; returns the record the JSON line is built from."""
   from seed_rl_amd import learner, ops
   T = unroll_len or (120 if config == 'r2d2' else 20)
@@ -248,7 +251,7 @@ def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, 
   kern = prof_all.summary()
   nattr = min(attribution_steps, max(warmup, 1))
   for v in kern.values():
-    v['total_ms'] /= nattr; v['calls'] //= nattr
+    v['total_ms'] /= nattr; v['calls'] /= nattr    # (true division in both places: step_roofline prices group calls)
     for g in v['groups']:
       g['calls'] /= nattr
   # dominant kernel = largest share of the step in that pass (averaged over the attribution steps so that two kernels
@@ -287,6 +290,21 @@ def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, 
   dt = time.perf_counter() - t0
   ops.set_profiler(None)
   loss = out[0]
+  # The contract's window above is what `value` / `ms_per_step` are computed from.  Behind it, extra_windows more windows
+  # of the SAME K steps with the same brackets: boxes of the pool differ by up to 18 % and one 19 ms window says nothing
+  # about its own spread -- the line carries median / min / max over all of them.
+  window_ms = [dt / steps * 1e3]
+  for _ in range(extra_windows if mode != 'eager' else 0):
+    barrier()
+    tw = time.perf_counter()
+    for _ in range(steps):
+      step_fn()
+    barrier()
+    window_ms.append((time.perf_counter() - tw) / steps * 1e3)
+  if distributed and len(window_ms) > 1:
+    wt = torch.tensor(window_ms, device=dev, dtype=torch.float64)
+    torch.distributed.all_reduce(wt, op=torch.distributed.ReduceOp.MAX)
+    window_ms = [float(x) for x in wt]
   if mode != 'eager':
     # free-running kernel time of the dominant kernel: HIP events around it on the launch stream, in a few eager
     # steps after the timed region (events cannot be recorded inside a replayed graph)
@@ -365,6 +383,9 @@ def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, 
   rec = dict(
       T=T, B=B, A=A, workload=workload, mode=mode, params=agent.flat.num_params(), loss=loss_val,
       ms_per_step=dt / steps * 1e3, frames_per_s=world * B * T / (dt / steps), roofline=roofline, dominant=dominant,
+      windows=dict(count=len(window_ms), steps_each=steps, ms_per_step=[round(x, 4) for x in window_ms],
+                   median=round(float(np.median(window_ms)), 4), min=round(min(window_ms), 4), max=round(max(window_ms), 4),
+                   note='window 0 is the contract\'s timed region (value / ms_per_step); the others repeat it'),
       step_roofline=step_roofline(kern, dt / steps * 1e3),
       kernels_ms_per_step={k: round(v['total_ms'], 4) for k, v in kern.items()}, exchange=exchange,
       # the other MFMA kernels of the attribution pass (>= 50 us per launch), same (serialized) accounting as `roofline`
@@ -608,7 +629,8 @@ def main():
   deep, r2 = args.config == 'dmlab', args.config == 'r2d2'
 
   rec = run_learner(args.config, args.steps, args.warmup, dev, rank, world, distributed, args.torso, args.batch,
-                    args.unroll, args.actions, args.reduction, args.graph, force_exchange=args.force_exchange)
+                    args.unroll, args.actions, args.reduction, args.graph, force_exchange=args.force_exchange,
+                    extra_windows=args.windows - 1)
   T, B, A = rec['T'], rec['B'], rec['A']
   roofline = rec['roofline']
   headline = args.config == 'atari' and args.torso == 'shallow' and B == 512 and T == 20 and A == 18
@@ -647,6 +669,7 @@ def main():
                  'grad_reduction': args.reduction, 'params': rec['params'], 'launch': rec['mode'],
                  'ingest': 'resident (unroll in HBM before the timed region)',
                  'process_group': (('rccl' if args.backend == 'nccl' else 'gloo') if distributed else None)},
+      'windows': rec['windows'],
       'roofline': roofline,
       'step_roofline': rec['step_roofline'],
       'exchange': rec['exchange'],

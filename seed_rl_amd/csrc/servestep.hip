@@ -306,16 +306,36 @@ serve_finish_kernel(const FinishArgs a) {
   f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const float* xr = x + j * LDX + 4 * kq;
   const float4* img = img_lds + lane;
-#pragma unroll 4
-  for (int blk = 0; blk < F / 16; ++blk) {
-    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(xr + 16 * blk);
-    const float4 bw0 = img[(2 * blk) * 64];
+  // what the row's lanes write at the end is requested now: one memory round trip under the MFMA chain, not behind it
+  const int rl = lane >> 2, part = lane & 3;
+  const long long i = row0 + rl;
+  const bool live = i < rows;
+  long long arow = -1, env = 0, pact = 0;
+  float rew = 0.f; uint8_t dn = 0, ab = 0; int es = 0;
+  unsigned long long seed = 0, call = 0;
+  if (live) {
+    arow = s.append_rows[i]; env = s.ids_safe[i]; pact = s.prev_actions[i]; rew = s.reward[i]; dn = s.done[i];
+    ab = s.abandoned ? s.abandoned[i] : (uint8_t)0; es = s.episode_step ? s.episode_step[i] : 0;
+    seed = s.rng_snapshot[0]; call = s.rng_snapshot[1];
+  }
+  // operands of block blk + 1 are read from LDS before block blk's MFMAs are issued (the loop did not unroll: every block
+  // waited out its own LDS round trip)
+  const int nblk = F / 16;
+  f32x4_t v_n = *reinterpret_cast<const f32x4_t*>(xr);
+  float4 bw0_n = img[0], bw1_n = img[64];
+  for (int blk = 0; blk < nblk; ++blk) {
+    const f32x4_t v = v_n;
+    const float4 bw0 = bw0_n, bw1 = bw1_n;
+    if (blk + 1 < nblk) {
+      v_n = *reinterpret_cast<const f32x4_t*>(xr + 16 * (blk + 1));
+      bw0_n = img[(2 * blk + 2) * 64];
+      bw1_n = img[(2 * blk + 3) * 64];
+    }
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[0], bw0.x, acc0, 0, 0, 0);
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[1], bw0.y, acc0, 0, 0, 0);
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2], bw0.z, acc0, 0, 0, 0);
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[3], bw0.w, acc0, 0, 0, 0);
     if (ntiles == 2) {
-      const float4 bw1 = img[(2 * blk + 1) * 64];
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[0], bw1.x, acc1, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[1], bw1.y, acc1, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2], bw1.z, acc1, 0, 0, 0);
@@ -329,14 +349,10 @@ serve_finish_kernel(const FinishArgs a) {
   }
   seedhip_wave_lds_fence();
   // lane (row = lane >> 2, part = lane & 3): Philox blocks part, part + 4, ... of the row (actions 4 blk .. 4 blk + 3)
-  const int rl = lane >> 2, part = lane & 3;
-  const long long i = row0 + rl;
-  const bool live = i < rows;
   const float* hr = head + rl * kHeadPitch;
   float best = -INFINITY;
   int arg = 0x7fffffff;
   if (live) {
-    const unsigned long long seed = s.rng_snapshot[0], call = s.rng_snapshot[1];
     const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
     for (int a0 = 4 * part; a0 < a.A; a0 += 16) {
       const uint4 r = seedhip::philox4x32_10(make_uint4((uint32_t)call, (uint32_t)(call >> 32), (unsigned)i, (uint32_t)(a0 >> 2)), key);
@@ -359,19 +375,17 @@ serve_finish_kernel(const FinishArgs a) {
     if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
   }
   if (arg == 0x7fffffff) arg = 0;                                      // every candidate was NaN / -inf: sample_categorical_row's 0
-  long long arow = -1;
   if (live) {
-    arow = s.append_rows[i];
     if (part == 0) {
       const long long act = arg;
       a.actions[i] = act;
       if (arow >= 0) {
-        s.actions_table[s.ids_safe[i]] = act;
-        a.f.prev_actions[arow] = s.prev_actions[i];
-        a.f.reward[arow] = s.reward[i];
-        a.f.done[arow] = s.done[i];
-        a.f.abandoned[arow] = s.abandoned ? s.abandoned[i] : (uint8_t)0;
-        a.f.episode_step[arow] = s.episode_step ? s.episode_step[i] : 0;
+        s.actions_table[env] = act;
+        a.f.prev_actions[arow] = pact;
+        a.f.reward[arow] = rew;
+        a.f.done[arow] = dn;
+        a.f.abandoned[arow] = ab;
+        a.f.episode_step[arow] = es;
         a.f.action[arow] = act;
         a.f.baseline[arow] = hr[a.A];
       }

@@ -204,6 +204,17 @@ class Learner(object):
       if lo > pos:
         all_reduce_gradients(self.agent.flat.grads[pos:lo], self.pg, force=True)
       pos = max(pos, hi)
+    self.exchange_step_guard()
+
+  def exchange_step_guard(self):
+    """The LSTM sequence kernels' sticky abort word travels WITH the gradient exchange (MAX over the replicas): a wait
+    that timed out on one rank makes EVERY rank's update kernel drop the step -- the summed gradients contain that rank's
+    garbage -- and every rank's host sees the word set one step later, demotes its agent and (GraphedStep) captures its
+    graphs again in lock step.  Without it one rank raised while the others blocked in their next all-reduce (ADVICE r4 /
+    VERDICT r5 item 8).  Agents without sequence kernels have no guard: no extra collective."""
+    guard = getattr(self.agent.flat, 'step_guard', None)
+    if guard is not None and self.exchanging:
+      torch.distributed.all_reduce(guard, op=torch.distributed.ReduceOp.MAX, group=self.pg)
 
   def update(self):
     self.optimizer.apply_gradients(self.agent.flat)
@@ -345,23 +356,25 @@ class GraphedStep(object):
       post()
     # the persistent LSTM kernels' abort flags: mirrored to pinned host memory after every replay and looked at
     # before the next one (by then the copy has landed: no sync) -- a wait that timed out during a replay raises here
+    # Data parallel: the word every rank looks at is the MAX over the ranks (Learner.exchange_step_guard) and the look
+    # WAITS for the previous replay's mirror copy -- every rank then takes the decision below at the same step, and the
+    # warm-up all-reduces of the new capture meet their partners.  (Single replica: no wait, the mirror is simply looked
+    # at once it has landed.)
     for a in self._agents:
       if getattr(a, '_last_lstm', None) is not None:
-        a._lstm_seq_check()                       # pylint: disable=protected-access
+        a._lstm_seq_check(wait=self.split)        # pylint: disable=protected-access
         a.mirror_error_flags()
+    self.recaptured = False
     if self._captured_seq and any(getattr(a, '_seq_demoted', False) for a in self._agents):
       # an agent fell back to the per-step LSTM kernels (a sequence kernel's wait timed out in an earlier replay -- of
-      # this graph or of another slot's; the update kernel dropped those steps): this graph still holds the sequence
-      # kernels -- capture again.  The step that timed out was dropped ON THE DEVICE; the host-side step counter (Adam's
-      # bias correction, the LR schedule position) still advanced for it: a rare fallback, not rolled back.
-      if self.split:
-        # the abort and the demotion are rank-local but the gradients are all-reduced: the other ranks applied this
-        # rank's invalid gradients, and a re-capture here would post warm-up all-reduces nobody matches
-        raise RuntimeError('seed_rl_amd: an LSTM sequence kernel timed out on this rank of a data-parallel learner; '
-                           'replicas have diverged -- restart from the last checkpoint with SEEDHIP_LSTM_SEQ=0')
+      # this graph or of another slot's, on this rank or on another; the update kernel dropped those steps everywhere):
+      # this graph still holds the sequence kernels -- capture again.  The step that timed out was dropped ON THE DEVICE;
+      # the host-side step counter (Adam's bias correction, the LR schedule position) still advanced for it on every
+      # rank alike: a rare fallback, not rolled back.
       out = self.outputs                          # this call's results (the new capture's outputs are not written yet)
       torch.cuda.synchronize()
       self.__init__(self.learner, self.unroll, *self.extra, warmup=1, max_cuts=self._max_cuts)
+      self.recaptured = True
       return out
     return self.outputs
 

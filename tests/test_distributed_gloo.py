@@ -219,3 +219,71 @@ def test_force_exchange_with_one_rank(tmp_path):
   from seed_rl_amd import learner
   with pytest.raises(ValueError):
     learner.Learner(object(), None, None, force_exchange=True)      # no process group in THIS process
+
+
+def _guard_worker(rank, world, port, out):
+  """Lock-step abort: rank 1's LSTM sequence kernel "times out" in step 2 (its sticky word is set, its
+  gradients are garbage).  The word travels with the gradient exchange (MAX), so BOTH ranks drop that step -- the stand-in
+  optimizer is guarded by flat.step_guard exactly like csrc/adam.hip -- both see the word afterwards (the host's demotion
+  signal), and the replicas stay bit-equal through the steps that follow."""
+  sys.path.insert(0, ROOT)
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from seed_rl_amd import learner
+    from seed_rl_amd.flat import FlatParams
+
+    class _Agent(object):
+      grad_ready_hook = None
+
+      def __init__(self):
+        self.flat = FlatParams([('conv', (37,)), ('core', (101,))], torch.device('cpu'))
+        self.flat.params.fill_(1.0)
+        self.flat.step_guard = torch.zeros(1, dtype=torch.int32)
+        self.step, self.fault_at = 0, None
+
+      def backward(self):
+        g = torch.arange(self.flat.size, dtype=torch.float32) * 1e-3 * (rank + 1) + self.step
+        if self.step == self.fault_at:                  # the aborted kernel: garbage gradients + the sticky word
+          g = torch.full_like(g, float('nan'))
+          self.flat.step_guard.fill_(1)
+        self.flat.grads.copy_(g)
+        if self.grad_ready_hook is not None:
+          self.grad_ready_hook(self.flat.offsets['core'], self.flat.size)
+        self.step += 1
+
+    class _GuardedSGD(object):
+      applied = 0
+
+      def apply_gradients(self, flat):
+        if int(flat.step_guard[0]) == 0:                # csrc/adam.hip: the update is dropped while the word is set
+          flat.params -= 0.1 * flat.grads
+          self.applied += 1
+
+    agent, opt = _Agent(), _GuardedSGD()
+    agent.fault_at = 2 if rank == 1 else None
+    lrn = learner.Learner(agent, opt, None)
+    seen = []
+    for step in range(5):
+      agent.grad_ready_hook = lrn._on_grads_ready
+      agent.backward()
+      agent.grad_ready_hook = None
+      lrn.apply_gradients()
+      seen.append(int(agent.flat.step_guard[0]))
+      if seen[-1]:                                       # what _lstm_seq_check does one step later: demote, clear the word
+        agent.flat.step_guard.zero_()
+    assert seen == [0, 0, 1, 0, 0], seen                 # BOTH ranks saw the word in step 2
+    assert opt.applied == 4
+    assert bool(torch.isfinite(agent.flat.params).all())
+    torch.save(agent.flat.params.clone(), out + str(rank))
+  finally:
+    torch.distributed.destroy_process_group()
+
+
+def test_lstm_abort_word_travels_with_the_gradient_exchange(tmp_path):
+  world, port = 2, _free_port()
+  out = str(tmp_path / 'p')
+  mp.spawn(_guard_worker, args=(world, port, out), nprocs=world, join=True)
+  p0, p1 = torch.load(out + '0'), torch.load(out + '1')
+  assert torch.equal(p0, p1)

@@ -199,3 +199,57 @@ def test_two_rank_learner_servers(device, tmp_path, graphed):
   assert not torch.equal(got[0]['params'], init)
   assert all(np.isfinite(l) for g in got for l in g['losses'])
   assert got[0]['losses'] != got[1]['losses']                         # different data on the two ranks
+
+
+def _abort_worker(rank, world, port, out):
+  """Two data-parallel replicas of an LSTM agent through GraphedStep's split mode; rank 1's sequence kernel "times out"
+  (its sticky word is armed the way the kernel arms it, as in tests/test_gpu_lstm_demotion.py).  The word travels with the
+  gradient exchange (MAX): both ranks drop the step, both see the word one step later, both demote and capture their
+  graphs again AT THE SAME STEP (the new capture's warm-up all-reduces meet their partners: no hang), and the replicas stay
+  bit-equal."""
+  sys.path.insert(0, ROOT)
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from seed_rl_amd import learner, networks, ops, optimizers, parametric_distribution as pd, smoke_step
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    Ad, T1d, Bd = 6, 21, 32
+    if not ops.lstm_seq_supported(T1d, Bd, 256):
+      torch.save(dict(skipped=True), out + str(rank))
+      return
+    agent = networks.ImpalaDeep(Ad, observation_shape=(24, 32, 3), device=dev, seed=0)
+    opt = optimizers.Adam(optimizers.PolynomialDecay(4.8e-4, 50), beta_1=0.0, epsilon=3.125e-7, capturable=True)
+    unroll = smoke_step.make_deep_unroll(agent, T1d, Bd, Ad, dev, seed=3 + rank, done_p=0.2)
+    lrn = learner.Learner(agent, opt, pd.categorical_distribution(Ad))
+    step = learner.GraphedStep(lrn, unroll, warmup=1)
+    assert step.split and step._captured_seq
+    step(); torch.cuda.synchronize()
+    p1 = agent.flat.params.clone()
+    if rank == 1:
+      agent._seq_sticky().fill_(1)                              # rank 1 only: its sequence kernel "timed out"
+    step(); torch.cuda.synchronize()
+    dropped = torch.equal(agent.flat.params, p1)                # BOTH ranks must have dropped this step
+    recaptured = []
+    for _ in range(3):
+      step(); torch.cuda.synchronize()
+      recaptured.append(bool(step.recaptured))
+    torch.save(dict(skipped=False, dropped=dropped, recaptured=recaptured, demoted=bool(agent._seq_demoted),
+                    sticky=int(agent._seq_sticky()[0]), params=agent.flat.params.cpu(),
+                    moved=not torch.equal(agent.flat.params, p1)), out + str(rank))
+  finally:
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_lstm_abort_is_lock_step(device, tmp_path):
+  world, port = 2, _free_port()
+  out = str(tmp_path / 'abort')
+  mp.spawn(_abort_worker, args=(world, port, out), nprocs=world, join=True)
+  got = [torch.load(out + str(r)) for r in range(world)]
+  if got[0]['skipped']:
+    pytest.skip('sequence kernels not available for this shape')
+  for g in got:
+    assert g['dropped'] and g['demoted'] and g['sticky'] == 0 and g['moved'], {k: v for k, v in g.items() if k != 'params'}
+  assert got[0]['recaptured'] == got[1]['recaptured'] and sum(got[0]['recaptured']) == 1, got[0]['recaptured']
+  assert torch.equal(got[0]['params'], got[1]['params'])
