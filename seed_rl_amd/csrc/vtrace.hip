@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256)
 vtrace_scan_kernel(const float* __restrict__ tgt, const float* __restrict__ beh,
                    const float* __restrict__ disc, const float* __restrict__ rew,
                    const float* __restrict__ val, const float* __restrict__ boot,
-                   float clip_rho, float clip_pg, float lambda, int T, long long B,
+                   float clip_rho, float clip_pg, float lambda, int T, long long B, long long row_ld,
                    float* __restrict__ vs_out, float* __restrict__ pg_out) {
   const long long col = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
   if (col >= B) return;
@@ -64,7 +64,7 @@ vtrace_scan_kernel(const float* __restrict__ tgt, const float* __restrict__ beh,
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (u < n) {
-        const long long off = (long long)(t - u) * B + col;
+        const long long off = (long long)(t - u) * row_ld + col;
         ldx<V, (NT & 2) != 0>(tgt + off, a_t[u]); ldx<V, (NT & 2) != 0>(beh + off, a_b[u]); ldx<V, (NT & 2) != 0>(disc + off, a_d[u]);
         ldx<V, (NT & 2) != 0>(rew + off, a_r[u]); ldx<V, (NT & 2) != 0>(val + off, a_v[u]);
       }
@@ -87,7 +87,7 @@ vtrace_scan_kernel(const float* __restrict__ tgt, const float* __restrict__ beh,
           o_pg[i] = cpg * ((r + d * vs_next[i]) - v);                  // :143-144
           o_vs[i] = vs; vs_next[i] = vs; v_next[i] = v;
         }
-        const long long off = (long long)(t - u) * B + col;
+        const long long off = (long long)(t - u) * row_ld + col;
         st<V, (NT & 1) != 0>(vs_out + off, o_vs); st<V, (NT & 1) != 0>(pg_out + off, o_pg);
       }
     }
@@ -113,7 +113,6 @@ extern "C" int seedhip_vtrace_from_importance_weights(
                     aligned16(rewards) && aligned16(values) && aligned16(bootstrap_value) &&
                     aligned16(vs) && aligned16(pg_advantages);
   if (vec4) {
-    const long long nthr = B / 4;
     const int block = 256;
     // Cache policy by working set (measured on MI355X, tools/bench_vtrace.py, GB/s of the 28 B per element):
     //   <= 0.3 GB (B <= 2^19; the 256 MB infinity cache still helps): plain loads / stores, one step in flight
@@ -123,11 +122,24 @@ extern "C" int seedhip_vtrace_from_importance_weights(
     static const int forced = getenv("SEEDHIP_VTRACE_VARIANT") ? atoi(getenv("SEEDHIP_VTRACE_VARIANT")) : -1;
     const long long bytes = 28LL * T * B;
     const int variant = forced >= 0 ? forced : (bytes <= (400LL << 20) ? 6 : (bytes <= (1500LL << 20) ? 7 : 4));
+    // Column chunks (r6; VERDICT r5 item 9: 0.73 of HBM at B = 2^20 fell to 0.58 at 2^22).  Every workgroup walks its
+    // columns at its own t, so one launch touches all T rows of all seven arrays over the column range in flight: at
+    // B = 2^22 that is 140 row streams 16 MB apart over 2.35 GB.  Launching the same problem as column chunks (row stride
+    // B, 2^19 columns = 0.29 GB of footprint each) bounds what is open at a time: 496 -> 447 us (4.77 -> 5.29 TB/s, 0.66
+    // of HBM) at 2^22; chunks of 2^20 / 2^21 give 470 / 485 us, B <= 2^21 does not move (tools/bench_vtrace.py with
+    // SEEDHIP_VTRACE_CHUNK).  The grid was never capped; the loss is the footprint (page / DRAM-row locality), not the launch.
+    static const long long forced_chunk = getenv("SEEDHIP_VTRACE_CHUNK") ? atoll(getenv("SEEDHIP_VTRACE_CHUNK")) : -1;
+    long long chunk = forced_chunk >= 0 ? forced_chunk : (bytes > (1500LL << 20) ? (1LL << 19) : 0);
+    if (chunk <= 0 || chunk > B) chunk = B;
+    chunk = chunk / 4 * 4;
 #define SEEDHIP_VT(U_, NT_)                                                                                        \
-    hipLaunchKernelGGL((vtrace_scan_kernel<4, U_, NT_>), dim3(seedhip::cdiv(nthr, block)), dim3(block), 0, s,      \
-                       target_action_log_probs, behaviour_action_log_probs, discounts, rewards, values,           \
-                       bootstrap_value, clip_rho_threshold, clip_pg_rho_threshold, lambda_, T, B, vs,             \
-                       pg_advantages)
+    for (long long c0 = 0; c0 < B; c0 += chunk) {                                                                 \
+      const long long bc = B - c0 < chunk ? B - c0 : chunk;                                                       \
+      hipLaunchKernelGGL((vtrace_scan_kernel<4, U_, NT_>), dim3(seedhip::cdiv(bc / 4, block)), dim3(block), 0, s, \
+                         target_action_log_probs + c0, behaviour_action_log_probs + c0, discounts + c0,           \
+                         rewards + c0, values + c0, bootstrap_value + c0, clip_rho_threshold,                     \
+                         clip_pg_rho_threshold, lambda_, T, bc, B, vs + c0, pg_advantages + c0);                  \
+    }
     switch (variant) {
       case 1: SEEDHIP_VT(4, 0); break;
       case 2: SEEDHIP_VT(2, 1); break;
@@ -144,7 +156,7 @@ extern "C" int seedhip_vtrace_from_importance_weights(
     const int block = (B >= (1 << 15)) ? 256 : 64;
     hipLaunchKernelGGL((vtrace_scan_kernel<1, 4>), dim3(seedhip::cdiv(B, block)), dim3(block), 0, s,
                        target_action_log_probs, behaviour_action_log_probs, discounts, rewards, values,
-                       bootstrap_value, clip_rho_threshold, clip_pg_rho_threshold, lambda_, T, B, vs,
+                       bootstrap_value, clip_rho_threshold, clip_pg_rho_threshold, lambda_, T, B, B, vs,
                        pg_advantages);
   }
   return seedhip::check_launch("vtrace_scan_kernel");

@@ -138,7 +138,7 @@ wdx_kernel(const Params p) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const xg::f32x2_t x = {it[2 * e], it[2 * e + 1]};
-      const xg::u32x2_t xu = __builtin_bit_cast(xg::u32x2_t, x) & 0xFFFF0000u;     // split by truncation (wfx.h)
+      const xg::u32x2_t xu = xg::hi_part(__builtin_bit_cast(xg::u32x2_t, x));     // split by truncation (wfx.h)
       const xg::f32x2_t r1 = x - __builtin_bit_cast(xg::f32x2_t, xu);
       const xg::u32x2_t ru = __builtin_bit_cast(xg::u32x2_t, r1) & 0xFFFF0000u;
       const xg::u32x2_t r2 = __builtin_bit_cast(xg::u32x2_t, r1 - __builtin_bit_cast(xg::f32x2_t, ru));

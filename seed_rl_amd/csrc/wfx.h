@@ -161,7 +161,7 @@ wfx_kernel(const Params p) {
     // The weights are split with round-to-nearest, so the dropped products am wl + al wm keep a random sign; their
     // bound doubles to 2^-24 |x w|, half an ulp of the product.
     const xg::f32x2_t x = {f0, f1};
-    const xg::u32x2_t xu = __builtin_bit_cast(xg::u32x2_t, x) & 0xFFFF0000u;
+    const xg::u32x2_t xu = xg::hi_part(__builtin_bit_cast(xg::u32x2_t, x));
     const xg::f32x2_t r1 = x - __builtin_bit_cast(xg::f32x2_t, xu);                 // (v_pk_add_f32)
     const xg::u32x2_t ru = __builtin_bit_cast(xg::u32x2_t, r1) & 0xFFFF0000u;
     const xg::u32x2_t r2 = __builtin_bit_cast(xg::u32x2_t, r1 - __builtin_bit_cast(xg::f32x2_t, ru));

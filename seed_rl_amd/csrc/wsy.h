@@ -132,7 +132,7 @@ wsy_kernel(const Params p) {
     for (int e = 0; e < 2; ++e) {
       xg::f32x2_t x = {it[2 * e], it[2 * e + 1]};
       if (!DG && p.in_relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); }
-      const xg::u32x2_t xu = __builtin_bit_cast(xg::u32x2_t, x) & 0xFFFF0000u;     // split by truncation (wfx.h)
+      const xg::u32x2_t xu = xg::hi_part(__builtin_bit_cast(xg::u32x2_t, x));     // split by truncation (wfx.h)
       const xg::f32x2_t r1 = x - __builtin_bit_cast(xg::f32x2_t, xu);
       const xg::u32x2_t ru = __builtin_bit_cast(xg::u32x2_t, r1) & 0xFFFF0000u;
       const xg::u32x2_t r2 = __builtin_bit_cast(xg::u32x2_t, r1 - __builtin_bit_cast(xg::f32x2_t, ru));

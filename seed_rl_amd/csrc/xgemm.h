@@ -63,11 +63,25 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& 
   l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
 }
 
+// The h part of the in-kernel splits below.  SEEDHIP_SPLIT_H_RNE = 0: truncation (one v_and); 1: round to nearest even
+// with integer operations (bits + 0x7FFF + ((bits >> 16) & 1), mask: v_bfe + v_add3 + v_and) -- m and l stay exact
+// truncations of an exactly representable remainder, but the remainder then has either sign, and the dropped products
+// am bl + al bm + al bl lose the common sign that truncating h gives them (r6 A/B: profiles/r06_split_rne_ab.txt).
+#ifndef SEEDHIP_SPLIT_H_RNE
+#define SEEDHIP_SPLIT_H_RNE 0
+#endif
+__device__ __forceinline__ unsigned hi_part(unsigned bits) {
+  return SEEDHIP_SPLIT_H_RNE ? ((bits + 0x7FFFu + ((bits >> 16) & 1u)) & 0xFFFF0000u) : (bits & 0xFFFF0000u);
+}
+__device__ __forceinline__ u32x2_t hi_part(u32x2_t bits) {
+  return SEEDHIP_SPLIT_H_RNE ? ((bits + 0x7FFFu + ((bits >> 16) & 1u)) & 0xFFFF0000u) : (bits & 0xFFFF0000u);
+}
+
 // the same split by TRUNCATION (plain integer / fp32 VALU operations only: v_cvt_pk_bf16_f32 issues at a quarter of
 // their rate): h = top 8 significant bits, m = top 8 of the rest, l = the remaining <= 8 bits; h + m + l == v exactly,
 // every part has the sign of v, so the dropped products am bl + al bm (<= 2^-23 |a b|) share the sign of a b
 __device__ __forceinline__ void split2_trunc(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-  const unsigned ha = __float_as_uint(a) & 0xFFFF0000u, hb = __float_as_uint(b) & 0xFFFF0000u;
+  const unsigned ha = hi_part(__float_as_uint(a)), hb = hi_part(__float_as_uint(b));
   const float ra = a - __uint_as_float(ha), rb = b - __uint_as_float(hb);
   const unsigned ma = __float_as_uint(ra) & 0xFFFF0000u, mb = __float_as_uint(rb) & 0xFFFF0000u;
   const float la = ra - __uint_as_float(ma), lb = rb - __uint_as_float(mb);

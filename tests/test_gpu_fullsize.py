@@ -52,12 +52,9 @@ def _check_grads_fp64(r):
   # per tensor: HIP's q99 distance to the fp64 evaluation <= 1.25 x the fp32 oracle's own + 5e-5 (r4: 3x + 1e-4 on the
   # worst tensors only, three times looser than what was measured)
   assert r['grad_q99_gate_vs_fp64'] <= 1.0, _show(r)
-  # Pinned deviation: BIAS gradients are plain sums of ~6e5 largely cancelling dY terms (|sum| ~ 1/760 of sum |.|), so a
-  # relative one-sidedness of 1e-7 per term upstream (a candidate: the activations of the bf16x6 conv kernels are split by
-  # TRUNCATION) is amplified ~760x.  r5, cfg3: stack2/res_1/conv2d_1/bias 2.1e-4 (q99) from fp64 against the fp32 oracle's 5.6e-5
-  # (ratio 1.78), stack2/res_0/conv2d_0/bias 1.10; every kernel tensor <= 0.81.  Summing them in fp64 inside wgx.h does not
-  # move these digits: the difference is in dY.  Bound: 2x the formula that kernels meet at 1x.
-  assert r['grad_q99_gate_bias_vs_fp64'] <= 2.0, _show(r)
+  # bias vectors: the same formula on the 90th percentile (tests/parity.py: the q99 of 32 elements is their maximum, and
+  # the r5 "bias deviation" was one ReLU-tie channel; r6 diagnosis in DESIGN.md section 8)
+  assert r['grad_q99_gate_bias_vs_fp64'] <= 1.0, _show(r)
   assert r['grad_max_rel_err_vs_fp64'] <= 1e-2, _show(r)
   assert r['grad_max_rel_err'] <= 1.1 * (r['grad_max_rel_err_vs_fp64'] + r['oracle_grad_max_rel_err_vs_fp64']) + 1e-6, \
       _show(r)
@@ -135,7 +132,7 @@ def test_cfg3_dmlab_T20_B256(device):
     # (+5e-5) at most (r4: 3x + 1e-4 on the worst tensors; measured 1.05x)
     assert r['grad_q99_rel_err_vs_fp64'] <= 1.5e-3, _show(r)
     assert r['grad_q99_gate_vs_fp64'] <= 1.0, _show(r)
-    assert r['grad_q99_gate_bias_vs_fp64'] <= 2.0, _show(r)           # (bias vectors: the pinned deviation in _check_grads_fp64)
+    assert r['grad_q99_gate_bias_vs_fp64'] <= 1.0, _show(r)           # (bias vectors: the same bound on their q90, tests/parity.py)
     assert r['grad_max_rel_err_vs_fp64'] <= 1e-2, _show(r)
   _check_params(r)
 

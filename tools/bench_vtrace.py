@@ -15,4 +15,4 @@ for B in (1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 1 << 22):
   for _ in range(30): run()
   e.record(); torch.cuda.synchronize()
   us = s.elapsed_time(e) * 1e3 / 30
-  print(os.environ.get('SEEDHIP_VTRACE_VARIANT', '0'), B, round(us, 1), 'us', round((T * B * 28 + B * 4) / us / 1e3), 'GB/s')
+  print(os.environ.get('SEEDHIP_VTRACE_VARIANT', '-'), os.environ.get('SEEDHIP_VTRACE_CHUNK', '-'), B, round(us, 1), 'us', round((T * B * 28 + B * 4) / us / 1e3), 'GB/s')
