@@ -128,7 +128,8 @@ class LearnerServer(object):
       raise ValueError('batch_capacity %d is too small: need >= batch_size + inference_batch_size * (inference_slots + 2) = %d'
                        % (cap, need))
     with torch.cuda.device(dev):
-      self.infer_stream = torch.cuda.Stream(device=dev, priority=-1)
+      import os
+      self.infer_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get('SEEDRL_INFER_PRIORITY', '-1')))
       self.train_stream = torch.cuda.Stream(device=dev)
     self.infer_agent = agent.inference_twin() if hasattr(agent, 'inference_twin') else agent
     self.state = inference.FusedInferenceState(self.infer_agent, num_envs, unroll_length, env_specs, ao_specs,
