@@ -115,6 +115,13 @@ int seedhip_impala_loss_fwd_bwd_adaptive(
  * reference (agents/vtrace/learner.py:286-296) at memory speed.  Host code; no stream. */
 unsigned int seedhip_crc32c(const void* data, size_t n, unsigned int crc);
 
+/* A HIP stream restricted to a subset of the compute units (r6): mask = `words` 32-bit words, bit i of word w = compute
+ * unit 32 w + i.  The closed serving loop runs central inference and the train step on disjoint CU sets
+ * (learner_server.LearnerServer); the reference places inference and training on different TPU cores
+ * (agents/vtrace/learner.py:199-214, 406-414).  *stream is a hipStream_t; destroy it with seedhip_stream_destroy. */
+int seedhip_stream_create_cu_mask(const unsigned int* mask, int words, void** stream);
+int seedhip_stream_destroy(void* stream);
+
 /* ---- optimizer --------------------------------------------------------------------
  * Replaces the Keras Adam apply_gradients of agents/vtrace/learner.py:272-275
  * (dmlab/vtrace_main.py:46-51) over ONE flat parameter buffer.  lr_t already

@@ -62,6 +62,8 @@ SIGNATURES = {
     'seedhip_last_error': (ctypes.c_char_p, []),
     'seedhip_abi_version': (c_int, []),
     'seedhip_crc32c': (ctypes.c_uint, [P, c_size_t, ctypes.c_uint]),
+    'seedhip_stream_create_cu_mask': (c_int, [P, c_int, P]),
+    'seedhip_stream_destroy': (c_int, [P]),
     'seedhip_vtrace_from_importance_weights':
         (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, c_int, c_ll, P, P, P]),
     'seedhip_categorical_log_prob_entropy': (c_int, [P, P, c_int, c_ll, c_int, P, P, P]),

@@ -49,3 +49,24 @@ extern "C" unsigned int seedhip_crc32c(const void* data, size_t n, unsigned int 
   while (n--) c = tb.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
   return ~c;
 }
+
+
+// A stream restricted to a subset of the compute units (hipExtStreamCreateWithCUMask): the closed serving loop gives
+// central inference and the train step DISJOINT sets of CUs, so that an inference kernel never waits for the persistent
+// workgroups of a train kernel to retire (learner_server.LearnerServer, SEEDRL_CU_SPLIT).
+// mask: `words` 32-bit words, bit i of word w = compute unit 32 w + i in the runtime's enumeration.
+extern "C" int seedhip_stream_create_cu_mask(const unsigned int* mask, int words, void** stream) {
+  SEEDHIP_REQUIRE(mask && words >= 1 && stream, "stream_create_cu_mask: null pointer / no mask words");
+  hipStream_t s = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
+  if (e != hipSuccess) return seedhip::fail(SEEDHIP_ERR_LAUNCH, "hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+  *stream = (void*)s;
+  return SEEDHIP_OK;
+}
+
+extern "C" int seedhip_stream_destroy(void* stream) {
+  if (!stream) return SEEDHIP_OK;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) return seedhip::fail(SEEDHIP_ERR_LAUNCH, "hipStreamDestroy: %s", hipGetErrorString(e));
+  return SEEDHIP_OK;
+}

@@ -107,7 +107,8 @@ class LearnerServer(object):
 
   def __init__(self, agent, learner, unroll_length, batch_size, inference_batch_size, num_envs, observation_shape,
                server_addresses, observation_dtype=torch.uint8, device='cuda', graphed=True, batch_capacity=None,
-               transport='native', num_unroll_slots=2, num_io_threads=None, inference_slots=4, inference_pipeline=3):
+               transport='native', num_unroll_slots=2, num_io_threads=None, inference_slots=4, inference_pipeline=3,
+               cu_split=None):
     self.agent, self.learner = agent, learner
     self.T, self.B, self.n = unroll_length, batch_size, inference_batch_size
     self.device = dev = torch.device(device)
@@ -127,10 +128,26 @@ class LearnerServer(object):
     if cap < need:
       raise ValueError('batch_capacity %d is too small: need >= batch_size + inference_batch_size * (inference_slots + 2) = %d'
                        % (cap, need))
+    # Inference and training on DISJOINT compute units (cu_split = k: the first k of the 32 CUs of EVERY XCD serve
+    # inference, the other 32 - k the train step; None / 0: one shared pool, inference on a high-priority stream).  On a
+    # shared pool an inference kernel only gets the CU slots that the train step's workgroups vacate, and the first conv's
+    # kernels keep theirs for the whole launch (persistent grids, ~130 us): in the closed loop every inference kernel ran
+    # ~3x its stand-alone time.  Mask bit 8 j + x is CU j of XCD x (measured: tools/cu_mask_check.py -- a mask that leaves
+    # an XCD empty is completed by the runtime, so "every other bit" keeps all 256 CUs while "bits 0..7 of every 16" keeps
+    # 16 CUs per XCD): a per-XCD prefix is bits [0, 8 k).
+    import os
+    if cu_split is None and os.environ.get('SEEDRL_CU_SPLIT'):
+      cu_split = int(os.environ['SEEDRL_CU_SPLIT'])
+    self.cu_split = int(cu_split) if cu_split and 0 < int(cu_split) < 32 else None
     with torch.cuda.device(dev):
-      import os
-      self.infer_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get('SEEDRL_INFER_PRIORITY', '-1')))
-      self.train_stream = torch.cuda.Stream(device=dev)
+      if self.cu_split:
+        from seed_rl_amd import ops
+        k_ = self.cu_split
+        self.infer_stream, self.infer_cus = ops.cu_mask_stream(dev, lambda i: i < 8 * k_)
+        self.train_stream, self.train_cus = ops.cu_mask_stream(dev, lambda i: i >= 8 * k_)
+      else:
+        self.infer_stream = torch.cuda.Stream(device=dev, priority=-1)
+        self.train_stream = torch.cuda.Stream(device=dev)
     self.infer_agent = agent.inference_twin() if hasattr(agent, 'inference_twin') else agent
     self.state = inference.FusedInferenceState(self.infer_agent, num_envs, unroll_length, env_specs, ao_specs,
                                                batch_capacity=cap, device=dev)

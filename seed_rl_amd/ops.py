@@ -827,3 +827,24 @@ def serve_emit(step, batch, store, row_bytes, first_table, batch_first, store_ob
           ctypes.byref(step), k, ctypes.cast(da, ctypes.c_void_p), ctypes.cast(sa, ctypes.c_void_p),
           ctypes.cast(ra, ctypes.c_void_p), _lib.ptr(first_table), _lib.ptr(batch_first), _lib.ptr(store_obs), int(hw),
           _lib.stream()), 'seedhip_serve_emit')
+
+
+
+# ---- streams on a subset of the compute units ------------------------------------------------------------------------ #
+def cu_mask_stream(device, keep, num_cus=256):
+  """A torch stream whose kernels run only on the compute units i with keep(i) true (hipExtStreamCreateWithCUMask through
+  the C ABI).  Returns (torch.cuda.ExternalStream, number of CUs kept).  The stream lives as long as the process."""
+  words = (num_cus + 31) // 32
+  mask = (ctypes.c_uint * words)()
+  kept = 0
+  for i in range(num_cus):
+    if keep(i):
+      mask[i // 32] |= 1 << (i % 32)
+      kept += 1
+  if kept == 0:
+    raise ValueError('cu_mask_stream: empty mask')
+  out = ctypes.c_void_p()
+  with torch.cuda.device(device):
+    _lib.check(_lib.lib().seedhip_stream_create_cu_mask(ctypes.cast(mask, ctypes.c_void_p), words, ctypes.byref(out)),
+               'seedhip_stream_create_cu_mask')
+  return torch.cuda.ExternalStream(out.value, device=device), kept
