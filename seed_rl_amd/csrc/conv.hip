@@ -541,7 +541,9 @@ extern "C" int seedhip_conv2d_bwd_data(const seedhip_conv_geom* geom, const floa
 // Dense data gradient with the byte mask: the bf16x6 kernel of xgemm.h, unsplit reduction only (the split-K epilogue
 // kernel reads the fp32 mask)
 static bool dense_bits_ok(const seedhip_conv_geom* g) {
-  if (!(xg::mode() & 2) || !is_dense(g)) return false;
+  // the mask is indexed [row][cin / 4]: a padded input row (ld_in > cin, the LSTM-input layers) would read it with the
+  // wrong pitch
+  if (!(xg::mode() & 2) || !is_dense(g) || g->ld_in != g->cin) return false;
   const xg::Plan xp = x6_dgrad_plan(g);
   return xp.ok && xp.slices == 1;
 }

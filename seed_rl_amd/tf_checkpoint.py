@@ -489,7 +489,9 @@ def save_agent(prefix, agent, root='agent', optimizer=None, optimizer_root='opti
           a = view.detach().cpu().numpy()
           tensors[key] = a.reshape(()) if name == 'entropy_cost_param' else a
   if 'save_counter' + _SUFFIX not in tensors:         # tf.train.Checkpoint.save() counts its calls there and names the
-    m = re.search(r'-(\d+)$', os.path.basename(prefix))   # file `<dir>/ckpt-<save_counter>` (learner.py:469-475): take it back
+    # file `<dir>/ckpt-<save_counter>` (learner.py:469-475): take it back -- only from names of exactly that form (a
+    # prefix such as `run-3` or `model-2024` is not a CheckpointManager number: ADVICE r5)
+    m = re.fullmatch(r'ckpt-(\d+)', os.path.basename(prefix))
     tensors['save_counter' + _SUFFIX] = np.asarray(int(m.group(1)) if m else 1, np.int64)
   tensors[OBJECT_GRAPH_KEY] = object_graph(tensors, optimizer_root).SerializeToString()
   write_checkpoint(prefix, tensors)
