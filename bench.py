@@ -741,7 +741,7 @@ def main():
       try:
         sys.path.insert(0, os.path.join(ROOT, 'tools'))
         import bench_serving
-        serving = dict(inprocess=bench_serving.run_inprocess(dev, seconds=3.0, n=2048, envs=8192))
+        serving = dict(inprocess=bench_serving.run_inprocess(dev, seconds=3.0, n=4096, envs=16384))
         _release()
         try:
           procs = 32 if (os.cpu_count() or 8) >= 64 else 8

@@ -31,11 +31,15 @@ import numpy as np
 OBS = (84, 84, 1)
 
 
-# CUs of every XCD (of 32) that serve inference in the IN-PROCESS run; the train step gets the other 20.  With the GPU
-# saturated from both sides the disjoint sets win (4.61 -> 5.00 M env-steps/s on one box: no inference kernel waits for a
-# train kernel's persistent workgroups to retire); through the transport the actors are latency-bound, the GPU is not
-# saturated, and the shared pool with a high-priority inference stream is faster (4.44 against 4.13 M): that run keeps it.
-CU_SPLIT = 12
+# CUs of every XCD (of 32) that serve inference on a stream of their own (0: one shared pool, inference on a high-priority
+# stream).  Measured on one box, in-process feeder (env-steps/s served):
+#   n = 2 048 / 8 192 envs:   shared 4.61 M   split 12 (96 + 160 CUs) 5.00-5.03 M   split 16: 4.96 M
+#   n = 4 096 / 16 384 envs:  shared 5.48 M   split 12               5.02 M  (the train step on 160 CUs, 2.05 ms, is the bound)
+#   transport, n = 2 048:     shared 4.44 M   split 12               4.13 M  (actors are latency-bound, the GPU is not saturated)
+# Disjoint CU sets stop an inference kernel from waiting for a train kernel's persistent workgroups to retire, but the
+# train step's grids are sized for 256 CUs and lose more than the inference side gains once the batches are large; the
+# default runs share the pool, SEEDRL_CU_SPLIT=12 selects the split.
+CU_SPLIT = 0
 
 
 def _make_server(dev, T, B, n, envs, address, transport='native', A=18, io_threads=None, slots=4, pipeline=None,
