@@ -249,6 +249,18 @@ def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, 
     lrn.minimize(unroll, *extra)
   ops.set_profiler(None)
   kern = prof_all.summary()
+  # what an event pair around ONE dispatch on a drained device reads for a kernel that does (almost) nothing: the
+  # dispatch latency of an idle queue sits inside every serialized region above and not inside rocprofv3's kernel
+  # durations (r6: stack_conv_fwd 139.1 us by events, 130.0 us in the kernel trace of the same box)
+  tiny = torch.zeros(64, device=dev)
+  floor_ms = []
+  for _ in range(20):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); tiny.add_(1.0); e1.record()
+    torch.cuda.synchronize()
+    floor_ms.append(e0.elapsed_time(e1))
+  dispatch_floor_ms = float(np.median(floor_ms))
   nattr = min(attribution_steps, max(warmup, 1))
   for v in kern.values():
     v['total_ms'] /= nattr; v['calls'] /= nattr    # (true division in both places: step_roofline prices group calls)
@@ -383,6 +395,8 @@ def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, 
   # it (what rocprofv3 --kernel-trace --stats shows: profiles/ must agree with THIS one); `frac_free_running` by its
   # duration in back-to-back steps, where it starts behind its producer with operands still in L2 / MALL
   roofline.update(frac_serialized=round(ach / peak, 4), avg_kernel_ms=round(d['avg_ms'], 4),
+                  dispatch_floor_ms=round(dispatch_floor_ms, 4),
+                  avg_kernel_ms_less_dispatch=round(max(d['avg_ms'] - dispatch_floor_ms, 0.0), 4),
                   frac_free_running=round(ach_free / peak, 4), avg_kernel_ms_free_running=round(free['avg_ms'], 4),
                   clock='HIP events on the launch stream; serialized = device drained before the kernel (rocprofv3 view)')
   rec = dict(
