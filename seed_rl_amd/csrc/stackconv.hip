@@ -619,6 +619,197 @@ stackconv_fwd_bf16r_kernel(const Params p) {
 }
 
 // ------------------------------------------------------------------------------------ //
+// bf16x3 forward, EIGHT waves (r6).  The five-wave kernel above cannot balance a CU: a workgroup's waves go to the four
+// SIMDs in a fixed cyclic order, so waves 0 and 4 of every workgroup share one -- with two workgroups per CU one SIMD
+// runs FOUR waves and the others two.  tools/probes/stack_probe.hip says so directly: the MFMA-only build takes 95.5 us
+// with two workgroups per CU and 90.2 us with ONE (= 10 080 MFMAs of 17.9 cycles on the loaded SIMD either way, the matrix
+// pipes of the other three half idle), and the full kernel 135-147 against 139.
+// Here one 512-thread workgroup per CU walks TWO batch columns; wave w (column w >> 2) owns a run of 16-pixel tiles of
+// its column's 400 output pixels -- 7 + 6 + 6 + 6 tiles for column 0, 6 + 6 + 6 + 7 for column 1 --, and waves w and
+// w + 4 share a SIMD: 13 / 12 / 12 / 13 tiles per SIMD.  A run of <= 7 tiles touches <= 7 output rows = a band of 28 input
+// rows (4 704 B in bf16, four ring slots per wave: 150.5 KB of LDS); two waves per SIMD have 256 registers each, so all
+// three planes of W / 255 stay in registers (96) and nothing but pixels is read from LDS.  Operands, MFMA order per
+// accumulator and epilogue are those of the five-wave kernel: bit-identical outputs.
+// ------------------------------------------------------------------------------------ //
+constexpr int kW8Waves = 8, kW8Threads = kW8Waves * 64;
+constexpr int kW8Rows = 28, kW8Band8 = kW8Rows * kIW, kW8Band16 = 2 * kW8Band8;       // 2 352 B of pixels, 4 704 B as bf16
+constexpr int kW8Vec = kW8Band8 / 16;                                               // 147 uint4 per band
+constexpr int kW8Ring = kSlots * kW8Band16;                                         // 18 816 B per wave
+constexpr int kW8Lds = kW8Waves * kW8Ring;                                          // 150 528 B
+
+struct Band3 { uint4 v[3]; };
+
+template <int NT, int EXP, bool BITS, bool RELU>
+__device__ __forceinline__ void w8_run(const Params& p, unsigned char* myring, const Frag8 (&wreg)[kGroups][3], const f32x4_t bias4,
+                                       int col, int p0, int lane) {
+  const int kq = lane >> 4, j = lane & 15;
+  const int co0 = blockIdx.z * 16;
+  const int row0 = 4 * (p0 / kOW);                     // first input row of the band
+  int aoff[NT];                                        // byte offset of (tile m, pixel j, row kq) inside a bf16 band slot
+  unsigned ov[NT];
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+    const int pix = p0 + m * 16 + j;
+    const int oy = pix / kOW, ox = pix - oy * kOW;
+    aoff[m] = ((oy * 4 - row0 + kq) * kIW + ox * 4) * 2;
+    ov[m] = (unsigned)((pix * p.ld_out + co0 + 4 * kq) * 4);
+  }
+  const __amdgpu_buffer_rsrc_t fview = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.frames_ext), 0, (int)((long long)(3 + p.T1) * p.B * p.fsz), 0x00020000);
+  const __amdgpu_buffer_rsrc_t oview = __builtin_amdgcn_make_buffer_rsrc(
+      p.out, 0, (int)((long long)p.T1 * p.B * 400 * p.ld_out * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t bview = __builtin_amdgcn_make_buffer_rsrc(
+      p.relu_bits, 0, BITS ? (int)((long long)p.T1 * p.B * 400 * p.ld_out / 4) : 0, 0x00020000);
+  // the band's 147 16-byte pieces: lanes 0..63 take pieces l, l + 64 and (l < 19) l + 128; a band that reaches past
+  // its frame (the last wave's 28 rows from row 56 / 60 on) reads into the next frame or, at the tensor's end, zeros:
+  // those rows belong to no pixel of the run
+  const unsigned fv[3] = {16u * (unsigned)lane, 16u * (unsigned)(lane + 64), lane + 128 < kW8Vec ? 16u * (unsigned)(lane + 128) : 0x80000000u};
+  auto band_get = [&](int e, int b) -> Band3 {
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((e * p.B + b) * p.fsz + row0 * kIW));
+    Band3 r;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) r.v[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(fview, fv[u], so, 0));
+    return r;
+  };
+  auto band_put = [&](unsigned char* slot, const Band3& r) {
+    uint4* dst = reinterpret_cast<uint4*>(slot);
+    uint4 a, b;
+    cvt16(r.v[0], a, b); dst[2 * lane] = a; dst[2 * lane + 1] = b;
+    cvt16(r.v[1], a, b); dst[2 * (lane + 64)] = a; dst[2 * (lane + 64) + 1] = b;
+    if (lane + 128 < kW8Vec) { cvt16(r.v[2], a, b); dst[2 * (lane + 128)] = a; dst[2 * (lane + 128) + 1] = b; }
+  };
+  const int pairs = (p.B + 1) >> 1;
+  for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+    const int b = 2 * (item % pairs) + col, chunk = item / pairs;
+    if (b >= p.B) continue;                            // odd B: the last pair has one column (wave-uniform)
+    const int t0 = chunk * p.spc;
+    const int t1 = (t0 + p.spc < p.T1) ? t0 + p.spc : p.T1;
+    {
+      Band3 f[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f[e] = band_get(t0 + e, b);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) band_put(myring + ((t0 + e) % kSlots) * kW8Band16, f[e]);
+      wave_lds_fence();
+    }
+    for (int t = t0; t < t1; ++t) {
+      const bool more = t + 1 < t1;
+      const int nv = nvalid_at(p.nvalid, (long long)t * p.B + b);
+      Band3 pf;
+      if (EXP & 2) { pf.v[0] = make_uint4(lane, t, 3, 4); pf.v[1] = pf.v[0]; pf.v[2] = pf.v[0]; }
+      else if (more) pf = band_get(t + 4, b);
+      f32x4_t acc[NT];
+#pragma unroll
+      for (int m = 0; m < NT; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      auto group = [&](int G) {                       // G static after unrolling
+        const unsigned char* base = myring + ((t + 3 - (G >> 1)) % kSlots) * kW8Band16 + (G & 1) * 4 * kIW * 2;
+        Frag8 xf[NT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+          typedef __attribute__((address_space(3))) const volatile unsigned long long lds_cv64_t;
+          lds_cv64_t* src = (lds_cv64_t*)(base + ((EXP & 8) ? aoff[0] : aoff[m]));
+          if ((EXP & 8) && (m > 0 || G > 0)) xf[m].u = make_uint4(t, G, m, lane);
+          else {
+            const unsigned long long x0 = src[0], x1 = src[1];
+            xf[m].u = make_uint4((unsigned)x0, (unsigned)(x0 >> 32), (unsigned)x1, (unsigned)(x1 >> 32));
+          }
+        }
+        if (EXP & 1) {
+#pragma unroll
+          for (int m = 0; m < NT; ++m) asm volatile("" :: "v"(xf[m].u.x), "v"(xf[m].u.y), "v"(xf[m].u.z), "v"(xf[m].u.w));
+          return;
+        }
+#pragma unroll
+        for (int s3 = 2; s3 >= 0; --s3)               // lo, mid, hi: consecutive MFMAs write different accumulators
+#pragma unroll
+          for (int m = 0; m < NT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[G][s3].v, xf[m].v, acc[m], 0, 0, 0);
+      };
+      if (nv == 4) {
+#pragma unroll
+        for (int G = 0; G < kGroups; ++G) group(G);
+      } else {
+#pragma unroll
+        for (int G = 0; G < kGroups; ++G) if (G < 2 * nv) group(G);
+      }
+      if (more) {                                      // the next band goes to LDS before this step's stores are issued (see above)
+        wave_lds_fence();
+        if (EXP & 16) asm volatile("" :: "v"(pf.v[0].x), "v"(pf.v[0].y), "v"(pf.v[1].x), "v"(pf.v[1].y), "v"(pf.v[2].x), "v"(pf.v[2].y));
+        else band_put(myring + ((t + 4) % kSlots) * kW8Band16, pf);
+        wave_lds_fence();
+      }
+      const unsigned oso = __builtin_amdgcn_readfirstlane((unsigned)((t * p.B + b) * 400 * p.ld_out) * 4u);
+      f32x4_t vout[NT];
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        vout[m] = acc[m] + bias4;
+        if (RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vout[m][r] = __builtin_amdgcn_fmed3f(vout[m][r], 0.f, __builtin_inff());
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < NT; ++m) asm volatile("" : "+v"(vout[m]));    // every output finished before the first store (see above)
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        const f32x4_t v = vout[m];
+        if (EXP & 4) asm volatile("" :: "v"(v));
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(su32x4_t, v), oview, ov[m], oso, 0);
+        if (BITS) {
+          const su32x4_t bu = __builtin_bit_cast(su32x4_t, v);
+          const unsigned m01 = ((bu[1] < 1u ? bu[1] : 1u) << 1) | (bu[0] < 1u ? bu[0] : 1u);
+          const unsigned m23 = ((bu[3] < 1u ? bu[3] : 1u) << 1) | (bu[2] < 1u ? bu[2] : 1u);
+          const unsigned char mk = (unsigned char)((m23 << 2) | m01);
+          if (!(EXP & 4)) __builtin_amdgcn_raw_buffer_store_b8(mk, bview, ov[m] >> 4, oso >> 4, 0);
+        }
+      }
+    }
+  }
+}
+
+template <int EXP, bool BITS = false, bool RELU = true>
+__global__ void __launch_bounds__(kW8Threads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+stackconv_fwd_w8_kernel(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* myring = smem + wave * kW8Ring;
+  const int kq = lane >> 4, j = lane & 15;
+  const int co0 = blockIdx.z * 16;
+  // W / 255 -> three bf16 parts in registers: wreg[G][part] = 8 k (kx = 0..7) of row ky = 4 * half + kq (the five-wave kernel's split)
+  Frag8 wreg[kGroups][3];
+#pragma unroll
+  for (int G = 0; G < kGroups; ++G) {
+    const int c = G >> 1, ky = 4 * (G & 1) + kq;
+    uint32_t part[3][4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float w = p.w[((ky * 8 + e) * 4 + c) * p.cout + co0 + j] / 255.0f;
+      const uint32_t hi = __float_as_uint(w) >> 16;
+      const float r1 = w - __uint_as_float(hi << 16);
+      const uint32_t mid = __float_as_uint(r1) >> 16;
+      const uint32_t lo = __float_as_uint(r1 - __uint_as_float(mid << 16)) >> 16;
+      const uint32_t v[3] = {hi, mid, lo};
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        if (e & 1) part[s3][e >> 1] |= v[s3] << 16; else part[s3][e >> 1] = v[s3];
+      }
+    }
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) wreg[G][s3].u = make_uint4(part[s3][0], part[s3][1], part[s3][2], part[s3][3]);
+  }
+  f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+    const float4 bv = *reinterpret_cast<const float4*>(p.bias + co0 + 4 * kq);
+    bias4 = f32x4_t{bv.x, bv.y, bv.z, bv.w};
+  }
+  // runs of tiles: column 0 = 7 + 6 + 6 + 6 from pixel 0 / 112 / 208 / 304, column 1 = 6 + 6 + 6 + 7 from 0 / 96 / 192 / 288
+  const int col = wave >> 2, q = wave & 3;
+  const int p0 = 96 * q + ((col == 0 && q > 0) ? 16 : 0);
+  if (wave == 0 || wave == 7) w8_run<7, EXP, BITS, RELU>(p, myring, wreg, bias4, col, p0, lane);
+  else w8_run<6, EXP, BITS, RELU>(p, myring, wreg, bias4, col, p0, lane);
+}
+
+// ------------------------------------------------------------------------------------ //
 // The same forward for CENTRAL INFERENCE (r6; servestep.hip): one step of n independent environments.  Row b's stack is
 // its request frame obs[b] plus the three frames the unroll store already holds for that env (store_obs rows
 // hist_rows[4b + c], c = 1..3; see servestep.hip), nvalid[b] of them inside the episode -- the bit-packed per-env
@@ -1063,6 +1254,11 @@ bool bf16x3_enabled() {
   return bf16x3 != 0;
 }
 
+bool w8_enabled() {                                    // SEEDHIP_STACK_W8=0: the five-wave forward (A/B)
+  static const int w8 = getenv("SEEDHIP_STACK_W8") ? atoi(getenv("SEEDHIP_STACK_W8")) : 1;
+  return w8 != 0;
+}
+
 int launch_fwd(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, const uint8_t* nvalid, const float* w,
                const float* bias, float* out, int out_relu, hipStream_t s, unsigned char* relu_bits = nullptr) {
   Params p = make_params(g, frames_ext, nvalid);
@@ -1082,6 +1278,20 @@ int launch_fwd(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, cons
     constexpr int buf_on = 1;
     const long long lim = (1LL << 31) - (1 << 20);
     p.buf32 = buf_on && (long long)(3 + p.T1) * p.B * p.fsz < lim && (long long)p.T1 * p.B * 400 * p.ld_out * 4 < lim;
+    if (p.buf32 && w8_enabled()) {                     // eight waves, two columns per workgroup, one workgroup per CU
+      int grid8;
+      decompose(p.T1, (p.B + 1) / 2, max_grid_for(1), &p.spc, &p.items, &grid8);
+#define SEEDHIP_SCF8(BITS_, RELU_)                                                                                 \
+      {                                                                                                           \
+        (void)hipFuncSetAttribute((const void*)stackconv_fwd_w8_kernel<0, BITS_, RELU_>, hipFuncAttributeMaxDynamicSharedMemorySize, kW8Lds); \
+        hipLaunchKernelGGL((stackconv_fwd_w8_kernel<0, BITS_, RELU_>), dim3(grid8, 1, g->cout / 16), dim3(kW8Threads), kW8Lds, s, p); \
+        return check_launch("stackconv_fwd_w8_kernel");                                                           \
+      }
+      if (relu_bits) SEEDHIP_SCF8(true, true)
+      if (out_relu) SEEDHIP_SCF8(false, true)
+      SEEDHIP_SCF8(false, false)
+#undef SEEDHIP_SCF8
+    }
     if (relu_bits) { if (p.buf32) SEEDHIP_SCF(true, true, true) else SEEDHIP_SCF(true, true, false) }
     if (p.buf32) { if (out_relu) SEEDHIP_SCF(false, true, true) else SEEDHIP_SCF(false, false, true) }
     if (out_relu) SEEDHIP_SCF(false, true, false)

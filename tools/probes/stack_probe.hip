@@ -23,6 +23,23 @@ static float run(Params p, int grid, size_t lds, int reps) {
   return ms / reps * 1e3f;
 }
 
+template <int EXP>
+static float run8(Params p, int grid, int reps) {
+  (void)hipFuncSetAttribute((const void*)stackconv_fwd_w8_kernel<EXP>, hipFuncAttributeMaxDynamicSharedMemorySize, kW8Lds);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(stackconv_fwd_w8_kernel<EXP>, dim3(grid, 1, 1), dim3(kW8Threads), kW8Lds, 0, p);
+  (void)hipEventRecord(e0, 0);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(stackconv_fwd_w8_kernel<EXP>, dim3(grid, 1, 1), dim3(kW8Threads), kW8Lds, 0, p);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) printf("error: %s\n", hipGetErrorString(e));
+  return ms / reps * 1e3f;
+}
+
 int main(int argc, char** argv) {
   const int T1 = 21, B = argc > 1 ? atoi(argv[1]) : 512;
   const int wgs_per_cu = argc > 2 ? atoi(argv[2]) : 2;
@@ -51,5 +68,30 @@ int main(int argc, char** argv) {
   R(0, "full") R(1, "no MFMA") R(2, "no global band prefetch") R(4, "no stores") R(8, "no LDS pixel reads") R(16, "no band convert + LDS store")
   R(2 | 4, "no global traffic") R(1 | 8, "no MFMA, no LDS pixel reads") R(2 | 4 | 16, "LDS reads + MFMA only") R(2 | 4 | 8 | 16, "MFMA only (+ w lo reads)")
   R(1 | 8 | 16, "memory only") R(1 | 2 | 4 | 16, "LDS pixel reads only")
+  {
+    Params q = p;
+    int grid8;
+    decompose(q.T1, (q.B + 1) / 2, max_grid_for(1), &q.spc, &q.items, &grid8);
+    printf("eight waves, two columns per workgroup: grid=%d spc=%d items=%d lds=%d\n", grid8, q.spc, q.items, kW8Lds);
+    {   // the eight-wave kernel against the five-wave kernel: bit-identical outputs
+      float* out2; (void)hipMalloc(&out2, no * 4);
+      (void)hipMemset(out, 0, no * 4); (void)hipMemset(out2, 0xff, no * 4);
+      (void)hipFuncSetAttribute((const void*)stackconv_fwd_bf16r_kernel<0, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      Params p5 = p; p5.buf32 = 1;
+      hipLaunchKernelGGL((stackconv_fwd_bf16r_kernel<0, false, true, true>), dim3(grid, 1, 1), dim3(kThreads), lds, 0, p5);
+      Params q2 = q; q2.out = out2;
+      (void)hipFuncSetAttribute((const void*)stackconv_fwd_w8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kW8Lds);
+      hipLaunchKernelGGL(stackconv_fwd_w8_kernel<0>, dim3(grid8, 1, 1), dim3(kW8Threads), kW8Lds, 0, q2);
+      std::vector<float> a(no), c(no);
+      (void)hipMemcpy(a.data(), out, no * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(c.data(), out2, no * 4, hipMemcpyDeviceToHost);
+      size_t bad = 0, first = 0;
+      for (size_t i = 0; i < no; ++i) if (memcmp(&a[i], &c[i], 4)) { if (!bad) first = i; ++bad; }
+      printf("  w8 vs five-wave outputs: %zu of %zu differ (first at %zu)\n", bad, no, first);
+    }
+#define R8(E, what) { float us = run8<E>(q, grid8, 20); printf("  %-46s %7.1f us  %6.1f algorithmic TF/s\n", what, us, flops / us / 1e6); }
+    R8(0, "full") R8(1, "no MFMA") R8(2, "no global band prefetch") R8(4, "no stores") R8(8, "no LDS pixel reads") R8(16, "no band convert + LDS store")
+    R8(2 | 4, "no global traffic") R8(2 | 4 | 16, "LDS reads + MFMA only") R8(2 | 4 | 8 | 16, "MFMA only")
+    R8(1 | 8 | 16, "memory only") R8(1 | 2 | 4 | 16, "LDS pixel reads only")
+  }
   return 0;
 }
