@@ -635,13 +635,14 @@ constexpr int kW8Waves = 8, kW8Threads = kW8Waves * 64;
 constexpr int kW8Rows = 28, kW8Band8 = kW8Rows * kIW, kW8Band16 = 2 * kW8Band8;       // 2 352 B of pixels, 4 704 B as bf16
 constexpr int kW8Vec = kW8Band8 / 16;                                               // 147 uint4 per band
 constexpr int kW8Ring = kSlots * kW8Band16;                                         // 18 816 B per wave
-constexpr int kW8Lds = kW8Waves * kW8Ring;                                          // 150 528 B
+constexpr int kW8Rings = kW8Waves * kW8Ring;                                        // 150 528 B
+constexpr int kW8Lds = kW8Rings + kW8Waves * 512;                                   // + the mask scratch of each wave
 
 struct Band3 { uint4 v[3]; };
 
-template <int NT, int EXP, bool BITS, bool RELU>
-__device__ __forceinline__ void w8_run(const Params& p, unsigned char* myring, const Frag8 (&wreg)[kGroups][3], const f32x4_t bias4,
-                                       int col, int p0, int lane) {
+template <int NT, int EXP, bool BITS, bool RELU, int MODE>
+__device__ __forceinline__ void w8_run(const Params& p, unsigned char* myring, unsigned char* scratch, const Frag8 (&wreg)[kGroups][3],
+                                       const f32x4_t bias4, int col, int p0, int lane) {
   const int kq = lane >> 4, j = lane & 15;
   const int co0 = blockIdx.z * 16;
   const int row0 = 4 * (p0 / kOW);                     // first input row of the band
@@ -678,6 +679,48 @@ __device__ __forceinline__ void w8_run(const Params& p, unsigned char* myring, c
     cvt16(r.v[1], a, b); dst[2 * (lane + 64)] = a; dst[2 * (lane + 64) + 1] = b;
     if (lane + 128 < kW8Vec) { cvt16(r.v[2], a, b); dst[2 * (lane + 128)] = a; dst[2 * (lane + 128) + 1] = b; }
   };
+  // MODE 2: the band requests are asm statements hipcc's s_waitcnt bookkeeping knows nothing about, and the wait for them
+  // counts the stores issued behind them (vector memory operations retire in order: hipcc itself waits vmcnt(1) for a
+  // load that one store follows); the registers are read behind the wait only (take_band)
+  typedef unsigned sgpr128_t __attribute__((ext_vector_type(4)));
+  const uint64_t fbase = reinterpret_cast<uint64_t>(p.frames_ext);
+  const sgpr128_t fwords = {(unsigned)__builtin_amdgcn_readfirstlane((unsigned)fbase),
+                            (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(fbase >> 32)) & 0xFFFFu,
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)((long long)(3 + p.T1) * p.B * p.fsz)), 0x00020000u};
+  auto band_req = [&](int e, int b, f32x4_t (&r)[3]) {
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((e * p.B + b) * p.fsz + row0 * kIW));
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %3, %6, %7 offen\n\tbuffer_load_dwordx4 %1, %4, %6, %7 offen\n\t"
+                 "buffer_load_dwordx4 %2, %5, %6, %7 offen"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]) : "v"(fv[0]), "v"(fv[1]), "v"(fv[2]), "s"(fwords), "s"(so));
+  };
+  constexpr int kStoresPerStep = (EXP & 4) ? 0 : (BITS ? NT + 2 : NT);
+  // BITS: byte offset of pixel lane + 64 h's mask dword inside a step's slice of relu_bits (pixels past the run: out of range)
+  const unsigned bvo[2] = {(unsigned)(((p0 + lane) * p.ld_out + co0) >> 2),
+                           lane + 64 < 16 * NT ? (unsigned)(((p0 + lane + 64) * p.ld_out + co0) >> 2) : 0x80000000u};
+  auto take_band = [&](const f32x4_t (&r)[3], bool first) -> Band3 {   // first: nothing was issued behind the request
+    if (first) asm volatile("s_waitcnt vmcnt(0)");
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t o[6];
+    asm volatile("s_waitcnt vmcnt(%12)\n\tv_mov_b64 %0, %6\n\tv_mov_b64 %1, %7\n\tv_mov_b64 %2, %8\n\tv_mov_b64 %3, %9\n\t"
+                 "v_mov_b64 %4, %10\n\tv_mov_b64 %5, %11"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])
+                 : "v"(__builtin_shufflevector(r[0], r[0], 0, 1)), "v"(__builtin_shufflevector(r[0], r[0], 2, 3)),
+                   "v"(__builtin_shufflevector(r[1], r[1], 0, 1)), "v"(__builtin_shufflevector(r[1], r[1], 2, 3)),
+                   "v"(__builtin_shufflevector(r[2], r[2], 0, 1)), "v"(__builtin_shufflevector(r[2], r[2], 2, 3)), "n"(kStoresPerStep));
+    Band3 b3;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      b3.v[u] = make_uint4(__float_as_uint(o[2 * u][0]), __float_as_uint(o[2 * u][1]), __float_as_uint(o[2 * u + 1][0]), __float_as_uint(o[2 * u + 1][1]));
+    return b3;
+  };
+  // EXP & 32 (probe): s_memtime stamps of workgroup 0's waves, five per step, into partial_w as [wave][step][8] words
+  unsigned* stamps = reinterpret_cast<unsigned*>(p.partial_w) + (size_t)(threadIdx.x >> 6) * 64 * 8;
+  auto stamp = [&](int t, int k) {
+    if ((EXP & 32) && blockIdx.x == 0 && t < 64) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      if (lane == 0) stamps[t * 8 + k] = (unsigned)now;
+    }
+  };
   const int pairs = (p.B + 1) >> 1;
   for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
     const int b = 2 * (item % pairs) + col, chunk = item / pairs;
@@ -692,81 +735,142 @@ __device__ __forceinline__ void w8_run(const Params& p, unsigned char* myring, c
       for (int e = 0; e < 4; ++e) band_put(myring + ((t0 + e) % kSlots) * kW8Band16, f[e]);
       wave_lds_fence();
     }
+    Band3 pf;
+    f32x4_t pfr[3];
+    if (MODE == 2) {                                   // the band of step t0 + 1 is on its way before the first step
+      if (EXP & 2) { pf.v[0] = make_uint4(lane, t0, 3, 4); pf.v[1] = pf.v[0]; pf.v[2] = pf.v[0]; }
+      else if (t0 + 1 < t1) band_req(t0 + 4, b, pfr);
+    }
     for (int t = t0; t < t1; ++t) {
       const bool more = t + 1 < t1;
       const int nv = nvalid_at(p.nvalid, (long long)t * p.B + b);
-      Band3 pf;
-      if (EXP & 2) { pf.v[0] = make_uint4(lane, t, 3, 4); pf.v[1] = pf.v[0]; pf.v[2] = pf.v[0]; }
-      else if (more) pf = band_get(t + 4, b);
+      if (MODE != 2) {
+        if (EXP & 2) { pf.v[0] = make_uint4(lane, t, 3, 4); pf.v[1] = pf.v[0]; pf.v[2] = pf.v[0]; }
+        else if (more) pf = band_get(t + 4, b);
+      }
       f32x4_t acc[NT];
 #pragma unroll
       for (int m = 0; m < NT; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      auto group = [&](int G) {                       // G static after unrolling
-        const unsigned char* base = myring + ((t + 3 - (G >> 1)) % kSlots) * kW8Band16 + (G & 1) * 4 * kIW * 2;
-        Frag8 xf[NT];
+      // the MFMAs of tiles [LO, HI) over the valid k-groups; the outputs of tiles [LO, HI): bias, activation, stores
+      auto mma = [&](auto lo_c, auto hi_c) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        auto group = [&](int G) {                     // G static after unrolling
+          const unsigned char* base = myring + ((t + 3 - (G >> 1)) % kSlots) * kW8Band16 + (G & 1) * 4 * kIW * 2;
+          Frag8 xf[NT];
 #pragma unroll
-        for (int m = 0; m < NT; ++m) {
-          typedef __attribute__((address_space(3))) const volatile unsigned long long lds_cv64_t;
-          lds_cv64_t* src = (lds_cv64_t*)(base + ((EXP & 8) ? aoff[0] : aoff[m]));
-          if ((EXP & 8) && (m > 0 || G > 0)) xf[m].u = make_uint4(t, G, m, lane);
-          else {
-            const unsigned long long x0 = src[0], x1 = src[1];
-            xf[m].u = make_uint4((unsigned)x0, (unsigned)(x0 >> 32), (unsigned)x1, (unsigned)(x1 >> 32));
+          for (int m = LO; m < HI; ++m) {
+            typedef __attribute__((address_space(3))) const volatile unsigned long long lds_cv64_t;
+            lds_cv64_t* src = (lds_cv64_t*)(base + ((EXP & 8) ? aoff[0] : aoff[m]));
+            if ((EXP & 8) && (m > 0 || G > 0)) xf[m].u = make_uint4(t, G, m, lane);
+            else {
+              const unsigned long long x0 = src[0], x1 = src[1];
+              xf[m].u = make_uint4((unsigned)x0, (unsigned)(x0 >> 32), (unsigned)x1, (unsigned)(x1 >> 32));
+            }
+          }
+          if (EXP & 1) {
+#pragma unroll
+            for (int m = LO; m < HI; ++m) asm volatile("" :: "v"(xf[m].u.x), "v"(xf[m].u.y), "v"(xf[m].u.z), "v"(xf[m].u.w));
+            return;
+          }
+#pragma unroll
+          for (int s3 = 2; s3 >= 0; --s3)             // lo, mid, hi: consecutive MFMAs write different accumulators
+#pragma unroll
+            for (int m = LO; m < HI; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[G][s3].v, xf[m].v, acc[m], 0, 0, 0);
+        };
+        if (nv == 4) {
+#pragma unroll
+          for (int G = 0; G < kGroups; ++G) group(G);
+        } else {
+#pragma unroll
+          for (int G = 0; G < kGroups; ++G) if (G < 2 * nv) group(G);
+        }
+      };
+      const unsigned oso = __builtin_amdgcn_readfirstlane((unsigned)((t * p.B + b) * 400 * p.ld_out) * 4u);
+      auto emit = [&](auto lo_c, auto hi_c) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        f32x4_t vout[NT];
+#pragma unroll
+        for (int m = LO; m < HI; ++m) {
+          vout[m] = acc[m] + bias4;
+          if (RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vout[m][r] = __builtin_amdgcn_fmed3f(vout[m][r], 0.f, __builtin_inff());
           }
         }
-        if (EXP & 1) {
 #pragma unroll
-          for (int m = 0; m < NT; ++m) asm volatile("" :: "v"(xf[m].u.x), "v"(xf[m].u.y), "v"(xf[m].u.z), "v"(xf[m].u.w));
-          return;
+        for (int m = LO; m < HI; ++m) asm volatile("" : "+v"(vout[m]));  // every output finished before the first store (see above)
+#pragma unroll
+        for (int m = LO; m < HI; ++m) {
+          const f32x4_t v = vout[m];
+          if (EXP & 4) asm volatile("" :: "v"(v));
+          else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(su32x4_t, v), oview, ov[m], oso, 0);
+          if (BITS) {
+            // the ReLU mask: the lane's byte (its four channels of tile m's pixel j) goes to the wave's LDS scratch as
+            // [pixel][kq]; one dword per PIXEL is stored from there -- two store instructions per run where every tile
+            // had its own byte store (a vector memory instruction costs its issue slot in the CU's queue whatever it carries:
+            // 7 byte stores per wave and step were 10 us of the kernel)
+            const su32x4_t bu = __builtin_bit_cast(su32x4_t, v);
+            const unsigned m01 = ((bu[1] < 1u ? bu[1] : 1u) << 1) | (bu[0] < 1u ? bu[0] : 1u);
+            const unsigned m23 = ((bu[3] < 1u ? bu[3] : 1u) << 1) | (bu[2] < 1u ? bu[2] : 1u);
+            scratch[m * 64 + j * 4 + kq] = (unsigned char)((m23 << 2) | m01);
+          }
         }
+        if (BITS && HI == NT) {
+          wave_lds_fence();
 #pragma unroll
-        for (int s3 = 2; s3 >= 0; --s3)               // lo, mid, hi: consecutive MFMAs write different accumulators
-#pragma unroll
-          for (int m = 0; m < NT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[G][s3].v, xf[m].v, acc[m], 0, 0, 0);
+          for (int h = 0; h < 2; ++h) {
+            const unsigned w = reinterpret_cast<const unsigned*>(scratch)[(lane + 64 * h < 16 * NT) ? lane + 64 * h : 0];
+            if (!(EXP & 4)) __builtin_amdgcn_raw_buffer_store_b32(w, bview, bvo[h], oso >> 4, 0);
+          }
+          wave_lds_fence();
+        }
       };
-      if (nv == 4) {
-#pragma unroll
-        for (int G = 0; G < kGroups; ++G) group(G);
-      } else {
-#pragma unroll
-        for (int G = 0; G < kGroups; ++G) if (G < 2 * nv) group(G);
-      }
-      if (more) {                                      // the next band goes to LDS before this step's stores are issued (see above)
-        wave_lds_fence();
-        if (EXP & 16) asm volatile("" :: "v"(pf.v[0].x), "v"(pf.v[0].y), "v"(pf.v[1].x), "v"(pf.v[1].y), "v"(pf.v[2].x), "v"(pf.v[2].y));
-        else band_put(myring + ((t + 4) % kSlots) * kW8Band16, pf);
-        wave_lds_fence();
-      }
-      const unsigned oso = __builtin_amdgcn_readfirstlane((unsigned)((t * p.B + b) * 400 * p.ld_out) * 4u);
-      f32x4_t vout[NT];
-#pragma unroll
-      for (int m = 0; m < NT; ++m) {
-        vout[m] = acc[m] + bias4;
-        if (RELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) vout[m][r] = __builtin_amdgcn_fmed3f(vout[m][r], 0.f, __builtin_inff());
+      auto stage = [&]() {                             // the next band goes to LDS before the stores behind it are issued (see above)
+        if (more) {
+          if (MODE == 2 && !(EXP & 2)) pf = take_band(pfr, t == t0);
+          if (MODE == 0 && (EXP & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          stamp(t, 2);
+          wave_lds_fence();
+          if (EXP & 16) asm volatile("" :: "v"(pf.v[0].x), "v"(pf.v[0].y), "v"(pf.v[1].x), "v"(pf.v[1].y), "v"(pf.v[2].x), "v"(pf.v[2].y));
+          else band_put(myring + ((t + 4) % kSlots) * kW8Band16, pf);
+          wave_lds_fence();
         }
-      }
-#pragma unroll
-      for (int m = 0; m < NT; ++m) asm volatile("" : "+v"(vout[m]));    // every output finished before the first store (see above)
-#pragma unroll
-      for (int m = 0; m < NT; ++m) {
-        const f32x4_t v = vout[m];
-        if (EXP & 4) asm volatile("" :: "v"(v));
-        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(su32x4_t, v), oview, ov[m], oso, 0);
-        if (BITS) {
-          const su32x4_t bu = __builtin_bit_cast(su32x4_t, v);
-          const unsigned m01 = ((bu[1] < 1u ? bu[1] : 1u) << 1) | (bu[0] < 1u ? bu[0] : 1u);
-          const unsigned m23 = ((bu[3] < 1u ? bu[3] : 1u) << 1) | (bu[2] < 1u ? bu[2] : 1u);
-          const unsigned char mk = (unsigned char)((m23 << 2) | m01);
-          if (!(EXP & 4)) __builtin_amdgcn_raw_buffer_store_b8(mk, bview, ov[m] >> 4, oso >> 4, 0);
-        }
+      };
+      typedef std::integral_constant<int, 0> c0_t;
+      typedef std::integral_constant<int, NT> cn_t;
+      if (MODE == 0) {
+        stamp(t, 0);
+        mma(c0_t(), cn_t());
+        stamp(t, 1);
+        stage();
+        stamp(t, 3);
+        emit(c0_t(), cn_t());
+        stamp(t, 4);
+      } else if (MODE == 2) {
+        // the request for step t + 2's band is issued IN FRONT of this step's stores: a CU's vector memory pipeline is a
+        // queue, and a load behind the 57 KB the eight waves store per step waits until they have drained; the wait for
+        // it, one step later, is vmcnt(number of younger stores), not vmcnt(0)
+        stamp(t, 0);
+        mma(c0_t(), cn_t());
+        stamp(t, 1);
+        stage();
+        stamp(t, 3);
+        if (!(EXP & 2) && t + 2 < t1) band_req(t + 5, b, pfr);
+        emit(c0_t(), cn_t());
+        stamp(t, 4);
+      } else {                                         // two chunks of tiles: the first chunk's stores drain under the second chunk's MFMAs
+        typedef std::integral_constant<int, NT - 3> ca_t;
+        mma(c0_t(), ca_t());
+        emit(c0_t(), ca_t());
+        mma(ca_t(), cn_t());
+        stage();
+        emit(ca_t(), cn_t());
       }
     }
   }
 }
 
-template <int EXP, bool BITS = false, bool RELU = true>
+template <int EXP, bool BITS = false, bool RELU = true, int MODE = 0>
 __global__ void __launch_bounds__(kW8Threads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 stackconv_fwd_w8_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -805,8 +909,8 @@ stackconv_fwd_w8_kernel(const Params p) {
   // runs of tiles: column 0 = 7 + 6 + 6 + 6 from pixel 0 / 112 / 208 / 304, column 1 = 6 + 6 + 6 + 7 from 0 / 96 / 192 / 288
   const int col = wave >> 2, q = wave & 3;
   const int p0 = 96 * q + ((col == 0 && q > 0) ? 16 : 0);
-  if (wave == 0 || wave == 7) w8_run<7, EXP, BITS, RELU>(p, myring, wreg, bias4, col, p0, lane);
-  else w8_run<6, EXP, BITS, RELU>(p, myring, wreg, bias4, col, p0, lane);
+  if (wave == 0 || wave == 7) w8_run<7, EXP, BITS, RELU, MODE>(p, myring, smem + kW8Rings + wave * 512, wreg, bias4, col, p0, lane);
+  else w8_run<6, EXP, BITS, RELU, MODE>(p, myring, smem + kW8Rings + wave * 512, wreg, bias4, col, p0, lane);
 }
 
 // ------------------------------------------------------------------------------------ //
@@ -1283,8 +1387,8 @@ int launch_fwd(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, cons
       decompose(p.T1, (p.B + 1) / 2, max_grid_for(1), &p.spc, &p.items, &grid8);
 #define SEEDHIP_SCF8(BITS_, RELU_)                                                                                 \
       {                                                                                                           \
-        (void)hipFuncSetAttribute((const void*)stackconv_fwd_w8_kernel<0, BITS_, RELU_>, hipFuncAttributeMaxDynamicSharedMemorySize, kW8Lds); \
-        hipLaunchKernelGGL((stackconv_fwd_w8_kernel<0, BITS_, RELU_>), dim3(grid8, 1, g->cout / 16), dim3(kW8Threads), kW8Lds, s, p); \
+        (void)hipFuncSetAttribute((const void*)stackconv_fwd_w8_kernel<0, BITS_, RELU_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kW8Lds); \
+        hipLaunchKernelGGL((stackconv_fwd_w8_kernel<0, BITS_, RELU_, 2>), dim3(grid8, 1, g->cout / 16), dim3(kW8Threads), kW8Lds, s, p); \
         return check_launch("stackconv_fwd_w8_kernel");                                                           \
       }
       if (relu_bits) SEEDHIP_SCF8(true, true)
