@@ -737,14 +737,14 @@ __device__ __forceinline__ void w8_run(const Params& p, unsigned char* myring, u
     }
     Band3 pf;
     f32x4_t pfr[3];
-    if (MODE == 2) {                                   // the band of step t0 + 1 is on its way before the first step
+    if (MODE >= 2) {                                   // the band of step t0 + 1 is on its way before the first step
       if (EXP & 2) { pf.v[0] = make_uint4(lane, t0, 3, 4); pf.v[1] = pf.v[0]; pf.v[2] = pf.v[0]; }
       else if (t0 + 1 < t1) band_req(t0 + 4, b, pfr);
     }
     for (int t = t0; t < t1; ++t) {
       const bool more = t + 1 < t1;
       const int nv = nvalid_at(p.nvalid, (long long)t * p.B + b);
-      if (MODE != 2) {
+      if (MODE < 2) {
         if (EXP & 2) { pf.v[0] = make_uint4(lane, t, 3, 4); pf.v[1] = pf.v[0]; pf.v[2] = pf.v[0]; }
         else if (more) pf = band_get(t + 4, b);
       }
@@ -858,13 +858,6 @@ __device__ __forceinline__ void w8_run(const Params& p, unsigned char* myring, u
         if (!(EXP & 2) && t + 2 < t1) band_req(t + 5, b, pfr);
         emit(c0_t(), cn_t());
         stamp(t, 4);
-      } else {                                         // two chunks of tiles: the first chunk's stores drain under the second chunk's MFMAs
-        typedef std::integral_constant<int, NT - 3> ca_t;
-        mma(c0_t(), ca_t());
-        emit(c0_t(), ca_t());
-        mma(ca_t(), cn_t());
-        stage();
-        emit(ca_t(), cn_t());
       }
     }
   }

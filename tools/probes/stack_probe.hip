@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
 #define R8(E, what) { float us = run8<E>(q, grid8, 20); printf("  %-46s %7.1f us  %6.1f algorithmic TF/s\n", what, us, flops / us / 1e6); }
     unsigned char* bits; (void)hipMalloc(&bits, no / 4); q.relu_bits = bits;
 #define R8X(E, B_, M_, what) { float us = run8<E, B_, M_>(q, grid8, 20); printf("  %-46s %7.1f us  %6.1f algorithmic TF/s\n", what, us, flops / us / 1e6); }
-    R8X(0, true, 0, "full + byte mask") R8X(0, false, 1, "full, two chunks") R8X(0, true, 1, "full + byte mask, two chunks")
+    R8X(0, true, 0, "full + byte mask")
     {
       unsigned* st; (void)hipMalloc(&st, 8 * 64 * 8 * 4);
       Params qs = q; qs.partial_w = (float*)st;
@@ -130,8 +130,6 @@ int main(int argc, char** argv) {
       (void)hipMemset(st, 0, 8 * 64 * 8 * 4); run8<32, false, 0>(qs, grid8, 1); show("mode 0");
       (void)hipMemset(st, 0, 8 * 64 * 8 * 4); run8<32, false, 2>(qs, grid8, 1); show("mode 2");
       (void)hipMemset(st, 0, 8 * 64 * 8 * 4); run8<32 | 4, false, 2>(qs, grid8, 1); show("mode 2, no stores");
-      (void)hipMemset(st, 0, 8 * 64 * 8 * 4); run8<32 | 4, false, 0>(qs, grid8, 1); show("mode 0, no stores");
-      (void)hipMemset(st, 0, 8 * 64 * 8 * 4); run8<32 | 2, false, 0>(qs, grid8, 1); show("mode 0, no prefetch");
     }
     {
       printf("  A/B, five interleaved rounds of 20 launches each, median us:\n");
@@ -139,14 +137,13 @@ int main(int argc, char** argv) {
       for (int round = 0; round < 5; ++round) {
         r[0].push_back(run8<0, false, 0>(q, grid8, 20)); r[1].push_back(run8<0, false, 2>(q, grid8, 20));
         r[2].push_back(run8<0, true, 0>(q, grid8, 20)); r[3].push_back(run8<0, true, 2>(q, grid8, 20));
-        r[4].push_back(run<0>(p, grid, lds, 20));
+        r[4].push_back(run<0>(p, grid, lds, 20)); r[5].push_back(run<0>(p, grid, lds, 20));
       }
-      const char* names[5] = {"w8 mode 0", "w8 mode 2 (loads before stores)", "w8 mode 0 + mask", "w8 mode 2 + mask", "five waves"};
-      for (int k = 0; k < 5; ++k) { std::sort(r[k].begin(), r[k].end()); printf("    %-34s %7.1f  (min %.1f max %.1f)\n", names[k], r[k][2], r[k][0], r[k][4]); }
+      const char* names[6] = {"w8 mode 0", "w8 mode 2 (loads before stores)", "w8 mode 0 + mask", "w8 mode 2 + mask", "five waves", "five waves (again)"};
+      for (int k = 0; k < 6; ++k) { std::sort(r[k].begin(), r[k].end()); printf("    %-34s %7.1f  (min %.1f max %.1f)\n", names[k], r[k][2], r[k][0], r[k][4]); }
     }
     R8X(0, false, 2, "full, loads before stores") R8X(0, true, 2, "full + byte mask, loads before stores")
     R8X(4, false, 2, "no stores, loads before stores") R8X(2, false, 2, "no prefetch, loads before stores")
-    R8X(4, false, 1, "no stores, two chunks") R8X(2, false, 1, "no prefetch, two chunks") R8X(2 | 4, false, 1, "no global traffic, two chunks")
     R8(0, "full") R8(1, "no MFMA") R8(2, "no global band prefetch") R8(4, "no stores") R8(8, "no LDS pixel reads") R8(16, "no band convert + LDS store")
     R8(2 | 4, "no global traffic") R8(2 | 4 | 16, "LDS reads + MFMA only") R8(2 | 4 | 8 | 16, "MFMA only")
     R8(1 | 8 | 16, "memory only") R8(1 | 2 | 4 | 16, "LDS pixel reads only")
