@@ -1131,8 +1131,8 @@ __device__ __forceinline__ bf16x8_t tr_operand(const unsigned char* base, unsign
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int LD>                                        // row stride of dY (floats) when it is 16 or 32, else 0 = run time
-__global__ void __launch_bounds__(512, 2)
+template <int LD, int EXP = 0>                           // row stride of dY (floats) when it is 16 or 32, else 0 = run time
+__global__ void __launch_bounds__(512, 2)                // EXP (tools/probes/stack_wgrad_probe.hip only): 32 = s_memtime stamps
 stackconv_wgrad_tr_kernel(const Params p) {
   const int ld_out = LD ? LD : p.ld_out;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1169,22 +1169,60 @@ stackconv_wgrad_tr_kernel(const Params p) {
 
   // dY of one step: 1600 16-byte items (pixel = item >> 2, channel quad = item & 3), four per thread (the last partly)
   const char* dy_base = reinterpret_cast<const char*>(p.dy);
-  f32x4_t ly[4];
-  auto issue_dy = [&](int t, int b) {
-    const unsigned dy_t = (unsigned)(((long long)t * p.B + b) * P * ld_out + co0) * 4u;
+  // Requests are asm statements (hipcc's s_waitcnt bookkeeping drained the queue at every step head and waited for a
+  // step's own requests inside the step: s_memtime stamps, tools/probes/stack_wgrad_probe.hip); the waits count the
+  // requests issued behind the one that is needed (vector memory operations retire in order) and the registers are read
+  // behind the wait only (take4).  dY and the frames are buffers: a uniform 32-bit step offset + a loop-invariant lane
+  // offset; a request that is not needed (past the chunk) goes out of range and costs no traffic.
+  typedef unsigned sgpr128_t __attribute__((ext_vector_type(4)));
+  auto words_of = [](const void* ptr, unsigned long long bytes) -> sgpr128_t {
+    const uint64_t ab = reinterpret_cast<uint64_t>(ptr);
+    return sgpr128_t{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ab), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ab >> 32)) & 0xFFFFu,
+                     (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes)), 0x00020000u};
+  };
+  const sgpr128_t ywords = words_of(p.dy, (unsigned long long)p.T1 * p.B * P * ld_out * 4ull);
+  const sgpr128_t fwords = words_of(p.frames_ext, (unsigned long long)(3 + p.T1) * p.B * p.fsz);
+  constexpr unsigned kOob = 0x80000000u;
+  unsigned yoff[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int it = tid + 512 * j;
-      if (j < 3 || it < 4 * P)
-        ly[j] = *reinterpret_cast<const f32x4_t*>(dy_base + (dy_t + (unsigned)(((it >> 2) * ld_out + 4 * (it & 3)) * 4)));
-    }
+  for (int j = 0; j < 4; ++j) {
+    const int it = tid + 512 * j;
+    yoff[j] = (j < 3 || it < 4 * P) ? (unsigned)(((it >> 2) * ld_out + 4 * (it & 3) + co0) * 4) : kOob;
+  }
+  const unsigned foff = tid < kVec ? 16u * (unsigned)tid : kOob;
+  f32x4_t ly[4], lf;
+  auto req_dy = [&](int t, int b, bool valid) {
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(((long long)t * p.B + b) * P * ld_out) * 4u);
+    const unsigned kill = valid ? 0u : kOob;
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %4, %8, %9 offen\n\tbuffer_load_dwordx4 %1, %5, %8, %9 offen\n\t"
+                 "buffer_load_dwordx4 %2, %6, %8, %9 offen\n\tbuffer_load_dwordx4 %3, %7, %8, %9 offen"
+                 : "=&v"(ly[0]), "=&v"(ly[1]), "=&v"(ly[2]), "=&v"(ly[3])
+                 : "v"(yoff[0] | kill), "v"(yoff[1] | kill), "v"(yoff[2] | kill), "v"(yoff[3] | kill), "s"(ywords), "s"(so));
+  };
+  auto req_frame = [&](int e, int b, bool valid) {
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(((long long)e * p.B + b) * p.fsz));
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(lf) : "v"(foff | (valid ? 0u : kOob)), "s"(fwords), "s"(so));
+  };
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  auto take4 = [&](const f32x4_t& r, auto n_c) -> f32x4_t {   // wait until at most N younger requests are outstanding, then copy
+    constexpr int N = decltype(n_c)::value;
+    f32x2_t lo, hi;
+    asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(lo), "=&v"(hi)
+                 : "v"(__builtin_shufflevector(r, r, 0, 1)), "v"(__builtin_shufflevector(r, r, 2, 3)), "n"(N));
+    return f32x4_t{lo[0], lo[1], hi[0], hi[1]};
+  };
+  f32x4_t ty[4];                                          // dY items behind their wait (take_dy), split by put_dy
+  auto take_dy = [&](auto n_c) {                          // N = requests issued behind the four dY requests
+    ty[0] = take4(ly[0], n_c);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) ty[j] = take4(ly[j], n_c);
   };
   auto put_dy = [&](unsigned char* dst) {                 // registers -> three planes (split by truncation, exact)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int it = tid + 512 * j;
       if (j < 3 || it < 4 * P) {
-        const f32x4_t v = ly[j];
+        const f32x4_t v = ty[j];
         bsum += v;
         uint32_t h[4], m[4], l[4];
 #pragma unroll
@@ -1229,6 +1267,14 @@ stackconv_wgrad_tr_kernel(const Params p) {
     }
   };
 
+  // EXP & 32: stamps of workgroup 0's waves into partial_b as [wave][step][8] words (the probe passes a buffer of its own)
+  unsigned* stamps = reinterpret_cast<unsigned*>(p.partial_b) + (size_t)wave * 64 * 8;
+  auto stamp = [&](int t, int k) {
+    if ((EXP & 32) && blockIdx.x == 0 && t < 64) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      if (lane == 0) stamps[t * 8 + k] = (unsigned)now;
+    }
+  };
   auto run = [&](auto wkc) {
     constexpr int WK = decltype(wkc)::value;
     for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
@@ -1240,28 +1286,51 @@ stackconv_wgrad_tr_kernel(const Params p) {
         const uint4* src = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t0 + e) * p.B + b) * p.fsz);
         for (int idx = tid; idx < kVec; idx += 512) frame_store16(smem + ((t0 + e) % kFrameSlots) * kFrame16, src[idx], idx);
       }
-      issue_dy(t0, b);
+      typedef std::integral_constant<int, 0> n0_t;
+      typedef std::integral_constant<int, 1> n1_t;
+      typedef std::integral_constant<int, 4> n4_t;
+      req_dy(t0, b, true);
+      take_dy(n0_t());
       put_dy(ybuf + (t0 & 1) * kTrYBuf);
-      if (t0 + 1 < t1) issue_dy(t0 + 1, b);
+      req_dy(t0 + 1, b, t0 + 1 < t1);
       __syncthreads();
       for (int t = t0; t < t1; ++t) {
         const bool more = t + 1 < t1;
         const int nv = nvalid_at(p.nvalid, (long long)t * p.B + b);
-        uint4 pf = make_uint4(0, 0, 0, 0);
-        if (more && tid < kVec)
-          pf = reinterpret_cast<const uint4*>(p.frames_ext + ((long long)(t + 4) * p.B + b) * p.fsz)[tid];
         const unsigned char* yp = ybuf + (t & 1) * kTrYBuf;
-        auto prepare = [&]() {                              // step t + 1: its dY planes; step t + 2's dY requested
-          if (more) {
-            put_dy(ybuf + ((t + 1) & 1) * kTrYBuf);
-            if (t + 2 < t1) issue_dy(t + 2, b);
-          }
-        };
-        if (WK == 0) { prepare(); if (c < nv) multiply(wkc, t, yp); }
-        else { if (c < nv) multiply(wkc, t, yp); prepare(); }
-        // the frame requested at the head of this step goes into the ring LAST (its load has had the whole step)
-        if (more && tid < kVec) frame_store16(smem + ((t + 4) % kFrameSlots) * kFrame16, pf, tid);   // a slot no wave reads in step t
-        __syncthreads();                                    // planes / frame of step t + 1 visible; every wave done with step t
+        // Per step every wave issues ONE frame request (ext row t + 4) and four dY requests (step t + 2), always (out of
+        // range past the chunk), so that the counts below hold.  No wait of a step covers a request of that step:
+        //   waves 0-3: take dY(t + 1) [vmcnt(0): requested before the previous step's MFMAs], planes, request frame + dY,
+        //              MFMAs, take the frame [vmcnt(4): the dY requests behind it stay in flight across the barrier]
+        //   waves 4-7: request the frame, MFMAs, take dY(t + 1) [vmcnt(1): requested at the end of the previous step], planes,
+        //              take the frame [vmcnt(0)], request dY
+        stamp(t, 0);
+        if (WK == 0 || (EXP & 64)) {                        // EXP & 64 (probe): every wave prepares first
+          take_dy(n0_t());
+          if (more) put_dy(ybuf + ((t + 1) & 1) * kTrYBuf);
+          req_frame(t + 4, b, more);
+          req_dy(t + 2, b, t + 2 < t1);
+          stamp(t, 1);
+          if (c < nv) multiply(wkc, t, yp);
+          stamp(t, 2);
+          const f32x4_t fv = take4(lf, n4_t());
+          if (more && tid < kVec) frame_store16(smem + ((t + 4) % kFrameSlots) * kFrame16, __builtin_bit_cast(uint4, fv), tid);   // a slot no wave reads in step t
+        } else {
+          req_frame(t + 4, b, more);
+          if (c < nv) multiply(wkc, t, yp);
+          stamp(t, 1);
+          take_dy(n1_t());
+          if (more) put_dy(ybuf + ((t + 1) & 1) * kTrYBuf);
+          stamp(t, 2);
+          const f32x4_t fv = take4(lf, n0_t());
+          if (more && tid < kVec) frame_store16(smem + ((t + 4) % kFrameSlots) * kFrame16, __builtin_bit_cast(uint4, fv), tid);
+          req_dy(t + 2, b, t + 2 < t1);
+        }
+        stamp(t, 3);
+        // planes / frame of step t + 1 visible, every wave done with step t.  NOT __syncthreads(): its fence would drain the
+        // requests in flight; the LDS writes of this wave are what the others need
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        stamp(t, 4);
       }
     }
   };
@@ -1287,7 +1356,7 @@ stackconv_wgrad_tr_kernel(const Params p) {
       }
     }
   }
-  if (p.partial_b) {                                      // thread t summed output channels 4 (t & 3) .. + 3 of its dY items
+  if (p.partial_b && !(EXP & 32)) {                       // thread t summed output channels 4 (t & 3) .. + 3 of its dY items
     __syncthreads();
     f32x4_t* redb = reinterpret_cast<f32x4_t*>(smem + 16384);
     redb[tid] = bsum;
