@@ -156,9 +156,16 @@ wdx_kernel(const Params p) {
   for (int i = 0; i < 2 * kItems; ++i) issue1(ld[0], 0, e0, i);
 #pragma unroll
   for (int i = 0; i < 2 * kItems; ++i) issue1(ld[1], e0, e1, i);
-  wait_set<2 * kItems>(ld[0]);
+  // (r6) The items are read BEHIND an operand-free wait through xg::move_item: the tied "+v" operands of wait_set let
+  // hipcc allocate them elsewhere and copy the in-flight registers in FRONT of the waiting statement -- it did, at the
+  // round loop's back edge (tools/isa_inflight.py with the wait COUNT held against the requests issued behind: eight
+  // v_mov_b64 of items requested a round earlier, a race their ~1 us of head start won in every test).
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kItems));
 #pragma unroll
-  for (int k = 0; k < kItems; ++k) { put_half(ld[0][k][0], k, 0, 0, e0); put_half(ld[0][k][1], k, 1, 0, e0); }
+  for (int k = 0; k < kItems; ++k) {
+    const f32x4_t i0 = xg::move_item(ld[0][k][0]), i1 = xg::move_item(ld[0][k][1]);
+    put_half(i0, k, 0, 0, e0); put_half(i1, k, 1, 0, e0);
+  }
 
   unsigned char* blk = smem + kRing + wave * 4096;           // this wave's outputs, [super-pixel][128 B], chunks swizzled
   unsigned char* msk = smem + kRing + 8 * 4096 + wave * 4096;   // this wave's mask pieces, [piece][lane] x 16 bytes
@@ -232,6 +239,7 @@ wdx_kernel(const Params p) {
     // waits BETWEEN stores wait for the stores' acknowledgements: loads and stores share vmcnt.)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    f32x4_t item[2 * kItems];                                // the round's row items behind their wait
 #define WDX_SB __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -240,7 +248,12 @@ wdx_kernel(const Params p) {
       const bf16x8_t (&x)[3] = xb[s & 1];
       const int j = s & 3;
       const bool mine = (s >> 2) == ph;
-      if (mine && j == 0) { wait_set<0>(wr); if (MASK == 2) bits_wait(); }
+      if (mine && j == 0) {
+        asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+        for (int k = 0; k < 2 * kItems; ++k) item[k] = xg::move_item(wr[k >> 1][k & 1]);
+        if (MASK == 2) bits_wait();
+      }
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[s], x[0], acc, 0, 0, 0);
       if (mine && !(EXP & 2)) issue1(nx, hi1, hi2, j);
       WDX_SB
@@ -254,7 +267,7 @@ wdx_kernel(const Params p) {
         acc[s] += (float)x[1][0] + (float)x[2][1];
       }
       if (mine) {
-        if (!(EXP & 1)) put_half(wr[j >> 1][j & 1], j >> 1, j & 1, lo1, hi1);
+        if (!(EXP & 1)) put_half(item[j], j >> 1, j & 1, lo1, hi1);
         if (!(EXP & 8)) {
           // piece j of the PREVIOUS round's outputs leaves (its sums wait in the block, its mask piece was requested in
           // this step of the previous round), then the same slot takes the mask of THIS round's tile

@@ -141,3 +141,16 @@ def test_in_flight_load_registers_are_not_read_before_their_wait():
         bad = isa_inflight.check(body, asm_only=False)
         assert not bad, (name, bad[:3])
   assert seen >= 20, seen
+
+
+def test_in_flight_check_counts_the_wait():
+  """tools/isa_inflight.py holds a wait to its COUNT: vmcnt(N) covers a request only when at most N vector
+  memory operations were issued behind it."""
+  import isa_inflight
+  load = 'buffer_load_dwordx4 v[4:7], v1, s[0:3], 0 offen'
+  store = 'buffer_store_dwordx4 v[8:11], v2, s[4:7], 0 offen'
+  use = 'v_add_f32_e32 v12, v4, v4'
+  assert not isa_inflight.check([load, store, store, 's_waitcnt vmcnt(2)', use])        # two younger operations: covered
+  assert isa_inflight.check([load, store, 's_waitcnt vmcnt(2)', use])                   # one younger: vmcnt(2) may pass early
+  assert isa_inflight.check([load, use])                                                # no wait at all
+  assert not isa_inflight.check([load, store, 's_waitcnt vmcnt(2)', 's_waitcnt vmcnt(0)', use])

@@ -7,7 +7,8 @@ compute phase (fgx.h, cgx.h) request them through `asm volatile("buffer_load_dwo
 made in front of the wait reads whatever the registers held before: cgx.h's first build).  This tool walks every
 matching kernel of an object in address order and reports, for each `buffer_load_dword[x2|x4] ... offen` with a literal 0
 scalar offset (the form the asm requests use), the first later instruction that READS one of its destination registers
-when no `s_waitcnt vmcnt` lies between the two.
+when no `s_waitcnt vmcnt(N)` with N <= the number of vector memory operations issued behind the request lies between the
+two (a wait that lets MORE operations stay outstanding than were issued behind the request does not cover it).
 
   python tools/isa_inflight.py build/obj/fgx.o fgx_kernel          # prints offenders, exit code 1 if any
 """
@@ -19,6 +20,8 @@ sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(_
 import isa_waits
 
 REG = re.compile(r'v\[(\d+):(\d+)\]|v(\d+)')
+VMEM = ('buffer_load', 'buffer_store', 'buffer_atomic', 'global_load', 'global_store', 'global_atomic', 'flat_load', 'flat_store',
+        'scratch_load', 'scratch_store')
 
 
 def regs(tok):
@@ -64,12 +67,20 @@ def check(body, asm_only=True):
       continue
     live = set(regs(ops[0]))
     waited = False
+    younger = 0                                   # vector memory operations issued behind the request (address order)
     for j in range(i + 1, len(body)):
       t = body[j]
       if t.startswith(('s_endpgm', 's_branch', 's_setpc')):
         break
       if t.startswith('s_waitcnt') and 'vmcnt' in t:
-        waited = True
+        # vmcnt(N) lets the N youngest operations stay outstanding: it covers this request only if at most `younger`
+        # operations were issued behind it on the way here (the COUNT, not only the presence of a wait).  A wait
+        # reached through a loop's back edge is not seen in address order: such requests pass on the presence test alone.
+        m = re.search(r'vmcnt\((\d+)\)', t)
+        if m and int(m.group(1)) <= younger:
+          waited = True
+      elif t.startswith(VMEM):
+        younger += 1
       p2 = t.split(None, 1)
       if len(p2) < 2:
         continue
