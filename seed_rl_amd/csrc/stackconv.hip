@@ -1084,6 +1084,166 @@ stackconv_rows_kernel(const RowsParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------ //
+// The rows forward on EIGHT waves (r6): stackconv_fwd_w8_kernel's organisation -- one 512-thread workgroup per CU, two
+// rows at a time (waves 0-3 row 2 i, waves 4-7 row 2 i + 1), runs of 7 + 6 + 6 + 6 / 6 + 6 + 6 + 7 tiles, 28-row bands, all
+// three planes of W / 255 in registers -- with the five-wave rows kernel's pipeline by stack channel (channel c's k-groups
+// are the only readers of ring slot 3 - c: the next row's frame c is staged behind them from two sets of prefetch
+// registers).  Same operands and MFMA order per accumulator: bit-identical outputs.
+// ------------------------------------------------------------------------------------ //
+template <int NT, bool RELU>
+__device__ __forceinline__ void rows8_run(const RowsParams& p, unsigned char* myring, const float* bias_lds, const Frag8 (&wreg)[kGroups][3],
+                                          int col, int p0, int lane) {
+  const int kq = lane >> 4, j = lane & 15;
+  const int co0 = blockIdx.z * 16;
+  const int row0 = 4 * (p0 / kOW);
+  const unsigned band0 = (unsigned)__builtin_amdgcn_readfirstlane(row0 * kIW);
+  int aoff[NT];
+  unsigned ov[NT];
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+    const int pix = p0 + m * 16 + j;
+    const int oy = pix / kOW, ox = pix - oy * kOW;
+    aoff[m] = ((oy * 4 - row0 + kq) * kIW + ox * 4) * 2;
+    ov[m] = (unsigned)((pix * p.ld_out + co0 + 4 * kq) * 4);
+  }
+  // frame c of row b as a buffer of its own (see stackconv_rows_kernel); a band that reaches past the frame reads zeros
+  const unsigned fv[3] = {16u * (unsigned)lane, 16u * (unsigned)(lane + 64), lane + 128 < kW8Vec ? 16u * (unsigned)(lane + 128) : 0x80000000u};
+  auto band_of = [&](int b, int c) -> Band3 {
+    typedef __attribute__((address_space(4))) const unsigned cu32_t;
+    long long row = b;
+    if (c) {
+      cu32_t* q = reinterpret_cast<cu32_t*>(reinterpret_cast<uintptr_t>(p.hist_rows + 4 * (long long)b + c));
+      row = (long long)(((unsigned long long)q[1] << 32) | q[0]);
+    }
+    const uint8_t* fr = (c == 0 ? p.obs : p.store_obs) + row * p.fsz;
+    const __amdgpu_buffer_rsrc_t v = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(fr), 0, p.fsz, 0x00020000);
+    Band3 r;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) r.v[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(v, fv[u], band0, 0));
+    return r;
+  };
+  auto band_put = [&](unsigned char* slot, const Band3& r) {
+    uint4* dst = reinterpret_cast<uint4*>(slot);
+    uint4 a, b;
+    cvt16(r.v[0], a, b); dst[2 * lane] = a; dst[2 * lane + 1] = b;
+    cvt16(r.v[1], a, b); dst[2 * (lane + 64)] = a; dst[2 * (lane + 64) + 1] = b;
+    if (lane + 128 < kW8Vec) { cvt16(r.v[2], a, b); dst[2 * (lane + 128)] = a; dst[2 * (lane + 128) + 1] = b; }
+  };
+  const int row_bytes = 400 * p.ld_out * 4;
+  const int stride = 2 * (int)gridDim.x;
+  int b = __builtin_amdgcn_readfirstlane(2 * (int)blockIdx.x + col);
+  if (b >= p.B) return;                               // odd B: the last pair has one row (wave-uniform; no barrier follows)
+  int nv = nvalid_at(p.nvalid, b);
+  {
+    Band3 f0[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) f0[c] = band_of(b, c);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) band_put(myring + (3 - c) * kW8Band16, f0[c]);     // stack channel c sits in ring slot 3 - c
+    wave_lds_fence();
+  }
+  for (;;) {
+    const int bn = __builtin_amdgcn_readfirstlane(b + stride);
+    const bool more = bn < p.B;
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) acc[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto group = [&](int G) {
+      const unsigned char* base = myring + (3 - (G >> 1)) * kW8Band16 + (G & 1) * 4 * kIW * 2;
+      Frag8 xf[NT];
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        typedef __attribute__((address_space(3))) const volatile unsigned long long lds_cv64_t;
+        lds_cv64_t* src = (lds_cv64_t*)(base + aoff[m]);
+        const unsigned long long x0 = src[0], x1 = src[1];
+        xf[m].u = make_uint4((unsigned)x0, (unsigned)(x0 >> 32), (unsigned)x1, (unsigned)(x1 >> 32));
+      }
+#pragma unroll
+      for (int s3 = 2; s3 >= 0; --s3)
+#pragma unroll
+        for (int m = 0; m < NT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[G][s3].v, xf[m].v, acc[m], 0, 0, 0);
+    };
+    int nvn = 0;
+    if (nv == 4 && more) {                             // the common case, straight-line: channel c's groups, then the next row's frame c
+      nvn = nvalid_at(p.nvalid, bn);
+      Band3 pa = band_of(bn, 0), pb = band_of(bn, 1);
+      group(0); group(1);
+      __builtin_amdgcn_sched_barrier(0);               // (the conversion may not be scheduled above its channel's k-groups: see the five-wave kernel)
+      wave_lds_fence(); band_put(myring + 3 * kW8Band16, pa);
+      pa = band_of(bn, 2);
+      group(2); group(3);
+      __builtin_amdgcn_sched_barrier(0);
+      wave_lds_fence(); band_put(myring + 2 * kW8Band16, pb);
+      pb = band_of(bn, 3);
+      group(4); group(5);
+      __builtin_amdgcn_sched_barrier(0);
+      wave_lds_fence(); band_put(myring + 1 * kW8Band16, pa);
+      group(6); group(7);
+      __builtin_amdgcn_sched_barrier(0);
+      wave_lds_fence(); band_put(myring + 0 * kW8Band16, pb);
+    } else {
+      Band3 pa, pb;
+      if (more) {
+        nvn = nvalid_at(p.nvalid, bn);
+        pa = band_of(bn, 0); pb = band_of(bn, 1);
+      }
+#pragma unroll
+      for (int G = 0; G < kGroups; ++G) if (G < 2 * nv) group(G);
+      wave_lds_fence();
+      if (more) {
+        band_put(myring + 3 * kW8Band16, pa); band_put(myring + 2 * kW8Band16, pb);
+        pa = band_of(bn, 2); pb = band_of(bn, 3);
+        band_put(myring + 1 * kW8Band16, pa); band_put(myring + 0 * kW8Band16, pb);
+      }
+    }
+    wave_lds_fence();
+    const f32x4_t bias4 = *reinterpret_cast<const f32x4_t*>(bias_lds + 4 * kq);
+    f32x4_t vout[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      vout[m] = acc[m] + bias4;
+      if (RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vout[m][r] = __builtin_amdgcn_fmed3f(vout[m][r], 0.f, __builtin_inff());
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < NT; ++m) asm volatile("" : "+v"(vout[m]));   // every output finished before the first store
+    const __amdgpu_buffer_rsrc_t oview = __builtin_amdgcn_make_buffer_rsrc(p.out + (long long)b * (row_bytes / 4), 0, row_bytes, 0x00020000);
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(su32x4_t, vout[m]), oview, ov[m], 0, 0);
+    if (!more) break;
+    b = bn; nv = nvn;
+  }
+}
+
+template <bool RELU>
+__global__ void __launch_bounds__(kW8Threads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+stackconv_rows_w8_kernel(const RowsParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int co0 = blockIdx.z * 16;
+  Frag8 wreg[kGroups][3];
+  {
+    const uint4* img = p.w_split + (long long)blockIdx.z * kGroups * 3 * 64 + lane;
+#pragma unroll
+    for (int G = 0; G < kGroups; ++G)
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) wreg[G][s3].u = img[(G * 3 + s3) * 64];
+  }
+  float* bias_lds = reinterpret_cast<float*>(smem + kW8Rings);
+  if (tid < 16) bias_lds[tid] = p.bias ? p.bias[co0 + tid] : 0.f;
+  __syncthreads();                                    // the biases; the only workgroup barrier
+  const int col = wave >> 2, q = wave & 3;
+  const int p0 = 96 * q + ((col == 0 && q > 0) ? 16 : 0);
+  unsigned char* myring = smem + wave * kW8Ring;
+  if (wave == 0 || wave == 7) rows8_run<7, RELU>(p, myring, bias_lds, wreg, col, p0, lane);
+  else rows8_run<6, RELU>(p, myring, bias_lds, wreg, col, p0, lane);
+}
+
 // (r1-r4: the channel-per-wave / channel-pair weight-gradient kernels lived here; r5: the transposing-read kernel below)
 constexpr int kFrame16 = kIH * kIW * 2;                  // 14112 B: one frame in bf16
 constexpr int kFrameSlots = 5;
@@ -1168,7 +1328,6 @@ stackconv_wgrad_tr_kernel(const Params p) {
   f32x4_t bsum = {0.f, 0.f, 0.f, 0.f};
 
   // dY of one step: 1600 16-byte items (pixel = item >> 2, channel quad = item & 3), four per thread (the last partly)
-  const char* dy_base = reinterpret_cast<const char*>(p.dy);
   // Requests are asm statements (hipcc's s_waitcnt bookkeeping drained the queue at every step head and waited for a
   // step's own requests inside the step: s_memtime stamps, tools/probes/stack_wgrad_probe.hip); the waits count the
   // requests issued behind the one that is needed (vector memory operations retire in order) and the registers are read
@@ -1579,9 +1738,22 @@ extern "C" int seedhip_conv2d_stack_fwd_rows(const seedhip_stack_conv_geom* geom
   p.obs = obs; p.store_obs = store_obs; p.hist_rows = hist_rows; p.nvalid = nvalid;
   p.bias = bias; p.w_split = (const uint4*)w_split; p.out = out; p.B = geom->B; p.cout = geom->cout;
   p.ld_out = geom->ld_out; p.fsz = geom->ih * geom->iw;
+  hipStream_t s = (hipStream_t)stream;
+  if (stackconv::w8_enabled()) {                      // eight waves, two rows per workgroup, one workgroup per CU
+    const int pairs = (p.B + 1) / 2;
+    const int grid8 = pairs < stackconv::max_grid_for(1) ? pairs : stackconv::max_grid_for(1);
+    const int lds8 = stackconv::kW8Rings + 64;
+    if (out_relu) {
+      (void)hipFuncSetAttribute((const void*)stackconv::stackconv_rows_w8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds8);
+      hipLaunchKernelGGL(stackconv::stackconv_rows_w8_kernel<true>, dim3(grid8, 1, geom->cout / 16), dim3(stackconv::kW8Threads), lds8, s, p);
+    } else {
+      (void)hipFuncSetAttribute((const void*)stackconv::stackconv_rows_w8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds8);
+      hipLaunchKernelGGL(stackconv::stackconv_rows_w8_kernel<false>, dim3(grid8, 1, geom->cout / 16), dim3(stackconv::kW8Threads), lds8, s, p);
+    }
+    return check_launch("stackconv_rows_w8_kernel");
+  }
   const size_t lds = (size_t)stackconv::kGroups * 64 * 16 + (size_t)stackconv::kWaves * stackconv::kWaveRing16 + 64;
   const int grid = p.B < stackconv::max_grid_for(2) ? p.B : stackconv::max_grid_for(2);
-  hipStream_t s = (hipStream_t)stream;
   if (out_relu) {
     (void)hipFuncSetAttribute((const void*)stackconv::stackconv_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(stackconv::stackconv_rows_kernel<true>, dim3(grid, 1, geom->cout / 16), dim3(stackconv::kThreads), lds, s, p);
