@@ -287,8 +287,10 @@ def run_learner(config, steps, warmup, dev, rank=0, world=1, distributed=False, 
         mode = 'hip-graph x%d segments + eager RCCL exchange + update graph' % len(gs.segments)
       # untimed replays of the captured graph: the first window after a capture ran 8 % slower than every later one
       # (0.993 against 0.914-0.922 ms, six windows, r6) -- the warm-up the contract asks for has to warm THIS launch path,
-      # not only the eager one the W steps above went through
-      for _ in range(max(warmup, 10)):
+      # not only the eager one the W steps above went through.  Ten replays (9 ms) still left window 0 3-4 % above the
+      # others (0.901 / 0.894 against 0.865-0.880); fifty (45 ms) put it among them (0.877 / 0.873 against 0.878-0.889, same
+      # box, alternating runs: the later windows are the chip's steady state, slightly SLOWER than a cold start's).
+      for _ in range(max(warmup, int(os.environ.get('SEEDRL_BENCH_GRAPH_WARMUP', '50')))):
         step_fn()
       torch.cuda.synchronize()
     except Exception as e:                       # pylint: disable=broad-except
