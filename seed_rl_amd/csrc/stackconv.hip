@@ -691,7 +691,8 @@ __device__ __forceinline__ void w8_run(const Params& p, unsigned char* myring, u
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((e * p.B + b) * p.fsz + row0 * kIW));
     asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %3, %6, %7 offen\n\tbuffer_load_dwordx4 %1, %4, %6, %7 offen\n\t"
                  "buffer_load_dwordx4 %2, %5, %6, %7 offen"
-                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]) : "v"(fv[0]), "v"(fv[1]), "v"(fv[2]), "s"(fwords), "s"(so));
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]) : "v"(fv[0]), "v"(fv[1]), "v"(fv[2]), "s"(fwords), "s"(so)
+                 : "memory");                          // (no store of the step may be moved in front of the request: the wait counts them)
   };
   constexpr int kStoresPerStep = (EXP & 4) ? 0 : (BITS ? NT + 2 : NT);
   // BITS: byte offset of pixel lane + 64 h's mask dword inside a step's slice of relu_bits (pixels past the run: out of range)
@@ -1341,7 +1342,7 @@ stackconv_wgrad_tr_kernel(const Params p) {
   };
   const sgpr128_t ywords = words_of(p.dy, (unsigned long long)p.T1 * p.B * P * ld_out * 4ull);
   const sgpr128_t fwords = words_of(p.frames_ext, (unsigned long long)(3 + p.T1) * p.B * p.fsz);
-  constexpr unsigned kOob = 0x80000000u;
+  constexpr unsigned kOob = 0xFFFFFFFFu;                  // >= any num_records: the request returns zeros without touching memory
   unsigned yoff[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -1356,11 +1357,12 @@ stackconv_wgrad_tr_kernel(const Params p) {
     asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %4, %8, %9 offen\n\tbuffer_load_dwordx4 %1, %5, %8, %9 offen\n\t"
                  "buffer_load_dwordx4 %2, %6, %8, %9 offen\n\tbuffer_load_dwordx4 %3, %7, %8, %9 offen"
                  : "=&v"(ly[0]), "=&v"(ly[1]), "=&v"(ly[2]), "=&v"(ly[3])
-                 : "v"(yoff[0] | kill), "v"(yoff[1] | kill), "v"(yoff[2] | kill), "v"(yoff[3] | kill), "s"(ywords), "s"(so));
+                 : "v"(yoff[0] | kill), "v"(yoff[1] | kill), "v"(yoff[2] | kill), "v"(yoff[3] | kill), "s"(ywords), "s"(so)
+                 : "memory");
   };
   auto req_frame = [&](int e, int b, bool valid) {
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(((long long)e * p.B + b) * p.fsz));
-    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(lf) : "v"(foff | (valid ? 0u : kOob)), "s"(fwords), "s"(so));
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(lf) : "v"(foff | (valid ? 0u : kOob)), "s"(fwords), "s"(so) : "memory");
   };
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
   auto take4 = [&](const f32x4_t& r, auto n_c) -> f32x4_t {   // wait until at most N younger requests are outstanding, then copy
@@ -1451,39 +1453,42 @@ stackconv_wgrad_tr_kernel(const Params p) {
       req_dy(t0, b, true);
       take_dy(n0_t());
       put_dy(ybuf + (t0 & 1) * kTrYBuf);
-      req_dy(t0 + 1, b, t0 + 1 < t1);
+      if (t0 + 1 < t1) req_dy(t0 + 1, b, true);
       __syncthreads();
       for (int t = t0; t < t1; ++t) {
         const bool more = t + 1 < t1;
         const int nv = nvalid_at(p.nvalid, (long long)t * p.B + b);
         const unsigned char* yp = ybuf + (t & 1) * kTrYBuf;
-        // Per step every wave issues ONE frame request (ext row t + 4) and four dY requests (step t + 2), always (out of
-        // range past the chunk), so that the counts below hold.  No wait of a step covers a request of that step:
+        // Per step every wave issues ONE frame request (ext row t + 4; out of range behind the chunk's last step) and, while
+        // step t + 2 exists, four dY requests.  No wait of a step covers a request of that step, and EVERY request is waited
+        // for inside the loop: a request left in flight at the loop's exit lands in registers hipcc has handed to the
+        // epilogue by then (an out-of-range one writes zeros: a pointer of the slice stores went to nil once in seven runs
+        // of the first build, "Memory access fault ... on address (nil)").
         //   waves 0-3: take dY(t + 1) [vmcnt(0): requested before the previous step's MFMAs], planes, request frame + dY,
-        //              MFMAs, take the frame [vmcnt(4): the dY requests behind it stay in flight across the barrier]
+        //              MFMAs, take the frame [vmcnt(4) with the dY requests behind it, else vmcnt(0)]
         //   waves 4-7: request the frame, MFMAs, take dY(t + 1) [vmcnt(1): requested at the end of the previous step], planes,
         //              take the frame [vmcnt(0)], request dY
+        const bool ask = t + 2 < t1;                        // (uniform)
         stamp(t, 0);
         if (WK == 0 || (EXP & 64)) {                        // EXP & 64 (probe): every wave prepares first
-          take_dy(n0_t());
-          if (more) put_dy(ybuf + ((t + 1) & 1) * kTrYBuf);
+          if (more) { take_dy(n0_t()); put_dy(ybuf + ((t + 1) & 1) * kTrYBuf); }
           req_frame(t + 4, b, more);
-          req_dy(t + 2, b, t + 2 < t1);
+          if (ask) req_dy(t + 2, b, true);
           stamp(t, 1);
           if (c < nv) multiply(wkc, t, yp);
           stamp(t, 2);
-          const f32x4_t fv = take4(lf, n4_t());
+          f32x4_t fv;
+          if (ask) fv = take4(lf, n4_t()); else fv = take4(lf, n0_t());
           if (more && tid < kVec) frame_store16(smem + ((t + 4) % kFrameSlots) * kFrame16, __builtin_bit_cast(uint4, fv), tid);   // a slot no wave reads in step t
         } else {
           req_frame(t + 4, b, more);
           if (c < nv) multiply(wkc, t, yp);
           stamp(t, 1);
-          take_dy(n1_t());
-          if (more) put_dy(ybuf + ((t + 1) & 1) * kTrYBuf);
+          if (more) { take_dy(n1_t()); put_dy(ybuf + ((t + 1) & 1) * kTrYBuf); }
           stamp(t, 2);
           const f32x4_t fv = take4(lf, n0_t());
           if (more && tid < kVec) frame_store16(smem + ((t + 4) % kFrameSlots) * kFrame16, __builtin_bit_cast(uint4, fv), tid);
-          req_dy(t + 2, b, t + 2 < t1);
+          if (ask) req_dy(t + 2, b, true);
         }
         stamp(t, 3);
         // planes / frame of step t + 1 visible, every wave done with step t.  NOT __syncthreads(): its fence would drain the
@@ -1494,6 +1499,8 @@ stackconv_wgrad_tr_kernel(const Params p) {
     }
   };
   if (wk == 0) run(std::integral_constant<int, 0>()); else run(std::integral_constant<int, 1>());
+  // (belt and braces: nothing is in flight here -- see the step loop --, and the request registers stay live up to this point)
+  asm volatile("s_waitcnt vmcnt(0)" :: "v"(ly[0]), "v"(ly[1]), "v"(ly[2]), "v"(ly[3]), "v"(lf) : "memory");
 
   // ---- the two k-step parities of a channel -> one tile set per channel (parity 1 through LDS), straight into the slice
   float* red = reinterpret_cast<float*>(smem);            // [c][tile][lane][4]
@@ -1635,13 +1642,18 @@ int launch_fwd(const seedhip_stack_conv_geom* g, const uint8_t* frames_ext, cons
 
 size_t wgrad_lds(int fsz) { (void)fsz; return (kWFloats + kWaves * 16) * sizeof(float) + (size_t)kWaves * kWaveRing; }
 
+bool wgrad_tr_fits(const seedhip_stack_conv_geom* g) {
+  const long long lim = (1LL << 32) - (1 << 20);
+  return (long long)(3 + g->T) * g->B * g->ih * g->iw < lim && (long long)g->T * g->B * g->oh * g->ow * g->ld_out * 4 < lim;
+}
+
 int wgrad_grid(const seedhip_stack_conv_geom* g, int* spc, int* items) {
   const size_t lds = wgrad_lds(g->ih * g->iw);
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 2) per_cu = 2;                     // measured: 2 workgroups per CU beat 3 (0.43 vs 0.48 ms at cfg2)
   if (per_cu < 1) per_cu = 1;
   static const int bf16x3 = getenv("SEEDHIP_STACK_BF16") ? atoi(getenv("SEEDHIP_STACK_BF16")) : 1;
-  if (bf16x3) per_cu = 1;                             // transposing-read kernel: 150 KB of LDS, one 8-wave workgroup per CU
+  if (bf16x3 && wgrad_tr_fits(g)) per_cu = 1;         // transposing-read kernel: 150 KB of LDS, one 8-wave workgroup per CU
   int grid;
   decompose(g->T, g->B, max_grid_for(per_cu), spc, items, &grid);
   return grid;
@@ -1789,7 +1801,9 @@ extern "C" int seedhip_conv2d_stack_bwd_weight(const seedhip_stack_conv_geom* ge
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)stackconv::stackconv_wgrad_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    static const int bf16x3 = getenv("SEEDHIP_STACK_BF16") ? atoi(getenv("SEEDHIP_STACK_BF16")) : 1;
+    static const int bf16x3_env = getenv("SEEDHIP_STACK_BF16") ? atoi(getenv("SEEDHIP_STACK_BF16")) : 1;
+    // the transposing-read kernel addresses the frames and dY as buffers with 32-bit offsets (r6)
+    const bool bf16x3 = bf16x3_env && stackconv::wgrad_tr_fits(geom);
     if (bf16x3) {
 #define SEEDHIP_TR(LD_)                                                                                            \
       {                                                                                                           \
