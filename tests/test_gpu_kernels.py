@@ -1192,6 +1192,8 @@ KNOB_CHILDREN = [
     (dict(SEEDHIP_CONV_BF16X6='0'), 'test_gpu_kernels.py', 'conv_fwd_bwd_parity or conv_residual'),   # conv layers back on the fp32 pipe
     (dict(SEEDHIP_X6='0', SEEDHIP_X8='0'), 'test_gpu_kernels.py', 'dense_padded_rows or test_conv_fwd_bwd_parity'),   # Dense layers on gemm.h
     (dict(SEEDHIP_STACK_BF16='0'), 'test_gpu_kernels.py', 'test_stack_conv_parity'),                    # fp32-MFMA first conv
+    (dict(SEEDHIP_STACK_W8='0'), 'test_gpu_kernels.py', 'test_stack_conv_parity or test_relu_byte_mask_pair'),  # five-wave first conv (forward: what tensors above 2 GB take)
+    (dict(SEEDHIP_STACK_W8='0'), 'test_gpu_store.py', 'fused_inference_matches'),                      # five-wave rows kernel of central inference
     (dict(SEEDHIP_CONVPOOL_MFMA='0'), 'test_gpu_kernels.py', 'test_convpool_fused_parity'),             # round-1 vector-ALU first stage
     (dict(SEEDHIP_RELU_BITS='0'), 'test_gpu_agent.py', ''),                                             # fp32 ReLU masks through the shallow torso
     (dict(SEEDHIP_LSTM_SEQ='0'), 'test_gpu_deep.py', ''),                                               # one launch per LSTM step
