@@ -1453,42 +1453,43 @@ stackconv_wgrad_tr_kernel(const Params p) {
       req_dy(t0, b, true);
       take_dy(n0_t());
       put_dy(ybuf + (t0 & 1) * kTrYBuf);
-      if (t0 + 1 < t1) req_dy(t0 + 1, b, true);
+      req_dy(t0 + 1, b, t0 + 1 < t1);
       __syncthreads();
       for (int t = t0; t < t1; ++t) {
         const bool more = t + 1 < t1;
         const int nv = nvalid_at(p.nvalid, (long long)t * p.B + b);
         const unsigned char* yp = ybuf + (t & 1) * kTrYBuf;
-        // Per step every wave issues ONE frame request (ext row t + 4; out of range behind the chunk's last step) and, while
-        // step t + 2 exists, four dY requests.  No wait of a step covers a request of that step, and EVERY request is waited
-        // for inside the loop: a request left in flight at the loop's exit lands in registers hipcc has handed to the
-        // epilogue by then (an out-of-range one writes zeros: a pointer of the slice stores went to nil once in seven runs
-        // of the first build, "Memory access fault ... on address (nil)").
+        // Per step every wave issues ONE frame request (ext row t + 4) and four dY requests (step t + 2) -- out of range behind
+        // the chunk, where they cost no traffic -- and takes one of each: every count below is unconditional (no wait depends
+        // on a branch taken earlier; tools/isa_inflight.py --cfg follows every path of the compiled loop), no wait of a step
+        // covers a request of that step, and the LAST dY request is taken behind the loop: a request left in flight at the
+        // loop's exit lands in registers hipcc has handed to the epilogue by then (an out-of-range one writes zeros: a
+        // pointer of the slice stores went to nil once in seven runs of the first build, "Memory access fault ... (nil)").
         //   waves 0-3: take dY(t + 1) [vmcnt(0): requested before the previous step's MFMAs], planes, request frame + dY,
-        //              MFMAs, take the frame [vmcnt(4) with the dY requests behind it, else vmcnt(0)]
+        //              MFMAs, take the frame [vmcnt(4): the dY requests behind it stay in flight across the barrier]
         //   waves 4-7: request the frame, MFMAs, take dY(t + 1) [vmcnt(1): requested at the end of the previous step], planes,
         //              take the frame [vmcnt(0)], request dY
-        const bool ask = t + 2 < t1;                        // (uniform)
         stamp(t, 0);
         if (WK == 0 || (EXP & 64)) {                        // EXP & 64 (probe): every wave prepares first
-          if (more) { take_dy(n0_t()); put_dy(ybuf + ((t + 1) & 1) * kTrYBuf); }
+          take_dy(n0_t());
+          if (more) put_dy(ybuf + ((t + 1) & 1) * kTrYBuf);
           req_frame(t + 4, b, more);
-          if (ask) req_dy(t + 2, b, true);
+          req_dy(t + 2, b, t + 2 < t1);
           stamp(t, 1);
           if (c < nv) multiply(wkc, t, yp);
           stamp(t, 2);
-          f32x4_t fv;
-          if (ask) fv = take4(lf, n4_t()); else fv = take4(lf, n0_t());
+          const f32x4_t fv = take4(lf, n4_t());
           if (more && tid < kVec) frame_store16(smem + ((t + 4) % kFrameSlots) * kFrame16, __builtin_bit_cast(uint4, fv), tid);   // a slot no wave reads in step t
         } else {
           req_frame(t + 4, b, more);
           if (c < nv) multiply(wkc, t, yp);
           stamp(t, 1);
-          if (more) { take_dy(n1_t()); put_dy(ybuf + ((t + 1) & 1) * kTrYBuf); }
+          take_dy(n1_t());
+          if (more) put_dy(ybuf + ((t + 1) & 1) * kTrYBuf);
           stamp(t, 2);
           const f32x4_t fv = take4(lf, n0_t());
           if (more && tid < kVec) frame_store16(smem + ((t + 4) % kFrameSlots) * kFrame16, __builtin_bit_cast(uint4, fv), tid);
-          if (ask) req_dy(t + 2, b, true);
+          req_dy(t + 2, b, t + 2 < t1);
         }
         stamp(t, 3);
         // planes / frame of step t + 1 visible, every wave done with step t.  NOT __syncthreads(): its fence would drain the
@@ -1496,6 +1497,7 @@ stackconv_wgrad_tr_kernel(const Params p) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         stamp(t, 4);
       }
+      take_dy(std::integral_constant<int, 0>());            // the out-of-range request of the last step: nothing stays in flight
     }
   };
   if (wk == 0) run(std::integral_constant<int, 0>()); else run(std::integral_constant<int, 1>());

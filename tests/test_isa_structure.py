@@ -154,3 +154,44 @@ def test_in_flight_check_counts_the_wait():
   assert isa_inflight.check([load, store, 's_waitcnt vmcnt(2)', use])                   # one younger: vmcnt(2) may pass early
   assert isa_inflight.check([load, use])                                                # no wait at all
   assert not isa_inflight.check([load, store, 's_waitcnt vmcnt(2)', 's_waitcnt vmcnt(0)', use])
+
+
+def test_in_flight_registers_along_the_control_flow():
+  """tools/isa_inflight.py --cfg (r6): from every buffer request of the conv objects, every path of the compiled kernel --
+  both sides of a conditional branch, loops through their back edges -- is followed to the first read of the request's
+  registers; a `s_waitcnt vmcnt(N)` with N <= the number of vector memory operations issued behind the request on that
+  path must lie in front of it.  This is what holds the first conv's kernels (requests that live across the step loop's
+  back edge, waits counted by hand) to their counts.  fgx.o is left to the address-order check above: its wait counts
+  assume the output stores of the previous unit, which a wave past the last band skips -- in the last unit only, after
+  which nothing is taken; the analysis is path-insensitive and reports that combination."""
+  import isa_inflight, isa_waits
+  obj_dir = os.path.join(ROOT, 'build', 'obj')
+  seen = 0
+  for obj in ('stackconv.o', 'conv.o', 'wgx.o', 'cgx.o'):
+    path = os.path.join(obj_dir, obj)
+    if not os.path.exists(path):
+      pytest.skip('%s is not built' % obj)
+    for co in isa_waits.device_code(path):
+      for name, rows in isa_inflight.kernels_cfg(co):
+        # conv.o: the kernels with asm requests (the igemm / gemm.h / halo kernels leave every wait to hipcc: two minutes
+        # of path walking for nothing)
+        if obj == 'conv.o' and not any(ns in name for ns in ('3wfx', '3wdx', '3wsx', '3wsy', '2xg', '3xg8')):
+          continue
+        seen += 1
+        bad = isa_inflight.check_cfg(rows, asm_only=False)
+        assert not bad, (name, bad[:3])
+  assert seen >= 20, seen
+
+
+def test_control_flow_check_follows_a_loop():
+  import isa_inflight
+  # request at the loop's end, stores behind it, the take at the next iteration's head: vmcnt(2) covers it, vmcnt(3) does not
+  def prog(n):
+    return [('s_nop 0', None),
+            ('s_waitcnt vmcnt(%d)' % n, None), ('v_add_f32_e32 v12, v4, v4', None),
+            ('buffer_load_dwordx4 v[4:7], v1, s[0:3], 0 offen', None),
+            ('buffer_store_dwordx4 v[8:11], v2, s[4:7], 0 offen', None), ('buffer_store_dwordx4 v[8:11], v2, s[4:7], 0 offen', None),
+            ('s_cbranch_scc1 65530', 1), ('s_endpgm', None)]
+  assert not isa_inflight.check_cfg(prog(2))
+  assert isa_inflight.check_cfg(prog(3))
+

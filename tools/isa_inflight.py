@@ -105,8 +105,135 @@ def check(body, asm_only=True):
   return bad
 
 
+def kernels_cfg(co):
+  """(name, [(text, branch target index or None)]) per kernel: llvm-objdump prints every instruction's address and a
+  branch's target as <kernel+0xOFFSET>."""
+  txt = subprocess.run([__import__('os').path.join(isa_waits.LLVM, 'llvm-objdump'), '-d', co], capture_output=True, text=True).stdout
+  out, name, base, rows = [], None, 0, []
+  def flush():
+    if name:
+      index = {a: i for i, (a, _, _) in enumerate(rows)}
+      out.append((name, [(t, index.get(base + off) if off is not None else None) for _, t, off in rows]))
+  for line in txt.splitlines():
+    m = re.match(r'^([0-9a-f]+) <(.+)>:$', line)
+    if m:
+      flush()
+      base, name, rows = int(m.group(1), 16), m.group(2), []
+    elif name and line.startswith('\t'):
+      parts = line.split('//')
+      ins = parts[0].strip()
+      ma = re.match(r'\s*([0-9A-F]+):', parts[1]) if len(parts) > 1 else None
+      if not ins or not ma:
+        continue
+      mt = re.search(r'<[^>]*\+0x([0-9a-f]+)>\s*$', line) if ins.startswith(('s_branch', 's_cbranch')) else None
+      rows.append((int(ma.group(1), 16), ins, int(mt.group(1), 16) if mt else None))
+  flush()
+  return out
+
+
+def _reads_writes(t):
+  p2 = t.split(None, 1)
+  if len(p2) < 2:
+    return [], []
+  o2 = [o.strip() for o in p2[1].split(',')]
+  mn = p2[0]
+  stores = mn.startswith(('buffer_store', 'global_store', 'ds_write', 'scratch_store', 'flat_store'))
+  reads = o2 if stores or mn.startswith(('v_cmp', 's_')) else o2[1:]
+  if mn.startswith(('v_mad_u64_u32', 'v_mad_i64_i32')):
+    reads = o2[2:4] + ['v%d' % min(regs(o2[4]))] if len(o2) > 4 and regs(o2[4]) else o2[2:]
+  writes = [] if stores or mn.startswith('v_mfma') else o2[:1]
+  return reads, writes
+
+
+def check_cfg(rows, asm_only=False):
+  """The same question along the CONTROL FLOW (r6): from every request, every path -- both sides of a conditional branch,
+  loops through their back edges -- is followed until the request's registers are read, overwritten, or the program
+  ends; a read is an offender unless a `s_waitcnt vmcnt(N)` with N <= the number of vector memory operations issued
+  behind the request ON THAT PATH lies in front of it.  States are (instruction, waited, live registers) with the
+  smallest count seen: a loop is walked until its counts stop shrinking.  A request whose registers are still live at
+  s_endpgm is not an offender here (nothing reads them) -- a request left in flight at a LOOP's exit shows up as the
+  read of whatever the epilogue keeps in those registers only if the epilogue reads them before writing."""
+  # every instruction once: (kind, wait count, registers read, registers written, branch target)
+  END, WAIT, MEM, BR, CBR, OTHER = range(6)
+  pre = []
+  for t, target in rows:
+    reads, writes = _reads_writes(t)
+    rd = frozenset().union(*[regs(r) for r in reads]) if reads else frozenset()
+    wr = frozenset().union(*[regs(w) for w in writes]) if writes else frozenset()
+    n = None
+    if t.startswith(('s_endpgm', 's_setpc')):
+      kind = END
+    elif t.startswith('s_waitcnt') and 'vmcnt' in t:
+      m = re.search(r'vmcnt\((\d+)\)', t)
+      kind, n = WAIT, (int(m.group(1)) if m else None)
+    elif t.startswith(VMEM):
+      kind = MEM
+    elif t.startswith('s_branch'):
+      kind = BR
+    elif t.startswith('s_cbranch') and target is not None:
+      kind = CBR
+    else:
+      kind = OTHER
+    pre.append((kind, n, rd, wr, target))
+  bad = []
+  for i, (ins, _) in enumerate(rows):
+    parts = ins.split(None, 1)
+    if not parts[0].startswith(('buffer_load_dword', 'buffer_load_ubyte', 'buffer_load_ushort')) or 'offen' not in ins or ' lds' in ins:
+      continue
+    ops = [o.strip() for o in parts[1].split(',')]
+    if len(ops) < 4 or (asm_only and not ops[3].startswith('0 ')):
+      continue
+    dst0 = frozenset(regs(ops[0]))
+    work = [(i + 1, 0, False, dst0)]
+    best = {}
+    found = None
+    while work and found is None:
+      pc, y, w, live = work.pop()
+      while pc is not None and pc < len(rows):
+        seen = best.setdefault((pc, w), [])               # (count, live registers) of earlier visits: a visit with a count
+        if any(y0 <= y and live <= l0 for y0, l0 in seen):   # no larger and no fewer live registers has covered this one
+          break
+        seen[:] = [(y0, l0) for y0, l0 in seen if not (y <= y0 and l0 <= live)] + [(y, live)]
+        kind, n, rd, wr, target = pre[pc]
+        if kind == END:
+          break
+        if kind == WAIT and n is not None and n <= y:
+          w = True
+        if rd & live:
+          if not w:
+            found = (i, pc, '%s   <-   %s' % (rows[pc][0], ins))
+          break
+        if kind == MEM:
+          y = min(y + 1, 64)
+        if wr & live:
+          live = live - wr
+          if not live:
+            break
+        if kind == BR:
+          pc = target
+          continue
+        if kind == CBR:
+          work.append((target, y, w, live))
+        pc += 1
+    if found:
+      bad.append(found)
+  return bad
+
+
 def main():
   obj, pat = sys.argv[1], sys.argv[2]
+  if '--cfg' in sys.argv:
+    n_bad = 0
+    for co in isa_waits.device_code(obj):
+      for name, rows in kernels_cfg(co):
+        if pat not in name:
+          continue
+        bad = check_cfg(rows, asm_only='--all' not in sys.argv)
+        print('%s: %d request(s) read before a covering wait on some path' % (name[:110], len(bad)))
+        for i, j, t in bad[:10]:
+          print('   load @%d read @%d: %s' % (i, j, t))
+        n_bad += len(bad)
+    return 1 if n_bad else 0
   n_bad = 0
   for co in isa_waits.device_code(obj):
     for name, body in kernels_text(co):
