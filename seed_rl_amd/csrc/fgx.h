@@ -292,8 +292,11 @@ fgx_kernel(const Params p) {
   };
   auto compute = [&](int u) __attribute__((always_inline)) {
     const int b = u * G::SUB + (wave * G::TPW) / G::BTILES;    // this wave's band (all its tiles lie in one)
-    if (b >= p.bands) return;
-    const unsigned ys = (unsigned)b * (unsigned)(G::NPIX * G::COUT * 4);
+    // a band past the batch (second half of the last unit): the wave multiplies whatever the ring holds and its stores go
+    // out of range -- NOT an early return: the loaders' waits count this unit's stores (r6: tools/isa_inflight.py --cfg
+    // follows every path; the return was only ever taken in the last unit, behind which nothing is waited for)
+    const unsigned dead = b >= p.bands ? kOut : 0u;
+    const unsigned ys = b >= p.bands ? 0u : (unsigned)b * (unsigned)(G::NPIX * G::COUT * 4);
 #pragma unroll
     for (int t = 0; t < G::TPW; ++t) {
       acc_t acc = acc0;
@@ -324,13 +327,13 @@ fgx_kernel(const Params p) {
         for (int g4 = 0; g4 < 4; ++g4) { o[g4] = f32x4_t{acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]}; asm volatile("" : "+v"(o[g4])); }
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[g4]), yr, ob[t] + (unsigned)(32 * g4), ys, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o[g4]), yr, (ob[t] + (unsigned)(32 * g4)) | dead, ys, 0);
           asm volatile("s_nop 1" ::: "memory");
         }
       } else {
         f32x4_t o = acc;
         asm volatile("" : "+v"(o));
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), yr, ob[t], ys, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), yr, ob[t] | dead, ys, 0);
         asm volatile("s_nop 1" ::: "memory");
       }
     }

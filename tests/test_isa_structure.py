@@ -161,13 +161,13 @@ def test_in_flight_registers_along_the_control_flow():
   both sides of a conditional branch, loops through their back edges -- is followed to the first read of the request's
   registers; a `s_waitcnt vmcnt(N)` with N <= the number of vector memory operations issued behind the request on that
   path must lie in front of it.  This is what holds the first conv's kernels (requests that live across the step loop's
-  back edge, waits counted by hand) to their counts.  fgx.o is left to the address-order check above: its wait counts
-  assume the output stores of the previous unit, which a wave past the last band skips -- in the last unit only, after
-  which nothing is taken; the analysis is path-insensitive and reports that combination."""
+  back edge, waits counted by hand) to their counts.  (The analysis is path-insensitive: fgx.h's loaders count the
+  previous unit's output stores, which a wave past the last band used to skip by returning early -- in the last unit only,
+  behind which nothing is taken; it now issues them out of range and the kernel passes on every path.)"""
   import isa_inflight, isa_waits
   obj_dir = os.path.join(ROOT, 'build', 'obj')
   seen = 0
-  for obj in ('stackconv.o', 'conv.o', 'wgx.o', 'cgx.o'):
+  for obj in ('stackconv.o', 'conv.o', 'wgx.o', 'cgx.o', 'fgx.o'):
     path = os.path.join(obj_dir, obj)
     if not os.path.exists(path):
       pytest.skip('%s is not built' % obj)
