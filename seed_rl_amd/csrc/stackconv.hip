@@ -31,7 +31,12 @@
 // kept for A/B runs (SEEDHIP_STACK_BF16=0).  The DEFAULT kernels further down evaluate the same fp32 arithmetic on
 // the bf16 matrix pipe through an exact three-way operand split ("bf16x3": uint8 pixels are exact in bf16, an fp32
 // weight / gradient is the exact sum of three bf16 numbers): forward with the same band-per-wave organisation and
-// the ring held in bf16, weight gradient with a channel-per-wave organisation.
+// the ring held in bf16 -- since r6 on EIGHT waves over two batch columns (stackconv_fwd_w8_kernel: a five-wave
+// workgroup puts two of its waves on one SIMD; the five-wave stackconv_fwd_bf16r_kernel stays for tensors above 2 GB
+// and SEEDHIP_STACK_W8=0) --, weight gradient through transposing LDS reads with a (stack channel, k-step parity)
+// wave organisation (stackconv_wgrad_tr_kernel), central inference's rows forward (stackconv_rows_w8_kernel).
+// Requests that live across a loop iteration are asm statements with hand-counted waits in all three:
+// tools/isa_inflight.py --cfg (tests/test_isa_structure.py) follows each of them through the compiled control flow.
 #include "common.h"
 #include <cstdlib>
 #include <type_traits>

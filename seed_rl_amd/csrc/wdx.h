@@ -56,16 +56,6 @@ struct Params {
   int n_img, per_wg;                      //     (seedhip_conv2d_stack_fwd_bits): 17 MB at cfg2 where X is 275 MB
 };
 
-template <int N>
-__device__ __forceinline__ void wait_item(f32x4_t (&r)[2]) {
-  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r[0]), "+v"(r[1]) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void wait_set(f32x4_t (&r)[kItems][2]) {
-  static_assert(kItems == 2, "operand list below");
-  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1]) : "n"(N));
-}
-
 // padded rows [0, end_row(r)) of the run are what rounds 0..r read
 __device__ __forceinline__ int end_row(int r, int total, int rows) {
   int sl = kRound * r + kRound - 1; if (sl > total - 1) sl = total - 1;
