@@ -1502,3 +1502,57 @@ def test_heads_fwd(device, rows, feat, A):
   want = x.astype(np.float64) @ w.astype(np.float64) + b
   np.testing.assert_allclose(y.cpu().numpy(), want, rtol=0, atol=1e-5 * max(1.0, np.abs(want).max()))
   assert not ops.heads_supported(100, 20) and not ops.heads_supported(256, 36) and not ops.heads_supported(1024, 20)
+
+
+_W8_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from tests import synth
+from seed_rl_amd import ops
+dev = torch.device('cuda')
+out = {}
+for T1, B, cout in ((21, 37, 16), (6, 50, 32), (1, 64, 16)):
+  u = synth.atari_unroll(5, T1, B, done_p=0.2, zero_state=False)
+  rng = np.random.default_rng(T1 * 100 + B)
+  w = torch.tensor((rng.normal(size=(8, 8, 4, cout)) / 16).astype(np.float32), device=dev)
+  b = torch.tensor((rng.normal(size=cout) * 0.5).astype(np.float32), device=dev)
+  HW = 84 * 84
+  ext = torch.zeros((T1 + 3, B, HW), dtype=torch.uint8, device=dev)
+  ext[3:] = torch.tensor(u['frames'].reshape(T1, B, HW), device=dev)
+  nv = torch.zeros((T1, B), dtype=torch.uint8, device=dev)
+  ops.stack_prepare(torch.tensor(u['frame_state'], device=dev), torch.tensor(u['done'].astype(np.uint8), device=dev), T1, B, HW, ext, nv)
+  g = ops.StackConvGeom(T1, B, 84, 84, 20, 20, 8, 8, 4, cout, cout)
+  y = torch.empty((T1 * B, 20, 20, cout), device=dev)
+  if ops.conv2d_stack_fwd_bits_supported(g):
+    bits = torch.zeros((T1 * B, 20, 20, cout // 4), dtype=torch.uint8, device=dev)
+    ops.conv2d_stack_fwd(g, ext, nv, w, b, y, out_relu=True, relu_bits=bits)
+    out['bits_%d_%d' % (T1, B)] = bits.cpu().numpy()
+  else:
+    ops.conv2d_stack_fwd(g, ext, nv, w, b, y, out_relu=True)
+  out['y_%d_%d' % (T1, B)] = y.cpu().numpy()
+np.savez(sys.argv[2], **out)
+'''
+
+
+def test_stack_fwd_eight_waves_bit_identical_to_five_waves(tmp_path):
+  """stackconv_fwd_w8_kernel (r6: eight waves, two batch columns per workgroup) against the five-wave kernel it replaced
+  (SEEDHIP_STACK_W8=0; also what tensors above 2 GB take): same operands and MFMA order per accumulator, so the
+  activations and the ReLU byte masks are BIT-identical -- odd B (a lone column in the last pair), several time chunks,
+  two 16-channel slices, T1 = 1.  One child process per build switch (the library reads it once)."""
+  import os, subprocess, sys
+  if os.environ.get('SEEDHIP_KNOB_CHILD') == '1':
+    pytest.skip('this IS a child')
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  res = {}
+  for w8 in ('1', '0'):
+    path = str(tmp_path / ('w8_%s.npz' % w8))
+    r = subprocess.run([sys.executable, '-c', _W8_CHILD, root, path], env=dict(os.environ, SEEDHIP_STACK_W8=w8),
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res[w8] = np.load(path)
+  assert sorted(res['1'].files) == sorted(res['0'].files) and len(res['1'].files) >= 5
+  for k in res['1'].files:
+    a, b = res['1'][k], res['0'][k]
+    assert a.shape == b.shape and a.tobytes() == b.tobytes(), k
+    if k.startswith('y_'):
+      assert float(np.abs(a).max()) > 0.1 and float((a > 0).mean()) > 0.1, k
