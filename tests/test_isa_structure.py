@@ -178,7 +178,9 @@ def test_in_flight_registers_along_the_control_flow():
         if obj == 'conv.o' and not any(ns in name for ns in ('3wfx', '3wdx', '3wsx', '3wsy', '2xg', '3xg8')):
           continue
         seen += 1
-        bad = isa_inflight.check_cfg(rows, asm_only=False)
+        # writes of registers a request may still be filling (a request left in flight at a loop's exit: the first conv's
+        # weight gradient, first build) where the kernels' loops give the path-insensitive walk no infeasible merges
+        bad = isa_inflight.check_cfg(rows, asm_only=False, overwrites=obj in ('stackconv.o', 'wgx.o', 'fgx.o'))
         assert not bad, (name, bad[:3])
   assert seen >= 20, seen
 
@@ -194,4 +196,8 @@ def test_control_flow_check_follows_a_loop():
             ('s_cbranch_scc1 65530', 1), ('s_endpgm', None)]
   assert not isa_inflight.check_cfg(prog(2))
   assert isa_inflight.check_cfg(prog(3))
+  # a request left in flight at the loop's exit: the epilogue writes its registers
+  tail = [('buffer_load_dwordx4 v[4:7], v1, s[0:3], 0 offen', None), ('s_cbranch_scc1 65534', 0), ('v_mov_b32_e32 v5, v9', None), ('s_endpgm', None)]
+  assert isa_inflight.check_cfg(tail, overwrites=True) and not isa_inflight.check_cfg(tail)
+  assert not isa_inflight.check_cfg(tail[:2] + [('s_waitcnt vmcnt(0)', None)] + tail[2:], overwrites=True)
 

@@ -145,14 +145,17 @@ def _reads_writes(t):
   return reads, writes
 
 
-def check_cfg(rows, asm_only=False):
+def check_cfg(rows, asm_only=False, overwrites=False):
   """The same question along the CONTROL FLOW (r6): from every request, every path -- both sides of a conditional branch,
   loops through their back edges -- is followed until the request's registers are read, overwritten, or the program
   ends; a read is an offender unless a `s_waitcnt vmcnt(N)` with N <= the number of vector memory operations issued
   behind the request ON THAT PATH lies in front of it.  States are (instruction, waited, live registers) with the
-  smallest count seen: a loop is walked until its counts stop shrinking.  A request whose registers are still live at
-  s_endpgm is not an offender here (nothing reads them) -- a request left in flight at a LOOP's exit shows up as the
-  read of whatever the epilogue keeps in those registers only if the epilogue reads them before writing."""
+  smallest count seen: a loop is walked until its counts stop shrinking.  A WRITE of the request's registers without a
+  covering wait in front of it is an offender as well with overwrites=True (the data lands behind the write): that is how
+  a request left in flight at a loop's exit shows.  Off by default: the analysis is path-insensitive, and a loop whose
+  first iteration hipcc peels merges "only one round" with "more rounds follow" behind the peeled copy -- the phi moves of
+  that merge write the next round's request registers on a path no run takes (wfx.h, wdx.h, wsx.h, cgx.h).  A request whose
+  registers are untouched up to s_endpgm is not reported."""
   # every instruction once: (kind, wait count, registers read, registers written, branch target)
   END, WAIT, MEM, BR, CBR, OTHER = range(6)
   pre = []
@@ -184,13 +187,13 @@ def check_cfg(rows, asm_only=False):
     if len(ops) < 4 or (asm_only and not ops[3].startswith('0 ')):
       continue
     dst0 = frozenset(regs(ops[0]))
-    work = [(i + 1, 0, False, dst0)]
+    work = [(i + 1, 0, False, dst0, False)]
     best = {}
     found = None
     while work and found is None:
-      pc, y, w, live = work.pop()
+      pc, y, w, live, looped = work.pop()
       while pc is not None and pc < len(rows):
-        seen = best.setdefault((pc, w), [])               # (count, live registers) of earlier visits: a visit with a count
+        seen = best.setdefault((pc, w, looped), [])               # (count, live registers) of earlier visits: a visit with a count
         if any(y0 <= y and live <= l0 for y0, l0 in seen):   # no larger and no fewer live registers has covered this one
           break
         seen[:] = [(y0, l0) for y0, l0 in seen if not (y <= y0 and l0 <= live)] + [(y, live)]
@@ -206,14 +209,25 @@ def check_cfg(rows, asm_only=False):
         if kind == MEM:
           y = min(y + 1, 64)
         if wr & live:
+          # a WRITE of a register the request may still be filling: the value is lost when the data lands behind it -- how a
+          # request left in flight at a loop's exit shows (the epilogue takes over its registers; r6, the first conv's weight
+          # gradient).  hipcc waits in front of such a write for the loads IT tracks; another load into the same registers is
+          # the next request of a register ring, not a hazard of this one.
+          # (only on paths that have not gone through a back edge since the request: a loop unrolled by two whose second
+          # half is conditional pairs "second half skipped" with "loop continues" here, which no run does, and the first
+          # half's temporaries share registers with the second half's requests)
+          if overwrites and not w and kind != MEM and not looped:
+            found = (i, pc, '%s   OVERWRITES (in flight)   %s' % (rows[pc][0], ins))
+            break
           live = live - wr
           if not live:
             break
         if kind == BR:
+          looped = looped or target <= pc
           pc = target
           continue
         if kind == CBR:
-          work.append((target, y, w, live))
+          work.append((target, y, w, live, looped or target <= pc))
         pc += 1
     if found:
       bad.append(found)
@@ -228,7 +242,7 @@ def main():
       for name, rows in kernels_cfg(co):
         if pat not in name:
           continue
-        bad = check_cfg(rows, asm_only='--all' not in sys.argv)
+        bad = check_cfg(rows, asm_only='--all' not in sys.argv, overwrites='--overwrites' in sys.argv)
         print('%s: %d request(s) read before a covering wait on some path' % (name[:110], len(bad)))
         for i, j, t in bad[:10]:
           print('   load @%d read @%d: %s' % (i, j, t))
